@@ -1,0 +1,338 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* by running the REFERENCE itself (imported from /root/reference) on CPU.
+
+Runs only in the build container (the reference does not travel to the GPU box); the outputs are
+small data fixtures -- inputs and the reference's outputs -- committed under tests/golden/.
+
+    python oracle/make_goldens.py            # writes tests/golden/*.npz, *.json
+
+Golden sets:
+  G1 unet_g1.npz      V2ce3d outputs for three consecutive calls (pins spectral-norm statefulness)
+                      + per-block intermediates of call #1 (forward hooks on the reference modules)
+  G3 ldati_g3_*.npz   LDATI: voxels, the uniforms the reference drew (torch.rand wrapped), events
+  G4 ldati_g4.json    full-size dense frame: SHA-256 of the packed event bytes + per-segment counts
+  G5 ldati_kat.json   hand known-answer re-derived from the reference here
+  G7 glue_g7.npz      v2ce.py video_to_voxels (center + pano) through a stub-imported v2ce.py,
+                      sequence plans and per-frame offsets
+
+Note on G4 / sqrt: this container's torch CPU build evaluates ``torch.sqrt`` through MKL VML, which
+is not correctly rounded (0.64 % of f32 inputs are 1 ulp off IEEE sqrt; measured here).  That moves
+~1e-5 of the multi-event timestamps by +-1 us relative to IEEE arithmetic (which is what numpy, gcc
+and the GPU's correctly-rounded sqrt compute).  G3 fixtures are chosen (asserted below) so that the
+unmodified reference and the IEEE-sqrt reference agree on them exactly; G4 is produced with
+``torch.sqrt`` routed through numpy's IEEE sqrt and records how many events differ from the
+unmodified run.
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+import logging
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+warnings.filterwarnings("ignore")
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+
+from scripts.v2ce_3d import V2ce3d                      # noqa: E402  (reference)
+import scripts.LDATI as REF_LDATI                       # noqa: E402  (reference)
+
+from v2ce_toolbox_amd import synth                      # noqa: E402  (build-owned inputs)
+from oracle import ldati as O                           # noqa: E402
+
+torch.set_num_threads(8)
+
+
+class RandCapture:
+    """Wraps torch.rand to record the uniforms the reference draws (LDATI.py:171)."""
+
+    def __enter__(self):
+        self.orig = torch.rand
+        self.last = None
+
+        def wrap(*a, **k):
+            r = self.orig(*a, **k)
+            self.last = r.clone()
+            return r
+        torch.rand = wrap
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand = self.orig
+
+
+class IeeeSqrt:
+    """Routes torch.sqrt through numpy (IEEE correctly rounded) instead of MKL VML."""
+
+    def __enter__(self):
+        self.orig = torch.sqrt
+        torch.sqrt = lambda x: torch.from_numpy(np.sqrt(x.numpy()))
+        return self
+
+    def __exit__(self, *exc):
+        torch.sqrt = self.orig
+
+
+def events_equal(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and a.tobytes() == b.tobytes()
+
+
+def mt_uniforms(seed, shape):
+    """CPU torch.rand(shape) after manual_seed(seed), regenerated with numpy's MT19937 (G6)."""
+    mt = np.random.MT19937()
+    mt._legacy_seeding(seed)
+    raw = mt.random_raw(int(np.prod(shape))).astype(np.uint32)
+    return ((raw & 0xFFFFFF).astype(np.float32) * np.float32(2.0 ** -24)).reshape(shape)
+
+
+# --------------------------------------------------------------------------------------------- G1
+def gen_unet():
+    sd = synth.make_state_dict(0)
+    model = V2ce3d()
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+
+    def pairs(frames):
+        x = frames.astype(np.float32) / 255
+        x = np.stack([x[:-1], x[1:]], axis=1)
+        return ((x - np.float32(0.153)) / np.float32(0.165)).astype(np.float32)
+
+    xa = pairs(synth.synthetic_frames(5, 16, 24, seed=11))[None]                 # [1,4,2,16,24]
+    fb = synth.synthetic_frames(8, 20, 28, seed=12, pattern="noise")
+    xb = np.stack([pairs(fb[0:4]), pairs(fb[4:8])])                              # [2,3,2,20,28]
+
+    inter = {}
+    hooks = []
+    names = {"head": model.UNet.head}
+    for i in range(4):
+        names[f"enc{i}"] = model.UNet.encoders[i]
+        names[f"dec{i}"] = model.UNet.decoders[i]
+    for i in range(2):
+        names[f"res{i}"] = model.UNet.resblocks[i]
+    for n, mod in names.items():
+        hooks.append(mod.register_forward_hook(
+            lambda m, i, o, n=n: inter.__setitem__(n, o.detach().clone().numpy())))
+    with torch.no_grad():
+        out1 = model(torch.from_numpy(xa)).contiguous().numpy()
+    for h in hooks:
+        h.remove()
+    inter1 = dict(inter)
+    with torch.no_grad():
+        out2 = model(torch.from_numpy(xa)).contiguous().numpy()
+        out3 = model(torch.from_numpy(xb)).contiguous().numpy()
+    sd_after = model.state_dict()
+    extra = {"u_after3_" + k: v.numpy() for k, v in sd_after.items()
+             if k.endswith("weight_u") and ("resblocks.0.conv1" in k or "decoders.3.conv2" in k)}
+    np.savez_compressed(os.path.join(GOLD, "unet_g1.npz"), xa=xa, xb=xb, out1=out1, out2=out2,
+                        out3=out3, **{"inter_" + k: v for k, v in inter1.items()}, **extra)
+    print("G1: out1 max %.4f  frac>0 %.3f  frac>1 %.4f | |out2-out1| max %.3e" %
+          (out1.max(), (out1 > 0).mean(), (out1 > 1).mean(), np.abs(out2 - out1).max()))
+
+
+# --------------------------------------------------------------------------------------------- G3
+def run_ref_ldati(vox, fps, t0, seed, ieee_sqrt=False):
+    with RandCapture() as cap:
+        torch.manual_seed(seed)
+        if ieee_sqrt:
+            with IeeeSqrt():
+                res = REF_LDATI.sample_voxel_statistical(torch.from_numpy(vox), t0=t0, fps=fps)
+        else:
+            res = REF_LDATI.sample_voxel_statistical(torch.from_numpy(vox), t0=t0, fps=fps)
+        u = cap.last.numpy()
+    return res, u
+
+
+def gen_ldati_small():
+    cases = {
+        "sparse": (synth.synthetic_voxels(3, 12, 14, seed=21, regime="sparse"), 30, 0),
+        "frac": (synth.synthetic_voxels(3, 12, 14, seed=22, regime="frac"), 25, 0),
+        "stress": (synth.synthetic_voxels(2, 12, 14, seed=23, regime="stress"), 30, 0),
+        "t0fps60": (synth.synthetic_voxels(2, 9, 11, seed=24, regime="stress"), 60, 0.5),
+        "ragged": (synth.synthetic_voxels(1, 1, 67, seed=25, regime="stress"), 24, 0),
+    }
+    for name, (vox, fps, t0) in cases.items():
+        seed = 100 + len(name)
+        res, u = run_ref_ldati(vox, fps, t0, seed)
+        res_ieee, _ = run_ref_ldati(vox, fps, t0, seed, ieee_sqrt=True)
+        assert all(events_equal(a, b) for a, b in zip(res, res_ieee)), \
+            f"{name}: MKL-VML sqrt and IEEE sqrt disagree on this fixture; pick another seed"
+        B, _, _, H, W = vox.shape
+        u = u.reshape(B, 2, 9, H, W, -1)
+        lens = np.array([len(r) for r in res], np.int64)
+        ev = np.concatenate([np.asarray(r) for r in res]) if lens.sum() else \
+            np.empty(0, O.EVENT_DTYPE)
+        assert ev.dtype.itemsize == 13
+        np.savez_compressed(os.path.join(GOLD, f"ldati_g3_{name}.npz"), vox=vox, uniforms=u,
+                            fps=np.float64(fps), t0=np.float64(t0), lens=lens,
+                            events=np.frombuffer(ev.tobytes(), np.uint8))
+        print(f"G3 {name}: B={B} HxW={H}x{W} fps={fps} t0={t0} max_n={u.shape[-1]} events={lens}")
+
+
+# --------------------------------------------------------------------------------------------- G4
+def gen_ldati_large():
+    H, W, seed = 260, 346, 4242
+    vox = synth.synthetic_voxels(1, H, W, seed=44, regime="stress")
+    res_raw, u = run_ref_ldati(vox, 30, 0, seed)
+    res, u2 = run_ref_ldati(vox, 30, 0, seed, ieee_sqrt=True)
+    assert np.array_equal(u, u2)
+    max_n = u.reshape(1, 2, 9, H, W, -1).shape[-1]
+    assert np.array_equal(mt_uniforms(seed, (1, 2, 9, H, W, max_n)).reshape(u.shape), u), "G6"
+    ev, raw = np.asarray(res[0]), np.asarray(res_raw[0])
+    seg, mx = O.count(vox)
+    assert mx == max_n and int(seg.sum()) == len(ev)
+    assert int(seg.min()) >= 32768, "every segment must take the stable-sort path"
+    key = lambda a: a[np.lexsort((a["timestamp"], a["x"], a["y"], a["polarity"]))]
+    ndiff = int((key(ev) != key(raw)).sum())
+    meta = {
+        "H": H, "W": W, "fps": 30, "t0": 0, "vox_seed": 44, "vox_regime": "stress",
+        "torch_seed": seed, "max_n": int(max_n), "num_events": int(len(ev)),
+        "seg_counts": seg.reshape(-1).tolist(),
+        "sha256_packed_events": hashlib.sha256(ev.tobytes()).hexdigest(),
+        "sha256_timestamps": hashlib.sha256(np.ascontiguousarray(ev["timestamp"]).tobytes()).hexdigest(),
+        "events_differing_from_mkl_vml_sqrt_run": ndiff,
+        "first_events": [[int(v) for v in e] for e in ev[:8].tolist()],
+        "last_events": [[int(v) for v in e] for e in ev[-4:].tolist()],
+    }
+    with open(os.path.join(GOLD, "ldati_g4.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("G4:", {k: meta[k] for k in ("num_events", "max_n", "events_differing_from_mkl_vml_sqrt_run")})
+
+
+# --------------------------------------------------------------------------------------------- G5
+def gen_kat():
+    y = np.zeros((1, 2, 10, 1, 2), np.float32)
+    y[0, 0, :, 0, 0] = [.3, .4, .5, 0, 0, 1.2, 0, 0, .9, .6]
+    y[0, 0, :, 0, 1] = [2, 3.5, 0, 0, 4, 1, 0, 0, 0, 2.7]
+    y[0, 1, :, 0, 0] = [0, 0, 1, 1, 1, 0, 0, 2.5, .25, .25]
+    res, u = run_ref_ldati(y, 30, 0, 0)
+    ev = np.asarray(res[0])
+    n, _ = REF_LDATI.y_relocate(torch.from_numpy(y).reshape(2, 10, 1, 2))
+    # notebook known-answer (train/scripts/stage2/vis_stage2.ipynb cells 1-2): the voxel printed in
+    # cell 1 and the three deterministic single-event times printed in cell 2 (units of 1/300 s)
+    nb_vox = np.zeros((1, 2, 10, 1, 1), np.float32)
+    nb_vox[0, 0, :, 0, 0] = [0, 0, 0.9179, 0.0821, 0.9962, 0.0038, 0.5287, 2.8454, 1.6884, 0.9375]
+    nb_res, _ = run_ref_ldati(nb_vox, 30, 0, 0)
+    nb_ts = np.sort(np.asarray(nb_res[0])["timestamp"]) * (300 / 1e6)
+    # empty input (all-zero voxels => max_n == 0): the reference raises from its debug logging
+    # (LDATI.py:200 torch.max of an empty tensor)
+    try:
+        run_ref_ldati(np.zeros((2, 2, 10, 5, 6), np.float32), 30, 0, 0)
+        empty_behaviour = "returns"
+    except RuntimeError as e:
+        empty_behaviour = "RuntimeError: " + str(e).split(".")[0]
+    meta = {
+        "empty_input": empty_behaviour,
+        "hand": {"vox": y.reshape(-1).tolist(), "shape": list(y.shape),
+                 "uniforms": u.reshape(-1).tolist(), "uniforms_shape": [1, 2, 9, 1, 2, int(u.size // 36)],
+                 "counts": n.numpy().reshape(-1).tolist(),
+                 "events": [[int(v) for v in e] for e in ev.tolist()]},
+        "notebook": {"vox": nb_vox.reshape(-1).tolist(),
+                     "printed_first_three": [2.3133, 4.4484, 7.1901],
+                     "reference_first_three_here": nb_ts[:3].tolist(), "num_events": int(len(nb_ts))},
+    }
+    with open(os.path.join(GOLD, "ldati_kat.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("G5: hand KAT events", len(ev), "| notebook first three", nb_ts[:3], "n =", len(nb_ts))
+
+
+# --------------------------------------------------------------------------------------------- G7
+def import_reference_v2ce():
+    """Import /root/reference/v2ce.py with its missing third-party imports stubbed."""
+    cv2 = types.ModuleType("cv2")
+
+    def resize(img, size):
+        assert (img.shape[1], img.shape[0]) == tuple(size), "stub resize: identity only"
+        return img
+    cv2.resize = resize
+    cv2.IMREAD_GRAYSCALE = 0
+    sys.modules["cv2"] = cv2
+    pl = types.ModuleType("pathlib2")
+    import pathlib
+    pl.Path = pathlib.Path
+    sys.modules["pathlib2"] = pl
+    tv = types.ModuleType("torchvision")
+    tr = types.ModuleType("torchvision.transforms")
+
+    class Normalize:
+        def __init__(self, mean, std):
+            self.mean, self.std = torch.tensor(mean), torch.tensor(std)
+
+        def __call__(self, t):     # torchvision F.normalize: tensor.sub_(mean).div_(std), f32
+            return t.clone().sub_(self.mean.view(-1, 1, 1)).div_(self.std.view(-1, 1, 1))
+
+    class Compose:
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+    tr.Normalize, tr.Compose = Normalize, Compose
+    tv.transforms = tr
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.transforms"] = tr
+    import v2ce as ref_v2ce
+    ref_v2ce.logger = logging.getLogger("V2CE")
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    return ref_v2ce
+
+
+def gen_glue():
+    ref = import_reference_v2ce()
+    H, WF, width, N, bs = 8, 20, 12, 20, 2
+    frames = synth.synthetic_frames(N, H, WF, seed=31)
+
+    class FakeCap:
+        frame_count = N
+
+        def read_frames_at_indices(self, idx):
+            return frames[list(idx)]
+
+    outs = {}
+    for infer_type in ("center", "pano"):
+        model = V2ce3d()
+        model.load_state_dict(synth.make_state_dict(0), strict=True)
+        model.eval()
+        outs[infer_type] = ref.video_to_voxels(model, vidcap=FakeCap(), infer_type=infer_type,
+                                               seq_len=16, width=width, height=H, batch_size=bs)
+    pre = ref.image_pre_processing(frames[:5], height=H).numpy()
+    plans = {}
+    for n in (17, 18, 33, 100, 2048):
+        sequence_num = np.ceil((n - 1) / 16).astype(int)
+        mode = (n - 1) % 16
+        starts = np.arange(sequence_num) * 16
+        if mode != 0:
+            starts[-1] -= (16 - mode)
+        plans[f"plan_{n}"] = np.concatenate([[sequence_num, mode], starts]).astype(np.int64)
+    offs = {f"offsets_fps{fps}": np.array([int(i * 1 / fps * 1e6) for i in range(4096)], np.int64)
+            for fps in (25, 30)}
+    np.savez_compressed(os.path.join(GOLD, "glue_g7.npz"), frames=frames, pre5=pre,
+                        center=outs["center"], pano=outs["pano"],
+                        params=np.array([H, WF, width, N, bs], np.int64), **plans, **offs)
+    print("G7: center", outs["center"].shape, "pano", outs["pano"].shape)
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    which = sys.argv[1:] or ["unet", "ldati", "large", "kat", "glue"]
+    if "unet" in which:
+        gen_unet()
+    if "ldati" in which:
+        gen_ldati_small()
+    if "large" in which:
+        gen_ldati_large()
+    if "kat" in which:
+        gen_kat()
+    if "glue" in which:
+        gen_glue()
