@@ -1,0 +1,127 @@
+/*
+ * v2ce_hip.h -- C ABI of libv2ce_hip.so, the MI355X (gfx950) implementation of the V2CE hot path.
+ *
+ * The reference (ucsd-hdsi-dvs/V2CE-Toolbox) is pure Python/PyTorch and has no FFI of its own; the
+ * hot path sits behind three Python call boundaries.  This header is the native
+ * boundary underneath them: every entry point names the reference code it replaces.  All pointers
+ * are DEVICE pointers unless the name ends in _host; the caller owns every buffer; `stream` is a
+ * hipStream_t passed as void* (NULL = the null stream); functions only enqueue work and never
+ * synchronise; they return V2CE_OK or a negative error code and never throw.
+ *
+ * Activation layout everywhere: [B][T][C][H][W] f32 ("frame-major planar"): the reference's own
+ * input layout [B,L,2,H,W] (scripts/v2ce_3d.py:26) and output layout [B,L,20,H,W]
+ * (scripts/v2ce_3d.py:29), which is also LDATI's [frames,2,10,H,W] (v2ce.py:351-352).
+ */
+#ifndef V2CE_HIP_H
+#define V2CE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define V2CE_OK 0
+#define V2CE_ERR_BAD_ARG (-1)      /* NULL pointer, non-positive size, bad enum */
+#define V2CE_ERR_UNSUPPORTED (-2)  /* shape / option outside what the kernels cover */
+#define V2CE_ERR_HIP (-3)          /* a HIP runtime call failed; see v2ce_last_error() */
+#define V2CE_ERR_WORKSPACE (-4)    /* workspace too small */
+
+#define V2CE_RNG_REPLAY 0 /* uniforms supplied: dense [B,2,9,H,W,replay_max_n] f32 (LDATI.py:171) */
+#define V2CE_RNG_PHILOX 1 /* Philox4x32-10, counter (pixel, j>>2, p*9+c, frame_base+b), key seed */
+
+#define V2CE_ACT_NONE 0
+#define V2CE_ACT_RELU 1   /* torch.relu / nn.ReLU           (submodules.py:105,232) */
+#define V2CE_ACT_LEAKY 2  /* nn.LeakyReLU(0.01)             (submodules.py:101-103) */
+
+typedef void *v2ce_stream_t;
+
+const char *v2ce_version(void);
+/* Message of the last failing call on this thread ("" if none). */
+const char *v2ce_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Stage 2 -- LDATI.  Replaces scripts/LDATI.py:126-310 (sample_voxel_statistical, y_relocate,
+ * calculate_statistical_linear_params_for_stage2, pick_elements, pick_and_sort) for the options the
+ * CLI uses (v2ce.py:356: 'slope', pooling 'none', bidirectional=False).
+ * Two-phase, because the output length is data dependent:
+ *   count -> (caller reads seg_counts, allocates) -> scan -> emit [-> pack]
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Per-(frame, time-bin) event counts and the chunk-wide maximum count per voxel.
+ * Replaces y_relocate (LDATI.py:80-106) + torch.max (LDATI.py:169) + the sizes implied by
+ * pick_elements' selections (LDATI.py:228,239).
+ * vox [B,2,10,H,W] f32; seg_counts [B*9] i64 (overwritten); max_n [1] i32 (overwritten). */
+int v2ce_ldati_count(const float *vox, int B, int H, int W, int64_t *seg_counts, int32_t *max_n,
+                     v2ce_stream_t stream);
+
+/* Exclusive prefix sum of seg_counts -> seg_offsets [B*9+1] (last element = total events). */
+int v2ce_ldati_scan(const int64_t *seg_counts, int B, int64_t *seg_offsets, v2ce_stream_t stream);
+
+/* Bytes of LDS the emit kernel needs per workgroup for this fps/t0 (0 if unsupported). */
+size_t v2ce_ldati_lds_bytes(double fps, double t0);
+
+/* Emit all events, each (frame, bin) segment stably sorted by timestamp, at seg_offsets.
+ * Replaces LDATI.py:156-165 (single-event times), :171-212 (slope-distributed times) and
+ * :217-310 (pick, concat negative-then-positive, sort by timestamp).  Tie order is the STABLE order
+ * [neg singles row-major, neg multis row-major then draw, pos singles, pos multis] -- what the
+ * reference's CPU argsort yields for segments >= 32768 events.
+ * uniforms/replay_max_n: REPLAY mode only.  frame_ts_add [B] i64 or NULL: added to every timestamp
+ * of frame b (v2ce.py:365 per-frame offset, fused).  Outputs are SoA of length seg_offsets[B*9]. */
+int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps, double t0, int rng_mode,
+                    const float *uniforms, int replay_max_n, uint64_t seed, int64_t frame_base,
+                    const int64_t *seg_offsets, const int64_t *frame_ts_add, int64_t *ts,
+                    int16_t *x, int16_t *y, int8_t *p, v2ce_stream_t stream);
+
+/* SoA -> packed 13-byte records {i8 timestamp, i2 x, i2 y, i1 polarity}: the numpy recarray layout
+ * of LDATI.py:308-309 (numpy.core.records.fromarrays, itemsize 13).  packed: n*13 bytes. */
+int v2ce_events_pack(const int64_t *ts, const int16_t *x, const int16_t *y, const int8_t *p,
+                     int64_t n, uint8_t *packed, v2ce_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Stage 1 -- V2ce3d building blocks.  Replaces the ATen ops behind scripts/unet_2layer.py:335-379,
+ * scripts/submodules.py:115-124,249-264 and scripts/spectral_norm.py:19-31.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* One fused 3-D convolution: y = act( conv(x) * scale[co] + shift[co] (+ residual) ).
+ * conv is nn.Conv3d with a cubic kernel (1 or 3), padding ksize/2, stride (1, s, s)
+ * (submodules.py:96,226-247); scale/shift fold the conv bias and the eval-mode BatchNorm3d
+ * (submodules.py:229-231,246); residual/act implement submodules.py:262-263.
+ * The input is a VIRTUAL concat of two sources (unet_2layer.py:358-364): channels [0,C0) come from
+ * x0 [B,T,C0,H0,W0], nearest-resampled to (Hin,Win) through hmap/wmap (source row/col per logical
+ * row/col; NULL = identity, requires H0==Hin, W0==Win); channels [C0,C0+C1) from x1 [B,T,C1,Hin,Win].
+ * w_packed: [Cin][k^3][Cout] f32 (see v2ce_pack_weights).  y: [B,T,Cout,Hout,Wout]. */
+typedef struct {
+    int32_t B, T;
+    int32_t C0, H0, W0;
+    int32_t C1;
+    int32_t Hin, Win;
+    int32_t Cout, Hout, Wout;
+    int32_t ksize;      /* 1 or 3 */
+    int32_t stride_hw;  /* 1 or 2 */
+    int32_t act;        /* V2CE_ACT_* */
+    int32_t tile_t, tile_h, tile_w; /* output tile per workgroup; 0 = choose automatically */
+} v2ce_conv3d_desc;
+
+int v2ce_conv3d_fwd(const v2ce_conv3d_desc *desc, const float *x0, const float *x1,
+                    const int32_t *hmap, const int32_t *wmap, const float *w_packed,
+                    const float *scale, const float *shift, const float *residual, float *y,
+                    v2ce_stream_t stream);
+
+/* Weight re-layout [Cout][Cin][k^3] -> [Cin][k^3][Cout], optionally divided elementwise by
+ * *sigma (spectral_norm.py:31 `w / sigma.expand_as(w)`; sigma NULL = plain re-layout). */
+int v2ce_pack_weights(const float *w, int Cout, int Cin, int k3, const float *sigma,
+                      float *w_packed, v2ce_stream_t stream);
+
+/* One spectral-norm power iteration (spectral_norm.py:19-31), in place on u [rows], v [cols]:
+ *   v = W^T u / (|W^T u| + 1e-12); u = W v / (|W v| + 1e-12); sigma = u . (W v)
+ * w_bar [rows][cols] f32; sigma [1] f32 out; workspace >= v2ce_sn_workspace_bytes(rows, cols). */
+size_t v2ce_sn_workspace_bytes(int rows, int cols);
+int v2ce_sn_power_iter(float *u, float *v, const float *w_bar, int rows, int cols, float *sigma,
+                       void *workspace, size_t workspace_bytes, v2ce_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* V2CE_HIP_H */

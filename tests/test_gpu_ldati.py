@@ -1,0 +1,148 @@
+"""GPU parity: HIP LDATI (through the C ABI) vs the C oracle and the reference goldens."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ldati as O
+from v2ce_toolbox_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def hip_events(vox, fps=30, t0=0, uniforms=None, seed=None, frame_base=0, frame_ts_add=None):
+    from v2ce_toolbox_amd.LDATI import ldati_device
+    y = torch.from_numpy(np.ascontiguousarray(vox)).cuda()
+    u = None if uniforms is None else torch.from_numpy(np.ascontiguousarray(uniforms)).cuda()
+    add = None if frame_ts_add is None else torch.from_numpy(frame_ts_add).cuda()
+    ev = ldati_device(y, t0=t0, fps=fps, uniforms=u, seed=seed, frame_base=frame_base, frame_ts_add=add)
+    torch.cuda.synchronize()
+    return ev
+
+
+def soa_equal(ev, seg, ts, x, y, p):
+    assert np.array_equal(ev.seg_counts, seg)
+    assert np.array_equal(ev.ts.cpu().numpy(), ts)
+    assert np.array_equal(ev.x.cpu().numpy(), x)
+    assert np.array_equal(ev.y.cpu().numpy(), y)
+    assert np.array_equal(ev.p.cpu().numpy(), p)
+
+
+@pytest.mark.parametrize("name", ["sparse", "frac", "stress", "t0fps60", "ragged"])
+def test_replay_matches_reference_golden_and_oracle(gold_dir, name):
+    z = np.load(os.path.join(gold_dir, f"ldati_g3_{name}.npz"))
+    vox, u, fps, t0 = z["vox"], z["uniforms"], float(z["fps"]), float(z["t0"])
+    ref = np.frombuffer(z["events"].tobytes(), O.EVENT_DTYPE)
+    ev = hip_events(vox, fps, t0, uniforms=u)
+    # bit-exact vs the oracle, including the stable tie order
+    soa_equal(ev, *O.emit_soa(vox, fps=fps, t0=t0, uniforms=u))
+    # vs the reference's own output: exact up to the tie order its unstable argsort leaves open
+    mine = np.concatenate(ev.to_recarrays()) if ev.num_events else np.empty(0, O.EVENT_DTYPE)
+    assert np.array_equal(ev.frame_counts, z["lens"])
+    assert np.array_equal(mine["timestamp"], ref["timestamp"])
+    assert O.canonicalize(mine, ev.seg_counts.reshape(-1)).tobytes() == \
+        O.canonicalize(ref, ev.seg_counts.reshape(-1)).tobytes()
+
+
+def test_hand_kat(gold_dir):
+    kat = json.load(open(os.path.join(gold_dir, "ldati_kat.json")))["hand"]
+    vox = np.array(kat["vox"], np.float32).reshape(kat["shape"])
+    u = np.array(kat["uniforms"], np.float32).reshape(kat["uniforms_shape"])
+    from v2ce_toolbox_amd.LDATI import sample_voxel_statistical
+    res = sample_voxel_statistical(torch.from_numpy(vox).cuda(), fps=30, uniforms=torch.from_numpy(u))
+    assert [[int(v) for v in e] for e in res[0].tolist()] == kat["events"]
+    assert res[0].dtype.itemsize == 13 and res[0].dtype.names == ("timestamp", "x", "y", "polarity")
+
+
+def test_full_size_golden_sha(gold_dir):
+    """G4: 346x260 dense frame; every segment >= 32768 events so the reference order is the stable
+    order: packed bytes must be bit-identical to the reference's."""
+    meta = json.load(open(os.path.join(gold_dir, "ldati_g4.json")))
+    H, W = meta["H"], meta["W"]
+    vox = synth.synthetic_voxels(1, H, W, seed=meta["vox_seed"], regime=meta["vox_regime"])
+    mt = np.random.MT19937()
+    mt._legacy_seeding(meta["torch_seed"])
+    n = 2 * 9 * H * W * meta["max_n"]
+    u = ((mt.random_raw(n).astype(np.uint32) & 0xFFFFFF).astype(np.float32) * np.float32(2.0 ** -24))
+    u = u.reshape(1, 2, 9, H, W, meta["max_n"])
+    ev = hip_events(vox, meta["fps"], meta["t0"], uniforms=u)
+    assert ev.max_n == meta["max_n"]
+    assert ev.seg_counts.reshape(-1).tolist() == meta["seg_counts"]
+    rec = ev.to_recarrays()[0]
+    assert hashlib.sha256(np.ascontiguousarray(rec["timestamp"]).tobytes()).hexdigest() == meta["sha256_timestamps"]
+    assert hashlib.sha256(rec.tobytes()).hexdigest() == meta["sha256_packed_events"]
+
+
+@pytest.mark.parametrize("shape,regime,fps,t0,fb", [
+    ((3, 12, 14), "sparse", 30, 0, 0), ((2, 33, 47), "stress", 25, 0, 7),
+    ((1, 1, 1), "stress", 30, 0, 0), ((2, 64, 80), "stress", 120, 0.25, 1000),
+    ((1, 260, 346), "sparse", 30, 0, 5), ((4, 5, 129), "frac", 24, 0, 0)])
+def test_philox_matches_oracle(shape, regime, fps, t0, fb):
+    B, H, W = shape
+    vox = synth.synthetic_voxels(B, H, W, seed=B * 1000 + H, regime=regime)
+    ev = hip_events(vox, fps, t0, seed=0xDEADBEEF12345, frame_base=fb)
+    soa_equal(ev, *O.emit_soa(vox, fps=fps, t0=t0, seed=0xDEADBEEF12345, frame_base=fb))
+
+
+def test_philox_batching_invariance():
+    vox = synth.synthetic_voxels(5, 20, 30, seed=9, regime="stress")
+    whole = hip_events(vox, seed=42, frame_base=100)
+    a = hip_events(vox[:2], seed=42, frame_base=100)
+    b = hip_events(vox[2:], seed=42, frame_base=102)
+    assert np.array_equal(whole.ts.cpu().numpy(), np.concatenate([a.ts.cpu().numpy(), b.ts.cpu().numpy()]))
+    assert np.array_equal(whole.x.cpu().numpy(), np.concatenate([a.x.cpu().numpy(), b.x.cpu().numpy()]))
+
+
+def test_frame_offset_and_pack():
+    vox = synth.synthetic_voxels(3, 16, 18, seed=4, regime="stress")
+    add = np.array([0, 33333, 66666], np.int64)
+    ev0 = hip_events(vox, seed=1)
+    ev = hip_events(vox, seed=1, frame_ts_add=add)
+    per = np.repeat(add, ev.frame_counts)
+    assert np.array_equal(ev.ts.cpu().numpy(), ev0.ts.cpu().numpy() + per)
+    rec = np.concatenate(ev.to_recarrays())
+    want = O.pack(ev.ts.cpu().numpy(), ev.x.cpu().numpy(), ev.y.cpu().numpy(), ev.p.cpu().numpy())
+    assert rec.tobytes() == np.asarray(want).tobytes()
+
+
+def test_empty_input():
+    from v2ce_toolbox_amd.LDATI import sample_voxel_statistical
+    y = torch.zeros(2, 2, 10, 5, 6, device="cuda")
+    res = sample_voxel_statistical(y)
+    assert len(res) == 2 and all(len(r) == 0 and r.dtype.itemsize == 13 for r in res)
+    with pytest.raises(RuntimeError):
+        sample_voxel_statistical(y, strict_reference_errors=True)
+
+
+def test_option_errors():
+    from v2ce_toolbox_amd.LDATI import sample_voxel_statistical
+    y = torch.zeros(1, 2, 10, 4, 4, device="cuda")
+    with pytest.raises(AssertionError):
+        sample_voxel_statistical(y, pooling_type="bogus")
+    with pytest.raises(NotImplementedError):
+        sample_voxel_statistical(y, bidirectional=True)
+    with pytest.raises(Exception):
+        sample_voxel_statistical(torch.zeros(1, 2, 10, 4, 4))      # CPU tensor: no CPU path
+
+
+def test_full_size_properties():
+    """BASELINE chunk size (24 frame-pairs, 346x260): size-independent properties."""
+    vox = synth.synthetic_voxels(24, 260, 346, seed=77, regime="sparse")
+    ev = hip_events(vox, seed=5)
+    seg, mx = O.count(vox[:2])
+    assert np.array_equal(ev.seg_counts[:2], seg)
+    ts = ev.ts.cpu().numpy()
+    offs = np.concatenate([[0], np.cumsum(ev.seg_counts.reshape(-1))])
+    assert offs[-1] == ts.shape[0]
+    d = np.diff(ts)
+    bad = np.nonzero(d < 0)[0] + 1
+    assert set(bad.tolist()) <= set(offs.tolist()), "timestamps must be sorted inside every segment"
+    x, y, p = ev.x.cpu().numpy(), ev.y.cpu().numpy(), ev.p.cpu().numpy()
+    assert x.min() >= 0 and x.max() <= 345 and y.min() >= 0 and y.max() <= 259 and set(np.unique(p)) <= {0, 1}
+    # voxelising the events per (frame, polarity, bin) gives back the relocated counts: first frame
+    n0 = int(ev.frame_counts[0])
+    _, ots, ox, oy, op = O.emit_soa(vox[:1], seed=5)
+    assert np.array_equal(ts[:n0], ots) and np.array_equal(x[:n0], ox) and np.array_equal(p[:n0], op)

@@ -1,0 +1,179 @@
+"""GPU parity: HIP stage 1 (conv3d / spectral norm / V2ce3d, through the C ABI) vs the torch-fp32
+oracle and the goldens captured from the reference.  Tolerance (north_star): 1e-5 abs + 1e-5 rel."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import unet as U
+from v2ce_toolbox_amd import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def assert_close(a, b, what="", tol=TOL):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = np.abs(a - b) - tol * np.abs(b)
+    i = np.unravel_index(np.argmax(err), err.shape)
+    assert err[i] <= tol, f"{what}: max excess at {i}: got {a[i]!r} want {b[i]!r} (|d|={abs(a[i]-b[i]):.3e})"
+
+
+def to_btchw(x_ncdhw):
+    return x_ncdhw.permute(0, 2, 1, 3, 4).contiguous()
+
+
+def hip_conv(x0, w, scale, shift, ksize, stride, act, x1=None, up_to=None, residual=None):
+    """x0/x1/residual given as NCDHW torch CPU tensors; returns NCDHW numpy."""
+    from v2ce_toolbox_amd import hip
+    from v2ce_toolbox_amd.v2ce_3d import V2ce3d
+    m = V2ce3d.__new__(V2ce3d)
+    torch.nn.Module.__init__(m)
+    m._maps = {}
+    wd = w.cuda().contiguous()
+    wp = V2ce3d._pack(m, wd)
+    y = V2ce3d._conv(m, to_btchw(x0).cuda(), None if x1 is None else to_btchw(x1).cuda(), wp,
+                     scale.cuda().contiguous(), shift.cuda().contiguous(), w.shape[0], ksize, stride,
+                     act, residual=None if residual is None else to_btchw(residual).cuda(), up_to=up_to)
+    torch.cuda.synchronize()
+    return y.permute(0, 2, 1, 3, 4).cpu().numpy()
+
+
+def ref_conv(x0, w, scale, shift, ksize, stride, act, x1=None, up_to=None, residual=None):
+    x = x0.double()
+    if up_to is not None:
+        x = U.upsample_nearest_hw(x0, up_to).double()
+    if x1 is not None:
+        x = torch.cat([x, x1.double()], dim=1)
+    y = F.conv3d(x, w.double(), None, (1, stride, stride), ksize // 2)
+    y = y * scale.double().view(1, -1, 1, 1, 1) + shift.double().view(1, -1, 1, 1, 1)
+    if residual is not None:
+        y = y + residual.double()
+    if act == 1:
+        y = torch.relu(y)
+    elif act == 2:
+        y = F.leaky_relu(y, 0.01)
+    return y.numpy()
+
+
+CONV_CASES = [
+    # B, T, Cin, Cout, H, W, k, s, act, residual
+    (1, 4, 2, 32, 20, 28, 3, 1, 2, False),      # head-like (Cin=2)
+    (2, 3, 32, 64, 19, 23, 3, 2, 1, False),     # encoder conv1 (stride 2, odd sizes)
+    (1, 16, 64, 64, 9, 11, 3, 1, 1, True),      # conv2 + residual + relu
+    (1, 2, 32, 64, 19, 23, 1, 2, 0, False),     # strided 1x1 shortcut
+    (1, 5, 32, 20, 33, 47, 1, 1, 1, False),     # pred-like (Cout=20)
+    (1, 2, 128, 128, 17, 22, 3, 1, 0, False),   # bottleneck-like spatial size
+    (1, 16, 32, 32, 40, 70, 3, 1, 1, True),     # Cout=32 full-depth tile
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3d_vs_f64(case):
+    B, T, Cin, Cout, H, W, k, s, act, use_res = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(B, Cin, T, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, k, generator=g) * (2.0 / (Cin * k ** 3)) ** 0.5
+    scale = 0.5 + torch.rand(Cout, generator=g)
+    shift = 0.2 * torch.randn(Cout, generator=g)
+    Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
+    res = torch.randn(B, Cout, T, Ho, Wo, generator=g) if use_res else None
+    got = hip_conv(x, w, scale, shift, k, s, act, residual=res)
+    want = ref_conv(x, w, scale, shift, k, s, act, residual=res)
+    assert_close(got, want, str(case))
+
+
+@pytest.mark.parametrize("k", [1, 3])
+def test_conv3d_virtual_upsample_concat(k):
+    """Decoder input: nearest-upsample(x0) ++ skip, never materialised (unet_2layer.py:358-364)."""
+    g = torch.Generator().manual_seed(5 + k)
+    x0 = torch.randn(1, 64, 3, 17, 22, generator=g)
+    x1 = torch.randn(1, 32, 3, 33, 44, generator=g)
+    w = torch.randn(32, 96, k, k, k, generator=g) * (2.0 / (96 * k ** 3)) ** 0.5
+    scale, shift = torch.ones(32), torch.zeros(32)
+    got = hip_conv(x0, w, scale, shift, k, 1, 1, x1=x1, up_to=(33, 44))
+    want = ref_conv(x0, w, scale, shift, k, 1, 1, x1=x1, up_to=(33, 44))
+    assert_close(got, want, f"upsample+concat k={k}")
+
+
+def test_sn_power_iteration_and_pack():
+    from v2ce_toolbox_amd import hip
+    g = torch.Generator().manual_seed(3)
+    rows, cols = 64, 96 * 27
+    w = torch.randn(rows, 96, 3, 3, 3, generator=g) * 0.05
+    u = torch.randn(rows, generator=g); u /= u.norm()
+    v = torch.randn(cols, generator=g); v /= v.norm()
+    sd = {"m.weight_u": u.clone(), "m.weight_v": v.clone(), "m.weight_bar": w.clone()}
+    L = hip.lib()
+    ud, vd, wd = u.cuda(), v.cuda(), w.cuda().contiguous()
+    ws = torch.empty(L.v2ce_sn_workspace_bytes(rows, cols), dtype=torch.uint8, device="cuda")
+    sig = torch.empty(1, device="cuda")
+    wp = torch.empty(rows * cols, device="cuda")
+    for it in range(3):
+        wn = U.sn_step(sd, "m")
+        hip.check(L.v2ce_sn_power_iter(ud.data_ptr(), vd.data_ptr(), wd.data_ptr(), rows, cols,
+                                       sig.data_ptr(), ws.data_ptr(), ws.numel(), hip.stream_ptr()), "sn")
+        hip.check(L.v2ce_pack_weights(wd.data_ptr(), rows, 96, 27, sig.data_ptr(), wp.data_ptr(),
+                                      hip.stream_ptr()), "pack")
+        torch.cuda.synchronize()
+        assert_close(ud.cpu().numpy(), sd["m.weight_u"].numpy(), f"u it{it}", 2e-6)
+        assert_close(vd.cpu().numpy(), sd["m.weight_v"].numpy(), f"v it{it}", 2e-6)
+        want = wn.reshape(rows, 96, 27).permute(1, 2, 0).contiguous().numpy()      # [ci][tap][co]
+        assert_close(wp.cpu().numpy().reshape(96, 27, rows), want, f"w/sigma it{it}", 2e-6)
+
+
+def load_model():
+    from v2ce_toolbox_amd.v2ce_3d import V2ce3d
+    m = V2ce3d()
+    m.load_state_dict(synth.make_state_dict(0), strict=True)
+    return m.eval().to("cuda")
+
+
+def test_v2ce3d_matches_reference_three_calls(gold_dir):
+    """G1: outputs of the reference V2ce3d for three consecutive calls (SN state advances)."""
+    z = np.load(os.path.join(gold_dir, "unet_g1.npz"))
+    m = load_model()
+    out1, inter = m(torch.from_numpy(z["xa"]).cuda(), return_intermediates=True)
+    torch.cuda.synchronize()
+    for k, v in inter.items():
+        assert_close(v.permute(0, 2, 1, 3, 4).cpu().numpy(), z["inter_" + k], k)
+    assert_close(out1.cpu().numpy(), z["out1"], "call 1")
+    out2 = m(torch.from_numpy(z["xa"]).cuda())
+    assert_close(out2.cpu().numpy(), z["out2"], "call 2")
+    out3 = m(torch.from_numpy(z["xb"]).cuda())
+    assert_close(out3.cpu().numpy(), z["out3"], "call 3")
+    assert m.calls == 3
+    sd = m.state_dict()
+    for k in z.files:
+        if k.startswith("u_after3_"):
+            assert_close(sd[k[len("u_after3_"):]].cpu().numpy(), z[k], k, 2e-6)
+
+
+def test_v2ce3d_state_dict_roundtrip():
+    m = load_model()
+    x = torch.randn(1, 2, 2, 16, 16, device="cuda")
+    m(x)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    from v2ce_toolbox_amd.v2ce_3d import V2ce3d
+    m2 = V2ce3d()
+    m2.load_state_dict(sd)
+    m2 = m2.eval().to("cuda")
+    assert torch.equal(m(x), m2(x))
+
+
+def test_v2ce3d_full_width_tile_vs_oracle():
+    """One 346x260 sequence slice (L=2 to keep the CPU oracle fast) against oracle/unet.py."""
+    sd = synth.make_state_dict(0)
+    fr = synth.synthetic_frames(3, 260, 346, seed=1)
+    x = fr.astype(np.float32) / 255
+    x = np.stack([x[:-1], x[1:]], axis=1)
+    x = ((x - np.float32(0.153)) / np.float32(0.165))[None]
+    want = U.forward(U.clone_state(sd), torch.from_numpy(x)).numpy()
+    m = load_model()
+    got = m(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert (want > 1).mean() > 1e-3          # the fixture exercises multi-event voxels
+    assert_close(got, want, "346x260 L=2")

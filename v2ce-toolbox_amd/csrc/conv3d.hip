@@ -1,0 +1,403 @@
+// conv3d.hip -- fused 3-D convolution for the V2ce3d UNet on gfx950 (fp32 MFMA, LDS halo tiles).
+//
+// Replaces nn.Conv3d + BatchNorm3d(eval) + ReLU/LeakyReLU + residual add + nearest-upsample +
+// channel concat as used by /root/reference/scripts/submodules.py:96,115-124,226-264 and
+// /root/reference/scripts/unet_2layer.py:341-374.
+//
+// Formulation: direct convolution as a GEMM per workgroup,
+//     D[co][pos] += W[co][(ci,tap)] * X[(ci,tap)][pos]
+// with v_mfma_f32_32x32x2_f32 (exact f32 FMA chain; 64 FLOP/clk/SIMD = the chip's f32 peak).
+// Output POSITIONS sit on the MFMA N / lane dimension and output CHANNELS on the M / register
+// dimension, so each accumulator register is one channel of 32 consecutive positions: the epilogue
+// stores (and the residual loads) are 128-byte runs of the planar [B][T][C][H][W] layout.
+//
+// Per workgroup (256 threads = 4 waves): an output box (TT x TH x TW positions, <= POS_TILE) times
+// CO_TILE output channels.  The K loop walks the input channels in chunks of CK; per chunk the
+// input HALO box ((TT+2) x ((TH-1)s+3) x ((TW-1)s+3)) and the [tap][ci][co] weight slab are staged
+// once in LDS and all 27 taps read their shifted B fragments straight out of the halo (no im2col
+// duplication; LDS read bandwidth is far below the f32 MFMA's appetite: 6 ds_read_b32 per 8 MFMA =
+// 512 matrix cycles).  The halo loader is a gather, which is what makes the decoder's virtual
+// "nearest-upsample + concat" input free: channels < C0 are fetched from the low-resolution tensor
+// through row/column index maps, the rest from the skip tensor -- neither the upsampled tensor nor
+// the concatenation is ever written to HBM.
+#include "common.h"
+
+#include <map>
+#include <mutex>
+#include <tuple>
+
+namespace v2ce {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvParams {
+    const float *x0, *x1;
+    const int *hmap, *wmap;
+    const float *wp, *scale, *shift, *res;
+    float *y;
+    int B, T, C0, H0, W0, C1, Hin, Win, Cin, Cout, Hout, Wout;
+    int act;
+    int TT, TH, TW;       // output box
+    int nT, nH, nW;       // boxes per dimension
+    int HT, HH, HWd;      // halo box
+    int plane;            // HT*HH*HWd  (LDS stride between channels)
+    int n_co_tiles;
+    int n_pos;            // TT*TH*TW
+};
+
+template <int KS, int S, int CO_FR, int PO_FR, int CK, int EPT>
+struct ConvCfg {
+    static constexpr int K3 = KS * KS * KS;
+    static constexpr int CO_TILE = CO_FR * 32;
+    static constexpr int POS_TILE = 4 * PO_FR * 32;
+    static constexpr int MAX_PLANE = 256 * EPT;
+};
+
+// global element offsets (relative to the sequence base of the source tensor) of this thread's halo
+// elements; -1 = zero padding.  Element r of the halo plane <-> LDS offset r.
+template <int EPT>
+__device__ __forceinline__ void halo_offsets(const ConvParams &P, int pad, int tin0, int hin0,
+                                             int win0, bool src1, int (&goff)[EPT]) {
+    const int Cs = src1 ? P.C1 : P.C0;
+    const int Hs = src1 ? P.Hin : P.H0, Ws = src1 ? P.Win : P.W0;
+    const bool mapped = !src1 && P.hmap != nullptr;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int r = threadIdx.x + 256 * i;
+        int off = -1;
+        if (r < P.plane) {
+            const int ht = r / (P.HH * P.HWd);
+            const int rem = r - ht * (P.HH * P.HWd);
+            const int hh = rem / P.HWd;
+            const int hw = rem - hh * P.HWd;
+            const int t = tin0 + ht, h = hin0 + hh, w = win0 + hw;
+            if (t >= 0 && t < P.T && h >= 0 && h < P.Hin && w >= 0 && w < P.Win) {
+                const int hs = mapped ? P.hmap[h] : h;
+                const int ws = mapped ? P.wmap[w] : w;
+                off = (t * Cs) * (Hs * Ws) + hs * Ws + ws;
+            }
+        }
+        goff[i] = off;
+    }
+    (void)pad;
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char conv_smem[];
+
+template <int KS, int S, int CO_FR, int PO_FR, int CK, int EPT>
+__global__ __launch_bounds__(256, 2) void conv3d_kernel(ConvParams P) {
+    using Cfg = ConvCfg<KS, S, CO_FR, PO_FR, CK, EPT>;
+    constexpr int K3 = Cfg::K3, CO_TILE = Cfg::CO_TILE;
+    constexpr int PAD = KS / 2;
+
+    float *hl = reinterpret_cast<float *>(conv_smem);        // [CK][plane]
+    float *wl = hl + CK * P.plane;                           // [K3][CK][CO_TILE]
+
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // block -> (co tile, spatial box)
+    int bid = blockIdx.x;
+    const int co_t = bid % P.n_co_tiles;  bid /= P.n_co_tiles;
+    const int iw = bid % P.nW;            bid /= P.nW;
+    const int ih = bid % P.nH;            bid /= P.nH;
+    const int it = bid % P.nT;            bid /= P.nT;
+    const int b = bid;
+    const int co0 = co_t * CO_TILE;
+    const int t0 = it * P.TT, h0 = ih * P.TH, w0 = iw * P.TW;
+    const int tin0 = t0 - PAD, hin0 = h0 * S - PAD, win0 = w0 * S - PAD;
+
+    // per-lane position fragments
+    int hoff[PO_FR];      // halo offset of the position (tap 0,0,0)
+    int poff[PO_FR];      // output offset inside the sequence, channel 0; -1 = no such position
+#pragma unroll
+    for (int f = 0; f < PO_FR; ++f) {
+        const int m = (wave * PO_FR + f) * 32 + l32;
+        hoff[f] = 0;
+        poff[f] = -1;
+        if (m < P.n_pos) {
+            const int tt = m / (P.TH * P.TW);
+            const int rem = m - tt * (P.TH * P.TW);
+            const int th = rem / P.TW;
+            const int tw = rem - th * P.TW;
+            hoff[f] = (tt * P.HH + th * S) * P.HWd + tw * S;
+            const int t = t0 + tt, h = h0 + th, w = w0 + tw;
+            if (t < P.T && h < P.Hout && w < P.Wout)
+                poff[f] = (t * P.Cout) * (P.Hout * P.Wout) + h * P.Wout + w;
+        }
+    }
+
+    f32x16 acc[CO_FR][PO_FR];
+#pragma unroll
+    for (int q = 0; q < CO_FR; ++q)
+#pragma unroll
+        for (int f = 0; f < PO_FR; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][f][r] = 0.0f;
+
+    int goff[EPT];
+    int cur_src = -1;
+    const float *src_base = nullptr;
+    int src_cstride = 0, src_cbase = 0;
+
+    for (int ci0 = 0; ci0 < P.Cin; ci0 += CK) {
+        const int want_src = ci0 < P.C0 ? 0 : 1;
+        if (want_src != cur_src) {   // uniform; happens at most twice per kernel
+            cur_src = want_src;
+            halo_offsets<EPT>(P, PAD, tin0, hin0, win0, want_src == 1, goff);
+            if (want_src == 0) {
+                src_base = P.x0 + (long long)b * P.T * P.C0 * (P.H0 * P.W0);
+                src_cstride = P.H0 * P.W0;
+                src_cbase = 0;
+            } else {
+                src_base = P.x1 + (long long)b * P.T * P.C1 * (P.Hin * P.Win);
+                src_cstride = P.Hin * P.Win;
+                src_cbase = P.C0;
+            }
+        }
+        __syncthreads();   // previous chunk fully consumed
+        // ---- stage halo: CK channels x plane (one channel's loads in flight at a time: registers)
+#pragma unroll 1
+        for (int ci = 0; ci < CK; ++ci) {
+            const int cg = ci0 + ci;
+            const bool cok = cg < P.Cin;
+            const float *cb = src_base + (long long)(cg - src_cbase) * src_cstride;
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) {
+                const int r = tid + 256 * i;
+                if (r < P.plane) {
+                    const int o = goff[i];
+                    hl[ci * P.plane + r] = (cok && o >= 0) ? cb[o] : 0.0f;
+                }
+            }
+        }
+        // ---- stage weights: [K3][CK][CO_TILE] from wp[ci][tap][co]
+        {
+            constexpr int ROWS = K3 * CK;           // (ci, tap) rows of CO_TILE floats
+            constexpr int V4 = CO_TILE / 4;
+#pragma unroll 2
+            for (int e = tid; e < ROWS * V4; e += 256) {
+                const int row = e / V4, v = e - row * V4;
+                const int ci = row / K3, tap = row - ci * K3;
+                const int cg = ci0 + ci;
+                const int co = co0 + v * 4;
+                float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (cg < P.Cin && co < P.Cout)   // Cout % 4 == 0 is checked on the host
+                    val = *reinterpret_cast<const float4 *>(
+                        P.wp + ((long long)cg * K3 + tap) * P.Cout + co);
+                *reinterpret_cast<float4 *>(wl + (tap * CK + ci) * CO_TILE + v * 4) = val;
+            }
+        }
+        __syncthreads();
+        // ---- compute: K3 taps x CK/2 MFMA k-steps
+        for (int dt = 0; dt < KS; ++dt) {
+            for (int dh = 0; dh < KS; ++dh) {
+#pragma unroll
+                for (int dw = 0; dw < KS; ++dw) {
+                    const int tap = (dt * KS + dh) * KS + dw;
+                    const int toff = (dt * P.HH + dh) * P.HWd + dw;
+#pragma unroll
+                    for (int kk = 0; kk < CK / 2; ++kk) {
+                        float a[CO_FR], bq[PO_FR];
+                        const float *wrow = wl + (tap * CK + 2 * kk + half) * CO_TILE + l32;
+                        const float *hrow = hl + (2 * kk + half) * P.plane + toff;
+#pragma unroll
+                        for (int q = 0; q < CO_FR; ++q) a[q] = wrow[q * 32];
+#pragma unroll
+                        for (int f = 0; f < PO_FR; ++f) bq[f] = hrow[hoff[f]];
+#pragma unroll
+                        for (int q = 0; q < CO_FR; ++q)
+#pragma unroll
+                            for (int f = 0; f < PO_FR; ++f)
+                                acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], bq[f],
+                                                                                acc[q][f], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: y = act(acc*scale + shift (+res))
+    const long long ybase = (long long)b * P.T * P.Cout * (P.Hout * P.Wout);
+    const int cstride = P.Hout * P.Wout;
+#pragma unroll
+    for (int q = 0; q < CO_FR; ++q) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + q * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (co < P.Cout) {
+                const float sc = P.scale[co], sh = P.shift[co];
+#pragma unroll
+                for (int f = 0; f < PO_FR; ++f) {
+                    if (poff[f] >= 0) {
+                        const long long idx = ybase + poff[f] + (long long)co * cstride;
+                        float v = acc[q][f][r] * sc + sh;
+                        if (P.res) v += P.res[idx];
+                        if (P.act == V2CE_ACT_RELU) v = v > 0.f ? v : 0.f;
+                        else if (P.act == V2CE_ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
+                        P.y[idx] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side: tile choice + dispatch
+// ---------------------------------------------------------------------------------------------
+struct Tile { int tt, th, tw; };
+
+// best (tt,th,tw) with tt*th*tw <= pos_tile and halo plane <= max_plane: maximise the fraction of
+// MFMA lanes that compute real outputs, then prefer wide rows (coalescing) and small halos.
+Tile choose_tile(int T, int Ho, int Wo, int ks, int s, int pos_tile, int max_plane) {
+    Tile best{1, 1, 1};
+    double best_eff = -1.0;
+    long long best_halo = 0;
+    for (int tt = 1; tt <= T && tt <= 16; tt *= 2) {
+        for (int th = 1; th <= Ho && th <= 64; ++th) {
+            const int max_tw = pos_tile / (tt * th);
+            if (max_tw < 1) break;
+            for (int tw = 1; tw <= Wo && tw <= max_tw; ++tw) {
+                const long long plane = (long long)(tt + ks - 1) * ((th - 1) * s + ks) * ((tw - 1) * s + ks);
+                if (plane > max_plane) break;
+                const long long ntiles = (long long)((T + tt - 1) / tt) * ((Ho + th - 1) / th) *
+                                         ((Wo + tw - 1) / tw);
+                const double eff = (double)T * Ho * Wo / ((double)ntiles * pos_tile);
+                const bool better = eff > best_eff + 1e-9 ||
+                                    (eff > best_eff - 1e-9 && (tw > best.tw || (tw == best.tw && plane < best_halo)));
+                if (better) { best = {tt, th, tw}; best_eff = eff; best_halo = plane; }
+            }
+        }
+    }
+    return best;
+}
+
+template <int KS, int S, int CO_FR, int PO_FR, int CK, int EPT>
+int launch(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream) {
+    using Cfg = ConvCfg<KS, S, CO_FR, PO_FR, CK, EPT>;
+    Tile t{d.tile_t, d.tile_h, d.tile_w};
+    if (t.tt <= 0 || t.th <= 0 || t.tw <= 0) {
+        static std::mutex mu;
+        static std::map<std::tuple<int, int, int, int, int, int, int>, Tile> cache;
+        std::lock_guard<std::mutex> g(mu);
+        auto key = std::make_tuple(d.T, d.Hout, d.Wout, KS, S, Cfg::POS_TILE, Cfg::MAX_PLANE);
+        auto it = cache.find(key);
+        if (it == cache.end())
+            it = cache.emplace(key, choose_tile(d.T, d.Hout, d.Wout, KS, S, Cfg::POS_TILE, Cfg::MAX_PLANE)).first;
+        t = it->second;
+    }
+    P.TT = t.tt; P.TH = t.th; P.TW = t.tw;
+    P.n_pos = t.tt * t.th * t.tw;
+    P.HT = t.tt + KS - 1; P.HH = (t.th - 1) * S + KS; P.HWd = (t.tw - 1) * S + KS;
+    P.plane = P.HT * P.HH * P.HWd;
+    V2CE_REQUIRE(P.n_pos <= Cfg::POS_TILE && P.plane <= Cfg::MAX_PLANE, V2CE_ERR_UNSUPPORTED,
+                 "v2ce_conv3d_fwd: tile %dx%dx%d does not fit (positions %d/%d, halo %d/%d)", t.tt,
+                 t.th, t.tw, P.n_pos, Cfg::POS_TILE, P.plane, Cfg::MAX_PLANE);
+    P.nT = (d.T + t.tt - 1) / t.tt; P.nH = (d.Hout + t.th - 1) / t.th; P.nW = (d.Wout + t.tw - 1) / t.tw;
+    P.n_co_tiles = (d.Cout + Cfg::CO_TILE - 1) / Cfg::CO_TILE;
+    const long long blocks = (long long)d.B * P.nT * P.nH * P.nW * P.n_co_tiles;
+    V2CE_REQUIRE(blocks > 0 && blocks < (1ll << 31), V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd: grid too large");
+    const size_t lds = (size_t)(CK * P.plane + Cfg::K3 * CK * Cfg::CO_TILE) * sizeof(float);
+    V2CE_REQUIRE(lds <= 160 * 1024, V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd: %zu B of LDS", lds);
+    auto kern = conv3d_kernel<KS, S, CO_FR, PO_FR, CK, EPT>;
+    V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, P);
+    V2CE_HIP_CHECK(hipGetLastError());
+    return V2CE_OK;
+}
+
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float *__restrict__ w, int Cout,
+                                                           int Cin, int k3, const float *sigma,
+                                                           float *__restrict__ wp) {
+    // wp[ci][tap][co] = w[co][ci][tap] / sigma     (spectral_norm.py:31: elementwise true division)
+    const long long n = (long long)Cout * Cin * k3;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int co = (int)(i % Cout);
+    const long long r = i / Cout;          // ci*k3 + tap
+    float v = w[(long long)co * Cin * k3 + r];
+    if (sigma) v = v / sigma[0];
+    wp[i] = v;
+}
+
+}  // namespace
+}  // namespace v2ce
+
+using namespace v2ce;
+
+extern "C" int v2ce_conv3d_fwd(const v2ce_conv3d_desc *desc, const float *x0, const float *x1,
+                               const int32_t *hmap, const int32_t *wmap, const float *w_packed,
+                               const float *scale, const float *shift, const float *residual,
+                               float *y, v2ce_stream_t stream) {
+    clear_error();
+    V2CE_REQUIRE(desc && x0 && w_packed && scale && shift && y, V2CE_ERR_BAD_ARG,
+                 "v2ce_conv3d_fwd: null pointer");
+    const v2ce_conv3d_desc &d = *desc;
+    V2CE_REQUIRE(d.B > 0 && d.T > 0 && d.C0 > 0 && d.C1 >= 0 && d.Hin > 0 && d.Win > 0 && d.Cout > 0,
+                 V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd: bad shape");
+    V2CE_REQUIRE(d.ksize == 1 || d.ksize == 3, V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd: ksize %d", d.ksize);
+    V2CE_REQUIRE(d.stride_hw == 1 || d.stride_hw == 2, V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd: stride %d", d.stride_hw);
+    V2CE_REQUIRE(d.act >= 0 && d.act <= 2, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd: act %d", d.act);
+    V2CE_REQUIRE(d.C1 == 0 || x1, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd: C1>0 needs x1");
+    V2CE_REQUIRE((hmap == nullptr) == (wmap == nullptr), V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd: hmap/wmap");
+    V2CE_REQUIRE(hmap || (d.H0 == d.Hin && d.W0 == d.Win), V2CE_ERR_BAD_ARG,
+                 "v2ce_conv3d_fwd: source 0 is %dx%d, logical input %dx%d: index maps required", d.H0,
+                 d.W0, d.Hin, d.Win);
+    const int pad = d.ksize / 2, s = d.stride_hw;
+    V2CE_REQUIRE(d.Hout == (d.Hin + 2 * pad - d.ksize) / s + 1 && d.Wout == (d.Win + 2 * pad - d.ksize) / s + 1,
+                 V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd: output size %dx%d inconsistent", d.Hout, d.Wout);
+    V2CE_REQUIRE(d.Cout % 4 == 0, V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd: Cout %% 4 != 0");
+    const long long seq_in0 = (long long)d.T * d.C0 * d.H0 * d.W0, seq_in1 = (long long)d.T * d.C1 * d.Hin * d.Win;
+    const long long seq_out = (long long)d.T * d.Cout * d.Hout * d.Wout;
+    V2CE_REQUIRE(seq_in0 < (1ll << 31) && seq_in1 < (1ll << 31) && seq_out < (1ll << 31),
+                 V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd: a single sequence exceeds 2^31 elements");
+
+    ConvParams P{};
+    P.x0 = x0; P.x1 = x1; P.hmap = hmap; P.wmap = wmap; P.wp = w_packed; P.scale = scale;
+    P.shift = shift; P.res = residual; P.y = y;
+    P.B = d.B; P.T = d.T; P.C0 = d.C0; P.H0 = d.H0; P.W0 = d.W0; P.C1 = d.C1; P.Hin = d.Hin;
+    P.Win = d.Win; P.Cin = d.C0 + d.C1; P.Cout = d.Cout; P.Hout = d.Hout; P.Wout = d.Wout;
+    P.act = d.act;
+    hipStream_t st = as_stream(stream);
+
+    // CK per (ksize, stride): sized so 2 workgroups share a CU's 160 KiB of LDS
+    const bool small_co = d.Cout <= 32;
+    // fewer positions per workgroup when the launch would otherwise leave CUs idle
+    const long long pos_total = (long long)d.B * d.T * d.Hout * d.Wout;
+    const int co_tiles = small_co ? 1 : (d.Cout + 63) / 64;
+    const bool small_pos = (pos_total / 512) * co_tiles < 512;
+#define V2CE_CK_OK(CK) V2CE_REQUIRE(d.C1 == 0 || d.C0 % (CK) == 0, V2CE_ERR_UNSUPPORTED, \
+                                    "v2ce_conv3d_fwd: C0=%d not a multiple of the channel chunk %d", d.C0, (CK))
+#define V2CE_DISPATCH(KS, S, CK, EPT)                                                    \
+    do {                                                                                 \
+        V2CE_CK_OK(CK);                                                                  \
+        if (small_co) {                                                                  \
+            if (small_pos) return launch<KS, S, 1, 2, CK, EPT>(P, d, st);                \
+            return launch<KS, S, 1, 4, CK, EPT>(P, d, st);                               \
+        }                                                                                \
+        if (small_pos) return launch<KS, S, 2, 2, CK, EPT>(P, d, st);                    \
+        return launch<KS, S, 2, 4, CK, EPT>(P, d, st);                                   \
+    } while (0)
+    if (d.ksize == 3 && s == 1) V2CE_DISPATCH(3, 1, 4, 8);
+    if (d.ksize == 3 && s == 2) V2CE_DISPATCH(3, 2, 2, 14);
+    if (d.ksize == 1 && s == 1) V2CE_DISPATCH(1, 1, 16, 2);
+    V2CE_DISPATCH(1, 2, 8, 8);
+    return V2CE_ERR_UNSUPPORTED;
+#undef V2CE_DISPATCH
+#undef V2CE_CK_OK
+}
+
+extern "C" int v2ce_pack_weights(const float *w, int Cout, int Cin, int k3, const float *sigma,
+                                 float *w_packed, v2ce_stream_t stream) {
+    clear_error();
+    V2CE_REQUIRE(w && w_packed && Cout > 0 && Cin > 0 && (k3 == 1 || k3 == 27), V2CE_ERR_BAD_ARG,
+                 "v2ce_pack_weights: bad argument");
+    const long long n = (long long)Cout * Cin * k3;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       as_stream(stream), w, Cout, Cin, k3, sigma, w_packed);
+    V2CE_HIP_CHECK(hipGetLastError());
+    return V2CE_OK;
+}

@@ -1,0 +1,102 @@
+"""ctypes binding of ``csrc/libv2ce_hip.so`` (C ABI: ``include/v2ce_hip.h``).
+
+PyTorch is used only for device memory and streams: every call passes ``tensor.data_ptr()`` and
+the current HIP stream handle.  There is NO fallback: if the library is missing or cannot be
+loaded, ``lib()`` raises, and so does every op built on it.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(CSRC, "libv2ce_hip.so")
+
+RNG_REPLAY, RNG_PHILOX = 0, 1
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+
+EXPORTS = [
+    "v2ce_version", "v2ce_last_error", "v2ce_ldati_count", "v2ce_ldati_scan",
+    "v2ce_ldati_lds_bytes", "v2ce_ldati_emit", "v2ce_events_pack", "v2ce_conv3d_fwd",
+    "v2ce_pack_weights", "v2ce_sn_workspace_bytes", "v2ce_sn_power_iter",
+]
+
+
+class ConvDesc(ctypes.Structure):
+    """``v2ce_conv3d_desc`` (include/v2ce_hip.h)."""
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "B", "T", "C0", "H0", "W0", "C1", "Hin", "Win", "Cout", "Hout", "Wout", "ksize",
+        "stride_hw", "act", "tile_t", "tile_h", "tile_w")]
+
+
+class V2ceHipError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP library in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "-s", "clean"])
+    subprocess.check_call(["make", "-C", CSRC, "-s", "-j4", "libv2ce_hip.so"])
+    return SO_PATH
+
+
+_LIB = None
+
+
+def lib() -> ctypes.CDLL:
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(SO_PATH):
+        raise V2ceHipError(
+            f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` (make -C {CSRC}).  There is no CPU fallback.")
+    L = ctypes.CDLL(SO_PATH)
+    vp, i32, i64, f64, u64, sz = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double,
+                                  ctypes.c_uint64, ctypes.c_size_t)
+    L.v2ce_version.restype = ctypes.c_char_p
+    L.v2ce_last_error.restype = ctypes.c_char_p
+    L.v2ce_ldati_count.argtypes = [vp, i32, i32, i32, vp, vp, vp]
+    L.v2ce_ldati_scan.argtypes = [vp, i32, vp, vp]
+    L.v2ce_ldati_lds_bytes.argtypes = [f64, f64]
+    L.v2ce_ldati_lds_bytes.restype = sz
+    L.v2ce_ldati_emit.argtypes = [vp, i32, i32, i32, f64, f64, i32, vp, i32, u64, i64, vp, vp,
+                                  vp, vp, vp, vp, vp]
+    L.v2ce_events_pack.argtypes = [vp, vp, vp, vp, i64, vp, vp]
+    L.v2ce_conv3d_fwd.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.v2ce_pack_weights.argtypes = [vp, i32, i32, i32, vp, vp, vp]
+    L.v2ce_sn_workspace_bytes.argtypes = [i32, i32]
+    L.v2ce_sn_workspace_bytes.restype = sz
+    L.v2ce_sn_power_iter.argtypes = [vp, vp, vp, i32, i32, vp, vp, sz, vp]
+    for name in ("v2ce_ldati_count", "v2ce_ldati_scan", "v2ce_ldati_emit", "v2ce_events_pack",
+                 "v2ce_conv3d_fwd", "v2ce_pack_weights", "v2ce_sn_power_iter"):
+        getattr(L, name).restype = ctypes.c_int
+    _LIB = L
+    return L
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().v2ce_last_error().decode()
+        raise V2ceHipError(f"{what} failed with code {rc}: {msg}")
+
+
+def stream_ptr(device=None) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def require_device_f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise V2ceHipError(f"{name} must live on a HIP device (got {t.device}); there is no CPU path")
+    if t.dtype != torch.float32:
+        raise V2ceHipError(f"{name} must be float32 (got {t.dtype})")
+    return t.contiguous()

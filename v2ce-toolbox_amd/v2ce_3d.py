@@ -1,0 +1,282 @@
+"""V2ce3d (stage 1) -- host side mirroring ``/root/reference/scripts/v2ce_3d.py``.
+
+``V2ce3d`` is an ``nn.Module`` whose parameter/buffer tree reproduces the reference state_dict
+exactly (218 keys; ``scripts/v2ce_3d.py:13-24``, ``scripts/unet_2layer.py:203-318``,
+``scripts/submodules.py:85-124,216-264``, ``scripts/spectral_norm.py:43-59``), so
+``model.load_state_dict(torch.load('weights/v2ce_3d.pt'))``, ``.eval()``, ``.to('cuda')`` and
+``model(x)`` work as in ``v2ce.py:30-43,81-82``.  The forward pass contains no torch compute ops:
+every convolution (with its folded BatchNorm, activation, residual add, nearest-upsample + concat
+input) is one ``v2ce_conv3d_fwd`` launch, every spectral-norm layer one ``v2ce_sn_power_iter`` +
+``v2ce_pack_weights`` (include/v2ce_hip.h).  Inference only (the reference runs it under
+``torch.no_grad()`` in eval mode, ``v2ce.py:41,66``).
+"""
+from __future__ import annotations
+
+import ctypes
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hip
+
+BN_EPS = 1e-5
+BASE, NUM_ENC, NUM_RES = 32, 4, 2
+
+
+class _Conv(nn.Module):
+    """Holds nn.Conv3d-shaped parameters (``weight`` [, ``bias``])."""
+
+    def __init__(self, cin, cout, k, bias):
+        super().__init__()
+        w = torch.empty(cout, cin, k, k, k)
+        nn.init.kaiming_normal_(w, 10.0)                       # unet_2layer.py:259
+        self.weight = nn.Parameter(w, requires_grad=False)
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(cout), requires_grad=False)
+        else:
+            self.register_parameter("bias", None)
+
+
+class _SNConvInner(nn.Module):
+    """The ``module`` of a SpectralNorm wrapper: weight_u / weight_v / weight_bar
+    (spectral_norm.py:43-59)."""
+
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        w = torch.empty(cout, cin, k, k, k)
+        nn.init.kaiming_normal_(w, 10.0)
+        u = torch.randn(cout)
+        v = torch.randn(cin * k ** 3)
+        self.weight_u = nn.Parameter(u / (u.norm() + 1e-12), requires_grad=False)
+        self.weight_v = nn.Parameter(v / (v.norm() + 1e-12), requires_grad=False)
+        self.weight_bar = nn.Parameter(w, requires_grad=False)
+
+
+class _SNConv(nn.Module):
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.module = _SNConvInner(cin, cout, k)
+
+
+class _BN(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c), requires_grad=False)
+        self.bias = nn.Parameter(torch.zeros(c), requires_grad=False)
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+
+class _ConvLayer3D(nn.Module):
+    """submodules.py:85-124 with norm=None: conv3d (+bias) then activation."""
+
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.conv3d = _Conv(cin, cout, k, bias=True)
+
+
+class _ResidualBlock3D(nn.Module):
+    """submodules.py:216-264 with norm='BN'."""
+
+    def __init__(self, cin, cout, stride_hw, sn):
+        super().__init__()
+        self.stride_hw, self.sn, self.cin, self.cout = stride_hw, sn, cin, cout
+        self.conv1 = _SNConv(cin, cout, 3) if sn else _Conv(cin, cout, 3, bias=False)
+        self.bn1 = _BN(cout)
+        self.bn2 = _BN(cout)
+        self.conv2 = _SNConv(cout, cout, 3) if sn else _Conv(cout, cout, 3, bias=False)
+        self.downsample = nn.Sequential(OrderedDict([("0", _Conv(cin, cout, 1, bias=True)),
+                                                     ("1", _BN(cout))]))
+
+
+class _UNet3D(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.head = _ConvLayer3D(cin, BASE, 3)
+        self.encoders = nn.ModuleList(
+            [_ResidualBlock3D(BASE * 2 ** i, BASE * 2 ** (i + 1), 2, sn=False) for i in range(NUM_ENC)])
+        cmax = BASE * 2 ** NUM_ENC
+        self.resblocks = nn.ModuleList(
+            [_ResidualBlock3D(cmax, cmax, 1, sn=True) for _ in range(NUM_RES)])
+        dec_in = [BASE * 2 ** (i + 1) for i in range(NUM_ENC)][::-1]          # 512,256,128,64
+        self.decoders = nn.ModuleList(
+            [_ResidualBlock3D(int(1.5 * c), c // 2, 1, sn=True) for c in dec_in])
+        self.pred = _ConvLayer3D(BASE, cout, 1)
+
+
+def _nearest_map(n_in: int, n_out: int) -> np.ndarray:
+    """ATen nearest: src = min(floorf(dst * (float)in/out), in-1) (unet_2layer.py:360)."""
+    scale = np.float32(n_in) / np.float32(n_out)
+    src = np.floor(np.arange(n_out, dtype=np.float32) * scale).astype(np.int64)
+    return np.minimum(src, n_in - 1).astype(np.int32)
+
+
+class V2ce3d(nn.Module):
+    """Drop-in for ``scripts/v2ce_3d.py:12``: ``V2ce3d()(x[B,L,2,H,W]) -> [B,L,20,H,W]``."""
+
+    def __init__(self, in_channels=2, out_channels=20):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.UNet = _UNet3D(in_channels, out_channels)
+        self._prep = None          # device-side derived constants (packed weights, folded BN)
+        self._maps = {}
+        self.calls = 0             # number of forward passes = spectral-norm iterations applied
+
+    # ---- state handling ---------------------------------------------------------------------
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        r = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._prep = None
+        return r
+
+    def _apply(self, fn, *a, **kw):
+        r = super()._apply(fn, *a, **kw)
+        self._prep = None
+        self._maps = {}
+        return r
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError("V2ce3d (HIP) is inference-only; the reference runs it in eval mode")
+        return super().train(False)
+
+    # ---- derived constants ------------------------------------------------------------------
+    @staticmethod
+    def _fold_bn(bn: _BN, conv_bias=None):
+        scale = bn.weight / torch.sqrt(bn.running_var + BN_EPS)
+        shift = bn.bias - bn.running_mean * scale
+        if conv_bias is not None:
+            shift = shift + conv_bias * scale
+        return scale.float().contiguous(), shift.float().contiguous()
+
+    def _pack(self, w, sigma=None, out=None):
+        cout, cin = w.shape[0], w.shape[1]
+        k3 = w.shape[2] * w.shape[3] * w.shape[4]
+        if out is None:
+            out = torch.empty(cin * k3 * cout, dtype=torch.float32, device=w.device)
+        hip.check(hip.lib().v2ce_pack_weights(w.data_ptr(), cout, cin, k3, hip.ptr(sigma),
+                                              out.data_ptr(), hip.stream_ptr(w.device)),
+                  "v2ce_pack_weights")
+        return out
+
+    def _prepare(self):
+        dev = self.UNet.head.conv3d.weight.device
+        if dev.type != "cuda":
+            raise hip.V2ceHipError("V2ce3d: parameters must be on a HIP device (.to('cuda')); "
+                                   "there is no CPU path")
+        for p in self.parameters():
+            if p.dtype != torch.float32:
+                raise hip.V2ceHipError("V2ce3d: parameters must be float32")
+        P = {}
+        ones = lambda c: torch.ones(c, dtype=torch.float32, device=dev)
+        h = self.UNet.head.conv3d
+        P["head"] = (self._pack(h.weight.contiguous()), ones(h.weight.shape[0]), h.bias.float().contiguous())
+        pr = self.UNet.pred.conv3d
+        P["pred"] = (self._pack(pr.weight.contiguous()), ones(pr.weight.shape[0]), pr.bias.float().contiguous())
+        sn_ws = 0
+        for name, blocks in (("enc", self.UNet.encoders), ("res", self.UNet.resblocks),
+                             ("dec", self.UNet.decoders)):
+            for i, blk in enumerate(blocks):
+                d = {}
+                d["bn1"] = self._fold_bn(blk.bn1)
+                d["bn2"] = self._fold_bn(blk.bn2)
+                d["down_w"] = self._pack(blk.downsample[0].weight.contiguous())
+                d["down_bn"] = self._fold_bn(blk.downsample[1], blk.downsample[0].bias)
+                if blk.sn:
+                    for cn in ("conv1", "conv2"):
+                        m = getattr(blk, cn).module
+                        rows, cols = m.weight_bar.shape[0], m.weight_bar[0].numel()
+                        d[cn + "_w"] = torch.empty(rows * cols, dtype=torch.float32, device=dev)
+                        sn_ws = max(sn_ws, hip.lib().v2ce_sn_workspace_bytes(rows, cols))
+                else:
+                    d["conv1_w"] = self._pack(blk.conv1.weight.contiguous())
+                    d["conv2_w"] = self._pack(blk.conv2.weight.contiguous())
+                P[f"{name}{i}"] = d
+        P["sn_ws"] = torch.empty(max(sn_ws, 16), dtype=torch.uint8, device=dev)
+        P["sigma"] = torch.empty(1, dtype=torch.float32, device=dev)
+        self._prep = P
+
+    def _map(self, n_in, n_out, dev):
+        key = (n_in, n_out, str(dev))
+        if key not in self._maps:
+            self._maps[key] = torch.from_numpy(_nearest_map(n_in, n_out)).to(dev)
+        return self._maps[key]
+
+    # ---- kernels ------------------------------------------------------------------------------
+    def _conv(self, x0, x1, w_packed, scale, shift, cout, ksize, stride, act, residual=None,
+              up_to=None):
+        """x0 [B,T,C0,H0,W0] (optionally nearest-upsampled to ``up_to``), x1 [B,T,C1,Hin,Win]."""
+        B, T, C0, H0, W0 = x0.shape
+        Hin, Win = up_to if up_to is not None else (H0, W0)
+        hmap = wmap = None
+        if (Hin, Win) != (H0, W0):
+            hmap, wmap = self._map(H0, Hin, x0.device), self._map(W0, Win, x0.device)
+        C1 = 0 if x1 is None else x1.shape[2]
+        pad = ksize // 2
+        Hout = (Hin + 2 * pad - ksize) // stride + 1
+        Wout = (Win + 2 * pad - ksize) // stride + 1
+        y = torch.empty((B, T, cout, Hout, Wout), dtype=torch.float32, device=x0.device)
+        d = hip.ConvDesc(B=B, T=T, C0=C0, H0=H0, W0=W0, C1=C1, Hin=Hin, Win=Win, Cout=cout,
+                         Hout=Hout, Wout=Wout, ksize=ksize, stride_hw=stride, act=act,
+                         tile_t=0, tile_h=0, tile_w=0)
+        hip.check(hip.lib().v2ce_conv3d_fwd(ctypes.byref(d), x0.data_ptr(), hip.ptr(x1),
+                                            hip.ptr(hmap), hip.ptr(wmap), w_packed.data_ptr(),
+                                            scale.data_ptr(), shift.data_ptr(), hip.ptr(residual),
+                                            y.data_ptr(), hip.stream_ptr(x0.device)),
+                  "v2ce_conv3d_fwd")
+        return y
+
+    def _sn_weight(self, inner: _SNConvInner, out):
+        """spectral_norm.py:19-31: one power iteration (u, v updated in place), W_bar/sigma packed."""
+        P = self._prep
+        rows, cols = inner.weight_bar.shape[0], inner.weight_bar[0].numel()
+        hip.check(hip.lib().v2ce_sn_power_iter(inner.weight_u.data_ptr(), inner.weight_v.data_ptr(),
+                                               inner.weight_bar.data_ptr(), rows, cols,
+                                               P["sigma"].data_ptr(), P["sn_ws"].data_ptr(),
+                                               P["sn_ws"].numel(),
+                                               hip.stream_ptr(inner.weight_bar.device)),
+                  "v2ce_sn_power_iter")
+        return self._pack(inner.weight_bar, P["sigma"], out)
+
+    def _block(self, blk: _ResidualBlock3D, d, x0, x1=None, up_to=None):
+        """submodules.py:249-264: relu(bn2(conv2(relu(bn1(conv1 x)))) + bn_d(conv_d x))."""
+        s = blk.stride_hw
+        w1 = self._sn_weight(blk.conv1.module, d["conv1_w"]) if blk.sn else d["conv1_w"]
+        t = self._conv(x0, x1, w1, *d["bn1"], blk.cout, 3, s, hip.ACT_RELU, up_to=up_to)
+        res = self._conv(x0, x1, d["down_w"], *d["down_bn"], blk.cout, 1, s, hip.ACT_NONE, up_to=up_to)
+        w2 = self._sn_weight(blk.conv2.module, d["conv2_w"]) if blk.sn else d["conv2_w"]
+        return self._conv(t, None, w2, *d["bn2"], blk.cout, 3, 1, hip.ACT_RELU, residual=res)
+
+    # ---- forward ------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, return_intermediates: bool = False):
+        """x [B,L,2,H,W] f32 on the device -> [B,L,20,H,W] (contiguous; the reference returns the
+        same values as a permuted view, v2ce_3d.py:29).  Like the reference, every call advances
+        the spectral-norm u/v of the 12 SN layers by one power iteration."""
+        if x.dim() != 5 or x.shape[2] != self.in_channels:
+            raise ValueError(f"expected x of shape [B,L,{self.in_channels},H,W], got {tuple(x.shape)}")
+        x = hip.require_device_f32(x, "x")
+        if self._prep is None:
+            self._prepare()
+        P, U = self._prep, self.UNet
+        inter = OrderedDict()
+        h = self._conv(x, None, *P["head"], BASE, 3, 1, hip.ACT_LEAKY)           # unet_2layer.py:341
+        inter["head"] = h
+        skips = []
+        for i, blk in enumerate(U.encoders):                                     # :345-347
+            skips.append(h)
+            h = self._block(blk, P[f"enc{i}"], h)
+            inter[f"enc{i}"] = h
+        for i, blk in enumerate(U.resblocks):                                    # :349-350
+            h = self._block(blk, P[f"res{i}"], h)
+            inter[f"res{i}"] = h
+        for i, (blk, skip) in enumerate(zip(U.decoders, reversed(skips))):       # :357-365
+            h = self._block(blk, P[f"dec{i}"], h, skip, up_to=(skip.shape[3], skip.shape[4]))
+            inter[f"dec{i}"] = h
+        out = self._conv(h, None, *P["pred"], self.out_channels, 1, 1, hip.ACT_RELU)   # :374
+        self.calls += 1
+        if return_intermediates:
+            return out, inter
+        return out
