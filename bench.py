@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: end-to-end frame-pairs/s (V2ce3d UNet + LDATI) at 346x260.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload e2e|ldati_stress|ldati_sparse]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch resident in HBM: `--batch` (default 4, the
+BASELINE.json configs[1] "batch=4 sliding frame-pairs" case) 16-pair sequences of preprocessed
+346x260 frames -> V2ce3d -> LDATI (count, scan, emit with the per-frame offset fused, pack) -> the
+packed event records on the device.  With N > 1 every rank processes its own contiguous block of
+sequences (weak scaling, no data-path collective) and the packed events are gathered to rank 0
+over RCCL inside the timed region.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from v2ce_toolbox_amd import synth                                   # noqa: E402
+from v2ce_toolbox_amd.LDATI import ldati_device                      # noqa: E402
+from v2ce_toolbox_amd.v2ce_3d import V2ce3d                          # noqa: E402
+from v2ce_toolbox_amd import dist as vdist                           # noqa: E402
+from v2ce_toolbox_amd import glue                                    # noqa: E402
+
+H, W, SEQ = 260, 346, 16
+PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: 256 CU x 256 FLOP/clk x 2.4 GHz
+PEAK_HBM_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FLOP_PER_PAIR = 135.58e9
+
+
+def make_inputs(batch, first_seq, device):
+    """[batch,16,2,H,W] f32 preprocessed frame pairs (v2ce.py:45-64) of synthetic drifting frames."""
+    xs = []
+    for s in range(batch):
+        fr = synth.synthetic_frames(SEQ + 1, H, W, seed=1000 + first_seq + s)
+        xs.append(glue.image_pre_processing(fr))
+    return torch.from_numpy(np.stack(xs)).to(device)
+
+
+def cpu_baseline(pairs=4):
+    """The oracle (CPU restatement: torch-CPU stage 1 on all cores + scalar C LDATI) on a bounded
+    sample of the same workload: one 346x260 sequence slice of `pairs` frame-pairs."""
+    from oracle import ldati as O
+    from oracle import unet as U
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = synth.make_state_dict(0)
+    fr = synth.synthetic_frames(pairs + 1, H, W, seed=1000)
+    x = torch.from_numpy(glue.image_pre_processing(fr)[None])
+    t0 = time.perf_counter()
+    vox = U.forward(sd, x).contiguous().numpy().reshape(pairs, 2, 10, H, W)
+    t1 = time.perf_counter()
+    seg, ts, _, _, _ = O.emit_soa(vox, fps=30, seed=1)
+    t2 = time.perf_counter()
+    return {"value": pairs / (t2 - t0), "unit": "frame-pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{pairs} frame-pairs (one 346x260 sequence slice): oracle stage 1 on torch-CPU "
+                      f"{t1 - t0:.1f} s ({cores} threads) + scalar C LDATI {t2 - t1:.1f} s (1 thread), "
+                      f"{int(seg.sum())} events"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=4, help="16-pair sequences per step per GPU")
+    ap.add_argument("--workload", default="e2e", choices=["e2e", "ldati_stress", "ldati_sparse"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    device = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    b = args.batch
+    pairs_per_step = b * SEQ
+    first_pair = rank * pairs_per_step                       # contiguous block of sequences per rank
+    fps = 30
+    ts_add = torch.tensor([glue.frame_offset_us(first_pair + i, fps) for i in range(pairs_per_step)],
+                          dtype=torch.int64, device=device)
+    model = None
+    if args.workload == "e2e":
+        model = V2ce3d()
+        model.load_state_dict(synth.make_state_dict(0))
+        model = model.eval().to(device)
+        x = make_inputs(b, rank * b, device)
+        vox_fixed = None
+    else:
+        regime = "stress" if args.workload == "ldati_stress" else "sparse"
+        pairs_per_step = 24                                   # reference stage-2 chunk (v2ce.py:302)
+        first_pair = rank * pairs_per_step
+        ts_add = ts_add[:1].repeat(pairs_per_step) * 0
+        vox_fixed = torch.from_numpy(synth.synthetic_voxels(pairs_per_step, H, W, seed=7 + rank,
+                                                            regime=regime)).to(device)
+    ldati_prof = []
+    gather_bytes = [0]
+
+    def step(profile):
+        if model is not None:
+            model.profile = [] if profile else None
+            vox = model(x).view(pairs_per_step, 2, 10, H, W)
+        else:
+            vox = vox_fixed
+        ev = ldati_device(vox, fps=fps, seed=0x5EED, frame_base=first_pair, frame_ts_add=ts_add,
+                          profile=ldati_prof if profile else None)
+        packed = ev.packed()
+        if world > 1:
+            out = vdist.gather_events(packed, dst=0)
+            if rank == 0:
+                gather_bytes[0] = int(out.numel())
+        conv_prof = model.profile if (model is not None and profile) else []
+        return ev.num_events, conv_prof
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    events = 0
+    conv_events = []
+    for _ in range(args.steps):
+        n, cp = step(True)
+        events += n
+        conv_events += cp
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt, float(events)], dtype=torch.float64, device=device)
+        tmax = t.clone()
+        torch.distributed.all_reduce(tmax[:1], op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(t[1:], op=torch.distributed.ReduceOp.SUM)
+        dt, events = float(tmax[0]), float(t[1])
+    total_pairs = world * pairs_per_step * args.steps
+
+    # ---- per-kernel HIP-event timings collected inside the timed region
+    per = {}
+    for name, flops, e0, e1 in conv_events:
+        d = per.setdefault(name, [0.0, 0.0, 0])
+        d[0] += e0.elapsed_time(e1) * 1e-3
+        d[1] += flops
+        d[2] += 1
+    kernels = {k: {"launches": v[2], "avg_ms": 1e3 * v[0] / v[2], "tflops": v[1] / v[0] / 1e12}
+               for k, v in sorted(per.items(), key=lambda kv: -kv[1][0])}
+    em = [(e0.elapsed_time(e1) * 1e-3, nb) for tag, e0, e1, nb in ldati_prof if tag == "emit"]
+    em_t, em_bytes, em_n = sum(t for t, _ in em), sum(nb for _, nb in em), len(em)
+    ldati = None
+    if em_n:
+        ldati = {"kernel": "ldati_emit_kernel", "avg_ms": 1e3 * em_t / em_n,
+                 "achieved_GBps": em_bytes / em_t / 1e9, "frac_hbm_peak": em_bytes / em_t / 1e9 / PEAK_HBM_GBS,
+                 "algorithmic_bytes_per_launch": em_bytes / em_n}
+    if args.workload == "e2e":
+        name = max(per, key=lambda k: per[k][0])
+        v = per[name]
+        roofline = {"bound": "mfma", "kernel": name, "achieved": v[1] / v[0] / 1e12,
+                    "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                    "frac": v[1] / v[0] / 1e12 / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
+                    "avg_launch_ms": 1e3 * v[0] / v[2], "flop_per_launch": v[1] / v[2],
+                    "all_conv_tflops": sum(x[1] for x in per.values()) / sum(x[0] for x in per.values()) / 1e12}
+    else:
+        roofline = {"bound": "hbm", "kernel": "ldati_emit_kernel", "achieved": ldati["achieved_GBps"],
+                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ldati["frac_hbm_peak"], "traffic": None,
+                    "avg_launch_ms": ldati["avg_ms"], "bytes_per_launch": ldati["algorithmic_bytes_per_launch"]}
+
+    if rank == 0:
+        line = {
+            "metric": "frame-pairs/sec end-to-end (UNet+LDATI), 346x260",
+            "value": total_pairs / dt, "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": {"e2e": f"346x260 center, batch={b} sequences x 16 frame-pairs per GPU, "
+                                           "V2ce3d (synthetic weights seed 0) + LDATI (Philox), inputs resident in HBM",
+                                    "ldati_stress": "LDATI only, 24 frame-pairs of 6*U[0,1) voxels (C5 stress)",
+                                    "ldati_sparse": "LDATI only, 24 frame-pairs of relu(0.8*randn) voxels"}[args.workload],
+                       "frame_pairs_per_step_per_gpu": pairs_per_step, "fps": fps,
+                       "parallelism": f"dp{world} over sequences"},
+            "mevents_per_s": events / dt / 1e6, "events_per_pair": events / total_pairs,
+            "stage1_mfma_frac_e2e": (FLOP_PER_PAIR * total_pairs / dt / 1e12 / PEAK_F32_MATRIX_TFLOPS / world)
+            if args.workload == "e2e" else None,
+            "roofline": roofline, "ldati": ldati, "kernels": kernels,
+        }
+        if world > 1:
+            line["gathered_bytes_per_step"] = gather_bytes[0]
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

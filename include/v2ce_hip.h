@@ -109,6 +109,11 @@ int v2ce_conv3d_fwd(const v2ce_conv3d_desc *desc, const float *x0, const float *
                     const float *scale, const float *shift, const float *residual, float *y,
                     v2ce_stream_t stream);
 
+/* Name of the kernel instantiation v2ce_conv3d_fwd would launch for desc ("conv3d_kernel<KS,S,
+ * CO_FR,PO_FR,CK,EPT>", as it appears demangled in rocprofv3 traces); mapped != 0 means hmap/wmap
+ * would be non-NULL.  Launches nothing.  Used by bench.py to attribute event timings. */
+int v2ce_conv3d_variant(const v2ce_conv3d_desc *desc, int mapped, char *name, size_t cap);
+
 /* Weight re-layout [Cout][Cin][k^3] -> [Cin][k^3][Cout], optionally divided elementwise by
  * *sigma (spectral_norm.py:31 `w / sigma.expand_as(w)`; sigma NULL = plain re-layout). */
 int v2ce_pack_weights(const float *w, int Cout, int Cin, int k3, const float *sigma,

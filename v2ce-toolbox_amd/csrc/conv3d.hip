@@ -274,9 +274,16 @@ Tile choose_tile(int T, int Ho, int Wo, int ks, int s, int pos_tile, int max_pla
     return best;
 }
 
+thread_local char *g_name_out = nullptr;   // non-null: report the variant instead of launching
+thread_local size_t g_name_cap = 0;
+
 template <int KS, int S, int CO_FR, int PO_FR, int CK, int EPT>
 int launch(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream) {
     using Cfg = ConvCfg<KS, S, CO_FR, PO_FR, CK, EPT>;
+    if (g_name_out) {
+        snprintf(g_name_out, g_name_cap, "conv3d_kernel<%d,%d,%d,%d,%d,%d>", KS, S, CO_FR, PO_FR, CK, EPT);
+        return V2CE_OK;
+    }
     Tile t{d.tile_t, d.tile_h, d.tile_w};
     if (t.tt <= 0 || t.th <= 0 || t.tw <= 0) {
         static std::mutex mu;
@@ -328,12 +335,12 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float *__restri
 
 using namespace v2ce;
 
-extern "C" int v2ce_conv3d_fwd(const v2ce_conv3d_desc *desc, const float *x0, const float *x1,
-                               const int32_t *hmap, const int32_t *wmap, const float *w_packed,
-                               const float *scale, const float *shift, const float *residual,
-                               float *y, v2ce_stream_t stream) {
+static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const float *x1,
+                           const int32_t *hmap, const int32_t *wmap, const float *w_packed,
+                           const float *scale, const float *shift, const float *residual,
+                           float *y, v2ce_stream_t stream) {
     clear_error();
-    V2CE_REQUIRE(desc && x0 && w_packed && scale && shift && y, V2CE_ERR_BAD_ARG,
+    V2CE_REQUIRE(desc && (g_name_out || (x0 && w_packed && scale && shift && y)), V2CE_ERR_BAD_ARG,
                  "v2ce_conv3d_fwd: null pointer");
     const v2ce_conv3d_desc &d = *desc;
     V2CE_REQUIRE(d.B > 0 && d.T > 0 && d.C0 > 0 && d.C1 >= 0 && d.Hin > 0 && d.Win > 0 && d.Cout > 0,
@@ -341,7 +348,7 @@ extern "C" int v2ce_conv3d_fwd(const v2ce_conv3d_desc *desc, const float *x0, co
     V2CE_REQUIRE(d.ksize == 1 || d.ksize == 3, V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd: ksize %d", d.ksize);
     V2CE_REQUIRE(d.stride_hw == 1 || d.stride_hw == 2, V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd: stride %d", d.stride_hw);
     V2CE_REQUIRE(d.act >= 0 && d.act <= 2, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd: act %d", d.act);
-    V2CE_REQUIRE(d.C1 == 0 || x1, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd: C1>0 needs x1");
+    V2CE_REQUIRE(d.C1 == 0 || x1 || g_name_out, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd: C1>0 needs x1");
     V2CE_REQUIRE((hmap == nullptr) == (wmap == nullptr), V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd: hmap/wmap");
     V2CE_REQUIRE(hmap || (d.H0 == d.Hin && d.W0 == d.Win), V2CE_ERR_BAD_ARG,
                  "v2ce_conv3d_fwd: source 0 is %dx%d, logical input %dx%d: index maps required", d.H0,
@@ -388,6 +395,27 @@ extern "C" int v2ce_conv3d_fwd(const v2ce_conv3d_desc *desc, const float *x0, co
     return V2CE_ERR_UNSUPPORTED;
 #undef V2CE_DISPATCH
 #undef V2CE_CK_OK
+}
+
+extern "C" int v2ce_conv3d_fwd(const v2ce_conv3d_desc *desc, const float *x0, const float *x1,
+                               const int32_t *hmap, const int32_t *wmap, const float *w_packed,
+                               const float *scale, const float *shift, const float *residual,
+                               float *y, v2ce_stream_t stream) {
+    g_name_out = nullptr;
+    return conv3d_dispatch(desc, x0, x1, hmap, wmap, w_packed, scale, shift, residual, y, stream);
+}
+
+extern "C" int v2ce_conv3d_variant(const v2ce_conv3d_desc *desc, int mapped, char *name, size_t cap) {
+    V2CE_REQUIRE(name && cap > 0, V2CE_ERR_BAD_ARG, "v2ce_conv3d_variant: no buffer");
+    name[0] = '\0';
+    g_name_out = name;
+    g_name_cap = cap;
+    static const int32_t dummy_map = 0;
+    const int32_t *m = mapped ? &dummy_map : nullptr;
+    const int rc = conv3d_dispatch(desc, nullptr, nullptr, m, m, nullptr, nullptr, nullptr, nullptr,
+                                   nullptr, nullptr);
+    g_name_out = nullptr;
+    return rc;
 }
 
 extern "C" int v2ce_pack_weights(const float *w, int Cout, int Cin, int k3, const float *sigma,

@@ -22,6 +22,7 @@ ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 EXPORTS = [
     "v2ce_version", "v2ce_last_error", "v2ce_ldati_count", "v2ce_ldati_scan",
     "v2ce_ldati_lds_bytes", "v2ce_ldati_emit", "v2ce_events_pack", "v2ce_conv3d_fwd",
+    "v2ce_conv3d_variant",
     "v2ce_pack_weights", "v2ce_sn_workspace_bytes", "v2ce_sn_power_iter",
 ]
 
@@ -70,11 +71,12 @@ def lib() -> ctypes.CDLL:
     L.v2ce_events_pack.argtypes = [vp, vp, vp, vp, i64, vp, vp]
     L.v2ce_conv3d_fwd.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.v2ce_pack_weights.argtypes = [vp, i32, i32, i32, vp, vp, vp]
+    L.v2ce_conv3d_variant.argtypes = [ctypes.POINTER(ConvDesc), i32, ctypes.c_char_p, sz]
     L.v2ce_sn_workspace_bytes.argtypes = [i32, i32]
     L.v2ce_sn_workspace_bytes.restype = sz
     L.v2ce_sn_power_iter.argtypes = [vp, vp, vp, i32, i32, vp, vp, sz, vp]
     for name in ("v2ce_ldati_count", "v2ce_ldati_scan", "v2ce_ldati_emit", "v2ce_events_pack",
-                 "v2ce_conv3d_fwd", "v2ce_pack_weights", "v2ce_sn_power_iter"):
+                 "v2ce_conv3d_fwd", "v2ce_conv3d_variant", "v2ce_pack_weights", "v2ce_sn_power_iter"):
         getattr(L, name).restype = ctypes.c_int
     _LIB = L
     return L
@@ -100,3 +102,9 @@ def require_device_f32(t: torch.Tensor, name: str) -> torch.Tensor:
     if t.dtype != torch.float32:
         raise V2ceHipError(f"{name} must be float32 (got {t.dtype})")
     return t.contiguous()
+
+
+def conv_variant(desc: ConvDesc, mapped: bool) -> str:
+    buf = ctypes.create_string_buffer(96)
+    check(lib().v2ce_conv3d_variant(ctypes.byref(desc), int(mapped), buf, 96), "v2ce_conv3d_variant")
+    return buf.value.decode()

@@ -124,6 +124,7 @@ class V2ce3d(nn.Module):
         self._prep = None          # device-side derived constants (packed weights, folded BN)
         self._maps = {}
         self.calls = 0             # number of forward passes = spectral-norm iterations applied
+        self.profile = None        # list -> every conv launch appends (variant, flops, ev0, ev1)
 
     # ---- state handling ---------------------------------------------------------------------
     def load_state_dict(self, state_dict, strict=True, **kw):
@@ -221,11 +222,19 @@ class V2ce3d(nn.Module):
         d = hip.ConvDesc(B=B, T=T, C0=C0, H0=H0, W0=W0, C1=C1, Hin=Hin, Win=Win, Cout=cout,
                          Hout=Hout, Wout=Wout, ksize=ksize, stride_hw=stride, act=act,
                          tile_t=0, tile_h=0, tile_w=0)
+        prof = getattr(self, "profile", None)
+        if prof is not None:       # HIP events on the launch stream (torch's current stream)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         hip.check(hip.lib().v2ce_conv3d_fwd(ctypes.byref(d), x0.data_ptr(), hip.ptr(x1),
                                             hip.ptr(hmap), hip.ptr(wmap), w_packed.data_ptr(),
                                             scale.data_ptr(), shift.data_ptr(), hip.ptr(residual),
                                             y.data_ptr(), hip.stream_ptr(x0.device)),
                   "v2ce_conv3d_fwd")
+        if prof is not None:
+            e1.record()
+            flops = 2.0 * B * T * Hout * Wout * cout * (C0 + C1) * ksize ** 3
+            prof.append((hip.conv_variant(d, hmap is not None), flops, e0, e1))
         return y
 
     def _sn_weight(self, inner: _SNConvInner, out):
@@ -248,6 +257,20 @@ class V2ce3d(nn.Module):
         res = self._conv(x0, x1, d["down_w"], *d["down_bn"], blk.cout, 1, s, hip.ACT_NONE, up_to=up_to)
         w2 = self._sn_weight(blk.conv2.module, d["conv2_w"]) if blk.sn else d["conv2_w"]
         return self._conv(t, None, w2, *d["bn2"], blk.cout, 3, 1, hip.ACT_RELU, residual=res)
+
+    @torch.no_grad()
+    def advance_spectral_norm(self):
+        """Apply the power iteration of one forward call to all 12 SN layers without running the
+        convolutions (the u/v trajectory is input independent): used to fast-forward a replica to
+        the global call index it emulates when calls are sharded over GPUs."""
+        if self._prep is None:
+            self._prepare()
+        for name, blocks in (("res", self.UNet.resblocks), ("dec", self.UNet.decoders)):
+            for i, blk in enumerate(blocks):
+                d = self._prep[f"{name}{i}"]
+                self._sn_weight(blk.conv1.module, d["conv1_w"])
+                self._sn_weight(blk.conv2.module, d["conv2_w"])
+        self.calls += 1
 
     # ---- forward ------------------------------------------------------------------------------
     @torch.no_grad()
