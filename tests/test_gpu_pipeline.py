@@ -1,0 +1,73 @@
+"""GPU: the glue around the two stages against goldens captured from the reference v2ce.py
+(center and pano tiling, batching, merge), and the CLI end to end."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import glue as OG
+from oracle import ldati as O
+from oracle import unet as U
+from v2ce_toolbox_amd import glue, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL = 1e-5
+
+
+def load_model():
+    from v2ce_toolbox_amd.v2ce_3d import V2ce3d
+    m = V2ce3d()
+    m.load_state_dict(synth.make_state_dict(0))
+    return m.eval().to("cuda")
+
+
+@pytest.mark.parametrize("infer_type", ["center", "pano"])
+def test_video_to_voxels_matches_reference(gold_dir, infer_type):
+    """G7: reference video_to_voxels on 20 frames 8x20, width 12, -b 2 (partial last tile, partial
+    last batch, overlapped last sequence; pano makes one model call per tile => SN call indices)."""
+    z = np.load(os.path.join(gold_dir, "glue_g7.npz"))
+    H, WF, width, N, bs = z["params"].tolist()
+    got = glue.video_to_voxels(load_model(), frames=z["frames"], infer_type=infer_type, seq_len=16,
+                               width=width, height=H, batch_size=bs).cpu().numpy()
+    want = z[infer_type]
+    assert got.shape == want.shape
+    assert np.all(np.abs(got - want) <= TOL + TOL * np.abs(want)), np.abs(got - want).max()
+
+
+def test_cli_end_to_end(tmp_path):
+    """python v2ce.py --synthetic 20 ...: file name, npz key, dtype; events == oracle LDATI applied
+    to the oracle-checked voxels with the per-frame offsets of v2ce.py:365."""
+    out = tmp_path / "out"
+    cmd = [sys.executable, os.path.join(ROOT, "v2ce.py"), "--synthetic", "20", "--height", "32",
+           "--width", "48", "--synthetic_weights", "0", "-o", str(out), "-b", "2", "--seed", "11",
+           "--write_event_frame_video", "false", "--stage2_batch_size", "7", "--out_name_suffix", "t"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    path = out / "synthetic20-ceil_10-fps_30-t-events.npz"
+    assert path.exists()
+    ev = np.load(path)["event_stream"]
+    assert ev.dtype == O.EVENT_DTYPE and ev.dtype.itemsize == 13
+    # rebuild the expectation stage-wise
+    frames = synth.synthetic_frames(20, 32, 48)
+    vox = glue.video_to_voxels(load_model(), frames=frames, width=48, height=32, batch_size=2).cpu().numpy()
+    sd = synth.make_state_dict(0)
+    num, mode, starts = OG.sequence_plan(20)
+    seqs = []
+    for b0 in range(0, num, 2):
+        x = np.stack([OG.preprocess(frames[starts[s]:starts[s] + 17]) for s in range(b0, min(b0 + 2, num))])
+        seqs += list(U.forward(sd, torch.from_numpy(x)).numpy())
+    want_vox = np.stack([seqs[s][j] for s, j in OG.merged_pair_sources(20)]).reshape(19, 2, 10, 32, 48)
+    assert np.all(np.abs(vox - want_vox) <= TOL + TOL * np.abs(want_vox))
+    exp = []
+    for i0 in range(0, 19, 7):
+        recs = O.sample_voxel_statistical_oracle(vox[i0:i0 + 7], fps=30, seed=11, frame_base=i0)
+        for j, rec in enumerate(recs):
+            rec = rec.copy()
+            rec["timestamp"] += OG.frame_offset_us(i0 + j, 30)
+            exp.append(rec)
+    exp = np.concatenate(exp)
+    assert ev.tobytes() == exp.tobytes()

@@ -1,0 +1,90 @@
+"""CPU: host glue of the product (v2ce-toolbox_amd/glue.py, dist.py) against the goldens captured
+from the reference v2ce.py and against the oracle restatement, with a stand-in model."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import glue as OG
+from v2ce_toolbox_amd import dist as vdist
+from v2ce_toolbox_amd import glue
+
+
+@pytest.fixture(scope="module")
+def g7(gold_dir):
+    return np.load(os.path.join(gold_dir, "glue_g7.npz"))
+
+
+class FakeModel:
+    """Deterministic stand-in with the call-index dependence of the real model (spectral norm)."""
+
+    def __init__(self):
+        self.calls = 0
+
+    def advance_spectral_norm(self):
+        self.calls += 1
+
+    def __call__(self, x):                        # [B,L,2,H,W] -> [B,L,20,H,W]
+        B, L, _, H, W = x.shape
+        base = x.mean(dim=2, keepdim=True) + 0.01 * self.calls
+        ch = torch.arange(20, dtype=torch.float32).view(1, 1, 20, 1, 1)
+        self.calls += 1
+        return (base * (1 + ch)).contiguous()
+
+
+def test_preprocess_and_plan(g7):
+    assert glue.image_pre_processing(g7["frames"][:5], height=8).tobytes() == g7["pre5"].tobytes()
+    for n in (17, 18, 33, 100, 2048):
+        num, mode, starts = glue.sequence_plan(n)
+        assert [num, mode] + list(starts) == g7[f"plan_{n}"].tolist()
+    for fps in (25, 30):
+        assert [glue.frame_offset_us(i, fps) for i in range(4096)] == g7[f"offsets_fps{fps}"].tolist()
+    with pytest.raises(ValueError):
+        glue.sequence_plan(16)
+
+
+@pytest.mark.parametrize("infer_type", ["center", "pano"])
+def test_video_to_voxels_matches_oracle_composition(g7, infer_type):
+    H, WF, width, N, bs = g7["params"].tolist()
+    frames = g7["frames"]
+    got = glue.video_to_voxels(FakeModel(), frames=frames, infer_type=infer_type, seq_len=16,
+                               width=width, height=H, batch_size=bs, device="cpu").numpy()
+    # independent composition from the oracle's index arithmetic
+    num, mode, starts = OG.sequence_plan(N)
+    m = FakeModel()
+    seq_out = {}
+    for b0 in range(0, num, bs):
+        units = np.stack([OG.preprocess(frames[starts[s]:starts[s] + 17]) for s in range(b0, min(b0 + bs, num))])
+        x = torch.from_numpy(units)
+        if infer_type == "center":
+            lo, hi = OG.center_crop_cols(WF, width)
+            out = m(x[..., lo:hi]).numpy()
+        else:
+            parts = []
+            for lo, hi, keep in OG.pano_tiles(WF, width):
+                o = m(x[..., lo:hi]).numpy()
+                parts.append(o[..., -keep:] if keep else o)
+            out = np.concatenate(parts, axis=-1)
+        for j, s in enumerate(range(b0, min(b0 + bs, num))):
+            seq_out[s] = out[j]
+    want = np.stack([seq_out[s][j] for s, j in OG.merged_pair_sources(N)]).reshape(N - 1, 2, 10, H, -1)
+    assert got.shape == want.shape == g7[infer_type].shape
+    assert np.array_equal(got, want)
+
+
+def test_resize_identity_and_shape():
+    img = np.random.RandomState(0).rand(20, 30).astype(np.float32)
+    assert glue._resize_bilinear(img, 30, 20) is img
+    out = glue._resize_bilinear(img, 15, 10)
+    assert out.shape == (10, 15) and abs(out.mean() - img.mean()) < 0.05
+
+
+def test_shard_range():
+    for n in (1, 7, 8, 128):
+        for world in (1, 2, 3, 8):
+            got = [vdist.shard_range(n, r, world) for r in range(world)]
+            assert got[0][0] == 0 and got[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(got, got[1:]))
+            sizes = [hi - lo for lo, hi in got]
+            assert max(sizes) - min(sizes) <= 1

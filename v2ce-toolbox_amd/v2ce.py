@@ -1,0 +1,230 @@
+"""Command line + driver of the hot path: drop-in for ``/root/reference/v2ce.py``.
+
+Flags, defaults, output file name (``{name}-ceil_{ceil}-fps_{fps}[-suffix]-events.npz``), npz key
+(``event_stream``) and record dtype are the reference's (v2ce.py:282-302,317,371-372).  Added flags:
+``--npy_frames`` / ``--synthetic`` (frame sources that need no OpenCV), ``--device``, ``--seed``,
+``--rng``.  Unlike the reference the voxel grid never leaves the device between the model and
+LDATI, the whole clip goes through LDATI in chunks on the device, and the per-frame timestamp
+offset (v2ce.py:365) is fused into the emit kernel.
+
+Under ``torchrun`` (WORLD_SIZE > 1) sequences are sharded over ranks in contiguous blocks and the
+packed events are gathered to rank 0 over RCCL (``dist.py``); rank 0 writes the file.
+"""
+from __future__ import annotations
+
+import argparse
+import logging
+import os
+import os.path as op
+from pathlib import Path
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import dist as vdist
+from . import glue
+from .LDATI import EVENT_DTYPE, ldati_device
+from .v2ce_3d import V2ce3d
+
+logger = logging.getLogger("V2CE")
+
+
+def SBool(v):
+    """v2ce.py:19-27."""
+    if isinstance(v, bool):
+        return v
+    if v.lower() in ("yes", "true", "t", "y", "1"):
+        return True
+    elif v.lower() in ("no", "false", "f", "n", "0"):
+        return False
+    raise argparse.ArgumentTypeError("Boolean value expected.")
+
+
+def get_trained_mode(model_path="./weights/v2ce_3d.pt", device="cuda"):
+    """v2ce.py:30-43."""
+    model = V2ce3d()
+    model.load_state_dict(torch.load(model_path, map_location="cpu"))
+    model = model.eval()
+    return model.to(device)
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument("--fps", type=int, default=30, help="FPS of the output video")
+    p.add_argument("--seq_len", type=int, default=16, help="Sequence length")
+    p.add_argument("--ceil", type=int, default=10, help="The ceiling of the ef value")
+    p.add_argument("-u", "--upper_bound_percentile", type=int, default=98)
+    p.add_argument("-f", "--image_folder", type=str, help="The folder containing the images to infer")
+    p.add_argument("-i", "--input_video_path", type=str, help="The path to the input video")
+    p.add_argument("-o", "--out_folder", type=str, default="./output")
+    p.add_argument("-t", "--infer_type", type=str, default="center", help="center or pano")
+    p.add_argument("-m", "--model_path", type=str, default="./weights/v2ce_3d.pt")
+    p.add_argument("--out_name_suffix", type=str, default="")
+    p.add_argument("--max_frame_num", type=int, default=1800)
+    p.add_argument("--width", type=int, default=346)
+    p.add_argument("--height", type=int, default=260)
+    p.add_argument("--write_event_frame_video", type=SBool, default=True, nargs="?", const=True)
+    p.add_argument("--vis_keep_polarity", type=SBool, default=True, nargs="?", const=True)
+    p.add_argument("-l", "--log_level", type=str, default="info")
+    p.add_argument("-b", "--batch_size", type=int, default=1, help="Batch size for inference")
+    p.add_argument("--stage2_batch_size", type=int, default=24)
+    # additions of this build
+    p.add_argument("--npy_frames", type=str, help="uint8 [N,H,W] grayscale frames in a .npy file")
+    p.add_argument("--synthetic", type=int, default=0, help="generate N synthetic frames instead of reading")
+    p.add_argument("--synthetic_weights", type=int, default=None,
+                   help="seed of synthetic weights (the pretrained file is a separate download)")
+    p.add_argument("--device", type=str, default="cuda")
+    p.add_argument("--seed", type=int, default=0, help="Philox seed of the LDATI draws")
+    p.add_argument("--rng", type=str, default="philox", choices=["philox", "torch"])
+    return p
+
+
+def read_image_folder(folder, max_frame_num):
+    """v2ce.py:325-326,172-174: sorted *.png, read as grayscale."""
+    from PIL import Image
+    paths = sorted(op.join(folder, f) for f in os.listdir(folder) if f.endswith(".png"))[:max_frame_num]
+    logger.info(f"Now processing {folder}, Found {len(paths)} images.")
+    return np.stack([np.asarray(Image.open(p).convert("L")) for p in paths], axis=0)
+
+
+def read_video(path, max_frame_num):
+    try:
+        import cv2
+    except ImportError as e:
+        raise RuntimeError("reading a video container needs OpenCV (scripts/video_reader.py of the "
+                           "reference); it is not installed here -- use -f, --npy_frames or "
+                           "--synthetic") from e
+    cap = cv2.VideoCapture(path)
+    frames = []
+    while len(frames) < max_frame_num:
+        ok, fr = cap.read()
+        if not ok:
+            break
+        frames.append(cv2.cvtColor(fr, cv2.COLOR_BGR2GRAY))
+    return np.stack(frames, axis=0)
+
+
+def events_from_voxels(pred_voxel: torch.Tensor, fps, stage2_batch_size=24, seed=0, rng="philox",
+                       first_pair=0):
+    """v2ce.py:351-367 on the device: LDATI in chunks of `stage2_batch_size` frame-pairs with the
+    per-frame offset int(i*1/fps*1e6) (global pair index) fused.  Returns packed uint8 records on
+    the device and the per-frame event counts."""
+    L = pred_voxel.shape[0]
+    packed, counts = [], []
+    for i in range(0, L, stage2_batch_size):
+        chunk = pred_voxel[i:i + stage2_batch_size]
+        add = torch.tensor([glue.frame_offset_us(first_pair + i + j, fps) for j in range(chunk.shape[0])],
+                           dtype=torch.int64, device=chunk.device)
+        ev = ldati_device(chunk, fps=fps, rng=rng, seed=seed, frame_base=first_pair + i, frame_ts_add=add)
+        packed.append(ev.packed())
+        counts.append(ev.frame_counts)
+    return torch.cat(packed), np.concatenate(counts)
+
+
+def run(frames: np.ndarray, model, infer_type="center", seq_len=16, width=346, height=260,
+        batch_size=1, fps=30, stage2_batch_size=24, seed=0, rng="philox", device="cuda") -> np.ndarray:
+    """frames [N,H,W] uint8 -> event_stream (numpy structured array, v2ce.py:368)."""
+    rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
+    world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+    if world == 1:
+        vox = glue.video_to_voxels(model, frames=frames, infer_type=infer_type, seq_len=seq_len,
+                                   width=width, height=height, batch_size=batch_size, device=device)
+        packed, _ = events_from_voxels(vox, fps, stage2_batch_size, seed, rng)
+        return np.ascontiguousarray(packed.cpu().numpy()).view(EVENT_DTYPE)
+    return _run_sharded(frames, model, infer_type, seq_len, width, height, batch_size, fps,
+                        stage2_batch_size, seed, rng, device, rank, world)
+
+
+def _run_sharded(frames, model, infer_type, seq_len, width, height, batch_size, fps, stage2_batch_size,
+                 seed, rng, device, rank, world) -> Optional[np.ndarray]:
+    """Sequences in contiguous blocks per rank.  The reference makes one model call per
+    batch of `batch_size` sequences (per tile in pano mode); each rank fast-forwards its
+    spectral-norm state to the global call index of its first batch."""
+    sequence_num, mode, starts = glue.sequence_plan(len(frames), seq_len)
+    n_batches = -(-sequence_num // batch_size)
+    lo_b, hi_b = vdist.shard_range(n_batches, rank, world)
+    calls_per_batch = 1
+    if infer_type == "pano":
+        fw = int(frames.shape[2] / frames.shape[1] * height)
+        calls_per_batch = int(np.ceil(fw / width))
+    vdist.fast_forward(model, lo_b * calls_per_batch)
+    packed = torch.empty(0, dtype=torch.uint8, device=device)
+    if hi_b > lo_b:
+        preds = []
+        for bi in range(lo_b, hi_b):
+            seqs = range(bi * batch_size, min((bi + 1) * batch_size, sequence_num))
+            units = [glue.image_pre_processing(frames[int(starts[s]):int(starts[s]) + seq_len + 1], height)
+                     for s in seqs]
+            batch = torch.from_numpy(np.stack(units)).to(device)
+            pred = (glue.infer_center_image_unit if infer_type == "center"
+                    else glue.infer_pano_image_unit)(model, batch, width)
+            preds.append(pred)
+        out_w = preds[0].shape[-1]
+        vox = torch.cat([p.reshape(-1, 2, 10, height, out_w) for p in preds])
+        first_seq = lo_b * batch_size
+        first_pair = first_seq * seq_len
+        owns_last = hi_b == n_batches
+        if owns_last and mode != 0:      # overlapped last sequence: keep its last `mode` pairs
+            keep = vox.shape[0] - seq_len
+            vox = torch.cat([vox[:keep], vox[keep + seq_len - mode:]])
+        packed, _ = events_from_voxels(vox, fps, stage2_batch_size, seed, rng, first_pair=first_pair)
+    out = vdist.gather_events(packed, dst=0)
+    if rank != 0:
+        return None
+    return np.ascontiguousarray(out.cpu().numpy()).view(EVENT_DTYPE)
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    logging.basicConfig(level=getattr(logging, args.log_level.upper()))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    device = args.device
+    if world > 1:
+        local = int(os.environ.get("LOCAL_RANK", 0))
+        device = f"cuda:{local}"
+        torch.cuda.set_device(local)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl")
+    sources = [args.image_folder, args.input_video_path, args.npy_frames, args.synthetic or None]
+    assert sum(s is not None for s in sources) == 1, "specify exactly one frame source"
+    if args.image_folder is not None:
+        assert os.path.exists(args.image_folder), f"{args.image_folder} does not exist"
+        name = Path(args.image_folder).name
+        frames = read_image_folder(args.image_folder, args.max_frame_num)
+    elif args.input_video_path is not None:
+        assert os.path.exists(args.input_video_path), f"{args.input_video_path} does not exist"
+        name = Path(args.input_video_path).stem
+        frames = read_video(args.input_video_path, args.max_frame_num)
+    elif args.npy_frames is not None:
+        name = Path(args.npy_frames).stem
+        frames = np.load(args.npy_frames)[:args.max_frame_num]
+    else:
+        from . import synth
+        name = f"synthetic{args.synthetic}"
+        frames = synth.synthetic_frames(args.synthetic, args.height, args.width)
+    output_name = f"{name}-ceil_{args.ceil}-fps_{args.fps}" if args.out_name_suffix == "" else \
+        f"{name}-ceil_{args.ceil}-fps_{args.fps}-{args.out_name_suffix}"
+    os.makedirs(args.out_folder, exist_ok=True)
+    if args.synthetic_weights is not None:
+        from . import synth
+        model = V2ce3d()
+        model.load_state_dict(synth.make_state_dict(args.synthetic_weights))
+        model = model.eval().to(device)
+    else:
+        model = get_trained_mode(args.model_path, device)
+    if args.write_event_frame_video:
+        logger.warning("event-frame mp4 (v2ce.py:241-280) needs OpenCV and is outside the hot path: skipped")
+    event_stream = run(frames, model, args.infer_type, args.seq_len, args.width, args.height,
+                       args.batch_size, args.fps, args.stage2_batch_size, args.seed, args.rng, device)
+    if event_stream is not None:
+        logger.info(f"Generated event stream shape: , {event_stream.shape}")
+        path = op.join(args.out_folder, f"{output_name}-events.npz")
+        np.savez(path, event_stream=event_stream)
+        print(path)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
