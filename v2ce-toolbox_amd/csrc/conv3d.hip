@@ -54,18 +54,24 @@ struct ConvCfg {
     static constexpr int MAX_PLANE = 256 * EPT;
 };
 
-// global element offsets (relative to the sequence base of the source tensor) of this thread's halo
-// elements; -1 = zero padding.  Element r of the halo plane <-> LDS offset r.
+#if defined(__HIP_DEVICE_COMPILE__)   // buffer-descriptor types exist only in the device pass
+constexpr unsigned kOOB = 0x80000000u;   // buffer voffset that is always out of range => load returns 0
+
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+
+// byte offsets (relative to the sequence base of the source tensor) of this thread's halo elements;
+// kOOB = zero padding (hardware range check of the buffer load supplies the zero).
+// Element r of the halo plane <-> LDS offset r inside the channel.
 template <int EPT>
-__device__ __forceinline__ void halo_offsets(const ConvParams &P, int pad, int tin0, int hin0,
-                                             int win0, bool src1, int (&goff)[EPT]) {
+__device__ __forceinline__ void halo_offsets(const ConvParams &P, int tin0, int hin0, int win0,
+                                             bool src1, unsigned (&goff)[EPT]) {
     const int Cs = src1 ? P.C1 : P.C0;
     const int Hs = src1 ? P.Hin : P.H0, Ws = src1 ? P.Win : P.W0;
     const bool mapped = !src1 && P.hmap != nullptr;
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
         const int r = threadIdx.x + 256 * i;
-        int off = -1;
+        unsigned off = kOOB;
         if (r < P.plane) {
             const int ht = r / (P.HH * P.HWd);
             const int rem = r - ht * (P.HH * P.HWd);
@@ -75,24 +81,96 @@ __device__ __forceinline__ void halo_offsets(const ConvParams &P, int pad, int t
             if (t >= 0 && t < P.T && h >= 0 && h < P.Hin && w >= 0 && w < P.Win) {
                 const int hs = mapped ? P.hmap[h] : h;
                 const int ws = mapped ? P.wmap[w] : w;
-                off = (t * Cs) * (Hs * Ws) + hs * Ws + ws;
+                off = 4u * (unsigned)((t * Cs) * (Hs * Ws) + hs * Ws + ws);
             }
         }
         goff[i] = off;
     }
-    (void)pad;
 }
+
+template <int EPT, int WPT>
+struct DmaState {
+    unsigned goff[EPT];
+    unsigned woff[WPT];
+    int cur_src;
+    __amdgpu_buffer_rsrc_t rs_in, rs_w;
+    int src_cstride4, src_cbase;
+};
+
+// issue the LDS-DMA of input-channel chunk ci0 into the buffer starting at `hb`
+template <int KS, int CK, int EPT, int WPT, int W_ROWS>
+__device__ __forceinline__ void issue_chunk(const ConvParams &P, DmaState<EPT, WPT> &D, int ci0,
+                                            float *hb, int chs, int b, int wave, int tin0, int hin0,
+                                            int win0) {
+    constexpr int K3 = KS * KS * KS;
+    const int want_src = ci0 < P.C0 ? 0 : 1;
+    if (want_src != D.cur_src) {   // uniform; at most twice per kernel
+        D.cur_src = want_src;
+        halo_offsets<EPT>(P, tin0, hin0, win0, want_src == 1, D.goff);
+        if (want_src == 0) {
+            const long long seq = (long long)P.T * P.C0 * (P.H0 * P.W0);
+            D.rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x0 + b * seq), 0,
+                                                        (int)(seq * 4), 0x00020000);
+            D.src_cstride4 = P.H0 * P.W0 * 4;
+            D.src_cbase = 0;
+        } else {
+            const long long seq = (long long)P.T * P.C1 * (P.Hin * P.Win);
+            D.rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x1 + b * seq), 0,
+                                                        (int)(seq * 4), 0x00020000);
+            D.src_cstride4 = P.Hin * P.Win * 4;
+            D.src_cbase = P.C0;
+        }
+    }
+    float *wb = hb + CK * chs;
+#pragma unroll
+    for (int ci = 0; ci < CK; ++ci) {
+        const int cg = ci0 + ci;
+        const bool cok = cg < P.Cin;
+        const int soff = (cg - D.src_cbase) * D.src_cstride4;
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const int r0 = wave * 64 + 256 * i;              // wave-uniform first element
+            if (r0 < P.plane) {
+                const unsigned vo = cok ? D.goff[i] : kOOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(D.rs_in, (lds_ptr_t)(hb + ci * chs + r0), 4, vo,
+                                                         cok ? soff : 0, 0, 0);
+            }
+        }
+    }
+    const int wsoff = ci0 * K3 * P.Cout * 4;
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) {
+        const int row = wave + 4 * j;
+        if (row < W_ROWS)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(D.rs_w, (lds_ptr_t)(wb + row * 256), 16, D.woff[j],
+                                                     wsoff, 0, 0);
+    }
+}
+
+#endif  // __HIP_DEVICE_COMPILE__
 
 extern __shared__ __attribute__((aligned(16))) unsigned char conv_smem[];
 
+// LDS-DMA double-buffered direct convolution (see the file header).
+//   per chunk of CK input channels:  halo  [CK][chs]            (chs = plane rounded up to 64)
+//                                    weights [K3][CK][CO_TILE]  (+ pad to a whole wave row)
+//   both staged by buffer_load ... lds (no VGPR round trip) into buffer (chunk & 1) while the
+//   MFMAs consume the other buffer; one workgroup barrier per chunk.
 template <int KS, int S, int CO_FR, int PO_FR, int CK, int EPT>
-__global__ __launch_bounds__(256, 2) void conv3d_kernel(ConvParams P) {
+__global__ __launch_bounds__(256, 1) void conv3d_kernel(ConvParams P) {
+#if defined(__HIP_DEVICE_COMPILE__)
     using Cfg = ConvCfg<KS, S, CO_FR, PO_FR, CK, EPT>;
     constexpr int K3 = Cfg::K3, CO_TILE = Cfg::CO_TILE;
     constexpr int PAD = KS / 2;
+    constexpr int V4 = CO_TILE / 4;                       // 16-byte units per weight row
+    constexpr int W_UNITS = K3 * CK * V4;                 // 16-byte units per weight slab
+    constexpr int W_ROWS = (W_UNITS + 63) / 64;           // wave instructions per slab
+    constexpr int WPT = (W_ROWS + 3) / 4;                 // per wave
+    constexpr int W_FLOATS = W_ROWS * 64 * 4;
 
-    float *hl = reinterpret_cast<float *>(conv_smem);        // [CK][plane]
-    float *wl = hl + CK * P.plane;                           // [K3][CK][CO_TILE]
+    const int chs = (P.plane + 63) & ~63;
+    const int buf_floats = CK * chs + W_FLOATS;
+    float *smem = reinterpret_cast<float *>(conv_smem);
 
     const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -128,6 +206,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_kernel(ConvParams P) {
         }
     }
 
+    // per-lane weight-slab source offsets (bytes, relative to chunk base ci0*K3*Cout*4)
+    unsigned woff[WPT];
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) {
+        const int u = (wave + 4 * j) * 64 + lane;         // 16-byte unit inside the LDS slab
+        const int row = u / V4, v = u - row * V4;         // row = tap*CK + ci
+        const int tap = row / CK, ci = row - tap * CK;
+        const int co = co0 + 4 * v;
+        woff[j] = (u < W_UNITS && co < P.Cout) ? 4u * (unsigned)((ci * K3 + tap) * P.Cout + co) : kOOB;
+    }
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(P.wp), 0, P.Cin * K3 * P.Cout * 4, 0x00020000);
+
     f32x16 acc[CO_FR][PO_FR];
 #pragma unroll
     for (int q = 0; q < CO_FR; ++q)
@@ -136,61 +227,25 @@ __global__ __launch_bounds__(256, 2) void conv3d_kernel(ConvParams P) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[q][f][r] = 0.0f;
 
-    int goff[EPT];
-    int cur_src = -1;
-    const float *src_base = nullptr;
-    int src_cstride = 0, src_cbase = 0;
-
-    for (int ci0 = 0; ci0 < P.Cin; ci0 += CK) {
-        const int want_src = ci0 < P.C0 ? 0 : 1;
-        if (want_src != cur_src) {   // uniform; happens at most twice per kernel
-            cur_src = want_src;
-            halo_offsets<EPT>(P, PAD, tin0, hin0, win0, want_src == 1, goff);
-            if (want_src == 0) {
-                src_base = P.x0 + (long long)b * P.T * P.C0 * (P.H0 * P.W0);
-                src_cstride = P.H0 * P.W0;
-                src_cbase = 0;
-            } else {
-                src_base = P.x1 + (long long)b * P.T * P.C1 * (P.Hin * P.Win);
-                src_cstride = P.Hin * P.Win;
-                src_cbase = P.C0;
-            }
-        }
-        __syncthreads();   // previous chunk fully consumed
-        // ---- stage halo: CK channels x plane (one channel's loads in flight at a time: registers)
-#pragma unroll 1
-        for (int ci = 0; ci < CK; ++ci) {
-            const int cg = ci0 + ci;
-            const bool cok = cg < P.Cin;
-            const float *cb = src_base + (long long)(cg - src_cbase) * src_cstride;
+    DmaState<EPT, WPT> D;
+    D.cur_src = -1;
+    D.rs_in = rs_w;
+    D.rs_w = rs_w;
+    D.src_cstride4 = 0;
+    D.src_cbase = 0;
 #pragma unroll
-            for (int i = 0; i < EPT; ++i) {
-                const int r = tid + 256 * i;
-                if (r < P.plane) {
-                    const int o = goff[i];
-                    hl[ci * P.plane + r] = (cok && o >= 0) ? cb[o] : 0.0f;
-                }
-            }
-        }
-        // ---- stage weights: [K3][CK][CO_TILE] from wp[ci][tap][co]
-        {
-            constexpr int ROWS = K3 * CK;           // (ci, tap) rows of CO_TILE floats
-            constexpr int V4 = CO_TILE / 4;
-#pragma unroll 2
-            for (int e = tid; e < ROWS * V4; e += 256) {
-                const int row = e / V4, v = e - row * V4;
-                const int ci = row / K3, tap = row - ci * K3;
-                const int cg = ci0 + ci;
-                const int co = co0 + v * 4;
-                float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (cg < P.Cin && co < P.Cout)   // Cout % 4 == 0 is checked on the host
-                    val = *reinterpret_cast<const float4 *>(
-                        P.wp + ((long long)cg * K3 + tap) * P.Cout + co);
-                *reinterpret_cast<float4 *>(wl + (tap * CK + ci) * CO_TILE + v * 4) = val;
-            }
-        }
+    for (int j = 0; j < WPT; ++j) D.woff[j] = woff[j];
+#define ISSUE(ci0_, buf_) issue_chunk<KS, CK, EPT, WPT, W_ROWS>(P, D, (ci0_), smem + (buf_) * buf_floats, chs, b, wave, tin0, hin0, win0)
+
+    ISSUE(0, 0);
+    int buf = 0;
+    for (int ci0 = 0; ci0 < P.Cin; ci0 += CK, buf ^= 1) {
+        // chunk ci0 has landed for every wave, and every wave is done reading the other buffer
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        // ---- compute: K3 taps x CK/2 MFMA k-steps
+        if (ci0 + CK < P.Cin) ISSUE(ci0 + CK, buf ^ 1);
+        const float *hl = smem + buf * buf_floats;
+        const float *wl = hl + CK * chs;
         for (int dt = 0; dt < KS; ++dt) {
             for (int dh = 0; dh < KS; ++dh) {
 #pragma unroll
@@ -201,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_kernel(ConvParams P) {
                     for (int kk = 0; kk < CK / 2; ++kk) {
                         float a[CO_FR], bq[PO_FR];
                         const float *wrow = wl + (tap * CK + 2 * kk + half) * CO_TILE + l32;
-                        const float *hrow = hl + (2 * kk + half) * P.plane + toff;
+                        const float *hrow = hl + (2 * kk + half) * chs + toff;
 #pragma unroll
                         for (int q = 0; q < CO_FR; ++q) a[q] = wrow[q * 32];
 #pragma unroll
@@ -218,6 +273,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_kernel(ConvParams P) {
         }
     }
 
+#undef ISSUE
     // ---- epilogue: y = act(acc*scale + shift (+res))
     const long long ybase = (long long)b * P.T * P.Cout * (P.Hout * P.Wout);
     const int cstride = P.Hout * P.Wout;
@@ -242,6 +298,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_kernel(ConvParams P) {
             }
         }
     }
+#endif  // __HIP_DEVICE_COMPILE__ (the host pass only needs the launch stub)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -306,7 +363,11 @@ int launch(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream) {
     P.n_co_tiles = (d.Cout + Cfg::CO_TILE - 1) / Cfg::CO_TILE;
     const long long blocks = (long long)d.B * P.nT * P.nH * P.nW * P.n_co_tiles;
     V2CE_REQUIRE(blocks > 0 && blocks < (1ll << 31), V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd: grid too large");
-    const size_t lds = (size_t)(CK * P.plane + Cfg::K3 * CK * Cfg::CO_TILE) * sizeof(float);
+    // two buffers of { halo [CK][plane rounded to 64], weight slab rounded to whole wave rows }
+    const int chs = (P.plane + 63) & ~63;
+    const int w_units = Cfg::K3 * CK * (Cfg::CO_TILE / 4);
+    const int w_floats = ((w_units + 63) / 64) * 256;
+    const size_t lds = (size_t)2 * (CK * chs + w_floats) * sizeof(float);
     V2CE_REQUIRE(lds <= 160 * 1024, V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd: %zu B of LDS", lds);
     auto kern = conv3d_kernel<KS, S, CO_FR, PO_FR, CK, EPT>;
     V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -359,8 +420,8 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
     V2CE_REQUIRE(d.Cout % 4 == 0, V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd: Cout %% 4 != 0");
     const long long seq_in0 = (long long)d.T * d.C0 * d.H0 * d.W0, seq_in1 = (long long)d.T * d.C1 * d.Hin * d.Win;
     const long long seq_out = (long long)d.T * d.Cout * d.Hout * d.Wout;
-    V2CE_REQUIRE(seq_in0 < (1ll << 31) && seq_in1 < (1ll << 31) && seq_out < (1ll << 31),
-                 V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd: a single sequence exceeds 2^31 elements");
+    V2CE_REQUIRE(seq_in0 < (1ll << 29) && seq_in1 < (1ll << 29) && seq_out < (1ll << 31),
+                 V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd: a single sequence exceeds the 2 GiB buffer-descriptor range");
 
     ConvParams P{};
     P.x0 = x0; P.x1 = x1; P.hmap = hmap; P.wmap = wmap; P.wp = w_packed; P.scale = scale;
