@@ -31,6 +31,8 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+
+
 struct ConvParams {
     const float *x0, *x1;
     const int *hmap, *wmap;
@@ -97,12 +99,16 @@ struct DmaState {
     int src_cstride4, src_cbase;
 };
 
-// issue the LDS-DMA of input-channel chunk ci0 into the buffer starting at `hb`
+// issue the LDS-DMA of input-channel chunk ci0 into the buffer starting at `hb`.
+// part/nparts: the chunk's DMA instructions are dealt round-robin over `nparts` call sites so that
+// they issue in the shadow of the MFMAs of the (dt,dh) tap groups instead of in one burst in front
+// of them (an LDS-DMA costs ~60-180 issue cycles, MI355X_MICROARCH.md "LDS-DMA piece").
 template <int KS, int CK, int EPT, int WPT, int W_ROWS>
 __device__ __forceinline__ void issue_chunk(const ConvParams &P, DmaState<EPT, WPT> &D, int ci0,
                                             float *hb, int chs, int b, int wave, int tin0, int hin0,
-                                            int win0) {
+                                            int win0, int part, int nparts) {
     constexpr int K3 = KS * KS * KS;
+    if (part == 0) {
     const int want_src = ci0 < P.C0 ? 0 : 1;
     if (want_src != D.cur_src) {   // uniform; at most twice per kernel
         D.cur_src = want_src;
@@ -121,6 +127,7 @@ __device__ __forceinline__ void issue_chunk(const ConvParams &P, DmaState<EPT, W
             D.src_cbase = P.C0;
         }
     }
+    }
     float *wb = hb + CK * chs;
 #pragma unroll
     for (int ci = 0; ci < CK; ++ci) {
@@ -130,7 +137,7 @@ __device__ __forceinline__ void issue_chunk(const ConvParams &P, DmaState<EPT, W
 #pragma unroll
         for (int i = 0; i < EPT; ++i) {
             const int r0 = wave * 64 + 256 * i;              // wave-uniform first element
-            if (r0 < P.plane) {
+            if (r0 < P.plane && (ci * EPT + i) % nparts == part) {
                 const unsigned vo = cok ? D.goff[i] : kOOB;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(D.rs_in, (lds_ptr_t)(hb + ci * chs + r0), 4, vo,
                                                          cok ? soff : 0, 0, 0);
@@ -141,7 +148,7 @@ __device__ __forceinline__ void issue_chunk(const ConvParams &P, DmaState<EPT, W
 #pragma unroll
     for (int j = 0; j < WPT; ++j) {
         const int row = wave + 4 * j;
-        if (row < W_ROWS)
+        if (row < W_ROWS && (CK * EPT + j) % nparts == part)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(D.rs_w, (lds_ptr_t)(wb + row * 256), 16, D.woff[j],
                                                      wsoff, 0, 0);
     }
@@ -156,8 +163,11 @@ extern __shared__ __attribute__((aligned(16))) unsigned char conv_smem[];
 //                                    weights [K3][CK][CO_TILE]  (+ pad to a whole wave row)
 //   both staged by buffer_load ... lds (no VGPR round trip) into buffer (chunk & 1) while the
 //   MFMAs consume the other buffer; one workgroup barrier per chunk.
-template <int KS, int S, int CO_FR, int PO_FR, int CK, int EPT>
-__global__ __launch_bounds__(256, 1) void conv3d_kernel(ConvParams P) {
+// MW: workgroups the register budget must leave room for per CU (2 independent workgroups per CU
+// hide each other's barrier / DMA-issue bubbles); IL: deal the DMA issue over the (dt,dh) tap groups
+// (measured on MI355X: IL pays only together with MW = 2)
+template <int KS, int S, int CO_FR, int PO_FR, int CK, int EPT, int MW, int IL>
+__global__ __launch_bounds__(256, MW) void conv3d_kernel(ConvParams P) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using Cfg = ConvCfg<KS, S, CO_FR, PO_FR, CK, EPT>;
     constexpr int K3 = Cfg::K3, CO_TILE = Cfg::CO_TILE;
@@ -235,19 +245,22 @@ __global__ __launch_bounds__(256, 1) void conv3d_kernel(ConvParams P) {
     D.src_cbase = 0;
 #pragma unroll
     for (int j = 0; j < WPT; ++j) D.woff[j] = woff[j];
-#define ISSUE(ci0_, buf_) issue_chunk<KS, CK, EPT, WPT, W_ROWS>(P, D, (ci0_), smem + (buf_) * buf_floats, chs, b, wave, tin0, hin0, win0)
+#define ISSUE(ci0_, buf_, part_, nparts_) issue_chunk<KS, CK, EPT, WPT, W_ROWS>(P, D, (ci0_), smem + (buf_) * buf_floats, chs, b, wave, tin0, hin0, win0, (part_), (nparts_))
 
-    ISSUE(0, 0);
+    ISSUE(0, 0, 0, 1);
     int buf = 0;
     for (int ci0 = 0; ci0 < P.Cin; ci0 += CK, buf ^= 1) {
         // chunk ci0 has landed for every wave, and every wave is done reading the other buffer
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (ci0 + CK < P.Cin) ISSUE(ci0 + CK, buf ^ 1);
+        const bool more = ci0 + CK < P.Cin;
+        constexpr int NPARTS = IL ? KS * KS : 1;
+        if (NPARTS == 1 && more) ISSUE(ci0 + CK, buf ^ 1, 0, 1);
         const float *hl = smem + buf * buf_floats;
         const float *wl = hl + CK * chs;
         for (int dt = 0; dt < KS; ++dt) {
             for (int dh = 0; dh < KS; ++dh) {
+                if (NPARTS > 1 && more) ISSUE(ci0 + CK, buf ^ 1, dt * KS + dh, NPARTS);
 #pragma unroll
                 for (int dw = 0; dw < KS; ++dw) {
                     const int tap = (dt * KS + dh) * KS + dw;
@@ -334,11 +347,11 @@ Tile choose_tile(int T, int Ho, int Wo, int ks, int s, int pos_tile, int max_pla
 thread_local char *g_name_out = nullptr;   // non-null: report the variant instead of launching
 thread_local size_t g_name_cap = 0;
 
-template <int KS, int S, int CO_FR, int PO_FR, int CK, int EPT>
+template <int KS, int S, int CO_FR, int PO_FR, int CK, int EPT, int MW, int IL>
 int launch(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream) {
     using Cfg = ConvCfg<KS, S, CO_FR, PO_FR, CK, EPT>;
     if (g_name_out) {
-        snprintf(g_name_out, g_name_cap, "conv3d_kernel<%d,%d,%d,%d,%d,%d>", KS, S, CO_FR, PO_FR, CK, EPT);
+        snprintf(g_name_out, g_name_cap, "conv3d_kernel<%d,%d,%d,%d,%d,%d,%d,%d>", KS, S, CO_FR, PO_FR, CK, EPT, MW, IL);
         return V2CE_OK;
     }
     Tile t{d.tile_t, d.tile_h, d.tile_w};
@@ -369,7 +382,7 @@ int launch(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream) {
     const int w_floats = ((w_units + 63) / 64) * 256;
     const size_t lds = (size_t)2 * (CK * chs + w_floats) * sizeof(float);
     V2CE_REQUIRE(lds <= 160 * 1024, V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd: %zu B of LDS", lds);
-    auto kern = conv3d_kernel<KS, S, CO_FR, PO_FR, CK, EPT>;
+    auto kern = conv3d_kernel<KS, S, CO_FR, PO_FR, CK, EPT, MW, IL>;
     V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, P);
@@ -439,17 +452,27 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
     const bool small_pos = (pos_total / 512) * co_tiles < 512;
 #define V2CE_CK_OK(CK) V2CE_REQUIRE(d.C1 == 0 || d.C0 % (CK) == 0, V2CE_ERR_UNSUPPORTED, \
                                     "v2ce_conv3d_fwd: C0=%d not a multiple of the channel chunk %d", d.C0, (CK))
+    // <KS, S, CO_FR, PO_FR, CK, EPT, MW, IL>; the (CK, MW, IL) choices are A/B-measured
+    if (d.ksize == 3 && s == 1) {
+        if (small_pos) {   // 256-position boxes: 80 KiB of LDS, two workgroups per CU as is
+            V2CE_CK_OK(4);
+            if (small_co) return launch<3, 1, 1, 2, 4, 8, 1, 0>(P, d, st);
+            return launch<3, 1, 2, 2, 4, 8, 1, 0>(P, d, st);
+        }
+        V2CE_CK_OK(2);     // 512-position boxes: CK = 2 keeps two workgroups per CU (48 KiB each)
+        if (small_co) return launch<3, 1, 1, 4, 2, 8, 2, 1>(P, d, st);
+        return launch<3, 1, 2, 4, 2, 8, 2, 1>(P, d, st);
+    }
 #define V2CE_DISPATCH(KS, S, CK, EPT)                                                    \
     do {                                                                                 \
         V2CE_CK_OK(CK);                                                                  \
         if (small_co) {                                                                  \
-            if (small_pos) return launch<KS, S, 1, 2, CK, EPT>(P, d, st);                \
-            return launch<KS, S, 1, 4, CK, EPT>(P, d, st);                               \
+            if (small_pos) return launch<KS, S, 1, 2, CK, EPT, 1, 0>(P, d, st);          \
+            return launch<KS, S, 1, 4, CK, EPT, 1, 0>(P, d, st);                         \
         }                                                                                \
-        if (small_pos) return launch<KS, S, 2, 2, CK, EPT>(P, d, st);                    \
-        return launch<KS, S, 2, 4, CK, EPT>(P, d, st);                                   \
+        if (small_pos) return launch<KS, S, 2, 2, CK, EPT, 1, 0>(P, d, st);              \
+        return launch<KS, S, 2, 4, CK, EPT, 1, 0>(P, d, st);                             \
     } while (0)
-    if (d.ksize == 3 && s == 1) V2CE_DISPATCH(3, 1, 4, 8);
     if (d.ksize == 3 && s == 2) V2CE_DISPATCH(3, 2, 2, 14);
     if (d.ksize == 1 && s == 1) V2CE_DISPATCH(1, 1, 16, 2);
     V2CE_DISPATCH(1, 2, 8, 8);

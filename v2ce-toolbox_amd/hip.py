@@ -14,7 +14,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SO_PATH = os.path.join(CSRC, "libv2ce_hip.so")
+SO_PATH = os.environ.get("V2CE_HIP_LIB", os.path.join(CSRC, "libv2ce_hip.so"))   # override: kernel A/B builds
 
 RNG_REPLAY, RNG_PHILOX = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
