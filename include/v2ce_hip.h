@@ -68,11 +68,20 @@ size_t v2ce_ldati_lds_bytes(double fps, double t0);
  * [neg singles row-major, neg multis row-major then draw, pos singles, pos multis] -- what the
  * reference's CPU argsort yields for segments >= 32768 events.
  * uniforms/replay_max_n: REPLAY mode only.  frame_ts_add [B] i64 or NULL: added to every timestamp
- * of frame b (v2ce.py:365 per-frame offset, fused).  Outputs are SoA of length seg_offsets[B*9]. */
+ * of frame b (v2ce.py:365 per-frame offset, fused).  Outputs are SoA of length seg_offsets[B*9].
+ * total_events / max_segment_events: host copies of seg_offsets[B*9] and of the largest segment
+ * count (the caller has read them to allocate).  workspace (>= v2ce_ldati_workspace_bytes) selects
+ * the bucketed path (pixel-parallel recompute -> coarse buckets -> LDS sort -> coalesced output);
+ * workspace NULL runs the one-workgroup-per-segment sweep for every segment (no scratch, slower).
+ * Both produce bit-identical output. */
+size_t v2ce_ldati_workspace_bytes(int B, int H, int W, double fps, double t0, int64_t total_events,
+                                  int64_t max_segment_events);
 int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps, double t0, int rng_mode,
                     const float *uniforms, int replay_max_n, uint64_t seed, int64_t frame_base,
                     const int64_t *seg_offsets, const int64_t *frame_ts_add, int64_t *ts,
-                    int16_t *x, int16_t *y, int8_t *p, v2ce_stream_t stream);
+                    int16_t *x, int16_t *y, int8_t *p, int64_t total_events,
+                    int64_t max_segment_events, void *workspace, size_t workspace_bytes,
+                    v2ce_stream_t stream);
 
 /* SoA -> packed 13-byte records {i8 timestamp, i2 x, i2 y, i1 polarity}: the numpy recarray layout
  * of LDATI.py:308-309 (numpy.core.records.fromarrays, itemsize 13).  packed: n*13 bytes. */

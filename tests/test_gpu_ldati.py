@@ -13,12 +13,13 @@ from v2ce_toolbox_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def hip_events(vox, fps=30, t0=0, uniforms=None, seed=None, frame_base=0, frame_ts_add=None):
+def hip_events(vox, fps=30, t0=0, uniforms=None, seed=None, frame_base=0, frame_ts_add=None, path="bucket"):
     from v2ce_toolbox_amd.LDATI import ldati_device
     y = torch.from_numpy(np.ascontiguousarray(vox)).cuda()
     u = None if uniforms is None else torch.from_numpy(np.ascontiguousarray(uniforms)).cuda()
     add = None if frame_ts_add is None else torch.from_numpy(frame_ts_add).cuda()
-    ev = ldati_device(y, t0=t0, fps=fps, uniforms=u, seed=seed, frame_base=frame_base, frame_ts_add=add)
+    ev = ldati_device(y, t0=t0, fps=fps, uniforms=u, seed=seed, frame_base=frame_base, frame_ts_add=add,
+                      path=path)
     torch.cuda.synchronize()
     return ev
 
@@ -31,12 +32,13 @@ def soa_equal(ev, seg, ts, x, y, p):
     assert np.array_equal(ev.p.cpu().numpy(), p)
 
 
+@pytest.mark.parametrize("path", ["bucket", "sweep"])
 @pytest.mark.parametrize("name", ["sparse", "frac", "stress", "t0fps60", "ragged"])
-def test_replay_matches_reference_golden_and_oracle(gold_dir, name):
+def test_replay_matches_reference_golden_and_oracle(gold_dir, name, path):
     z = np.load(os.path.join(gold_dir, f"ldati_g3_{name}.npz"))
     vox, u, fps, t0 = z["vox"], z["uniforms"], float(z["fps"]), float(z["t0"])
     ref = np.frombuffer(z["events"].tobytes(), O.EVENT_DTYPE)
-    ev = hip_events(vox, fps, t0, uniforms=u)
+    ev = hip_events(vox, fps, t0, uniforms=u, path=path)
     # bit-exact vs the oracle, including the stable tie order
     soa_equal(ev, *O.emit_soa(vox, fps=fps, t0=t0, uniforms=u))
     # vs the reference's own output: exact up to the tie order its unstable argsort leaves open
@@ -57,7 +59,8 @@ def test_hand_kat(gold_dir):
     assert res[0].dtype.itemsize == 13 and res[0].dtype.names == ("timestamp", "x", "y", "polarity")
 
 
-def test_full_size_golden_sha(gold_dir):
+@pytest.mark.parametrize("path", ["bucket", "sweep"])
+def test_full_size_golden_sha(gold_dir, path):
     """G4: 346x260 dense frame; every segment >= 32768 events so the reference order is the stable
     order: packed bytes must be bit-identical to the reference's."""
     meta = json.load(open(os.path.join(gold_dir, "ldati_g4.json")))
@@ -68,7 +71,7 @@ def test_full_size_golden_sha(gold_dir):
     n = 2 * 9 * H * W * meta["max_n"]
     u = ((mt.random_raw(n).astype(np.uint32) & 0xFFFFFF).astype(np.float32) * np.float32(2.0 ** -24))
     u = u.reshape(1, 2, 9, H, W, meta["max_n"])
-    ev = hip_events(vox, meta["fps"], meta["t0"], uniforms=u)
+    ev = hip_events(vox, meta["fps"], meta["t0"], uniforms=u, path=path)
     assert ev.max_n == meta["max_n"]
     assert ev.seg_counts.reshape(-1).tolist() == meta["seg_counts"]
     rec = ev.to_recarrays()[0]
@@ -83,8 +86,22 @@ def test_full_size_golden_sha(gold_dir):
 def test_philox_matches_oracle(shape, regime, fps, t0, fb):
     B, H, W = shape
     vox = synth.synthetic_voxels(B, H, W, seed=B * 1000 + H, regime=regime)
-    ev = hip_events(vox, fps, t0, seed=0xDEADBEEF12345, frame_base=fb)
-    soa_equal(ev, *O.emit_soa(vox, fps=fps, t0=t0, seed=0xDEADBEEF12345, frame_base=fb))
+    want = O.emit_soa(vox, fps=fps, t0=t0, seed=0xDEADBEEF12345, frame_base=fb)
+    for path in ("bucket", "sweep"):
+        ev = hip_events(vox, fps, t0, seed=0xDEADBEEF12345, frame_base=fb, path=path)
+        soa_equal(ev, *want)
+
+
+def test_degenerate_ties_take_the_sweep_fallback():
+    """Constant voxels: every pixel emits identical timestamps, so one (segment, key) bucket holds
+    far more records than the LDS sort capacity; the flagged segments go through the sweep kernel
+    and the output is still the stable order."""
+    vox = np.full((2, 2, 10, 120, 130), 0.5, np.float32)      # singles at identical times
+    vox[1, :, 3] = 2.0                                        # plus multi-event voxels in one bin
+    want = O.emit_soa(vox, fps=30, seed=9)
+    assert want[0].max() > 8192
+    for path in ("bucket", "sweep"):
+        soa_equal(hip_events(vox, seed=9, path=path), *want)
 
 
 def test_philox_batching_invariance():

@@ -78,7 +78,8 @@ def _check_fps(fps) -> None:
 
 def ldati_device(y: torch.Tensor, t0=0, fps=30, *, rng: str = "philox", seed: Optional[int] = None,
                  frame_base: int = 0, uniforms: Optional[torch.Tensor] = None,
-                 frame_ts_add: Optional[torch.Tensor] = None, profile: Optional[list] = None) -> DeviceEvents:
+                 frame_ts_add: Optional[torch.Tensor] = None, profile: Optional[list] = None,
+                 path: str = "bucket") -> DeviceEvents:
     """Run count -> scan -> emit on the device and leave the events there.
 
     y: [B,2,10,H,W] on a HIP device.  One host synchronisation (reading the B*9+1 segment offsets
@@ -134,19 +135,28 @@ def ldati_device(y: torch.Tensor, t0=0, fps=30, *, rng: str = "philox", seed: Op
             frame_ts_add = frame_ts_add.to(device=dev, dtype=torch.int64).contiguous()
             assert frame_ts_add.numel() == B
             add_ptr = frame_ts_add.data_ptr()
-        if profile is not None:    # HIP events on the launch stream around the emit kernel
+        max_seg = int(segc.max())
+        ws, ws_bytes = None, 0
+        if path == "bucket":       # pixel-parallel bucketed path; "sweep" = one workgroup per segment
+            ws_bytes = L.v2ce_ldati_workspace_bytes(B, H, W, float(fps), float(t0), total, max_seg)
+            if ws_bytes:
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        elif path != "sweep":
+            raise ValueError(f"path must be 'bucket' or 'sweep', got {path!r}")
+        if profile is not None:    # HIP events on the launch stream around the emit kernels
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         hip.check(L.v2ce_ldati_emit(y.data_ptr(), B, H, W, float(fps), float(t0), mode, u_ptr,
                                     int(replay_max_n), int(seed or 0) & (2 ** 64 - 1), int(frame_base),
                                     offsets.data_ptr(), add_ptr, ts.data_ptr(), x.data_ptr(),
-                                    yy.data_ptr(), p.data_ptr(), st), "v2ce_ldati_emit")
+                                    yy.data_ptr(), p.data_ptr(), total, max_seg, hip.ptr(ws),
+                                    int(ws_bytes), st), "v2ce_ldati_emit")
         if profile is not None:
             e1.record()
             # algorithmic bytes: 80 B per pixel read once + 13 B per event written once
             profile.append(("emit", e0, e1, 80 * B * H * W + 13 * total))
     ev = DeviceEvents(ts, x, yy, p, segc, max_n)
-    ev._keepalive = (y, keep, frame_ts_add, offsets)
+    ev._keepalive = (y, keep, frame_ts_add, offsets, ws if total else None)
     return ev
 
 

@@ -50,7 +50,16 @@ struct LdatiParams {
     short *x;
     short *y;
     signed char *p;
+    // bucketed path (v2): coarse bucket = key >> key_shift; NB buckets per segment
+    int key_shift, NB, PB;        // PB = bits of a pixel index
+    unsigned *cbcount;            // [B*9][NB] events per bucket
+    unsigned *cursor;             // [B*9][NB] append cursors
+    unsigned *bofs;               // [B*9][NB] exclusive offsets inside the segment
+    unsigned *temp;               // [total events] unsorted 32-bit records (fine key | category | pixel)
+    int *seg_flag;                // [B*9] 1 = a bucket exceeds the LDS sort capacity -> segment sweep path
 };
+
+constexpr int kSortCap = 8192;    // 32-bit records one workgroup sorts in LDS
 
 // ---- Philox4x32-10, counter (pixel, j>>2, p*9+c, frame), key = seed ---------------------------
 __device__ __forceinline__ float philox_uniform(unsigned long long seed, unsigned pixel, unsigned j,
@@ -380,6 +389,7 @@ __global__ __launch_bounds__(256) void ldati_emit_kernel(LdatiParams P) {
     const long long seg_lo = P.seg_offsets[seg];
     const long long seg_n = P.seg_offsets[seg + 1] - seg_lo;
     if (seg_n <= 0) return;              // uniform per workgroup
+    if (P.seg_flag && !P.seg_flag[seg]) return;   // bucketed path handled this segment
     const long long ts_add = P.frame_ts_add ? P.frame_ts_add[b] : 0;
 
     unsigned *cnt = reinterpret_cast<unsigned *>(ldati_smem);            // [4][NK]
@@ -439,6 +449,157 @@ __global__ __launch_bounds__(256) void ldati_emit_kernel(LdatiParams P) {
         sweep_multis<true>(b, c, pidx, cat, pol, lane, seg_lo, ts_add, cnt, my_start, my_k, my_bb, P);
     else
         sweep_singles<true>(b, c, pidx, cat, pol, lane, seg_lo, ts_add, cnt, P);
+}
+
+// ---------------------------------------------------------------------------------------------
+// bucketed path (v2): pixel-parallel recompute -> coarse buckets -> LDS sort -> coalesced output
+//
+//   pass<false> : thread per (frame, polarity, pixel); ONE relocation recurrence over the 9 bins;
+//                 every event's timestamp; histogram of coarse buckets (key >> key_shift) per segment
+//   scan        : exclusive offsets of the buckets inside each segment; segments whose largest
+//                 bucket exceeds kSortCap are flagged for the segment-sweep kernel above
+//   pass<true>  : same recompute; append a 32-bit record (fine key | category | pixel) to its bucket
+//   sort        : one workgroup per bucket: bitonic sort of the records in LDS, then the final SoA
+//                 events are written as coalesced runs.  The record order (key, category, pixel) IS the
+//                 reference's stable order: events that tie on all three are identical records.
+// ---------------------------------------------------------------------------------------------
+template <bool APPEND>
+__device__ __forceinline__ void bucket_event(const LdatiParams &P, int seg, int c, long long T,
+                                             unsigned cat, unsigned px) {
+    const int key = key_of(T, P.kbase[c], P.NK);
+    const unsigned slot_idx = (unsigned)seg * P.NB + (unsigned)(key >> P.key_shift);
+    if (!APPEND) {
+        atomicAdd(&P.cbcount[slot_idx], 1u);
+    } else {
+        const unsigned slot = atomicAdd(&P.cursor[slot_idx], 1u);
+        const long long pos = P.seg_offsets[seg] + P.bofs[slot_idx] + slot;
+        const unsigned fine = (unsigned)key & ((1u << P.key_shift) - 1u);
+        P.temp[pos] = (fine << (2 + P.PB)) | (cat << P.PB) | px;
+    }
+}
+
+template <bool APPEND>
+__global__ __launch_bounds__(256) void ldati_bucket_pass_kernel(LdatiParams P) {
+    const int bp = blockIdx.y, b = bp >> 1, pidx = bp & 1;
+    const int px = blockIdx.x * 256 + threadIdx.x;
+    if (px >= P.HW) return;
+    const float *plane0 = P.vox + (long long)bp * 10 * P.HW;
+    float yv[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) yv[i] = plane0[(long long)i * P.HW + px];
+    int n[9];
+    float dbt[9];
+    {
+        const float eps = 1e-6f;
+        float d = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const float r = yv[i] - d;
+            const float cc = ceilf(r - eps);
+            d = cc - r;
+            int ni = (int)cc;
+            if (i == 8) ni += (int)(yv[9] - d);
+            n[i] = ni;
+            dbt[i] = d;
+        }
+    }
+    const unsigned frame = (unsigned)(P.frame_base + b);
+    const unsigned cat_single = pidx ? 0u : 2u;    // negative events live in P index 1
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+        const int nc = n[c];
+        if (nc < 1) continue;
+        const int seg = b * 9 + c;
+        if (nc == 1) {
+            bucket_event<APPEND>(P, seg, c, single_ts(dbt[c], P.fps, P.offt[c]), cat_single, (unsigned)px);
+        } else {
+            float k, bb;
+            slope_params(c > 0 ? n[c - 1] : 0, nc, c < 8 ? n[c + 1] : 0, c, P, k, bb);
+            const long long ubase = (((long long)bp * 9 + c) * P.HW + px) * P.replay_max_n;
+            for (int j = 0; j < nc; ++j) {
+                float u = 0.0f;
+                if (P.rng_mode == V2CE_RNG_REPLAY) {
+                    if (j < P.replay_max_n) u = P.uniforms[ubase + j];
+                } else {
+                    u = philox_uniform(P.seed, (unsigned)px, (unsigned)j, (unsigned)(pidx * 9 + c), frame);
+                }
+                bucket_event<APPEND>(P, seg, c, multi_ts(k, bb, u, P.offt[c], P), cat_single + 1u,
+                                     (unsigned)px);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ldati_bucket_scan_kernel(LdatiParams P) {
+    __shared__ unsigned part[256];
+    __shared__ unsigned big;
+    const int seg = blockIdx.x, t = threadIdx.x;
+    const unsigned *cnt = P.cbcount + (long long)seg * P.NB;
+    unsigned *ofs = P.bofs + (long long)seg * P.NB;
+    const int per = (P.NB + 255) / 256;
+    const int lo = t * per, hi = (lo + per < P.NB) ? lo + per : P.NB;
+    if (t == 0) big = 0;
+    __syncthreads();
+    unsigned s = 0, mx = 0;
+    for (int i = lo; i < hi; ++i) {
+        const unsigned v = cnt[i];
+        s += v;
+        mx = v > mx ? v : mx;
+    }
+    part[t] = s;
+    if (mx > (unsigned)kSortCap) atomicOr(&big, 1u);
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const unsigned v = t >= o ? part[t - o] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    unsigned run = part[t] - s;
+    for (int i = lo; i < hi; ++i) {
+        ofs[i] = run;
+        run += cnt[i];
+    }
+    if (t == 0) P.seg_flag[seg] = (int)big;
+}
+
+__global__ __launch_bounds__(256) void ldati_bucket_sort_kernel(LdatiParams P) {
+    __shared__ unsigned keys[kSortCap];
+    const unsigned bucket = blockIdx.x;
+    const int seg = bucket / P.NB, cb = bucket - seg * P.NB;
+    const unsigned n = P.cbcount[bucket];
+    if (n == 0 || P.seg_flag[seg]) return;          // uniform per workgroup
+    const long long base = P.seg_offsets[seg] + P.bofs[bucket];
+    unsigned np = 2;
+    while (np < n) np <<= 1;
+    const int tid = threadIdx.x;
+    for (unsigned i = tid; i < np; i += 256) keys[i] = i < n ? P.temp[base + i] : 0xFFFFFFFFu;
+    __syncthreads();
+    for (unsigned k = 2; k <= np; k <<= 1) {
+        for (unsigned j = k >> 1; j > 0; j >>= 1) {
+            for (unsigned t = tid; t < (np >> 1); t += 256) {
+                const unsigned i = 2 * t - (t & (j - 1));
+                const unsigned l = i + j;
+                const unsigned a = keys[i], bq = keys[l];
+                const bool up = (i & k) == 0;
+                if ((a > bq) == up) { keys[i] = bq; keys[l] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    const int b = seg / 9, c = seg - b * 9;
+    const long long tbase = P.kbase[c] + ((long long)cb << P.key_shift) +
+                            (P.frame_ts_add ? P.frame_ts_add[b] : 0);
+    const unsigned pmask = (1u << P.PB) - 1u;
+    for (unsigned i = tid; i < n; i += 256) {
+        const unsigned r = keys[i];
+        const unsigned px = r & pmask, cat = (r >> P.PB) & 3u, fine = r >> (P.PB + 2);
+        const unsigned yy = px / (unsigned)P.W;
+        P.ts[base + i] = tbase + fine;
+        P.x[base + i] = (short)(px - yy * P.W);
+        P.y[base + i] = (short)yy;
+        P.p[base + i] = (signed char)(cat >> 1);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -550,11 +711,43 @@ extern "C" size_t v2ce_ldati_lds_bytes(double fps, double t0) {
     return h.ok ? h.lds_bytes : 0;
 }
 
+namespace {
+struct BucketPlan { int shift, NB, PB; size_t counters, bytes; };
+
+// coarse-bucket width: average bucket of the LARGEST segment ~ kSortCap/4 records
+BucketPlan bucket_plan(const HostScalars &h, int B, int H, int W, int64_t total_events,
+                       int64_t max_segment_events) {
+    BucketPlan bp{};
+    int shift = 0;
+    while (shift < 13 && (double)max_segment_events * (double)(2 << shift) / (double)h.NK <= kSortCap / 4) ++shift;
+    int pb = 1;
+    while ((1ll << pb) < (long long)H * W) ++pb;
+    if (shift + 2 + pb > 32) shift = 32 - 2 - pb;     // the record must fit 32 bits
+    if (shift < 0) shift = -1;                        // too many pixels for the 32-bit record
+    bp.shift = shift;
+    bp.PB = pb;
+    bp.NB = shift >= 0 ? (h.NK + (1 << shift) - 1) >> shift : 0;
+    bp.counters = (size_t)B * 9 * (size_t)bp.NB;
+    bp.bytes = (3 * bp.counters + (size_t)B * 9 + (size_t)(total_events > 0 ? total_events : 0)) * 4;
+    return bp;
+}
+}  // namespace
+
+extern "C" size_t v2ce_ldati_workspace_bytes(int B, int H, int W, double fps, double t0,
+                                             int64_t total_events, int64_t max_segment_events) {
+    if (!(fps > 0) || B <= 0 || H <= 0 || W <= 0) return 0;
+    const HostScalars h = host_scalars(fps, t0);
+    if (!h.ok) return 0;
+    const BucketPlan bp = bucket_plan(h, B, H, W, total_events, max_segment_events);
+    return bp.shift >= 0 ? bp.bytes : 0;
+}
+
 extern "C" int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps, double t0,
                                int rng_mode, const float *uniforms, int replay_max_n,
                                uint64_t seed, int64_t frame_base, const int64_t *seg_offsets,
                                const int64_t *frame_ts_add, int64_t *ts, int16_t *x, int16_t *y,
-                               int8_t *p, v2ce_stream_t stream) {
+                               int8_t *p, int64_t total_events, int64_t max_segment_events,
+                               void *workspace, size_t workspace_bytes, v2ce_stream_t stream) {
     clear_error();
     V2CE_REQUIRE(vox && seg_offsets, V2CE_ERR_BAD_ARG, "v2ce_ldati_emit: null pointer");
     V2CE_REQUIRE(B > 0 && H > 0 && W > 0 && (long long)H * W < (1ll << 30), V2CE_ERR_BAD_ARG,
@@ -580,10 +773,37 @@ extern "C" int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps
     P.frame_ts_add = reinterpret_cast<const long long *>(frame_ts_add);
     P.ts = reinterpret_cast<long long *>(ts); P.x = x; P.y = y;
     P.p = reinterpret_cast<signed char *>(p);
+    hipStream_t st = as_stream(stream);
     V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ldati_emit_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)h.lds_bytes));
-    hipLaunchKernelGGL(ldati_emit_kernel, dim3(B * 9), dim3(256), h.lds_bytes, as_stream(stream), P);
+    if (workspace != nullptr) {
+        // ---- bucketed path; segments with an oversized bucket fall through to the sweep kernel
+        V2CE_REQUIRE(total_events >= 0 && max_segment_events >= 0 && total_events < (1ll << 32),
+                     V2CE_ERR_BAD_ARG, "v2ce_ldati_emit: bad event counts");
+        const BucketPlan bp = bucket_plan(h, B, H, W, total_events, max_segment_events);
+        V2CE_REQUIRE(bp.shift >= 0, V2CE_ERR_UNSUPPORTED,
+                     "v2ce_ldati_emit: %d x %d pixels do not fit the 32-bit bucket record; pass workspace = NULL", H, W);
+        V2CE_REQUIRE(workspace_bytes >= bp.bytes, V2CE_ERR_WORKSPACE,
+                     "v2ce_ldati_emit: workspace %zu < %zu", workspace_bytes, bp.bytes);
+        V2CE_REQUIRE(bp.counters < (1ull << 31) && 2 * B <= 65535, V2CE_ERR_UNSUPPORTED,
+                     "v2ce_ldati_emit: too many buckets for one launch");
+        unsigned *w = static_cast<unsigned *>(workspace);
+        P.key_shift = bp.shift; P.NB = bp.NB; P.PB = bp.PB;
+        P.cbcount = w;
+        P.cursor = w + bp.counters;
+        P.bofs = w + 2 * bp.counters;
+        P.seg_flag = reinterpret_cast<int *>(w + 3 * bp.counters);
+        P.temp = w + 3 * bp.counters + (size_t)B * 9;
+        V2CE_HIP_CHECK(hipMemsetAsync(w, 0, 2 * bp.counters * 4, st));     // cbcount + cursor
+        dim3 grid((P.HW + 255) / 256, 2 * B);
+        hipLaunchKernelGGL(ldati_bucket_pass_kernel<false>, grid, dim3(256), 0, st, P);
+        hipLaunchKernelGGL(ldati_bucket_scan_kernel, dim3(B * 9), dim3(256), 0, st, P);
+        hipLaunchKernelGGL(ldati_bucket_pass_kernel<true>, grid, dim3(256), 0, st, P);
+        hipLaunchKernelGGL(ldati_bucket_sort_kernel, dim3((unsigned)bp.counters), dim3(256), 0, st, P);
+    }
+    // segment-sweep kernel: every segment when there is no workspace, else only the flagged ones
+    hipLaunchKernelGGL(ldati_emit_kernel, dim3(B * 9), dim3(256), h.lds_bytes, st, P);
     V2CE_HIP_CHECK(hipGetLastError());
     return V2CE_OK;
 }

@@ -21,7 +21,7 @@ ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 
 EXPORTS = [
     "v2ce_version", "v2ce_last_error", "v2ce_ldati_count", "v2ce_ldati_scan",
-    "v2ce_ldati_lds_bytes", "v2ce_ldati_emit", "v2ce_events_pack", "v2ce_conv3d_fwd",
+    "v2ce_ldati_lds_bytes", "v2ce_ldati_workspace_bytes", "v2ce_ldati_emit", "v2ce_events_pack", "v2ce_conv3d_fwd",
     "v2ce_conv3d_variant",
     "v2ce_pack_weights", "v2ce_sn_workspace_bytes", "v2ce_sn_power_iter",
 ]
@@ -67,7 +67,9 @@ def lib() -> ctypes.CDLL:
     L.v2ce_ldati_lds_bytes.argtypes = [f64, f64]
     L.v2ce_ldati_lds_bytes.restype = sz
     L.v2ce_ldati_emit.argtypes = [vp, i32, i32, i32, f64, f64, i32, vp, i32, u64, i64, vp, vp,
-                                  vp, vp, vp, vp, vp]
+                                  vp, vp, vp, vp, i64, i64, vp, sz, vp]
+    L.v2ce_ldati_workspace_bytes.argtypes = [i32, i32, i32, f64, f64, i64, i64]
+    L.v2ce_ldati_workspace_bytes.restype = sz
     L.v2ce_events_pack.argtypes = [vp, vp, vp, vp, i64, vp, vp]
     L.v2ce_conv3d_fwd.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.v2ce_pack_weights.argtypes = [vp, i32, i32, i32, vp, vp, vp]
