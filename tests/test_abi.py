@@ -33,7 +33,7 @@ def test_argument_validation_without_gpu():
     assert b"null" in L.v2ce_last_error()
     assert L.v2ce_ldati_lds_bytes(30.0, 0.0) > 0
     assert L.v2ce_ldati_lds_bytes(5.0, 0.0) == 0          # bin too wide for the LDS histogram
-    assert L.v2ce_sn_workspace_bytes(512, 13824) == 4 * (512 + 13824)
+    assert L.v2ce_sn_workspace_bytes(512, 13824) >= 4 * (512 + 13824)
     d = hip.ConvDesc(B=1, T=16, C0=64, H0=130, W0=173, C1=0, Hin=130, Win=173, Cout=64, Hout=130,
                      Wout=173, ksize=5, stride_hw=1, act=1, tile_t=0, tile_h=0, tile_w=0)
     buf = ctypes.create_string_buffer(64)

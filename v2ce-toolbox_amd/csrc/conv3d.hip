@@ -22,6 +22,7 @@
 // the concatenation is ever written to HBM.
 #include "common.h"
 
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -46,6 +47,8 @@ struct ConvParams {
     int plane;            // HT*HH*HWd  (LDS stride between channels)
     int n_co_tiles;
     int n_pos;            // TT*TH*TW
+    int n_spatial;        // B*nT*nH*nW
+    int xcd_remap;        // 1: blocks that share an input box (different co tiles) share an XCD/L2
 };
 
 template <int KS, int S, int CO_FR, int PO_FR, int CK, int EPT>
@@ -186,8 +189,18 @@ __global__ __launch_bounds__(256, MW) void conv3d_kernel(ConvParams P) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // block -> (co tile, spatial box)
-    int bid = blockIdx.x;
-    const int co_t = bid % P.n_co_tiles;  bid /= P.n_co_tiles;
+    // Blocks are dealt round-robin over the 8 XCDs (b and b+8 share one): with xcd_remap the co tiles
+    // of one input box run back to back on ONE XCD, so its halo is fetched into one L2 only.
+    int bid = blockIdx.x, co_t;
+    if (P.xcd_remap) {
+        const int xcd = bid & 7, q = bid >> 3;
+        co_t = q % P.n_co_tiles;
+        bid = (q / P.n_co_tiles) * 8 + xcd;
+        if (bid >= P.n_spatial) return;      // padding block (uniform)
+    } else {
+        co_t = bid % P.n_co_tiles;
+        bid /= P.n_co_tiles;
+    }
     const int iw = bid % P.nW;            bid /= P.nW;
     const int ih = bid % P.nH;            bid /= P.nH;
     const int it = bid % P.nT;            bid /= P.nT;
@@ -374,7 +387,11 @@ int launch(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream) {
                  t.th, t.tw, P.n_pos, Cfg::POS_TILE, P.plane, Cfg::MAX_PLANE);
     P.nT = (d.T + t.tt - 1) / t.tt; P.nH = (d.Hout + t.th - 1) / t.th; P.nW = (d.Wout + t.tw - 1) / t.tw;
     P.n_co_tiles = (d.Cout + Cfg::CO_TILE - 1) / Cfg::CO_TILE;
-    const long long blocks = (long long)d.B * P.nT * P.nH * P.nW * P.n_co_tiles;
+    P.n_spatial = d.B * P.nT * P.nH * P.nW;
+    static const int remap_env = [] { const char *e = getenv("V2CE_XCD_REMAP"); return e ? atoi(e) : 1; }();
+    P.xcd_remap = (remap_env && P.n_co_tiles > 1) ? 1 : 0;
+    const long long blocks = P.xcd_remap ? (long long)((P.n_spatial + 7) / 8) * 8 * P.n_co_tiles
+                                         : (long long)P.n_spatial * P.n_co_tiles;
     V2CE_REQUIRE(blocks > 0 && blocks < (1ll << 31), V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd: grid too large");
     // two buffers of { halo [CK][plane rounded to 64], weight slab rounded to whole wave rows }
     const int chs = (P.plane + 63) & ~63;

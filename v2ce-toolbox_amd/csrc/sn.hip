@@ -27,23 +27,38 @@ __device__ __forceinline__ double block_sum(double v, double *sh) {
     return s;
 }
 
-// t[j] = sum_i W[i][j] * u[i]
+constexpr int kRowChunks = 16;   // W^T u is split over row chunks to fill the chip; partials are
+                                 // reduced in a fixed order (bitwise reproducible, no atomics)
+
+// part[c][j] = sum_{i in chunk c} W[i][j] * u[i]
 __global__ __launch_bounds__(256) void sn_wt_u_kernel(const float *__restrict__ w,
                                                       const float *__restrict__ u, int rows,
-                                                      int cols, float *__restrict__ t) {
+                                                      int cols, double *__restrict__ part) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= cols) return;
+    const int per = (rows + kRowChunks - 1) / kRowChunks;
+    const int lo = blockIdx.y * per, hi = (lo + per < rows) ? lo + per : rows;
     double s = 0.0;
-    for (int i = 0; i < rows; ++i) s += (double)w[(long long)i * cols + j] * (double)u[i];
-    t[j] = (float)s;
+#pragma unroll 4
+    for (int i = lo; i < hi; ++i) s += (double)w[(long long)i * cols + j] * (double)u[i];
+    part[(long long)blockIdx.y * cols + j] = s;
 }
 
-// v = t / (|t| + eps)     (single workgroup)
-__global__ __launch_bounds__(1024) void sn_normalize_kernel(const float *__restrict__ t, int n,
+// t = sum of the row-chunk partials; v = t / (|t| + eps)     (single workgroup)
+__global__ __launch_bounds__(1024) void sn_normalize_kernel(const double *__restrict__ part, int n,
+                                                            float *__restrict__ t,
                                                             float *__restrict__ out) {
     __shared__ double sh[16];
     double s = 0.0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) s += (double)t[i] * (double)t[i];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        double a = 0.0;
+#pragma unroll
+        for (int c = 0; c < kRowChunks; ++c) a += part[(long long)c * n + i];
+        const float ti = (float)a;
+        t[i] = ti;
+        s += (double)ti * (double)ti;
+    }
+    __syncthreads();
     const float norm = (float)sqrt(block_sum(s, sh));
     const float den = norm + 1e-12f;
     for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] = t[i] / den;
@@ -87,7 +102,7 @@ using namespace v2ce;
 
 extern "C" size_t v2ce_sn_workspace_bytes(int rows, int cols) {
     if (rows <= 0 || cols <= 0) return 0;
-    return ((size_t)rows + (size_t)cols) * sizeof(float);
+    return ((size_t)rows + (size_t)cols) * sizeof(float) + (size_t)kRowChunks * cols * sizeof(double);
 }
 
 extern "C" int v2ce_sn_power_iter(float *u, float *v, const float *w_bar, int rows, int cols,
@@ -100,10 +115,12 @@ extern "C" int v2ce_sn_power_iter(float *u, float *v, const float *w_bar, int ro
                  "v2ce_sn_power_iter: workspace %zu < %zu", workspace_bytes,
                  v2ce_sn_workspace_bytes(rows, cols));
     hipStream_t st = as_stream(stream);
-    float *t = static_cast<float *>(workspace);   // [cols]
-    float *s = t + cols;                          // [rows]
-    hipLaunchKernelGGL(sn_wt_u_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, w_bar, u, rows, cols, t);
-    hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(1024), 0, st, t, cols, v);
+    double *part = static_cast<double *>(workspace);                  // [kRowChunks][cols]
+    float *t = reinterpret_cast<float *>(part + (size_t)kRowChunks * cols);   // [cols]
+    float *s = t + cols;                                                       // [rows]
+    hipLaunchKernelGGL(sn_wt_u_kernel, dim3((cols + 255) / 256, kRowChunks), dim3(256), 0, st, w_bar, u,
+                       rows, cols, part);
+    hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(1024), 0, st, part, cols, t, v);
     hipLaunchKernelGGL(sn_w_v_kernel, dim3(rows), dim3(256), 0, st, w_bar, v, cols, s);
     hipLaunchKernelGGL(sn_finalize_kernel, dim3(1), dim3(1024), 0, st, s, rows, u, sigma);
     V2CE_HIP_CHECK(hipGetLastError());
