@@ -181,6 +181,18 @@ def main():
                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ldati["frac_hbm_peak"], "traffic": None,
                     "avg_launch_ms": ldati["avg_ms"], "bytes_per_launch": ldati["algorithmic_bytes_per_launch"]}
 
+    # HBM-side traffic of the same kernel from the latest committed PMC summary (rocprofv3 --pmc
+    # FETCH_SIZE / WRITE_SIZE in separate passes, tools/pmc_summary.py): bytes per launch, or null
+    try:
+        import glob
+        pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))[-1]))
+        key = roofline["kernel"].replace(" ", "")
+        if key in pmc:
+            roofline["traffic"] = pmc[key]["traffic_bytes"]
+            roofline["traffic_source"] = "profiles (PMC FETCH_SIZE x2 + WRITE_SIZE, avg per launch)"
+    except Exception:
+        pass
+
     if rank == 0:
         line = {
             "metric": "frame-pairs/sec end-to-end (UNet+LDATI), 346x260",

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of individual V2ce3d conv layers (b = 4 sequences, 346x260 pyramid) through the
+C ABI; used for kernel A/B runs (tile shapes, build knobs, V2CE_DBG ablations)."""
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from v2ce_toolbox_amd import hip  # noqa: E402
+
+L = [(260, 346), (130, 173), (65, 87), (33, 44), (17, 22)]
+LAYERS = {   # name: (C0, lvl0, C1, lvl_in, Cout, ksize, stride)
+    "enc0.conv2": (64, 1, 0, 1, 64, 3, 1), "enc1.conv1": (64, 1, 0, 1, 128, 3, 2),
+    "res0.conv1": (512, 4, 0, 4, 512, 3, 1), "dec1.conv1": (256, 3, 128, 2, 128, 3, 1),
+    "dec3.conv1": (64, 1, 32, 0, 32, 3, 1), "dec3.conv2": (32, 0, 0, 0, 32, 3, 1),
+    "dec2.down": (128, 2, 64, 1, 64, 1, 1), "pred": (32, 0, 0, 0, 20, 1, 1), "enc0.down": (32, 0, 0, 0, 64, 1, 2),
+}
+
+
+def run(name, B=4, T=16, iters=5, tile=(0, 0, 0)):
+    C0, l0, C1, lin, Cout, k, s = LAYERS[name]
+    H0, W0 = L[l0]
+    Hin, Win = L[lin]
+    dev = "cuda"
+    x0 = torch.randn(B, T, C0, H0, W0, device=dev)
+    x1 = torch.randn(B, T, C1, Hin, Win, device=dev) if C1 else None
+    hmap = wmap = None
+    if (H0, W0) != (Hin, Win):
+        hmap = (torch.arange(Hin, device=dev) * H0 // Hin).int()
+        wmap = (torch.arange(Win, device=dev) * W0 // Win).int()
+    pad = k // 2
+    Ho, Wo = (Hin + 2 * pad - k) // s + 1, (Win + 2 * pad - k) // s + 1
+    w = torch.randn((C0 + C1) * k ** 3 * Cout, device=dev) * 0.02
+    sc, sh = torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev)
+    y = torch.empty(B, T, Cout, Ho, Wo, device=dev)
+    d = hip.ConvDesc(B=B, T=T, C0=C0, H0=H0, W0=W0, C1=C1, Hin=Hin, Win=Win, Cout=Cout, Hout=Ho, Wout=Wo,
+                     ksize=k, stride_hw=s, act=1, tile_t=tile[0], tile_h=tile[1], tile_w=tile[2])
+    lib = hip.lib()
+
+    def call():
+        hip.check(lib.v2ce_conv3d_fwd(ctypes.byref(d), x0.data_ptr(), hip.ptr(x1), hip.ptr(hmap), hip.ptr(wmap),
+                                      w.data_ptr(), sc.data_ptr(), sh.data_ptr(), None, y.data_ptr(),
+                                      hip.stream_ptr()), "conv")
+    call()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    fl = 2.0 * B * T * Ho * Wo * Cout * (C0 + C1) * k ** 3
+    return hip.conv_variant(d, hmap is not None), ms, fl / ms / 1e9
+
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(LAYERS)
+    for n in names:
+        v, ms, tf = run(n)
+        print(f"{n:12s} {v:34s} {ms:8.3f} ms {tf:7.1f} TF")

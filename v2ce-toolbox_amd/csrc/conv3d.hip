@@ -34,6 +34,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 
 
+
 struct ConvParams {
     const float *x0, *x1;
     const int *hmap, *wmap;
@@ -49,6 +50,7 @@ struct ConvParams {
     int n_pos;            // TT*TH*TW
     int n_spatial;        // B*nT*nH*nW
     int xcd_remap;        // 1: blocks that share an input box (different co tiles) share an XCD/L2
+    int dbg;              // timing ablations (results wrong): 1 no DMA after prologue, 2 no barrier
 };
 
 template <int KS, int S, int CO_FR, int PO_FR, int CK, int EPT>
@@ -264,9 +266,11 @@ __global__ __launch_bounds__(256, MW) void conv3d_kernel(ConvParams P) {
     int buf = 0;
     for (int ci0 = 0; ci0 < P.Cin; ci0 += CK, buf ^= 1) {
         // chunk ci0 has landed for every wave, and every wave is done reading the other buffer
+        if (!(P.dbg & 2)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const bool more = ci0 + CK < P.Cin;
+        }
+        const bool more = (ci0 + CK < P.Cin) && !(P.dbg & 1);
         constexpr int NPARTS = IL ? KS * KS : 1;
         if (NPARTS == 1 && more) ISSUE(ci0 + CK, buf ^ 1, 0, 1);
         const float *hl = smem + buf * buf_floats;
@@ -360,6 +364,12 @@ Tile choose_tile(int T, int Ho, int Wo, int ks, int s, int pos_tile, int max_pla
 thread_local char *g_name_out = nullptr;   // non-null: report the variant instead of launching
 thread_local size_t g_name_cap = 0;
 
+double tile_efficiency(int T, int Ho, int Wo, int ks, int s, int pos_tile, int max_plane) {
+    const Tile t = choose_tile(T, Ho, Wo, ks, s, pos_tile, max_plane);
+    const long long ntiles = (long long)((T + t.tt - 1) / t.tt) * ((Ho + t.th - 1) / t.th) * ((Wo + t.tw - 1) / t.tw);
+    return (double)T * Ho * Wo / ((double)ntiles * pos_tile);
+}
+
 template <int KS, int S, int CO_FR, int PO_FR, int CK, int EPT, int MW, int IL>
 int launch(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream) {
     using Cfg = ConvCfg<KS, S, CO_FR, PO_FR, CK, EPT>;
@@ -390,6 +400,8 @@ int launch(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream) {
     P.n_spatial = d.B * P.nT * P.nH * P.nW;
     static const int remap_env = [] { const char *e = getenv("V2CE_XCD_REMAP"); return e ? atoi(e) : 1; }();
     P.xcd_remap = (remap_env && P.n_co_tiles > 1) ? 1 : 0;
+    static const int dbg_env = [] { const char *e = getenv("V2CE_DBG"); return e ? atoi(e) : 0; }();
+    P.dbg = dbg_env;
     const long long blocks = P.xcd_remap ? (long long)((P.n_spatial + 7) / 8) * 8 * P.n_co_tiles
                                          : (long long)P.n_spatial * P.n_co_tiles;
     V2CE_REQUIRE(blocks > 0 && blocks < (1ll << 31), V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd: grid too large");
@@ -474,6 +486,12 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
         if (small_pos) {   // 256-position boxes: 80 KiB of LDS, two workgroups per CU as is
             V2CE_CK_OK(4);
             if (small_co) return launch<3, 1, 1, 2, 4, 8, 1, 0>(P, d, st);
+            // 384-position boxes waste fewer MFMA lanes on 17x22 planes (16x1x22 = 352 of 384)
+            if (tile_efficiency(d.T, d.Hout, d.Wout, 3, 1, 384, 2048) >
+                tile_efficiency(d.T, d.Hout, d.Wout, 3, 1, 256, 2048)) {
+                V2CE_CK_OK(2);
+                return launch<3, 1, 2, 3, 2, 8, 1, 0>(P, d, st);
+            }
             return launch<3, 1, 2, 2, 4, 8, 1, 0>(P, d, st);
         }
         V2CE_CK_OK(2);     // 512-position boxes: CK = 2 keeps two workgroups per CU (48 KiB each)
