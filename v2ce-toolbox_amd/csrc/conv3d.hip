@@ -50,7 +50,6 @@ struct ConvParams {
     int n_pos;            // TT*TH*TW
     int n_spatial;        // B*nT*nH*nW
     int xcd_remap;        // 1: blocks that share an input box (different co tiles) share an XCD/L2
-    int dbg;              // timing ablations (results wrong): 1 no DMA after prologue, 2 no barrier
 };
 
 template <int KS, int S, int CO_FR, int PO_FR, int CK, int EPT>
@@ -266,24 +265,23 @@ __global__ __launch_bounds__(256, MW) void conv3d_kernel(ConvParams P) {
     int buf = 0;
     for (int ci0 = 0; ci0 < P.Cin; ci0 += CK, buf ^= 1) {
         // chunk ci0 has landed for every wave, and every wave is done reading the other buffer
-        if (!(P.dbg & 2)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        }
-        const bool more = (ci0 + CK < P.Cin) && !(P.dbg & 1);
-        constexpr int NPARTS = IL ? KS * KS : 1;
+        const bool more = ci0 + CK < P.Cin;
+        constexpr int NPARTS = IL ? (KS == 1 ? CK / 2 : KS * KS) : 1;
         if (NPARTS == 1 && more) ISSUE(ci0 + CK, buf ^ 1, 0, 1);
         const float *hl = smem + buf * buf_floats;
         const float *wl = hl + CK * chs;
         for (int dt = 0; dt < KS; ++dt) {
             for (int dh = 0; dh < KS; ++dh) {
-                if (NPARTS > 1 && more) ISSUE(ci0 + CK, buf ^ 1, dt * KS + dh, NPARTS);
+                if (KS > 1 && NPARTS > 1 && more) ISSUE(ci0 + CK, buf ^ 1, dt * KS + dh, NPARTS);
 #pragma unroll
                 for (int dw = 0; dw < KS; ++dw) {
                     const int tap = (dt * KS + dh) * KS + dw;
                     const int toff = (dt * P.HH + dh) * P.HWd + dw;
 #pragma unroll
                     for (int kk = 0; kk < CK / 2; ++kk) {
+                        if (KS == 1 && NPARTS > 1 && more) ISSUE(ci0 + CK, buf ^ 1, kk, NPARTS);
                         float a[CO_FR], bq[PO_FR];
                         const float *wrow = wl + (tap * CK + 2 * kk + half) * CO_TILE + l32;
                         const float *hrow = hl + (2 * kk + half) * chs + toff;
@@ -400,8 +398,6 @@ int launch(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream) {
     P.n_spatial = d.B * P.nT * P.nH * P.nW;
     static const int remap_env = [] { const char *e = getenv("V2CE_XCD_REMAP"); return e ? atoi(e) : 1; }();
     P.xcd_remap = (remap_env && P.n_co_tiles > 1) ? 1 : 0;
-    static const int dbg_env = [] { const char *e = getenv("V2CE_DBG"); return e ? atoi(e) : 0; }();
-    P.dbg = dbg_env;
     const long long blocks = P.xcd_remap ? (long long)((P.n_spatial + 7) / 8) * 8 * P.n_co_tiles
                                          : (long long)P.n_spatial * P.n_co_tiles;
     V2CE_REQUIRE(blocks > 0 && blocks < (1ll << 31), V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd: grid too large");
@@ -527,7 +523,13 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
         return launch<3, 2, 2, 2, 2, 14, 1, 0>(P, d, st);
     }
     if (d.ksize == 3 && s == 2) V2CE_DISPATCH(3, 2, 2, 14);
-    if (d.ksize == 1 && s == 1) V2CE_DISPATCH(1, 1, 16, 2);
+    if (d.ksize == 1 && s == 1) {
+        // 1x1x1: no tap reuse, so the LDS-DMA issue rate (one 256-byte piece per 4 MFMAs) and HBM
+        // bound these; measured best: DMA issue dealt over the k-steps, small boxes for Cout >= 64
+        if (small_co) { V2CE_CK_OK(8); return launch<1, 1, 1, 4, 8, 2, 2, 1>(P, d, st); }
+        V2CE_CK_OK(16);
+        return launch<1, 1, 2, 2, 16, 2, 1, 1>(P, d, st);
+    }
     V2CE_DISPATCH(1, 2, 8, 8);
     return V2CE_ERR_UNSUPPORTED;
 #undef V2CE_DISPATCH
