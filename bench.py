@@ -127,7 +127,8 @@ def main():
         return ev.num_events, conv_prof
 
     for _ in range(args.warmup):
-        step(False)
+        step(True)            # same code path as the timed steps (warms the HIP event pool too)
+    ldati_prof.clear()
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
