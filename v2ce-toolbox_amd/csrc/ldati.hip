@@ -55,6 +55,8 @@ struct LdatiParams {
     unsigned *cbcount;            // [B*9][NB] events per bucket
     unsigned *cursor;             // [B*9][NB] append cursors
     unsigned *bofs;               // [B*9][NB] exclusive offsets inside the segment
+    unsigned *wgtab;              // [B][wg_per_frame][9*NB] per-workgroup bucket counts -> offsets
+    int wg_per_frame, blk_per_pol;
     unsigned *temp;               // [total events] unsorted 32-bit records (fine key | category | pixel)
     int *seg_flag;                // [B*9] 1 = a bucket exceeds the LDS sort capacity -> segment sweep path
 };
@@ -463,71 +465,111 @@ __global__ __launch_bounds__(256) void ldati_emit_kernel(LdatiParams P) {
 //                 events are written as coalesced runs.  The record order (key, category, pixel) IS the
 //                 reference's stable order: events that tie on all three are identical records.
 // ---------------------------------------------------------------------------------------------
+constexpr int kPixPerWg = 1024;   // pixels of one polarity plane per workgroup (4 per thread)
+
+// One event of (frame b, bin c): count it in / append it through the workgroup's LDS table.
 template <bool APPEND>
-__device__ __forceinline__ void bucket_event(const LdatiParams &P, int seg, int c, long long T,
-                                             unsigned cat, unsigned px) {
+__device__ __forceinline__ void bucket_event(const LdatiParams &P, unsigned *lds, int c,
+                                             long long seg_lo, long long T, unsigned cat,
+                                             unsigned px) {
     const int key = key_of(T, P.kbase[c], P.NK);
-    const unsigned slot_idx = (unsigned)seg * P.NB + (unsigned)(key >> P.key_shift);
+    unsigned *slot = lds + c * P.NB + (key >> P.key_shift);
     if (!APPEND) {
-        atomicAdd(&P.cbcount[slot_idx], 1u);
+        atomicAdd(slot, 1u);                               // LDS atomic, no return
     } else {
-        const unsigned slot = atomicAdd(&P.cursor[slot_idx], 1u);
-        const long long pos = P.seg_offsets[seg] + P.bofs[slot_idx] + slot;
+        const unsigned pos = atomicAdd(slot, 1u);          // LDS cursor (bucket base + rank)
         const unsigned fine = (unsigned)key & ((1u << P.key_shift) - 1u);
-        P.temp[pos] = (fine << (2 + P.PB)) | (cat << P.PB) | px;
+        P.temp[seg_lo + pos] = (fine << (2 + P.PB)) | (cat << P.PB) | px;
     }
 }
 
+extern __shared__ __attribute__((aligned(16))) unsigned char bucket_smem[];
+
+// Pixel-parallel pass.  APPEND = false: per-workgroup histogram of coarse buckets (9 bins x NB) in
+// LDS, stored to wgtab.  APPEND = true: the LDS table is preloaded with this workgroup's exclusive
+// offsets (bucket offset inside the segment + events of earlier workgroups), and every event takes
+// its slot with one LDS atomic: no global atomics anywhere.
 template <bool APPEND>
 __global__ __launch_bounds__(256) void ldati_bucket_pass_kernel(LdatiParams P) {
+    unsigned *lds = reinterpret_cast<unsigned *>(bucket_smem);           // [9][NB]
     const int bp = blockIdx.y, b = bp >> 1, pidx = bp & 1;
-    const int px = blockIdx.x * 256 + threadIdx.x;
-    if (px >= P.HW) return;
+    const int wg = pidx * P.blk_per_pol + blockIdx.x;
+    const int ntab = 9 * P.NB;
+    unsigned *tab = P.wgtab + ((long long)b * P.wg_per_frame + wg) * ntab;
+    for (int i = threadIdx.x; i < ntab; i += 256)
+        lds[i] = APPEND ? tab[i] + P.bofs[(long long)b * ntab + i] : 0u;
+    __syncthreads();
     const float *plane0 = P.vox + (long long)bp * 10 * P.HW;
-    float yv[10];
-#pragma unroll
-    for (int i = 0; i < 10; ++i) yv[i] = plane0[(long long)i * P.HW + px];
-    int n[9];
-    float dbt[9];
-    {
-        const float eps = 1e-6f;
-        float d = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            const float r = yv[i] - d;
-            const float cc = ceilf(r - eps);
-            d = cc - r;
-            int ni = (int)cc;
-            if (i == 8) ni += (int)(yv[9] - d);
-            n[i] = ni;
-            dbt[i] = d;
-        }
-    }
     const unsigned frame = (unsigned)(P.frame_base + b);
     const unsigned cat_single = pidx ? 0u : 2u;    // negative events live in P index 1
+    for (int it = 0; it < kPixPerWg / 256; ++it) {
+        const int px = blockIdx.x * kPixPerWg + it * 256 + threadIdx.x;
+        if (px >= P.HW) break;
+        float yv[10];
 #pragma unroll
-    for (int c = 0; c < 9; ++c) {
-        const int nc = n[c];
-        if (nc < 1) continue;
-        const int seg = b * 9 + c;
-        if (nc == 1) {
-            bucket_event<APPEND>(P, seg, c, single_ts(dbt[c], P.fps, P.offt[c]), cat_single, (unsigned)px);
-        } else {
-            float k, bb;
-            slope_params(c > 0 ? n[c - 1] : 0, nc, c < 8 ? n[c + 1] : 0, c, P, k, bb);
-            const long long ubase = (((long long)bp * 9 + c) * P.HW + px) * P.replay_max_n;
-            for (int j = 0; j < nc; ++j) {
-                float u = 0.0f;
-                if (P.rng_mode == V2CE_RNG_REPLAY) {
-                    if (j < P.replay_max_n) u = P.uniforms[ubase + j];
-                } else {
-                    u = philox_uniform(P.seed, (unsigned)px, (unsigned)j, (unsigned)(pidx * 9 + c), frame);
-                }
-                bucket_event<APPEND>(P, seg, c, multi_ts(k, bb, u, P.offt[c], P), cat_single + 1u,
+        for (int i = 0; i < 10; ++i) yv[i] = plane0[(long long)i * P.HW + px];
+        int n[9];
+        float dbt[9];
+        {
+            const float eps = 1e-6f;
+            float d = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const float r = yv[i] - d;
+                const float cc = ceilf(r - eps);
+                d = cc - r;
+                int ni = (int)cc;
+                if (i == 8) ni += (int)(yv[9] - d);
+                n[i] = ni;
+                dbt[i] = d;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            const int nc = n[c];
+            if (nc < 1) continue;
+            const long long seg_lo = APPEND ? P.seg_offsets[b * 9 + c] : 0;
+            if (nc == 1) {
+                bucket_event<APPEND>(P, lds, c, seg_lo, single_ts(dbt[c], P.fps, P.offt[c]), cat_single,
                                      (unsigned)px);
+            } else {
+                float k, bb;
+                slope_params(c > 0 ? n[c - 1] : 0, nc, c < 8 ? n[c + 1] : 0, c, P, k, bb);
+                const long long ubase = (((long long)bp * 9 + c) * P.HW + px) * P.replay_max_n;
+                for (int j = 0; j < nc; ++j) {
+                    float u = 0.0f;
+                    if (P.rng_mode == V2CE_RNG_REPLAY) {
+                        if (j < P.replay_max_n) u = P.uniforms[ubase + j];
+                    } else {
+                        u = philox_uniform(P.seed, (unsigned)px, (unsigned)j, (unsigned)(pidx * 9 + c), frame);
+                    }
+                    bucket_event<APPEND>(P, lds, c, seg_lo, multi_ts(k, bb, u, P.offt[c], P),
+                                         cat_single + 1u, (unsigned)px);
+                }
             }
         }
     }
+    if (!APPEND) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < ntab; i += 256) tab[i] = lds[i];
+    }
+}
+
+// column scan over the workgroups of a frame: wgtab[b][w][i] -> exclusive prefix over w;
+// cbcount[b][i] = total
+__global__ __launch_bounds__(256) void ldati_wgtab_scan_kernel(LdatiParams P) {
+    const int ntab = 9 * P.NB;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (i >= ntab) return;
+    unsigned *col = P.wgtab + (long long)b * P.wg_per_frame * ntab + i;
+    unsigned run = 0;
+    for (int w = 0; w < P.wg_per_frame; ++w) {
+        const unsigned v = col[(long long)w * ntab];
+        col[(long long)w * ntab] = run;
+        run += v;
+    }
+    P.cbcount[(long long)b * ntab + i] = run;
 }
 
 __global__ __launch_bounds__(256) void ldati_bucket_scan_kernel(LdatiParams P) {
@@ -712,23 +754,28 @@ extern "C" size_t v2ce_ldati_lds_bytes(double fps, double t0) {
 }
 
 namespace {
-struct BucketPlan { int shift, NB, PB; size_t counters, bytes; };
+struct BucketPlan { int shift, NB, PB, blk_per_pol, wg_per_frame; size_t counters, tab, lds, bytes; };
 
-// coarse-bucket width: average bucket of the LARGEST segment ~ kSortCap/4 records
+// coarse-bucket width: average bucket of the LARGEST segment ~ kSortCap/4 records, but never so
+// narrow that a workgroup's [9][NB] table exceeds its LDS budget
 BucketPlan bucket_plan(const HostScalars &h, int B, int H, int W, int64_t total_events,
                        int64_t max_segment_events) {
     BucketPlan bp{};
     int shift = 0;
     while (shift < 13 && (double)max_segment_events * (double)(2 << shift) / (double)h.NK <= kSortCap / 4) ++shift;
+    while (shift < 13 && (size_t)9 * ((h.NK + (1 << shift) - 1) >> shift) * 4 > 96 * 1024) ++shift;
     int pb = 1;
     while ((1ll << pb) < (long long)H * W) ++pb;
-    if (shift + 2 + pb > 32) shift = 32 - 2 - pb;     // the record must fit 32 bits
-    if (shift < 0) shift = -1;                        // too many pixels for the 32-bit record
+    if (shift + 2 + pb > 32) shift = -1;              // the record must fit 32 bits
     bp.shift = shift;
     bp.PB = pb;
     bp.NB = shift >= 0 ? (h.NK + (1 << shift) - 1) >> shift : 0;
+    bp.blk_per_pol = (H * W + kPixPerWg - 1) / kPixPerWg;
+    bp.wg_per_frame = 2 * bp.blk_per_pol;
     bp.counters = (size_t)B * 9 * (size_t)bp.NB;
-    bp.bytes = (3 * bp.counters + (size_t)B * 9 + (size_t)(total_events > 0 ? total_events : 0)) * 4;
+    bp.tab = bp.counters * (size_t)bp.wg_per_frame;
+    bp.lds = (size_t)9 * bp.NB * 4;
+    bp.bytes = (2 * bp.counters + bp.tab + (size_t)B * 9 + (size_t)(total_events > 0 ? total_events : 0)) * 4;
     return bp;
 }
 }  // namespace
@@ -790,16 +837,22 @@ extern "C" int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps
                      "v2ce_ldati_emit: too many buckets for one launch");
         unsigned *w = static_cast<unsigned *>(workspace);
         P.key_shift = bp.shift; P.NB = bp.NB; P.PB = bp.PB;
+        P.blk_per_pol = bp.blk_per_pol; P.wg_per_frame = bp.wg_per_frame;
         P.cbcount = w;
-        P.cursor = w + bp.counters;
-        P.bofs = w + 2 * bp.counters;
-        P.seg_flag = reinterpret_cast<int *>(w + 3 * bp.counters);
-        P.temp = w + 3 * bp.counters + (size_t)B * 9;
-        V2CE_HIP_CHECK(hipMemsetAsync(w, 0, 2 * bp.counters * 4, st));     // cbcount + cursor
-        dim3 grid((P.HW + 255) / 256, 2 * B);
-        hipLaunchKernelGGL(ldati_bucket_pass_kernel<false>, grid, dim3(256), 0, st, P);
+        P.bofs = w + bp.counters;
+        P.wgtab = w + 2 * bp.counters;
+        P.seg_flag = reinterpret_cast<int *>(w + 2 * bp.counters + bp.tab);
+        P.temp = w + 2 * bp.counters + bp.tab + (size_t)B * 9;
+        P.cursor = nullptr;
+        V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ldati_bucket_pass_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bp.lds));
+        V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ldati_bucket_pass_kernel<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bp.lds));
+        dim3 grid(bp.blk_per_pol, 2 * B);
+        hipLaunchKernelGGL(ldati_bucket_pass_kernel<false>, grid, dim3(256), bp.lds, st, P);
+        hipLaunchKernelGGL(ldati_wgtab_scan_kernel, dim3((9 * bp.NB + 255) / 256, B), dim3(256), 0, st, P);
         hipLaunchKernelGGL(ldati_bucket_scan_kernel, dim3(B * 9), dim3(256), 0, st, P);
-        hipLaunchKernelGGL(ldati_bucket_pass_kernel<true>, grid, dim3(256), 0, st, P);
+        hipLaunchKernelGGL(ldati_bucket_pass_kernel<true>, grid, dim3(256), bp.lds, st, P);
         hipLaunchKernelGGL(ldati_bucket_sort_kernel, dim3((unsigned)bp.counters), dim3(256), 0, st, P);
     }
     // segment-sweep kernel: every segment when there is no workspace, else only the flagged ones
