@@ -1,6 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_gpu_unet.py tests/test_gpu_pipeline.py -m gpu -q -x 2>&1 | tail -2
-for rep in 1 2; do
-timeout 200 python bench.py --steps 4 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value'],1), round(d['ms_per_step'],2), round(d['roofline']['all_conv_tflops'],1), {k.replace('conv3d_kernel',''):round(v['avg_ms'],2) for k,v in list(d['kernels'].items())}, d['ldati']['avg_ms'])"
-done
+for t in 2048 1024 512 256 128; do for w in ldati_stress ldati_sparse e2e; do V2CE_BUCKET=$t timeout 300 python bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('bucket=$t $w', round(d['ms_per_step'],2), round(d['ldati']['avg_ms'],2))"; done; done

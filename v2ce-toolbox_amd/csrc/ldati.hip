@@ -169,20 +169,24 @@ __device__ __forceinline__ unsigned long long match_key(bool has, int key, int n
 // ---------------------------------------------------------------------------------------------
 // count kernel
 // ---------------------------------------------------------------------------------------------
+constexpr int kCountPixPerBlock = 4096;   // 16 pixels per thread: 16x fewer (contended) atomics
+
 __global__ __launch_bounds__(256) void ldati_count_kernel(const float *__restrict__ vox, int HW,
                                                           unsigned long long *seg_counts,
                                                           int *max_n) {
     // grid: (pixel blocks, 2*B)
     const int bp = blockIdx.y;           // b*2 + p
     const int b = bp >> 1;
-    const int px = blockIdx.x * 256 + threadIdx.x;
-    const bool valid = px < HW;
     const float *plane0 = vox + (long long)bp * 10 * HW;
-    float yv[10];
-    load_bins(plane0, HW, px, valid, 8, yv);
     int cnt[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) cnt[i] = 0;
     int mx = 0;
-    {
+    for (int it = 0; it < kCountPixPerBlock / 256; ++it) {
+        const int px = blockIdx.x * kCountPixPerBlock + it * 256 + threadIdx.x;
+        if (px >= HW) break;
+        float yv[10];
+        load_bins(plane0, HW, px, true, 8, yv);
         const float eps = 1e-6f;
         float d = 0.0f;
 #pragma unroll
@@ -192,8 +196,7 @@ __global__ __launch_bounds__(256) void ldati_count_kernel(const float *__restric
             d = cc - r;
             int ni = (int)cc;
             if (i == 8) ni += (int)(yv[9] - d);
-            if (!valid) ni = 0;
-            cnt[i] = ni > 0 ? ni : 0;
+            cnt[i] += ni > 0 ? ni : 0;
             mx = ni > mx ? ni : mx;
         }
     }
@@ -729,7 +732,7 @@ extern "C" int v2ce_ldati_count(const float *vox, int B, int H, int W, int64_t *
     V2CE_HIP_CHECK(hipMemsetAsync(seg_counts, 0, sizeof(int64_t) * 9 * (size_t)B, s));
     V2CE_HIP_CHECK(hipMemsetAsync(max_n, 0, sizeof(int32_t), s));
     const int HW = H * W;
-    dim3 grid((HW + 255) / 256, 2 * B);
+    dim3 grid((HW + kCountPixPerBlock - 1) / kCountPixPerBlock, 2 * B);
     hipLaunchKernelGGL(ldati_count_kernel, grid, dim3(256), 0, s, vox, HW,
                        reinterpret_cast<unsigned long long *>(seg_counts), max_n);
     V2CE_HIP_CHECK(hipGetLastError());
