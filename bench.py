@@ -166,7 +166,7 @@ def main():
     em_t, em_bytes, em_n = sum(t for t, _ in em), sum(nb for _, nb in em), len(em)
     ldati = None
     if em_n:
-        ldati = {"kernel": "ldati_emit_kernel", "avg_ms": 1e3 * em_t / em_n,
+        ldati = {"kernel": "v2ce_ldati_emit", "avg_ms": 1e3 * em_t / em_n,
                  "achieved_GBps": em_bytes / em_t / 1e9, "frac_hbm_peak": em_bytes / em_t / 1e9 / PEAK_HBM_GBS,
                  "algorithmic_bytes_per_launch": em_bytes / em_n}
     if args.workload == "e2e":
@@ -178,19 +178,25 @@ def main():
                     "avg_launch_ms": 1e3 * v[0] / v[2], "flop_per_launch": v[1] / v[2],
                     "all_conv_tflops": sum(x[1] for x in per.values()) / sum(x[0] for x in per.values()) / 1e12}
     else:
-        roofline = {"bound": "hbm", "kernel": "ldati_emit_kernel", "achieved": ldati["achieved_GBps"],
+        roofline = {"bound": "hbm", "kernel": "v2ce_ldati_emit (bucket_pass x2, wgtab_scan, bucket_scan, bucket_sort)",
+                    "achieved": ldati["achieved_GBps"],
                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ldati["frac_hbm_peak"], "traffic": None,
                     "avg_launch_ms": ldati["avg_ms"], "bytes_per_launch": ldati["algorithmic_bytes_per_launch"]}
 
-    # HBM-side traffic of the same kernel from the latest committed PMC summary (rocprofv3 --pmc
-    # FETCH_SIZE / WRITE_SIZE in separate passes, tools/pmc_summary.py): bytes per launch, or null
+    # HBM-side traffic of the same kernel(s) from the latest committed PMC summary of this workload
+    # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, tools/pmc_summary.py): bytes per
+    # launch, or null when no summary for this workload is committed
     try:
         import glob
-        pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))[-1]))
-        key = roofline["kernel"].replace(" ", "")
-        if key in pmc:
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*{args.workload}_pmc_traffic.json")))
+        pmc = json.load(open(files[-1]))
+        if args.workload == "e2e":
+            key = roofline["kernel"].replace(" ", "")
             roofline["traffic"] = pmc[key]["traffic_bytes"]
-            roofline["traffic_source"] = "profiles (PMC FETCH_SIZE x2 + WRITE_SIZE, avg per launch)"
+        else:   # the emit call = all ldati_* kernels except the count/scan pair in front of it
+            roofline["traffic"] = sum(v["traffic_bytes"] for k, v in pmc.items()
+                                      if k.startswith("ldati_") and k not in ("ldati_count_kernel", "ldati_scan_kernel"))
+        roofline["traffic_source"] = os.path.basename(files[-1]) + " (PMC FETCH_SIZE x2 + WRITE_SIZE, avg per launch)"
     except Exception:
         pass
 
