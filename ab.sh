@@ -1,13 +1,6 @@
 cd $GRAFT_REPO_ROOT
-export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -3
-python bench.py --steps 8 --warmup 2 > gpurun_out/r01c_bench_e2e.json 2>/dev/null
-python bench.py --workload ldati_stress --steps 8 --warmup 2 --no-cpu-baseline > gpurun_out/r01c_bench_ldati_stress.json 2>/dev/null
-python bench.py --workload ldati_sparse --steps 8 --warmup 2 --no-cpu-baseline > gpurun_out/r01c_bench_ldati_sparse.json 2>/dev/null
-cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r01c_prof_e2e -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r01c_prof_stress -- python3 $R/bench.py --workload ldati_stress --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-for c in FETCH_SIZE WRITE_SIZE; do rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/r01c_pmc_$c -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1; done
-for c in FETCH_SIZE WRITE_SIZE; do rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/r01c_pmcs_$c -- python3 $R/bench.py --workload ldati_stress --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1; done
-ls $R/gpurun_out | grep r01c
+timeout 600 python -m pytest tests/test_gpu_unet.py tests/test_gpu_pipeline.py -m gpu -q -x 2>&1 | tail -2
+for rep in 1 2; do
+timeout 200 python bench.py --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value'],1), round(d['ms_per_step'],2), round(d['roofline']['all_conv_tflops'],1), {k.replace('conv3d_kernel',''):round(v['tflops'],1) for k,v in list(d['kernels'].items())}, round(d['ldati']['avg_ms'],2), d['roofline']['traffic'])"
+done

@@ -26,6 +26,7 @@
 #include <map>
 #include <mutex>
 #include <tuple>
+#include <type_traits>
 
 namespace v2ce {
 namespace {
@@ -160,6 +161,15 @@ __device__ __forceinline__ void issue_chunk(const ConvParams &P, DmaState<EPT, W
 
 #endif  // __HIP_DEVICE_COMPILE__
 
+// compile-time loop: f(integral_constant<int, I>) for I in [I0, N)
+template <int I, int N, typename F>
+__device__ __forceinline__ void step_loop(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        step_loop<I + 1, N>(f);
+    }
+}
+
 extern __shared__ __attribute__((aligned(16))) unsigned char conv_smem[];
 
 // LDS-DMA double-buffered direct convolution (see the file header).
@@ -272,33 +282,42 @@ __global__ __launch_bounds__(256, MW) void conv3d_kernel(ConvParams P) {
         if (NPARTS == 1 && more) ISSUE(ci0 + CK, buf ^ 1, 0, 1);
         const float *hl = smem + buf * buf_floats;
         const float *wl = hl + CK * chs;
-        for (int dt = 0; dt < KS; ++dt) {
-            for (int dh = 0; dh < KS; ++dh) {
-                if (KS > 1 && NPARTS > 1 && more) ISSUE(ci0 + CK, buf ^ 1, dt * KS + dh, NPARTS);
-#pragma unroll
-                for (int dw = 0; dw < KS; ++dw) {
-                    const int tap = (dt * KS + dh) * KS + dw;
-                    const int toff = (dt * P.HH + dh) * P.HWd + dw;
-#pragma unroll
-                    for (int kk = 0; kk < CK / 2; ++kk) {
-                        if (KS == 1 && NPARTS > 1 && more) ISSUE(ci0 + CK, buf ^ 1, kk, NPARTS);
-                        float a[CO_FR], bq[PO_FR];
-                        const float *wrow = wl + (tap * CK + 2 * kk + half) * CO_TILE + l32;
-                        const float *hrow = hl + (2 * kk + half) * chs + toff;
-#pragma unroll
-                        for (int q = 0; q < CO_FR; ++q) a[q] = wrow[q * 32];
-#pragma unroll
-                        for (int f = 0; f < PO_FR; ++f) bq[f] = hrow[hoff[f]];
-#pragma unroll
-                        for (int q = 0; q < CO_FR; ++q)
-#pragma unroll
-                            for (int f = 0; f < PO_FR; ++f)
-                                acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], bq[f],
-                                                                                acc[q][f], 0, 0, 0);
-                    }
-                }
-            }
+        // K3*CK/2 MFMA k-steps, fully unrolled, with the A/B fragments of step s+1 loaded into a
+        // second register set BEFORE the MFMAs of step s: a fragment read issued right behind the
+        // last MFMA that uses its register comes back ~50 cycles after the matrix pipe has drained
+        // (ISA of the naive loop), costing ~12 % of every k-step.
+        constexpr int KH = CK / 2, NSTEP = K3 * KH;
+        float a[2][CO_FR], bq[2][PO_FR];
+#define V2CE_LOAD_STEP(slot_, s_)                                                            \
+        {                                                                                    \
+            constexpr int tap_ = (s_) / KH, kk_ = (s_) % KH;                                 \
+            constexpr int dt_ = tap_ / (KS * KS), dh_ = (tap_ / KS) % KS, dw_ = tap_ % KS;   \
+            const int toff_ = (dt_ * P.HH + dh_) * P.HWd + dw_;                              \
+            const float *wrow_ = wl + (tap_ * CK + 2 * kk_ + half) * CO_TILE + l32;          \
+            const float *hrow_ = hl + (2 * kk_ + half) * chs + toff_;                        \
+            _Pragma("unroll") for (int q = 0; q < CO_FR; ++q) a[slot_][q] = wrow_[q * 32];   \
+            _Pragma("unroll") for (int f = 0; f < PO_FR; ++f) bq[slot_][f] = hrow_[hoff[f]]; \
         }
+        step_loop<0, NSTEP>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            if constexpr (s == 0) V2CE_LOAD_STEP(0, 0)
+            if constexpr (KS > 1) {
+                if constexpr (s % (KS * KH) == 0) {
+                    if (NPARTS > 1 && more) ISSUE(ci0 + CK, buf ^ 1, s / (KS * KH), NPARTS);
+                }
+            } else {
+                if (NPARTS > 1 && more) ISSUE(ci0 + CK, buf ^ 1, s, NPARTS);
+            }
+            if constexpr (s + 1 < NSTEP) V2CE_LOAD_STEP((s + 1) & 1, s + 1)
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ABOVE this step's MFMAs
+#pragma unroll
+            for (int q = 0; q < CO_FR; ++q)
+#pragma unroll
+                for (int f = 0; f < PO_FR; ++f)
+                    acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s & 1][q], bq[s & 1][f],
+                                                                    acc[q][f], 0, 0, 0);
+        });
+#undef V2CE_LOAD_STEP
     }
 
 #undef ISSUE
