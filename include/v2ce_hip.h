@@ -89,6 +89,14 @@ int v2ce_events_pack(const int64_t *ts, const int16_t *x, const int16_t *y, cons
                      int64_t n, uint8_t *packed, v2ce_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Frame ingest.  Replaces v2ce.py:45-64 (image_pre_processing) for frames already at the target
+ * height: frames [N][H][W] u8 -> units [N-1][2][H][W] f32 = ((u8/255) - mean) / std of (frame i,
+ * frame i+1); separate correctly rounded f32 operations, bit-identical to the host path.
+ * ---------------------------------------------------------------------------------------------- */
+int v2ce_preprocess_pairs(const uint8_t *frames, int N, int H, int W, float mean, float stdv,
+                          float *units, v2ce_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Stage 1 -- V2ce3d building blocks.  Replaces the ATen ops behind scripts/unet_2layer.py:335-379,
  * scripts/submodules.py:115-124,249-264 and scripts/spectral_norm.py:19-31.
  * ---------------------------------------------------------------------------------------------- */

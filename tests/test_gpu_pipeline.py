@@ -71,3 +71,13 @@ def test_cli_end_to_end(tmp_path):
             exp.append(rec)
     exp = np.concatenate(exp)
     assert ev.tobytes() == exp.tobytes()
+
+
+def test_device_preprocess_bit_exact(gold_dir):
+    """v2ce_preprocess_pairs == the reference's image_pre_processing (golden pre5) bit for bit."""
+    z = np.load(os.path.join(gold_dir, "glue_g7.npz"))
+    got = glue.image_pre_processing_device(torch.from_numpy(z["frames"][:5]).cuda()).cpu().numpy()
+    assert got.tobytes() == z["pre5"].tobytes()
+    fr = synth.synthetic_frames(17, 260, 346, seed=5, pattern="noise")
+    got = glue.image_pre_processing_device(torch.from_numpy(fr).cuda()).cpu().numpy()
+    assert got.tobytes() == OG.preprocess(fr).tobytes()

@@ -48,6 +48,21 @@ def image_pre_processing(images: np.ndarray, height: int = 260) -> np.ndarray:
     return ((units - MEAN) / STD).astype(np.float32)       # transforms.Normalize: sub then div, f32
 
 
+def image_pre_processing_device(frames: torch.Tensor) -> torch.Tensor:
+    """Device twin of ``image_pre_processing`` for frames already at the target height:
+    frames [N,H,W] uint8 on the device -> [N-1,2,H,W] f32 (bit-identical to the host path)."""
+    from . import hip
+    if not frames.is_cuda or frames.dtype != torch.uint8 or frames.dim() != 3:
+        raise hip.V2ceHipError("image_pre_processing_device: expected a uint8 [N,H,W] device tensor")
+    frames = frames.contiguous()
+    n, h, w = frames.shape
+    units = torch.empty((n - 1, 2, h, w), dtype=torch.float32, device=frames.device)
+    hip.check(hip.lib().v2ce_preprocess_pairs(frames.data_ptr(), n, h, w, float(MEAN), float(STD),
+                                              units.data_ptr(), hip.stream_ptr(frames.device)),
+              "v2ce_preprocess_pairs")
+    return units
+
+
 def sequence_plan(frame_count: int, seq_len: int = 16):
     """v2ce.py:149-154 -> (sequence_num, mode, starting_indexes)."""
     if frame_count < seq_len + 1:
@@ -123,8 +138,13 @@ def video_to_voxels(model, frames: Optional[np.ndarray] = None, read_frames=None
     out_width = width
     for seq_idx, start in enumerate(starts):
         images = np.asarray(read_frames(range(int(start), int(start) + seq_len + 1)))
-        units = image_pre_processing(images, height=height)
-        pending.append(torch.from_numpy(units[np.newaxis]))
+        if images.dtype == np.uint8 and images.shape[1] == height and str(device).startswith("cuda"):
+            # no resize needed: ship the u8 frames (4x fewer PCIe bytes) and normalise on the device
+            units = image_pre_processing_device(torch.from_numpy(images).to(device, non_blocking=True))
+            pending.append(units[None])
+        else:
+            units = image_pre_processing(images, height=height)
+            pending.append(torch.from_numpy(units[np.newaxis]))
         if len(pending) == batch_size or seq_idx == len(starts) - 1:
             batch = torch.cat(pending, dim=0).to(device, non_blocking=True)
             if infer_type == "center":
