@@ -22,7 +22,7 @@ def _fake_events_from_voxels(pred_voxel, fps, stage2_batch_size=24, seed=0, rng=
         rec["timestamp"][i] = glue.frame_offset_us(first_pair + i, fps)
         rec["x"][i] = (first_pair + i) % 30000
         rec["y"][i] = int(float(pred_voxel[i].double().sum()) * 10) % 30000
-    return torch.from_numpy(np.frombuffer(rec.tobytes(), np.uint8).copy()), np.ones(L, np.int64)
+    return [torch.from_numpy(np.frombuffer(rec.tobytes(), np.uint8).copy())], np.ones(L, np.int64)
 
 
 def _worker(rank, world, port, n_frames, infer_type, bs, q):

@@ -107,19 +107,40 @@ def read_video(path, max_frame_num):
 
 def events_from_voxels(pred_voxel: torch.Tensor, fps, stage2_batch_size=24, seed=0, rng="philox",
                        first_pair=0):
-    """v2ce.py:351-367 on the device: LDATI in chunks of `stage2_batch_size` frame-pairs with the
-    per-frame offset int(i*1/fps*1e6) (global pair index) fused.  Returns packed uint8 records on
-    the device and the per-frame event counts."""
+    """v2ce.py:351-367 on the device: LDATI in chunks of frame-pairs with the per-frame offset
+    int(i*1/fps*1e6) (global pair index) fused.  Returns the list of packed uint8 record buffers
+    (device) and the per-frame event counts.
+
+    With the counter-based Philox draws the result does not depend on the chunking, so chunks are
+    at least 96 pairs (fewer host synchronisations); with rng='torch' the chunk size shapes the dense
+    uniform tensor exactly like the reference's --stage2_batch_size (LDATI.py:169-171)."""
     L = pred_voxel.shape[0]
+    chunk = stage2_batch_size if rng == "torch" else max(stage2_batch_size, 96)
     packed, counts = [], []
-    for i in range(0, L, stage2_batch_size):
-        chunk = pred_voxel[i:i + stage2_batch_size]
-        add = torch.tensor([glue.frame_offset_us(first_pair + i + j, fps) for j in range(chunk.shape[0])],
-                           dtype=torch.int64, device=chunk.device)
-        ev = ldati_device(chunk, fps=fps, rng=rng, seed=seed, frame_base=first_pair + i, frame_ts_add=add)
+    for i in range(0, L, chunk):
+        part = pred_voxel[i:i + chunk]
+        add = torch.tensor([glue.frame_offset_us(first_pair + i + j, fps) for j in range(part.shape[0])],
+                           dtype=torch.int64, device=part.device)
+        ev = ldati_device(part, fps=fps, rng=rng, seed=seed, frame_base=first_pair + i, frame_ts_add=add)
         packed.append(ev.packed())
         counts.append(ev.frame_counts)
-    return torch.cat(packed), np.concatenate(counts)
+    return packed, np.concatenate(counts)
+
+
+def download_events(packed_list) -> np.ndarray:
+    """One D2H pass of the packed records into a pinned host buffer, viewed as the structured
+    array of LDATI.py:308 (no host-side concatenation)."""
+    total = sum(int(p.numel()) for p in packed_list)
+    if not packed_list or not packed_list[0].is_cuda:          # CPU stand-ins (tests)
+        return np.ascontiguousarray(torch.cat(list(packed_list)).numpy()).view(EVENT_DTYPE)
+    host = torch.empty(total, dtype=torch.uint8, pin_memory=True)
+    off = 0
+    for p in packed_list:
+        n = int(p.numel())
+        host[off:off + n].copy_(p, non_blocking=True)
+        off += n
+    torch.cuda.synchronize()
+    return host.numpy().view(EVENT_DTYPE)
 
 
 def run(frames: np.ndarray, model, infer_type="center", seq_len=16, width=346, height=260,
@@ -131,7 +152,7 @@ def run(frames: np.ndarray, model, infer_type="center", seq_len=16, width=346, h
         vox = glue.video_to_voxels(model, frames=frames, infer_type=infer_type, seq_len=seq_len,
                                    width=width, height=height, batch_size=batch_size, device=device)
         packed, _ = events_from_voxels(vox, fps, stage2_batch_size, seed, rng)
-        return np.ascontiguousarray(packed.cpu().numpy()).view(EVENT_DTYPE)
+        return download_events(packed)
     return _run_sharded(frames, model, infer_type, seq_len, width, height, batch_size, fps,
                         stage2_batch_size, seed, rng, device, rank, world)
 
@@ -149,7 +170,7 @@ def _run_sharded(frames, model, infer_type, seq_len, width, height, batch_size, 
         fw = int(frames.shape[2] / frames.shape[1] * height)
         calls_per_batch = int(np.ceil(fw / width))
     vdist.fast_forward(model, lo_b * calls_per_batch)
-    packed = torch.empty(0, dtype=torch.uint8, device=device)
+    packed = [torch.empty(0, dtype=torch.uint8, device=device)]
     if hi_b > lo_b:
         preds = []
         for bi in range(lo_b, hi_b):
@@ -169,10 +190,10 @@ def _run_sharded(frames, model, infer_type, seq_len, width, height, batch_size, 
             keep = vox.shape[0] - seq_len
             vox = torch.cat([vox[:keep], vox[keep + seq_len - mode:]])
         packed, _ = events_from_voxels(vox, fps, stage2_batch_size, seed, rng, first_pair=first_pair)
-    out = vdist.gather_events(packed, dst=0)
+    out = vdist.gather_events(torch.cat(packed), dst=0)
     if rank != 0:
         return None
-    return np.ascontiguousarray(out.cpu().numpy()).view(EVENT_DTYPE)
+    return download_events([out]) if out.is_cuda else np.ascontiguousarray(out.numpy()).view(EVENT_DTYPE)
 
 
 def main(argv=None):
