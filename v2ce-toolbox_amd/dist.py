@@ -4,9 +4,9 @@
 The path shards over independent 16-pair SEQUENCES (v2ce.py:163-204 processes them in a plain loop)
 with no collective on the data path; the only exchange is the final variable-length gather of the
 packed 13-byte event records to rank 0 (north_star: "RCCL-over-xGMI gather of the final event
-list").  RCCL has no gatherv, so it is one all_gather of byte counts plus grouped point-to-point
-send/recv straight into the concatenated result at prefix-sum offsets.  Event traffic (13 B/event)
-is orders of magnitude below one xGMI link, so this is latency- not bandwidth-bound.
+list").  RCCL has no gatherv, so it is one all_gather of byte counts plus one gather of buffers
+padded to the longest rank.  Event traffic (13 B/event) is orders of magnitude below one xGMI
+link, so this is latency- not bandwidth-bound.
 
 Spectral-norm state under sharding: the reference applies one power iteration per
 model call, so a replica that emulates global call index k must have applied k iterations before
@@ -30,7 +30,11 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
 
 def gather_events(packed: torch.Tensor, dst: int = 0, group=None) -> Optional[torch.Tensor]:
     """Gather variable-length uint8 record buffers to `dst`, concatenated in rank order.
-    Returns the concatenated tensor on `dst`, None elsewhere."""
+    Returns the concatenated tensor on `dst`, None elsewhere.
+
+    RCCL has no gatherv: one all_gather of the byte counts, then ONE `gather` of buffers padded to
+    the longest rank (event traffic is 13 B/event -- far below an xGMI link -- so the padding is
+    cheaper than a second protocol)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return packed
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -38,22 +42,15 @@ def gather_events(packed: torch.Tensor, dst: int = 0, group=None) -> Optional[to
     sizes = [torch.zeros(1, dtype=torch.int64, device=packed.device) for _ in range(world)]
     dist.all_gather(sizes, n, group=group)
     sizes = [int(s.item()) for s in sizes]
-    if rank == dst:
-        out = torch.empty(sum(sizes), dtype=torch.uint8, device=packed.device)
-        offs = [0]
-        for s in sizes:
-            offs.append(offs[-1] + s)
-        out[offs[rank]:offs[rank + 1]] = packed
-        ops = [dist.P2POp(dist.irecv, out[offs[r]:offs[r + 1]], r, group=group)
-               for r in range(world) if r != dst and sizes[r] > 0]
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-        return out
-    if packed.numel() > 0:
-        for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, packed.contiguous(), dst, group=group)]):
-            req.wait()
-    return None
+    longest = max(max(sizes), 1)
+    send = torch.zeros(longest, dtype=torch.uint8, device=packed.device)
+    send[:packed.numel()] = packed
+    recv = [torch.empty(longest, dtype=torch.uint8, device=packed.device) for _ in range(world)] \
+        if rank == dst else None
+    dist.gather(send, recv, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return torch.cat([recv[r][:sizes[r]] for r in range(world)])
 
 
 def fast_forward(model, global_call_index: int) -> None:
