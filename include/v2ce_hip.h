@@ -31,6 +31,9 @@ extern "C" {
 #define V2CE_RNG_REPLAY 0 /* uniforms supplied: dense [B,2,9,H,W,replay_max_n] f32 (LDATI.py:171) */
 #define V2CE_RNG_PHILOX 1 /* Philox4x32-10, counter (pixel, j>>2, p*9+c, frame_base+b), key seed */
 
+#define V2CE_STRATEGY_SLOPE 0 /* additional_events_strategy='slope' (the CLI's, v2ce.py:356) */
+#define V2CE_STRATEGY_NONE 1  /* 'none': voxels with more than one event emit nothing (LDATI.py:241) */
+
 #define V2CE_ACT_NONE 0
 #define V2CE_ACT_RELU 1   /* torch.relu / nn.ReLU           (submodules.py:105,232) */
 #define V2CE_ACT_LEAKY 2  /* nn.LeakyReLU(0.01)             (submodules.py:101-103) */
@@ -53,8 +56,8 @@ const char *v2ce_last_error(void);
  * Replaces y_relocate (LDATI.py:80-106) + torch.max (LDATI.py:169) + the sizes implied by
  * pick_elements' selections (LDATI.py:228,239).
  * vox [B,2,10,H,W] f32; seg_counts [B*9] i64 (overwritten); max_n [1] i32 (overwritten). */
-int v2ce_ldati_count(const float *vox, int B, int H, int W, int64_t *seg_counts, int32_t *max_n,
-                     v2ce_stream_t stream);
+int v2ce_ldati_count(const float *vox, int B, int H, int W, int strategy, int64_t *seg_counts,
+                     int32_t *max_n, v2ce_stream_t stream);
 
 /* Exclusive prefix sum of seg_counts -> seg_offsets [B*9+1] (last element = total events). */
 int v2ce_ldati_scan(const int64_t *seg_counts, int B, int64_t *seg_offsets, v2ce_stream_t stream);
@@ -76,7 +79,7 @@ size_t v2ce_ldati_lds_bytes(double fps, double t0);
  * Both produce bit-identical output. */
 size_t v2ce_ldati_workspace_bytes(int B, int H, int W, double fps, double t0, int64_t total_events,
                                   int64_t max_segment_events);
-int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps, double t0, int rng_mode,
+int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps, double t0, int strategy, int rng_mode,
                     const float *uniforms, int replay_max_n, uint64_t seed, int64_t frame_base,
                     const int64_t *seg_offsets, const int64_t *frame_ts_add, int64_t *ts,
                     int16_t *x, int16_t *y, int8_t *p, int64_t total_events,

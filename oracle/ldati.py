@@ -36,12 +36,12 @@ def lib() -> ctypes.CDLL:
     if _LIB is None:
         L = ctypes.CDLL(build())
         i64p, f32p = ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_float)
-        L.v2ce_oracle_ldati_count.argtypes = [f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, i64p,
+        L.v2ce_oracle_ldati_count.argtypes = [f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, i64p,
                                               ctypes.POINTER(ctypes.c_int32)]
         L.v2ce_oracle_ldati_count.restype = ctypes.c_int
         L.v2ce_oracle_ldati_emit.argtypes = [
             f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double,
-            ctypes.c_int, f32p, ctypes.c_int, ctypes.c_uint64, ctypes.c_int64, i64p, i64p,
+            ctypes.c_int, ctypes.c_int, f32p, ctypes.c_int, ctypes.c_uint64, ctypes.c_int64, i64p, i64p,
             ctypes.POINTER(ctypes.c_int16), ctypes.POINTER(ctypes.c_int16),
             ctypes.POINTER(ctypes.c_int8)]
         L.v2ce_oracle_ldati_emit.restype = ctypes.c_int
@@ -79,14 +79,17 @@ def relocate(y10: np.ndarray):
     return n, d
 
 
-def count(vox: np.ndarray):
+STRATEGY = {"slope": 0, "none": 1}
+
+
+def count(vox: np.ndarray, strategy="slope"):
     """vox [B,2,10,H,W] f32 -> (seg_counts [B,9] i64, max_n)."""
     vox = np.ascontiguousarray(vox, dtype=np.float32)
     B, P, C, H, W = vox.shape
     assert P == 2 and C == 10
     seg = np.zeros((B, 9), np.int64)
     mx = ctypes.c_int32(0)
-    rc = lib().v2ce_oracle_ldati_count(_p(vox, ctypes.c_float), B, H, W, _p(seg, ctypes.c_int64),
+    rc = lib().v2ce_oracle_ldati_count(_p(vox, ctypes.c_float), B, H, W, STRATEGY[strategy], _p(seg, ctypes.c_int64),
                                        ctypes.byref(mx))
     assert rc == 0
     return seg, int(mx.value)
@@ -98,13 +101,13 @@ def philox_uniforms(B, H, W, max_n, seed, frame_base=0) -> np.ndarray:
     return out
 
 
-def emit_soa(vox, fps=30, t0=0.0, uniforms=None, seed=0, frame_base=0):
+def emit_soa(vox, fps=30, t0=0.0, uniforms=None, seed=0, frame_base=0, strategy="slope"):
     """Run count + emit.  ``uniforms`` (dense [B,2,9,H,W,max_n] f32) selects REPLAY mode, else
     Philox with ``seed``.  Returns (seg_counts [B,9], ts, x, y, p)."""
     check_arange_len(fps)
     vox = np.ascontiguousarray(vox, dtype=np.float32)
     B, _, _, H, W = vox.shape
-    seg, max_n = count(vox)
+    seg, max_n = count(vox, strategy)
     offs = np.zeros(B * 9 + 1, np.int64)
     np.cumsum(seg.reshape(-1), out=offs[1:])
     total = int(offs[-1])
@@ -120,7 +123,7 @@ def emit_soa(vox, fps=30, t0=0.0, uniforms=None, seed=0, frame_base=0):
         mode, uptr = RNG_REPLAY, _p(uniforms, ctypes.c_float)
     else:
         replay_max_n, mode, uptr = 0, RNG_PHILOX, None
-    rc = lib().v2ce_oracle_ldati_emit(_p(vox, ctypes.c_float), B, H, W, float(fps), float(t0), mode,
+    rc = lib().v2ce_oracle_ldati_emit(_p(vox, ctypes.c_float), B, H, W, float(fps), float(t0), STRATEGY[strategy], mode,
                                       uptr, replay_max_n, int(seed), int(frame_base),
                                       _p(offs, ctypes.c_int64), _p(ts, ctypes.c_int64),
                                       _p(x, ctypes.c_int16), _p(y, ctypes.c_int16),
@@ -136,11 +139,11 @@ def pack(ts, x, y, p) -> np.recarray:
     return rec.view(np.recarray)
 
 
-def sample_voxel_statistical_oracle(y, t0=0, fps=30, uniforms=None, seed=0, frame_base=0):
+def sample_voxel_statistical_oracle(y, t0=0, fps=30, uniforms=None, seed=0, frame_base=0, strategy="slope"):
     """Oracle twin of ``sample_voxel_statistical`` (LDATI.py:126): list[B] of packed recarrays."""
     vox = np.asarray(y, dtype=np.float32)
     seg, ts, x, yy, p = emit_soa(vox, fps=fps, t0=t0, uniforms=uniforms, seed=seed,
-                                 frame_base=frame_base)
+                                 frame_base=frame_base, strategy=strategy)
     per_frame = seg.sum(axis=1)
     ends = np.cumsum(per_frame)
     out = []

@@ -80,7 +80,7 @@ void v2ce_oracle_philox_fill(float *out, int B, int H, int W, int max_n, uint64_
 }
 
 /* --------------------------------------------------------------------------------------------- */
-int v2ce_oracle_ldati_count(const float *vox, int B, int H, int W, int64_t *seg_counts,
+int v2ce_oracle_ldati_count(const float *vox, int B, int H, int W, int strategy, int64_t *seg_counts,
                             int32_t *max_n) {
     const int64_t HW = (int64_t)H * W;
     int64_t mx = 0;
@@ -96,7 +96,8 @@ int v2ce_oracle_ldati_count(const float *vox, int B, int H, int W, int64_t *seg_
                 for (int c = 0; c < 9; ++c) {
                     /* pick_elements keeps n==1 singles and the first n draws of n>=2 voxels
                      * (LDATI.py:228,236-239); n<=0 contributes nothing. */
-                    if (n[c] > 0) sc[c] += n[c];
+                    if (strategy == V2CE_ORACLE_STRATEGY_NONE) sc[c] += (n[c] == 1); /* LDATI.py:241 */
+                    else if (n[c] > 0) sc[c] += n[c];
                     if (n[c] > mx) mx = n[c]; /* LDATI.py:169 torch.max(y) over all counts */
                 }
             }
@@ -123,7 +124,7 @@ static void merge_sort_idx(const int64_t *key, int64_t *idx, int64_t *tmp, int64
 }
 
 int v2ce_oracle_ldati_emit(const float *vox, int B, int H, int W, double fps, double t0,
-                           int rng_mode, const float *uniforms, int replay_max_n, uint64_t seed,
+                           int strategy, int rng_mode, const float *uniforms, int replay_max_n, uint64_t seed,
                            int64_t frame_base, const int64_t *seg_offsets, int64_t *ts_out,
                            int16_t *x_out, int16_t *y_out, int8_t *p_out) {
     if (rng_mode == V2CE_ORACLE_RNG_REPLAY && uniforms == NULL && replay_max_n > 0) return -1;
@@ -184,7 +185,7 @@ int v2ce_oracle_ldati_emit(const float *vox, int B, int H, int W, double fps, do
                 for (int64_t px = 0; px < HW; ++px) {
                     const int64_t *n = nn + (p * HW + px) * 9;
                     const int64_t nc = n[c];
-                    if (nc < 2) continue;
+                    if (nc < 2 || strategy == V2CE_ORACLE_STRATEGY_NONE) continue;
                     /* slope: reflect pad + [-1,0,1] conv -- LDATI.py:25,30,39; (3*sxy-0)/6 :45 */
                     const int64_t nl = c == 0 ? n[1] : n[c - 1];
                     const int64_t nr = c == 8 ? n[7] : n[c + 1];

@@ -20,6 +20,9 @@
 extern "C" {
 #endif
 
+#define V2CE_ORACLE_STRATEGY_SLOPE 0 /* additional_events_strategy='slope' */
+#define V2CE_ORACLE_STRATEGY_NONE 1  /* 'none': only single-event voxels emit (LDATI.py:206-207,241) */
+
 #define V2CE_ORACLE_RNG_REPLAY 0 /* uniforms read from a dense [B,2,9,H,W,max_n] tensor      */
 #define V2CE_ORACLE_RNG_PHILOX 1 /* Philox4x32-10, counter (pixel, j>>2, p*9+c, frame), key seed */
 
@@ -28,7 +31,7 @@ void v2ce_oracle_relocate(const float *y10, int64_t stride, int64_t n[9], float 
 
 /* Phase 1: per-(frame, bin) event counts and the chunk-wide max count (LDATI.py:169).
  * vox: [B,2,10,H,W] f32.  seg_counts: [B*9] int64.  Returns 0. */
-int v2ce_oracle_ldati_count(const float *vox, int B, int H, int W, int64_t *seg_counts,
+int v2ce_oracle_ldati_count(const float *vox, int B, int H, int W, int strategy, int64_t *seg_counts,
                             int32_t *max_n);
 
 /* Phase 2: emit the events of every (frame, bin) segment in the reference's *stable* order
@@ -37,7 +40,7 @@ int v2ce_oracle_ldati_count(const float *vox, int B, int H, int W, int64_t *seg_
  * frame_base: global index of frame 0 (only used by the Philox counter).  Returns 0, or <0 on a
  * bad argument. */
 int v2ce_oracle_ldati_emit(const float *vox, int B, int H, int W, double fps, double t0,
-                           int rng_mode, const float *uniforms, int replay_max_n, uint64_t seed,
+                           int strategy, int rng_mode, const float *uniforms, int replay_max_n, uint64_t seed,
                            int64_t frame_base, const int64_t *seg_offsets, int64_t *ts,
                            int16_t *x, int16_t *y, int8_t *p);
 

@@ -140,14 +140,15 @@ def gen_unet():
 
 
 # --------------------------------------------------------------------------------------------- G3
-def run_ref_ldati(vox, fps, t0, seed, ieee_sqrt=False):
+def run_ref_ldati(vox, fps, t0, seed, ieee_sqrt=False, strategy="slope"):
     with RandCapture() as cap:
         torch.manual_seed(seed)
+        kw = dict(t0=t0, fps=fps, additional_events_strategy=strategy)
         if ieee_sqrt:
             with IeeeSqrt():
-                res = REF_LDATI.sample_voxel_statistical(torch.from_numpy(vox), t0=t0, fps=fps)
+                res = REF_LDATI.sample_voxel_statistical(torch.from_numpy(vox), **kw)
         else:
-            res = REF_LDATI.sample_voxel_statistical(torch.from_numpy(vox), t0=t0, fps=fps)
+            res = REF_LDATI.sample_voxel_statistical(torch.from_numpy(vox), **kw)
         u = cap.last.numpy()
     return res, u
 
@@ -160,10 +161,13 @@ def gen_ldati_small():
         "t0fps60": (synth.synthetic_voxels(2, 9, 11, seed=24, regime="stress"), 60, 0.5),
         "ragged": (synth.synthetic_voxels(1, 1, 67, seed=25, regime="stress"), 24, 0),
     }
+    # additional_events_strategy='none' (only single-event voxels emit, LDATI.py:206-207,241)
+    cases["none"] = (synth.synthetic_voxels(2, 12, 14, seed=26, regime="stress"), 30, 0)
     for name, (vox, fps, t0) in cases.items():
         seed = 100 + len(name)
-        res, u = run_ref_ldati(vox, fps, t0, seed)
-        res_ieee, _ = run_ref_ldati(vox, fps, t0, seed, ieee_sqrt=True)
+        strategy = "none" if name == "none" else "slope"
+        res, u = run_ref_ldati(vox, fps, t0, seed, strategy=strategy)
+        res_ieee, _ = run_ref_ldati(vox, fps, t0, seed, ieee_sqrt=True, strategy=strategy)
         assert all(events_equal(a, b) for a, b in zip(res, res_ieee)), \
             f"{name}: MKL-VML sqrt and IEEE sqrt disagree on this fixture; pick another seed"
         B, _, _, H, W = vox.shape

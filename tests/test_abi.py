@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_argument_validation_without_gpu():
     L = hip.lib()
-    assert L.v2ce_ldati_count(None, 1, 4, 4, None, None, None) == -1
+    assert L.v2ce_ldati_count(None, 1, 4, 4, 0, None, None, None) == -1
     assert b"null" in L.v2ce_last_error()
     assert L.v2ce_ldati_lds_bytes(30.0, 0.0) > 0
     assert L.v2ce_ldati_lds_bytes(5.0, 0.0) == 0          # bin too wide for the LDS histogram

@@ -13,13 +13,14 @@ from v2ce_toolbox_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def hip_events(vox, fps=30, t0=0, uniforms=None, seed=None, frame_base=0, frame_ts_add=None, path="bucket"):
+def hip_events(vox, fps=30, t0=0, uniforms=None, seed=None, frame_base=0, frame_ts_add=None, path="bucket",
+               strategy="slope"):
     from v2ce_toolbox_amd.LDATI import ldati_device
     y = torch.from_numpy(np.ascontiguousarray(vox)).cuda()
     u = None if uniforms is None else torch.from_numpy(np.ascontiguousarray(uniforms)).cuda()
     add = None if frame_ts_add is None else torch.from_numpy(frame_ts_add).cuda()
     ev = ldati_device(y, t0=t0, fps=fps, uniforms=u, seed=seed, frame_base=frame_base, frame_ts_add=add,
-                      path=path)
+                      path=path, strategy=strategy)
     torch.cuda.synchronize()
     return ev
 
@@ -33,14 +34,15 @@ def soa_equal(ev, seg, ts, x, y, p):
 
 
 @pytest.mark.parametrize("path", ["bucket", "sweep"])
-@pytest.mark.parametrize("name", ["sparse", "frac", "stress", "t0fps60", "ragged"])
+@pytest.mark.parametrize("name", ["sparse", "frac", "stress", "t0fps60", "ragged", "none"])
 def test_replay_matches_reference_golden_and_oracle(gold_dir, name, path):
     z = np.load(os.path.join(gold_dir, f"ldati_g3_{name}.npz"))
     vox, u, fps, t0 = z["vox"], z["uniforms"], float(z["fps"]), float(z["t0"])
     ref = np.frombuffer(z["events"].tobytes(), O.EVENT_DTYPE)
-    ev = hip_events(vox, fps, t0, uniforms=u, path=path)
+    strategy = "none" if name == "none" else "slope"
+    ev = hip_events(vox, fps, t0, uniforms=u, path=path, strategy=strategy)
     # bit-exact vs the oracle, including the stable tie order
-    soa_equal(ev, *O.emit_soa(vox, fps=fps, t0=t0, uniforms=u))
+    soa_equal(ev, *O.emit_soa(vox, fps=fps, t0=t0, uniforms=u, strategy=strategy))
     # vs the reference's own output: exact up to the tie order its unstable argsort leaves open
     mine = np.concatenate(ev.to_recarrays()) if ev.num_events else np.empty(0, O.EVENT_DTYPE)
     assert np.array_equal(ev.frame_counts, z["lens"])
@@ -141,6 +143,9 @@ def test_option_errors():
         sample_voxel_statistical(y, pooling_type="bogus")
     with pytest.raises(NotImplementedError):
         sample_voxel_statistical(y, bidirectional=True)
+    with pytest.raises(NotImplementedError):
+        sample_voxel_statistical(y, additional_events_strategy="random")
+    assert len(sample_voxel_statistical(y, additional_events_strategy="none")) == 1
     with pytest.raises(Exception):
         sample_voxel_statistical(torch.zeros(1, 2, 10, 4, 4))      # CPU tensor: no CPU path
 

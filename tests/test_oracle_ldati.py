@@ -10,7 +10,7 @@ import pytest
 from oracle import ldati as O
 from v2ce_toolbox_amd import synth
 
-CASES = ["sparse", "frac", "stress", "t0fps60", "ragged"]
+CASES = ["sparse", "frac", "stress", "t0fps60", "ragged", "none"]
 
 
 def load_g3(gold_dir, name):
@@ -22,7 +22,8 @@ def load_g3(gold_dir, name):
 @pytest.mark.parametrize("name", CASES)
 def test_oracle_matches_reference_golden(gold_dir, name):
     vox, u, fps, t0, lens, ref = load_g3(gold_dir, name)
-    seg, ts, x, y, p = O.emit_soa(vox, fps=fps, t0=t0, uniforms=u)
+    strategy = "none" if name == "none" else "slope"       # additional_events_strategy
+    seg, ts, x, y, p = O.emit_soa(vox, fps=fps, t0=t0, uniforms=u, strategy=strategy)
     mine = np.asarray(O.pack(ts, x, y, p))
     assert np.array_equal(seg.sum(axis=1), lens)            # per-frame counts exact
     assert mine.dtype.itemsize == 13

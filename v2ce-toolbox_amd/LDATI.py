@@ -79,7 +79,7 @@ def _check_fps(fps) -> None:
 def ldati_device(y: torch.Tensor, t0=0, fps=30, *, rng: str = "philox", seed: Optional[int] = None,
                  frame_base: int = 0, uniforms: Optional[torch.Tensor] = None,
                  frame_ts_add: Optional[torch.Tensor] = None, profile: Optional[list] = None,
-                 path: str = "bucket") -> DeviceEvents:
+                 path: str = "bucket", strategy: str = "slope") -> DeviceEvents:
     """Run count -> scan -> emit on the device and leave the events there.
 
     y: [B,2,10,H,W] on a HIP device.  One host synchronisation (reading the B*9+1 segment offsets
@@ -100,7 +100,8 @@ def ldati_device(y: torch.Tensor, t0=0, fps=30, *, rng: str = "philox", seed: Op
     seg_counts = torch.empty(B * 9, dtype=torch.int64, device=dev)
     max_n_t = torch.empty(1, dtype=torch.int32, device=dev)
     offsets = torch.empty(B * 9 + 2, dtype=torch.int64, device=dev)
-    hip.check(L.v2ce_ldati_count(y.data_ptr(), B, H, W, seg_counts.data_ptr(), max_n_t.data_ptr(), st),
+    strat = {"slope": hip.STRATEGY_SLOPE, "none": hip.STRATEGY_NONE}[strategy]
+    hip.check(L.v2ce_ldati_count(y.data_ptr(), B, H, W, strat, seg_counts.data_ptr(), max_n_t.data_ptr(), st),
               "v2ce_ldati_count")
     hip.check(L.v2ce_ldati_scan(seg_counts.data_ptr(), B, offsets.data_ptr(), st), "v2ce_ldati_scan")
     offsets[B * 9 + 1:] = max_n_t.to(torch.int64)
@@ -146,7 +147,7 @@ def ldati_device(y: torch.Tensor, t0=0, fps=30, *, rng: str = "philox", seed: Op
         if profile is not None:    # HIP events on the launch stream around the emit kernels
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        hip.check(L.v2ce_ldati_emit(y.data_ptr(), B, H, W, float(fps), float(t0), mode, u_ptr,
+        hip.check(L.v2ce_ldati_emit(y.data_ptr(), B, H, W, float(fps), float(t0), strat, mode, u_ptr,
                                     int(replay_max_n), int(seed or 0) & (2 ** 64 - 1), int(frame_base),
                                     offsets.data_ptr(), add_ptr, ts.data_ptr(), x.data_ptr(),
                                     yy.data_ptr(), p.data_ptr(), total, max_seg, hip.ptr(ws),
@@ -172,11 +173,12 @@ def sample_voxel_statistical(y, t0=0, fps=30, pooling_type="none", pooling_kerne
     """
     assert pooling_type in ["avg", "weighted", "none"]                     # LDATI.py:135
     assert additional_events_strategy in ["none", "random", "slope"]       # LDATI.py:136
-    if pooling_type != "none" or additional_events_strategy != "slope" or bidirectional:
+    if pooling_type != "none" or additional_events_strategy == "random" or bidirectional:
         raise NotImplementedError(
-            "the HIP path implements pooling_type='none', additional_events_strategy='slope', "
-            "bidirectional=False (the configuration of v2ce.py:356)")
-    ev = ldati_device(y, t0=t0, fps=fps, rng=rng, seed=seed, frame_base=frame_base, uniforms=uniforms)
+            "the HIP path implements pooling_type='none', additional_events_strategy in "
+            "{'slope' (v2ce.py:356), 'none'}, bidirectional=False")
+    ev = ldati_device(y, t0=t0, fps=fps, rng=rng, seed=seed, frame_base=frame_base, uniforms=uniforms,
+                      strategy=additional_events_strategy)
     if strict_reference_errors and ev.max_n == 0:
         raise RuntimeError("max(): Expected reduction dim to be specified for input.numel() == 0 "
                            "(reference LDATI.py:200 raises on an event-free chunk)")

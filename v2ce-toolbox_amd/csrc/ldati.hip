@@ -39,6 +39,7 @@ struct LdatiParams {
     float offt[9];     // f32(arange(0,1/fps,1/fps/9)[c]) + f32(t0)
     long long kbase[9];  // key = timestamp - kbase[c], clamped to [0, NK)
     int NK, nbits;
+    int strategy;      // V2CE_STRATEGY_*: NONE drops every multi-event voxel (LDATI.py:206-207,241)
     int rng_mode;
     const float *uniforms;
     int replay_max_n;
@@ -173,7 +174,7 @@ constexpr int kCountPixPerBlock = 4096;   // 16 pixels per thread: 16x fewer (co
 
 __global__ __launch_bounds__(256) void ldati_count_kernel(const float *__restrict__ vox, int HW,
                                                           unsigned long long *seg_counts,
-                                                          int *max_n) {
+                                                          int *max_n, int strategy) {
     // grid: (pixel blocks, 2*B)
     const int bp = blockIdx.y;           // b*2 + p
     const int b = bp >> 1;
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256) void ldati_count_kernel(const float *__restric
             d = cc - r;
             int ni = (int)cc;
             if (i == 8) ni += (int)(yv[9] - d);
-            cnt[i] += ni > 0 ? ni : 0;
+            cnt[i] += (strategy == V2CE_STRATEGY_NONE) ? (ni == 1) : (ni > 0 ? ni : 0);
             mx = ni > mx ? ni : mx;
         }
     }
@@ -408,6 +409,7 @@ __global__ __launch_bounds__(256) void ldati_emit_kernel(LdatiParams P) {
     const int pidx = cat < 2 ? 1 : 0;    // negative events live in P index 1 (LDATI.py:289)
     const signed char pol = cat < 2 ? 0 : 1;
     const bool multi = cat & 1;
+    const bool skip = multi && P.strategy == V2CE_STRATEGY_NONE;   // wave-uniform
     int *my_start = s_start + (cat >> 1) * 64;
     float *my_k = s_k + (cat >> 1) * 64, *my_bb = s_bb + (cat >> 1) * 64;
 
@@ -415,7 +417,8 @@ __global__ __launch_bounds__(256) void ldati_emit_kernel(LdatiParams P) {
     __syncthreads();
 
     // A. histogram
-    if (multi)
+    if (skip) {
+    } else if (multi)
         sweep_multis<false>(b, c, pidx, cat, pol, lane, seg_lo, ts_add, cnt, my_start, my_k, my_bb, P);
     else
         sweep_singles<false>(b, c, pidx, cat, pol, lane, seg_lo, ts_add, cnt, P);
@@ -450,7 +453,8 @@ __global__ __launch_bounds__(256) void ldati_emit_kernel(LdatiParams P) {
     __syncthreads();
 
     // C. rank + scatter
-    if (multi)
+    if (skip) {
+    } else if (multi)
         sweep_multis<true>(b, c, pidx, cat, pol, lane, seg_lo, ts_add, cnt, my_start, my_k, my_bb, P);
     else
         sweep_singles<true>(b, c, pidx, cat, pol, lane, seg_lo, ts_add, cnt, P);
@@ -535,7 +539,7 @@ __global__ __launch_bounds__(256) void ldati_bucket_pass_kernel(LdatiParams P) {
             if (nc == 1) {
                 bucket_event<APPEND>(P, lds, c, seg_lo, single_ts(dbt[c], P.fps, P.offt[c]), cat_single,
                                      (unsigned)px);
-            } else {
+            } else if (P.strategy != V2CE_STRATEGY_NONE) {
                 float k, bb;
                 slope_params(c > 0 ? n[c - 1] : 0, nc, c < 8 ? n[c + 1] : 0, c, P, k, bb);
                 const long long ubase = (((long long)bp * 9 + c) * P.HW + px) * P.replay_max_n;
@@ -719,8 +723,8 @@ HostScalars host_scalars(double fps, double t0) {
 
 using namespace v2ce;
 
-extern "C" int v2ce_ldati_count(const float *vox, int B, int H, int W, int64_t *seg_counts,
-                                int32_t *max_n, v2ce_stream_t stream) {
+extern "C" int v2ce_ldati_count(const float *vox, int B, int H, int W, int strategy,
+                                int64_t *seg_counts, int32_t *max_n, v2ce_stream_t stream) {
     clear_error();
     V2CE_REQUIRE(vox && seg_counts && max_n, V2CE_ERR_BAD_ARG, "v2ce_ldati_count: null pointer");
     V2CE_REQUIRE(B > 0 && H > 0 && W > 0 && (long long)H * W < (1ll << 30), V2CE_ERR_BAD_ARG,
@@ -728,13 +732,15 @@ extern "C" int v2ce_ldati_count(const float *vox, int B, int H, int W, int64_t *
     V2CE_REQUIRE(W <= 32767 && H <= 32767, V2CE_ERR_UNSUPPORTED,
                  "v2ce_ldati_count: x/y are int16 (LDATI.py:230-231)");
     V2CE_REQUIRE(2 * B <= 65535, V2CE_ERR_UNSUPPORTED, "v2ce_ldati_count: B too large for one launch");
+    V2CE_REQUIRE(strategy == V2CE_STRATEGY_SLOPE || strategy == V2CE_STRATEGY_NONE, V2CE_ERR_UNSUPPORTED,
+                 "v2ce_ldati_count: strategy %d not implemented", strategy);
     hipStream_t s = as_stream(stream);
     V2CE_HIP_CHECK(hipMemsetAsync(seg_counts, 0, sizeof(int64_t) * 9 * (size_t)B, s));
     V2CE_HIP_CHECK(hipMemsetAsync(max_n, 0, sizeof(int32_t), s));
     const int HW = H * W;
     dim3 grid((HW + kCountPixPerBlock - 1) / kCountPixPerBlock, 2 * B);
     hipLaunchKernelGGL(ldati_count_kernel, grid, dim3(256), 0, s, vox, HW,
-                       reinterpret_cast<unsigned long long *>(seg_counts), max_n);
+                       reinterpret_cast<unsigned long long *>(seg_counts), max_n, strategy);
     V2CE_HIP_CHECK(hipGetLastError());
     return V2CE_OK;
 }
@@ -793,7 +799,7 @@ extern "C" size_t v2ce_ldati_workspace_bytes(int B, int H, int W, double fps, do
 }
 
 extern "C" int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps, double t0,
-                               int rng_mode, const float *uniforms, int replay_max_n,
+                               int strategy, int rng_mode, const float *uniforms, int replay_max_n,
                                uint64_t seed, int64_t frame_base, const int64_t *seg_offsets,
                                const int64_t *frame_ts_add, int64_t *ts, int16_t *x, int16_t *y,
                                int8_t *p, int64_t total_events, int64_t max_segment_events,
@@ -806,6 +812,8 @@ extern "C" int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps
     V2CE_REQUIRE(fps > 0, V2CE_ERR_BAD_ARG, "v2ce_ldati_emit: fps must be positive");
     V2CE_REQUIRE(rng_mode == V2CE_RNG_REPLAY || rng_mode == V2CE_RNG_PHILOX, V2CE_ERR_BAD_ARG,
                  "v2ce_ldati_emit: bad rng_mode %d", rng_mode);
+    V2CE_REQUIRE(strategy == V2CE_STRATEGY_SLOPE || strategy == V2CE_STRATEGY_NONE, V2CE_ERR_UNSUPPORTED,
+                 "v2ce_ldati_emit: strategy %d not implemented", strategy);
     V2CE_REQUIRE(rng_mode != V2CE_RNG_REPLAY || replay_max_n == 0 || uniforms != nullptr,
                  V2CE_ERR_BAD_ARG, "v2ce_ldati_emit: REPLAY mode needs the uniform tensor");
     const HostScalars h = host_scalars(fps, t0);
@@ -817,6 +825,7 @@ extern "C" int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps
     P.fps = fps; P.VS = h.VS; P.VS2 = h.VS2; P.INV = h.INV; P.FPS = h.FPS;
     for (int c = 0; c < 9; ++c) { P.offt[c] = h.offt[c]; P.kbase[c] = h.kbase[c]; }
     P.NK = h.NK; P.nbits = h.nbits;
+    P.strategy = strategy;
     P.rng_mode = rng_mode; P.uniforms = uniforms; P.replay_max_n = replay_max_n;
     P.seed = seed; P.frame_base = frame_base;
     P.seg_offsets = reinterpret_cast<const long long *>(seg_offsets);

@@ -17,6 +17,7 @@ CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.environ.get("V2CE_HIP_LIB", os.path.join(CSRC, "libv2ce_hip.so"))   # override: kernel A/B builds
 
 RNG_REPLAY, RNG_PHILOX = 0, 1
+STRATEGY_SLOPE, STRATEGY_NONE = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 
 EXPORTS = [
@@ -62,11 +63,11 @@ def lib() -> ctypes.CDLL:
                                   ctypes.c_uint64, ctypes.c_size_t)
     L.v2ce_version.restype = ctypes.c_char_p
     L.v2ce_last_error.restype = ctypes.c_char_p
-    L.v2ce_ldati_count.argtypes = [vp, i32, i32, i32, vp, vp, vp]
+    L.v2ce_ldati_count.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp]
     L.v2ce_ldati_scan.argtypes = [vp, i32, vp, vp]
     L.v2ce_ldati_lds_bytes.argtypes = [f64, f64]
     L.v2ce_ldati_lds_bytes.restype = sz
-    L.v2ce_ldati_emit.argtypes = [vp, i32, i32, i32, f64, f64, i32, vp, i32, u64, i64, vp, vp,
+    L.v2ce_ldati_emit.argtypes = [vp, i32, i32, i32, f64, f64, i32, i32, vp, i32, u64, i64, vp, vp,
                                   vp, vp, vp, vp, i64, i64, vp, sz, vp]
     L.v2ce_ldati_workspace_bytes.argtypes = [i32, i32, i32, f64, f64, i64, i64]
     L.v2ce_ldati_workspace_bytes.restype = sz
