@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="16-pair sequences per step per GPU")
     ap.add_argument("--workload", default="e2e", choices=["e2e", "ldati_stress", "ldati_sparse"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16x2"],
+                    help="stage-1 conv arithmetic: exact f32 MFMA (default) or the opt-in split-half path")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -95,7 +97,7 @@ def main():
                           dtype=torch.int64, device=device)
     model = None
     if args.workload == "e2e":
-        model = V2ce3d()
+        model = V2ce3d(precision=args.precision)
         model.load_state_dict(synth.make_state_dict(0))
         model = model.eval().to(device)
         x = make_inputs(b, rank * b, device)
@@ -205,7 +207,9 @@ def main():
             "metric": "frame-pairs/sec end-to-end (UNet+LDATI), 346x260",
             "value": total_pairs / dt, "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precision == "f32" else "f16x2-split (3 fp16 MFMAs per k-step, f32 accumulate, 1e-5 parity)",
+            "data": "synthetic",
             "config": {"workload": {"e2e": f"346x260 center, batch={b} sequences x 16 frame-pairs per GPU, "
                                            "V2ce3d (synthetic weights seed 0) + LDATI (Philox), inputs resident in HBM",
                                     "ldati_stress": "LDATI only, 24 frame-pairs of 6*U[0,1) voxels (C5 stress)",

@@ -122,7 +122,17 @@ typedef struct {
     int32_t stride_hw;  /* 1 or 2 */
     int32_t act;        /* V2CE_ACT_* */
     int32_t tile_t, tile_h, tile_w; /* output tile per workgroup; 0 = choose automatically */
+    int32_t precision;  /* V2CE_PRECISION_F32 (exact f32 MFMA) or V2CE_PRECISION_F16X2 (see below) */
 } v2ce_conv3d_desc;
+
+/* V2CE_PRECISION_F16X2 (3x3x3 kernels, channel counts multiples of 16): every operand is split into
+ * two fp16 numbers (22 bits) and each k-step is three v_mfma_f32_32x32x16_f16 with f32 accumulation;
+ * w_packed must then be the buffer written by v2ce_pack_weights_f16x2 (2*Cout*Cin*27 fp16).  Within
+ * the 1e-5 bar of the reference (tools/split_precision_sim.py); OPT-IN, the default is exact f32. */
+#define V2CE_PRECISION_F32 0
+#define V2CE_PRECISION_F16X2 1
+int v2ce_pack_weights_f16x2(const float *w, int Cout, int Cin, int k3, const float *sigma, void *w_f16x2,
+                            v2ce_stream_t stream);
 
 int v2ce_conv3d_fwd(const v2ce_conv3d_desc *desc, const float *x0, const float *x1,
                     const int32_t *hmap, const int32_t *wmap, const float *w_packed,

@@ -35,7 +35,7 @@ def test_argument_validation_without_gpu():
     assert L.v2ce_ldati_lds_bytes(5.0, 0.0) == 0          # bin too wide for the LDS histogram
     assert L.v2ce_sn_workspace_bytes(512, 13824) >= 4 * (512 + 13824)
     d = hip.ConvDesc(B=1, T=16, C0=64, H0=130, W0=173, C1=0, Hin=130, Win=173, Cout=64, Hout=130,
-                     Wout=173, ksize=5, stride_hw=1, act=1, tile_t=0, tile_h=0, tile_w=0)
+                     Wout=173, ksize=5, stride_hw=1, act=1, tile_t=0, tile_h=0, tile_w=0, precision=0)
     buf = ctypes.create_string_buffer(64)
     assert L.v2ce_conv3d_variant(ctypes.byref(d), 0, buf, 64) == -2     # ksize 5 unsupported
     d.ksize = 3

@@ -177,3 +177,65 @@ def test_v2ce3d_full_width_tile_vs_oracle():
     got = m(torch.from_numpy(x).cuda()).cpu().numpy()
     assert (want > 1).mean() > 1e-3          # the fixture exercises multi-event voxels
     assert_close(got, want, "346x260 L=2")
+
+
+# ---- opt-in split-half precision (V2CE_PRECISION_F16X2): same 1e-5 bar -------------------------
+def hip_conv_split(x0, w, scale, shift, stride, act, x1=None, up_to=None, residual=None):
+    from v2ce_toolbox_amd.v2ce_3d import V2ce3d
+    m = V2ce3d.__new__(V2ce3d)
+    torch.nn.Module.__init__(m)
+    m._maps = {}
+    wq = V2ce3d._pack(m, w.cuda().contiguous(), split=True)
+    y = V2ce3d._conv(m, to_btchw(x0).cuda(), None if x1 is None else to_btchw(x1).cuda(), wq,
+                     scale.cuda().contiguous(), shift.cuda().contiguous(), w.shape[0], 3, stride, act,
+                     residual=None if residual is None else to_btchw(residual).cuda(), up_to=up_to,
+                     split=True)
+    torch.cuda.synchronize()
+    return y.permute(0, 2, 1, 3, 4).cpu().numpy()
+
+
+SPLIT_CASES = [
+    # B, T, Cin, Cout, H, W, s, act, residual
+    (1, 16, 64, 64, 9, 11, 1, 1, True),
+    (2, 3, 32, 64, 19, 23, 2, 1, False),
+    (1, 2, 128, 128, 17, 22, 1, 0, False),
+    (1, 16, 32, 32, 40, 70, 1, 1, True),
+    (1, 4, 64, 32, 21, 30, 2, 0, False),
+]
+
+
+@pytest.mark.parametrize("case", SPLIT_CASES)
+def test_conv3d_split_half_vs_f64(case):
+    B, T, Cin, Cout, H, W, s, act, use_res = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(B, Cin, T, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) * (2.0 / (Cin * 27)) ** 0.5
+    scale = 0.5 + torch.rand(Cout, generator=g)
+    shift = 0.2 * torch.randn(Cout, generator=g)
+    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    res = torch.randn(B, Cout, T, Ho, Wo, generator=g) if use_res else None
+    got = hip_conv_split(x, w, scale, shift, s, act, residual=res)
+    want = ref_conv(x, w, scale, shift, 3, s, act, residual=res)
+    assert_close(got, want, "split " + str(case))
+
+
+def test_conv3d_split_half_virtual_concat():
+    g = torch.Generator().manual_seed(77)
+    x0 = torch.randn(1, 64, 3, 17, 22, generator=g)
+    x1 = torch.randn(1, 32, 3, 33, 44, generator=g)
+    w = torch.randn(32, 96, 3, 3, 3, generator=g) * (2.0 / (96 * 27)) ** 0.5
+    got = hip_conv_split(x0, w, torch.ones(32), torch.zeros(32), 1, 1, x1=x1, up_to=(33, 44))
+    want = ref_conv(x0, w, torch.ones(32), torch.zeros(32), 3, 1, 1, x1=x1, up_to=(33, 44))
+    assert_close(got, want, "split upsample+concat")
+
+
+def test_v2ce3d_split_half_matches_reference_three_calls(gold_dir):
+    """The reference goldens at the same 1e-5 bar with precision='f16x2'."""
+    from v2ce_toolbox_amd.v2ce_3d import V2ce3d
+    z = np.load(os.path.join(gold_dir, "unet_g1.npz"))
+    m = V2ce3d(precision="f16x2")
+    m.load_state_dict(synth.make_state_dict(0), strict=True)
+    m = m.eval().to("cuda")
+    for x, want in ((z["xa"], z["out1"]), (z["xa"], z["out2"]), (z["xb"], z["out3"])):
+        got = m(torch.from_numpy(x).cuda()).cpu().numpy()
+        assert_close(got, want, "split-half golden")

@@ -32,11 +32,19 @@ def run(name, B=4, T=16, iters=5, tile=(0, 0, 0)):
         wmap = (torch.arange(Win, device=dev) * W0 // Win).int()
     pad = k // 2
     Ho, Wo = (Hin + 2 * pad - k) // s + 1, (Win + 2 * pad - k) // s + 1
-    w = torch.randn((C0 + C1) * k ** 3 * Cout, device=dev) * 0.02
+    split = os.environ.get("PRECISION", "f32") == "f16x2" and k == 3
+    if split:
+        w32 = torch.randn(Cout, C0 + C1, k, k, k, device=dev) * 0.02
+        w = torch.empty(2 * w32.numel(), dtype=torch.float16, device=dev)
+        hip.check(hip.lib().v2ce_pack_weights_f16x2(w32.data_ptr(), Cout, C0 + C1, k ** 3, None, w.data_ptr(),
+                                                    hip.stream_ptr()), "pack")
+    else:
+        w = torch.randn((C0 + C1) * k ** 3 * Cout, device=dev) * 0.02
     sc, sh = torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev)
     y = torch.empty(B, T, Cout, Ho, Wo, device=dev)
     d = hip.ConvDesc(B=B, T=T, C0=C0, H0=H0, W0=W0, C1=C1, Hin=Hin, Win=Win, Cout=Cout, Hout=Ho, Wout=Wo,
-                     ksize=k, stride_hw=s, act=1, tile_t=tile[0], tile_h=tile[1], tile_w=tile[2])
+                     ksize=k, stride_hw=s, act=1, tile_t=tile[0], tile_h=tile[1], tile_w=tile[2],
+                     precision=1 if split else 0)
     lib = hip.lib()
 
     def call():

@@ -51,7 +51,14 @@ struct ConvParams {
     int n_pos;            // TT*TH*TW
     int n_spatial;        // B*nT*nH*nW
     int xcd_remap;        // 1: blocks that share an input box (different co tiles) share an XCD/L2
+    // split-half path (conv3d_f16x2_kernel): weights as fp16 hi/lo planes [2][K3][Cin/16][Cout][16]
+    const _Float16 *wq;
+    float inv_scale;      // 1 / (activation pre-scale * weight pre-scale)
 };
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr float kActScale = 16.0f;      // 2^4: keeps the low halves out of the fp16 subnormals
+constexpr float kWgtScale = 256.0f;     // 2^8
 
 template <int KS, int S, int CO_FR, int PO_FR, int CK, int EPT>
 struct ConvCfg {
@@ -349,6 +356,180 @@ __global__ __launch_bounds__(256, MW) void conv3d_kernel(ConvParams P) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Split-half variant: every operand is the sum of two fp16 numbers (x = (xh + xl)/16,
+// w = (wh + wl)/256) and each 16-channel k-step is three v_mfma_f32_32x32x16_f16
+// (wh.xh + wh.xl + wl.xh; products exact, f32 accumulation): 22-bit operands at 5.3x the f32 MFMA
+// rate per k-step.  tools/split_precision_sim.py shows the result stays 9x inside the 1e-5 bar.
+// Same tensors, tiling, halo gather and epilogue as conv3d_kernel; per 16-channel chunk the f32 halo
+// is DMA-staged, then converted once into position-major fp16 pieces ([piece][pos] x 16 B, piece =
+// plane*2 + channel half) so a B fragment is one ds_read_b128; weights come straight from L2 as
+// 16-byte A fragments, prefetched two taps ahead.
+// ---------------------------------------------------------------------------------------------
+template <int KS, int S, int WCO, int CO_FR, int PO_FR, int EPT>
+__global__ __launch_bounds__(256, 1) void conv3d_f16x2_kernel(ConvParams P) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int K3 = KS * KS * KS, CK = 16, WPO = 4 / WCO;
+    constexpr int CO_TILE = WCO * CO_FR * 32;
+    constexpr int PAD = KS / 2;
+    const int chs = (P.plane + 63) & ~63;
+    float *stage = reinterpret_cast<float *>(conv_smem);                       // [16][chs] f32
+    f16x8 *qb = reinterpret_cast<f16x8 *>(stage + CK * chs);                   // [4][chs] x 16 B
+
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = wave % WCO, wpo = wave / WCO;
+
+    int bid = blockIdx.x, co_t;
+    if (P.xcd_remap) {
+        const int xcd = bid & 7, q = bid >> 3;
+        co_t = q % P.n_co_tiles;
+        bid = (q / P.n_co_tiles) * 8 + xcd;
+        if (bid >= P.n_spatial) return;
+    } else {
+        co_t = bid % P.n_co_tiles;
+        bid /= P.n_co_tiles;
+    }
+    const int iw = bid % P.nW;            bid /= P.nW;
+    const int ih = bid % P.nH;            bid /= P.nH;
+    const int it = bid % P.nT;            bid /= P.nT;
+    const int b = bid;
+    const int co0 = co_t * CO_TILE + wco * CO_FR * 32;     // this wave's first channel
+    const int t0 = it * P.TT, h0 = ih * P.TH, w0 = iw * P.TW;
+    const int tin0 = t0 - PAD, hin0 = h0 * S - PAD, win0 = w0 * S - PAD;
+
+    int hoff[PO_FR], poff[PO_FR];
+#pragma unroll
+    for (int f = 0; f < PO_FR; ++f) {
+        const int m = (wpo * PO_FR + f) * 32 + l32;
+        hoff[f] = 0;
+        poff[f] = -1;
+        if (m < P.n_pos) {
+            const int tt = m / (P.TH * P.TW);
+            const int rem = m - tt * (P.TH * P.TW);
+            const int th = rem / P.TW;
+            const int tw = rem - th * P.TW;
+            hoff[f] = (tt * P.HH + th * S) * P.HWd + tw * S;
+            const int t = t0 + tt, h = h0 + th, w = w0 + tw;
+            if (t < P.T && h < P.Hout && w < P.Wout)
+                poff[f] = (t * P.Cout) * (P.Hout * P.Wout) + h * P.Wout + w;
+        }
+    }
+
+    // this lane's A-fragment source: channel co (clamped; rows >= Cout are never stored)
+    const int CG = P.Cin / CK;
+    const long long wplane = (long long)K3 * CG * P.Cout * 16;               // halves per plane
+    int wlane[CO_FR];
+#pragma unroll
+    for (int q = 0; q < CO_FR; ++q) {
+        int co = co0 + q * 32 + l32;
+        co = co < P.Cout ? co : P.Cout - 1;
+        wlane[q] = co * 16 + 8 * half;
+    }
+
+    f32x16 acc[CO_FR][PO_FR];
+#pragma unroll
+    for (int q = 0; q < CO_FR; ++q)
+#pragma unroll
+        for (int f = 0; f < PO_FR; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][f][r] = 0.0f;
+
+    DmaState<EPT, 1> D;
+    D.cur_src = -1;
+    D.src_cstride4 = 0;
+    D.src_cbase = 0;
+    D.woff[0] = kOOB;
+    D.rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x0), 0, 0, 0x00020000);
+    D.rs_in = D.rs_w;
+#define ISSUE16(ci0_, part_, nparts_) issue_chunk<KS, CK, EPT, 1, 0>(P, D, (ci0_), stage, chs, b, wave, tin0, hin0, win0, (part_), (nparts_))
+    ISSUE16(0, 0, 1);
+
+    for (int cg = 0; cg < CG; ++cg) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                       // chunk cg staged; every wave done with the fp16 pieces
+        // A fragments of taps 0 and 1 (independent of LDS: their latency hides behind the conversion)
+        f16x8 ah[3][CO_FR], al[3][CO_FR];
+        const _Float16 *wc = P.wq + (long long)cg * P.Cout * 16;
+#define V2CE_LOAD_W(slot_, tap_)                                                               \
+        {                                                                                      \
+            const _Float16 *wt_ = wc + (long long)(tap_) * CG * P.Cout * 16;                   \
+            _Pragma("unroll") for (int q = 0; q < CO_FR; ++q) {                                \
+                ah[slot_][q] = *reinterpret_cast<const f16x8 *>(wt_ + wlane[q]);               \
+                al[slot_][q] = *reinterpret_cast<const f16x8 *>(wt_ + wplane + wlane[q]);      \
+            }                                                                                  \
+        }
+        V2CE_LOAD_W(0, 0)
+        if constexpr (K3 > 1) V2CE_LOAD_W(1, 1)
+        // f32 channel-major staging -> position-major fp16 hi/lo pieces
+#pragma unroll
+        for (int hg = 0; hg < 2; ++hg) {
+            for (int r = tid; r < P.plane; r += 256) {
+                f16x8 vh, vl;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float v = stage[(8 * hg + c) * chs + r] * kActScale;
+                    const _Float16 hh = (_Float16)v;
+                    vh[c] = hh;
+                    vl[c] = (_Float16)(v - (float)hh);
+                }
+                qb[hg * chs + r] = vh;
+                qb[(2 + hg) * chs + r] = vl;
+            }
+        }
+        __syncthreads();                       // pieces ready; staging buffer free again
+        const bool more = cg + 1 < CG;
+        step_loop<0, K3>([&](auto tc) {
+            constexpr int tap = decltype(tc)::value;
+            constexpr int dt = tap / (KS * KS), dh = (tap / KS) % KS, dw = tap % KS;
+            if (more) ISSUE16((cg + 1) * CK, tap, K3);              // DMA of the next chunk, dealt over the taps
+            if constexpr (tap + 2 < K3) V2CE_LOAD_W((tap + 2) % 3, tap + 2)
+            const int toff = (dt * P.HH + dh) * P.HWd + dw;
+            f16x8 bh[PO_FR], bl[PO_FR];
+#pragma unroll
+            for (int f = 0; f < PO_FR; ++f) {
+                bh[f] = qb[half * chs + hoff[f] + toff];
+                bl[f] = qb[(2 + half) * chs + hoff[f] + toff];
+            }
+#pragma unroll
+            for (int q = 0; q < CO_FR; ++q)
+#pragma unroll
+                for (int f = 0; f < PO_FR; ++f) {
+                    acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tap % 3][q], bh[f], acc[q][f], 0, 0, 0);
+                    acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tap % 3][q], bl[f], acc[q][f], 0, 0, 0);
+                    acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tap % 3][q], bh[f], acc[q][f], 0, 0, 0);
+                }
+        });
+#undef V2CE_LOAD_W
+    }
+#undef ISSUE16
+
+    const long long ybase = (long long)b * P.T * P.Cout * (P.Hout * P.Wout);
+    const int cstride = P.Hout * P.Wout;
+#pragma unroll
+    for (int q = 0; q < CO_FR; ++q) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + q * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (co < P.Cout) {
+                const float sc = P.scale[co] * P.inv_scale, sh = P.shift[co];
+#pragma unroll
+                for (int f = 0; f < PO_FR; ++f) {
+                    if (poff[f] >= 0) {
+                        const long long idx = ybase + poff[f] + (long long)co * cstride;
+                        float v = acc[q][f][r] * sc + sh;
+                        if (P.res) v += P.res[idx];
+                        if (P.act == V2CE_ACT_RELU) v = v > 0.f ? v : 0.f;
+                        else if (P.act == V2CE_ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
+                        P.y[idx] = v;
+                    }
+                }
+            }
+        }
+    }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side: tile choice + dispatch
 // ---------------------------------------------------------------------------------------------
 struct Tile { int tt, th, tw; };
@@ -434,6 +615,58 @@ int launch(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream) {
     return V2CE_OK;
 }
 
+template <int KS, int S, int WCO, int CO_FR, int PO_FR, int EPT>
+int launch_f16x2(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream) {
+    constexpr int CO_TILE = WCO * CO_FR * 32, POS_TILE = (4 / WCO) * PO_FR * 32, MAX_PLANE = 256 * EPT;
+    if (g_name_out) {
+        snprintf(g_name_out, g_name_cap, "conv3d_f16x2_kernel<%d,%d,%d,%d,%d,%d>", KS, S, WCO, CO_FR, PO_FR, EPT);
+        return V2CE_OK;
+    }
+    const Tile t = choose_tile(d.T, d.Hout, d.Wout, KS, S, POS_TILE, MAX_PLANE);
+    P.TT = t.tt; P.TH = t.th; P.TW = t.tw;
+    P.n_pos = t.tt * t.th * t.tw;
+    P.HT = t.tt + KS - 1; P.HH = (t.th - 1) * S + KS; P.HWd = (t.tw - 1) * S + KS;
+    P.plane = P.HT * P.HH * P.HWd;
+    V2CE_REQUIRE(P.n_pos <= POS_TILE && P.plane <= MAX_PLANE, V2CE_ERR_UNSUPPORTED,
+                 "v2ce_conv3d_fwd(f16x2): tile does not fit");
+    P.nT = (d.T + t.tt - 1) / t.tt; P.nH = (d.Hout + t.th - 1) / t.th; P.nW = (d.Wout + t.tw - 1) / t.tw;
+    P.n_co_tiles = (d.Cout + CO_TILE - 1) / CO_TILE;
+    P.n_spatial = d.B * P.nT * P.nH * P.nW;
+    P.xcd_remap = P.n_co_tiles > 1 ? 1 : 0;
+    const long long blocks = P.xcd_remap ? (long long)((P.n_spatial + 7) / 8) * 8 * P.n_co_tiles
+                                         : (long long)P.n_spatial * P.n_co_tiles;
+    const int chs = (P.plane + 63) & ~63;
+    const size_t lds = (size_t)chs * (16 * 4 + 4 * 16);
+    V2CE_REQUIRE(lds <= 160 * 1024, V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd(f16x2): %zu B of LDS", lds);
+    auto kern = conv3d_f16x2_kernel<KS, S, WCO, CO_FR, PO_FR, EPT>;
+    V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, P);
+    V2CE_HIP_CHECK(hipGetLastError());
+    return V2CE_OK;
+}
+
+// wq[plane][tap][cg][co][16] = fp16 hi / lo of 256 * w[co][cg*16 + j][tap] / sigma
+__global__ __launch_bounds__(256) void pack_weights_f16x2_kernel(const float *__restrict__ w, int Cout,
+                                                                 int Cin, int k3, const float *sigma,
+                                                                 _Float16 *__restrict__ wq) {
+    const long long n = (long long)Cout * Cin * k3;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // ((tap*CG + cg)*Cout + co)*16 + j
+    if (i >= n) return;
+    const int j = (int)(i & 15);
+    long long r = i >> 4;
+    const int co = (int)(r % Cout); r /= Cout;
+    const int CG = Cin / 16;
+    const int cg = (int)(r % CG);
+    const int tap = (int)(r / CG);
+    float v = w[((long long)co * Cin + cg * 16 + j) * k3 + tap];
+    if (sigma) v = v / sigma[0];
+    v *= kWgtScale;
+    const _Float16 h = (_Float16)v;
+    wq[i] = h;
+    wq[n + i] = (_Float16)(v - (float)h);
+}
+
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float *__restrict__ w, int Cout,
                                                            int Cin, int k3, const float *sigma,
                                                            float *__restrict__ wp) {
@@ -488,8 +721,22 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
     P.act = d.act;
     hipStream_t st = as_stream(stream);
 
-    // CK per (ksize, stride): sized so 2 workgroups share a CU's 160 KiB of LDS
     const bool small_co = d.Cout <= 32;
+    if (d.precision == V2CE_PRECISION_F16X2) {
+        // split-half path: w_packed is the fp16 hi/lo buffer of v2ce_pack_weights_f16x2
+        V2CE_REQUIRE(d.ksize == 3 && P.Cin % 16 == 0 && (d.C1 == 0 || d.C0 % 16 == 0), V2CE_ERR_UNSUPPORTED,
+                     "v2ce_conv3d_fwd(f16x2): needs a 3x3x3 kernel and channel counts that are multiples of 16");
+        P.wq = reinterpret_cast<const _Float16 *>(w_packed);
+        P.inv_scale = 1.0f / (kActScale * kWgtScale);
+        if (s == 1) {
+            if (small_co) return launch_f16x2<3, 1, 1, 1, 2, 4>(P, d, st);
+            return launch_f16x2<3, 1, 2, 1, 4, 4>(P, d, st);
+        }
+        if (small_co) return launch_f16x2<3, 2, 1, 1, 1, 4>(P, d, st);
+        return launch_f16x2<3, 2, 2, 1, 2, 4>(P, d, st);
+    }
+    V2CE_REQUIRE(d.precision == V2CE_PRECISION_F32, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd: precision %d", d.precision);
+    // CK per (ksize, stride): sized so 2 workgroups share a CU's 160 KiB of LDS
     // fewer positions per workgroup when the launch would otherwise leave CUs idle
     const long long pos_total = (long long)d.B * d.T * d.Hout * d.Wout;
     const int co_tiles = small_co ? 1 : (d.Cout + 63) / 64;
@@ -574,6 +821,18 @@ extern "C" int v2ce_conv3d_variant(const v2ce_conv3d_desc *desc, int mapped, cha
                                    nullptr, nullptr);
     g_name_out = nullptr;
     return rc;
+}
+
+extern "C" int v2ce_pack_weights_f16x2(const float *w, int Cout, int Cin, int k3, const float *sigma,
+                                       void *w_f16x2, v2ce_stream_t stream) {
+    clear_error();
+    V2CE_REQUIRE(w && w_f16x2 && Cout > 0 && Cin > 0 && Cin % 16 == 0 && k3 == 27, V2CE_ERR_BAD_ARG,
+                 "v2ce_pack_weights_f16x2: needs a 3x3x3 kernel and Cin %% 16 == 0");
+    const long long n = (long long)Cout * Cin * k3;
+    hipLaunchKernelGGL(pack_weights_f16x2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       as_stream(stream), w, Cout, Cin, k3, sigma, static_cast<_Float16 *>(w_f16x2));
+    V2CE_HIP_CHECK(hipGetLastError());
+    return V2CE_OK;
 }
 
 extern "C" int v2ce_pack_weights(const float *w, int Cout, int Cin, int k3, const float *sigma,

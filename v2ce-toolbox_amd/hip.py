@@ -19,11 +19,12 @@ SO_PATH = os.environ.get("V2CE_HIP_LIB", os.path.join(CSRC, "libv2ce_hip.so"))  
 RNG_REPLAY, RNG_PHILOX = 0, 1
 STRATEGY_SLOPE, STRATEGY_NONE = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+PRECISION_F32, PRECISION_F16X2 = 0, 1
 
 EXPORTS = [
     "v2ce_version", "v2ce_last_error", "v2ce_ldati_count", "v2ce_ldati_scan",
     "v2ce_ldati_lds_bytes", "v2ce_ldati_workspace_bytes", "v2ce_ldati_emit", "v2ce_events_pack", "v2ce_conv3d_fwd",
-    "v2ce_conv3d_variant",
+    "v2ce_conv3d_variant", "v2ce_pack_weights_f16x2",
     "v2ce_pack_weights", "v2ce_sn_workspace_bytes", "v2ce_sn_power_iter", "v2ce_preprocess_pairs",
 ]
 
@@ -32,7 +33,7 @@ class ConvDesc(ctypes.Structure):
     """``v2ce_conv3d_desc`` (include/v2ce_hip.h)."""
     _fields_ = [(n, ctypes.c_int32) for n in (
         "B", "T", "C0", "H0", "W0", "C1", "Hin", "Win", "Cout", "Hout", "Wout", "ksize",
-        "stride_hw", "act", "tile_t", "tile_h", "tile_w")]
+        "stride_hw", "act", "tile_t", "tile_h", "tile_w", "precision")]
 
 
 class V2ceHipError(RuntimeError):
@@ -74,6 +75,8 @@ def lib() -> ctypes.CDLL:
     L.v2ce_events_pack.argtypes = [vp, vp, vp, vp, i64, vp, vp]
     L.v2ce_conv3d_fwd.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.v2ce_pack_weights.argtypes = [vp, i32, i32, i32, vp, vp, vp]
+    L.v2ce_pack_weights_f16x2.argtypes = [vp, i32, i32, i32, vp, vp, vp]
+    L.v2ce_pack_weights_f16x2.restype = ctypes.c_int
     L.v2ce_conv3d_variant.argtypes = [ctypes.POINTER(ConvDesc), i32, ctypes.c_char_p, sz]
     L.v2ce_preprocess_pairs.argtypes = [vp, i32, i32, i32, ctypes.c_float, ctypes.c_float, vp, vp]
     L.v2ce_preprocess_pairs.restype = ctypes.c_int

@@ -117,8 +117,14 @@ def _nearest_map(n_in: int, n_out: int) -> np.ndarray:
 class V2ce3d(nn.Module):
     """Drop-in for ``scripts/v2ce_3d.py:12``: ``V2ce3d()(x[B,L,2,H,W]) -> [B,L,20,H,W]``."""
 
-    def __init__(self, in_channels=2, out_channels=20):
+    def __init__(self, in_channels=2, out_channels=20, precision: str = "f32"):
+        """precision: "f32" (default: exact f32 MFMA) or "f16x2" (opt-in: the 3x3x3 convolutions of
+        the residual blocks run as 3 fp16 MFMAs on operands split into two halves, 22 bits; within
+        the 1e-5 bar, see tools/split_precision_sim.py)."""
         super().__init__()
+        if precision not in ("f32", "f16x2"):
+            raise ValueError(f"precision must be 'f32' or 'f16x2', got {precision!r}")
+        self.precision = precision
         self.in_channels, self.out_channels = in_channels, out_channels
         self.UNet = _UNet3D(in_channels, out_channels)
         self._prep = None          # device-side derived constants (packed weights, folded BN)
@@ -152,9 +158,16 @@ class V2ce3d(nn.Module):
             shift = shift + conv_bias * scale
         return scale.float().contiguous(), shift.float().contiguous()
 
-    def _pack(self, w, sigma=None, out=None):
+    def _pack(self, w, sigma=None, out=None, split=False):
         cout, cin = w.shape[0], w.shape[1]
         k3 = w.shape[2] * w.shape[3] * w.shape[4]
+        if split:      # fp16 hi/lo planes for the split-half conv path
+            if out is None:
+                out = torch.empty(2 * cin * k3 * cout, dtype=torch.float16, device=w.device)
+            hip.check(hip.lib().v2ce_pack_weights_f16x2(w.data_ptr(), cout, cin, k3, hip.ptr(sigma),
+                                                        out.data_ptr(), hip.stream_ptr(w.device)),
+                      "v2ce_pack_weights_f16x2")
+            return out
         if out is None:
             out = torch.empty(cin * k3 * cout, dtype=torch.float32, device=w.device)
         hip.check(hip.lib().v2ce_pack_weights(w.data_ptr(), cout, cin, k3, hip.ptr(sigma),
@@ -171,6 +184,7 @@ class V2ce3d(nn.Module):
             if p.dtype != torch.float32:
                 raise hip.V2ceHipError("V2ce3d: parameters must be float32")
         P = {}
+        split = self.precision == "f16x2"     # all residual-block 3x3x3 convs have Cin % 16 == 0
         ones = lambda c: torch.ones(c, dtype=torch.float32, device=dev)
         h = self.UNet.head.conv3d
         P["head"] = (self._pack(h.weight.contiguous()), ones(h.weight.shape[0]), h.bias.float().contiguous())
@@ -189,11 +203,12 @@ class V2ce3d(nn.Module):
                     for cn in ("conv1", "conv2"):
                         m = getattr(blk, cn).module
                         rows, cols = m.weight_bar.shape[0], m.weight_bar[0].numel()
-                        d[cn + "_w"] = torch.empty(rows * cols, dtype=torch.float32, device=dev)
+                        d[cn + "_w"] = (torch.empty(2 * rows * cols, dtype=torch.float16, device=dev)
+                                        if split else torch.empty(rows * cols, dtype=torch.float32, device=dev))
                         sn_ws = max(sn_ws, hip.lib().v2ce_sn_workspace_bytes(rows, cols))
                 else:
-                    d["conv1_w"] = self._pack(blk.conv1.weight.contiguous())
-                    d["conv2_w"] = self._pack(blk.conv2.weight.contiguous())
+                    d["conv1_w"] = self._pack(blk.conv1.weight.contiguous(), split=split)
+                    d["conv2_w"] = self._pack(blk.conv2.weight.contiguous(), split=split)
                 P[f"{name}{i}"] = d
         P["sn_ws"] = torch.empty(max(sn_ws, 16), dtype=torch.uint8, device=dev)
         P["sigma"] = torch.empty(1, dtype=torch.float32, device=dev)
@@ -207,7 +222,7 @@ class V2ce3d(nn.Module):
 
     # ---- kernels ------------------------------------------------------------------------------
     def _conv(self, x0, x1, w_packed, scale, shift, cout, ksize, stride, act, residual=None,
-              up_to=None):
+              up_to=None, split=False):
         """x0 [B,T,C0,H0,W0] (optionally nearest-upsampled to ``up_to``), x1 [B,T,C1,Hin,Win]."""
         B, T, C0, H0, W0 = x0.shape
         Hin, Win = up_to if up_to is not None else (H0, W0)
@@ -221,7 +236,8 @@ class V2ce3d(nn.Module):
         y = torch.empty((B, T, cout, Hout, Wout), dtype=torch.float32, device=x0.device)
         d = hip.ConvDesc(B=B, T=T, C0=C0, H0=H0, W0=W0, C1=C1, Hin=Hin, Win=Win, Cout=cout,
                          Hout=Hout, Wout=Wout, ksize=ksize, stride_hw=stride, act=act,
-                         tile_t=0, tile_h=0, tile_w=0)
+                         tile_t=0, tile_h=0, tile_w=0,
+                         precision=hip.PRECISION_F16X2 if split else hip.PRECISION_F32)
         prof = getattr(self, "profile", None)
         if prof is not None:       # HIP events on the launch stream (torch's current stream)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -247,16 +263,17 @@ class V2ce3d(nn.Module):
                                                P["sn_ws"].numel(),
                                                hip.stream_ptr(inner.weight_bar.device)),
                   "v2ce_sn_power_iter")
-        return self._pack(inner.weight_bar, P["sigma"], out)
+        return self._pack(inner.weight_bar, P["sigma"], out, split=self.precision == "f16x2")
 
     def _block(self, blk: _ResidualBlock3D, d, x0, x1=None, up_to=None):
         """submodules.py:249-264: relu(bn2(conv2(relu(bn1(conv1 x)))) + bn_d(conv_d x))."""
         s = blk.stride_hw
         w1 = self._sn_weight(blk.conv1.module, d["conv1_w"]) if blk.sn else d["conv1_w"]
-        t = self._conv(x0, x1, w1, *d["bn1"], blk.cout, 3, s, hip.ACT_RELU, up_to=up_to)
+        split = self.precision == "f16x2"
+        t = self._conv(x0, x1, w1, *d["bn1"], blk.cout, 3, s, hip.ACT_RELU, up_to=up_to, split=split)
         res = self._conv(x0, x1, d["down_w"], *d["down_bn"], blk.cout, 1, s, hip.ACT_NONE, up_to=up_to)
         w2 = self._sn_weight(blk.conv2.module, d["conv2_w"]) if blk.sn else d["conv2_w"]
-        return self._conv(t, None, w2, *d["bn2"], blk.cout, 3, 1, hip.ACT_RELU, residual=res)
+        return self._conv(t, None, w2, *d["bn2"], blk.cout, 3, 1, hip.ACT_RELU, residual=res, split=split)
 
     @torch.no_grad()
     def advance_spectral_norm(self):
