@@ -730,9 +730,13 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
         P.inv_scale = 1.0f / (kActScale * kWgtScale);
         if (s == 1) {
             if (small_co) return launch_f16x2<3, 1, 1, 1, 2, 4>(P, d, st);
-            return launch_f16x2<3, 1, 2, 1, 4, 4>(P, d, st);
+            // measured (tools/conv_bench.py): 128 channels x 256 positions per workgroup (24 MFMAs per
+            // A/B fragment set) 320 TF-equivalent; 64-channel layers: 64 x 128 boxes, 207
+            if (d.Cout >= 128) return launch_f16x2<3, 1, 2, 2, 4, 4>(P, d, st);
+            return launch_f16x2<3, 1, 2, 1, 2, 4>(P, d, st);
         }
         if (small_co) return launch_f16x2<3, 2, 1, 1, 1, 4>(P, d, st);
+        if (d.Cout >= 128) return launch_f16x2<3, 2, 2, 2, 2, 4>(P, d, st);   // 180-198 TF-equivalent
         return launch_f16x2<3, 2, 2, 1, 2, 4>(P, d, st);
     }
     V2CE_REQUIRE(d.precision == V2CE_PRECISION_F32, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd: precision %d", d.precision);

@@ -184,7 +184,6 @@ class V2ce3d(nn.Module):
             if p.dtype != torch.float32:
                 raise hip.V2ceHipError("V2ce3d: parameters must be float32")
         P = {}
-        split = self.precision == "f16x2"     # all residual-block 3x3x3 convs have Cin % 16 == 0
         ones = lambda c: torch.ones(c, dtype=torch.float32, device=dev)
         h = self.UNet.head.conv3d
         P["head"] = (self._pack(h.weight.contiguous()), ones(h.weight.shape[0]), h.bias.float().contiguous())
@@ -195,6 +194,7 @@ class V2ce3d(nn.Module):
                              ("dec", self.UNet.decoders)):
             for i, blk in enumerate(blocks):
                 d = {}
+                split = self._split(blk)
                 d["bn1"] = self._fold_bn(blk.bn1)
                 d["bn2"] = self._fold_bn(blk.bn2)
                 d["down_w"] = self._pack(blk.downsample[0].weight.contiguous())
@@ -213,6 +213,12 @@ class V2ce3d(nn.Module):
         P["sn_ws"] = torch.empty(max(sn_ws, 16), dtype=torch.uint8, device=dev)
         P["sigma"] = torch.empty(1, dtype=torch.float32, device=dev)
         self._prep = P
+
+    def _split(self, blk) -> bool:
+        """Split-half arithmetic for this block's 3x3x3 convs?  All blocks have Cin % 16 == 0; with
+        only 32 output channels a workgroup has too few MFMAs per A/B fragment set and the exact-f32
+        kernel is faster (measured: 128 vs 113 TF-equivalent), so those stay f32."""
+        return self.precision == "f16x2" and blk.cout > 32
 
     def _map(self, n_in, n_out, dev):
         key = (n_in, n_out, str(dev))
@@ -263,13 +269,13 @@ class V2ce3d(nn.Module):
                                                P["sn_ws"].numel(),
                                                hip.stream_ptr(inner.weight_bar.device)),
                   "v2ce_sn_power_iter")
-        return self._pack(inner.weight_bar, P["sigma"], out, split=self.precision == "f16x2")
+        return self._pack(inner.weight_bar, P["sigma"], out, split=out.dtype == torch.float16)
 
     def _block(self, blk: _ResidualBlock3D, d, x0, x1=None, up_to=None):
         """submodules.py:249-264: relu(bn2(conv2(relu(bn1(conv1 x)))) + bn_d(conv_d x))."""
         s = blk.stride_hw
         w1 = self._sn_weight(blk.conv1.module, d["conv1_w"]) if blk.sn else d["conv1_w"]
-        split = self.precision == "f16x2"
+        split = self._split(blk)
         t = self._conv(x0, x1, w1, *d["bn1"], blk.cout, 3, s, hip.ACT_RELU, up_to=up_to, split=split)
         res = self._conv(x0, x1, d["down_w"], *d["down_bn"], blk.cout, 1, s, hip.ACT_NONE, up_to=up_to)
         w2 = self._sn_weight(blk.conv2.module, d["conv2_w"]) if blk.sn else d["conv2_w"]
