@@ -127,16 +127,26 @@ typedef struct {
 
 /* V2CE_PRECISION_F16X2 (3x3x3 kernels, channel counts multiples of 16): every operand is split into
  * two fp16 numbers (22 bits) and each k-step is three v_mfma_f32_32x32x16_f16 with f32 accumulation;
- * w_packed must then be the buffer written by v2ce_pack_weights_f16x2 (2*Cout*Cin*27 fp16).  Within
- * the 1e-5 bar of the reference (tools/split_precision_sim.py); OPT-IN, the default is exact f32. */
+ * w_packed must then be the buffer written by v2ce_pack_weights_f16x2
+ * (v2ce_pack_weights_f16x2_bytes: two fp16 planes of Cout*Cin*27 + {max |w|, pre-scale} as 2 floats;
+ * the weight pre-scale is the power of two that puts max |w/sigma| in [2^14, 2^15)).  Error against an
+ * f64 evaluation equals the exact-f32 path's (profiles/r01_d_precision_report.json). */
 #define V2CE_PRECISION_F32 0
 #define V2CE_PRECISION_F16X2 1
+size_t v2ce_pack_weights_f16x2_bytes(int Cout, int Cin, int k3);
 int v2ce_pack_weights_f16x2(const float *w, int Cout, int Cin, int k3, const float *sigma, void *w_f16x2,
                             v2ce_stream_t stream);
 
+/* Range tracking (all three may be NULL): y_absmax [1] device float, zeroed by the caller, receives
+ * max |y| of the launch by atomic max.  x0_absmax / x1_absmax [1] are the slots the launches that
+ * produced x0 / x1 wrote (any upper bound of max |x| works); the split-half kernel derives its
+ * power-of-two activation pre-scale from them on the device, so no magnitude can overflow fp16.
+ * With x0_absmax NULL the split-half kernel uses the fixed pre-scale 16 and requires |x| < 4094.
+ * Ignored (inputs) by the exact-f32 kernels; both precisions record y_absmax. */
 int v2ce_conv3d_fwd(const v2ce_conv3d_desc *desc, const float *x0, const float *x1,
                     const int32_t *hmap, const int32_t *wmap, const float *w_packed,
                     const float *scale, const float *shift, const float *residual, float *y,
+                    const float *x0_absmax, const float *x1_absmax, float *y_absmax,
                     v2ce_stream_t stream);
 
 /* Name of the kernel instantiation v2ce_conv3d_fwd would launch for desc ("conv3d_kernel<KS,S,

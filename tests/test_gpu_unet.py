@@ -34,6 +34,7 @@ def hip_conv(x0, w, scale, shift, ksize, stride, act, x1=None, up_to=None, resid
     m = V2ce3d.__new__(V2ce3d)
     torch.nn.Module.__init__(m)
     m._maps = {}
+    m.precision = "f32"
     wd = w.cuda().contiguous()
     wp = V2ce3d._pack(m, wd)
     y = V2ce3d._conv(m, to_btchw(x0).cuda(), None if x1 is None else to_btchw(x1).cuda(), wp,
@@ -180,13 +181,24 @@ def test_v2ce3d_full_width_tile_vs_oracle():
 
 
 # ---- opt-in split-half precision (V2CE_PRECISION_F16X2): same 1e-5 bar -------------------------
-def hip_conv_split(x0, w, scale, shift, stride, act, x1=None, up_to=None, residual=None):
+def hip_conv_split(x0, w, scale, shift, stride, act, x1=None, up_to=None, residual=None, tracked=False):
+    """tracked: pass max|x| slots like V2ce3d does (dynamic power-of-two pre-scale); otherwise the
+    kernel's fixed pre-scale (|x| < 4094)."""
     from v2ce_toolbox_amd.v2ce_3d import V2ce3d
     m = V2ce3d.__new__(V2ce3d)
     torch.nn.Module.__init__(m)
     m._maps = {}
+    m.precision = "f16x2" if tracked else "f32"
+    m._prep = {"absmax": torch.zeros(4, device="cuda")}
+    m._slot = 0
     wq = V2ce3d._pack(m, w.cuda().contiguous(), split=True)
-    y = V2ce3d._conv(m, to_btchw(x0).cuda(), None if x1 is None else to_btchw(x1).cuda(), wq,
+    x0d = to_btchw(x0).cuda()
+    x1d = None if x1 is None else to_btchw(x1).cuda()
+    if tracked:
+        x0d.absmax = x0d.abs().max().reshape(1)
+        if x1d is not None:
+            x1d.absmax = x1d.abs().max().reshape(1)
+    y = V2ce3d._conv(m, x0d, x1d, wq,
                      scale.cuda().contiguous(), shift.cuda().contiguous(), w.shape[0], 3, stride, act,
                      residual=None if residual is None else to_btchw(residual).cuda(), up_to=up_to,
                      split=True)
@@ -229,6 +241,40 @@ def test_conv3d_split_half_virtual_concat():
     assert_close(got, want, "split upsample+concat")
 
 
+@pytest.mark.parametrize("mag", [1e-6, 1.0, 3e4, 1e9])
+def test_conv3d_split_half_dynamic_range(mag):
+    """Activations and weights far outside the fp16 range: the tracked power-of-two pre-scales keep
+    the split-half result at f32 accuracy (relative to the output magnitude) and the launch records
+    max |y| for its consumer."""
+    g = torch.Generator().manual_seed(7)
+    x0 = torch.randn(1, 32, 2, 9, 12, generator=g) * mag
+    x1 = torch.randn(1, 32, 2, 17, 23, generator=g) * (mag * 1e-3)
+    w = torch.randn(64, 64, 3, 3, 3, generator=g) * (300.0 / mag)      # |w| beyond 256 for small mag
+    one, zero = torch.ones(64), torch.zeros(64)
+    got = hip_conv_split(x0, w, one, zero, 1, 0, x1=x1, up_to=(17, 23), tracked=True)
+    want = ref_conv(x0, w, one, zero, 3, 1, 0, x1=x1, up_to=(17, 23))
+    assert np.isfinite(got).all()
+    ref_mag = np.abs(want).max()
+    assert np.abs(got - want).max() <= 2e-6 * ref_mag
+
+
+def test_conv3d_records_output_absmax():
+    from v2ce_toolbox_amd.v2ce_3d import V2ce3d
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 16, 3, 10, 13, generator=g)
+    w = torch.randn(32, 16, 3, 3, 3, generator=g) * 0.1
+    for split in (False, True):
+        m = V2ce3d.__new__(V2ce3d)
+        torch.nn.Module.__init__(m)
+        m._maps, m.precision, m._slot = {}, "f16x2", 0
+        m._prep = {"absmax": torch.zeros(4, device="cuda")}
+        xd = to_btchw(x).cuda()
+        xd.absmax = xd.abs().max().reshape(1)
+        wp = V2ce3d._pack(m, w.cuda().contiguous(), split=split)
+        y = V2ce3d._conv(m, xd, None, wp, torch.ones(32).cuda(), torch.zeros(32).cuda(), 32, 3, 1, 2, split=split, track=True)
+        assert float(y.absmax) == float(y.abs().max())
+
+
 def test_v2ce3d_split_half_matches_reference_three_calls(gold_dir):
     """The reference goldens at the same 1e-5 bar with precision='f16x2'."""
     from v2ce_toolbox_amd.v2ce_3d import V2ce3d
@@ -239,3 +285,39 @@ def test_v2ce3d_split_half_matches_reference_three_calls(gold_dir):
     for x, want in ((z["xa"], z["out1"]), (z["xa"], z["out2"]), (z["xb"], z["out3"])):
         got = m(torch.from_numpy(x).cuda()).cpu().numpy()
         assert_close(got, want, "split-half golden")
+
+
+def test_precision_report_vs_f64_truth():
+    """Error of every arithmetic path against an f64 evaluation of the same network (346x260, L=2):
+    the CPU f32 restatement (what the reference computes), the exact-f32 HIP path and the split-half
+    HIP path.  All must sit inside the 1e-5 bar; the numbers go to gpurun_out/ for profiles/."""
+    import json
+    sd = synth.make_state_dict(0)
+    fr = synth.synthetic_frames(3, 260, 346, seed=1)
+    x = fr.astype(np.float32) / 255
+    x = np.stack([x[:-1], x[1:]], axis=1)
+    x = ((x - np.float32(0.153)) / np.float32(0.165))[None]
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in U.clone_state(sd).items()}
+    truth = U.forward(sd64, torch.from_numpy(x).double()).numpy()
+    cpu32 = U.forward(U.clone_state(sd), torch.from_numpy(x)).numpy().astype(np.float64)
+    rep = {"shape": list(truth.shape), "max_abs_truth": float(np.abs(truth).max())}
+
+    def stats(a):
+        d = np.abs(a - truth)
+        return {"max_abs": float(d.max()), "rms": float(np.sqrt((d ** 2).mean())),
+                "max_excess_over_1e-5_bar": float((d - TOL * np.abs(truth)).max())}
+
+    rep["cpu_f32_oracle"] = stats(cpu32)
+    from v2ce_toolbox_amd.v2ce_3d import V2ce3d
+    for prec in ("f32", "f16x2"):
+        m = V2ce3d(precision=prec)
+        m.load_state_dict(synth.make_state_dict(0), strict=True)
+        m = m.eval().to("cuda")
+        got = m(torch.from_numpy(x).cuda()).cpu().numpy().astype(np.float64)
+        rep["hip_" + prec] = stats(got)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/precision_report.json", "w") as f:
+        json.dump(rep, f, indent=1)
+    print(json.dumps(rep))
+    for k in ("cpu_f32_oracle", "hip_f32", "hip_f16x2"):
+        assert rep[k]["max_excess_over_1e-5_bar"] <= TOL, (k, rep[k])

@@ -35,7 +35,7 @@ def run(name, B=4, T=16, iters=5, tile=(0, 0, 0)):
     split = os.environ.get("PRECISION", "f32") == "f16x2" and k == 3
     if split:
         w32 = torch.randn(Cout, C0 + C1, k, k, k, device=dev) * 0.02
-        w = torch.empty(2 * w32.numel(), dtype=torch.float16, device=dev)
+        w = torch.empty(2 * w32.numel() + 4, dtype=torch.float16, device=dev)
         hip.check(hip.lib().v2ce_pack_weights_f16x2(w32.data_ptr(), Cout, C0 + C1, k ** 3, None, w.data_ptr(),
                                                     hip.stream_ptr()), "pack")
     else:
@@ -50,7 +50,7 @@ def run(name, B=4, T=16, iters=5, tile=(0, 0, 0)):
     def call():
         hip.check(lib.v2ce_conv3d_fwd(ctypes.byref(d), x0.data_ptr(), hip.ptr(x1), hip.ptr(hmap), hip.ptr(wmap),
                                       w.data_ptr(), sc.data_ptr(), sh.data_ptr(), None, y.data_ptr(),
-                                      hip.stream_ptr()), "conv")
+                                      None, None, None, hip.stream_ptr()), "conv")
     call()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

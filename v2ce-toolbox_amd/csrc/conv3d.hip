@@ -52,13 +52,28 @@ struct ConvParams {
     int n_spatial;        // B*nT*nH*nW
     int xcd_remap;        // 1: blocks that share an input box (different co tiles) share an XCD/L2
     // split-half path (conv3d_f16x2_kernel): weights as fp16 hi/lo planes [2][K3][Cin/16][Cout][16]
+    // followed by { max |w|, power-of-two pre-scale } as two floats (pack_weights_f16x2_kernel)
     const _Float16 *wq;
-    float inv_scale;      // 1 / (activation pre-scale * weight pre-scale)
+    // dynamic range tracking: y_absmax (may be null) receives max |y| of this launch by atomic max;
+    // x0_absmax / x1_absmax (may be null) are the slots the producers of x0 / x1 wrote -- the
+    // split-half kernel derives its power-of-two activation pre-scale from them
+    const float *x0_absmax, *x1_absmax;
+    float *y_absmax;
 };
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-constexpr float kActScale = 16.0f;      // 2^4: keeps the low halves out of the fp16 subnormals
-constexpr float kWgtScale = 256.0f;     // 2^8
+constexpr float kActScale = 16.0f;      // pre-scale when the caller tracks no range: |x| < 4094 required
+
+// power of two s with  amax * s  in [2^14, 2^15): the hi halves use the top of the fp16 range (max
+// 65504) and the lo halves stay normal for every element within 2^-15 of the maximum
+__host__ __device__ __forceinline__ float pow2_prescale(float amax) {
+    if (!(amax > 0.0f)) return 1.0f;
+    int e;
+    frexpf(amax, &e);                       // amax = m * 2^e, m in [0.5, 1)
+    int k = 15 - e;
+    k = k < -100 ? -100 : (k > 100 ? 100 : k);
+    return ldexpf(1.0f, k);
+}
 
 template <int KS, int S, int CO_FR, int PO_FR, int CK, int EPT>
 struct ConvCfg {
@@ -72,6 +87,16 @@ struct ConvCfg {
 constexpr unsigned kOOB = 0x80000000u;   // buffer voffset that is always out of range => load returns 0
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
+
+// wave-level max of m (>= 0), then one atomic max per wave on the float's bit pattern
+__device__ __forceinline__ void absmax_commit(float m, float *slot) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    // the running maximum settles after the first few workgroups: test before paying for the atomic
+    if ((threadIdx.x & 63) == 0 &&
+        __float_as_uint(m) > __atomic_load_n(reinterpret_cast<unsigned *>(slot), __ATOMIC_RELAXED))
+        atomicMax(reinterpret_cast<unsigned *>(slot), __float_as_uint(m));
+}
 
 // byte offsets (relative to the sequence base of the source tensor) of this thread's halo elements;
 // kOOB = zero padding (hardware range check of the buffer load supplies the zero).
@@ -331,6 +356,7 @@ __global__ __launch_bounds__(256, MW) void conv3d_kernel(ConvParams P) {
     // ---- epilogue: y = act(acc*scale + shift (+res))
     const long long ybase = (long long)b * P.T * P.Cout * (P.Hout * P.Wout);
     const int cstride = P.Hout * P.Wout;
+    float ymax = 0.0f;
 #pragma unroll
     for (int q = 0; q < CO_FR; ++q) {
 #pragma unroll
@@ -347,11 +373,13 @@ __global__ __launch_bounds__(256, MW) void conv3d_kernel(ConvParams P) {
                         if (P.act == V2CE_ACT_RELU) v = v > 0.f ? v : 0.f;
                         else if (P.act == V2CE_ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
                         P.y[idx] = v;
+                        ymax = fmaxf(ymax, fabsf(v));
                     }
                 }
             }
         }
     }
+    if (P.y_absmax) absmax_commit(ymax, P.y_absmax);
 #endif  // __HIP_DEVICE_COMPILE__ (the host pass only needs the launch stub)
 }
 
@@ -434,6 +462,16 @@ __global__ __launch_bounds__(256, 1) void conv3d_f16x2_kernel(ConvParams P) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[q][f][r] = 0.0f;
 
+    // pre-scales: weights carry theirs behind the fp16 planes; activations from the tracked range
+    const float w_scale = reinterpret_cast<const float *>(P.wq + 2 * wplane)[1];
+    float x_scale = kActScale;
+    if (P.x0_absmax) {
+        float am = *P.x0_absmax;
+        if (P.x1_absmax) am = fmaxf(am, *P.x1_absmax);
+        x_scale = pow2_prescale(am);
+    }
+    const float inv_scale = 1.0f / (x_scale * w_scale);     // a power of two: exact
+
     DmaState<EPT, 1> D;
     D.cur_src = -1;
     D.src_cstride4 = 0;
@@ -467,7 +505,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_f16x2_kernel(ConvParams P) {
                 f16x8 vh, vl;
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    const float v = stage[(8 * hg + c) * chs + r] * kActScale;
+                    const float v = stage[(8 * hg + c) * chs + r] * x_scale;
                     const _Float16 hh = (_Float16)v;
                     vh[c] = hh;
                     vl[c] = (_Float16)(v - (float)hh);
@@ -505,13 +543,14 @@ __global__ __launch_bounds__(256, 1) void conv3d_f16x2_kernel(ConvParams P) {
 
     const long long ybase = (long long)b * P.T * P.Cout * (P.Hout * P.Wout);
     const int cstride = P.Hout * P.Wout;
+    float ymax = 0.0f;
 #pragma unroll
     for (int q = 0; q < CO_FR; ++q) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + q * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             if (co < P.Cout) {
-                const float sc = P.scale[co] * P.inv_scale, sh = P.shift[co];
+                const float sc = P.scale[co] * inv_scale, sh = P.shift[co];
 #pragma unroll
                 for (int f = 0; f < PO_FR; ++f) {
                     if (poff[f] >= 0) {
@@ -521,11 +560,13 @@ __global__ __launch_bounds__(256, 1) void conv3d_f16x2_kernel(ConvParams P) {
                         if (P.act == V2CE_ACT_RELU) v = v > 0.f ? v : 0.f;
                         else if (P.act == V2CE_ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
                         P.y[idx] = v;
+                        ymax = fmaxf(ymax, fabsf(v));
                     }
                 }
             }
         }
     }
+    if (P.y_absmax) absmax_commit(ymax, P.y_absmax);
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
@@ -646,12 +687,30 @@ int launch_f16x2(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream) {
     return V2CE_OK;
 }
 
-// wq[plane][tap][cg][co][16] = fp16 hi / lo of 256 * w[co][cg*16 + j][tap] / sigma
+// tail[0] = max |w / sigma| (tail[0] zeroed by the caller)
+__global__ __launch_bounds__(256) void weights_absmax_kernel(const float *__restrict__ w, long long n,
+                                                             const float *sigma, float *tail) {
+    float m = 0.0f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float v = w[i];
+        if (sigma) v = v / sigma[0];
+        m = fmaxf(m, fabsf(v));
+    }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned *>(tail), __float_as_uint(m));
+}
+
+// wq[plane][tap][cg][co][16] = fp16 hi / lo of s * w[co][cg*16 + j][tap] / sigma, s = the power of two
+// that puts max |w/sigma| in [2^14, 2^15); tail = { max |w/sigma|, s } behind the two planes
 __global__ __launch_bounds__(256) void pack_weights_f16x2_kernel(const float *__restrict__ w, int Cout,
                                                                  int Cin, int k3, const float *sigma,
                                                                  _Float16 *__restrict__ wq) {
     const long long n = (long long)Cout * Cin * k3;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // ((tap*CG + cg)*Cout + co)*16 + j
+    float *tail = reinterpret_cast<float *>(wq + 2 * n);
+    const float w_scale = pow2_prescale(tail[0]);
+    if (i == 0) tail[1] = w_scale;
     if (i >= n) return;
     const int j = (int)(i & 15);
     long long r = i >> 4;
@@ -661,7 +720,7 @@ __global__ __launch_bounds__(256) void pack_weights_f16x2_kernel(const float *__
     const int tap = (int)(r / CG);
     float v = w[((long long)co * Cin + cg * 16 + j) * k3 + tap];
     if (sigma) v = v / sigma[0];
-    v *= kWgtScale;
+    v *= w_scale;
     const _Float16 h = (_Float16)v;
     wq[i] = h;
     wq[n + i] = (_Float16)(v - (float)h);
@@ -689,7 +748,8 @@ using namespace v2ce;
 static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const float *x1,
                            const int32_t *hmap, const int32_t *wmap, const float *w_packed,
                            const float *scale, const float *shift, const float *residual,
-                           float *y, v2ce_stream_t stream) {
+                           float *y, const float *x0_absmax, const float *x1_absmax, float *y_absmax,
+                           v2ce_stream_t stream) {
     clear_error();
     V2CE_REQUIRE(desc && (g_name_out || (x0 && w_packed && scale && shift && y)), V2CE_ERR_BAD_ARG,
                  "v2ce_conv3d_fwd: null pointer");
@@ -719,6 +779,7 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
     P.B = d.B; P.T = d.T; P.C0 = d.C0; P.H0 = d.H0; P.W0 = d.W0; P.C1 = d.C1; P.Hin = d.Hin;
     P.Win = d.Win; P.Cin = d.C0 + d.C1; P.Cout = d.Cout; P.Hout = d.Hout; P.Wout = d.Wout;
     P.act = d.act;
+    P.x0_absmax = x0_absmax; P.x1_absmax = d.C1 > 0 ? x1_absmax : nullptr; P.y_absmax = y_absmax;
     hipStream_t st = as_stream(stream);
 
     const bool small_co = d.Cout <= 32;
@@ -727,7 +788,8 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
         V2CE_REQUIRE(d.ksize == 3 && P.Cin % 16 == 0 && (d.C1 == 0 || d.C0 % 16 == 0), V2CE_ERR_UNSUPPORTED,
                      "v2ce_conv3d_fwd(f16x2): needs a 3x3x3 kernel and channel counts that are multiples of 16");
         P.wq = reinterpret_cast<const _Float16 *>(w_packed);
-        P.inv_scale = 1.0f / (kActScale * kWgtScale);
+        V2CE_REQUIRE(x0_absmax || !x1_absmax, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd(f16x2): x1_absmax without x0_absmax");
+        V2CE_REQUIRE(d.C1 == 0 || !x0_absmax || x1_absmax, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd(f16x2): x0_absmax without x1_absmax");
         if (s == 1) {
             if (small_co) return launch_f16x2<3, 1, 1, 1, 2, 4>(P, d, st);
             // measured (tools/conv_bench.py): 128 channels x 256 positions per workgroup (24 MFMAs per
@@ -809,9 +871,11 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
 extern "C" int v2ce_conv3d_fwd(const v2ce_conv3d_desc *desc, const float *x0, const float *x1,
                                const int32_t *hmap, const int32_t *wmap, const float *w_packed,
                                const float *scale, const float *shift, const float *residual,
-                               float *y, v2ce_stream_t stream) {
+                               float *y, const float *x0_absmax, const float *x1_absmax,
+                               float *y_absmax, v2ce_stream_t stream) {
     g_name_out = nullptr;
-    return conv3d_dispatch(desc, x0, x1, hmap, wmap, w_packed, scale, shift, residual, y, stream);
+    return conv3d_dispatch(desc, x0, x1, hmap, wmap, w_packed, scale, shift, residual, y, x0_absmax,
+                           x1_absmax, y_absmax, stream);
 }
 
 extern "C" int v2ce_conv3d_variant(const v2ce_conv3d_desc *desc, int mapped, char *name, size_t cap) {
@@ -822,9 +886,13 @@ extern "C" int v2ce_conv3d_variant(const v2ce_conv3d_desc *desc, int mapped, cha
     static const int32_t dummy_map = 0;
     const int32_t *m = mapped ? &dummy_map : nullptr;
     const int rc = conv3d_dispatch(desc, nullptr, nullptr, m, m, nullptr, nullptr, nullptr, nullptr,
-                                   nullptr, nullptr);
+                                   nullptr, nullptr, nullptr, nullptr, nullptr);
     g_name_out = nullptr;
     return rc;
+}
+
+extern "C" size_t v2ce_pack_weights_f16x2_bytes(int Cout, int Cin, int k3) {
+    return (size_t)Cout * Cin * k3 * 4 + 2 * sizeof(float);
 }
 
 extern "C" int v2ce_pack_weights_f16x2(const float *w, int Cout, int Cin, int k3, const float *sigma,
@@ -833,7 +901,12 @@ extern "C" int v2ce_pack_weights_f16x2(const float *w, int Cout, int Cin, int k3
     V2CE_REQUIRE(w && w_f16x2 && Cout > 0 && Cin > 0 && Cin % 16 == 0 && k3 == 27, V2CE_ERR_BAD_ARG,
                  "v2ce_pack_weights_f16x2: needs a 3x3x3 kernel and Cin %% 16 == 0");
     const long long n = (long long)Cout * Cin * k3;
-    hipLaunchKernelGGL(pack_weights_f16x2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+    float *tail = reinterpret_cast<float *>(static_cast<_Float16 *>(w_f16x2) + 2 * n);
+    V2CE_HIP_CHECK(hipMemsetAsync(tail, 0, 2 * sizeof(float), as_stream(stream)));
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(weights_absmax_kernel, dim3(nb < 1024 ? nb : 1024), dim3(256), 0, as_stream(stream), w, n,
+                       sigma, tail);
+    hipLaunchKernelGGL(pack_weights_f16x2_kernel, dim3(nb), dim3(256), 0,
                        as_stream(stream), w, Cout, Cin, k3, sigma, static_cast<_Float16 *>(w_f16x2));
     V2CE_HIP_CHECK(hipGetLastError());
     return V2CE_OK;

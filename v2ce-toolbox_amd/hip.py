@@ -24,7 +24,7 @@ PRECISION_F32, PRECISION_F16X2 = 0, 1
 EXPORTS = [
     "v2ce_version", "v2ce_last_error", "v2ce_ldati_count", "v2ce_ldati_scan",
     "v2ce_ldati_lds_bytes", "v2ce_ldati_workspace_bytes", "v2ce_ldati_emit", "v2ce_events_pack", "v2ce_conv3d_fwd",
-    "v2ce_conv3d_variant", "v2ce_pack_weights_f16x2",
+    "v2ce_conv3d_variant", "v2ce_pack_weights_f16x2", "v2ce_pack_weights_f16x2_bytes",
     "v2ce_pack_weights", "v2ce_sn_workspace_bytes", "v2ce_sn_power_iter", "v2ce_preprocess_pairs",
 ]
 
@@ -73,10 +73,12 @@ def lib() -> ctypes.CDLL:
     L.v2ce_ldati_workspace_bytes.argtypes = [i32, i32, i32, f64, f64, i64, i64]
     L.v2ce_ldati_workspace_bytes.restype = sz
     L.v2ce_events_pack.argtypes = [vp, vp, vp, vp, i64, vp, vp]
-    L.v2ce_conv3d_fwd.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.v2ce_conv3d_fwd.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 13
     L.v2ce_pack_weights.argtypes = [vp, i32, i32, i32, vp, vp, vp]
     L.v2ce_pack_weights_f16x2.argtypes = [vp, i32, i32, i32, vp, vp, vp]
     L.v2ce_pack_weights_f16x2.restype = ctypes.c_int
+    L.v2ce_pack_weights_f16x2_bytes.argtypes = [i32, i32, i32]
+    L.v2ce_pack_weights_f16x2_bytes.restype = sz
     L.v2ce_conv3d_variant.argtypes = [ctypes.POINTER(ConvDesc), i32, ctypes.c_char_p, sz]
     L.v2ce_preprocess_pairs.argtypes = [vp, i32, i32, i32, ctypes.c_float, ctypes.c_float, vp, vp]
     L.v2ce_preprocess_pairs.restype = ctypes.c_int

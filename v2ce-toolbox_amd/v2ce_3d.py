@@ -163,7 +163,7 @@ class V2ce3d(nn.Module):
         k3 = w.shape[2] * w.shape[3] * w.shape[4]
         if split:      # fp16 hi/lo planes for the split-half conv path
             if out is None:
-                out = torch.empty(2 * cin * k3 * cout, dtype=torch.float16, device=w.device)
+                out = self._split_buffer(cout, cin, k3, w.device)
             hip.check(hip.lib().v2ce_pack_weights_f16x2(w.data_ptr(), cout, cin, k3, hip.ptr(sigma),
                                                         out.data_ptr(), hip.stream_ptr(w.device)),
                       "v2ce_pack_weights_f16x2")
@@ -174,6 +174,12 @@ class V2ce3d(nn.Module):
                                               out.data_ptr(), hip.stream_ptr(w.device)),
                   "v2ce_pack_weights")
         return out
+
+    @staticmethod
+    def _split_buffer(cout, cin, k3, dev):
+        """fp16 hi/lo planes + the {max |w|, pre-scale} tail of v2ce_pack_weights_f16x2."""
+        return torch.empty(hip.lib().v2ce_pack_weights_f16x2_bytes(cout, cin, k3) // 2, dtype=torch.float16,
+                           device=dev)
 
     def _prepare(self):
         dev = self.UNet.head.conv3d.weight.device
@@ -203,7 +209,7 @@ class V2ce3d(nn.Module):
                     for cn in ("conv1", "conv2"):
                         m = getattr(blk, cn).module
                         rows, cols = m.weight_bar.shape[0], m.weight_bar[0].numel()
-                        d[cn + "_w"] = (torch.empty(2 * rows * cols, dtype=torch.float16, device=dev)
+                        d[cn + "_w"] = (self._split_buffer(rows, m.weight_bar.shape[1], 27, dev)
                                         if split else torch.empty(rows * cols, dtype=torch.float32, device=dev))
                         sn_ws = max(sn_ws, hip.lib().v2ce_sn_workspace_bytes(rows, cols))
                 else:
@@ -212,6 +218,9 @@ class V2ce3d(nn.Module):
                 P[f"{name}{i}"] = d
         P["sn_ws"] = torch.empty(max(sn_ws, 16), dtype=torch.uint8, device=dev)
         P["sigma"] = torch.empty(1, dtype=torch.float32, device=dev)
+        # one max-|y| slot per conv launch of a forward pass (split-half path: the consumer derives its
+        # power-of-two activation pre-scale from the producer's slot, all on the device)
+        P["absmax"] = torch.zeros(64, dtype=torch.float32, device=dev)
         self._prep = P
 
     def _split(self, blk) -> bool:
@@ -228,7 +237,7 @@ class V2ce3d(nn.Module):
 
     # ---- kernels ------------------------------------------------------------------------------
     def _conv(self, x0, x1, w_packed, scale, shift, cout, ksize, stride, act, residual=None,
-              up_to=None, split=False):
+              up_to=None, split=False, track=False):
         """x0 [B,T,C0,H0,W0] (optionally nearest-upsampled to ``up_to``), x1 [B,T,C1,Hin,Win]."""
         B, T, C0, H0, W0 = x0.shape
         Hin, Win = up_to if up_to is not None else (H0, W0)
@@ -244,6 +253,13 @@ class V2ce3d(nn.Module):
                          Hout=Hout, Wout=Wout, ksize=ksize, stride_hw=stride, act=act,
                          tile_t=0, tile_h=0, tile_w=0,
                          precision=hip.PRECISION_F16X2 if split else hip.PRECISION_F32)
+        a0 = a1 = ay = None
+        if track or split:         # range tracking for the split-half consumers (device side only)
+            ay = y.absmax = self._prep["absmax"][self._slot:self._slot + 1]
+            self._slot += 1
+            if split:          # untracked inputs (None) select the kernel's fixed pre-scale
+                a0 = getattr(x0, "absmax", None)
+                a1 = None if x1 is None or a0 is None else x1.absmax
         prof = getattr(self, "profile", None)
         if prof is not None:       # HIP events on the launch stream (torch's current stream)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -251,7 +267,8 @@ class V2ce3d(nn.Module):
         hip.check(hip.lib().v2ce_conv3d_fwd(ctypes.byref(d), x0.data_ptr(), hip.ptr(x1),
                                             hip.ptr(hmap), hip.ptr(wmap), w_packed.data_ptr(),
                                             scale.data_ptr(), shift.data_ptr(), hip.ptr(residual),
-                                            y.data_ptr(), hip.stream_ptr(x0.device)),
+                                            y.data_ptr(), hip.ptr(a0), hip.ptr(a1), hip.ptr(ay),
+                                            hip.stream_ptr(x0.device)),
                   "v2ce_conv3d_fwd")
         if prof is not None:
             e1.record()
@@ -277,9 +294,11 @@ class V2ce3d(nn.Module):
         w1 = self._sn_weight(blk.conv1.module, d["conv1_w"]) if blk.sn else d["conv1_w"]
         split = self._split(blk)
         t = self._conv(x0, x1, w1, *d["bn1"], blk.cout, 3, s, hip.ACT_RELU, up_to=up_to, split=split)
+        track = self.precision == "f16x2"      # the block output may feed a split-half conv
         res = self._conv(x0, x1, d["down_w"], *d["down_bn"], blk.cout, 1, s, hip.ACT_NONE, up_to=up_to)
         w2 = self._sn_weight(blk.conv2.module, d["conv2_w"]) if blk.sn else d["conv2_w"]
-        return self._conv(t, None, w2, *d["bn2"], blk.cout, 3, 1, hip.ACT_RELU, residual=res, split=split)
+        return self._conv(t, None, w2, *d["bn2"], blk.cout, 3, 1, hip.ACT_RELU, residual=res, split=split,
+                          track=track)
 
     @torch.no_grad()
     def advance_spectral_norm(self):
@@ -307,8 +326,12 @@ class V2ce3d(nn.Module):
         if self._prep is None:
             self._prepare()
         P, U = self._prep, self.UNet
+        self._slot = 0
+        if self.precision == "f16x2":
+            P["absmax"].zero_()
         inter = OrderedDict()
-        h = self._conv(x, None, *P["head"], BASE, 3, 1, hip.ACT_LEAKY)           # unet_2layer.py:341
+        h = self._conv(x, None, *P["head"], BASE, 3, 1, hip.ACT_LEAKY,           # unet_2layer.py:341
+                       track=self.precision == "f16x2")
         inter["head"] = h
         skips = []
         for i, blk in enumerate(U.encoders):                                     # :345-347
