@@ -14,6 +14,7 @@ L = [(260, 346), (130, 173), (65, 87), (33, 44), (17, 22)]
 LAYERS = {   # name: (C0, lvl0, C1, lvl_in, Cout, ksize, stride)
     "enc0.conv2": (64, 1, 0, 1, 64, 3, 1), "enc1.conv1": (64, 1, 0, 1, 128, 3, 2),
     "res0.conv1": (512, 4, 0, 4, 512, 3, 1), "enc0.conv1": (32, 0, 0, 0, 64, 3, 2), "enc3.conv1": (256, 3, 0, 3, 512, 3, 2), "dec1.conv1": (256, 3, 128, 2, 128, 3, 1),
+    "dec2.conv1": (128, 2, 64, 1, 64, 3, 1), "dec0.conv1": (512, 4, 256, 3, 256, 3, 1), "dec1.conv2": (128, 2, 0, 2, 128, 3, 1),
     "dec3.conv1": (64, 1, 32, 0, 32, 3, 1), "dec3.conv2": (32, 0, 0, 0, 32, 3, 1),
     "dec2.down": (128, 2, 64, 1, 64, 1, 1), "pred": (32, 0, 0, 0, 20, 1, 1), "enc0.down": (32, 0, 0, 0, 64, 1, 2),
 }

@@ -103,13 +103,13 @@ __device__ __forceinline__ void absmax_commit(float m, float *slot) {
 // Element r of the halo plane <-> LDS offset r inside the channel.
 template <int EPT>
 __device__ __forceinline__ void halo_offsets(const ConvParams &P, int tin0, int hin0, int win0,
-                                             bool src1, unsigned (&goff)[EPT]) {
+                                             bool src1, int tid, unsigned (&goff)[EPT]) {
     const int Cs = src1 ? P.C1 : P.C0;
     const int Hs = src1 ? P.Hin : P.H0, Ws = src1 ? P.Win : P.W0;
     const bool mapped = !src1 && P.hmap != nullptr;
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
-        const int r = threadIdx.x + 256 * i;
+        const int r = tid + 256 * i;
         unsigned off = kOOB;
         if (r < P.plane) {
             const int ht = r / (P.HH * P.HWd);
@@ -149,7 +149,7 @@ __device__ __forceinline__ void issue_chunk(const ConvParams &P, DmaState<EPT, W
     const int want_src = ci0 < P.C0 ? 0 : 1;
     if (want_src != D.cur_src) {   // uniform; at most twice per kernel
         D.cur_src = want_src;
-        halo_offsets<EPT>(P, tin0, hin0, win0, want_src == 1, D.goff);
+        halo_offsets<EPT>(P, tin0, hin0, win0, want_src == 1, wave * 64 + (int)(threadIdx.x & 63), D.goff);
         if (want_src == 0) {
             const long long seq = (long long)P.T * P.C0 * (P.H0 * P.W0);
             D.rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x0 + b * seq), 0,
@@ -571,6 +571,220 @@ __global__ __launch_bounds__(256, 1) void conv3d_f16x2_kernel(ConvParams P) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Split-half, wave-specialised (stride 1): the same arithmetic as conv3d_f16x2_kernel, but the
+// workgroup is 8 waves = 2 per SIMD with fixed roles.
+//   waves 4-7 (producers): LDS-DMA chunk c+1 of the f32 halo into the staging buffer, convert it to
+//       the fp16 hi/lo pieces of buffer (c+1)&1, issue the DMA of chunk c+2.  Each wave converts
+//       exactly the slices it DMA'd itself, so it only needs its own vmcnt(0), no barrier.
+//   waves 0-3 (consumers): per tap 8 ds_read_b128 + 4 global A-fragment loads + 24 MFMAs out of
+//       pieces buffer c&1; B fragments are refilled in place for the next tap as soon as the MFMAs
+//       that read them have issued, A fragments are double-buffered one tap ahead.
+// One workgroup barrier per 16-channel chunk hands buffer (c+1)&1 over.  The conversion, the DMA
+// issue and its branches never sit in the MFMA waves' instruction stream.
+// LDS: staging 64 B + 2 x 64 B of pieces per halo element.
+// ---------------------------------------------------------------------------------------------
+template <int S, int WCO, int CO_FR, int PO_FR>
+__global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int KS = 3, K3 = 27, CK = 16, EPT = 4, PAD = 1;
+    constexpr int WPO = 4 / WCO;
+    constexpr int CO_TILE = WCO * CO_FR * 32;
+    const int chs = (P.plane + 63) & ~63;
+    float *stage = reinterpret_cast<float *>(conv_smem);                       // [16][chs] f32
+    f16x8 *pieces = reinterpret_cast<f16x8 *>(stage + CK * chs);               // [2][4][chs] x 16 B
+
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    int bid = blockIdx.x, co_t;
+    if (P.xcd_remap) {
+        const int xcd = bid & 7, q = bid >> 3;
+        co_t = q % P.n_co_tiles;
+        bid = (q / P.n_co_tiles) * 8 + xcd;
+        if (bid >= P.n_spatial) return;
+    } else {
+        co_t = bid % P.n_co_tiles;
+        bid /= P.n_co_tiles;
+    }
+    const int iw = bid % P.nW;            bid /= P.nW;
+    const int ih = bid % P.nH;            bid /= P.nH;
+    const int it = bid % P.nT;            bid /= P.nT;
+    const int b = bid;
+    const int t0 = it * P.TT, h0 = ih * P.TH, w0 = iw * P.TW;
+    const int tin0 = t0 - PAD, hin0 = h0 * S - PAD, win0 = w0 * S - PAD;
+    const int CG = P.Cin / CK;
+    const long long wplane = (long long)K3 * CG * P.Cout * 16;               // halves per plane
+
+    const float w_scale = reinterpret_cast<const float *>(P.wq + 2 * wplane)[1];
+    float x_scale = kActScale;
+    if (P.x0_absmax) {
+        float am = *P.x0_absmax;
+        if (P.x1_absmax) am = fmaxf(am, *P.x1_absmax);
+        x_scale = pow2_prescale(am);
+    }
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ producers
+        const int pw = wave - 4, ptid = tid - 256;
+        DmaState<EPT, 1> D;
+        D.cur_src = -1;
+        D.src_cstride4 = 0;
+        D.src_cbase = 0;
+        D.woff[0] = kOOB;
+        D.rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x0), 0, 0, 0x00020000);
+        D.rs_in = D.rs_w;
+        issue_chunk<KS, CK, EPT, 1, 0>(P, D, 0, stage, chs, b, pw, tin0, hin0, win0, 0, 1);
+        for (int cg = 0; cg < CG; ++cg) {
+            f16x8 *qb = pieces + (cg & 1) * 4 * chs;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's slices of chunk cg landed
+            for (int r = ptid; r < P.plane; r += 256) {
+#pragma unroll
+                for (int hg = 0; hg < 2; ++hg) {
+                    f16x8 vh, vl;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const float v = stage[(8 * hg + c) * chs + r] * x_scale;
+                        const _Float16 hh = (_Float16)v;
+                        vh[c] = hh;
+                        vl[c] = (_Float16)(v - (float)hh);
+                    }
+                    qb[hg * chs + r] = vh;
+                    qb[(2 + hg) * chs + r] = vl;
+                }
+            }
+            if (cg + 1 < CG) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // staging reads done before the DMA overwrites
+                issue_chunk<KS, CK, EPT, 1, 0>(P, D, (cg + 1) * CK, stage, chs, b, pw, tin0, hin0, win0, 0, 1);
+            }
+            __syncthreads();                                          // barrier cg: pieces[cg & 1] ready
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers
+    __builtin_amdgcn_s_setprio(2);
+    const int wco = wave % WCO, wpo = wave / WCO;
+    const int co0 = co_t * CO_TILE + wco * CO_FR * 32;     // this wave's first channel
+    int bhb[PO_FR], poff[PO_FR];
+#pragma unroll
+    for (int f = 0; f < PO_FR; ++f) {
+        const int m = (wpo * PO_FR + f) * 32 + l32;
+        bhb[f] = half * chs;
+        poff[f] = -1;
+        if (m < P.n_pos) {
+            const int tt = m / (P.TH * P.TW);
+            const int rem = m - tt * (P.TH * P.TW);
+            const int th = rem / P.TW;
+            const int tw = rem - th * P.TW;
+            bhb[f] += (tt * P.HH + th * S) * P.HWd + tw * S;
+            const int t = t0 + tt, h = h0 + th, w = w0 + tw;
+            if (t < P.T && h < P.Hout && w < P.Wout)
+                poff[f] = (t * P.Cout) * (P.Hout * P.Wout) + h * P.Wout + w;
+        }
+    }
+    // A fragments: buffer loads with a per-lane byte offset (VGPR) and a per-(tap, chunk, plane)
+    // scalar offset, so no per-tap 64-bit addresses are kept in registers
+    int wlane[CO_FR];
+#pragma unroll
+    for (int q = 0; q < CO_FR; ++q) {
+        int co = co0 + q * 32 + l32;
+        co = co < P.Cout ? co : P.Cout - 1;
+        wlane[q] = (co * 16 + 8 * half) * 2;
+    }
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<_Float16 *>(P.wq), 0, (int)(4 * wplane), 0x00020000);
+    const int lo_off = (int)(2 * wplane);                  // bytes from the hi plane to the lo plane
+    const int tap_stride = CG * P.Cout * 32;               // bytes between taps
+    const int cg_stride = P.Cout * 32;                     // bytes between 16-channel groups
+
+    f32x16 acc[CO_FR][PO_FR];
+#pragma unroll
+    for (int q = 0; q < CO_FR; ++q)
+#pragma unroll
+        for (int f = 0; f < PO_FR; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][f][r] = 0.0f;
+
+    f16x8 ah[2][CO_FR], al[2][CO_FR], bh[PO_FR], bl[PO_FR];
+#define V2CE_LOAD_A(slot_, soff_)                                                              \
+    {                                                                                          \
+        const int so_ = (soff_);                                                               \
+        _Pragma("unroll") for (int q = 0; q < CO_FR; ++q) {                                    \
+            ah[slot_][q] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_a, wlane[q], so_, 0));          \
+            al[slot_][q] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_a, wlane[q], so_ + lo_off, 0)); \
+        }                                                                                      \
+    }
+    V2CE_LOAD_A(1, 0)                                      // chunk 0, tap 0 (moved to slot 0 below)
+    for (int cg = 0; cg < CG; ++cg) {
+        const f16x8 *qb = pieces + (cg & 1) * 4 * chs;
+        const int wc = cg * cg_stride;
+#pragma unroll
+        for (int q = 0; q < CO_FR; ++q) { ah[0][q] = ah[1][q]; al[0][q] = al[1][q]; }
+        __syncthreads();                                   // barrier cg: pieces[cg & 1] ready
+#pragma unroll
+        for (int f = 0; f < PO_FR; ++f) {
+            bh[f] = qb[bhb[f]];
+            bl[f] = qb[bhb[f] + 2 * chs];
+        }
+        step_loop<0, K3>([&](auto tc) {
+            constexpr int tap = decltype(tc)::value;
+            constexpr int nt = tap + 1;
+            constexpr int dt = nt / 9, dh = (nt / 3) % 3, dw = nt % 3;
+            if constexpr (nt < K3) {
+                V2CE_LOAD_A(nt & 1, wc + nt * tap_stride)
+            } else {
+                if (cg + 1 < CG) V2CE_LOAD_A(1, wc + cg_stride)       // next chunk, tap 0
+            }
+            const int toff = (dt * P.HH + dh) * P.HWd + dw;          // next tap's offset in the halo box
+#pragma unroll
+            for (int f = 0; f < PO_FR; ++f) {
+#pragma unroll
+                for (int q = 0; q < CO_FR; ++q) {
+                    acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tap & 1][q], bh[f], acc[q][f], 0, 0, 0);
+                    acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tap & 1][q], bl[f], acc[q][f], 0, 0, 0);
+                    acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tap & 1][q], bh[f], acc[q][f], 0, 0, 0);
+                }
+                if constexpr (nt < K3) {                 // refill in place for the next tap
+                    bh[f] = qb[bhb[f] + toff];
+                    bl[f] = qb[bhb[f] + toff + 2 * chs];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+    }
+#undef V2CE_LOAD_A
+
+    const float inv_scale = 1.0f / (x_scale * w_scale);     // a power of two: exact
+    const long long ybase = (long long)b * P.T * P.Cout * (P.Hout * P.Wout);
+    const int cstride = P.Hout * P.Wout;
+    float ymax = 0.0f;
+#pragma unroll
+    for (int q = 0; q < CO_FR; ++q) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + q * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (co < P.Cout) {
+                const float sc = P.scale[co] * inv_scale, sh = P.shift[co];
+#pragma unroll
+                for (int f = 0; f < PO_FR; ++f) {
+                    if (poff[f] >= 0) {
+                        const long long idx = ybase + poff[f] + (long long)co * cstride;
+                        float v = acc[q][f][r] * sc + sh;
+                        if (P.res) v += P.res[idx];
+                        if (P.act == V2CE_ACT_RELU) v = v > 0.f ? v : 0.f;
+                        else if (P.act == V2CE_ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
+                        P.y[idx] = v;
+                        ymax = fmaxf(ymax, fabsf(v));
+                    }
+                }
+            }
+        }
+    }
+    if (P.y_absmax) absmax_commit(ymax, P.y_absmax);
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side: tile choice + dispatch
 // ---------------------------------------------------------------------------------------------
 struct Tile { int tt, th, tw; };
@@ -701,6 +915,40 @@ __global__ __launch_bounds__(256) void weights_absmax_kernel(const float *__rest
     if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned *>(tail), __float_as_uint(m));
 }
 
+template <int S, int WCO, int CO_FR, int PO_FR>
+int launch_f16x2_ws(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream) {
+    constexpr int KS = 3;
+    constexpr int CO_TILE = WCO * CO_FR * 32, POS_TILE = (4 / WCO) * PO_FR * 32;
+    constexpr int MAX_PLANE = 832;          // 192 B of LDS per halo element (rounded to 64 elements)
+    if (g_name_out) {
+        snprintf(g_name_out, g_name_cap, "conv3d_f16x2_ws_kernel<%d,%d,%d,%d>", S, WCO, CO_FR, PO_FR);
+        return V2CE_OK;
+    }
+    Tile t{d.tile_t, d.tile_h, d.tile_w};
+    if (t.tt <= 0 || t.th <= 0 || t.tw <= 0) t = choose_tile(d.T, d.Hout, d.Wout, KS, S, POS_TILE, MAX_PLANE);
+    P.TT = t.tt; P.TH = t.th; P.TW = t.tw;
+    P.n_pos = t.tt * t.th * t.tw;
+    P.HT = t.tt + KS - 1; P.HH = (t.th - 1) * S + KS; P.HWd = (t.tw - 1) * S + KS;
+    P.plane = P.HT * P.HH * P.HWd;
+    V2CE_REQUIRE(P.n_pos <= POS_TILE && P.plane <= MAX_PLANE, V2CE_ERR_UNSUPPORTED,
+                 "v2ce_conv3d_fwd(f16x2 ws): tile does not fit");
+    P.nT = (d.T + t.tt - 1) / t.tt; P.nH = (d.Hout + t.th - 1) / t.th; P.nW = (d.Wout + t.tw - 1) / t.tw;
+    P.n_co_tiles = (d.Cout + CO_TILE - 1) / CO_TILE;
+    P.n_spatial = d.B * P.nT * P.nH * P.nW;
+    P.xcd_remap = P.n_co_tiles > 1 ? 1 : 0;
+    const long long blocks = P.xcd_remap ? (long long)((P.n_spatial + 7) / 8) * 8 * P.n_co_tiles
+                                         : (long long)P.n_spatial * P.n_co_tiles;
+    const int chs = (P.plane + 63) & ~63;
+    const size_t lds = (size_t)chs * (16 * 4 + 2 * 4 * 16);
+    V2CE_REQUIRE(lds <= 160 * 1024, V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd(f16x2 ws): %zu B of LDS", lds);
+    auto kern = conv3d_f16x2_ws_kernel<S, WCO, CO_FR, PO_FR>;
+    V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, stream, P);
+    V2CE_HIP_CHECK(hipGetLastError());
+    return V2CE_OK;
+}
+
 // wq[plane][tap][cg][co][16] = fp16 hi / lo of s * w[co][cg*16 + j][tap] / sigma, s = the power of two
 // that puts max |w/sigma| in [2^14, 2^15); tail = { max |w/sigma|, s } behind the two planes
 __global__ __launch_bounds__(256) void pack_weights_f16x2_kernel(const float *__restrict__ w, int Cout,
@@ -790,6 +1038,12 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
         P.wq = reinterpret_cast<const _Float16 *>(w_packed);
         V2CE_REQUIRE(x0_absmax || !x1_absmax, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd(f16x2): x1_absmax without x0_absmax");
         V2CE_REQUIRE(d.C1 == 0 || !x0_absmax || x1_absmax, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd(f16x2): x0_absmax without x1_absmax");
+        static const int ws = [] { const char *e = getenv("V2CE_WS"); return e ? atoi(e) : 1; }();
+        if (s == 1 && ws) {
+            if (small_co) return launch_f16x2_ws<1, 1, 1, 2>(P, d, st);
+            if (d.Cout >= 128) return launch_f16x2_ws<1, 2, 2, 4>(P, d, st);
+            return launch_f16x2_ws<1, 1, 2, 2>(P, d, st);
+        }
         if (s == 1) {
             if (small_co) return launch_f16x2<3, 1, 1, 1, 2, 4>(P, d, st);
             // measured (tools/conv_bench.py): 128 channels x 256 positions per workgroup (24 MFMAs per

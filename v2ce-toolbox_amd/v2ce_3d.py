@@ -200,7 +200,7 @@ class V2ce3d(nn.Module):
                              ("dec", self.UNet.decoders)):
             for i, blk in enumerate(blocks):
                 d = {}
-                split = self._split(blk)
+                splits = {"conv1": self._split(blk.cin, blk.cout), "conv2": self._split(blk.cout, blk.cout)}
                 d["bn1"] = self._fold_bn(blk.bn1)
                 d["bn2"] = self._fold_bn(blk.bn2)
                 d["down_w"] = self._pack(blk.downsample[0].weight.contiguous())
@@ -210,11 +210,11 @@ class V2ce3d(nn.Module):
                         m = getattr(blk, cn).module
                         rows, cols = m.weight_bar.shape[0], m.weight_bar[0].numel()
                         d[cn + "_w"] = (self._split_buffer(rows, m.weight_bar.shape[1], 27, dev)
-                                        if split else torch.empty(rows * cols, dtype=torch.float32, device=dev))
+                                        if splits[cn] else torch.empty(rows * cols, dtype=torch.float32, device=dev))
                         sn_ws = max(sn_ws, hip.lib().v2ce_sn_workspace_bytes(rows, cols))
                 else:
-                    d["conv1_w"] = self._pack(blk.conv1.weight.contiguous(), split=split)
-                    d["conv2_w"] = self._pack(blk.conv2.weight.contiguous(), split=split)
+                    d["conv1_w"] = self._pack(blk.conv1.weight.contiguous(), split=splits["conv1"])
+                    d["conv2_w"] = self._pack(blk.conv2.weight.contiguous(), split=splits["conv2"])
                 P[f"{name}{i}"] = d
         P["sn_ws"] = torch.empty(max(sn_ws, 16), dtype=torch.uint8, device=dev)
         P["sigma"] = torch.empty(1, dtype=torch.float32, device=dev)
@@ -223,11 +223,11 @@ class V2ce3d(nn.Module):
         P["absmax"] = torch.zeros(64, dtype=torch.float32, device=dev)
         self._prep = P
 
-    def _split(self, blk) -> bool:
-        """Split-half arithmetic for this block's 3x3x3 convs?  All blocks have Cin % 16 == 0; with
-        only 32 output channels a workgroup has too few MFMAs per A/B fragment set and the exact-f32
-        kernel is faster (measured: 128 vs 113 TF-equivalent), so those stay f32."""
-        return self.precision == "f16x2" and blk.cout > 32
+    def _split(self, cin, cout) -> bool:
+        """Split-half arithmetic for a 3x3x3 conv of a residual block?  (All have Cin % 16 == 0.)
+        The 32 -> 32 conv of the last decoder has two 16-channel chunks and one 32-row MFMA fragment
+        per wave; there the exact-f32 kernel is as fast (measured 127 vs 122 TF-equivalent) and stays."""
+        return self.precision == "f16x2" and (cout > 32 or cin >= 64)
 
     def _map(self, n_in, n_out, dev):
         key = (n_in, n_out, str(dev))
@@ -292,13 +292,13 @@ class V2ce3d(nn.Module):
         """submodules.py:249-264: relu(bn2(conv2(relu(bn1(conv1 x)))) + bn_d(conv_d x))."""
         s = blk.stride_hw
         w1 = self._sn_weight(blk.conv1.module, d["conv1_w"]) if blk.sn else d["conv1_w"]
-        split = self._split(blk)
-        t = self._conv(x0, x1, w1, *d["bn1"], blk.cout, 3, s, hip.ACT_RELU, up_to=up_to, split=split)
+        t = self._conv(x0, x1, w1, *d["bn1"], blk.cout, 3, s, hip.ACT_RELU, up_to=up_to,
+                       split=self._split(blk.cin, blk.cout))
         track = self.precision == "f16x2"      # the block output may feed a split-half conv
         res = self._conv(x0, x1, d["down_w"], *d["down_bn"], blk.cout, 1, s, hip.ACT_NONE, up_to=up_to)
         w2 = self._sn_weight(blk.conv2.module, d["conv2_w"]) if blk.sn else d["conv2_w"]
-        return self._conv(t, None, w2, *d["bn2"], blk.cout, 3, 1, hip.ACT_RELU, residual=res, split=split,
-                          track=track)
+        return self._conv(t, None, w2, *d["bn2"], blk.cout, 3, 1, hip.ACT_RELU, residual=res,
+                          split=self._split(blk.cout, blk.cout), track=track)
 
     @torch.no_grad()
     def advance_spectral_norm(self):
