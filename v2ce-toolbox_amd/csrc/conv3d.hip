@@ -26,6 +26,10 @@
 #include <map>
 #include <mutex>
 #include <tuple>
+#ifdef V2CE_STAMP
+#include <algorithm>
+#include <vector>
+#endif
 #include <type_traits>
 
 namespace v2ce {
@@ -59,6 +63,9 @@ struct ConvParams {
     // split-half kernel derives its power-of-two activation pre-scale from them
     const float *x0_absmax, *x1_absmax;
     float *y_absmax;
+#ifdef V2CE_STAMP
+    unsigned long long *stamps;   // diagnostic build only: [block][role][8] s_memtime stamps
+#endif
 };
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -87,6 +94,11 @@ struct ConvCfg {
 constexpr unsigned kOOB = 0x80000000u;   // buffer voffset that is always out of range => load returns 0
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
+#ifdef V2CE_STAMP
+#define STAMP(role_, k_) do { if (lane == 0 && (wave == 0 || wave == 4)) P.stamps[((long long)blockIdx.x * 2 + (role_)) * 8 + (k_)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(role_, k_) do {} while (0)
+#endif
 
 // wave-level max of m (>= 0), then one atomic max per wave on the float's bit pattern
 __device__ __forceinline__ void absmax_commit(float m, float *slot) {
@@ -96,6 +108,107 @@ __device__ __forceinline__ void absmax_commit(float m, float *slot) {
     if ((threadIdx.x & 63) == 0 &&
         __float_as_uint(m) > __atomic_load_n(reinterpret_cast<unsigned *>(slot), __ATOMIC_RELAXED))
         atomicMax(reinterpret_cast<unsigned *>(slot), __float_as_uint(m));
+}
+
+// y = act(acc * scale + shift (+ residual)), max |y| tracking.  Accumulator register r of fragment
+// row q is channel co0 + 32 q + (r & 3) + 8 (r >> 2) + 4 half, lane l32 of fragment column f is the
+// position poff[f] (< 0: outside the tensor).  Branch-free: loads and stores are buffer operations
+// whose per-lane offset is pushed out of range for masked lanes (the hardware range check returns 0 /
+// drops the store), the channel offset rides in the scalar offset.  y must not alias the other
+// tensors; the sequence must be < 2 GiB (checked by the launcher).
+template <int CO_FR, int PO_FR>
+__device__ __forceinline__ void conv_epilogue(const ConvParams &P, const f32x16 (&acc)[CO_FR][PO_FR],
+                                              const int (&poff)[PO_FR], int co0, int half, int b,
+                                              float inv_scale) {
+    const float *__restrict__ scale = P.scale;
+    const float *__restrict__ shift = P.shift;
+    const long long seq = (long long)P.T * P.Cout * (P.Hout * P.Wout);
+    const int cstride4 = P.Hout * P.Wout * 4;
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(P.y + b * seq, 0, (int)(seq * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(P.res ? P.res + b * seq : P.y), 0, P.res ? (int)(seq * 4) : 0, 0x00020000);
+    const int cbase = co0 + 4 * half;                      // this lane's channel for (q, r) = (0, 0)
+    unsigned vo[PO_FR];
+#pragma unroll
+    for (int f = 0; f < PO_FR; ++f)
+        vo[f] = poff[f] >= 0 ? (unsigned)(poff[f] * 4 + cbase * cstride4) : kOOB;
+    float ymax = 0.0f;
+#pragma unroll
+    for (int q = 0; q < CO_FR; ++q) {
+        float sc[16], sh[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int co = cbase + q * 32 + (r & 3) + 8 * (r >> 2);
+            co = co < P.Cout ? co : P.Cout - 1;
+            sc[r] = scale[co] * inv_scale;
+            sh[r] = shift[co];
+        }
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            float rv[4][PO_FR];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int cq = q * 32 + k + 8 * r4;            // channel relative to cbase (uniform)
+#pragma unroll
+                for (int f = 0; f < PO_FR; ++f) {
+                    rv[k][f] = 0.0f;
+                    if (P.res)                                  // uniform
+                        rv[k][f] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                            rs_r, cbase + cq < P.Cout ? vo[f] : kOOB, cq * cstride4, 0));
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = 4 * r4 + k;
+                const int cq = q * 32 + k + 8 * r4;
+#pragma unroll
+                for (int f = 0; f < PO_FR; ++f) {
+                    float v = acc[q][f][r] * sc[r] + sh[r];
+                    v += rv[k][f];
+                    if (P.act == V2CE_ACT_RELU) v = v > 0.f ? v : 0.f;
+                    else if (P.act == V2CE_ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
+                    const bool ok = poff[f] >= 0 && cbase + cq < P.Cout;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y,
+                                                          ok ? vo[f] : kOOB, cq * cstride4, 0);
+                    ymax = fmaxf(ymax, ok ? fabsf(v) : 0.0f);
+                }
+            }
+        }
+    }
+    if (P.y_absmax) absmax_commit(ymax, P.y_absmax);
+}
+
+// The same epilogue in streaming order (constants, residual and store per element): used by the
+// exact-f32 kernels, whose two-workgroups-per-CU register budgets leave no room for the batches.
+template <int CO_FR, int PO_FR>
+__device__ __forceinline__ void conv_epilogue_stream(const ConvParams &P, const f32x16 (&acc)[CO_FR][PO_FR],
+                                                     const int (&poff)[PO_FR], int co0, int half, int b) {
+    const long long ybase = (long long)b * P.T * P.Cout * (P.Hout * P.Wout);
+    const int cstride = P.Hout * P.Wout;
+    float ymax = 0.0f;
+#pragma unroll
+    for (int q = 0; q < CO_FR; ++q) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + q * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (co < P.Cout) {
+                const float sc = P.scale[co], sh = P.shift[co];
+#pragma unroll
+                for (int f = 0; f < PO_FR; ++f) {
+                    if (poff[f] >= 0) {
+                        const long long idx = ybase + poff[f] + (long long)co * cstride;
+                        float v = acc[q][f][r] * sc + sh;
+                        if (P.res) v += P.res[idx];
+                        if (P.act == V2CE_ACT_RELU) v = v > 0.f ? v : 0.f;
+                        else if (P.act == V2CE_ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
+                        P.y[idx] = v;
+                        ymax = fmaxf(ymax, fabsf(v));
+                    }
+                }
+            }
+        }
+    }
+    if (P.y_absmax) absmax_commit(ymax, P.y_absmax);
 }
 
 // byte offsets (relative to the sequence base of the source tensor) of this thread's halo elements;
@@ -353,33 +466,7 @@ __global__ __launch_bounds__(256, MW) void conv3d_kernel(ConvParams P) {
     }
 
 #undef ISSUE
-    // ---- epilogue: y = act(acc*scale + shift (+res))
-    const long long ybase = (long long)b * P.T * P.Cout * (P.Hout * P.Wout);
-    const int cstride = P.Hout * P.Wout;
-    float ymax = 0.0f;
-#pragma unroll
-    for (int q = 0; q < CO_FR; ++q) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + q * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (co < P.Cout) {
-                const float sc = P.scale[co], sh = P.shift[co];
-#pragma unroll
-                for (int f = 0; f < PO_FR; ++f) {
-                    if (poff[f] >= 0) {
-                        const long long idx = ybase + poff[f] + (long long)co * cstride;
-                        float v = acc[q][f][r] * sc + sh;
-                        if (P.res) v += P.res[idx];
-                        if (P.act == V2CE_ACT_RELU) v = v > 0.f ? v : 0.f;
-                        else if (P.act == V2CE_ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
-                        P.y[idx] = v;
-                        ymax = fmaxf(ymax, fabsf(v));
-                    }
-                }
-            }
-        }
-    }
-    if (P.y_absmax) absmax_commit(ymax, P.y_absmax);
+    conv_epilogue_stream<CO_FR, PO_FR>(P, acc, poff, co0, half, b);
 #endif  // __HIP_DEVICE_COMPILE__ (the host pass only needs the launch stub)
 }
 
@@ -541,57 +628,31 @@ __global__ __launch_bounds__(256, 1) void conv3d_f16x2_kernel(ConvParams P) {
     }
 #undef ISSUE16
 
-    const long long ybase = (long long)b * P.T * P.Cout * (P.Hout * P.Wout);
-    const int cstride = P.Hout * P.Wout;
-    float ymax = 0.0f;
-#pragma unroll
-    for (int q = 0; q < CO_FR; ++q) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + q * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (co < P.Cout) {
-                const float sc = P.scale[co] * inv_scale, sh = P.shift[co];
-#pragma unroll
-                for (int f = 0; f < PO_FR; ++f) {
-                    if (poff[f] >= 0) {
-                        const long long idx = ybase + poff[f] + (long long)co * cstride;
-                        float v = acc[q][f][r] * sc + sh;
-                        if (P.res) v += P.res[idx];
-                        if (P.act == V2CE_ACT_RELU) v = v > 0.f ? v : 0.f;
-                        else if (P.act == V2CE_ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
-                        P.y[idx] = v;
-                        ymax = fmaxf(ymax, fabsf(v));
-                    }
-                }
-            }
-        }
-    }
-    if (P.y_absmax) absmax_commit(ymax, P.y_absmax);
+    conv_epilogue<CO_FR, PO_FR>(P, acc, poff, co0, half, b, inv_scale);
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
 // ---------------------------------------------------------------------------------------------
 // Split-half, wave-specialised (stride 1): the same arithmetic as conv3d_f16x2_kernel, but the
 // workgroup is 8 waves = 2 per SIMD with fixed roles.
-//   waves 4-7 (producers): LDS-DMA chunk c+1 of the f32 halo into the staging buffer, convert it to
-//       the fp16 hi/lo pieces of buffer (c+1)&1, issue the DMA of chunk c+2.  Each wave converts
-//       exactly the slices it DMA'd itself, so it only needs its own vmcnt(0), no barrier.
+//   waves 4-7 (producers): gather chunk c+1 of the f32 halo into registers (buffer loads; the
+//       hardware range check supplies the zero padding), convert it to the fp16 hi/lo pieces of
+//       buffer (c+1)&1, issue the loads of chunk c+2 (they land during the barrier wait).
 //   waves 0-3 (consumers): per tap 8 ds_read_b128 + 4 global A-fragment loads + 24 MFMAs out of
 //       pieces buffer c&1; B fragments are refilled in place for the next tap as soon as the MFMAs
 //       that read them have issued, A fragments are double-buffered one tap ahead.
 // One workgroup barrier per 16-channel chunk hands buffer (c+1)&1 over.  The conversion, the DMA
 // issue and its branches never sit in the MFMA waves' instruction stream.
-// LDS: staging 64 B + 2 x 64 B of pieces per halo element.
+// LDS: 2 x 64 B of pieces per halo element (up to 1280 elements: 512-position boxes).
 // ---------------------------------------------------------------------------------------------
-template <int S, int WCO, int CO_FR, int PO_FR>
+template <int S, int WCO, int CO_FR, int PO_FR, int NA>
 __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int KS = 3, K3 = 27, CK = 16, EPT = 4, PAD = 1;
+    constexpr int K3 = 27, CK = 16, EPT = 5, PAD = 1;
     constexpr int WPO = 4 / WCO;
     constexpr int CO_TILE = WCO * CO_FR * 32;
     const int chs = (P.plane + 63) & ~63;
-    float *stage = reinterpret_cast<float *>(conv_smem);                       // [16][chs] f32
-    f16x8 *pieces = reinterpret_cast<f16x8 *>(stage + CK * chs);               // [2][4][chs] x 16 B
+    f16x8 *pieces = reinterpret_cast<f16x8 *>(conv_smem);                      // [2][4][chs] x 16 B
 
     const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -625,43 +686,78 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
 
     if (wave >= 4) {
         // ------------------------------------------------------------------ producers
-        const int pw = wave - 4, ptid = tid - 256;
-        DmaState<EPT, 1> D;
-        D.cur_src = -1;
-        D.src_cstride4 = 0;
-        D.src_cbase = 0;
-        D.woff[0] = kOOB;
-        D.rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x0), 0, 0, 0x00020000);
-        D.rs_in = D.rs_w;
-        issue_chunk<KS, CK, EPT, 1, 0>(P, D, 0, stage, chs, b, pw, tin0, hin0, win0, 0, 1);
-        for (int cg = 0; cg < CG; ++cg) {
-            f16x8 *qb = pieces + (cg & 1) * 4 * chs;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's slices of chunk cg landed
-            for (int r = ptid; r < P.plane; r += 256) {
-#pragma unroll
-                for (int hg = 0; hg < 2; ++hg) {
-                    f16x8 vh, vl;
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        const float v = stage[(8 * hg + c) * chs + r] * x_scale;
-                        const _Float16 hh = (_Float16)v;
-                        vh[c] = hh;
-                        vl[c] = (_Float16)(v - (float)hh);
-                    }
-                    qb[hg * chs + r] = vh;
-                    qb[(2 + hg) * chs + r] = vl;
+        // chunk c+1 travels global -> registers (gather with the halo offsets; out-of-range offsets
+        // read as the zero padding) -> fp16 hi/lo pieces in LDS.  The loads of chunk c+2 are issued
+        // before the barrier and land while the consumers work through chunk c+1.
+        const int ptid = tid - 256;
+        unsigned goff[EPT];
+        float R[CK][EPT];
+        __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x0), 0, 0, 0x00020000);
+        int cur_src = -1, src_cstride4 = 0, src_cbase = 0;
+        auto load_chunk = [&](int ci0) {
+            const int want_src = ci0 < P.C0 ? 0 : 1;
+            if (want_src != cur_src) {   // uniform; at most twice per kernel
+                cur_src = want_src;
+                halo_offsets<EPT>(P, tin0, hin0, win0, want_src == 1, ptid, goff);
+                if (want_src == 0) {
+                    const long long seq = (long long)P.T * P.C0 * (P.H0 * P.W0);
+                    rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x0 + b * seq), 0, (int)(seq * 4), 0x00020000);
+                    src_cstride4 = P.H0 * P.W0 * 4;
+                    src_cbase = 0;
+                } else {
+                    const long long seq = (long long)P.T * P.C1 * (P.Hin * P.Win);
+                    rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x1 + b * seq), 0, (int)(seq * 4), 0x00020000);
+                    src_cstride4 = P.Hin * P.Win * 4;
+                    src_cbase = P.C0;
                 }
             }
-            if (cg + 1 < CG) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // staging reads done before the DMA overwrites
-                issue_chunk<KS, CK, EPT, 1, 0>(P, D, (cg + 1) * CK, stage, chs, b, pw, tin0, hin0, win0, 0, 1);
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) {
+                if ((wave - 4) * 64 + 256 * i < P.plane) {            // wave-uniform
+#pragma unroll
+                    for (int ci = 0; ci < CK; ++ci)
+                        R[ci][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                            rs_in, goff[i], (ci0 + ci - src_cbase) * src_cstride4, 0));
+                }
             }
+        };
+        STAMP(1, 0);
+        load_chunk(0);
+        STAMP(1, 1);
+        for (int cg = 0; cg < CG; ++cg) {
+            f16x8 *qb = pieces + (cg & 1) * 4 * chs;
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) {
+                const int r = ptid + 256 * i;
+                if ((wave - 4) * 64 + 256 * i < P.plane) {            // wave-uniform (lanes past the plane write padding)
+#pragma unroll
+                    for (int hg = 0; hg < 2; ++hg) {
+                        f16x8 vh, vl;
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            const float v = R[8 * hg + c][i] * x_scale;
+                            const _Float16 hh = (_Float16)v;
+                            vh[c] = hh;
+                            vl[c] = (_Float16)(v - (float)hh);
+                        }
+                        qb[hg * chs + r] = vh;
+                        qb[(2 + hg) * chs + r] = vl;
+                    }
+                }
+            }
+            if (cg == 0) STAMP(1, 2);
+            if (cg + 1 < CG) load_chunk((cg + 1) * CK);
+            if (cg == 0) STAMP(1, 3);
             __syncthreads();                                          // barrier cg: pieces[cg & 1] ready
+            if (cg == 0) STAMP(1, 4);
+            if (cg == 1) STAMP(1, 5);
         }
+        STAMP(1, 6);
         return;
     }
 
     // ---------------------------------------------------------------------- consumers
+    STAMP(0, 0);
     __builtin_amdgcn_s_setprio(2);
     const int wco = wave % WCO, wpo = wave / WCO;
     const int co0 = co_t * CO_TILE + wco * CO_FR * 32;     // this wave's first channel
@@ -705,7 +801,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[q][f][r] = 0.0f;
 
-    f16x8 ah[2][CO_FR], al[2][CO_FR], bh[PO_FR], bl[PO_FR];
+    // A fragments come from L2 (a chunk's weights exceed the 32 KiB L1): ring of NA slots, loaded
+    // NA-1 taps ahead; 27 % NA == 0, so slot = tap % NA stays static across chunk boundaries
+    f16x8 ah[NA][CO_FR], al[NA][CO_FR], bh[PO_FR], bl[PO_FR];
 #define V2CE_LOAD_A(slot_, soff_)                                                              \
     {                                                                                          \
         const int so_ = (soff_);                                                               \
@@ -714,13 +812,17 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
             al[slot_][q] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_a, wlane[q], so_ + lo_off, 0)); \
         }                                                                                      \
     }
-    V2CE_LOAD_A(1, 0)                                      // chunk 0, tap 0 (moved to slot 0 below)
+    step_loop<0, NA - 1>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        V2CE_LOAD_A(t, t * tap_stride)                      // chunk 0, taps 0 .. NA-2
+    });
     for (int cg = 0; cg < CG; ++cg) {
         const f16x8 *qb = pieces + (cg & 1) * 4 * chs;
         const int wc = cg * cg_stride;
-#pragma unroll
-        for (int q = 0; q < CO_FR; ++q) { ah[0][q] = ah[1][q]; al[0][q] = al[1][q]; }
+        const int wn = cg + 1 < CG ? wc + cg_stride : 0;    // last chunk: harmless re-read of chunk 0
         __syncthreads();                                   // barrier cg: pieces[cg & 1] ready
+        if (cg == 0) STAMP(0, 1);
+        if (cg == 1) STAMP(0, 2);
 #pragma unroll
         for (int f = 0; f < PO_FR; ++f) {
             bh[f] = qb[bhb[f]];
@@ -730,19 +832,20 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
             constexpr int tap = decltype(tc)::value;
             constexpr int nt = tap + 1;
             constexpr int dt = nt / 9, dh = (nt / 3) % 3, dw = nt % 3;
-            if constexpr (nt < K3) {
-                V2CE_LOAD_A(nt & 1, wc + nt * tap_stride)
+            constexpr int pt = tap + NA - 1;              // the tap whose A fragments are fetched now
+            if constexpr (pt < K3) {
+                V2CE_LOAD_A(pt % NA, wc + pt * tap_stride)
             } else {
-                if (cg + 1 < CG) V2CE_LOAD_A(1, wc + cg_stride)       // next chunk, tap 0
+                V2CE_LOAD_A(pt % NA, wn + (pt - K3) * tap_stride)
             }
             const int toff = (dt * P.HH + dh) * P.HWd + dw;          // next tap's offset in the halo box
 #pragma unroll
             for (int f = 0; f < PO_FR; ++f) {
 #pragma unroll
                 for (int q = 0; q < CO_FR; ++q) {
-                    acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tap & 1][q], bh[f], acc[q][f], 0, 0, 0);
-                    acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tap & 1][q], bl[f], acc[q][f], 0, 0, 0);
-                    acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tap & 1][q], bh[f], acc[q][f], 0, 0, 0);
+                    acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tap % NA][q], bh[f], acc[q][f], 0, 0, 0);
+                    acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tap % NA][q], bl[f], acc[q][f], 0, 0, 0);
+                    acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tap % NA][q], bh[f], acc[q][f], 0, 0, 0);
                 }
                 if constexpr (nt < K3) {                 // refill in place for the next tap
                     bh[f] = qb[bhb[f] + toff];
@@ -754,33 +857,11 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
     }
 #undef V2CE_LOAD_A
 
+    STAMP(0, 3);
     const float inv_scale = 1.0f / (x_scale * w_scale);     // a power of two: exact
-    const long long ybase = (long long)b * P.T * P.Cout * (P.Hout * P.Wout);
-    const int cstride = P.Hout * P.Wout;
-    float ymax = 0.0f;
-#pragma unroll
-    for (int q = 0; q < CO_FR; ++q) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + q * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (co < P.Cout) {
-                const float sc = P.scale[co] * inv_scale, sh = P.shift[co];
-#pragma unroll
-                for (int f = 0; f < PO_FR; ++f) {
-                    if (poff[f] >= 0) {
-                        const long long idx = ybase + poff[f] + (long long)co * cstride;
-                        float v = acc[q][f][r] * sc + sh;
-                        if (P.res) v += P.res[idx];
-                        if (P.act == V2CE_ACT_RELU) v = v > 0.f ? v : 0.f;
-                        else if (P.act == V2CE_ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
-                        P.y[idx] = v;
-                        ymax = fmaxf(ymax, fabsf(v));
-                    }
-                }
-            }
-        }
-    }
-    if (P.y_absmax) absmax_commit(ymax, P.y_absmax);
+    STAMP(0, 3);
+    conv_epilogue<CO_FR, PO_FR>(P, acc, poff, co0, half, b, inv_scale);
+    STAMP(0, 4);
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
@@ -884,6 +965,8 @@ int launch_f16x2(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream) {
     P.plane = P.HT * P.HH * P.HWd;
     V2CE_REQUIRE(P.n_pos <= POS_TILE && P.plane <= MAX_PLANE, V2CE_ERR_UNSUPPORTED,
                  "v2ce_conv3d_fwd(f16x2): tile does not fit");
+    V2CE_REQUIRE((long long)d.T * d.Cout * d.Hout * d.Wout < (1ll << 29), V2CE_ERR_UNSUPPORTED,
+                 "v2ce_conv3d_fwd(f16x2): an output sequence exceeds the 2 GiB buffer-descriptor range");
     P.nT = (d.T + t.tt - 1) / t.tt; P.nH = (d.Hout + t.th - 1) / t.th; P.nW = (d.Wout + t.tw - 1) / t.tw;
     P.n_co_tiles = (d.Cout + CO_TILE - 1) / CO_TILE;
     P.n_spatial = d.B * P.nT * P.nH * P.nW;
@@ -915,13 +998,14 @@ __global__ __launch_bounds__(256) void weights_absmax_kernel(const float *__rest
     if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned *>(tail), __float_as_uint(m));
 }
 
-template <int S, int WCO, int CO_FR, int PO_FR>
+template <int S, int WCO, int CO_FR, int PO_FR, int NA>
 int launch_f16x2_ws(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream) {
+    static_assert(27 % NA == 0 && NA >= 2, "the A-fragment ring must divide the 27 taps");
     constexpr int KS = 3;
     constexpr int CO_TILE = WCO * CO_FR * 32, POS_TILE = (4 / WCO) * PO_FR * 32;
-    constexpr int MAX_PLANE = 832;          // 192 B of LDS per halo element (rounded to 64 elements)
+    constexpr int MAX_PLANE = 1280;         // 128 B of LDS per halo element; 5 elements per producer lane
     if (g_name_out) {
-        snprintf(g_name_out, g_name_cap, "conv3d_f16x2_ws_kernel<%d,%d,%d,%d>", S, WCO, CO_FR, PO_FR);
+        snprintf(g_name_out, g_name_cap, "conv3d_f16x2_ws_kernel<%d,%d,%d,%d,%d>", S, WCO, CO_FR, PO_FR, NA);
         return V2CE_OK;
     }
     Tile t{d.tile_t, d.tile_h, d.tile_w};
@@ -932,6 +1016,8 @@ int launch_f16x2_ws(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream)
     P.plane = P.HT * P.HH * P.HWd;
     V2CE_REQUIRE(P.n_pos <= POS_TILE && P.plane <= MAX_PLANE, V2CE_ERR_UNSUPPORTED,
                  "v2ce_conv3d_fwd(f16x2 ws): tile does not fit");
+    V2CE_REQUIRE((long long)d.T * d.Cout * d.Hout * d.Wout < (1ll << 29), V2CE_ERR_UNSUPPORTED,
+                 "v2ce_conv3d_fwd(f16x2): an output sequence exceeds the 2 GiB buffer-descriptor range");
     P.nT = (d.T + t.tt - 1) / t.tt; P.nH = (d.Hout + t.th - 1) / t.th; P.nW = (d.Wout + t.tw - 1) / t.tw;
     P.n_co_tiles = (d.Cout + CO_TILE - 1) / CO_TILE;
     P.n_spatial = d.B * P.nT * P.nH * P.nW;
@@ -939,13 +1025,39 @@ int launch_f16x2_ws(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream)
     const long long blocks = P.xcd_remap ? (long long)((P.n_spatial + 7) / 8) * 8 * P.n_co_tiles
                                          : (long long)P.n_spatial * P.n_co_tiles;
     const int chs = (P.plane + 63) & ~63;
-    const size_t lds = (size_t)chs * (16 * 4 + 2 * 4 * 16);
+    const size_t lds = (size_t)chs * (2 * 4 * 16);
     V2CE_REQUIRE(lds <= 160 * 1024, V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd(f16x2 ws): %zu B of LDS", lds);
-    auto kern = conv3d_f16x2_ws_kernel<S, WCO, CO_FR, PO_FR>;
+    auto kern = conv3d_f16x2_ws_kernel<S, WCO, CO_FR, PO_FR, NA>;
     V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#ifdef V2CE_STAMP
+    V2CE_HIP_CHECK(hipMalloc(&P.stamps, (size_t)blocks * 16 * sizeof(unsigned long long)));
+    V2CE_HIP_CHECK(hipMemset(P.stamps, 0, (size_t)blocks * 16 * sizeof(unsigned long long)));
+#endif
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, stream, P);
     V2CE_HIP_CHECK(hipGetLastError());
+#ifdef V2CE_STAMP
+    {
+        std::vector<unsigned long long> h((size_t)blocks * 16);
+        V2CE_HIP_CHECK(hipDeviceSynchronize());
+        V2CE_HIP_CHECK(hipMemcpy(h.data(), P.stamps, h.size() * 8, hipMemcpyDeviceToHost));
+        V2CE_HIP_CHECK(hipFree(P.stamps));
+        auto med = [&](int role, int a, int b) {
+            std::vector<long long> v;
+            for (long long k = 0; k < blocks; ++k) {
+                const unsigned long long x = h[(k * 2 + role) * 8 + a], y = h[(k * 2 + role) * 8 + b];
+                if (x && y) v.push_back((long long)(y - x));
+            }
+            if (v.empty()) return -1ll;
+            std::sort(v.begin(), v.end());
+            return v[v.size() / 2];
+        };
+        fprintf(stderr, "[stamp ws<%d,%d,%d,%d,%d> CG=%d plane=%d blocks=%lld] consumer: setup->bar0 %lld, chunk0 %lld, bar1->end-of-loop %lld, epilogue %lld, total %lld | "
+                "producer: issue0 %lld, wait+convert0 %lld, issue1 %lld, bar0 wait %lld, chunk1 iter %lld, total %lld\n",
+                S, WCO, CO_FR, PO_FR, NA, P.Cin / 16, P.plane, blocks, med(0, 0, 1), med(0, 1, 2), med(0, 2, 3), med(0, 3, 4), med(0, 0, 4),
+                med(1, 0, 1), med(1, 1, 2), med(1, 2, 3), med(1, 3, 4), med(1, 4, 5), med(1, 0, 6));
+    }
+#endif
     return V2CE_OK;
 }
 
@@ -1040,9 +1152,19 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
         V2CE_REQUIRE(d.C1 == 0 || !x0_absmax || x1_absmax, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd(f16x2): x0_absmax without x1_absmax");
         static const int ws = [] { const char *e = getenv("V2CE_WS"); return e ? atoi(e) : 1; }();
         if (s == 1 && ws) {
-            if (small_co) return launch_f16x2_ws<1, 1, 1, 2>(P, d, st);
-            if (d.Cout >= 128) return launch_f16x2_ws<1, 2, 2, 4>(P, d, st);
-            return launch_f16x2_ws<1, 1, 2, 2>(P, d, st);
+            // wave-specialised kernel, measured (tools/conv_bench.py, TF-equivalent): 128 x 256 boxes
+            // 370-450; 64 x 512: 285-390 (64 x 256: 248-358); 32 x 512: 186-299 (32 x 256: 114-205)
+            static const int na = [] { const char *e = getenv("V2CE_NA"); return e ? atoi(e) : 3; }();
+            if (small_co) return na == 9 ? launch_f16x2_ws<1, 1, 1, 4, 9>(P, d, st) : launch_f16x2_ws<1, 1, 1, 4, 3>(P, d, st);
+            if (d.Cout >= 128) return launch_f16x2_ws<1, 2, 2, 4, 3>(P, d, st);
+            return launch_f16x2_ws<1, 1, 2, 4, 3>(P, d, st);
+        }
+        if (s == 2 && ws) {
+            // stride 2: the halo box is ~4x the output box, 128-position boxes; measured 223-293
+            // TF-equivalent with one 32-channel fragment row per wave (Cout >= 128), 121 at Cout = 64
+            static const int na = [] { const char *e = getenv("V2CE_NA"); return e ? atoi(e) : 3; }();
+            if (d.Cout >= 128) return na == 9 ? launch_f16x2_ws<2, 4, 1, 4, 9>(P, d, st) : launch_f16x2_ws<2, 4, 1, 4, 3>(P, d, st);
+            if (!small_co) return na == 9 ? launch_f16x2_ws<2, 2, 1, 2, 9>(P, d, st) : launch_f16x2_ws<2, 2, 1, 2, 3>(P, d, st);
         }
         if (s == 1) {
             if (small_co) return launch_f16x2<3, 1, 1, 1, 2, 4>(P, d, st);

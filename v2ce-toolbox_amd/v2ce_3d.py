@@ -224,10 +224,8 @@ class V2ce3d(nn.Module):
         self._prep = P
 
     def _split(self, cin, cout) -> bool:
-        """Split-half arithmetic for a 3x3x3 conv of a residual block?  (All have Cin % 16 == 0.)
-        The 32 -> 32 conv of the last decoder has two 16-channel chunks and one 32-row MFMA fragment
-        per wave; there the exact-f32 kernel is as fast (measured 127 vs 122 TF-equivalent) and stays."""
-        return self.precision == "f16x2" and (cout > 32 or cin >= 64)
+        """Split-half arithmetic for a 3x3x3 conv of a residual block?  (All have Cin % 16 == 0.)"""
+        return self.precision == "f16x2"
 
     def _map(self, n_in, n_out, dev):
         key = (n_in, n_out, str(dev))
