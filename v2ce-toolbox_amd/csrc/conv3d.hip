@@ -110,12 +110,20 @@ __device__ __forceinline__ void absmax_commit(float m, float *slot) {
         atomicMax(reinterpret_cast<unsigned *>(slot), __float_as_uint(m));
 }
 
+// Activation without control flow: act(t) = max(t, slope * t) + 0 with slope 1 (none), 0 (ReLU) or
+// 0.01 (LeakyReLU); the "+ 0" turns the -0 that 0 * t leaves for negative t into the +0 of max(t, 0).
+__device__ __forceinline__ float act_slope(int act) {
+    return act == V2CE_ACT_RELU ? 0.0f : (act == V2CE_ACT_LEAKY ? 0.01f : 1.0f);
+}
+__device__ __forceinline__ float apply_act(float t, float slope) { return fmaxf(t, slope * t) + 0.0f; }
+
 // y = act(acc * scale + shift (+ residual)), max |y| tracking.  Accumulator register r of fragment
 // row q is channel co0 + 32 q + (r & 3) + 8 (r >> 2) + 4 half, lane l32 of fragment column f is the
-// position poff[f] (< 0: outside the tensor).  Branch-free: loads and stores are buffer operations
-// whose per-lane offset is pushed out of range for masked lanes (the hardware range check returns 0 /
-// drops the store), the channel offset rides in the scalar offset.  y must not alias the other
-// tensors; the sequence must be < 2 GiB (checked by the launcher).
+// position poff[f] (< 0: outside the tensor).  Straight-line code (a per-element branch costs more
+// than the store it guards: the first version of this epilogue spent 200 cycles per output in
+// scalar branches): loads and stores are buffer operations whose per-lane offset is pushed out of
+// range for masked lanes (the hardware range check returns 0 / drops the store), the channel offset
+// rides in the scalar offset.  Requires Cout % 32 == 0, sequences < 2 GiB, y not aliasing the inputs.
 template <int CO_FR, int PO_FR>
 __device__ __forceinline__ void conv_epilogue(const ConvParams &P, const f32x16 (&acc)[CO_FR][PO_FR],
                                               const int (&poff)[PO_FR], int co0, int half, int b,
@@ -128,18 +136,20 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &P, const f32x16 
     const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(P.res ? P.res + b * seq : P.y), 0, P.res ? (int)(seq * 4) : 0, 0x00020000);
     const int cbase = co0 + 4 * half;                      // this lane's channel for (q, r) = (0, 0)
-    unsigned vo[PO_FR];
+    const float slope = act_slope(P.act);
+    unsigned vo[PO_FR], vmask[PO_FR];
 #pragma unroll
-    for (int f = 0; f < PO_FR; ++f)
+    for (int f = 0; f < PO_FR; ++f) {
         vo[f] = poff[f] >= 0 ? (unsigned)(poff[f] * 4 + cbase * cstride4) : kOOB;
-    float ymax = 0.0f;
+        vmask[f] = poff[f] >= 0 ? 0x7fffffffu : 0u;        // |v| of a masked lane counts as 0
+    }
+    unsigned ymax = 0u;                                    // max |y| as a bit pattern (non-negative floats order as integers)
 #pragma unroll
     for (int q = 0; q < CO_FR; ++q) {
         float sc[16], sh[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            int co = cbase + q * 32 + (r & 3) + 8 * (r >> 2);
-            co = co < P.Cout ? co : P.Cout - 1;
+            const int co = cbase + q * 32 + (r & 3) + 8 * (r >> 2);
             sc[r] = scale[co] * inv_scale;
             sh[r] = shift[co];
         }
@@ -147,35 +157,31 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &P, const f32x16 
         for (int r4 = 0; r4 < 4; ++r4) {
             float rv[4][PO_FR];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int cq = q * 32 + k + 8 * r4;            // channel relative to cbase (uniform)
+            for (int k = 0; k < 4; ++k)
 #pragma unroll
                 for (int f = 0; f < PO_FR; ++f) {
                     rv[k][f] = 0.0f;
                     if (P.res)                                  // uniform
                         rv[k][f] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                            rs_r, cbase + cq < P.Cout ? vo[f] : kOOB, cq * cstride4, 0));
+                            rs_r, vo[f], (q * 32 + k + 8 * r4) * cstride4, 0));
                 }
-            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int r = 4 * r4 + k;
-                const int cq = q * 32 + k + 8 * r4;
 #pragma unroll
                 for (int f = 0; f < PO_FR; ++f) {
                     float v = acc[q][f][r] * sc[r] + sh[r];
                     v += rv[k][f];
-                    if (P.act == V2CE_ACT_RELU) v = v > 0.f ? v : 0.f;
-                    else if (P.act == V2CE_ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
-                    const bool ok = poff[f] >= 0 && cbase + cq < P.Cout;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y,
-                                                          ok ? vo[f] : kOOB, cq * cstride4, 0);
-                    ymax = fmaxf(ymax, ok ? fabsf(v) : 0.0f);
+                    v = apply_act(v, slope);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, vo[f],
+                                                          (q * 32 + k + 8 * r4) * cstride4, 0);
+                    const unsigned av = __builtin_bit_cast(unsigned, v) & vmask[f];
+                    ymax = av > ymax ? av : ymax;
                 }
             }
         }
     }
-    if (P.y_absmax) absmax_commit(ymax, P.y_absmax);
+    if (P.y_absmax) absmax_commit(__builtin_bit_cast(float, ymax), P.y_absmax);
 }
 
 // The same epilogue in streaming order (constants, residual and store per element): used by the
@@ -185,6 +191,7 @@ __device__ __forceinline__ void conv_epilogue_stream(const ConvParams &P, const 
                                                      const int (&poff)[PO_FR], int co0, int half, int b) {
     const long long ybase = (long long)b * P.T * P.Cout * (P.Hout * P.Wout);
     const int cstride = P.Hout * P.Wout;
+    const float slope = act_slope(P.act);
     float ymax = 0.0f;
 #pragma unroll
     for (int q = 0; q < CO_FR; ++q) {
@@ -199,8 +206,7 @@ __device__ __forceinline__ void conv_epilogue_stream(const ConvParams &P, const 
                         const long long idx = ybase + poff[f] + (long long)co * cstride;
                         float v = acc[q][f][r] * sc + sh;
                         if (P.res) v += P.res[idx];
-                        if (P.act == V2CE_ACT_RELU) v = v > 0.f ? v : 0.f;
-                        else if (P.act == V2CE_ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
+                        v = apply_act(v, slope);
                         P.y[idx] = v;
                         ymax = fmaxf(ymax, fabsf(v));
                     }
@@ -1145,8 +1151,9 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
     const bool small_co = d.Cout <= 32;
     if (d.precision == V2CE_PRECISION_F16X2) {
         // split-half path: w_packed is the fp16 hi/lo buffer of v2ce_pack_weights_f16x2
-        V2CE_REQUIRE(d.ksize == 3 && P.Cin % 16 == 0 && (d.C1 == 0 || d.C0 % 16 == 0), V2CE_ERR_UNSUPPORTED,
-                     "v2ce_conv3d_fwd(f16x2): needs a 3x3x3 kernel and channel counts that are multiples of 16");
+        V2CE_REQUIRE(d.ksize == 3 && P.Cin % 16 == 0 && (d.C1 == 0 || d.C0 % 16 == 0) && d.Cout % 32 == 0,
+                     V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd(f16x2): needs a 3x3x3 kernel, input channel counts that "
+                     "are multiples of 16 and an output channel count that is a multiple of 32");
         P.wq = reinterpret_cast<const _Float16 *>(w_packed);
         V2CE_REQUIRE(x0_absmax || !x1_absmax, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd(f16x2): x1_absmax without x0_absmax");
         V2CE_REQUIRE(d.C1 == 0 || !x0_absmax || x1_absmax, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd(f16x2): x0_absmax without x1_absmax");
