@@ -33,6 +33,9 @@ from v2ce_toolbox_amd import glue                                    # noqa: E40
 
 H, W, SEQ = 260, 346, 16
 PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: 256 CU x 256 FLOP/clk x 2.4 GHz
+PEAK_F16_MATRIX_TFLOPS = 16 * PEAK_F32_MATRIX_TFLOPS   # same table: f32 MFMA = 1/16 of the BF16/F16 rate (~2.5 PF dense)
+# split-half kernels execute 3 fp16 MFMAs per algorithmic product (hi*hi + hi*lo + lo*hi)
+PEAK_SPLIT_TFLOPS = PEAK_F16_MATRIX_TFLOPS / 3
 PEAK_HBM_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FLOP_PER_PAIR = 135.58e9
 
@@ -75,8 +78,11 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="16-pair sequences per step per GPU")
     ap.add_argument("--workload", default="e2e", choices=["e2e", "ldati_stress", "ldati_sparse"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="f32", choices=["f32", "f16x2"],
-                    help="stage-1 conv arithmetic: exact f32 MFMA (default) or the opt-in split-half path")
+    ap.add_argument("--precision", default="f16x2", choices=["f32", "f16x2"],
+                    help="stage-1 3x3x3 conv arithmetic: f16x2 = f32 operands split into two fp16 halves, 3 fp16 "
+                         "MFMAs per product, f32 accumulation (error vs f64 equals the exact path's: "
+                         "profiles/r01_d_precision_report.json); f32 = exact f32 MFMA")
+    ap.add_argument("--no-exact-f32", action="store_true", help="skip the extra exact-f32 measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -174,10 +180,15 @@ def main():
     if args.workload == "e2e":
         name = max(per, key=lambda k: per[k][0])
         v = per[name]
+        split = "f16x2" in name
+        peak = PEAK_SPLIT_TFLOPS if split else PEAK_F32_MATRIX_TFLOPS
         roofline = {"bound": "mfma", "kernel": name, "achieved": v[1] / v[0] / 1e12,
-                    "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                    "frac": v[1] / v[0] / 1e12 / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
+                    "peak": peak, "unit": "TFLOP/s",
+                    "frac": v[1] / v[0] / 1e12 / peak, "traffic": None,
                     "avg_launch_ms": 1e3 * v[0] / v[2], "flop_per_launch": v[1] / v[2],
+                    "peak_note": ("algorithmic (f32-equivalent) FLOP; the kernel executes 3 fp16 MFMAs per product, so "
+                                  f"peak = dense fp16 MFMA peak {PEAK_F16_MATRIX_TFLOPS:.0f} / 3") if split else
+                                 "dense f32 MFMA peak",
                     "all_conv_tflops": sum(x[1] for x in per.values()) / sum(x[0] for x in per.values()) / 1e12}
     else:
         roofline = {"bound": "hbm", "kernel": "v2ce_ldati_emit (bucket_pass x2, wgtab_scan, bucket_scan, bucket_sort)",
@@ -208,7 +219,7 @@ def main():
             "value": total_pairs / dt, "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "f32" else "f16x2-split (3 fp16 MFMAs per k-step, f32 accumulate, 1e-5 parity)",
+            "dtype": "f32" if args.precision == "f32" else "f32-as-f16x2 (operands split hi/lo in fp16, 3 MFMAs per product, f32 accumulate)",
             "data": "synthetic",
             "config": {"workload": {"e2e": f"346x260 center, batch={b} sequences x 16 frame-pairs per GPU, "
                                            "V2ce3d (synthetic weights seed 0) + LDATI (Philox), inputs resident in HBM",
@@ -217,12 +228,31 @@ def main():
                        "frame_pairs_per_step_per_gpu": pairs_per_step, "fps": fps,
                        "parallelism": f"dp{world} over sequences"},
             "mevents_per_s": events / dt / 1e6, "events_per_pair": events / total_pairs,
-            "stage1_mfma_frac_e2e": (FLOP_PER_PAIR * total_pairs / dt / 1e12 / PEAK_F32_MATRIX_TFLOPS / world)
+            "stage1_mfma_frac_e2e": (FLOP_PER_PAIR * total_pairs / dt / 1e12 / world /
+                                     (PEAK_F32_MATRIX_TFLOPS if args.precision == "f32" else PEAK_SPLIT_TFLOPS))
             if args.workload == "e2e" else None,
             "roofline": roofline, "ldati": ldati, "kernels": kernels,
         }
         if world > 1:
             line["gathered_bytes_per_step"] = gather_bytes[0]
+        if world == 1 and args.workload == "e2e" and args.precision != "f32" and not args.no_exact_f32:
+            # the same step with exact f32 MFMA arithmetic in every conv, for reference (not `value`)
+            del model
+            m32 = V2ce3d(precision="f32")
+            m32.load_state_dict(synth.make_state_dict(0))
+            m32 = m32.eval().to(device)
+
+            def step32():
+                vox = m32(x).view(pairs_per_step, 2, 10, H, W)
+                return ldati_device(vox, fps=fps, seed=0x5EED, frame_base=first_pair, frame_ts_add=ts_add).packed()
+            step32()
+            torch.cuda.synchronize()
+            t32 = time.perf_counter()
+            for _ in range(3):
+                step32()
+            torch.cuda.synchronize()
+            t32 = (time.perf_counter() - t32) / 3
+            line["exact_f32"] = {"value": pairs_per_step / t32, "unit": "frame-pairs/s", "ms_per_step": 1e3 * t32, "steps": 3}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

@@ -127,9 +127,10 @@ def test_sn_power_iteration_and_pack():
         assert_close(wp.cpu().numpy().reshape(96, 27, rows), want, f"w/sigma it{it}", 2e-6)
 
 
-def load_model():
+def load_model(precision="f32"):
+    """The exact-f32 arithmetic path (the split-half default has its own tests below)."""
     from v2ce_toolbox_amd.v2ce_3d import V2ce3d
-    m = V2ce3d()
+    m = V2ce3d(precision=precision)
     m.load_state_dict(synth.make_state_dict(0), strict=True)
     return m.eval().to("cuda")
 
@@ -160,7 +161,7 @@ def test_v2ce3d_state_dict_roundtrip():
     m(x)
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     from v2ce_toolbox_amd.v2ce_3d import V2ce3d
-    m2 = V2ce3d()
+    m2 = V2ce3d(precision="f32")
     m2.load_state_dict(sd)
     m2 = m2.eval().to("cuda")
     assert torch.equal(m(x), m2(x))

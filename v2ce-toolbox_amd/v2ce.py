@@ -41,9 +41,9 @@ def SBool(v):
     raise argparse.ArgumentTypeError("Boolean value expected.")
 
 
-def get_trained_mode(model_path="./weights/v2ce_3d.pt", device="cuda"):
+def get_trained_mode(model_path="./weights/v2ce_3d.pt", device="cuda", precision="f16x2"):
     """v2ce.py:30-43."""
-    model = V2ce3d()
+    model = V2ce3d(precision=precision)
     model.load_state_dict(torch.load(model_path, map_location="cpu"))
     model = model.eval()
     return model.to(device)
@@ -77,6 +77,8 @@ def build_parser():
     p.add_argument("--device", type=str, default="cuda")
     p.add_argument("--seed", type=int, default=0, help="Philox seed of the LDATI draws")
     p.add_argument("--rng", type=str, default="philox", choices=["philox", "torch"])
+    p.add_argument("--precision", type=str, default="f16x2", choices=["f16x2", "f32"],
+                   help="stage-1 conv arithmetic: split-half fp16 MFMA (f32-equivalent accuracy) or exact f32 MFMA")
     return p
 
 
@@ -229,11 +231,11 @@ def main(argv=None):
     os.makedirs(args.out_folder, exist_ok=True)
     if args.synthetic_weights is not None:
         from . import synth
-        model = V2ce3d()
+        model = V2ce3d(precision=args.precision)
         model.load_state_dict(synth.make_state_dict(args.synthetic_weights))
         model = model.eval().to(device)
     else:
-        model = get_trained_mode(args.model_path, device)
+        model = get_trained_mode(args.model_path, device, args.precision)
     if args.write_event_frame_video:
         logger.warning("event-frame mp4 (v2ce.py:241-280) needs OpenCV and is outside the hot path: skipped")
     event_stream = run(frames, model, args.infer_type, args.seq_len, args.width, args.height,

@@ -117,10 +117,13 @@ def _nearest_map(n_in: int, n_out: int) -> np.ndarray:
 class V2ce3d(nn.Module):
     """Drop-in for ``scripts/v2ce_3d.py:12``: ``V2ce3d()(x[B,L,2,H,W]) -> [B,L,20,H,W]``."""
 
-    def __init__(self, in_channels=2, out_channels=20, precision: str = "f32"):
-        """precision: "f32" (default: exact f32 MFMA) or "f16x2" (opt-in: the 3x3x3 convolutions of
-        the residual blocks run as 3 fp16 MFMAs on operands split into two halves, 22 bits; within
-        the 1e-5 bar, see tools/split_precision_sim.py)."""
+    def __init__(self, in_channels=2, out_channels=20, precision: str = "f16x2"):
+        """precision of the 3x3x3 convolutions of the residual blocks (99 % of the FLOP):
+        "f16x2" (default): every f32 operand is split into two fp16 halves (22 bits, power-of-two
+            pre-scales tracked on the device) and each product is three fp16 MFMAs accumulated in f32;
+            measured against an f64 evaluation of the network its error equals the exact-f32 path's
+            (profiles/r01_d_precision_report.json: rms 9.8e-8 both, 10x inside the 1e-5 parity bar);
+        "f32": exact f32 MFMA arithmetic (v_mfma_f32_32x32x2_f32) everywhere."""
         super().__init__()
         if precision not in ("f32", "f16x2"):
             raise ValueError(f"precision must be 'f32' or 'f16x2', got {precision!r}")
@@ -289,14 +292,41 @@ class V2ce3d(nn.Module):
     def _block(self, blk: _ResidualBlock3D, d, x0, x1=None, up_to=None):
         """submodules.py:249-264: relu(bn2(conv2(relu(bn1(conv1 x)))) + bn_d(conv_d x))."""
         s = blk.stride_hw
-        w1 = self._sn_weight(blk.conv1.module, d["conv1_w"]) if blk.sn else d["conv1_w"]
+        if blk.sn:
+            self._await_sn()
+        w1 = d["conv1_w"]
         t = self._conv(x0, x1, w1, *d["bn1"], blk.cout, 3, s, hip.ACT_RELU, up_to=up_to,
                        split=self._split(blk.cin, blk.cout))
         track = self.precision == "f16x2"      # the block output may feed a split-half conv
         res = self._conv(x0, x1, d["down_w"], *d["down_bn"], blk.cout, 1, s, hip.ACT_NONE, up_to=up_to)
-        w2 = self._sn_weight(blk.conv2.module, d["conv2_w"]) if blk.sn else d["conv2_w"]
+        w2 = d["conv2_w"]
         return self._conv(t, None, w2, *d["bn2"], blk.cout, 3, 1, hip.ACT_RELU, residual=res,
                           split=self._split(blk.cout, blk.cout), track=track)
+
+    def _launch_sn(self):
+        """One power iteration + re-pack for all 12 spectral-norm layers (the trajectory does not depend
+        on the input), enqueued on a side stream so that it overlaps the head conv and the four
+        (non-SN) encoder blocks; `_await_sn` joins it in front of the first SN block."""
+        main = torch.cuda.current_stream()
+        dev = self.UNet.head.conv3d.weight.device
+        if getattr(self, "_sn_stream", None) is None or self._sn_stream.device != dev:
+            self._sn_stream = torch.cuda.Stream(device=dev)
+        side = self._sn_stream
+        side.wait_stream(main)                   # the previous call's convs are done with the packed weights
+        with torch.cuda.stream(side):
+            for name, blocks in (("res", self.UNet.resblocks), ("dec", self.UNet.decoders)):
+                for i, blk in enumerate(blocks):
+                    d = self._prep[f"{name}{i}"]
+                    self._sn_weight(blk.conv1.module, d["conv1_w"])
+                    self._sn_weight(blk.conv2.module, d["conv2_w"])
+            self._sn_event = torch.cuda.Event()
+            self._sn_event.record(side)
+
+    def _await_sn(self):
+        ev = getattr(self, "_sn_event", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            self._sn_event = None
 
     @torch.no_grad()
     def advance_spectral_norm(self):
@@ -327,6 +357,7 @@ class V2ce3d(nn.Module):
         self._slot = 0
         if self.precision == "f16x2":
             P["absmax"].zero_()
+        self._launch_sn()
         inter = OrderedDict()
         h = self._conv(x, None, *P["head"], BASE, 3, 1, hip.ACT_LEAKY,           # unet_2layer.py:341
                        track=self.precision == "f16x2")
