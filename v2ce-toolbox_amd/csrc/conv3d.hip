@@ -125,7 +125,7 @@ __device__ __forceinline__ float apply_act(float t, float slope) { return fmaxf(
 // scalar branches): loads and stores are buffer operations whose per-lane offset is pushed out of
 // range for masked lanes (the hardware range check returns 0 / drops the store), the channel offset
 // rides in the scalar offset.  Requires Cout % 32 == 0, sequences < 2 GiB, y not aliasing the inputs.
-template <int CO_FR, int PO_FR>
+template <int CO_FR, int PO_FR, bool CHECK_CO = false>
 __device__ __forceinline__ void conv_epilogue(const ConvParams &P, const f32x16 (&acc)[CO_FR][PO_FR],
                                               const int (&poff)[PO_FR], int co0, int half, int b,
                                               float inv_scale) {
@@ -150,7 +150,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &P, const f32x16 
         float sc[16], sh[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int co = cbase + q * 32 + (r & 3) + 8 * (r >> 2);
+            int co = cbase + q * 32 + (r & 3) + 8 * (r >> 2);
+            if (CHECK_CO) co = co < P.Cout ? co : P.Cout - 1;
             sc[r] = scale[co] * inv_scale;
             sh[r] = shift[co];
         }
@@ -162,9 +163,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &P, const f32x16 
 #pragma unroll
                 for (int f = 0; f < PO_FR; ++f) {
                     rv[k][f] = 0.0f;
+                    const bool cok = !CHECK_CO || cbase + q * 32 + k + 8 * r4 < P.Cout;
                     if (P.res)                                  // uniform
                         rv[k][f] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                            rs_r, vo[f], (q * 32 + k + 8 * r4) * cstride4, 0));
+                            rs_r, cok ? vo[f] : kOOB, (q * 32 + k + 8 * r4) * cstride4, 0));
                 }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -174,9 +176,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &P, const f32x16 
                     float v = acc[q][f][r] * sc[r] + sh[r];
                     v += rv[k][f];
                     v = apply_act(v, slope);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, vo[f],
+                    const bool cok = !CHECK_CO || cbase + q * 32 + k + 8 * r4 < P.Cout;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, cok ? vo[f] : kOOB,
                                                           (q * 32 + k + 8 * r4) * cstride4, 0);
-                    const unsigned av = __builtin_bit_cast(unsigned, v) & vmask[f];
+                    const unsigned av = __builtin_bit_cast(unsigned, v) & (cok ? vmask[f] : 0u);
                     ymax = av > ymax ? av : ymax;
                 }
             }
@@ -473,7 +476,10 @@ __global__ __launch_bounds__(256, MW) void conv3d_kernel(ConvParams P) {
     }
 
 #undef ISSUE
-    conv_epilogue_stream<CO_FR, PO_FR>(P, acc, poff, co0, half, b);
+    // measured: the batched straight-line epilogue wins on the store-heavy 1x1x1 kernels (enc0.down 0.48 ->
+    // 0.37 ms), the streaming one on the register-tight 3x3x3 kernels (127 vs 117 TF)
+    if constexpr (KS == 1) conv_epilogue<CO_FR, PO_FR, true>(P, acc, poff, co0, half, b, 1.0f);
+    else conv_epilogue_stream<CO_FR, PO_FR>(P, acc, poff, co0, half, b);
 #endif  // __HIP_DEVICE_COMPILE__ (the host pass only needs the launch stub)
 }
 
@@ -1195,7 +1201,7 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
     V2CE_REQUIRE(d.Cout % 4 == 0, V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd: Cout %% 4 != 0");
     const long long seq_in0 = (long long)d.T * d.C0 * d.H0 * d.W0, seq_in1 = (long long)d.T * d.C1 * d.Hin * d.Win;
     const long long seq_out = (long long)d.T * d.Cout * d.Hout * d.Wout;
-    V2CE_REQUIRE(seq_in0 < (1ll << 29) && seq_in1 < (1ll << 29) && seq_out < (1ll << 31),
+    V2CE_REQUIRE(seq_in0 < (1ll << 29) && seq_in1 < (1ll << 29) && seq_out < (1ll << 29),
                  V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd: a single sequence exceeds the 2 GiB buffer-descriptor range");
 
     ConvParams P{};
