@@ -56,6 +56,7 @@ struct ConvParams {
     int n_spatial;        // B*nT*nH*nW
     int xcd_remap;        // 1: blocks that share an input box (different co tiles) share an XCD/L2
     int total_blocks;     // persistent kernels: number of virtual blocks to walk
+    int per_xcd;          // persistent kernels: spatial boxes per XCD
     // split-half path (conv3d_f16x2_kernel): weights as fp16 hi/lo planes [2][K3][Cin/16][Cout][16]
     // followed by { max |w|, power-of-two pre-scale } as two floats (pack_weights_f16x2_kernel)
     const _Float16 *wq;
@@ -678,17 +679,16 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
     // boundaries, so a tile's first chunk is gathered and converted while the consumers are still in
     // the previous tile's last chunk and epilogue.
     struct TileId { int b, co_t, t0, h0, w0; };
+    // XCD x = vb & 7 owns the contiguous range [x * per_xcd, (x + 1) * per_xcd) of spatial boxes and walks
+    // it in order, all channel tiles of a box back to back: the 32 workgroups of an XCD work on
+    // neighbouring boxes at the same time, so the halo overlap (2.4x the tensor for 512-position
+    // boxes) is served by that XCD's L2 instead of being fetched once per XCD.
     auto decode = [&](int vb, TileId &T) -> bool {
-        int bid = vb;
-        if (P.xcd_remap) {
-            const int xcd = bid & 7, q = bid >> 3;
-            T.co_t = q % P.n_co_tiles;
-            bid = (q / P.n_co_tiles) * 8 + xcd;
-            if (bid >= P.n_spatial) return false;
-        } else {
-            T.co_t = bid % P.n_co_tiles;
-            bid /= P.n_co_tiles;
-        }
+        const int xcd = vb & 7, q = vb >> 3;
+        T.co_t = q % P.n_co_tiles;
+        const int sp = q / P.n_co_tiles;
+        int bid = xcd * P.per_xcd + sp;
+        if (sp >= P.per_xcd || bid >= P.n_spatial) return false;
         const int iw = bid % P.nW;            bid /= P.nW;
         const int ih = bid % P.nH;            bid /= P.nH;
         const int it = bid % P.nT;            bid /= P.nT;
@@ -1030,9 +1030,9 @@ int launch_f16x2(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream) {
     P.nT = (d.T + t.tt - 1) / t.tt; P.nH = (d.Hout + t.th - 1) / t.th; P.nW = (d.Wout + t.tw - 1) / t.tw;
     P.n_co_tiles = (d.Cout + CO_TILE - 1) / CO_TILE;
     P.n_spatial = d.B * P.nT * P.nH * P.nW;
-    P.xcd_remap = P.n_co_tiles > 1 ? 1 : 0;
-    const long long blocks = P.xcd_remap ? (long long)((P.n_spatial + 7) / 8) * 8 * P.n_co_tiles
-                                         : (long long)P.n_spatial * P.n_co_tiles;
+    P.xcd_remap = 1;
+    P.per_xcd = (P.n_spatial + 7) / 8;
+    const long long blocks = (long long)8 * P.per_xcd * P.n_co_tiles;
     const int chs = (P.plane + 63) & ~63;
     const size_t lds = (size_t)chs * (16 * 4 + 4 * 16);
     V2CE_REQUIRE(lds <= 160 * 1024, V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd(f16x2): %zu B of LDS", lds);
@@ -1081,9 +1081,9 @@ int launch_f16x2_ws(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream)
     P.nT = (d.T + t.tt - 1) / t.tt; P.nH = (d.Hout + t.th - 1) / t.th; P.nW = (d.Wout + t.tw - 1) / t.tw;
     P.n_co_tiles = (d.Cout + CO_TILE - 1) / CO_TILE;
     P.n_spatial = d.B * P.nT * P.nH * P.nW;
-    P.xcd_remap = P.n_co_tiles > 1 ? 1 : 0;
-    const long long blocks = P.xcd_remap ? (long long)((P.n_spatial + 7) / 8) * 8 * P.n_co_tiles
-                                         : (long long)P.n_spatial * P.n_co_tiles;
+    P.xcd_remap = 1;
+    P.per_xcd = (P.n_spatial + 7) / 8;
+    const long long blocks = (long long)8 * P.per_xcd * P.n_co_tiles;
     const int chs = (P.plane + 63) & ~63;
     const size_t lds = (size_t)chs * (2 * 4 * 16);
     V2CE_REQUIRE(lds <= 160 * 1024, V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd(f16x2 ws): %zu B of LDS", lds);
