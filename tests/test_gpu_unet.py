@@ -182,7 +182,7 @@ def test_v2ce3d_full_width_tile_vs_oracle():
 
 
 # ---- opt-in split-half precision (V2CE_PRECISION_F16X2): same 1e-5 bar -------------------------
-def hip_conv_split(x0, w, scale, shift, stride, act, x1=None, up_to=None, residual=None, tracked=False):
+def hip_conv_split(x0, w, scale, shift, stride, act, x1=None, up_to=None, residual=None, tracked=False, ksize=3):
     """tracked: pass max|x| slots like V2ce3d does (dynamic power-of-two pre-scale); otherwise the
     kernel's fixed pre-scale (|x| < 4094)."""
     from v2ce_toolbox_amd.v2ce_3d import V2ce3d
@@ -200,7 +200,7 @@ def hip_conv_split(x0, w, scale, shift, stride, act, x1=None, up_to=None, residu
         if x1d is not None:
             x1d.absmax = x1d.abs().max().reshape(1)
     y = V2ce3d._conv(m, x0d, x1d, wq,
-                     scale.cuda().contiguous(), shift.cuda().contiguous(), w.shape[0], 3, stride, act,
+                     scale.cuda().contiguous(), shift.cuda().contiguous(), w.shape[0], ksize, stride, act,
                      residual=None if residual is None else to_btchw(residual).cuda(), up_to=up_to,
                      split=True)
     torch.cuda.synchronize()
@@ -240,6 +240,29 @@ def test_conv3d_split_half_virtual_concat():
     got = hip_conv_split(x0, w, torch.ones(32), torch.zeros(32), 1, 1, x1=x1, up_to=(33, 44))
     want = ref_conv(x0, w, torch.ones(32), torch.zeros(32), 3, 1, 1, x1=x1, up_to=(33, 44))
     assert_close(got, want, "split upsample+concat")
+
+
+@pytest.mark.parametrize("case", [
+    # B, T, C0, C1, Cout, H, W, stride, upsampled source 0
+    (1, 5, 32, 0, 64, 21, 30, 2, False),     # encoder shortcut: strided gather
+    (2, 3, 64, 32, 32, 19, 26, 1, True),     # decoder shortcut: virtual upsample + concat, 32 channels
+    (1, 16, 128, 0, 128, 9, 11, 1, False),
+    (1, 4, 64, 0, 128, 18, 23, 2, False),
+])
+def test_conv1x1_split_half_vs_f64(case):
+    """The 1x1x1 shortcut convs on the split-half kernel (one tap per chunk, strided / virtual gathers)."""
+    B, T, C0, C1, Cout, H, W, s, ups = case
+    g = torch.Generator().manual_seed(11)
+    h0, w0 = ((H + 1) // 2, (W + 1) // 2) if ups else (H, W)
+    x0 = torch.randn(B, C0, T, h0, w0, generator=g)
+    x1 = torch.randn(B, C1, T, H, W, generator=g) if C1 else None
+    w = torch.randn(Cout, C0 + C1, 1, 1, 1, generator=g) * (2.0 / (C0 + C1)) ** 0.5
+    scale = 0.5 + torch.rand(Cout, generator=g)
+    shift = 0.2 * torch.randn(Cout, generator=g)
+    up_to = (H, W) if ups else None
+    got = hip_conv_split(x0, w, scale, shift, s, 0, x1=x1, up_to=up_to, tracked=True, ksize=1)
+    want = ref_conv(x0, w, scale, shift, 1, s, 0, x1=x1, up_to=up_to)
+    assert_close(got, want, "split 1x1 " + str(case))
 
 
 @pytest.mark.parametrize("mag", [1e-6, 1.0, 3e4, 1e9])

@@ -16,7 +16,8 @@ LAYERS = {   # name: (C0, lvl0, C1, lvl_in, Cout, ksize, stride)
     "res0.conv1": (512, 4, 0, 4, 512, 3, 1), "enc0.conv1": (32, 0, 0, 0, 64, 3, 2), "enc3.conv1": (256, 3, 0, 3, 512, 3, 2), "dec1.conv1": (256, 3, 128, 2, 128, 3, 1),
     "dec2.conv1": (128, 2, 64, 1, 64, 3, 1), "dec0.conv1": (512, 4, 256, 3, 256, 3, 1), "dec1.conv2": (128, 2, 0, 2, 128, 3, 1),
     "dec3.conv1": (64, 1, 32, 0, 32, 3, 1), "dec3.conv2": (32, 0, 0, 0, 32, 3, 1),
-    "dec2.down": (128, 2, 64, 1, 64, 1, 1), "pred": (32, 0, 0, 0, 20, 1, 1), "enc0.down": (32, 0, 0, 0, 64, 1, 2),
+    "dec2.down": (128, 2, 64, 1, 64, 1, 1), "dec1.down": (256, 3, 128, 2, 128, 1, 1), "res0.down": (512, 4, 0, 4, 512, 1, 1),
+    "enc1.down": (64, 1, 0, 1, 128, 1, 2), "enc3.down": (256, 3, 0, 3, 512, 1, 2), "dec3.down": (64, 1, 32, 0, 32, 1, 1), "pred": (32, 0, 0, 0, 20, 1, 1), "enc0.down": (32, 0, 0, 0, 64, 1, 2),
 }
 
 
@@ -33,7 +34,7 @@ def run(name, B=4, T=16, iters=5, tile=(0, 0, 0)):
         wmap = (torch.arange(Win, device=dev) * W0 // Win).int()
     pad = k // 2
     Ho, Wo = (Hin + 2 * pad - k) // s + 1, (Win + 2 * pad - k) // s + 1
-    split = os.environ.get("PRECISION", "f32") == "f16x2" and k == 3
+    split = os.environ.get("PRECISION", "f32") == "f16x2" and Cout % 32 == 0 and (C0 + C1) % 16 == 0
     if split:
         w32 = torch.randn(Cout, C0 + C1, k, k, k, device=dev) * 0.02
         w = torch.empty(2 * w32.numel() + 4, dtype=torch.float16, device=dev)

@@ -227,7 +227,7 @@ __device__ __forceinline__ void conv_epilogue_stream(const ConvParams &P, const 
 // Element r of the halo plane <-> LDS offset r inside the channel.
 template <int EPT>
 __device__ __forceinline__ void halo_offsets(const ConvParams &P, int tin0, int hin0, int win0,
-                                             bool src1, int tid, unsigned (&goff)[EPT]) {
+                                             bool src1, int tid, unsigned (&goff)[EPT], int gs = 1) {
     const int Cs = src1 ? P.C1 : P.C0;
     const int Hs = src1 ? P.Hin : P.H0, Ws = src1 ? P.Win : P.W0;
     const bool mapped = !src1 && P.hmap != nullptr;
@@ -240,7 +240,7 @@ __device__ __forceinline__ void halo_offsets(const ConvParams &P, int tin0, int 
             const int rem = r - ht * (P.HH * P.HWd);
             const int hh = rem / P.HWd;
             const int hw = rem - hh * P.HWd;
-            const int t = tin0 + ht, h = hin0 + hh, w = win0 + hw;
+            const int t = tin0 + ht, h = hin0 + hh * gs, w = win0 + hw * gs;   // gs > 1: strided 1x1x1 gather
             if (t >= 0 && t < P.T && h >= 0 && h < P.Hin && w >= 0 && w < P.Win) {
                 const int hs = mapped ? P.hmap[h] : h;
                 const int ws = mapped ? P.wmap[w] : w;
@@ -659,10 +659,11 @@ __global__ __launch_bounds__(256, 1) void conv3d_f16x2_kernel(ConvParams P) {
 // issue and its branches never sit in the MFMA waves' instruction stream.
 // LDS: 2 x 64 B of pieces per halo element (up to 1280 elements: 512-position boxes).
 // ---------------------------------------------------------------------------------------------
-template <int S, int WCO, int CO_FR, int PO_FR, int NA>
+template <int KS, int S, int WCO, int CO_FR, int PO_FR, int NA>
 __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int K3 = 27, CK = 16, EPT = 5, PAD = 1;
+    // KS = 1: the "halo box" is the output box itself (positions gathered with stride S), one tap
+    constexpr int K3 = KS * KS * KS, CK = 16, EPT = 5, PAD = KS / 2, GS = KS == 1 ? S : 1;
     constexpr int WPO = 4 / WCO;
     constexpr int CO_TILE = WCO * CO_FR * 32;
     const int chs = (P.plane + 63) & ~63;
@@ -729,7 +730,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
             const int want_src = ci0 < P.C0 ? 0 : 1;
             if (want_src != cur_src) {   // uniform; at most twice per tile
                 cur_src = want_src;
-                halo_offsets<EPT>(P, L.t0 - PAD, L.h0 * S - PAD, L.w0 * S - PAD, want_src == 1, ptid, goff);
+                halo_offsets<EPT>(P, L.t0 - PAD, L.h0 * S - PAD, L.w0 * S - PAD, want_src == 1, ptid, goff, GS);
                 if (want_src == 0) {
                     const long long seq = (long long)P.T * P.C0 * (P.H0 * P.W0);
                     rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x0 + L.b * seq), 0, (int)(seq * 4), 0x00020000);
@@ -812,7 +813,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
     // NA-1 taps ahead; 27 % NA == 0, so slot = tap % NA stays static across chunk boundaries.  The
     // last chunk of a tile prefetches chunk 0 again: exactly what the workgroup's next tile starts
     // with when it has the same channel tile (always, for power-of-two tile counts).
-    f16x8 ah[NA][CO_FR], al[NA][CO_FR], bh[PO_FR], bl[PO_FR];
+    f16x8 ah[KS == 1 ? 2 : NA][CO_FR], al[KS == 1 ? 2 : NA][CO_FR], bh[PO_FR], bl[PO_FR];
     int wlane[CO_FR];
 #define V2CE_LOAD_A(slot_, soff_)                                                              \
     {                                                                                          \
@@ -836,7 +837,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
                 const int rem = m - tt * (P.TH * P.TW);
                 const int th = rem / P.TW;
                 const int tw = rem - th * P.TW;
-                bhb[f] += (tt * P.HH + th * S) * P.HWd + tw * S;
+                bhb[f] += KS == 1 ? m : (tt * P.HH + th * S) * P.HWd + tw * S;
             }
         }
         if (T.co_t != ring_co_t) {                          // uniform: (re)load the ring for this channel tile
@@ -847,10 +848,14 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
                 co = co < P.Cout ? co : P.Cout - 1;
                 wlane[q] = (co * 16 + 8 * half) * 2;
             }
-            step_loop<0, NA - 1>([&](auto tc) {
-                constexpr int t = decltype(tc)::value;
-                V2CE_LOAD_A(t, t * tap_stride)              // chunk 0, taps 0 .. NA-2
-            });
+            if constexpr (KS == 1) {
+                V2CE_LOAD_A(1, 0)                           // chunk 0 (moved to slot 0 at the top of the chunk)
+            } else {
+                step_loop<0, NA - 1>([&](auto tc) {
+                    constexpr int t = decltype(tc)::value;
+                    V2CE_LOAD_A(t, t * tap_stride)          // chunk 0, taps 0 .. NA-2
+                });
+            }
         }
 
         f32x16 acc[CO_FR][PO_FR];
@@ -865,6 +870,11 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
             const f16x8 *qb = pieces + (gc & 1) * 4 * chs;
             const int wc = cg * cg_stride;
             const int wn = cg + 1 < CG ? wc + cg_stride : 0;    // last chunk: chunk 0 again (the next tile's start)
+            if constexpr (KS == 1) {                            // one tap per chunk: A double-buffered over chunks
+#pragma unroll
+                for (int q = 0; q < CO_FR; ++q) { ah[0][q] = ah[1][q]; al[0][q] = al[1][q]; }
+                V2CE_LOAD_A(1, wn)
+            }
             __syncthreads();                                   // barrier gc: pieces[gc & 1] ready
             if (gc == 0) STAMP(0, 1);
             if (gc == 1) STAMP(0, 2);
@@ -873,6 +883,16 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
                 bh[f] = qb[bhb[f]];
                 bl[f] = qb[bhb[f] + 2 * chs];
             }
+            if constexpr (KS == 1) {
+#pragma unroll
+                for (int f = 0; f < PO_FR; ++f)
+#pragma unroll
+                    for (int q = 0; q < CO_FR; ++q) {
+                        acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][q], bh[f], acc[q][f], 0, 0, 0);
+                        acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][q], bl[f], acc[q][f], 0, 0, 0);
+                        acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[0][q], bh[f], acc[q][f], 0, 0, 0);
+                    }
+            } else
             step_loop<0, K3>([&](auto tc) {
                 constexpr int tap = decltype(tc)::value;
                 constexpr int nt = tap + 1;
@@ -1058,21 +1078,21 @@ __global__ __launch_bounds__(256) void weights_absmax_kernel(const float *__rest
     if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned *>(tail), __float_as_uint(m));
 }
 
-template <int S, int WCO, int CO_FR, int PO_FR, int NA>
+template <int KS, int S, int WCO, int CO_FR, int PO_FR, int NA>
 int launch_f16x2_ws(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream) {
     static_assert(27 % NA == 0 && NA >= 2, "the A-fragment ring must divide the 27 taps");
-    constexpr int KS = 3;
     constexpr int CO_TILE = WCO * CO_FR * 32, POS_TILE = (4 / WCO) * PO_FR * 32;
     constexpr int MAX_PLANE = 1280;         // 128 B of LDS per halo element; 5 elements per producer lane
     if (g_name_out) {
-        snprintf(g_name_out, g_name_cap, "conv3d_f16x2_ws_kernel<%d,%d,%d,%d,%d>", S, WCO, CO_FR, PO_FR, NA);
+        snprintf(g_name_out, g_name_cap, "conv3d_f16x2_ws_kernel<%d,%d,%d,%d,%d,%d>", KS, S, WCO, CO_FR, PO_FR, NA);
         return V2CE_OK;
     }
     Tile t{d.tile_t, d.tile_h, d.tile_w};
-    if (t.tt <= 0 || t.th <= 0 || t.tw <= 0) t = choose_tile(d.T, d.Hout, d.Wout, KS, S, POS_TILE, MAX_PLANE);
+    if (t.tt <= 0 || t.th <= 0 || t.tw <= 0) t = choose_tile(d.T, d.Hout, d.Wout, KS, KS == 1 ? 1 : S, POS_TILE, MAX_PLANE);
     P.TT = t.tt; P.TH = t.th; P.TW = t.tw;
     P.n_pos = t.tt * t.th * t.tw;
-    P.HT = t.tt + KS - 1; P.HH = (t.th - 1) * S + KS; P.HWd = (t.tw - 1) * S + KS;
+    if (KS == 1) { P.HT = t.tt; P.HH = t.th; P.HWd = t.tw; }          // the gathered box is the output box
+    else { P.HT = t.tt + KS - 1; P.HH = (t.th - 1) * S + KS; P.HWd = (t.tw - 1) * S + KS; }
     P.plane = P.HT * P.HH * P.HWd;
     V2CE_REQUIRE(P.n_pos <= POS_TILE && P.plane <= MAX_PLANE, V2CE_ERR_UNSUPPORTED,
                  "v2ce_conv3d_fwd(f16x2 ws): tile does not fit");
@@ -1087,7 +1107,7 @@ int launch_f16x2_ws(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream)
     const int chs = (P.plane + 63) & ~63;
     const size_t lds = (size_t)chs * (2 * 4 * 16);
     V2CE_REQUIRE(lds <= 160 * 1024, V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd(f16x2 ws): %zu B of LDS", lds);
-    auto kern = conv3d_f16x2_ws_kernel<S, WCO, CO_FR, PO_FR, NA>;
+    auto kern = conv3d_f16x2_ws_kernel<KS, S, WCO, CO_FR, PO_FR, NA>;
     V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 #ifdef V2CE_STAMP
@@ -1123,9 +1143,9 @@ int launch_f16x2_ws(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream)
             std::sort(v.begin(), v.end());
             return v[v.size() / 2];
         };
-        fprintf(stderr, "[stamp ws<%d,%d,%d,%d,%d> CG=%d plane=%d blocks=%lld] consumer: setup->bar0 %lld, chunk0 %lld, bar1->end-of-loop %lld, epilogue %lld, total %lld | "
+        fprintf(stderr, "[stamp ws<%d,%d,%d,%d,%d,%d> CG=%d plane=%d blocks=%lld] consumer: setup->bar0 %lld, chunk0 %lld, bar1->end-of-loop %lld, epilogue %lld, total %lld | "
                 "producer: issue0 %lld, wait+convert0 %lld, issue1 %lld, bar0 wait %lld, chunk1 iter %lld, total %lld\n",
-                S, WCO, CO_FR, PO_FR, NA, P.Cin / 16, P.plane, blocks, med(0, 0, 1), med(0, 1, 2), med(0, 2, 3), med(0, 3, 4), med(0, 0, 4),
+                KS, S, WCO, CO_FR, PO_FR, NA, P.Cin / 16, P.plane, blocks, med(0, 0, 1), med(0, 1, 2), med(0, 2, 3), med(0, 3, 4), med(0, 0, 4),
                 med(1, 0, 1), med(1, 1, 2), med(1, 2, 3), med(1, 3, 4), med(1, 4, 5), med(1, 0, 6));
     }
 #endif
@@ -1216,27 +1236,39 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
     const bool small_co = d.Cout <= 32;
     if (d.precision == V2CE_PRECISION_F16X2) {
         // split-half path: w_packed is the fp16 hi/lo buffer of v2ce_pack_weights_f16x2
-        V2CE_REQUIRE(d.ksize == 3 && P.Cin % 16 == 0 && (d.C1 == 0 || d.C0 % 16 == 0) && d.Cout % 32 == 0,
-                     V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd(f16x2): needs a 3x3x3 kernel, input channel counts that "
-                     "are multiples of 16 and an output channel count that is a multiple of 32");
+        V2CE_REQUIRE(P.Cin % 16 == 0 && (d.C1 == 0 || d.C0 % 16 == 0) && d.Cout % 32 == 0,
+                     V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd(f16x2): needs input channel counts that are multiples "
+                     "of 16 and an output channel count that is a multiple of 32");
         P.wq = reinterpret_cast<const _Float16 *>(w_packed);
         V2CE_REQUIRE(x0_absmax || !x1_absmax, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd(f16x2): x1_absmax without x0_absmax");
         V2CE_REQUIRE(d.C1 == 0 || !x0_absmax || x1_absmax, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd(f16x2): x0_absmax without x1_absmax");
         static const int ws = [] { const char *e = getenv("V2CE_WS"); return e ? atoi(e) : 1; }();
+        if (d.ksize == 1) {
+            // 1x1x1 (shortcuts): one tap per chunk, so the producers set the pace; still ~2x the exact-f32
+            // kernel, which is MFMA-bound on these (100 TF)
+            if (s == 1) {
+                if (small_co) return launch_f16x2_ws<1, 1, 1, 1, 4, 3>(P, d, st);
+                if (d.Cout >= 128) return launch_f16x2_ws<1, 1, 2, 2, 4, 3>(P, d, st);
+                return launch_f16x2_ws<1, 1, 1, 2, 4, 3>(P, d, st);
+            }
+            if (small_co) return launch_f16x2_ws<1, 2, 1, 1, 4, 3>(P, d, st);
+            if (d.Cout >= 128) return launch_f16x2_ws<1, 2, 2, 2, 4, 3>(P, d, st);
+            return launch_f16x2_ws<1, 2, 1, 2, 4, 3>(P, d, st);
+        }
         if (s == 1 && ws) {
             // wave-specialised kernel, measured (tools/conv_bench.py, TF-equivalent): 128 x 256 boxes
             // 370-450; 64 x 512: 285-390 (64 x 256: 248-358); 32 x 512: 186-299 (32 x 256: 114-205)
             static const int na = [] { const char *e = getenv("V2CE_NA"); return e ? atoi(e) : 3; }();
-            if (small_co) return na == 9 ? launch_f16x2_ws<1, 1, 1, 4, 9>(P, d, st) : launch_f16x2_ws<1, 1, 1, 4, 3>(P, d, st);
-            if (d.Cout >= 128) return launch_f16x2_ws<1, 2, 2, 4, 3>(P, d, st);
-            return launch_f16x2_ws<1, 1, 2, 4, 3>(P, d, st);
+            if (small_co) return na == 9 ? launch_f16x2_ws<3, 1, 1, 1, 4, 9>(P, d, st) : launch_f16x2_ws<3, 1, 1, 1, 4, 3>(P, d, st);
+            if (d.Cout >= 128) return launch_f16x2_ws<3, 1, 2, 2, 4, 3>(P, d, st);
+            return launch_f16x2_ws<3, 1, 1, 2, 4, 3>(P, d, st);
         }
         if (s == 2 && ws) {
             // stride 2: the halo box is ~4x the output box, 128-position boxes; measured 223-293
             // TF-equivalent with one 32-channel fragment row per wave (Cout >= 128), 121 at Cout = 64
             static const int na = [] { const char *e = getenv("V2CE_NA"); return e ? atoi(e) : 3; }();
-            if (d.Cout >= 128) return na == 9 ? launch_f16x2_ws<2, 4, 1, 4, 9>(P, d, st) : launch_f16x2_ws<2, 4, 1, 4, 3>(P, d, st);
-            if (!small_co) return na == 9 ? launch_f16x2_ws<2, 2, 1, 2, 9>(P, d, st) : launch_f16x2_ws<2, 2, 1, 2, 3>(P, d, st);
+            if (d.Cout >= 128) return na == 9 ? launch_f16x2_ws<3, 2, 4, 1, 4, 9>(P, d, st) : launch_f16x2_ws<3, 2, 4, 1, 4, 3>(P, d, st);
+            if (!small_co) return na == 9 ? launch_f16x2_ws<3, 2, 2, 1, 2, 9>(P, d, st) : launch_f16x2_ws<3, 2, 2, 1, 2, 3>(P, d, st);
         }
         if (s == 1) {
             if (small_co) return launch_f16x2<3, 1, 1, 1, 2, 4>(P, d, st);
@@ -1346,8 +1378,8 @@ extern "C" size_t v2ce_pack_weights_f16x2_bytes(int Cout, int Cin, int k3) {
 extern "C" int v2ce_pack_weights_f16x2(const float *w, int Cout, int Cin, int k3, const float *sigma,
                                        void *w_f16x2, v2ce_stream_t stream) {
     clear_error();
-    V2CE_REQUIRE(w && w_f16x2 && Cout > 0 && Cin > 0 && Cin % 16 == 0 && k3 == 27, V2CE_ERR_BAD_ARG,
-                 "v2ce_pack_weights_f16x2: needs a 3x3x3 kernel and Cin %% 16 == 0");
+    V2CE_REQUIRE(w && w_f16x2 && Cout > 0 && Cin > 0 && Cin % 16 == 0 && (k3 == 27 || k3 == 1), V2CE_ERR_BAD_ARG,
+                 "v2ce_pack_weights_f16x2: needs a 3x3x3 or 1x1x1 kernel and Cin %% 16 == 0");
     const long long n = (long long)Cout * Cin * k3;
     float *tail = reinterpret_cast<float *>(static_cast<_Float16 *>(w_f16x2) + 2 * n);
     V2CE_HIP_CHECK(hipMemsetAsync(tail, 0, 2 * sizeof(float), as_stream(stream)));
