@@ -719,14 +719,17 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
     if (wave >= 4) {
         // ------------------------------------------------------------------ producers
         // a chunk travels global -> registers (gather with the halo offsets; out-of-range offsets
-        // read as the zero padding) -> fp16 hi/lo pieces in LDS.  The loads of the chunk after it are
-        // issued before the barrier and land while the consumers work.
+        // read as the zero padding) -> fp16 hi/lo pieces in LDS.  Two register buffers: the loads of
+        // chunk c+2 are issued right after chunk c has been converted, so every gather has a whole
+        // consumer chunk to land in (measured: with one buffer the producers spent 18-28 k cycles per
+        // chunk, most of it waiting for their own loads, and set the pace of every layer).  The load
+        // cursor (tile, chunk) therefore runs two chunks ahead of the conversion, across tiles.
         const int ptid = tid - 256;
         unsigned goff[EPT];
-        float R[CK][EPT];
+        float R0[CK][EPT], R1[CK][EPT];
         __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x0), 0, 0, 0x00020000);
         int cur_src = -1, src_cstride4 = 0, src_cbase = 0;
-        auto load_chunk = [&](const TileId &L, int ci0) {
+        auto load_chunk = [&](const TileId &L, int ci0, float (&R)[CK][EPT]) {
             const int want_src = ci0 < P.C0 ? 0 : 1;
             if (want_src != cur_src) {   // uniform; at most twice per tile
                 cur_src = want_src;
@@ -753,46 +756,71 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
                 }
             }
         };
-        STAMP(1, 0);
-        load_chunk(T, 0);
-        STAMP(1, 1);
-        bool more = true;
-        while (more) {
-            for (int cg = 0; cg < CG; ++cg, ++gc) {
-                f16x8 *qb = pieces + (gc & 1) * 4 * chs;
+        // load cursor
+        int vbL = vb, cgL = 0;
+        TileId TL = T;
+        bool moreL = true;
+        auto load_next = [&](float (&R)[CK][EPT]) {
+            if (!moreL) return;
+            load_chunk(TL, cgL * CK, R);
+            if (++cgL == CG) {
+                cgL = 0;
+                vbL += (int)gridDim.x;
+                moreL = next_tile(vbL, TL);
+                cur_src = -1;
+            }
+        };
+        auto convert = [&](const float (&R)[CK][EPT]) {
+            f16x8 *qb = pieces + (gc & 1) * 4 * chs;
 #pragma unroll
-                for (int i = 0; i < EPT; ++i) {
-                    const int r = ptid + 256 * i;
-                    if ((wave - 4) * 64 + 256 * i < P.plane) {        // wave-uniform (lanes past the plane write padding)
+            for (int i = 0; i < EPT; ++i) {
+                const int r = ptid + 256 * i;
+                if ((wave - 4) * 64 + 256 * i < P.plane) {            // wave-uniform (lanes past the plane write padding)
 #pragma unroll
-                        for (int hg = 0; hg < 2; ++hg) {
-                            f16x8 vh, vl;
+                    for (int hg = 0; hg < 2; ++hg) {
+                        f16x8 vh, vl;
 #pragma unroll
-                            for (int c = 0; c < 8; ++c) {
-                                const float v = R[8 * hg + c][i] * x_scale;
-                                const _Float16 hh = (_Float16)v;
-                                vh[c] = hh;
-                                vl[c] = (_Float16)(v - (float)hh);
-                            }
-                            qb[hg * chs + r] = vh;
-                            qb[(2 + hg) * chs + r] = vl;
+                        for (int c = 0; c < 8; ++c) {
+                            const float v = R[8 * hg + c][i] * x_scale;
+                            const _Float16 hh = (_Float16)v;
+                            vh[c] = hh;
+                            vl[c] = (_Float16)(v - (float)hh);
                         }
+                        qb[hg * chs + r] = vh;
+                        qb[(2 + hg) * chs + r] = vl;
                     }
                 }
-                if (gc == 0) STAMP(1, 2);
-                if (cg + 1 < CG) {
-                    load_chunk(T, (cg + 1) * CK);
-                } else {                                              // first chunk of the next tile
-                    vb += (int)gridDim.x;
-                    more = next_tile(vb, T);
-                    cur_src = -1;
-                    if (more) load_chunk(T, 0);
-                }
-                if (gc == 0) STAMP(1, 3);
-                __syncthreads();                                      // barrier gc: pieces[gc & 1] ready
-                if (gc == 0) STAMP(1, 4);
-                if (gc == 1) STAMP(1, 5);
             }
+        };
+        // conversion cursor: counts the chunks of this workgroup's tiles
+        int cgC = 0;
+        bool moreC = true;
+        auto advance = [&]() {
+            ++gc;
+            if (++cgC == CG) {
+                cgC = 0;
+                vb += (int)gridDim.x;
+                moreC = next_tile(vb, T);
+            }
+        };
+        STAMP(1, 0);
+        load_next(R0);
+        load_next(R1);
+        STAMP(1, 1);
+        while (moreC) {
+            convert(R0);
+            if (gc == 0) STAMP(1, 2);
+            load_next(R0);
+            if (gc == 0) STAMP(1, 3);
+            __syncthreads();                                          // barrier gc: pieces[gc & 1] ready
+            if (gc == 0) STAMP(1, 4);
+            advance();
+            if (!moreC) break;
+            convert(R1);
+            load_next(R1);
+            __syncthreads();
+            if (gc == 1) STAMP(1, 5);
+            advance();
         }
         STAMP(1, 6);
         return;
