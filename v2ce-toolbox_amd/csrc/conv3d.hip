@@ -57,7 +57,7 @@ struct ConvParams {
     int xcd_remap;        // 1: blocks that share an input box (different co tiles) share an XCD/L2
     int total_blocks;     // persistent kernels: number of virtual blocks to walk
     int per_xcd;          // persistent kernels: spatial boxes per XCD
-    // split-half path (conv3d_f16x2_kernel): weights as fp16 hi/lo planes [2][K3][Cin/16][Cout][16]
+    // split-half path (conv3d_f16x2_ws_kernel): weights as fp16 hi/lo planes [2][K3][Cin/16][Cout][16]
     // followed by { max |w|, power-of-two pre-scale } as two floats (pack_weights_f16x2_kernel)
     const _Float16 *wq;
     // dynamic range tracking: y_absmax (may be null) receives max |y| of this launch by atomic max;
@@ -485,170 +485,13 @@ __global__ __launch_bounds__(256, MW) void conv3d_kernel(ConvParams P) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Split-half variant: every operand is the sum of two fp16 numbers (x = (xh + xl)/16,
-// w = (wh + wl)/256) and each 16-channel k-step is three v_mfma_f32_32x32x16_f16
-// (wh.xh + wh.xl + wl.xh; products exact, f32 accumulation): 22-bit operands at 5.3x the f32 MFMA
-// rate per k-step.  tools/split_precision_sim.py shows the result stays 9x inside the 1e-5 bar.
-// Same tensors, tiling, halo gather and epilogue as conv3d_kernel; per 16-channel chunk the f32 halo
-// is DMA-staged, then converted once into position-major fp16 pieces ([piece][pos] x 16 B, piece =
-// plane*2 + channel half) so a B fragment is one ds_read_b128; weights come straight from L2 as
-// 16-byte A fragments, prefetched two taps ahead.
-// ---------------------------------------------------------------------------------------------
-template <int KS, int S, int WCO, int CO_FR, int PO_FR, int EPT>
-__global__ __launch_bounds__(256, 1) void conv3d_f16x2_kernel(ConvParams P) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int K3 = KS * KS * KS, CK = 16, WPO = 4 / WCO;
-    constexpr int CO_TILE = WCO * CO_FR * 32;
-    constexpr int PAD = KS / 2;
-    const int chs = (P.plane + 63) & ~63;
-    float *stage = reinterpret_cast<float *>(conv_smem);                       // [16][chs] f32
-    f16x8 *qb = reinterpret_cast<f16x8 *>(stage + CK * chs);                   // [4][chs] x 16 B
-
-    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wco = wave % WCO, wpo = wave / WCO;
-
-    int bid = blockIdx.x, co_t;
-    if (P.xcd_remap) {
-        const int xcd = bid & 7, q = bid >> 3;
-        co_t = q % P.n_co_tiles;
-        bid = (q / P.n_co_tiles) * 8 + xcd;
-        if (bid >= P.n_spatial) return;
-    } else {
-        co_t = bid % P.n_co_tiles;
-        bid /= P.n_co_tiles;
-    }
-    const int iw = bid % P.nW;            bid /= P.nW;
-    const int ih = bid % P.nH;            bid /= P.nH;
-    const int it = bid % P.nT;            bid /= P.nT;
-    const int b = bid;
-    const int co0 = co_t * CO_TILE + wco * CO_FR * 32;     // this wave's first channel
-    const int t0 = it * P.TT, h0 = ih * P.TH, w0 = iw * P.TW;
-    const int tin0 = t0 - PAD, hin0 = h0 * S - PAD, win0 = w0 * S - PAD;
-
-    int hoff[PO_FR], poff[PO_FR];
-#pragma unroll
-    for (int f = 0; f < PO_FR; ++f) {
-        const int m = (wpo * PO_FR + f) * 32 + l32;
-        hoff[f] = 0;
-        poff[f] = -1;
-        if (m < P.n_pos) {
-            const int tt = m / (P.TH * P.TW);
-            const int rem = m - tt * (P.TH * P.TW);
-            const int th = rem / P.TW;
-            const int tw = rem - th * P.TW;
-            hoff[f] = (tt * P.HH + th * S) * P.HWd + tw * S;
-            const int t = t0 + tt, h = h0 + th, w = w0 + tw;
-            if (t < P.T && h < P.Hout && w < P.Wout)
-                poff[f] = (t * P.Cout) * (P.Hout * P.Wout) + h * P.Wout + w;
-        }
-    }
-
-    // this lane's A-fragment source: channel co (clamped; rows >= Cout are never stored)
-    const int CG = P.Cin / CK;
-    const long long wplane = (long long)K3 * CG * P.Cout * 16;               // halves per plane
-    int wlane[CO_FR];
-#pragma unroll
-    for (int q = 0; q < CO_FR; ++q) {
-        int co = co0 + q * 32 + l32;
-        co = co < P.Cout ? co : P.Cout - 1;
-        wlane[q] = co * 16 + 8 * half;
-    }
-
-    f32x16 acc[CO_FR][PO_FR];
-#pragma unroll
-    for (int q = 0; q < CO_FR; ++q)
-#pragma unroll
-        for (int f = 0; f < PO_FR; ++f)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[q][f][r] = 0.0f;
-
-    // pre-scales: weights carry theirs behind the fp16 planes; activations from the tracked range
-    const float w_scale = reinterpret_cast<const float *>(P.wq + 2 * wplane)[1];
-    float x_scale = kActScale;
-    if (P.x0_absmax) {
-        float am = *P.x0_absmax;
-        if (P.x1_absmax) am = fmaxf(am, *P.x1_absmax);
-        x_scale = pow2_prescale(am);
-    }
-    const float inv_scale = 1.0f / (x_scale * w_scale);     // a power of two: exact
-
-    DmaState<EPT, 1> D;
-    D.cur_src = -1;
-    D.src_cstride4 = 0;
-    D.src_cbase = 0;
-    D.woff[0] = kOOB;
-    D.rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x0), 0, 0, 0x00020000);
-    D.rs_in = D.rs_w;
-#define ISSUE16(ci0_, part_, nparts_) issue_chunk<KS, CK, EPT, 1, 0>(P, D, (ci0_), stage, chs, b, wave, tin0, hin0, win0, (part_), (nparts_))
-    ISSUE16(0, 0, 1);
-
-    for (int cg = 0; cg < CG; ++cg) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                       // chunk cg staged; every wave done with the fp16 pieces
-        // A fragments of taps 0 and 1 (independent of LDS: their latency hides behind the conversion)
-        f16x8 ah[3][CO_FR], al[3][CO_FR];
-        const _Float16 *wc = P.wq + (long long)cg * P.Cout * 16;
-#define V2CE_LOAD_W(slot_, tap_)                                                               \
-        {                                                                                      \
-            const _Float16 *wt_ = wc + (long long)(tap_) * CG * P.Cout * 16;                   \
-            _Pragma("unroll") for (int q = 0; q < CO_FR; ++q) {                                \
-                ah[slot_][q] = *reinterpret_cast<const f16x8 *>(wt_ + wlane[q]);               \
-                al[slot_][q] = *reinterpret_cast<const f16x8 *>(wt_ + wplane + wlane[q]);      \
-            }                                                                                  \
-        }
-        V2CE_LOAD_W(0, 0)
-        if constexpr (K3 > 1) V2CE_LOAD_W(1, 1)
-        // f32 channel-major staging -> position-major fp16 hi/lo pieces
-#pragma unroll
-        for (int hg = 0; hg < 2; ++hg) {
-            for (int r = tid; r < P.plane; r += 256) {
-                f16x8 vh, vl;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const float v = stage[(8 * hg + c) * chs + r] * x_scale;
-                    const _Float16 hh = (_Float16)v;
-                    vh[c] = hh;
-                    vl[c] = (_Float16)(v - (float)hh);
-                }
-                qb[hg * chs + r] = vh;
-                qb[(2 + hg) * chs + r] = vl;
-            }
-        }
-        __syncthreads();                       // pieces ready; staging buffer free again
-        const bool more = cg + 1 < CG;
-        step_loop<0, K3>([&](auto tc) {
-            constexpr int tap = decltype(tc)::value;
-            constexpr int dt = tap / (KS * KS), dh = (tap / KS) % KS, dw = tap % KS;
-            if (more) ISSUE16((cg + 1) * CK, tap, K3);              // DMA of the next chunk, dealt over the taps
-            if constexpr (tap + 2 < K3) V2CE_LOAD_W((tap + 2) % 3, tap + 2)
-            const int toff = (dt * P.HH + dh) * P.HWd + dw;
-            f16x8 bh[PO_FR], bl[PO_FR];
-#pragma unroll
-            for (int f = 0; f < PO_FR; ++f) {
-                bh[f] = qb[half * chs + hoff[f] + toff];
-                bl[f] = qb[(2 + half) * chs + hoff[f] + toff];
-            }
-#pragma unroll
-            for (int q = 0; q < CO_FR; ++q)
-#pragma unroll
-                for (int f = 0; f < PO_FR; ++f) {
-                    acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tap % 3][q], bh[f], acc[q][f], 0, 0, 0);
-                    acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tap % 3][q], bl[f], acc[q][f], 0, 0, 0);
-                    acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tap % 3][q], bh[f], acc[q][f], 0, 0, 0);
-                }
-        });
-#undef V2CE_LOAD_W
-    }
-#undef ISSUE16
-
-    conv_epilogue<CO_FR, PO_FR>(P, acc, poff, co0, half, b, inv_scale);
-#endif  // __HIP_DEVICE_COMPILE__
-}
-
-// ---------------------------------------------------------------------------------------------
-// Split-half, wave-specialised (stride 1): the same arithmetic as conv3d_f16x2_kernel, but the
-// workgroup is 8 waves = 2 per SIMD with fixed roles.
+// Split-half, wave-specialised conv.  Every operand is the sum of two fp16 numbers (x * s_x = xh + xl,
+// w * s_w = wh + wl, power-of-two pre-scales s_x, s_w) and each 16-channel k-step is three
+// v_mfma_f32_32x32x16_f16 (wh.xh + wh.xl + wl.xh; fp16 products are exact in the f32 accumulator):
+// 22-bit operands at 5.3x the f32 MFMA rate per k-step; measured against f64 the result is as
+// accurate as f32 arithmetic (profiles/r01_d_precision_report.json).  Same tensors, tiling, halo
+// gather (zero padding, virtual upsample + concat) and fused epilogue as conv3d_kernel.
+// The workgroup is 8 waves = 2 per SIMD with fixed roles.
 //   waves 4-7 (producers): gather chunk c+1 of the f32 halo into registers (buffer loads; the
 //       hardware range check supplies the zero padding), convert it to the fp16 hi/lo pieces of
 //       buffer (c+1)&1, issue the loads of chunk c+2 (they land during the barrier wait).
@@ -664,7 +507,6 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
 #if defined(__HIP_DEVICE_COMPILE__)
     // KS = 1: the "halo box" is the output box itself (positions gathered with stride S), one tap
     constexpr int K3 = KS * KS * KS, CK = 16, EPT = 5, PAD = KS / 2, GS = KS == 1 ? S : 1;
-    constexpr int WPO = 4 / WCO;
     constexpr int CO_TILE = WCO * CO_FR * 32;
     const int chs = (P.plane + 63) & ~63;
     f16x8 *pieces = reinterpret_cast<f16x8 *>(conv_smem);                      // [2][4][chs] x 16 B
@@ -1059,39 +901,6 @@ int launch(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream) {
     return V2CE_OK;
 }
 
-template <int KS, int S, int WCO, int CO_FR, int PO_FR, int EPT>
-int launch_f16x2(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream) {
-    constexpr int CO_TILE = WCO * CO_FR * 32, POS_TILE = (4 / WCO) * PO_FR * 32, MAX_PLANE = 256 * EPT;
-    if (g_name_out) {
-        snprintf(g_name_out, g_name_cap, "conv3d_f16x2_kernel<%d,%d,%d,%d,%d,%d>", KS, S, WCO, CO_FR, PO_FR, EPT);
-        return V2CE_OK;
-    }
-    const Tile t = choose_tile(d.T, d.Hout, d.Wout, KS, S, POS_TILE, MAX_PLANE);
-    P.TT = t.tt; P.TH = t.th; P.TW = t.tw;
-    P.n_pos = t.tt * t.th * t.tw;
-    P.HT = t.tt + KS - 1; P.HH = (t.th - 1) * S + KS; P.HWd = (t.tw - 1) * S + KS;
-    P.plane = P.HT * P.HH * P.HWd;
-    V2CE_REQUIRE(P.n_pos <= POS_TILE && P.plane <= MAX_PLANE, V2CE_ERR_UNSUPPORTED,
-                 "v2ce_conv3d_fwd(f16x2): tile does not fit");
-    V2CE_REQUIRE((long long)d.T * d.Cout * d.Hout * d.Wout < (1ll << 29), V2CE_ERR_UNSUPPORTED,
-                 "v2ce_conv3d_fwd(f16x2): an output sequence exceeds the 2 GiB buffer-descriptor range");
-    P.nT = (d.T + t.tt - 1) / t.tt; P.nH = (d.Hout + t.th - 1) / t.th; P.nW = (d.Wout + t.tw - 1) / t.tw;
-    P.n_co_tiles = (d.Cout + CO_TILE - 1) / CO_TILE;
-    P.n_spatial = d.B * P.nT * P.nH * P.nW;
-    P.xcd_remap = 1;
-    P.per_xcd = (P.n_spatial + 7) / 8;
-    const long long blocks = (long long)8 * P.per_xcd * P.n_co_tiles;
-    const int chs = (P.plane + 63) & ~63;
-    const size_t lds = (size_t)chs * (16 * 4 + 4 * 16);
-    V2CE_REQUIRE(lds <= 160 * 1024, V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd(f16x2): %zu B of LDS", lds);
-    auto kern = conv3d_f16x2_kernel<KS, S, WCO, CO_FR, PO_FR, EPT>;
-    V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, P);
-    V2CE_HIP_CHECK(hipGetLastError());
-    return V2CE_OK;
-}
-
 // tail[0] = max |w / sigma| (tail[0] zeroed by the caller)
 __global__ __launch_bounds__(256) void weights_absmax_kernel(const float *__restrict__ w, long long n,
                                                              const float *sigma, float *tail) {
@@ -1145,9 +954,9 @@ int launch_f16x2_ws(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream)
     // persistent: one workgroup per CU walks the virtual blocks (a multiple of 8 keeps tiles on their XCD)
     static const int n_cu = [] {
         int dev = 0, n = 256;
-        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        const char *e = getenv("V2CE_WS_GRID");
-        if (e) n = atoi(e);
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            n = 256;
         return n < 8 ? 8 : (n / 8) * 8;
     }();
     P.total_blocks = (int)blocks;
@@ -1270,10 +1079,9 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
         P.wq = reinterpret_cast<const _Float16 *>(w_packed);
         V2CE_REQUIRE(x0_absmax || !x1_absmax, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd(f16x2): x1_absmax without x0_absmax");
         V2CE_REQUIRE(d.C1 == 0 || !x0_absmax || x1_absmax, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd(f16x2): x0_absmax without x1_absmax");
-        static const int ws = [] { const char *e = getenv("V2CE_WS"); return e ? atoi(e) : 1; }();
         if (d.ksize == 1) {
             // 1x1x1 (shortcuts): one tap per chunk, so the producers set the pace; still ~2x the exact-f32
-            // kernel, which is MFMA-bound on these (100 TF)
+            // kernel on >= 128 output channels and on the strided ones
             if (s == 1) {
                 if (small_co) return launch_f16x2_ws<1, 1, 1, 1, 4, 3>(P, d, st);
                 if (d.Cout >= 128) return launch_f16x2_ws<1, 1, 2, 2, 4, 3>(P, d, st);
@@ -1283,31 +1091,18 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
             if (d.Cout >= 128) return launch_f16x2_ws<1, 2, 2, 2, 4, 3>(P, d, st);
             return launch_f16x2_ws<1, 2, 1, 2, 4, 3>(P, d, st);
         }
-        if (s == 1 && ws) {
-            // wave-specialised kernel, measured (tools/conv_bench.py, TF-equivalent): 128 x 256 boxes
-            // 370-450; 64 x 512: 285-390 (64 x 256: 248-358); 32 x 512: 186-299 (32 x 256: 114-205)
-            static const int na = [] { const char *e = getenv("V2CE_NA"); return e ? atoi(e) : 3; }();
-            if (small_co) return na == 9 ? launch_f16x2_ws<3, 1, 1, 1, 4, 9>(P, d, st) : launch_f16x2_ws<3, 1, 1, 1, 4, 3>(P, d, st);
+        if (s == 1) {
+            // measured (tools/conv_bench.py, TF-equivalent): 128 channels x 256 positions per workgroup
+            // 390-450; 64 x 512: 370-430 (64 x 256: 248-358); 32 x 512: 300-350 (32 x 256: 114-205)
+            if (small_co) return launch_f16x2_ws<3, 1, 1, 1, 4, 3>(P, d, st);
             if (d.Cout >= 128) return launch_f16x2_ws<3, 1, 2, 2, 4, 3>(P, d, st);
             return launch_f16x2_ws<3, 1, 1, 2, 4, 3>(P, d, st);
         }
-        if (s == 2 && ws) {
-            // stride 2: the halo box is ~4x the output box, 128-position boxes; measured 223-293
-            // TF-equivalent with one 32-channel fragment row per wave (Cout >= 128), 121 at Cout = 64
-            static const int na = [] { const char *e = getenv("V2CE_NA"); return e ? atoi(e) : 3; }();
-            if (d.Cout >= 128) return na == 9 ? launch_f16x2_ws<3, 2, 4, 1, 4, 9>(P, d, st) : launch_f16x2_ws<3, 2, 4, 1, 4, 3>(P, d, st);
-            if (!small_co) return na == 9 ? launch_f16x2_ws<3, 2, 2, 1, 2, 9>(P, d, st) : launch_f16x2_ws<3, 2, 2, 1, 2, 3>(P, d, st);
-        }
-        if (s == 1) {
-            if (small_co) return launch_f16x2<3, 1, 1, 1, 2, 4>(P, d, st);
-            // measured (tools/conv_bench.py): 128 channels x 256 positions per workgroup (24 MFMAs per
-            // A/B fragment set) 320 TF-equivalent; 64-channel layers: 64 x 128 boxes, 207
-            if (d.Cout >= 128) return launch_f16x2<3, 1, 2, 2, 4, 4>(P, d, st);
-            return launch_f16x2<3, 1, 2, 1, 2, 4>(P, d, st);
-        }
-        if (small_co) return launch_f16x2<3, 2, 1, 1, 1, 4>(P, d, st);
-        if (d.Cout >= 128) return launch_f16x2<3, 2, 2, 2, 2, 4>(P, d, st);   // 180-198 TF-equivalent
-        return launch_f16x2<3, 2, 2, 1, 2, 4>(P, d, st);
+        // stride 2: the halo box is ~4x the output box, so 128-position boxes; one 32-channel fragment
+        // row per wave measured best (Cout >= 128: 300-320; Cout = 64: 245)
+        if (d.Cout >= 128) return launch_f16x2_ws<3, 2, 4, 1, 4, 3>(P, d, st);
+        if (!small_co) return launch_f16x2_ws<3, 2, 2, 1, 2, 3>(P, d, st);
+        return launch_f16x2_ws<3, 2, 1, 1, 1, 3>(P, d, st);
     }
     V2CE_REQUIRE(d.precision == V2CE_PRECISION_F32, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd: precision %d", d.precision);
     // CK per (ksize, stride): sized so 2 workgroups share a CU's 160 KiB of LDS
