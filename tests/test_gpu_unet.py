@@ -265,6 +265,41 @@ def test_conv1x1_split_half_vs_f64(case):
     assert_close(got, want, "split 1x1 " + str(case))
 
 
+def _sweep_cases():
+    rng = np.random.RandomState(2024)
+    cases = []
+    for _ in range(14):
+        ks = int(rng.choice([1, 3]))
+        s = int(rng.choice([1, 2]))
+        ups = bool(rng.rand() < 0.35) and s == 1
+        c0 = int(rng.choice([16, 32, 48, 64, 96, 128]))
+        c1 = int(rng.choice([16, 32, 64])) if ups else 0
+        cout = int(rng.choice([32, 64, 96, 128, 160]))
+        cases.append((int(rng.randint(1, 3)), int(rng.randint(1, 6)), c0, c1, cout, int(rng.randint(5, 40)),
+                      int(rng.randint(5, 50)), ks, s, ups, bool(rng.rand() < 0.5) and ks == 3 and s == 1))
+    return cases
+
+
+@pytest.mark.parametrize("case", _sweep_cases())
+def test_split_half_shape_sweep(case):
+    """Randomised shapes for the persistent wave-specialised kernel: odd planes, T < tile, several
+    (also non-power-of-two) channel tiles, partial last channel tile, strided / virtual gathers."""
+    B, T, C0, C1, Cout, H, W, ks, s, ups, use_res = case
+    g = torch.Generator().manual_seed(abs(hash(case)) % 100000)
+    h0, w0 = ((H + 1) // 2, (W + 1) // 2) if ups else (H, W)
+    x0 = torch.randn(B, C0, T, h0, w0, generator=g)
+    x1 = torch.randn(B, C1, T, H, W, generator=g) if C1 else None
+    w = torch.randn(Cout, C0 + C1, ks, ks, ks, generator=g) * (2.0 / ((C0 + C1) * ks ** 3)) ** 0.5
+    scale = 0.5 + torch.rand(Cout, generator=g)
+    shift = 0.2 * torch.randn(Cout, generator=g)
+    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    res = torch.randn(B, Cout, T, Ho, Wo, generator=g) if use_res else None
+    up_to = (H, W) if ups else None
+    got = hip_conv_split(x0, w, scale, shift, s, 1, x1=x1, up_to=up_to, residual=res, tracked=True, ksize=ks)
+    want = ref_conv(x0, w, scale, shift, ks, s, 1, x1=x1, up_to=up_to, residual=res)
+    assert_close(got, want, "sweep " + str(case))
+
+
 @pytest.mark.parametrize("mag", [1e-6, 1.0, 3e4, 1e9])
 def test_conv3d_split_half_dynamic_range(mag):
     """Activations and weights far outside the fp16 range: the tracked power-of-two pre-scales keep

@@ -806,7 +806,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
                     poff[f] = (t * P.Cout) * (P.Hout * P.Wout) + h * P.Wout + w;
             }
         }
-        conv_epilogue<CO_FR, PO_FR>(P, acc, poff, co0, half, T.b, inv_scale);
+        conv_epilogue<CO_FR, PO_FR, true>(P, acc, poff, co0, half, T.b, inv_scale);   // Cout need not fill the last channel tile
         if (gc == CG) STAMP(0, 4);
         vb += (int)gridDim.x;
         more = next_tile(vb, T);
