@@ -70,13 +70,64 @@ def cpu_baseline(pairs=4):
                       f"{int(seg.sum())} events"}
 
 
+def bench_voxelize(args, device, rank, world):
+    """events of 24 stress frame-pairs (one LDATI chunk) -> one [20,260,346] volume per
+    frame-pair.  A step = the 24 voxelise calls; HBM-bound: 13 B read per event + the zeroed volume."""
+    from v2ce_toolbox_amd.voxelize import gen_discretized_event_volume
+    pairs = 24
+    vox = torch.from_numpy(synth.synthetic_voxels(pairs, H, W, seed=7 + rank, regime="stress")).to(device)
+    ev = ldati_device(vox, fps=30, seed=0x5EED)
+    ends = np.cumsum(ev.frame_counts)
+    frames = [(ev.ts[e - c:e].contiguous(), ev.x[e - c:e].contiguous(), ev.y[e - c:e].contiguous(),
+               ev.p[e - c:e].contiguous()) for e, c in zip(ends, ev.frame_counts)]
+    n_events = int(ends[-1])
+
+    def step():
+        for f in frames:
+            gen_discretized_event_volume(f, (20, H, W))
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    gpu_s = e0.elapsed_time(e1) * 1e-3
+    nbytes = 13.0 * n_events + pairs * 20 * H * W * 4.0          # events read once + volumes written once
+    achieved = nbytes * args.steps / gpu_s / 1e9
+    line = {"metric": "frame-pairs/sec voxelised (events -> [20,260,346] volume)", "value": pairs * args.steps / dt,
+            "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "voxeliser only: LDATI events of 24 stress frame-pairs (6*U[0,1) voxels), one call per frame-pair",
+                       "events_per_step": n_events},
+            "mevents_per_s": n_events * args.steps / dt / 1e6,
+            "roofline": {"bound": "hbm", "kernel": "v2ce_voxelize_events (time_range + voxelize kernels, memset)",
+                         "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
+                         "traffic": None, "bytes_per_step": nbytes}}
+    if not args.no_cpu_baseline:
+        from oracle.voxelize import gen_discretized_event_volume as oracle_vox
+        rec = ev.to_recarrays()[0]
+        t0 = time.perf_counter()
+        oracle_vox(rec, (20, H, W))
+        t1 = time.perf_counter() - t0
+        line["cpu_baseline"] = {"value": 1.0 / t1, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+                                "sample": f"1 frame-pair, {len(rec)} events, numpy restatement"}
+    if rank == 0:
+        print(json.dumps(line))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4, help="16-pair sequences per step per GPU")
-    ap.add_argument("--workload", default="e2e", choices=["e2e", "ldati_stress", "ldati_sparse"])
+    ap.add_argument("--workload", default="e2e", choices=["e2e", "ldati_stress", "ldati_sparse", "voxelize"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="f16x2", choices=["f32", "f16x2"],
                     help="stage-1 3x3x3 conv arithmetic: f16x2 = f32 operands split into two fp16 halves, 3 fp16 "
@@ -117,6 +168,8 @@ def main():
                                                             regime=regime)).to(device)
     ldati_prof = []
     gather_bytes = [0]
+    if args.workload == "voxelize":
+        return bench_voxelize(args, device, rank, world)
 
     def step(profile):
         if model is not None:

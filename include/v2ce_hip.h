@@ -159,6 +159,17 @@ int v2ce_conv3d_variant(const v2ce_conv3d_desc *desc, int mapped, char *name, si
 int v2ce_pack_weights(const float *w, int Cout, int Cin, int k3, const float *sigma,
                       float *w_packed, v2ce_stream_t stream);
 
+/* Voxeliser (the inverse of LDATI): gen_discretized_event_volume of
+ * train/scripts/utils/events_utils.py:118-175.  SoA events on the device -> volume [2*bins][H][W]
+ * f32 (zeroed here): time rescaled to [0, bins-1] over the set's own [t_min, t_max] (computed here
+ * into t_range [2] int64, device), each event split between its floor and ceil bin, polarity 1 in
+ * planes [0,bins), polarity 0 in [bins,2*bins).  Same f32 arithmetic as the reference per event;
+ * accumulation by float atomics (order differs).  n > 0 and t_max > t_min required (the reference
+ * raises / produces NaN otherwise); events with x/y outside the volume are skipped (the reference
+ * asserts). */
+int v2ce_voxelize_events(const int64_t *ts, const int16_t *x, const int16_t *y, const int8_t *p, int64_t n,
+                         int bins, int H, int W, float *volume, int64_t *t_range, v2ce_stream_t stream);
+
 /* One spectral-norm power iteration (spectral_norm.py:19-31), in place on u [rows], v [cols]:
  *   v = W^T u / (|W^T u| + 1e-12); u = W v / (|W v| + 1e-12); sigma = u . (W v)
  * w_bar [rows][cols] f32; sigma [1] f32 out; workspace >= v2ce_sn_workspace_bytes(rows, cols). */

@@ -14,6 +14,10 @@ Golden sets:
   G5 ldati_kat.json   hand known-answer re-derived from the reference here
   G7 glue_g7.npz      v2ce.py video_to_voxels (center + pano) through a stub-imported v2ce.py,
                       sequence plans and per-frame offsets
+  G8 voxelize_g8.npz  the reference voxeliser gen_discretized_event_volume (its three function
+                      definitions are compiled here straight from the reference file: the module
+                      itself imports h5py / numba / plotly, absent from this image) on reference
+                      LDATI events
 
 Note on G4 / sqrt: this container's torch CPU build evaluates ``torch.sqrt`` through MKL VML, which
 is not correctly rounded (0.64 % of f32 inputs are 1 ulp off IEEE sqrt; measured here).  That moves
@@ -327,9 +331,45 @@ def gen_glue():
     print("G7: center", outs["center"].shape, "pano", outs["pano"].shape)
 
 
+# --------------------------------------------------------------------------------------------- G8
+def reference_voxelizer():
+    """gen_discretized_event_volume + its two helpers, compiled from the reference source file at
+    generation time (nothing of it is stored in this repo)."""
+    import ast
+    path = os.path.join("/root/reference", "train", "scripts", "utils", "events_utils.py")
+    tree = ast.parse(open(path).read())
+    want = {"calc_floor_ceil_delta", "create_update", "gen_discretized_event_volume"}
+    mod = ast.Module(body=[n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in want],
+                     type_ignores=[])
+    assert {n.name for n in mod.body} == want
+    ns = {"torch": torch, "np": np}
+    exec(compile(mod, path, "exec"), ns)
+    return ns["gen_discretized_event_volume"]
+
+
+def gen_voxelize():
+    from oracle.voxelize import gen_discretized_event_volume as oracle_vox
+    ref = reference_voxelizer()
+    out = {}
+    for name in ("stress", "sparse"):
+        z = np.load(os.path.join(GOLD, f"ldati_g3_{name}.npz"), allow_pickle=True)
+        H, W = z["vox"].shape[-2:]
+        lens = z["lens"]
+        ev = z["events"].view(O.EVENT_DTYPE)[:int(lens[0])]  # the events of frame-pair 0 (the reference's unit)
+        vol = ref(ev.copy(), (20, H, W)).numpy()
+        mine = oracle_vox(ev, (20, H, W))
+        assert np.array_equal(vol, mine), f"oracle voxeliser differs from the reference on {name}"
+        out[f"events_{name}"] = ev
+        out[f"volume_{name}"] = vol
+        print(f"G8 {name}: {len(ev)} events, sum {vol.sum():.3f}")
+    np.savez_compressed(os.path.join(GOLD, "voxelize_g8.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["unet", "ldati", "large", "kat", "glue"]
+    which = sys.argv[1:] or ["unet", "ldati", "large", "kat", "glue", "voxelize"]
+    if "voxelize" in which:
+        gen_voxelize()
     if "unet" in which:
         gen_unet()
     if "ldati" in which:
