@@ -1,4 +1,8 @@
-// conv3d.hip -- fused 3-D convolution for the V2ce3d UNet on gfx950 (fp32 MFMA, LDS halo tiles).
+// conv3d.hip -- fused 3-D convolution for the V2ce3d UNet on gfx950.
+//
+// Two kernels behind v2ce_conv3d_fwd: conv3d_kernel (exact f32 MFMA; described first) and
+// conv3d_f16x2_ws_kernel (operands split into fp16 halves, wave-specialised, persistent; its own
+// header further down), selected by desc.precision.
 //
 // Replaces nn.Conv3d + BatchNorm3d(eval) + ReLU/LeakyReLU + residual add + nearest-upsample +
 // channel concat as used by /root/reference/scripts/submodules.py:96,115-124,226-264 and

@@ -7,8 +7,11 @@ exactly (218 keys; ``scripts/v2ce_3d.py:13-24``, ``scripts/unet_2layer.py:203-31
 ``model(x)`` work as in ``v2ce.py:30-43,81-82``.  The forward pass contains no torch compute ops:
 every convolution (with its folded BatchNorm, activation, residual add, nearest-upsample + concat
 input) is one ``v2ce_conv3d_fwd`` launch, every spectral-norm layer one ``v2ce_sn_power_iter`` +
-``v2ce_pack_weights`` (include/v2ce_hip.h).  Inference only (the reference runs it under
-``torch.no_grad()`` in eval mode, ``v2ce.py:41,66``).
+``v2ce_pack_weights[_f16x2]`` (include/v2ce_hip.h), the latter on a side stream overlapping the
+encoder.  ``precision`` selects the arithmetic of the residual-block convs: "f16x2" (default) =
+f32 operands split into two fp16 halves on the fp16 MFMA with device-side range tracking
+(f32-equivalent accuracy), "f32" = exact f32 MFMA.  Inference only (the
+reference runs it under ``torch.no_grad()`` in eval mode, ``v2ce.py:41,66``).
 """
 from __future__ import annotations
 
