@@ -346,6 +346,20 @@ def test_v2ce3d_split_half_matches_reference_three_calls(gold_dir):
         assert_close(got, want, "split-half golden")
 
 
+@pytest.mark.parametrize("precision", ["f16x2", "f32"])
+def test_forward_is_bitwise_reproducible(precision):
+    """Same weights, same spectral-norm state, same input -> identical bits (the range-tracking
+    atomics only form maxima, the convs have a fixed summation order)."""
+    from v2ce_toolbox_amd.v2ce_3d import V2ce3d
+    x = torch.randn(2, 5, 2, 40, 56, generator=torch.Generator().manual_seed(1)).cuda()
+    outs = []
+    for _ in range(3):
+        m = V2ce3d(precision=precision)
+        m.load_state_dict(synth.make_state_dict(0), strict=True)
+        outs.append(m.eval().to("cuda")(x).clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 def test_precision_report_vs_f64_truth():
     """Error of every arithmetic path against an f64 evaluation of the same network (346x260, L=2):
     the CPU f32 restatement (what the reference computes), the exact-f32 HIP path and the split-half
