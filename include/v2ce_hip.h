@@ -149,6 +149,22 @@ int v2ce_conv3d_fwd(const v2ce_conv3d_desc *desc, const float *x0, const float *
                     const float *x0_absmax, const float *x1_absmax, float *y_absmax,
                     v2ce_stream_t stream);
 
+/* v2ce_conv3d_fwd with a fused 1x1x1 head (the UNet's last two layers in one launch: the 32-channel
+ * 3x3x3 conv of the last decoder block, scripts/submodules.py:249-264, and `pred`,
+ * scripts/unet_2layer.py:374 / submodules.py:85-124 with relu): pred_y[b][t][o][h][w] =
+ * relu(sum_c pred_w[o][c] * y[b][t][c][h][w] + pred_b[o]), o < pred_cout <= 32, evaluated on the conv's
+ * accumulators before they leave the registers.  Requires precision F16X2, ksize 3, stride 1, Cout 32,
+ * act RELU.  pred_w = table of v2ce_pack_pred_weights_f16x2 (from the [pred_cout][32] f32 weights),
+ * pred_b = 32 floats (zero padded).  y may be NULL when only the head's output is wanted. */
+size_t v2ce_pack_pred_weights_f16x2_bytes(void);
+int v2ce_pack_pred_weights_f16x2(const float *w, int cout, int cin, void *table, v2ce_stream_t stream);
+int v2ce_conv3d_fwd_pred(const v2ce_conv3d_desc *desc, const float *x0, const float *x1,
+                         const int32_t *hmap, const int32_t *wmap, const float *w_packed,
+                         const float *scale, const float *shift, const float *residual, float *y,
+                         const float *x0_absmax, const float *x1_absmax, float *y_absmax,
+                         const void *pred_w, const float *pred_b, int pred_cout, float *pred_y,
+                         v2ce_stream_t stream);
+
 /* Name of the kernel instantiation v2ce_conv3d_fwd would launch for desc ("conv3d_kernel<KS,S,
  * CO_FR,PO_FR,CK,EPT>", as it appears demangled in rocprofv3 traces); mapped != 0 means hmap/wmap
  * would be non-NULL.  Launches nothing.  Used by bench.py to attribute event timings. */

@@ -346,6 +346,23 @@ def test_v2ce3d_split_half_matches_reference_three_calls(gold_dir):
         assert_close(got, want, "split-half golden")
 
 
+def test_fused_head_matches_unfused():
+    """Default path: `pred` fused into the last decoder conv (v2ce_conv3d_fwd_pred).  Asking for the
+    intermediates runs the layers separately; both must agree to f32 rounding."""
+    from v2ce_toolbox_amd.v2ce_3d import V2ce3d
+    x = torch.randn(2, 5, 2, 37, 50, generator=torch.Generator().manual_seed(2)).cuda()
+    outs = []
+    for inter in (False, True):
+        m = V2ce3d()
+        m.load_state_dict(synth.make_state_dict(0), strict=True)
+        m = m.eval().to("cuda")
+        assert m.precision == "f16x2"
+        o = m(x, return_intermediates=inter)
+        outs.append((o[0] if inter else o).cpu().numpy())
+    assert outs[0].shape == (2, 5, 20, 37, 50)
+    assert_close(outs[0], outs[1], "fused vs separate head", 2e-6)
+
+
 @pytest.mark.parametrize("precision", ["f16x2", "f32"])
 def test_forward_is_bitwise_reproducible(precision):
     """Same weights, same spectral-norm state, same input -> identical bits (the range-tracking

@@ -69,6 +69,11 @@ struct ConvParams {
     // split-half kernel derives its power-of-two activation pre-scale from them
     const float *x0_absmax, *x1_absmax;
     float *y_absmax;
+    // fused 1x1x1 head behind a 32-channel conv (v2ce_conv3d_fwd_pred): pred_y[o] = relu(pred_w[o][:] . y + pred_b[o])
+    const _Float16 *pred_w;       // table of v2ce_pack_pred_weights_f16x2 (A fragments hi/lo + pre-scale)
+    const float *pred_b;          // [32], zero padded
+    float *pred_y;                // [B][T][pred_cout][Hout][Wout]
+    int pred_cout;
 #ifdef V2CE_STAMP
     unsigned long long *stamps;   // diagnostic build only: [block][role][8] s_memtime stamps
 #endif
@@ -130,17 +135,18 @@ __device__ __forceinline__ float apply_act(float t, float slope) { return fmaxf(
 // scalar branches): loads and stores are buffer operations whose per-lane offset is pushed out of
 // range for masked lanes (the hardware range check returns 0 / drops the store), the channel offset
 // rides in the scalar offset.  Requires Cout % 32 == 0, sequences < 2 GiB, y not aliasing the inputs.
-template <int CO_FR, int PO_FR, bool CHECK_CO = false>
-__device__ __forceinline__ void conv_epilogue(const ConvParams &P, const f32x16 (&acc)[CO_FR][PO_FR],
+template <int CO_FR, int PO_FR, bool CHECK_CO = false, bool KEEP = false>
+__device__ __forceinline__ void conv_epilogue(const ConvParams &P, f32x16 (&acc)[CO_FR][PO_FR],
                                               const int (&poff)[PO_FR], int co0, int half, int b,
                                               float inv_scale) {
     const float *__restrict__ scale = P.scale;
     const float *__restrict__ shift = P.shift;
     const long long seq = (long long)P.T * P.Cout * (P.Hout * P.Wout);
     const int cstride4 = P.Hout * P.Wout * 4;
-    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(P.y + b * seq, 0, (int)(seq * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(P.y ? P.y + b * seq : const_cast<float *>(P.scale), 0,
+                                                                          P.y ? (int)(seq * 4) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(P.res ? P.res + b * seq : P.y), 0, P.res ? (int)(seq * 4) : 0, 0x00020000);
+        const_cast<float *>(P.res ? P.res + b * seq : P.scale), 0, P.res ? (int)(seq * 4) : 0, 0x00020000);
     const int cbase = co0 + 4 * half;                      // this lane's channel for (q, r) = (0, 0)
     const float slope = act_slope(P.act);
     unsigned vo[PO_FR], vmask[PO_FR];
@@ -182,15 +188,100 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &P, const f32x16 
                     v += rv[k][f];
                     v = apply_act(v, slope);
                     const bool cok = !CHECK_CO || cbase + q * 32 + k + 8 * r4 < P.Cout;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, cok ? vo[f] : kOOB,
-                                                          (q * 32 + k + 8 * r4) * cstride4, 0);
+                    if (!KEEP || P.y)                           // uniform: a fused head may not want y itself
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, cok ? vo[f] : kOOB,
+                                                              (q * 32 + k + 8 * r4) * cstride4, 0);
                     const unsigned av = __builtin_bit_cast(unsigned, v) & (cok ? vmask[f] : 0u);
+                    if (KEEP) acc[q][f][r] = __builtin_bit_cast(float, av == 0u ? 0u : __builtin_bit_cast(unsigned, v));
                     ymax = av > ymax ? av : ymax;
                 }
             }
         }
     }
     if (P.y_absmax) absmax_commit(__builtin_bit_cast(float, ymax), P.y_absmax);
+}
+
+// Fused 1x1x1 head (the UNet's `pred` layer, unet_2layer.py:374) behind a 32-channel conv: the
+// wave's 32 x (PO_FR*32) block of post-activation outputs v is still in its accumulator registers
+// (conv_epilogue<KEEP>), so out[o][pos] = relu(sum_c Wp[o][c] v[c][pos] + b[o]) is two more k-steps
+// of the same split-half MFMA with the roles kept: lane (pos, half) already holds exactly the 8
+// channels c(j) = (j & 3) + 8 (j >> 2) + 16 k + 4 half of k-step k that a B fragment needs, so no
+// value moves between lanes; the host packs Wp's columns in that order (v2ce_pack_pred_weights_f16x2).
+// v is pre-scaled by a power of two from the wave's own maximum.
+template <int PO_FR>
+__device__ __forceinline__ void pred_epilogue(const ConvParams &P, const f32x16 (&v)[1][PO_FR], int pos0,
+                                              int lane, int b, int t0, int h0, int w0) {
+    const int l32 = lane & 31, half = lane >> 5;
+    float m = 0.0f;
+#pragma unroll
+    for (int f = 0; f < PO_FR; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(v[0][f][r]));
+#pragma unroll
+    for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    const float v_scale = pow2_prescale(m);
+    const float w_scale = reinterpret_cast<const float *>(P.pred_w + 2048)[0];
+    f16x8 ahp[2], alp[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        ahp[k] = *reinterpret_cast<const f16x8 *>(P.pred_w + ((k * 2 + 0) * 32 + l32) * 16 + 8 * half);
+        alp[k] = *reinterpret_cast<const f16x8 *>(P.pred_w + ((k * 2 + 1) * 32 + l32) * 16 + 8 * half);
+    }
+    f32x16 out[PO_FR];
+#pragma unroll
+    for (int f = 0; f < PO_FR; ++f) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[f][r] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            f16x8 bh, bl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = v[0][f][8 * k + j] * v_scale;
+                const _Float16 hh = (_Float16)x;
+                bh[j] = hh;
+                bl[j] = (_Float16)(x - (float)hh);
+            }
+            out[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahp[k], bh, out[f], 0, 0, 0);
+            out[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahp[k], bl, out[f], 0, 0, 0);
+            out[f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alp[k], bh, out[f], 0, 0, 0);
+        }
+    }
+    const float inv = 1.0f / (v_scale * w_scale);
+    const long long seq = (long long)P.T * P.pred_cout * (P.Hout * P.Wout);
+    const int cstride4 = P.Hout * P.Wout * 4;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(P.pred_y + b * seq, 0, (int)(seq * 4), 0x00020000);
+    const float *__restrict__ pb = P.pred_b;
+    float bias[16];                                          // batch of loads ahead of the stores
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias[r] = pb[(r & 3) + 8 * (r >> 2) + 4 * half];
+    unsigned vo[PO_FR];
+#pragma unroll
+    for (int f = 0; f < PO_FR; ++f) {
+        const int mm = pos0 + f * 32 + l32;
+        vo[f] = kOOB;
+        if (mm < P.n_pos) {
+            const int tt = mm / (P.TH * P.TW);
+            const int rem = mm - tt * (P.TH * P.TW);
+            const int th = rem / P.TW;
+            const int tw = rem - th * P.TW;
+            const int t = t0 + tt, h = h0 + th, w = w0 + tw;
+            if (t < P.T && h < P.Hout && w < P.Wout)
+                vo[f] = (unsigned)((((t * P.pred_cout) * (P.Hout * P.Wout)) + h * P.Wout + w) * 4 + 4 * half * cstride4);
+        }
+    }
+    // straight-line stores: rows >= pred_cout are pushed out of range instead of branched around
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int oq = (r & 3) + 8 * (r >> 2);               // output channel minus 4 * half
+        const bool ook = oq + 4 * half < P.pred_cout;
+#pragma unroll
+        for (int f = 0; f < PO_FR; ++f) {
+            float y = out[f][r] * inv + bias[r];
+            y = fmaxf(y, 0.0f) + 0.0f;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), rs, ook ? vo[f] : kOOB, oq * cstride4, 0);
+        }
+    }
 }
 
 // The same epilogue in streaming order (constants, residual and store per element): used by the
@@ -506,7 +597,7 @@ __global__ __launch_bounds__(256, MW) void conv3d_kernel(ConvParams P) {
 // issue and its branches never sit in the MFMA waves' instruction stream.
 // LDS: 2 x 64 B of pieces per halo element (up to 1280 elements: 512-position boxes).
 // ---------------------------------------------------------------------------------------------
-template <int KS, int S, int WCO, int CO_FR, int PO_FR, int NA>
+template <int KS, int S, int WCO, int CO_FR, int PO_FR, int NA, int PRED = 0>
 __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
 #if defined(__HIP_DEVICE_COMPILE__)
     // KS = 1: the "halo box" is the output box itself (positions gathered with stride S), one tap
@@ -810,7 +901,13 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
                     poff[f] = (t * P.Cout) * (P.Hout * P.Wout) + h * P.Wout + w;
             }
         }
-        conv_epilogue<CO_FR, PO_FR, true>(P, acc, poff, co0, half, T.b, inv_scale);   // Cout need not fill the last channel tile
+        if constexpr (PRED) {                                   // 32-channel conv with the fused 1x1x1 head
+            static_assert(KS == 3 && S == 1 && WCO == 1 && CO_FR == 1, "the fused head rides on a 32-channel tile");
+            conv_epilogue<CO_FR, PO_FR, true, true>(P, acc, poff, co0, half, T.b, inv_scale);
+            pred_epilogue<PO_FR>(P, acc, wpo * PO_FR * 32, lane, T.b, T.t0, T.h0, T.w0);
+        } else {
+            conv_epilogue<CO_FR, PO_FR, true>(P, acc, poff, co0, half, T.b, inv_scale);   // Cout need not fill the last channel tile
+        }
         if (gc == CG) STAMP(0, 4);
         vb += (int)gridDim.x;
         more = next_tile(vb, T);
@@ -919,13 +1016,14 @@ __global__ __launch_bounds__(256) void weights_absmax_kernel(const float *__rest
     if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned *>(tail), __float_as_uint(m));
 }
 
-template <int KS, int S, int WCO, int CO_FR, int PO_FR, int NA>
+template <int KS, int S, int WCO, int CO_FR, int PO_FR, int NA, int PRED = 0>
 int launch_f16x2_ws(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream) {
     static_assert(27 % NA == 0 && NA >= 2, "the A-fragment ring must divide the 27 taps");
     constexpr int CO_TILE = WCO * CO_FR * 32, POS_TILE = (4 / WCO) * PO_FR * 32;
     constexpr int MAX_PLANE = 1280;         // 128 B of LDS per halo element; 5 elements per producer lane
     if (g_name_out) {
-        snprintf(g_name_out, g_name_cap, "conv3d_f16x2_ws_kernel<%d,%d,%d,%d,%d,%d>", KS, S, WCO, CO_FR, PO_FR, NA);
+        if (PRED) snprintf(g_name_out, g_name_cap, "conv3d_f16x2_ws_kernel<%d,%d,%d,%d,%d,%d,%d>", KS, S, WCO, CO_FR, PO_FR, NA, PRED);
+        else snprintf(g_name_out, g_name_cap, "conv3d_f16x2_ws_kernel<%d,%d,%d,%d,%d,%d>", KS, S, WCO, CO_FR, PO_FR, NA);
         return V2CE_OK;
     }
     Tile t{d.tile_t, d.tile_h, d.tile_w};
@@ -948,7 +1046,7 @@ int launch_f16x2_ws(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream)
     const int chs = (P.plane + 63) & ~63;
     const size_t lds = (size_t)chs * (2 * 4 * 16);
     V2CE_REQUIRE(lds <= 160 * 1024, V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd(f16x2 ws): %zu B of LDS", lds);
-    auto kern = conv3d_f16x2_ws_kernel<KS, S, WCO, CO_FR, PO_FR, NA>;
+    auto kern = conv3d_f16x2_ws_kernel<KS, S, WCO, CO_FR, PO_FR, NA, PRED>;
     V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 #ifdef V2CE_STAMP
@@ -1018,6 +1116,33 @@ __global__ __launch_bounds__(256) void pack_weights_f16x2_kernel(const float *__
     wq[n + i] = (_Float16)(v - (float)h);
 }
 
+// A fragments of the fused 1x1x1 head: table[k][plane][o][16] fp16 (o < 32, rows >= cout zero) with
+// table[k][.][o][8 * half + j] = hi / lo of s * w[o][(j & 3) + 8 (j >> 2) + 16 k + 4 half]  (the channel
+// order in which a lane of the 32-channel conv holds its outputs, see pred_epilogue), then { s } as a
+// float; s = the power of two that puts max |w| in [2^14, 2^15).  One workgroup.
+__global__ __launch_bounds__(256) void pack_pred_weights_kernel(const float *__restrict__ w, int cout,
+                                                                _Float16 *__restrict__ table) {
+    __shared__ float red[256];
+    float m = 0.0f;
+    for (int i = threadIdx.x; i < cout * 32; i += 256) m = fmaxf(m, fabsf(w[i]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    const float s = pow2_prescale(red[0]);
+    for (int e = threadIdx.x; e < 2 * 32 * 16; e += 256) {
+        const int k = e >> 9, o = (e >> 4) & 31, kk = e & 15, half = kk >> 3, j = kk & 7;
+        const int c = (j & 3) + 8 * (j >> 2) + 16 * k + 4 * half;
+        const float v = o < cout ? w[o * 32 + c] * s : 0.0f;
+        const _Float16 h = (_Float16)v;
+        table[((k * 2 + 0) * 32 + o) * 16 + kk] = h;
+        table[((k * 2 + 1) * 32 + o) * 16 + kk] = (_Float16)(v - (float)h);
+    }
+    if (threadIdx.x == 0) reinterpret_cast<float *>(table + 2048)[0] = s;
+}
+
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float *__restrict__ w, int Cout,
                                                            int Cin, int k3, const float *sigma,
                                                            float *__restrict__ wp) {
@@ -1041,9 +1166,10 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
                            const int32_t *hmap, const int32_t *wmap, const float *w_packed,
                            const float *scale, const float *shift, const float *residual,
                            float *y, const float *x0_absmax, const float *x1_absmax, float *y_absmax,
-                           v2ce_stream_t stream) {
+                           v2ce_stream_t stream, const void *pred_w = nullptr, const float *pred_b = nullptr,
+                           int pred_cout = 0, float *pred_y = nullptr) {
     clear_error();
-    V2CE_REQUIRE(desc && (g_name_out || (x0 && w_packed && scale && shift && y)), V2CE_ERR_BAD_ARG,
+    V2CE_REQUIRE(desc && (g_name_out || (x0 && w_packed && scale && shift && (y || pred_w))), V2CE_ERR_BAD_ARG,
                  "v2ce_conv3d_fwd: null pointer");
     const v2ce_conv3d_desc &d = *desc;
     V2CE_REQUIRE(d.B > 0 && d.T > 0 && d.C0 > 0 && d.C1 >= 0 && d.Hin > 0 && d.Win > 0 && d.Cout > 0,
@@ -1072,6 +1198,15 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
     P.Win = d.Win; P.Cin = d.C0 + d.C1; P.Cout = d.Cout; P.Hout = d.Hout; P.Wout = d.Wout;
     P.act = d.act;
     P.x0_absmax = x0_absmax; P.x1_absmax = d.C1 > 0 ? x1_absmax : nullptr; P.y_absmax = y_absmax;
+    P.pred_w = static_cast<const _Float16 *>(pred_w); P.pred_b = pred_b; P.pred_cout = pred_cout; P.pred_y = pred_y;
+    if (pred_w) {
+        V2CE_REQUIRE(d.precision == V2CE_PRECISION_F16X2 && d.ksize == 3 && d.stride_hw == 1 && d.Cout == 32 &&
+                     d.act == V2CE_ACT_RELU && pred_b && pred_y && pred_cout > 0 && pred_cout <= 32,
+                     V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd_pred: the fused head needs a split-half 3x3x3 stride-1 conv with "
+                     "32 output channels and ReLU, and 1..32 head channels");
+        V2CE_REQUIRE((long long)d.T * pred_cout * d.Hout * d.Wout < (1ll << 29), V2CE_ERR_UNSUPPORTED,
+                     "v2ce_conv3d_fwd_pred: an output sequence exceeds the 2 GiB buffer-descriptor range");
+    }
     hipStream_t st = as_stream(stream);
 
     const bool small_co = d.Cout <= 32;
@@ -1098,6 +1233,7 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
         if (s == 1) {
             // measured (tools/conv_bench.py, TF-equivalent): 128 channels x 256 positions per workgroup
             // 390-450; 64 x 512: 370-430 (64 x 256: 248-358); 32 x 512: 300-350 (32 x 256: 114-205)
+            if (small_co && P.pred_w) return launch_f16x2_ws<3, 1, 1, 1, 4, 3, 1>(P, d, st);
             if (small_co) return launch_f16x2_ws<3, 1, 1, 1, 4, 3>(P, d, st);
             if (d.Cout >= 128) return launch_f16x2_ws<3, 1, 2, 2, 4, 3>(P, d, st);
             return launch_f16x2_ws<3, 1, 1, 2, 4, 3>(P, d, st);
@@ -1185,6 +1321,31 @@ extern "C" int v2ce_conv3d_fwd(const v2ce_conv3d_desc *desc, const float *x0, co
     g_name_out = nullptr;
     return conv3d_dispatch(desc, x0, x1, hmap, wmap, w_packed, scale, shift, residual, y, x0_absmax,
                            x1_absmax, y_absmax, stream);
+}
+
+extern "C" int v2ce_conv3d_fwd_pred(const v2ce_conv3d_desc *desc, const float *x0, const float *x1,
+                                    const int32_t *hmap, const int32_t *wmap, const float *w_packed,
+                                    const float *scale, const float *shift, const float *residual,
+                                    float *y, const float *x0_absmax, const float *x1_absmax,
+                                    float *y_absmax, const void *pred_w, const float *pred_b, int pred_cout,
+                                    float *pred_y, v2ce_stream_t stream) {
+    g_name_out = nullptr;
+    clear_error();
+    V2CE_REQUIRE(pred_w, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd_pred: null head weights");
+    return conv3d_dispatch(desc, x0, x1, hmap, wmap, w_packed, scale, shift, residual, y, x0_absmax,
+                           x1_absmax, y_absmax, stream, pred_w, pred_b, pred_cout, pred_y);
+}
+
+extern "C" size_t v2ce_pack_pred_weights_f16x2_bytes(void) { return 2048 * 2 + 16; }
+
+extern "C" int v2ce_pack_pred_weights_f16x2(const float *w, int cout, int cin, void *table, v2ce_stream_t stream) {
+    clear_error();
+    V2CE_REQUIRE(w && table && cout > 0 && cout <= 32 && cin == 32, V2CE_ERR_BAD_ARG,
+                 "v2ce_pack_pred_weights_f16x2: needs [cout <= 32][32] weights");
+    hipLaunchKernelGGL(pack_pred_weights_kernel, dim3(1), dim3(256), 0, as_stream(stream), w, cout,
+                       static_cast<_Float16 *>(table));
+    V2CE_HIP_CHECK(hipGetLastError());
+    return V2CE_OK;
 }
 
 extern "C" int v2ce_conv3d_variant(const v2ce_conv3d_desc *desc, int mapped, char *name, size_t cap) {

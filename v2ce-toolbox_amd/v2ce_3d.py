@@ -201,6 +201,16 @@ class V2ce3d(nn.Module):
         P["head"] = (self._pack(h.weight.contiguous()), ones(h.weight.shape[0]), h.bias.float().contiguous())
         pr = self.UNet.pred.conv3d
         P["pred"] = (self._pack(pr.weight.contiguous()), ones(pr.weight.shape[0]), pr.bias.float().contiguous())
+        P["pred_fused"] = None
+        if self.precision == "f16x2" and pr.weight.shape[1] == 32 and pr.weight.shape[0] <= 32:
+            # the 1x1x1 head rides on the last decoder conv's accumulators (v2ce_conv3d_fwd_pred)
+            tab = torch.empty(hip.lib().v2ce_pack_pred_weights_f16x2_bytes() // 2, dtype=torch.float16, device=dev)
+            hip.check(hip.lib().v2ce_pack_pred_weights_f16x2(pr.weight.contiguous().data_ptr(), pr.weight.shape[0], 32,
+                                                             tab.data_ptr(), hip.stream_ptr(dev)),
+                      "v2ce_pack_pred_weights_f16x2")
+            bias = torch.zeros(32, dtype=torch.float32, device=dev)
+            bias[:pr.weight.shape[0]] = pr.bias.float()
+            P["pred_fused"] = (tab, bias, int(pr.weight.shape[0]))
         sn_ws = 0
         for name, blocks in (("enc", self.UNet.encoders), ("res", self.UNet.resblocks),
                              ("dec", self.UNet.decoders)):
@@ -248,7 +258,7 @@ class V2ce3d(nn.Module):
 
     # ---- kernels ------------------------------------------------------------------------------
     def _conv(self, x0, x1, w_packed, scale, shift, cout, ksize, stride, act, residual=None,
-              up_to=None, split=False, track=False):
+              up_to=None, split=False, track=False, pred=None):
         """x0 [B,T,C0,H0,W0] (optionally nearest-upsampled to ``up_to``), x1 [B,T,C1,Hin,Win]."""
         B, T, C0, H0, W0 = x0.shape
         Hin, Win = up_to if up_to is not None else (H0, W0)
@@ -275,15 +285,28 @@ class V2ce3d(nn.Module):
         if prof is not None:       # HIP events on the launch stream (torch's current stream)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        hip.check(hip.lib().v2ce_conv3d_fwd(ctypes.byref(d), x0.data_ptr(), hip.ptr(x1),
-                                            hip.ptr(hmap), hip.ptr(wmap), w_packed.data_ptr(),
-                                            scale.data_ptr(), shift.data_ptr(), hip.ptr(residual),
-                                            y.data_ptr(), hip.ptr(a0), hip.ptr(a1), hip.ptr(ay),
-                                            hip.stream_ptr(x0.device)),
-                  "v2ce_conv3d_fwd")
+        if pred is not None:           # fused 1x1x1 head: only its output is materialised
+            tab, pbias, pcout = pred
+            y = torch.empty((B, T, pcout, Hout, Wout), dtype=torch.float32, device=x0.device)
+            hip.check(hip.lib().v2ce_conv3d_fwd_pred(ctypes.byref(d), x0.data_ptr(), hip.ptr(x1),
+                                                     hip.ptr(hmap), hip.ptr(wmap), w_packed.data_ptr(),
+                                                     scale.data_ptr(), shift.data_ptr(), hip.ptr(residual),
+                                                     None, hip.ptr(a0), hip.ptr(a1), None,
+                                                     tab.data_ptr(), pbias.data_ptr(), pcout, y.data_ptr(),
+                                                     hip.stream_ptr(x0.device)),
+                      "v2ce_conv3d_fwd_pred")
+        else:
+            hip.check(hip.lib().v2ce_conv3d_fwd(ctypes.byref(d), x0.data_ptr(), hip.ptr(x1),
+                                                hip.ptr(hmap), hip.ptr(wmap), w_packed.data_ptr(),
+                                                scale.data_ptr(), shift.data_ptr(), hip.ptr(residual),
+                                                y.data_ptr(), hip.ptr(a0), hip.ptr(a1), hip.ptr(ay),
+                                                hip.stream_ptr(x0.device)),
+                      "v2ce_conv3d_fwd")
         if prof is not None:
             e1.record()
             flops = 2.0 * B * T * Hout * Wout * cout * (C0 + C1) * ksize ** 3
+            if pred is not None:
+                flops += 2.0 * B * T * Hout * Wout * pred[2] * cout
             prof.append((hip.conv_variant(d, hmap is not None), flops, e0, e1))
         return y
 
@@ -299,7 +322,7 @@ class V2ce3d(nn.Module):
                   "v2ce_sn_power_iter")
         return self._pack(inner.weight_bar, P["sigma"], out, split=out.dtype == torch.float16)
 
-    def _block(self, blk: _ResidualBlock3D, d, x0, x1=None, up_to=None):
+    def _block(self, blk: _ResidualBlock3D, d, x0, x1=None, up_to=None, pred=None):
         """submodules.py:249-264: relu(bn2(conv2(relu(bn1(conv1 x)))) + bn_d(conv_d x))."""
         s = blk.stride_hw
         if blk.sn:
@@ -312,7 +335,7 @@ class V2ce3d(nn.Module):
                          split=self._split(blk.cin, blk.cout, 1, s))
         w2 = d["conv2_w"]
         return self._conv(t, None, w2, *d["bn2"], blk.cout, 3, 1, hip.ACT_RELU, residual=res,
-                          split=self._split(blk.cout, blk.cout), track=track)
+                          split=self._split(blk.cout, blk.cout), track=track and pred is None, pred=pred)
 
     def _launch_sn(self):
         """One power iteration + re-pack for all 12 spectral-norm layers (the trajectory does not depend
@@ -381,10 +404,16 @@ class V2ce3d(nn.Module):
         for i, blk in enumerate(U.resblocks):                                    # :349-350
             h = self._block(blk, P[f"res{i}"], h)
             inter[f"res{i}"] = h
+        fuse = P["pred_fused"] if not return_intermediates else None
         for i, (blk, skip) in enumerate(zip(U.decoders, reversed(skips))):       # :357-365
-            h = self._block(blk, P[f"dec{i}"], h, skip, up_to=(skip.shape[3], skip.shape[4]))
+            last = i == len(U.decoders) - 1
+            h = self._block(blk, P[f"dec{i}"], h, skip, up_to=(skip.shape[3], skip.shape[4]),
+                            pred=fuse if last else None)
             inter[f"dec{i}"] = h
-        out = self._conv(h, None, *P["pred"], self.out_channels, 1, 1, hip.ACT_RELU)   # :374
+        if fuse is not None:
+            out = h                                                               # pred rode on dec3.conv2
+        else:
+            out = self._conv(h, None, *P["pred"], self.out_channels, 1, 1, hip.ACT_RELU)   # :374
         self.calls += 1
         if return_intermediates:
             return out, inter
