@@ -165,6 +165,19 @@ int v2ce_conv3d_fwd_pred(const v2ce_conv3d_desc *desc, const float *x0, const fl
                          const void *pred_w, const float *pred_b, int pred_cout, float *pred_y,
                          v2ce_stream_t stream);
 
+/* v2ce_conv3d_fwd with the block's 1x1x1 shortcut fused in (scripts/submodules.py:249-264: conv1 and
+ * `downsample` read the same input; the centre tap of the 3x3x3 conv touches exactly the (strided)
+ * positions the shortcut reads): sc_y = sc_scale[co] * (sc_w (*) x) + sc_shift[co], no activation.
+ * sc_w = v2ce_pack_weights_f16x2 of the [Cout][Cin][1] shortcut weights.  Requires precision F16X2,
+ * ksize 3 and (stride 2 or Cout <= 32): the kernel variants whose waves own one 32-channel fragment
+ * row and can hold the second accumulator set. */
+int v2ce_conv3d_fwd_sc(const v2ce_conv3d_desc *desc, const float *x0, const float *x1,
+                       const int32_t *hmap, const int32_t *wmap, const float *w_packed,
+                       const float *scale, const float *shift, float *y,
+                       const float *x0_absmax, const float *x1_absmax, float *y_absmax,
+                       const void *sc_w, const float *sc_scale, const float *sc_shift, float *sc_y,
+                       v2ce_stream_t stream);
+
 /* Name of the kernel instantiation v2ce_conv3d_fwd would launch for desc ("conv3d_kernel<KS,S,
  * CO_FR,PO_FR,CK,EPT>", as it appears demangled in rocprofv3 traces); mapped != 0 means hmap/wmap
  * would be non-NULL.  Launches nothing.  Used by bench.py to attribute event timings. */

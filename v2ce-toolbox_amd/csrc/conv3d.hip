@@ -74,6 +74,11 @@ struct ConvParams {
     const float *pred_b;          // [32], zero padded
     float *pred_y;                // [B][T][pred_cout][Hout][Wout]
     int pred_cout;
+    // fused 1x1x1 shortcut of a residual block (v2ce_conv3d_fwd_sc): the centre tap of the 3x3x3 conv reads exactly
+    // the (strided) positions the shortcut conv reads, so it rides along in a second accumulator set
+    const _Float16 *sc_w;         // v2ce_pack_weights_f16x2 buffer of the [Cout][Cin][1] shortcut weights
+    const float *sc_scale, *sc_shift;
+    float *sc_y;                  // [B][T][Cout][Hout][Wout]
 #ifdef V2CE_STAMP
     unsigned long long *stamps;   // diagnostic build only: [block][role][8] s_memtime stamps
 #endif
@@ -597,7 +602,8 @@ __global__ __launch_bounds__(256, MW) void conv3d_kernel(ConvParams P) {
 // issue and its branches never sit in the MFMA waves' instruction stream.
 // LDS: 2 x 64 B of pieces per halo element (up to 1280 elements: 512-position boxes).
 // ---------------------------------------------------------------------------------------------
-template <int KS, int S, int WCO, int CO_FR, int PO_FR, int NA, int PRED = 0>
+// FUSE: 0 = plain, 1 = fused 1x1x1 head (pred_epilogue), 2 = fused 1x1x1 shortcut (second accumulator set)
+template <int KS, int S, int WCO, int CO_FR, int PO_FR, int NA, int FUSE = 0>
 __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
 #if defined(__HIP_DEVICE_COMPILE__)
     // KS = 1: the "halo box" is the output box itself (positions gathered with stride S), one tap
@@ -773,6 +779,11 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
     const int tap_stride = CG * P.Cout * 32;               // bytes between taps
     const int cg_stride = P.Cout * 32;                     // bytes between 16-channel groups
     const float inv_scale = 1.0f / (x_scale * w_scale);     // a power of two: exact
+    constexpr bool SC = FUSE == 2;
+    static_assert(!SC || (KS == 3 && CO_FR == 1), "the fused shortcut needs a second accumulator set: 32-channel wave tiles");
+    const long long wplane_d = (long long)CG * P.Cout * 16;                  // halves per plane of the shortcut weights
+    const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<_Float16 *>(SC ? P.sc_w : P.wq), 0, (int)(4 * wplane_d), 0x00020000);
 
     // A fragments come from L2 (a chunk's weights exceed the 32 KiB L1): ring of NA slots, loaded
     // NA-1 taps ahead; 27 % NA == 0, so slot = tap % NA stays static across chunk boundaries.  The
@@ -831,9 +842,26 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[q][f][r] = 0.0f;
 
+        f32x16 accd[SC ? CO_FR : 1][SC ? PO_FR : 1];         // shortcut accumulators
+        if constexpr (SC) {
+#pragma unroll
+            for (int q = 0; q < CO_FR; ++q)
+#pragma unroll
+                for (int f = 0; f < PO_FR; ++f)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) accd[q][f][r] = 0.0f;
+        }
         for (int cg = 0; cg < CG; ++cg, ++gc) {
             const f16x8 *qb = pieces + (gc & 1) * 4 * chs;
             const int wc = cg * cg_stride;
+            f16x8 ahd[CO_FR], ald[CO_FR];                    // this chunk's shortcut weights (used at the centre tap)
+            if constexpr (SC) {
+#pragma unroll
+                for (int q = 0; q < CO_FR; ++q) {
+                    ahd[q] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_d, wlane[q], wc, 0));
+                    ald[q] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_d, wlane[q], wc + (int)(2 * wplane_d), 0));
+                }
+            }
             const int wn = cg + 1 < CG ? wc + cg_stride : 0;    // last chunk: chunk 0 again (the next tile's start)
             if constexpr (KS == 1) {                            // one tap per chunk: A double-buffered over chunks
 #pragma unroll
@@ -877,6 +905,14 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
                         acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tap % NA][q], bl[f], acc[q][f], 0, 0, 0);
                         acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tap % NA][q], bh[f], acc[q][f], 0, 0, 0);
                     }
+                    if constexpr (SC && tap == 13) {         // centre tap = the positions the 1x1x1 shortcut reads
+#pragma unroll
+                        for (int q = 0; q < CO_FR; ++q) {
+                            accd[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahd[q], bh[f], accd[q][f], 0, 0, 0);
+                            accd[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahd[q], bl[f], accd[q][f], 0, 0, 0);
+                            accd[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ald[q], bh[f], accd[q][f], 0, 0, 0);
+                        }
+                    }
                     if constexpr (nt < K3) {                 // refill in place for the next tap
                         bh[f] = qb[bhb[f] + toff];
                         bl[f] = qb[bhb[f] + toff + 2 * chs];
@@ -901,12 +937,19 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
                     poff[f] = (t * P.Cout) * (P.Hout * P.Wout) + h * P.Wout + w;
             }
         }
-        if constexpr (PRED) {                                   // 32-channel conv with the fused 1x1x1 head
+        if constexpr (FUSE == 1) {                              // 32-channel conv with the fused 1x1x1 head
             static_assert(KS == 3 && S == 1 && WCO == 1 && CO_FR == 1, "the fused head rides on a 32-channel tile");
             conv_epilogue<CO_FR, PO_FR, true, true>(P, acc, poff, co0, half, T.b, inv_scale);
             pred_epilogue<PO_FR>(P, acc, wpo * PO_FR * 32, lane, T.b, T.t0, T.h0, T.w0);
         } else {
             conv_epilogue<CO_FR, PO_FR, true>(P, acc, poff, co0, half, T.b, inv_scale);   // Cout need not fill the last channel tile
+        }
+        if constexpr (SC) {                                     // shortcut: bn_d(conv_d x), no activation, no residual
+            ConvParams Q = P;
+            Q.scale = P.sc_scale; Q.shift = P.sc_shift; Q.res = nullptr; Q.y = P.sc_y; Q.act = V2CE_ACT_NONE;
+            Q.y_absmax = nullptr;
+            const float wd_scale = reinterpret_cast<const float *>(P.sc_w + 2 * wplane_d)[1];
+            conv_epilogue<CO_FR, PO_FR, true>(Q, accd, poff, co0, half, T.b, 1.0f / (x_scale * wd_scale));
         }
         if (gc == CG) STAMP(0, 4);
         vb += (int)gridDim.x;
@@ -1016,13 +1059,13 @@ __global__ __launch_bounds__(256) void weights_absmax_kernel(const float *__rest
     if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned *>(tail), __float_as_uint(m));
 }
 
-template <int KS, int S, int WCO, int CO_FR, int PO_FR, int NA, int PRED = 0>
+template <int KS, int S, int WCO, int CO_FR, int PO_FR, int NA, int FUSE = 0>
 int launch_f16x2_ws(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream) {
     static_assert(27 % NA == 0 && NA >= 2, "the A-fragment ring must divide the 27 taps");
     constexpr int CO_TILE = WCO * CO_FR * 32, POS_TILE = (4 / WCO) * PO_FR * 32;
     constexpr int MAX_PLANE = 1280;         // 128 B of LDS per halo element; 5 elements per producer lane
     if (g_name_out) {
-        if (PRED) snprintf(g_name_out, g_name_cap, "conv3d_f16x2_ws_kernel<%d,%d,%d,%d,%d,%d,%d>", KS, S, WCO, CO_FR, PO_FR, NA, PRED);
+        if (FUSE) snprintf(g_name_out, g_name_cap, "conv3d_f16x2_ws_kernel<%d,%d,%d,%d,%d,%d,%d>", KS, S, WCO, CO_FR, PO_FR, NA, FUSE);
         else snprintf(g_name_out, g_name_cap, "conv3d_f16x2_ws_kernel<%d,%d,%d,%d,%d,%d>", KS, S, WCO, CO_FR, PO_FR, NA);
         return V2CE_OK;
     }
@@ -1046,7 +1089,7 @@ int launch_f16x2_ws(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream)
     const int chs = (P.plane + 63) & ~63;
     const size_t lds = (size_t)chs * (2 * 4 * 16);
     V2CE_REQUIRE(lds <= 160 * 1024, V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd(f16x2 ws): %zu B of LDS", lds);
-    auto kern = conv3d_f16x2_ws_kernel<KS, S, WCO, CO_FR, PO_FR, NA, PRED>;
+    auto kern = conv3d_f16x2_ws_kernel<KS, S, WCO, CO_FR, PO_FR, NA, FUSE>;
     V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 #ifdef V2CE_STAMP
@@ -1167,7 +1210,8 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
                            const float *scale, const float *shift, const float *residual,
                            float *y, const float *x0_absmax, const float *x1_absmax, float *y_absmax,
                            v2ce_stream_t stream, const void *pred_w = nullptr, const float *pred_b = nullptr,
-                           int pred_cout = 0, float *pred_y = nullptr) {
+                           int pred_cout = 0, float *pred_y = nullptr, const void *sc_w = nullptr,
+                           const float *sc_scale = nullptr, const float *sc_shift = nullptr, float *sc_y = nullptr) {
     clear_error();
     V2CE_REQUIRE(desc && (g_name_out || (x0 && w_packed && scale && shift && (y || pred_w))), V2CE_ERR_BAD_ARG,
                  "v2ce_conv3d_fwd: null pointer");
@@ -1199,6 +1243,13 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
     P.act = d.act;
     P.x0_absmax = x0_absmax; P.x1_absmax = d.C1 > 0 ? x1_absmax : nullptr; P.y_absmax = y_absmax;
     P.pred_w = static_cast<const _Float16 *>(pred_w); P.pred_b = pred_b; P.pred_cout = pred_cout; P.pred_y = pred_y;
+    P.sc_w = static_cast<const _Float16 *>(sc_w); P.sc_scale = sc_scale; P.sc_shift = sc_shift; P.sc_y = sc_y;
+    if (sc_w) {
+        V2CE_REQUIRE(d.precision == V2CE_PRECISION_F16X2 && d.ksize == 3 && (d.stride_hw == 2 || d.Cout <= 32) &&
+                     !pred_w && sc_scale && sc_shift && sc_y, V2CE_ERR_UNSUPPORTED,
+                     "v2ce_conv3d_fwd_sc: the fused shortcut needs a split-half 3x3x3 conv that is strided or has <= 32 "
+                     "output channels (one 32-channel fragment row per wave)");
+    }
     if (pred_w) {
         V2CE_REQUIRE(d.precision == V2CE_PRECISION_F16X2 && d.ksize == 3 && d.stride_hw == 1 && d.Cout == 32 &&
                      d.act == V2CE_ACT_RELU && pred_b && pred_y && pred_cout > 0 && pred_cout <= 32,
@@ -1234,12 +1285,18 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
             // measured (tools/conv_bench.py, TF-equivalent): 128 channels x 256 positions per workgroup
             // 390-450; 64 x 512: 370-430 (64 x 256: 248-358); 32 x 512: 300-350 (32 x 256: 114-205)
             if (small_co && P.pred_w) return launch_f16x2_ws<3, 1, 1, 1, 4, 3, 1>(P, d, st);
+            if (small_co && P.sc_w) return launch_f16x2_ws<3, 1, 1, 1, 4, 3, 2>(P, d, st);
             if (small_co) return launch_f16x2_ws<3, 1, 1, 1, 4, 3>(P, d, st);
             if (d.Cout >= 128) return launch_f16x2_ws<3, 1, 2, 2, 4, 3>(P, d, st);
             return launch_f16x2_ws<3, 1, 1, 2, 4, 3>(P, d, st);
         }
         // stride 2: the halo box is ~4x the output box, so 128-position boxes; one 32-channel fragment
         // row per wave measured best (Cout >= 128: 300-320; Cout = 64: 245)
+        if (P.sc_w) {
+            if (d.Cout >= 128) return launch_f16x2_ws<3, 2, 4, 1, 4, 3, 2>(P, d, st);
+            if (!small_co) return launch_f16x2_ws<3, 2, 2, 1, 2, 3, 2>(P, d, st);
+            return launch_f16x2_ws<3, 2, 1, 1, 1, 3, 2>(P, d, st);
+        }
         if (d.Cout >= 128) return launch_f16x2_ws<3, 2, 4, 1, 4, 3>(P, d, st);
         if (!small_co) return launch_f16x2_ws<3, 2, 2, 1, 2, 3>(P, d, st);
         return launch_f16x2_ws<3, 2, 1, 1, 1, 3>(P, d, st);
@@ -1334,6 +1391,19 @@ extern "C" int v2ce_conv3d_fwd_pred(const v2ce_conv3d_desc *desc, const float *x
     V2CE_REQUIRE(pred_w, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd_pred: null head weights");
     return conv3d_dispatch(desc, x0, x1, hmap, wmap, w_packed, scale, shift, residual, y, x0_absmax,
                            x1_absmax, y_absmax, stream, pred_w, pred_b, pred_cout, pred_y);
+}
+
+extern "C" int v2ce_conv3d_fwd_sc(const v2ce_conv3d_desc *desc, const float *x0, const float *x1,
+                                  const int32_t *hmap, const int32_t *wmap, const float *w_packed,
+                                  const float *scale, const float *shift, float *y,
+                                  const float *x0_absmax, const float *x1_absmax, float *y_absmax,
+                                  const void *sc_w, const float *sc_scale, const float *sc_shift, float *sc_y,
+                                  v2ce_stream_t stream) {
+    g_name_out = nullptr;
+    clear_error();
+    V2CE_REQUIRE(sc_w, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd_sc: null shortcut weights");
+    return conv3d_dispatch(desc, x0, x1, hmap, wmap, w_packed, scale, shift, nullptr, y, x0_absmax,
+                           x1_absmax, y_absmax, stream, nullptr, nullptr, 0, nullptr, sc_w, sc_scale, sc_shift, sc_y);
 }
 
 extern "C" size_t v2ce_pack_pred_weights_f16x2_bytes(void) { return 2048 * 2 + 16; }

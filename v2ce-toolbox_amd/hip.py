@@ -26,7 +26,7 @@ EXPORTS = [
     "v2ce_ldati_lds_bytes", "v2ce_ldati_workspace_bytes", "v2ce_ldati_emit", "v2ce_events_pack", "v2ce_conv3d_fwd",
     "v2ce_conv3d_variant", "v2ce_pack_weights_f16x2", "v2ce_pack_weights_f16x2_bytes",
     "v2ce_pack_weights", "v2ce_sn_workspace_bytes", "v2ce_sn_power_iter", "v2ce_preprocess_pairs",
-    "v2ce_voxelize_events", "v2ce_conv3d_fwd_pred", "v2ce_pack_pred_weights_f16x2", "v2ce_pack_pred_weights_f16x2_bytes",
+    "v2ce_voxelize_events", "v2ce_conv3d_fwd_pred", "v2ce_conv3d_fwd_sc", "v2ce_pack_pred_weights_f16x2", "v2ce_pack_pred_weights_f16x2_bytes",
 ]
 
 
@@ -87,6 +87,8 @@ def lib() -> ctypes.CDLL:
     L.v2ce_voxelize_events.restype = ctypes.c_int
     L.v2ce_conv3d_fwd_pred.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 14 + [i32, vp, vp]
     L.v2ce_conv3d_fwd_pred.restype = ctypes.c_int
+    L.v2ce_conv3d_fwd_sc.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 16
+    L.v2ce_conv3d_fwd_sc.restype = ctypes.c_int
     L.v2ce_pack_pred_weights_f16x2.argtypes = [vp, i32, i32, vp, vp]
     L.v2ce_pack_pred_weights_f16x2.restype = ctypes.c_int
     L.v2ce_pack_pred_weights_f16x2_bytes.argtypes = []

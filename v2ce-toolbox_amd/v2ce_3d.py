@@ -220,7 +220,7 @@ class V2ce3d(nn.Module):
                 d["bn1"] = self._fold_bn(blk.bn1)
                 d["bn2"] = self._fold_bn(blk.bn2)
                 d["down_w"] = self._pack(blk.downsample[0].weight.contiguous(),
-                                         split=self._split(blk.cin, blk.cout, 1, blk.stride_hw))
+                                         split=self._fuse_shortcut(blk) or self._split(blk.cin, blk.cout, 1, blk.stride_hw))
                 d["down_bn"] = self._fold_bn(blk.downsample[1], blk.downsample[0].bias)
                 if blk.sn:
                     for cn in ("conv1", "conv2"):
@@ -250,6 +250,13 @@ class V2ce3d(nn.Module):
             return False
         return ksize == 3 or stride == 2 or cout >= 128
 
+    def _fuse_shortcut(self, blk) -> bool:
+        """Ride the block's 1x1x1 shortcut on conv1's launch (v2ce_conv3d_fwd_sc)?  Possible where conv1's
+        waves own one 32-channel fragment row (strided blocks, and the 32-channel last decoder): the
+        second accumulator set fits, the shortcut's input is never read a second time and its launch
+        disappears (enc0-3, dec3: ~0.9 ms per 64 frame-pairs)."""
+        return self.precision == "f16x2" and (blk.stride_hw == 2 or blk.cout <= 32)
+
     def _map(self, n_in, n_out, dev):
         key = (n_in, n_out, str(dev))
         if key not in self._maps:
@@ -258,7 +265,7 @@ class V2ce3d(nn.Module):
 
     # ---- kernels ------------------------------------------------------------------------------
     def _conv(self, x0, x1, w_packed, scale, shift, cout, ksize, stride, act, residual=None,
-              up_to=None, split=False, track=False, pred=None):
+              up_to=None, split=False, track=False, pred=None, sc=None):
         """x0 [B,T,C0,H0,W0] (optionally nearest-upsampled to ``up_to``), x1 [B,T,C1,Hin,Win]."""
         B, T, C0, H0, W0 = x0.shape
         Hin, Win = up_to if up_to is not None else (H0, W0)
@@ -295,6 +302,16 @@ class V2ce3d(nn.Module):
                                                      tab.data_ptr(), pbias.data_ptr(), pcout, y.data_ptr(),
                                                      hip.stream_ptr(x0.device)),
                       "v2ce_conv3d_fwd_pred")
+        elif sc is not None:           # fused 1x1x1 shortcut: second output tensor
+            sc_w, sc_scale, sc_shift = sc
+            y_sc = torch.empty_like(y)
+            hip.check(hip.lib().v2ce_conv3d_fwd_sc(ctypes.byref(d), x0.data_ptr(), hip.ptr(x1),
+                                                   hip.ptr(hmap), hip.ptr(wmap), w_packed.data_ptr(),
+                                                   scale.data_ptr(), shift.data_ptr(), y.data_ptr(),
+                                                   hip.ptr(a0), hip.ptr(a1), hip.ptr(ay),
+                                                   sc_w.data_ptr(), sc_scale.data_ptr(), sc_shift.data_ptr(),
+                                                   y_sc.data_ptr(), hip.stream_ptr(x0.device)),
+                      "v2ce_conv3d_fwd_sc")
         else:
             hip.check(hip.lib().v2ce_conv3d_fwd(ctypes.byref(d), x0.data_ptr(), hip.ptr(x1),
                                                 hip.ptr(hmap), hip.ptr(wmap), w_packed.data_ptr(),
@@ -307,7 +324,11 @@ class V2ce3d(nn.Module):
             flops = 2.0 * B * T * Hout * Wout * cout * (C0 + C1) * ksize ** 3
             if pred is not None:
                 flops += 2.0 * B * T * Hout * Wout * pred[2] * cout
+            if sc is not None:
+                flops += 2.0 * B * T * Hout * Wout * cout * (C0 + C1)
             prof.append((hip.conv_variant(d, hmap is not None), flops, e0, e1))
+        if sc is not None:
+            return y, y_sc
         return y
 
     def _sn_weight(self, inner: _SNConvInner, out):
@@ -328,11 +349,15 @@ class V2ce3d(nn.Module):
         if blk.sn:
             self._await_sn()
         w1 = d["conv1_w"]
-        t = self._conv(x0, x1, w1, *d["bn1"], blk.cout, 3, s, hip.ACT_RELU, up_to=up_to,
-                       split=self._split(blk.cin, blk.cout))
         track = self.precision == "f16x2"      # the block output may feed a split-half conv
-        res = self._conv(x0, x1, d["down_w"], *d["down_bn"], blk.cout, 1, s, hip.ACT_NONE, up_to=up_to,
-                         split=self._split(blk.cin, blk.cout, 1, s))
+        if self._fuse_shortcut(blk):
+            t, res = self._conv(x0, x1, w1, *d["bn1"], blk.cout, 3, s, hip.ACT_RELU, up_to=up_to, split=True,
+                                sc=(d["down_w"], *d["down_bn"]))
+        else:
+            t = self._conv(x0, x1, w1, *d["bn1"], blk.cout, 3, s, hip.ACT_RELU, up_to=up_to,
+                           split=self._split(blk.cin, blk.cout))
+            res = self._conv(x0, x1, d["down_w"], *d["down_bn"], blk.cout, 1, s, hip.ACT_NONE, up_to=up_to,
+                             split=self._split(blk.cin, blk.cout, 1, s))
         w2 = d["conv2_w"]
         return self._conv(t, None, w2, *d["bn2"], blk.cout, 3, 1, hip.ACT_RELU, residual=res,
                           split=self._split(blk.cout, blk.cout), track=track and pred is None, pred=pred)
