@@ -1065,8 +1065,7 @@ int launch_f16x2_ws(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream)
     constexpr int CO_TILE = WCO * CO_FR * 32, POS_TILE = (4 / WCO) * PO_FR * 32;
     constexpr int MAX_PLANE = 1280;         // 128 B of LDS per halo element; 5 elements per producer lane
     if (g_name_out) {
-        if (FUSE) snprintf(g_name_out, g_name_cap, "conv3d_f16x2_ws_kernel<%d,%d,%d,%d,%d,%d,%d>", KS, S, WCO, CO_FR, PO_FR, NA, FUSE);
-        else snprintf(g_name_out, g_name_cap, "conv3d_f16x2_ws_kernel<%d,%d,%d,%d,%d,%d>", KS, S, WCO, CO_FR, PO_FR, NA);
+        snprintf(g_name_out, g_name_cap, "conv3d_f16x2_ws_kernel<%d,%d,%d,%d,%d,%d,%d>", KS, S, WCO, CO_FR, PO_FR, NA, FUSE);
         return V2CE_OK;
     }
     Tile t{d.tile_t, d.tile_h, d.tile_w};
@@ -1418,17 +1417,26 @@ extern "C" int v2ce_pack_pred_weights_f16x2(const float *w, int cout, int cin, v
     return V2CE_OK;
 }
 
-extern "C" int v2ce_conv3d_variant(const v2ce_conv3d_desc *desc, int mapped, char *name, size_t cap) {
+extern "C" int v2ce_conv3d_variant_fused(const v2ce_conv3d_desc *desc, int mapped, int fuse, char *name, size_t cap) {
     V2CE_REQUIRE(name && cap > 0, V2CE_ERR_BAD_ARG, "v2ce_conv3d_variant: no buffer");
     name[0] = '\0';
     g_name_out = name;
     g_name_cap = cap;
     static const int32_t dummy_map = 0;
+    static const float dummy = 0.0f;
     const int32_t *m = mapped ? &dummy_map : nullptr;
     const int rc = conv3d_dispatch(desc, nullptr, nullptr, m, m, nullptr, nullptr, nullptr, nullptr,
-                                   nullptr, nullptr, nullptr, nullptr, nullptr);
+                                   nullptr, nullptr, nullptr, nullptr, nullptr,
+                                   fuse == 1 ? &dummy : nullptr, fuse == 1 ? &dummy : nullptr, fuse == 1 ? 1 : 0,
+                                   fuse == 1 ? const_cast<float *>(&dummy) : nullptr,
+                                   fuse == 2 ? &dummy : nullptr, fuse == 2 ? &dummy : nullptr,
+                                   fuse == 2 ? &dummy : nullptr, fuse == 2 ? const_cast<float *>(&dummy) : nullptr);
     g_name_out = nullptr;
     return rc;
+}
+
+extern "C" int v2ce_conv3d_variant(const v2ce_conv3d_desc *desc, int mapped, char *name, size_t cap) {
+    return v2ce_conv3d_variant_fused(desc, mapped, 0, name, cap);
 }
 
 extern "C" size_t v2ce_pack_weights_f16x2_bytes(int Cout, int Cin, int k3) {

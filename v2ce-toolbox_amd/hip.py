@@ -24,7 +24,7 @@ PRECISION_F32, PRECISION_F16X2 = 0, 1
 EXPORTS = [
     "v2ce_version", "v2ce_last_error", "v2ce_ldati_count", "v2ce_ldati_scan",
     "v2ce_ldati_lds_bytes", "v2ce_ldati_workspace_bytes", "v2ce_ldati_emit", "v2ce_events_pack", "v2ce_conv3d_fwd",
-    "v2ce_conv3d_variant", "v2ce_pack_weights_f16x2", "v2ce_pack_weights_f16x2_bytes",
+    "v2ce_conv3d_variant", "v2ce_conv3d_variant_fused", "v2ce_pack_weights_f16x2", "v2ce_pack_weights_f16x2_bytes",
     "v2ce_pack_weights", "v2ce_sn_workspace_bytes", "v2ce_sn_power_iter", "v2ce_preprocess_pairs",
     "v2ce_voxelize_events", "v2ce_conv3d_fwd_pred", "v2ce_conv3d_fwd_sc", "v2ce_pack_pred_weights_f16x2", "v2ce_pack_pred_weights_f16x2_bytes",
 ]
@@ -81,6 +81,8 @@ def lib() -> ctypes.CDLL:
     L.v2ce_pack_weights_f16x2_bytes.argtypes = [i32, i32, i32]
     L.v2ce_pack_weights_f16x2_bytes.restype = sz
     L.v2ce_conv3d_variant.argtypes = [ctypes.POINTER(ConvDesc), i32, ctypes.c_char_p, sz]
+    L.v2ce_conv3d_variant_fused.argtypes = [ctypes.POINTER(ConvDesc), i32, i32, ctypes.c_char_p, sz]
+    L.v2ce_conv3d_variant_fused.restype = ctypes.c_int
     L.v2ce_preprocess_pairs.argtypes = [vp, i32, i32, i32, ctypes.c_float, ctypes.c_float, vp, vp]
     L.v2ce_preprocess_pairs.restype = ctypes.c_int
     L.v2ce_voxelize_events.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp]
@@ -125,7 +127,7 @@ def require_device_f32(t: torch.Tensor, name: str) -> torch.Tensor:
     return t.contiguous()
 
 
-def conv_variant(desc: ConvDesc, mapped: bool) -> str:
+def conv_variant(desc: ConvDesc, mapped: bool, fuse: int = 0) -> str:
     buf = ctypes.create_string_buffer(96)
-    check(lib().v2ce_conv3d_variant(ctypes.byref(desc), int(mapped), buf, 96), "v2ce_conv3d_variant")
+    check(lib().v2ce_conv3d_variant_fused(ctypes.byref(desc), int(mapped), int(fuse), buf, 96), "v2ce_conv3d_variant")
     return buf.value.decode()
