@@ -121,6 +121,24 @@ def bench_voxelize(args, device, rank, world):
         print(json.dumps(line))
 
 
+def self_launch(n_gpus: int) -> int:
+    """Run this script under torch.distributed.run with `n_gpus` ranks in a child process."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()                 # does not initialise the GPU runtime
+    if have < n_gpus:
+        print(f"bench.py: --gpus {n_gpus} but only {have} GPU(s) are visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL between processes on this driver)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,10 +154,16 @@ def main():
     ap.add_argument("--no-exact-f32", action="store_true", help="skip the extra exact-f32 measurement")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` outside torchrun: start the N ranks as CHILD processes (one per
+        # GPU, RCCL rendezvous on 127.0.0.1) before this process has made any GPU call, and exit
+        # with their code.  Rank 0 of the children prints the JSON line.
+        sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     device = torch.device(f"cuda:{local}")
     torch.cuda.set_device(device)
     if world > 1:

@@ -53,9 +53,10 @@ class DeviceEvents:
         out = torch.empty(max(n * 13, 4), dtype=torch.uint8, device=self.ts.device)
         if n:
             L = hip.lib()
-            hip.check(L.v2ce_events_pack(hip.ptr(self.ts), hip.ptr(self.x), hip.ptr(self.y),
-                                         hip.ptr(self.p), n, hip.ptr(out),
-                                         hip.stream_ptr(self.ts.device)), "v2ce_events_pack")
+            with torch.cuda.device(self.ts.device):
+                hip.check(L.v2ce_events_pack(hip.ptr(self.ts), hip.ptr(self.x), hip.ptr(self.y),
+                                             hip.ptr(self.p), n, hip.ptr(out),
+                                             hip.stream_ptr(self.ts.device)), "v2ce_events_pack")
         return out[: n * 13]
 
     def to_recarrays(self) -> List[np.recarray]:
@@ -90,6 +91,12 @@ def ldati_device(y: torch.Tensor, t0=0, fps=30, *, rng: str = "philox", seed: Op
     _check_fps(fps)
     if not y.is_cuda:
         raise hip.V2ceHipError("sample_voxel_statistical: y must be on a HIP device; no CPU path")
+    # the C ABI launches on the current device's stream: make y's device current for the call
+    with torch.cuda.device(y.device):
+        return _ldati_device(y, t0, fps, rng, seed, frame_base, uniforms, frame_ts_add, profile, path, strategy)
+
+
+def _ldati_device(y, t0, fps, rng, seed, frame_base, uniforms, frame_ts_add, profile, path, strategy):
     y = y.float().contiguous()                         # LDATI.py:143 `.float()`
     B, _, _, H, W = y.shape
     dev = y.device

@@ -57,9 +57,10 @@ def image_pre_processing_device(frames: torch.Tensor) -> torch.Tensor:
     frames = frames.contiguous()
     n, h, w = frames.shape
     units = torch.empty((n - 1, 2, h, w), dtype=torch.float32, device=frames.device)
-    hip.check(hip.lib().v2ce_preprocess_pairs(frames.data_ptr(), n, h, w, float(MEAN), float(STD),
-                                              units.data_ptr(), hip.stream_ptr(frames.device)),
-              "v2ce_preprocess_pairs")
+    with torch.cuda.device(frames.device):
+        hip.check(hip.lib().v2ce_preprocess_pairs(frames.data_ptr(), n, h, w, float(MEAN), float(STD),
+                                                  units.data_ptr(), hip.stream_ptr(frames.device)),
+                  "v2ce_preprocess_pairs")
     return units
 
 
@@ -138,8 +139,11 @@ def video_to_voxels(model, frames: Optional[np.ndarray] = None, read_frames=None
     out_width = width
     for seq_idx, start in enumerate(starts):
         images = np.asarray(read_frames(range(int(start), int(start) + seq_len + 1)))
-        if images.dtype == np.uint8 and images.shape[1] == height and str(device).startswith("cuda"):
-            # no resize needed: ship the u8 frames (4x fewer PCIe bytes) and normalise on the device
+        if (images.dtype == np.uint8 and images.shape[1] == height and str(device).startswith("cuda")
+                and int(images.shape[2] / images.shape[1] * height) == images.shape[2]):
+            # no resize needed (the reference's target width int(W/H*height), v2ce.py:57, can be W-1
+            # through float rounding even when H == height: those clips take the host path):
+            # ship the u8 frames (4x fewer PCIe bytes) and normalise on the device
             units = image_pre_processing_device(torch.from_numpy(images).to(device, non_blocking=True))
             pending.append(units[None])
         else:

@@ -141,7 +141,7 @@ def download_events(packed_list) -> np.ndarray:
         n = int(p.numel())
         host[off:off + n].copy_(p, non_blocking=True)
         off += n
-    torch.cuda.synchronize()
+    torch.cuda.synchronize(packed_list[0].device)
     return host.numpy().view(EVENT_DTYPE)
 
 
@@ -209,6 +209,9 @@ def main(argv=None):
         torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group("nccl")
+    elif str(device).startswith("cuda"):
+        # the C ABI launches on the current device's streams: make --device cuda:N the current one
+        torch.cuda.set_device(torch.device(device))
     sources = [args.image_folder, args.input_video_path, args.npy_frames, args.synthetic or None]
     assert sum(s is not None for s in sources) == 1, "specify exactly one frame source"
     if args.image_folder is not None:

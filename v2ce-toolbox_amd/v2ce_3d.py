@@ -367,8 +367,8 @@ class V2ce3d(nn.Module):
         """One power iteration + re-pack for all 12 spectral-norm layers (the trajectory does not depend
         on the input), enqueued on a side stream so that it overlaps the head conv and the four
         (non-SN) encoder blocks; `_await_sn` joins it in front of the first SN block."""
-        main = torch.cuda.current_stream()
         dev = self.UNet.head.conv3d.weight.device
+        main = torch.cuda.current_stream(dev)
         if getattr(self, "_sn_stream", None) is None or self._sn_stream.device != dev:
             self._sn_stream = torch.cuda.Stream(device=dev)
         side = self._sn_stream
@@ -385,7 +385,7 @@ class V2ce3d(nn.Module):
     def _await_sn(self):
         ev = getattr(self, "_sn_event", None)
         if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
+            torch.cuda.current_stream(self.UNet.head.conv3d.weight.device).wait_event(ev)
             self._sn_event = None
 
     @torch.no_grad()
@@ -393,6 +393,10 @@ class V2ce3d(nn.Module):
         """Apply the power iteration of one forward call to all 12 SN layers without running the
         convolutions (the u/v trajectory is input independent): used to fast-forward a replica to
         the global call index it emulates when calls are sharded over GPUs."""
+        with torch.cuda.device(self.UNet.head.conv3d.weight.device):
+            self._advance_spectral_norm()
+
+    def _advance_spectral_norm(self):
         if self._prep is None:
             self._prepare()
         for name, blocks in (("res", self.UNet.resblocks), ("dec", self.UNet.decoders)):
@@ -411,6 +415,12 @@ class V2ce3d(nn.Module):
         if x.dim() != 5 or x.shape[2] != self.in_channels:
             raise ValueError(f"expected x of shape [B,L,{self.in_channels},H,W], got {tuple(x.shape)}")
         x = hip.require_device_f32(x, "x")
+        # every launch below goes to the current stream of x's device through the C ABI: make that
+        # device current for the whole call (the ABI has no device argument, like a HIP stream call)
+        with torch.cuda.device(x.device):
+            return self._forward(x, return_intermediates)
+
+    def _forward(self, x, return_intermediates):
         if self._prep is None:
             self._prepare()
         P, U = self._prep, self.UNet

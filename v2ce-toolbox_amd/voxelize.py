@@ -51,9 +51,10 @@ def gen_discretized_event_volume(events: Union[np.ndarray, DeviceEvents, Sequenc
     bad = ((x < 0) | (x >= W) | (y < 0) | (y >= H)).any().to(torch.int64).reshape(1)
     vol = torch.empty((nb2, H, W), dtype=torch.float32, device=ts.device)
     rng = torch.empty(2, dtype=torch.int64, device=ts.device)
-    hip.check(hip.lib().v2ce_voxelize_events(ts.data_ptr(), x.data_ptr(), y.data_ptr(), p.data_ptr(), n, nb2 // 2,
-                                             H, W, vol.data_ptr(), rng.data_ptr(), hip.stream_ptr(ts.device)),
-              "v2ce_voxelize_events")
+    with torch.cuda.device(ts.device):
+        hip.check(hip.lib().v2ce_voxelize_events(ts.data_ptr(), x.data_ptr(), y.data_ptr(), p.data_ptr(), n, nb2 // 2,
+                                                 H, W, vol.data_ptr(), rng.data_ptr(), hip.stream_ptr(ts.device)),
+                  "v2ce_voxelize_events")
     t_min, t_max, is_bad = (int(v) for v in torch.cat([rng, bad]).tolist())
     if is_bad:
         raise AssertionError("gen_discretized_event_volume: event coordinates outside the volume")
