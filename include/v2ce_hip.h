@@ -47,49 +47,63 @@ const char *v2ce_last_error(void);
 /* ------------------------------------------------------------------------------------------------
  * Stage 2 -- LDATI.  Replaces scripts/LDATI.py:126-310 (sample_voxel_statistical, y_relocate,
  * calculate_statistical_linear_params_for_stage2, pick_elements, pick_and_sort) for the options the
- * CLI uses (v2ce.py:356: 'slope', pooling 'none', bidirectional=False).
+ * CLI uses (v2ce.py:356: 'slope', pooling 'none', bidirectional=False) and 'none'.
  * Two-phase, because the output length is data dependent:
- *   count -> (caller reads seg_counts, allocates) -> scan -> emit [-> pack]
+ *   count -> (caller reads seg_offsets + stats, allocates) -> emit
  * ---------------------------------------------------------------------------------------------- */
 
-/* Per-(frame, time-bin) event counts and the chunk-wide maximum count per voxel.
- * Replaces y_relocate (LDATI.py:80-106) + torch.max (LDATI.py:169) + the sizes implied by
+/* Per-(frame, time-bin) event counts, their exclusive prefix, and the statistics the caller needs to
+ * allocate.  Replaces y_relocate (LDATI.py:80-106) + torch.max (LDATI.py:169) + the sizes implied by
  * pick_elements' selections (LDATI.py:228,239).
- * vox [B,2,10,H,W] f32; seg_counts [B*9] i64 (overwritten); max_n [1] i32 (overwritten). */
-int v2ce_ldati_count(const float *vox, int B, int H, int W, int strategy, int64_t *seg_counts,
-                     int32_t *max_n, v2ce_stream_t stream);
+ * vox [B,2,10,H,W] f32.  seg_offsets [B*9+1] i64: exclusive prefix of the segment counts (last =
+ * total events).  stats [4] i64 = {max count of any voxel (LDATI.py:169 max_n), most events of one
+ * (2048-pixel tile, bin), largest segment, total events}.  tile_ws (>= v2ce_ldati_tile_ws_bytes):
+ * per-tile counts and offsets, consumed by v2ce_ldati_emit's two-level path. */
+size_t v2ce_ldati_tile_ws_bytes(int B, int H, int W);
+int v2ce_ldati_count(const float *vox, int B, int H, int W, int strategy, void *tile_ws,
+                     size_t tile_ws_bytes, int64_t *seg_offsets, int64_t *stats, v2ce_stream_t stream);
 
-/* Exclusive prefix sum of seg_counts -> seg_offsets [B*9+1] (last element = total events). */
-int v2ce_ldati_scan(const int64_t *seg_counts, int B, int64_t *seg_offsets, v2ce_stream_t stream);
-
-/* Bytes of LDS the emit kernel needs per workgroup for this fps/t0 (0 if unsupported). */
+/* Bytes of LDS the sweep (fallback) kernel needs per workgroup for this fps/t0; 0 = the key range
+ * of one time bin does not fit its LDS histogram (fps < ~12): only the two-level path runs then. */
 size_t v2ce_ldati_lds_bytes(double fps, double t0);
 
 /* Emit all events, each (frame, bin) segment stably sorted by timestamp, at seg_offsets.
  * Replaces LDATI.py:156-165 (single-event times), :171-212 (slope-distributed times) and
- * :217-310 (pick, concat negative-then-positive, sort by timestamp).  Tie order is the STABLE order
- * [neg singles row-major, neg multis row-major then draw, pos singles, pos multis] -- what the
- * reference's CPU argsort yields for segments >= 32768 events.
+ * :217-310 (pick, concat negative-then-positive, sort by timestamp, pack to 13-byte records).  Tie
+ * order is the STABLE order [neg singles row-major, neg multis row-major then draw, pos singles,
+ * pos multis] -- what the reference's CPU argsort yields for segments >= 32768 events.
  * uniforms/replay_max_n: REPLAY mode only.  frame_ts_add [B] i64 or NULL: added to every timestamp
- * of frame b (v2ce.py:365 per-frame offset, fused).  Outputs are SoA of length seg_offsets[B*9].
- * total_events / max_segment_events: host copies of seg_offsets[B*9] and of the largest segment
- * count (the caller has read them to allocate).  workspace (>= v2ce_ldati_workspace_bytes) selects
- * the bucketed path (pixel-parallel recompute -> coarse buckets -> LDS sort -> coalesced output);
- * workspace NULL runs the one-workgroup-per-segment sweep for every segment (no scratch, slower).
- * Both produce bit-identical output. */
+ * of frame b (v2ce.py:365 per-frame offset, fused).
+ * Output: either the four SoA arrays (ts, x, y, p; length seg_offsets[B*9]) or `packed` (13-byte
+ * records {i8 timestamp, i2 x, i2 y, i1 polarity} = the numpy recarray layout of LDATI.py:308-309,
+ * 4-byte aligned, total*13 bytes); the other must be NULL.
+ * total_events / max_segment_events / max_tile_events: host copies of stats[3], [2], [1].
+ * workspace (>= v2ce_ldati_workspace_bytes, which returns 0 when shape or density is outside the
+ * path: > 512 tiles per frame, > 15360 events in one tile-bin) + the tile_ws of v2ce_ldati_count
+ * select the two-level path (tile pass -> coarse buckets -> LDS counting sort -> coalesced output);
+ * workspace NULL runs the one-workgroup-per-segment sweep for every segment (no scratch, slower,
+ * needs v2ce_ldati_lds_bytes != 0).  Both produce bit-identical output.  Segments with a coarse
+ * bucket beyond the LDS capacity (degenerate ties) go to the sweep kernel inside the same call; if
+ * the sweep cannot hold this fps either, the device status word (v2ce_ldati_status) becomes 1. */
 size_t v2ce_ldati_workspace_bytes(int B, int H, int W, double fps, double t0, int64_t total_events,
-                                  int64_t max_segment_events);
+                                  int64_t max_segment_events, int64_t max_tile_events);
 int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps, double t0, int strategy, int rng_mode,
                     const float *uniforms, int replay_max_n, uint64_t seed, int64_t frame_base,
                     const int64_t *seg_offsets, const int64_t *frame_ts_add, int64_t *ts,
-                    int16_t *x, int16_t *y, int8_t *p, int64_t total_events,
-                    int64_t max_segment_events, void *workspace, size_t workspace_bytes,
-                    v2ce_stream_t stream);
+                    int16_t *x, int16_t *y, int8_t *p, uint8_t *packed, int64_t total_events,
+                    int64_t max_segment_events, int64_t max_tile_events, const void *tile_ws,
+                    void *workspace, size_t workspace_bytes, v2ce_stream_t stream);
+/* Device address of the status word (int32) inside a workspace used with the same arguments. */
+int v2ce_ldati_status(const void *workspace, int B, int H, int W, double fps, double t0,
+                      int64_t total_events, int64_t max_segment_events, int64_t max_tile_events,
+                      const int32_t **status_dev);
 
-/* SoA -> packed 13-byte records {i8 timestamp, i2 x, i2 y, i1 polarity}: the numpy recarray layout
+/* SoA <-> packed 13-byte records {i8 timestamp, i2 x, i2 y, i1 polarity}: the numpy recarray layout
  * of LDATI.py:308-309 (numpy.core.records.fromarrays, itemsize 13).  packed: n*13 bytes. */
 int v2ce_events_pack(const int64_t *ts, const int16_t *x, const int16_t *y, const int8_t *p,
                      int64_t n, uint8_t *packed, v2ce_stream_t stream);
+int v2ce_events_unpack(const uint8_t *packed, int64_t n, int64_t *ts, int16_t *x, int16_t *y, int8_t *p,
+                       v2ce_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Frame ingest.  Replaces v2ce.py:45-64 (image_pre_processing) for frames already at the target

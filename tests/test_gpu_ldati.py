@@ -14,14 +14,15 @@ pytestmark = pytest.mark.gpu
 
 
 def hip_events(vox, fps=30, t0=0, uniforms=None, seed=None, frame_base=0, frame_ts_add=None, path="bucket",
-               strategy="slope"):
+               strategy="slope", layout="packed"):
     from v2ce_toolbox_amd.LDATI import ldati_device
     y = torch.from_numpy(np.ascontiguousarray(vox)).cuda()
     u = None if uniforms is None else torch.from_numpy(np.ascontiguousarray(uniforms)).cuda()
     add = None if frame_ts_add is None else torch.from_numpy(frame_ts_add).cuda()
     ev = ldati_device(y, t0=t0, fps=fps, uniforms=u, seed=seed, frame_base=frame_base, frame_ts_add=add,
-                      path=path, strategy=strategy)
+                      path=path, strategy=strategy, layout=layout)
     torch.cuda.synchronize()
+    ev.check()
     return ev
 
 
@@ -89,9 +90,41 @@ def test_philox_matches_oracle(shape, regime, fps, t0, fb):
     B, H, W = shape
     vox = synth.synthetic_voxels(B, H, W, seed=B * 1000 + H, regime=regime)
     want = O.emit_soa(vox, fps=fps, t0=t0, seed=0xDEADBEEF12345, frame_base=fb)
-    for path in ("bucket", "sweep"):
-        ev = hip_events(vox, fps, t0, seed=0xDEADBEEF12345, frame_base=fb, path=path)
+    for path, layout in (("bucket", "packed"), ("bucket", "soa"), ("sweep", "soa"), ("sweep", "packed")):
+        ev = hip_events(vox, fps, t0, seed=0xDEADBEEF12345, frame_base=fb, path=path, layout=layout)
         soa_equal(ev, *want)
+
+
+@pytest.mark.parametrize("shape,regime,fps", [((2, 40, 50), "stress", 10), ((1, 64, 64), "sparse", 5),
+                                               ((2, 30, 41), "stress", 1)])
+def test_low_fps_two_level_path(shape, regime, fps):
+    """fps below ~12: a time bin spans more microsecond keys than the sweep kernel's LDS histogram
+    holds (round 1 rejected these); the two-level path covers them (reference CLI accepts any fps)."""
+    from v2ce_toolbox_amd import hip
+    B, H, W = shape
+    assert hip.lib().v2ce_ldati_lds_bytes(float(fps), 0.0) == 0
+    vox = synth.synthetic_voxels(B, H, W, seed=fps, regime=regime)
+    want = O.emit_soa(vox, fps=fps, seed=77, frame_base=3)
+    for layout in ("packed", "soa"):
+        soa_equal(hip_events(vox, fps, seed=77, frame_base=3, layout=layout), *want)
+
+
+def test_pano_width_and_many_tiles():
+    """1384-wide frames (BASELINE config 4: 352 tiles per frame) and a ragged last tile."""
+    vox = synth.synthetic_voxels(1, 260, 1384, seed=3, regime="sparse")
+    soa_equal(hip_events(vox, seed=11), *O.emit_soa(vox, seed=11))
+    vox = synth.synthetic_voxels(2, 37, 167, seed=4, regime="stress")        # 6179 px: 3 full tiles + 35
+    soa_equal(hip_events(vox, seed=12, frame_base=9), *O.emit_soa(vox, seed=12, frame_base=9))
+
+
+def test_dense_tile_falls_back_to_sweep():
+    """More events in one (tile, bin) than the tile pass holds in LDS: no two-level plan, the whole
+    call takes the sweep kernel (bit-identical)."""
+    vox = np.zeros((1, 2, 10, 50, 60), np.float32)
+    vox[0, 0, 2] = 9.3                                            # 3000 px x 9.3 -> > 15360 events in a tile-bin
+    vox[0, 1, 5, :7] = 1.7
+    want = O.emit_soa(vox, seed=21)
+    soa_equal(hip_events(vox, seed=21), *want)
 
 
 def test_degenerate_ties_take_the_sweep_fallback():

@@ -19,6 +19,7 @@ Differences from the reference, all deliberate (DESIGN.md "Stage 2"):
 """
 from __future__ import annotations
 
+import ctypes
 import math
 from typing import List, Optional
 
@@ -32,35 +33,72 @@ assert EVENT_DTYPE.itemsize == 13
 
 
 class DeviceEvents:
-    """Events of one LDATI call, resident on the device (SoA) + host-side segment table."""
+    """Events of one LDATI call, resident on the device as packed 13-byte records (the numpy record
+    layout of LDATI.py:308) + the host-side segment table.  ``ts`` / ``x`` / ``y`` / ``p`` are SoA
+    views materialised on first use (``v2ce_events_unpack``)."""
 
-    def __init__(self, ts, x, y, p, seg_counts, max_n):
-        self.ts, self.x, self.y, self.p = ts, x, y, p
+    def __init__(self, packed, seg_counts, max_n, soa=None):
+        self._packed = packed                   # uint8 [N*13] device tensor (or None when soa is given)
+        self._soa = soa                         # (ts i64, x i16, y i16, p i8) device tensors
         self.seg_counts = seg_counts            # np.int64 [B, 9]
         self.max_n = max_n
+        self._status = None                     # device int32[1]: see check()
 
     @property
     def num_events(self) -> int:
-        return int(self.ts.shape[0])
+        return int(self.seg_counts.sum())
 
     @property
     def frame_counts(self) -> np.ndarray:
         return self.seg_counts.sum(axis=1)
 
+    @property
+    def device(self):
+        return (self._packed if self._packed is not None else self._soa[0]).device
+
+    def _unpacked(self):
+        if self._soa is None:
+            n, dev = self.num_events, self._packed.device
+            ts = torch.empty(n, dtype=torch.int64, device=dev)
+            x = torch.empty(n, dtype=torch.int16, device=dev)
+            y = torch.empty(n, dtype=torch.int16, device=dev)
+            p = torch.empty(n, dtype=torch.int8, device=dev)
+            if n:
+                with torch.cuda.device(dev):
+                    hip.check(hip.lib().v2ce_events_unpack(self._packed.data_ptr(), n, ts.data_ptr(), x.data_ptr(),
+                                                           y.data_ptr(), p.data_ptr(), hip.stream_ptr(dev)),
+                              "v2ce_events_unpack")
+            self._soa = (ts, x, y, p)
+        return self._soa
+
+    ts = property(lambda self: self._unpacked()[0])
+    x = property(lambda self: self._unpacked()[1])
+    y = property(lambda self: self._unpacked()[2])
+    p = property(lambda self: self._unpacked()[3])
+
     def packed(self) -> torch.Tensor:
         """uint8 [N*13] device tensor of packed records (LDATI.py:308 dtype)."""
-        n = self.num_events
-        out = torch.empty(max(n * 13, 4), dtype=torch.uint8, device=self.ts.device)
-        if n:
-            L = hip.lib()
-            with torch.cuda.device(self.ts.device):
-                hip.check(L.v2ce_events_pack(hip.ptr(self.ts), hip.ptr(self.x), hip.ptr(self.y),
-                                             hip.ptr(self.p), n, hip.ptr(out),
-                                             hip.stream_ptr(self.ts.device)), "v2ce_events_pack")
-        return out[: n * 13]
+        if self._packed is None:
+            ts, x, y, p = self._soa
+            n = self.num_events
+            out = torch.empty(max(n * 13, 4), dtype=torch.uint8, device=ts.device)
+            if n:
+                with torch.cuda.device(ts.device):
+                    hip.check(hip.lib().v2ce_events_pack(ts.data_ptr(), x.data_ptr(), y.data_ptr(), p.data_ptr(), n,
+                                                         out.data_ptr(), hip.stream_ptr(ts.device)), "v2ce_events_pack")
+            self._packed = out[: n * 13]
+        return self._packed
+
+    def check(self) -> None:
+        """Raise if the device reported a segment it could not order (a coarse bucket beyond the LDS
+        capacity at an fps whose key range the sweep fallback cannot hold).  Synchronises."""
+        if self._status is not None and int(self._status.item()) != 0:
+            raise hip.V2ceHipError("LDATI: a (frame, bin) segment has more equal-time events than the LDS sort "
+                                   "holds and the key range of this fps exceeds the sweep kernel's histogram")
 
     def to_recarrays(self) -> List[np.recarray]:
         ev = np.ascontiguousarray(self.packed().cpu().numpy()).view(EVENT_DTYPE)
+        self.check()
         out, lo = [], 0
         for n in self.frame_counts:
             out.append(ev[lo:lo + int(n)].copy().view(np.recarray))
@@ -77,95 +115,139 @@ def _check_fps(fps) -> None:
                            f"does not have 9 elements (reference LDATI.py:163 raises as well)")
 
 
-def ldati_device(y: torch.Tensor, t0=0, fps=30, *, rng: str = "philox", seed: Optional[int] = None,
-                 frame_base: int = 0, uniforms: Optional[torch.Tensor] = None,
-                 frame_ts_add: Optional[torch.Tensor] = None, profile: Optional[list] = None,
-                 path: str = "bucket", strategy: str = "slope") -> DeviceEvents:
-    """Run count -> scan -> emit on the device and leave the events there.
+class PendingLdati:
+    """An LDATI call whose count phase is enqueued (``ldati_begin``).  ``finish()`` waits for the
+    segment table -- the one host synchronisation inherent to a variable-length output --, allocates
+    and enqueues the emit phase.  Splitting the call lets a caller enqueue other GPU work (the next
+    batch's UNet) before it blocks on the counts."""
 
-    y: [B,2,10,H,W] on a HIP device.  One host synchronisation (reading the B*9+1 segment offsets
-    and max_n) is inherent to the variable-length output.
-    """
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+    def finish(self) -> DeviceEvents:
+        with torch.cuda.device(self.y.device):
+            return _ldati_finish(self)
+
+
+def ldati_begin(y: torch.Tensor, t0=0, fps=30, *, rng: str = "philox", seed: Optional[int] = None,
+                frame_base: int = 0, uniforms: Optional[torch.Tensor] = None,
+                frame_ts_add: Optional[torch.Tensor] = None, profile: Optional[list] = None,
+                path: str = "bucket", strategy: str = "slope", layout: str = "packed") -> PendingLdati:
+    """Enqueue the count phase of LDATI on y [B,2,10,H,W] (HIP device) and start the asynchronous
+    copy of the segment table to pinned host memory."""
     if y.dim() != 5 or y.shape[1] != 2 or y.shape[2] != 10:
         raise ValueError(f"expected y of shape [B,2,10,H,W], got {tuple(y.shape)}")
     _check_fps(fps)
     if not y.is_cuda:
         raise hip.V2ceHipError("sample_voxel_statistical: y must be on a HIP device; no CPU path")
+    if path not in ("bucket", "sweep"):
+        raise ValueError(f"path must be 'bucket' or 'sweep', got {path!r}")
+    if layout not in ("packed", "soa"):
+        raise ValueError(f"layout must be 'packed' or 'soa', got {layout!r}")
+    if rng not in ("philox", "torch"):
+        raise ValueError(f"rng must be 'philox' or 'torch', got {rng!r}")
     # the C ABI launches on the current device's stream: make y's device current for the call
     with torch.cuda.device(y.device):
-        return _ldati_device(y, t0, fps, rng, seed, frame_base, uniforms, frame_ts_add, profile, path, strategy)
+        y = y.float().contiguous()                     # LDATI.py:143 `.float()`
+        B, _, _, H, W = y.shape
+        dev = y.device
+        L = hip.lib()
+        st = hip.stream_ptr(dev)
+        if path == "sweep" and L.v2ce_ldati_lds_bytes(float(fps), float(t0)) == 0:
+            raise hip.V2ceHipError(f"fps={fps}, t0={t0}: time bin too wide for the sweep kernel's LDS key histogram")
+        strat = {"slope": hip.STRATEGY_SLOPE, "none": hip.STRATEGY_NONE}[strategy]
+        tile_ws = torch.empty(L.v2ce_ldati_tile_ws_bytes(B, H, W), dtype=torch.uint8, device=dev)
+        meta = torch.empty(B * 9 + 1 + 4, dtype=torch.int64, device=dev)       # seg_offsets | stats
+        hip.check(L.v2ce_ldati_count(y.data_ptr(), B, H, W, strat, tile_ws.data_ptr(), tile_ws.numel(),
+                                     meta.data_ptr(), meta[B * 9 + 1:].data_ptr(), st), "v2ce_ldati_count")
+        host = torch.empty(meta.shape, dtype=torch.int64, pin_memory=True)
+        host.copy_(meta, non_blocking=True)
+        ready = torch.cuda.Event()
+        ready.record()
+    return PendingLdati(y=y, t0=t0, fps=fps, rng=rng, seed=seed, frame_base=frame_base, uniforms=uniforms,
+                        frame_ts_add=frame_ts_add, profile=profile, path=path, strat=strat, layout=layout,
+                        tile_ws=tile_ws, meta=meta, host=host, ready=ready)
 
 
-def _ldati_device(y, t0, fps, rng, seed, frame_base, uniforms, frame_ts_add, profile, path, strategy):
-    y = y.float().contiguous()                         # LDATI.py:143 `.float()`
+def _ldati_finish(q: PendingLdati) -> DeviceEvents:
+    y, fps, t0 = q.y, q.fps, q.t0
     B, _, _, H, W = y.shape
     dev = y.device
     L = hip.lib()
     st = hip.stream_ptr(dev)
-    if L.v2ce_ldati_lds_bytes(float(fps), float(t0)) == 0:
-        raise hip.V2ceHipError(f"fps={fps}, t0={t0}: time bin too wide for the LDS key histogram")
-    seg_counts = torch.empty(B * 9, dtype=torch.int64, device=dev)
-    max_n_t = torch.empty(1, dtype=torch.int32, device=dev)
-    offsets = torch.empty(B * 9 + 2, dtype=torch.int64, device=dev)
-    strat = {"slope": hip.STRATEGY_SLOPE, "none": hip.STRATEGY_NONE}[strategy]
-    hip.check(L.v2ce_ldati_count(y.data_ptr(), B, H, W, strat, seg_counts.data_ptr(), max_n_t.data_ptr(), st),
-              "v2ce_ldati_count")
-    hip.check(L.v2ce_ldati_scan(seg_counts.data_ptr(), B, offsets.data_ptr(), st), "v2ce_ldati_scan")
-    offsets[B * 9 + 1:] = max_n_t.to(torch.int64)
-    host = offsets.cpu().numpy()                       # the one sync
-    offs, max_n = host[:B * 9 + 1], int(host[B * 9 + 1])
-    total = int(offs[-1])
+    q.ready.synchronize()                              # the one sync
+    host = q.host.numpy()
+    offs = host[:B * 9 + 1]
+    max_n, max_tile, max_seg, total = (int(v) for v in host[B * 9 + 1:])
     segc = np.diff(offs).reshape(B, 9)
 
     mode, u_ptr, replay_max_n = hip.RNG_PHILOX, None, 0
-    keep = None
+    keep, seed, uniforms = None, q.seed, q.uniforms
     if uniforms is not None:
         uniforms = hip.require_device_f32(uniforms.to(dev), "uniforms")
         if tuple(uniforms.shape[:5]) != (B, 2, 9, H, W) or uniforms.shape[5] < max_n:
             raise ValueError(f"uniforms must be [B,2,9,H,W,>=max_n={max_n}], got {tuple(uniforms.shape)}")
         mode, u_ptr, replay_max_n, keep = hip.RNG_REPLAY, uniforms.data_ptr(), uniforms.shape[5], uniforms
-    elif rng == "torch":
+    elif q.rng == "torch":
         keep = torch.rand([B, 2, 9, H, W, max_n], device=dev)      # LDATI.py:171
         mode, u_ptr, replay_max_n = hip.RNG_REPLAY, keep.data_ptr(), max_n
-    elif rng == "philox":
-        if seed is None:   # reproducible under torch.manual_seed, like the reference's draw
-            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
-    else:
-        raise ValueError(f"rng must be 'philox' or 'torch', got {rng!r}")
+    elif seed is None:     # reproducible under torch.manual_seed, like the reference's draw
+        seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
 
-    ts = torch.empty(total, dtype=torch.int64, device=dev)
-    x = torch.empty(total, dtype=torch.int16, device=dev)
-    yy = torch.empty(total, dtype=torch.int16, device=dev)
-    p = torch.empty(total, dtype=torch.int8, device=dev)
+    packed = soa = None
+    ptrs = [None] * 5
+    if q.layout == "packed":
+        packed = torch.empty(max(total * 13, 4), dtype=torch.uint8, device=dev)
+        ptrs[4] = packed.data_ptr()
+    else:
+        soa = (torch.empty(total, dtype=torch.int64, device=dev), torch.empty(total, dtype=torch.int16, device=dev),
+               torch.empty(total, dtype=torch.int16, device=dev), torch.empty(total, dtype=torch.int8, device=dev))
+        ptrs[:4] = [t.data_ptr() for t in soa]
+    ev = DeviceEvents(None if packed is None else packed[: total * 13], segc, max_n, soa)
+    frame_ts_add = q.frame_ts_add
+    ws = None
     if total:
         add_ptr = None
         if frame_ts_add is not None:
             frame_ts_add = frame_ts_add.to(device=dev, dtype=torch.int64).contiguous()
             assert frame_ts_add.numel() == B
             add_ptr = frame_ts_add.data_ptr()
-        max_seg = int(segc.max())
-        ws, ws_bytes = None, 0
-        if path == "bucket":       # pixel-parallel bucketed path; "sweep" = one workgroup per segment
-            ws_bytes = L.v2ce_ldati_workspace_bytes(B, H, W, float(fps), float(t0), total, max_seg)
+        ws_bytes = 0
+        if q.path == "bucket":     # two-level path; "sweep" = one workgroup per segment
+            ws_bytes = L.v2ce_ldati_workspace_bytes(B, H, W, float(fps), float(t0), total, max_seg, max_tile)
             if ws_bytes:
                 ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        elif path != "sweep":
-            raise ValueError(f"path must be 'bucket' or 'sweep', got {path!r}")
-        if profile is not None:    # HIP events on the launch stream around the emit kernels
+            elif L.v2ce_ldati_lds_bytes(float(fps), float(t0)) == 0:
+                raise hip.V2ceHipError(f"LDATI: fps={fps}, t0={t0}, {H}x{W}, {max_tile} events in one tile-bin: outside "
+                                       "both the two-level path and the sweep kernel")
+        if q.profile is not None:    # HIP events on the launch stream around the emit kernels
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        hip.check(L.v2ce_ldati_emit(y.data_ptr(), B, H, W, float(fps), float(t0), strat, mode, u_ptr,
-                                    int(replay_max_n), int(seed or 0) & (2 ** 64 - 1), int(frame_base),
-                                    offsets.data_ptr(), add_ptr, ts.data_ptr(), x.data_ptr(),
-                                    yy.data_ptr(), p.data_ptr(), total, max_seg, hip.ptr(ws),
-                                    int(ws_bytes), st), "v2ce_ldati_emit")
-        if profile is not None:
+        hip.check(L.v2ce_ldati_emit(y.data_ptr(), B, H, W, float(fps), float(t0), q.strat, mode, u_ptr,
+                                    int(replay_max_n), int(seed or 0) & (2 ** 64 - 1), int(q.frame_base),
+                                    q.meta.data_ptr(), add_ptr, ptrs[0], ptrs[1], ptrs[2], ptrs[3], ptrs[4],
+                                    total, max_seg, max_tile, q.tile_ws.data_ptr(), hip.ptr(ws), int(ws_bytes), st),
+                  "v2ce_ldati_emit")
+        if q.profile is not None:
             e1.record()
             # algorithmic bytes (SURVEY 8d): 80 B per pixel read once + 13 B per event written once
-            profile.append(("emit", e0, e1, 80 * B * H * W + 13 * total))
-    ev = DeviceEvents(ts, x, yy, p, segc, max_n)
-    ev._keepalive = (y, keep, frame_ts_add, offsets, ws if total else None)
+            q.profile.append(("emit", e0, e1, 80 * B * H * W + 13 * total))
+        if ws is not None:
+            sp = ctypes.c_void_p()
+            hip.check(L.v2ce_ldati_status(ws.data_ptr(), B, H, W, float(fps), float(t0), total, max_seg, max_tile,
+                                          ctypes.byref(sp)), "v2ce_ldati_status")
+            off = (sp.value - ws.data_ptr())
+            ev._status = ws[off:off + 4].view(torch.int32)
+    ev._keepalive = (y, keep, frame_ts_add, q.meta, q.tile_ws, ws)
     return ev
+
+
+def ldati_device(y: torch.Tensor, t0=0, fps=30, **kw) -> DeviceEvents:
+    """Run count -> emit on the device and leave the events there (``ldati_begin(...).finish()``).
+
+    y: [B,2,10,H,W] on a HIP device.  One host synchronisation (reading the B*9+1 segment offsets
+    and the allocation statistics) is inherent to the variable-length output."""
+    return ldati_begin(y, t0, fps, **kw).finish()
 
 
 def sample_voxel_statistical(y, t0=0, fps=30, pooling_type="none", pooling_kernel_size=3,

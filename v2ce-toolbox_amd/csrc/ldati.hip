@@ -3,23 +3,30 @@
 // Replaces /root/reference/scripts/LDATI.py:80-106 (y_relocate), :13-51 (slope), :126-214
 // (sample_voxel_statistical) and :217-310 (pick_elements / pick_and_sort).
 //
-// Design (DESIGN.md "Stage 2"): nothing of size O(voxels x max_n) or O(events) is materialised
-// except the final output.  Because every timestamp is a pure function of (voxel column, draw
-// index) -- counter-based Philox, or a replayed uniform tensor -- it is RECOMPUTED wherever it is
-// needed instead of being stored, sorted and gathered:
+// Design.  Every timestamp is a pure function of (voxel column, draw index) --
+// counter-based Philox, or a replayed uniform tensor.  The reference's output order inside a
+// (frame, bin) SEGMENT is the stable sort by timestamp of [neg singles, neg multis, pos singles,
+// pos multis], each listed pixel-row-major; i.e. the order of the key (timestamp, category, pixel).
+// Two-level counting sort with the pixel order kept BY CONSTRUCTION, so no pass ever sorts on the
+// pixel bits:
 //
-//   v2ce_ldati_count : thread per (frame, polarity, pixel); 9-step relocation recurrence in
-//                      registers; per-(frame,bin) totals by wave reduce + one atomic per block.
-//   v2ce_ldati_emit  : one workgroup per (frame, bin) SEGMENT = one stable counting sort with the
-//                      whole key histogram in LDS (a bin spans ~1e6/fps/9 = 3704 distinct
-//                      microsecond keys at 30 fps).  4 waves = the 4 tie-order categories
-//                      [neg single, neg multi, pos single, pos multi]:
-//                        A. histogram  cnt[cat][key] += 1          (LDS atomics, order free)
-//                        B. exclusive scan in (key-major, category-minor) order = stable ranks
-//                        C. replay the same events in pixel order; the rank of an event among the
-//                           equal-key events of ITS wave batch comes from a ballot "match-any"
-//                           (wave64), the running base from LDS; scatter straight to the final
-//                           sorted position.  No global scratch, no sort passes over records.
+//   count      : workgroup per (frame, polarity, 2048-pixel TILE): relocation recurrence in
+//                registers -> events per (tile, bin); one tiny scan kernel -> per-tile record
+//                offsets, segment offsets, statistics the host needs to allocate.
+//   tile pass  : workgroup per tile, bin by bin.  Timestamps are computed ONCE: singles and
+//                4-draw multi-event UNITS are compacted so that every lane of the f64 / Philox +
+//                sqrt / divide code does useful work; the records land in LDS in pixel order.  A
+//                stable counting sort on the COARSE key (timestamp >> shift; per-wave histograms +
+//                ballot match-any ranks -- deterministic, no atomics decide an order) groups them
+//                by bucket, and the tile's 4-byte records leave as ONE contiguous, coalesced run
+//                per bin.
+//   bucket scan: per segment, bucket totals over the tiles -> output offsets.
+//   bucket sort: workgroup per (segment, bucket): gathers the tiles' runs in tile order (= pixel
+//                order), one stable counting sort on (fine key, category) in LDS, and writes the
+//                final 13-byte packed records (or SoA) as full coalesced lines.
+//   sweep      : the v1 kernel (one workgroup per segment, whole key histogram in LDS) remains the
+//                fallback for segments with a bucket beyond the LDS capacity (degenerate ties) and
+//                for workspace == NULL; both paths are bit-identical.
 //
 // Arithmetic is bit-exact w.r.t. the CPU reference: every f32/f64 operation is a separate IEEE
 // operation (-ffp-contract=off, correctly rounded '/' and sqrt), in the reference's order.
@@ -29,6 +36,17 @@
 
 namespace v2ce {
 namespace {
+
+constexpr int kTilePix = 2048;        // pixels of one polarity plane per tile
+constexpr int kTileThreads = 512;     // 4 consecutive pixels per thread
+constexpr int kPixPerThread = kTilePix / kTileThreads;
+constexpr int kLocalBits = 11;        // log2(kTilePix)
+constexpr int kMaxTiles = 512;        // tiles per frame (both polarities) the bucket sort indexes
+constexpr int kMaxNB = 512;           // coarse buckets per segment
+constexpr int kMaxShift = 8;          // fine-key bits
+constexpr int kCapTile = 15360;       // events of one (tile, bin) the tile pass can hold in LDS
+constexpr int kSortThreads = 512;
+constexpr int kSortWaves = kSortThreads / 64;
 
 struct LdatiParams {
     const float *vox;
@@ -47,40 +65,52 @@ struct LdatiParams {
     long long frame_base;
     const long long *seg_offsets;
     const long long *frame_ts_add;
-    long long *ts;
+    long long *ts;                // SoA outputs (all four or none)
     short *x;
     short *y;
     signed char *p;
-    // bucketed path (v2): coarse bucket = key >> key_shift; NB buckets per segment
-    int key_shift, NB, PB;        // PB = bits of a pixel index
-    unsigned *cbcount;            // [B*9][NB] events per bucket
-    unsigned *cursor;             // [B*9][NB] append cursors
-    unsigned *bofs;               // [B*9][NB] exclusive offsets inside the segment
-    unsigned *wgtab;              // [B][wg_per_frame][9*NB] per-workgroup bucket counts -> offsets
-    int wg_per_frame, blk_per_pol;
-    unsigned *temp;               // [total events] unsorted 32-bit records (fine key | category | pixel)
-    int *seg_flag;                // [B*9] 1 = a bucket exceeds the LDS sort capacity -> segment sweep path
+    unsigned char *packed;        // or 13-byte packed records
+    // two-level path
+    int shift, NB, nb1;           // coarse bucket = key >> shift; nb1 = bits of a bucket index
+    int T, tpp;                   // tiles per frame (2*tpp), tiles per polarity plane
+    int PB;                       // bits of a pixel index
+    int capA, cap2;               // LDS capacities (records) of the tile pass / the bucket sort
+    const unsigned *tile_off;     // [B][T][9] exclusive prefix of the tile counts inside the segment
+    unsigned *cntT;               // [B*9][NB][T] records of tile t in the bucket
+    unsigned *runoff;             // [B*9][NB][T] start of that run inside the tile's region
+    unsigned *btot;               // [B*9][NB]
+    unsigned *bofs;               // [B*9][NB] exclusive prefix inside the segment
+    unsigned *temp;               // [total events] 4-byte records (fine | multi | local pixel)
+    int *seg_flag;                // [B*9] 1 = a bucket exceeds cap2 -> segment goes to the sweep kernel
+    int *status;                  // [1] != 0: a flagged segment could not be swept (NK too large)
+    int sweep_ok;
 };
 
-constexpr int kSortCap = 8192;    // 32-bit records one workgroup sorts in LDS
-
 // ---- Philox4x32-10, counter (pixel, j>>2, p*9+c, frame), key = seed ---------------------------
-__device__ __forceinline__ float philox_uniform(unsigned long long seed, unsigned pixel, unsigned j,
-                                                unsigned pc, unsigned frame) {
-    unsigned c0 = pixel, c1 = j >> 2, c2 = pc, c3 = frame;
+__device__ __forceinline__ void philox4(unsigned long long seed, unsigned pixel, unsigned jb,
+                                        unsigned pc, unsigned frame, unsigned (&out)[4]) {
+    unsigned c0 = pixel, c1 = jb, c2 = pc, c3 = frame;
     unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
-        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+        c0 = n0; c1 = (unsigned)p1; c2 = n2; c3 = (unsigned)p0;
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
     }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ float u24(unsigned w) { return (float)(w >> 8) * (1.0f / 16777216.0f); }
+
+__device__ __forceinline__ float philox_uniform(unsigned long long seed, unsigned pixel, unsigned j,
+                                                unsigned pc, unsigned frame) {
+    unsigned o[4];
+    philox4(seed, pixel, j >> 2, pc, frame, o);
     const unsigned sel = j & 3u;
-    const unsigned w = sel == 0 ? c0 : sel == 1 ? c1 : sel == 2 ? c2 : c3;
-    return (float)(w >> 8) * (1.0f / 16777216.0f);
+    return u24(sel == 0 ? o[0] : sel == 1 ? o[1] : sel == 2 ? o[2] : o[3]);
 }
 
 // ---- relocation recurrence (LDATI.py:94-106) up to bin `last` ----------------------------------
@@ -167,41 +197,84 @@ __device__ __forceinline__ unsigned long long match_key(bool has, int key, int n
     return peers;
 }
 
-// ---------------------------------------------------------------------------------------------
-// count kernel
-// ---------------------------------------------------------------------------------------------
-constexpr int kCountPixPerBlock = 4096;   // 16 pixels per thread: 16x fewer (contended) atomics
+__device__ __forceinline__ void store_packed_bytes(unsigned char *dst, long long t, unsigned xx,
+                                                   unsigned yy, unsigned pp) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dst[k] = (unsigned char)((unsigned long long)t >> (8 * k));
+    dst[8] = (unsigned char)xx; dst[9] = (unsigned char)(xx >> 8);
+    dst[10] = (unsigned char)yy; dst[11] = (unsigned char)(yy >> 8);
+    dst[12] = (unsigned char)pp;
+}
 
-__global__ __launch_bounds__(256) void ldati_count_kernel(const float *__restrict__ vox, int HW,
-                                                          unsigned long long *seg_counts,
-                                                          int *max_n, int strategy) {
-    // grid: (pixel blocks, 2*B)
-    const int bp = blockIdx.y;           // b*2 + p
-    const int b = bp >> 1;
-    const float *plane0 = vox + (long long)bp * 10 * HW;
+// inclusive scan over the 64 lanes of a wave
+__device__ __forceinline__ unsigned wave_incl_scan(unsigned v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// exclusive scan of one value per thread over a workgroup of NW waves; `part` = NW+1 LDS words.
+// Returns the exclusive prefix; *total = sum over the workgroup.  Two barriers.
+template <int NW>
+__device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned *part, unsigned *total) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const unsigned incl = wave_incl_scan(v, lane);
+    if (lane == 63) part[wid] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned run = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const unsigned t = part[i];
+            part[i] = run;
+            run += t;
+        }
+        part[NW] = run;
+    }
+    __syncthreads();
+    *total = part[NW];
+    return part[wid] + incl - v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// count: workgroup per (frame, tile); events per (tile, bin); max count per voxel
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kTileThreads) void ldati_count_tiles_kernel(
+    const float *__restrict__ vox, int HW, int tpp, int strategy, unsigned *__restrict__ tc,
+    unsigned long long *stats) {
+    const int t = blockIdx.x, b = blockIdx.y, T = 2 * tpp;
+    const int pidx = t < tpp ? 1 : 0;                 // negative tiles first (LDATI.py:289)
+    const int x0 = (t < tpp ? t : t - tpp) * kTilePix;
+    const float *plane0 = vox + (long long)(b * 2 + pidx) * 10 * HW;
     int cnt[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) cnt[i] = 0;
     int mx = 0;
-    for (int it = 0; it < kCountPixPerBlock / 256; ++it) {
-        const int px = blockIdx.x * kCountPixPerBlock + it * 256 + threadIdx.x;
-        if (px >= HW) break;
-        float yv[10];
-        load_bins(plane0, HW, px, true, 8, yv);
-        const float eps = 1e-6f;
-        float d = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            const float r = yv[i] - d;
-            const float cc = ceilf(r - eps);
-            d = cc - r;
-            int ni = (int)cc;
-            if (i == 8) ni += (int)(yv[9] - d);
-            cnt[i] += (strategy == V2CE_STRATEGY_NONE) ? (ni == 1) : (ni > 0 ? ni : 0);
-            mx = ni > mx ? ni : mx;
+    for (int q = 0; q < kPixPerThread; ++q) {
+        const int px = x0 + q * kTileThreads + threadIdx.x;      // any order: only sums are formed
+        if (px < HW) {
+            float yv[10];
+#pragma unroll
+            for (int i = 0; i < 10; ++i) yv[i] = plane0[(long long)i * HW + px];
+            const float eps = 1e-6f;
+            float d = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const float r = yv[i] - d;
+                const float cc = ceilf(r - eps);
+                d = cc - r;
+                int ni = (int)cc;
+                if (i == 8) ni += (int)(yv[9] - d);
+                cnt[i] += (strategy == V2CE_STRATEGY_NONE) ? (ni == 1) : (ni > 0 ? ni : 0);
+                mx = ni > mx ? ni : mx;
+            }
         }
     }
-    __shared__ int red[4][10];
+    __shared__ int red[kTileThreads / 64][10];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
@@ -212,33 +285,59 @@ __global__ __launch_bounds__(256) void ldati_count_kernel(const float *__restric
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-        const int t = __shfl_xor(mx, o);
-        mx = t > mx ? t : mx;
+        const int m = __shfl_xor(mx, o);
+        mx = m > mx ? m : mx;
     }
     if (lane == 0) red[wid][9] = mx;
     __syncthreads();
     if (threadIdx.x < 9) {
-        const int i = threadIdx.x;
-        const long long s = (long long)red[0][i] + red[1][i] + red[2][i] + red[3][i];
-        if (s) atomicAdd(&seg_counts[(long long)b * 9 + i], (unsigned long long)s);
+        unsigned s = 0;
+#pragma unroll
+        for (int w = 0; w < kTileThreads / 64; ++w) s += (unsigned)red[w][threadIdx.x];
+        tc[((long long)b * T + t) * 9 + threadIdx.x] = s;
     } else if (threadIdx.x == 9) {
-        int m = red[0][9];
-        m = red[1][9] > m ? red[1][9] : m;
-        m = red[2][9] > m ? red[2][9] : m;
-        m = red[3][9] > m ? red[3][9] : m;
-        if (m > 0) atomicMax(max_n, m);
+        int m = 0;
+#pragma unroll
+        for (int w = 0; w < kTileThreads / 64; ++w) m = red[w][9] > m ? red[w][9] : m;
+        if (m > 0) atomicMax(&stats[0], (unsigned long long)m);
     }
 }
 
-// exclusive scan of B*9 counts, single block (B*9 is small)
-__global__ __launch_bounds__(256) void ldati_scan_kernel(const long long *counts, int n,
-                                                         long long *offsets) {
+// One workgroup: tile counts -> exclusive tile offsets inside each segment; segment counts ->
+// exclusive segment offsets; stats = {max_n (set by the count kernel), largest (tile, bin) count,
+// largest segment, total}.
+__global__ __launch_bounds__(256) void ldati_tile_scan_kernel(const unsigned *__restrict__ tc, int B,
+                                                              int T, unsigned *__restrict__ tile_off,
+                                                              long long *seg_offsets,
+                                                              unsigned long long *stats) {
     __shared__ long long part[256];
-    const int t = threadIdx.x;
+    __shared__ unsigned long long mx_tile, mx_seg;
+    const int t = threadIdx.x, n = B * 9;
+    if (t == 0) { mx_tile = 0; mx_seg = 0; }
+    __syncthreads();
+    // phase 1: per segment, scan over the tiles (the segment count lands in seg_offsets[seg] for now)
+    unsigned long long my_tile = 0, my_seg = 0;
+    for (int seg = t; seg < n; seg += 256) {
+        const int b = seg / 9, c = seg - b * 9;
+        unsigned run = 0;
+        for (int tt = 0; tt < T; ++tt) {
+            const long long i = ((long long)b * T + tt) * 9 + c;
+            const unsigned v = tc[i];
+            tile_off[i] = run;
+            run += v;
+            my_tile = v > my_tile ? v : my_tile;
+        }
+        seg_offsets[seg] = run;
+        my_seg = run > my_seg ? run : my_seg;
+    }
+    atomicMax(&mx_tile, my_tile);
+    atomicMax(&mx_seg, my_seg);
+    __syncthreads();
+    // phase 2: exclusive scan of the n segment counts
     const int per = (n + 255) / 256;
     const int lo = t * per, hi = (lo + per < n) ? lo + per : n;
     long long s = 0;
-    for (int i = lo; i < hi; ++i) s += counts[i];
+    for (int i = lo; i < hi; ++i) s += seg_offsets[i];
     part[t] = s;
     __syncthreads();
     if (t == 0) {
@@ -248,18 +347,25 @@ __global__ __launch_bounds__(256) void ldati_scan_kernel(const long long *counts
             part[i] = run;
             run += v;
         }
-        offsets[n] = run;
+        seg_offsets[n] = run;
+        stats[1] = mx_tile;
+        stats[2] = mx_seg;
+        stats[3] = (unsigned long long)run;
     }
     __syncthreads();
     long long run = part[t];
     for (int i = lo; i < hi; ++i) {
-        offsets[i] = run;
-        run += counts[i];
+        const long long v = seg_offsets[i];
+        seg_offsets[i] = run;
+        run += v;
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// emit kernel: one workgroup (4 waves) per (frame, bin) segment
+// sweep kernel (v1): one workgroup (4 waves = the 4 tie-order categories) per (frame, bin) segment:
+//   A. histogram cnt[cat][key]  B. exclusive scan in (key, category) order = stable ranks
+//   C. replay the same events in pixel order; rank among the equal-key events of the wave batch
+//      from a ballot match-any, running base from LDS; scatter straight to the final position.
 // ---------------------------------------------------------------------------------------------
 template <bool RANK>
 __device__ __forceinline__ void handle_event(bool has, long long T, int px, int c, int cat,
@@ -284,10 +390,15 @@ __device__ __forceinline__ void handle_event(bool has, long long T, int px, int 
         if (leader) *vs = base + npeer;            // ... then the highest peer advances it
         const long long pos = seg_lo + (long long)base + rank;
         const int yy = px / P.W;
-        P.ts[pos] = T + ts_add;
-        P.x[pos] = (short)(px - yy * P.W);
-        P.y[pos] = (short)yy;
-        P.p[pos] = pol;
+        if (P.packed) {
+            store_packed_bytes(P.packed + pos * 13, T + ts_add, (unsigned)(px - yy * P.W) & 0xFFFFu,
+                               (unsigned)yy & 0xFFFFu, (unsigned)pol);
+        } else {
+            P.ts[pos] = T + ts_add;
+            P.x[pos] = (short)(px - yy * P.W);
+            P.y[pos] = (short)yy;
+            P.p[pos] = pol;
+        }
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -296,7 +407,6 @@ template <bool RANK>
 __device__ __forceinline__ void sweep_singles(int b, int c, int pidx, int cat, signed char pol,
                                               int lane, long long seg_lo, long long ts_add,
                                               unsigned *cnt, const LdatiParams &P) {
-    const int last = c + 1 < 8 ? c + 1 : 8;
     const float *plane0 = P.vox + (long long)(b * 2 + pidx) * 10 * P.HW;
     float cur[10], nxt[10];
     load_bins(plane0, P.HW, lane, lane < P.HW, c, cur);   // singles only need bins 0..c
@@ -314,7 +424,6 @@ __device__ __forceinline__ void sweep_singles(int b, int c, int pidx, int cat, s
 #pragma unroll
         for (int i = 0; i < 10; ++i) cur[i] = nxt[i];
     }
-    (void)last;
 }
 
 template <bool RANK>
@@ -395,7 +504,7 @@ __global__ __launch_bounds__(256) void ldati_emit_kernel(LdatiParams P) {
     const long long seg_lo = P.seg_offsets[seg];
     const long long seg_n = P.seg_offsets[seg + 1] - seg_lo;
     if (seg_n <= 0) return;              // uniform per workgroup
-    if (P.seg_flag && !P.seg_flag[seg]) return;   // bucketed path handled this segment
+    if (P.seg_flag && !P.seg_flag[seg]) return;   // the two-level path handled this segment
     const long long ts_add = P.frame_ts_add ? P.frame_ts_add[b] : 0;
 
     unsigned *cnt = reinterpret_cast<unsigned *>(ldati_smem);            // [4][NK]
@@ -461,198 +570,422 @@ __global__ __launch_bounds__(256) void ldati_emit_kernel(LdatiParams P) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// bucketed path (v2): pixel-parallel recompute -> coarse buckets -> LDS sort -> coalesced output
-//
-//   pass<false> : thread per (frame, polarity, pixel); ONE relocation recurrence over the 9 bins;
-//                 every event's timestamp; histogram of coarse buckets (key >> key_shift) per segment
-//   scan        : exclusive offsets of the buckets inside each segment; segments whose largest
-//                 bucket exceeds kSortCap are flagged for the segment-sweep kernel above
-//   pass<true>  : same recompute; append a 32-bit record (fine key | category | pixel) to its bucket
-//   sort        : one workgroup per bucket: bitonic sort of the records in LDS, then the final SoA
-//                 events are written as coalesced runs.  The record order (key, category, pixel) IS the
-//                 reference's stable order: events that tie on all three are identical records.
+// tile pass: workgroup per (frame, tile), 512 threads, 4 consecutive pixels per thread, bin by bin
 // ---------------------------------------------------------------------------------------------
-constexpr int kPixPerWg = 1024;   // pixels of one polarity plane per workgroup (4 per thread)
+// LDS map (dynamic): S [capA] u32 | O [capA + 2048] u32 (aliased by the unit tables while the
+// timestamps are computed) | PT [2048] {k, bb} | hist [8][NB] u32 | misc
+extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
 
-// One event of (frame b, bin c): count it in / append it through the workgroup's LDS table.
-template <bool APPEND>
-__device__ __forceinline__ void bucket_event(const LdatiParams &P, unsigned *lds, int c,
-                                             long long seg_lo, long long T, unsigned cat,
-                                             unsigned px) {
-    const int key = key_of(T, P.kbase[c], P.NK);
-    unsigned *slot = lds + c * P.NB + (key >> P.key_shift);
-    if (!APPEND) {
-        atomicAdd(slot, 1u);                               // LDS atomic, no return
-    } else {
-        const unsigned pos = atomicAdd(slot, 1u);          // LDS cursor (bucket base + rank)
-        const unsigned fine = (unsigned)key & ((1u << P.key_shift) - 1u);
-        P.temp[seg_lo + pos] = (fine << (2 + P.PB)) | (cat << P.PB) | px;
-    }
-}
+__global__ __launch_bounds__(kTileThreads) void ldati_tile_pass_kernel(LdatiParams P) {
+    const int t = blockIdx.x, b = blockIdx.y;
+    const int pidx = t < P.tpp ? 1 : 0;
+    const int x0 = (t < P.tpp ? t : t - P.tpp) * kTilePix;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    constexpr int NW = kTileThreads / 64;
 
-extern __shared__ __attribute__((aligned(16))) unsigned char bucket_smem[];
+    unsigned *S = reinterpret_cast<unsigned *>(tile_smem);
+    unsigned *O = S + P.capA;
+    float2 *PT = reinterpret_cast<float2 *>(O + P.capA + 2048);
+    unsigned *hist = reinterpret_cast<unsigned *>(PT + kTilePix);
+    unsigned *part = hist + NW * P.NB;                 // [NW + 1] x 2
+    // unit tables alias O: singles {debt bits, local} then multi units {info, event offset}
+    uint2 *SL = reinterpret_cast<uint2 *>(O);
 
-// Pixel-parallel pass.  APPEND = false: per-workgroup histogram of coarse buckets (9 bins x NB) in
-// LDS, stored to wgtab.  APPEND = true: the LDS table is preloaded with this workgroup's exclusive
-// offsets (bucket offset inside the segment + events of earlier workgroups), and every event takes
-// its slot with one LDS atomic: no global atomics anywhere.
-template <bool APPEND>
-__global__ __launch_bounds__(256) void ldati_bucket_pass_kernel(LdatiParams P) {
-    unsigned *lds = reinterpret_cast<unsigned *>(bucket_smem);           // [9][NB]
-    const int bp = blockIdx.y, b = bp >> 1, pidx = bp & 1;
-    const int wg = pidx * P.blk_per_pol + blockIdx.x;
-    const int ntab = 9 * P.NB;
-    unsigned *tab = P.wgtab + ((long long)b * P.wg_per_frame + wg) * ntab;
-    for (int i = threadIdx.x; i < ntab; i += 256)
-        lds[i] = APPEND ? tab[i] + P.bofs[(long long)b * ntab + i] : 0u;
-    __syncthreads();
-    const float *plane0 = P.vox + (long long)bp * 10 * P.HW;
+    const float *plane0 = P.vox + (long long)(b * 2 + pidx) * 10 * P.HW;
     const unsigned frame = (unsigned)(P.frame_base + b);
-    const unsigned cat_single = pidx ? 0u : 2u;    // negative events live in P index 1
-    for (int it = 0; it < kPixPerWg / 256; ++it) {
-        const int px = blockIdx.x * kPixPerWg + it * 256 + threadIdx.x;
-        if (px >= P.HW) break;
-        float yv[10];
+    const int lpx0 = tid * kPixPerThread;              // first local pixel of this thread
+    const float eps = 1e-6f;
+
+    // rolling relocation state per pixel: counts of bins c-1, c, c+1; debts after bins c, c+1
+    int nprev[kPixPerThread], ncur[kPixPerThread], nnext[kPixPerThread];
+    float dcur[kPixPerThread], dnext[kPixPerThread];
+    bool valid[kPixPerThread];
 #pragma unroll
-        for (int i = 0; i < 10; ++i) yv[i] = plane0[(long long)i * P.HW + px];
-        int n[9];
-        float dbt[9];
-        {
-            const float eps = 1e-6f;
-            float d = 0.0f;
+    for (int q = 0; q < kPixPerThread; ++q) {
+        const int px = x0 + lpx0 + q;
+        valid[q] = px < P.HW;
+        const float y0 = valid[q] ? plane0[px] : 0.0f;
+        const float y1 = valid[q] ? plane0[(long long)P.HW + px] : 0.0f;
+        float r = y0 - 0.0f;
+        float cc = ceilf(r - eps);
+        dcur[q] = cc - r;
+        ncur[q] = (int)cc;
+        r = y1 - dcur[q];
+        cc = ceilf(r - eps);
+        dnext[q] = cc - r;
+        nnext[q] = (int)cc;
+        nprev[q] = 0;
+    }
+
+    for (int c = 0; c < 9; ++c) {
+        // prefetch the voxels of bin c+2 (and bin 9 with it when c+2 == 8)
+        float ynn[kPixPerThread], y9[kPixPerThread];
 #pragma unroll
-            for (int i = 0; i < 9; ++i) {
-                const float r = yv[i] - d;
-                const float cc = ceilf(r - eps);
-                d = cc - r;
-                int ni = (int)cc;
-                if (i == 8) ni += (int)(yv[9] - d);
-                n[i] = ni;
-                dbt[i] = d;
-            }
+        for (int q = 0; q < kPixPerThread; ++q) {
+            const int px = x0 + lpx0 + q;
+            ynn[q] = (c + 2 <= 8 && valid[q]) ? plane0[(long long)(c + 2) * P.HW + px] : 0.0f;
+            y9[q] = (c + 2 == 8 && valid[q]) ? plane0[(long long)9 * P.HW + px] : 0.0f;
         }
+        // ---- P1: classify ------------------------------------------------------------------
+        unsigned a_tot = 0, e_tot = 0;                  // per thread: singles | units << 12, multi events
+        unsigned a_q[kPixPerThread], e_q[kPixPerThread];
 #pragma unroll
-        for (int c = 0; c < 9; ++c) {
-            const int nc = n[c];
-            if (nc < 1) continue;
-            const long long seg_lo = APPEND ? P.seg_offsets[b * 9 + c] : 0;
-            if (nc == 1) {
-                bucket_event<APPEND>(P, lds, c, seg_lo, single_ts(dbt[c], P.fps, P.offt[c]), cat_single,
-                                     (unsigned)px);
-            } else if (P.strategy != V2CE_STRATEGY_NONE) {
+        for (int q = 0; q < kPixPerThread; ++q) {
+            const int n = valid[q] ? ncur[q] : 0;
+            const bool single = n == 1;
+            const bool multi = n >= 2 && P.strategy != V2CE_STRATEGY_NONE;
+            a_q[q] = a_tot;
+            e_q[q] = e_tot;
+            a_tot += (single ? 1u : 0u) + (multi ? ((unsigned)(n + 3) >> 2) << 12 : 0u);
+            e_tot += multi ? (unsigned)n : 0u;
+        }
+        // ---- P2: workgroup scans in pixel order (thread-major, pixel-minor) ----------------
+        unsigned A_all, E_all;
+        const unsigned a_base = block_excl_scan<NW>(a_tot, part, &A_all);
+        const unsigned e_base = block_excl_scan<NW>(e_tot, part + NW + 1, &E_all);
+        const unsigned Ns = A_all & 0xFFFu, Um = A_all >> 12, Nm = E_all;
+        const unsigned N = Ns + Nm;
+        uint2 *MU = SL + Ns;
+        for (int i = tid; i < NW * P.NB; i += kTileThreads) hist[i] = 0;
+        // ---- P3: unit tables ----------------------------------------------------------------
+#pragma unroll
+        for (int q = 0; q < kPixPerThread; ++q) {
+            const int n = valid[q] ? ncur[q] : 0;
+            const unsigned local = (unsigned)(lpx0 + q);
+            const unsigned ab = a_base + a_q[q];
+            if (n == 1) {
+                SL[ab & 0xFFFu] = make_uint2(__float_as_uint(dcur[q]), local);
+            } else if (n >= 2 && P.strategy != V2CE_STRATEGY_NONE) {
                 float k, bb;
-                slope_params(c > 0 ? n[c - 1] : 0, nc, c < 8 ? n[c + 1] : 0, c, P, k, bb);
-                const long long ubase = (((long long)bp * 9 + c) * P.HW + px) * P.replay_max_n;
-                for (int j = 0; j < nc; ++j) {
-                    float u = 0.0f;
-                    if (P.rng_mode == V2CE_RNG_REPLAY) {
-                        if (j < P.replay_max_n) u = P.uniforms[ubase + j];
-                    } else {
-                        u = philox_uniform(P.seed, (unsigned)px, (unsigned)j, (unsigned)(pidx * 9 + c), frame);
-                    }
-                    bucket_event<APPEND>(P, lds, c, seg_lo, multi_ts(k, bb, u, P.offt[c], P),
-                                         cat_single + 1u, (unsigned)px);
+                slope_params(nprev[q], n, nnext[q], c, P, k, bb);
+                PT[local] = make_float2(k, bb);
+                const unsigned u0 = ab >> 12, ev0 = e_base + e_q[q];
+                const unsigned units = (unsigned)(n + 3) >> 2;
+                for (unsigned jb = 0; jb < units; ++jb) {
+                    const unsigned left = (unsigned)n - 4u * jb;
+                    MU[u0 + jb] = make_uint2(local | (jb << kLocalBits) | ((left < 4u ? left : 4u) << 28),
+                                             ev0 + 4u * jb);
                 }
             }
         }
-    }
-    if (!APPEND) {
         __syncthreads();
-        for (int i = threadIdx.x; i < ntab; i += 256) tab[i] = lds[i];
+        // ---- P4: timestamps, once, every lane busy -------------------------------------------
+        for (unsigned q = tid; q < Ns; q += kTileThreads) {
+            const uint2 e = SL[q];
+            const long long Tq = single_ts(__uint_as_float(e.x), P.fps, P.offt[c]);
+            S[q] = ((unsigned)key_of(Tq, P.kbase[c], P.NK) << 12) | e.y;
+        }
+        for (unsigned q = tid; q < Um; q += kTileThreads) {
+            const uint2 e = MU[q];
+            const unsigned local = e.x & (kTilePix - 1), jb = (e.x >> kLocalBits) & 0x1FFFFu, cnt = e.x >> 28;
+            const float2 kb = PT[local];
+            const unsigned px = (unsigned)x0 + local;
+            float u[4];
+            if (P.rng_mode == V2CE_RNG_REPLAY) {
+                const long long ub = (((long long)(b * 2 + pidx) * 9 + c) * P.HW + px) * P.replay_max_n;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int j = (int)(4u * jb) + s;
+                    u[s] = ((unsigned)s < cnt && j < P.replay_max_n) ? P.uniforms[ub + j] : 0.0f;
+                }
+            } else {
+                unsigned o[4];
+                philox4(P.seed, px, jb, (unsigned)(pidx * 9 + c), frame, o);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) u[s] = u24(o[s]);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if ((unsigned)s < cnt) {
+                    const long long Tq = multi_ts(kb.x, kb.y, u[s], P.offt[c], P);
+                    S[Ns + e.y + s] = ((unsigned)key_of(Tq, P.kbase[c], P.NK) << 12) | (1u << kLocalBits) | local;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- P5: per-wave histograms of the coarse bucket over contiguous chunks of S ----------
+        const unsigned L = ((N + kTileThreads - 1) / kTileThreads) * 64;      // chunk per wave
+        const unsigned lo = wid * L, hi = (lo + L < N) ? lo + L : N;
+        for (unsigned i = lo + lane; i < hi; i += 64)
+            atomicAdd(&hist[wid * P.NB + (S[i] >> (12 + P.shift))], 1u);
+        __syncthreads();
+        // bucket-major, wave-minor exclusive scan; the tile's bucket counts and run offsets
+        {
+            unsigned run = 0;
+            if (tid < P.NB) {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    const unsigned v = hist[w * P.NB + tid];
+                    hist[w * P.NB + tid] = run;
+                    run += v;
+                }
+            }
+            unsigned tot;
+            const unsigned boff = block_excl_scan<NW>(run, part, &tot);
+            if (tid < P.NB) {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) hist[w * P.NB + tid] += boff;
+                const long long gi = ((long long)(b * 9 + c) * P.NB + tid) * P.T + t;
+                P.cntT[gi] = run;
+                P.runoff[gi] = boff;
+            }
+        }
+        __syncthreads();
+        // ---- P6: stable ranks: ballot match-any inside a 64-record batch, running base in LDS ----
+        for (unsigned i0 = lo; i0 < hi; i0 += 64) {
+            const unsigned i = i0 + lane;
+            const bool has = i < hi;
+            const unsigned rec = has ? S[i] : 0u;
+            const int bucket = (int)(rec >> (12 + P.shift));
+            const unsigned long long peers = match_key(has, bucket, P.nb1);
+            if (has) {
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                const unsigned rank = (unsigned)__popcll(peers & lt);
+                unsigned *slot = &hist[wid * P.NB + bucket];
+                const unsigned base = *reinterpret_cast<volatile unsigned *>(slot);
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 63 - __clzll((long long)peers))
+                    *reinterpret_cast<volatile unsigned *>(slot) = base + (unsigned)__popcll(peers);
+                const unsigned fine = (rec >> 12) & ((1u << P.shift) - 1u);
+                O[base + rank] = (fine << 12) | (rec & 0xFFFu);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+        // ---- P7: the tile's records of this bin leave as one contiguous run ---------------------
+        {
+            unsigned *dst = P.temp + P.seg_offsets[b * 9 + c] + P.tile_off[((long long)b * P.T + t) * 9 + c];
+            for (unsigned i = tid; i < N; i += kTileThreads) dst[i] = O[i];
+        }
+        // ---- advance the relocation recurrence to bin c+2 ---------------------------------------
+#pragma unroll
+        for (int q = 0; q < kPixPerThread; ++q) {
+            nprev[q] = ncur[q];
+            ncur[q] = nnext[q];
+            dcur[q] = dnext[q];
+            if (c + 2 <= 8) {
+                const float r = ynn[q] - dnext[q];
+                const float cc = ceilf(r - eps);
+                dnext[q] = cc - r;
+                int ni = (int)cc;
+                if (c + 2 == 8) ni += (int)(y9[q] - dnext[q]);   // LDATI.py:106
+                nnext[q] = ni;
+            }
+        }
+        __syncthreads();                                // S / O / hist are reused by the next bin
     }
 }
 
-// column scan over the workgroups of a frame: wgtab[b][w][i] -> exclusive prefix over w;
-// cbcount[b][i] = total
-__global__ __launch_bounds__(256) void ldati_wgtab_scan_kernel(LdatiParams P) {
-    const int ntab = 9 * P.NB;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int b = blockIdx.y;
-    if (i >= ntab) return;
-    unsigned *col = P.wgtab + (long long)b * P.wg_per_frame * ntab + i;
-    unsigned run = 0;
-    for (int w = 0; w < P.wg_per_frame; ++w) {
-        const unsigned v = col[(long long)w * ntab];
-        col[(long long)w * ntab] = run;
-        run += v;
-    }
-    P.cbcount[(long long)b * ntab + i] = run;
-}
-
+// per segment: bucket totals over the tiles, exclusive offsets, oversize flag
 __global__ __launch_bounds__(256) void ldati_bucket_scan_kernel(LdatiParams P) {
-    __shared__ unsigned part[256];
+    __shared__ unsigned part[8];
     __shared__ unsigned big;
     const int seg = blockIdx.x, t = threadIdx.x;
-    const unsigned *cnt = P.cbcount + (long long)seg * P.NB;
-    unsigned *ofs = P.bofs + (long long)seg * P.NB;
-    const int per = (P.NB + 255) / 256;
-    const int lo = t * per, hi = (lo + per < P.NB) ? lo + per : P.NB;
     if (t == 0) big = 0;
     __syncthreads();
-    unsigned s = 0, mx = 0;
-    for (int i = lo; i < hi; ++i) {
-        const unsigned v = cnt[i];
-        s += v;
-        mx = v > mx ? v : mx;
-    }
-    part[t] = s;
-    if (mx > (unsigned)kSortCap) atomicOr(&big, 1u);
-    __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
-        const unsigned v = t >= o ? part[t - o] : 0u;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    unsigned run = part[t] - s;
-    for (int i = lo; i < hi; ++i) {
-        ofs[i] = run;
-        run += cnt[i];
-    }
-    if (t == 0) P.seg_flag[seg] = (int)big;
-}
-
-__global__ __launch_bounds__(256) void ldati_bucket_sort_kernel(LdatiParams P) {
-    __shared__ unsigned keys[kSortCap];
-    const unsigned bucket = blockIdx.x;
-    const int seg = bucket / P.NB, cb = bucket - seg * P.NB;
-    const unsigned n = P.cbcount[bucket];
-    if (n == 0 || P.seg_flag[seg]) return;          // uniform per workgroup
-    const long long base = P.seg_offsets[seg] + P.bofs[bucket];
-    unsigned np = 2;
-    while (np < n) np <<= 1;
-    const int tid = threadIdx.x;
-    for (unsigned i = tid; i < np; i += 256) keys[i] = i < n ? P.temp[base + i] : 0xFFFFFFFFu;
-    __syncthreads();
-    for (unsigned k = 2; k <= np; k <<= 1) {
-        for (unsigned j = k >> 1; j > 0; j >>= 1) {
-            for (unsigned t = tid; t < (np >> 1); t += 256) {
-                const unsigned i = 2 * t - (t & (j - 1));
-                const unsigned l = i + j;
-                const unsigned a = keys[i], bq = keys[l];
-                const bool up = (i & k) == 0;
-                if ((a > bq) == up) { keys[i] = bq; keys[l] = a; }
-            }
-            __syncthreads();
+    unsigned carry = 0;
+    for (int b0 = 0; b0 < P.NB; b0 += 256) {            // NB <= 512: at most two rounds
+        const int i = b0 + t;
+        unsigned s = 0;
+        if (i < P.NB) {
+            const unsigned *row = P.cntT + ((long long)seg * P.NB + i) * P.T;
+            for (int tt = 0; tt < P.T; ++tt) s += row[tt];
+            if (s > (unsigned)P.cap2) atomicOr(&big, 1u);
         }
+        unsigned tot;
+        const unsigned ex = block_excl_scan<4>(s, part, &tot);
+        if (i < P.NB) {
+            P.btot[(long long)seg * P.NB + i] = s;
+            P.bofs[(long long)seg * P.NB + i] = carry + ex;
+        }
+        carry += tot;
+        __syncthreads();
     }
-    const int b = seg / 9, c = seg - b * 9;
-    const long long tbase = P.kbase[c] + ((long long)cb << P.key_shift) +
-                            (P.frame_ts_add ? P.frame_ts_add[b] : 0);
-    const unsigned pmask = (1u << P.PB) - 1u;
-    for (unsigned i = tid; i < n; i += 256) {
-        const unsigned r = keys[i];
-        const unsigned px = r & pmask, cat = (r >> P.PB) & 3u, fine = r >> (P.PB + 2);
-        const unsigned yy = px / (unsigned)P.W;
-        P.ts[base + i] = tbase + fine;
-        P.x[base + i] = (short)(px - yy * P.W);
-        P.y[base + i] = (short)yy;
-        P.p[base + i] = (signed char)(cat >> 1);
+    if (t == 0) {
+        P.seg_flag[seg] = (int)big;
+        if (big && !P.sweep_ok) atomicOr(reinterpret_cast<unsigned *>(P.status), 1u);
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// pack kernel: SoA -> 13-byte records, staged through LDS so the global stores are whole dwords
+// bucket sort: workgroup per (segment, bucket).  LDS map (dynamic):
+//   In [cap2] u32 | Out [cap2] u32 | hist [8][bins] u32 | tcnt/toff/tpre [T] | stage [512*13] u32
+// (stage aliases In when In is large enough)
+// ---------------------------------------------------------------------------------------------
+extern __shared__ __attribute__((aligned(16))) unsigned char sort_smem[];
+
+template <bool PACKED>
+__global__ __launch_bounds__(kSortThreads) void ldati_bucket_sort_kernel(LdatiParams P) {
+    const int bucket = blockIdx.x, seg = blockIdx.y;
+    const long long bi = (long long)seg * P.NB + bucket;
+    const unsigned N = P.btot[bi];
+    if (N == 0 || P.seg_flag[seg]) return;               // uniform per workgroup
+    const int b = seg / 9, c = seg - b * 9;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int bins = 4 << P.shift, nb2 = P.shift + 2;
+
+    unsigned *In = reinterpret_cast<unsigned *>(sort_smem);
+    unsigned *Out = In + P.cap2;
+    unsigned *hist = Out + P.cap2;
+    unsigned *tcnt = hist + kSortWaves * bins;
+    unsigned *toff = tcnt + P.T;
+    unsigned *tpre = toff + P.T;
+    unsigned *part = tpre + P.T;                         // [kSortWaves + 1]
+    unsigned *stage = (P.cap2 >= kSortThreads * 13) ? In : part + kSortWaves + 1;
+
+    // S0: this bucket's run in every tile, exclusive prefix over the tiles
+    {
+        unsigned v = 0;
+        if (tid < P.T) {
+            v = P.cntT[bi * P.T + tid];
+            tcnt[tid] = v;
+            toff[tid] = P.runoff[bi * P.T + tid] + P.tile_off[((long long)b * P.T + tid) * 9 + c];
+        }
+        unsigned tot;
+        const unsigned ex = block_excl_scan<kSortWaves>(v, part, &tot);
+        if (tid < P.T) tpre[tid] = ex;
+    }
+    for (int i = tid; i < kSortWaves * bins; i += kSortThreads) hist[i] = 0;
+    __syncthreads();
+    // S1: gather the runs in tile order (negative tiles first, each in pixel order) and widen the
+    // records to (fine | category | global pixel)
+    {
+        const unsigned *seg_temp = P.temp + P.seg_offsets[seg];
+        for (int tt = wid; tt < P.T; tt += kSortWaves) {
+            const unsigned n = tcnt[tt];
+            const unsigned *src = seg_temp + toff[tt];
+            const unsigned dst = tpre[tt];
+            const unsigned pxb = (unsigned)(tt < P.tpp ? tt : tt - P.tpp) * kTilePix;
+            const unsigned catb = tt < P.tpp ? 0u : 2u;
+            for (unsigned i = lane; i < n; i += 64) {
+                const unsigned r = src[i];
+                const unsigned cat = catb + ((r >> kLocalBits) & 1u);
+                In[dst + i] = ((r >> 12) << (2 + P.PB)) | (cat << P.PB) | (pxb + (r & (kTilePix - 1)));
+            }
+        }
+    }
+    __syncthreads();
+    // S2: per-wave histograms of (fine, category) over contiguous chunks
+    const unsigned L = ((N + kSortThreads - 1) / kSortThreads) * 64;
+    const unsigned lo = wid * L, hi = (lo + L < N) ? lo + L : N;
+    for (unsigned i = lo + lane; i < hi; i += 64) atomicAdd(&hist[wid * bins + (In[i] >> P.PB)], 1u);
+    __syncthreads();
+    // S3: bin-major, wave-minor exclusive scan
+    {
+        const int per = (bins + kSortThreads - 1) / kSortThreads;
+        const int b0 = tid * per, b1 = (b0 + per < bins) ? b0 + per : bins;
+        unsigned s = 0;
+        for (int q = b0; q < b1; ++q)
+#pragma unroll
+            for (int w = 0; w < kSortWaves; ++w) s += hist[w * bins + q];
+        unsigned tot;
+        unsigned run = block_excl_scan<kSortWaves>(s, part, &tot);
+        for (int q = b0; q < b1; ++q) {
+#pragma unroll
+            for (int w = 0; w < kSortWaves; ++w) {
+                const unsigned v = hist[w * bins + q];
+                hist[w * bins + q] = run;
+                run += v;
+            }
+        }
+    }
+    __syncthreads();
+    // S4: stable ranks
+    for (unsigned i0 = lo; i0 < hi; i0 += 64) {
+        const unsigned i = i0 + lane;
+        const bool has = i < hi;
+        const unsigned rec = has ? In[i] : 0u;
+        const int bin = (int)(rec >> P.PB);
+        const unsigned long long peers = match_key(has, bin, nb2);
+        if (has) {
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            unsigned *slot = &hist[wid * bins + bin];
+            const unsigned base = *reinterpret_cast<volatile unsigned *>(slot);
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 63 - __clzll((long long)peers))
+                *reinterpret_cast<volatile unsigned *>(slot) = base + (unsigned)__popcll(peers);
+            Out[base + (unsigned)__popcll(peers & lt)] = rec;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // S5: decode and write the final records
+    const long long g0 = P.seg_offsets[seg] + P.bofs[bi];                 // first global record
+    const long long tbase = P.kbase[c] + ((long long)bucket << P.shift) +
+                            (P.frame_ts_add ? P.frame_ts_add[b] : 0);
+    const unsigned pmask = (1u << P.PB) - 1u;
+    const unsigned W = (unsigned)P.W;
+    if (!PACKED) {
+        for (unsigned i = tid; i < N; i += kSortThreads) {
+            const unsigned r = Out[i];
+            const unsigned px = r & pmask, cat = (r >> P.PB) & 3u, fine = r >> (P.PB + 2);
+            const unsigned yy = px / W;
+            P.ts[g0 + i] = tbase + fine;
+            P.x[g0 + i] = (short)(px - yy * W);
+            P.y[g0 + i] = (short)yy;
+            P.p[g0 + i] = (signed char)(cat >> 1);
+        }
+        return;
+    }
+    // groups of four records starting at a global record index that is a multiple of 4 are
+    // 13 whole dwords (52 bytes); only the first and the last group of a bucket can be partial
+    const long long gN = g0 + N;
+    const long long G0 = g0 >> 2, G1 = (gN + 3) >> 2;
+    unsigned *out32 = reinterpret_cast<unsigned *>(P.packed);
+    for (long long Ga = G0; Ga < G1; Ga += kSortThreads) {
+        const long long G = Ga + tid;
+        if (G < G1) {
+            unsigned A[4], Bh[4], C[4], D[4];
+            bool ok[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const long long i = 4 * G + q - g0;
+                ok[q] = i >= 0 && i < (long long)N;
+                const unsigned r = ok[q] ? Out[i] : 0u;
+                const unsigned px = r & pmask, cat = (r >> P.PB) & 3u, fine = r >> (P.PB + 2);
+                const unsigned yy = px / W;
+                const long long tq = tbase + fine;
+                A[q] = (unsigned)tq;
+                Bh[q] = (unsigned)((unsigned long long)tq >> 32);
+                C[q] = ((px - yy * W) & 0xFFFFu) | (yy << 16);
+                D[q] = cat >> 1;
+            }
+            if (ok[0] && ok[1] && ok[2] && ok[3]) {
+                unsigned *d = stage + tid * 13;
+                d[0] = A[0]; d[1] = Bh[0]; d[2] = C[0];
+                d[3] = D[0] | (A[1] << 8);
+                d[4] = (A[1] >> 24) | (Bh[1] << 8);
+                d[5] = (Bh[1] >> 24) | (C[1] << 8);
+                d[6] = (C[1] >> 24) | (D[1] << 8) | (A[2] << 16);
+                d[7] = (A[2] >> 16) | (Bh[2] << 16);
+                d[8] = (Bh[2] >> 16) | (C[2] << 16);
+                d[9] = (C[2] >> 16) | (D[2] << 16) | (A[3] << 24);
+                d[10] = (A[3] >> 8) | (Bh[3] << 24);
+                d[11] = (Bh[3] >> 8) | (C[3] << 24);
+                d[12] = (C[3] >> 8) | (D[3] << 24);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (ok[q])
+                        store_packed_bytes(P.packed + (4 * G + q) * 13,
+                                           (long long)(((unsigned long long)Bh[q] << 32) | A[q]),
+                                           C[q] & 0xFFFFu, C[q] >> 16, D[q]);
+            }
+        }
+        __syncthreads();
+        const long long left = G1 - Ga;
+        const unsigned nG = left < kSortThreads ? (unsigned)left : (unsigned)kSortThreads;
+        for (unsigned d = tid; d < nG * 13; d += kSortThreads) {
+            const long long G = Ga + d / 13;
+            const bool partial = (G == G0 && (g0 & 3)) || (G == G1 - 1 && (gN & 3));
+            if (!partial) out32[Ga * 13 + d] = stage[d];
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pack / unpack kernels: SoA <-> 13-byte records
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void events_pack_kernel(const long long *__restrict__ ts,
                                                           const short *__restrict__ x,
@@ -662,16 +995,9 @@ __global__ __launch_bounds__(256) void events_pack_kernel(const long long *__res
     __shared__ __attribute__((aligned(16))) unsigned char stage[256 * 13 + 12];
     const long long first = (long long)blockIdx.x * 256;
     const long long i = first + threadIdx.x;
-    if (i < n) {
-        const long long t = ts[i];
-        const unsigned short xx = (unsigned short)x[i], yy = (unsigned short)y[i];
-        unsigned char *d = stage + threadIdx.x * 13;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) d[k] = (unsigned char)((unsigned long long)t >> (8 * k));
-        d[8] = (unsigned char)xx; d[9] = (unsigned char)(xx >> 8);
-        d[10] = (unsigned char)yy; d[11] = (unsigned char)(yy >> 8);
-        d[12] = (unsigned char)p[i];
-    }
+    if (i < n)
+        store_packed_bytes(stage + threadIdx.x * 13, ts[i], (unsigned short)x[i], (unsigned short)y[i],
+                           (unsigned char)p[i]);
     __syncthreads();
     const long long remain = n - first;
     const int nev = remain < 256 ? (int)remain : 256;
@@ -683,13 +1009,42 @@ __global__ __launch_bounds__(256) void events_pack_kernel(const long long *__res
     for (int r = (nd << 2) + threadIdx.x; r < nbytes; r += 256) dst[r] = stage[r];
 }
 
+__global__ __launch_bounds__(256) void events_unpack_kernel(const unsigned char *__restrict__ packed,
+                                                            long long n, long long *ts, short *x,
+                                                            short *y, signed char *p) {
+    __shared__ __attribute__((aligned(16))) unsigned char stage[256 * 13 + 12];
+    const long long first = (long long)blockIdx.x * 256;
+    const long long remain = n - first;
+    const int nev = remain < 256 ? (int)remain : 256;
+    const int nbytes = nev * 13;
+    const unsigned char *src = packed + first * 13;
+    const int nd = nbytes >> 2;
+    for (int w = threadIdx.x; w < nd; w += 256)
+        reinterpret_cast<unsigned *>(stage)[w] = reinterpret_cast<const unsigned *>(src)[w];
+    for (int r = (nd << 2) + threadIdx.x; r < nbytes; r += 256) stage[r] = src[r];
+    __syncthreads();
+    const long long i = first + threadIdx.x;
+    if (i < n) {
+        const unsigned char *s = stage + threadIdx.x * 13;
+        unsigned long long t = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t |= (unsigned long long)s[k] << (8 * k);
+        ts[i] = (long long)t;
+        x[i] = (short)(s[8] | (s[9] << 8));
+        y[i] = (short)(s[10] | (s[11] << 8));
+        p[i] = (signed char)s[12];
+    }
+}
+
 // host-side scalars, computed exactly like CPU torch does
 struct HostScalars {
     float VS, VS2, INV, FPS;
     float offt[9];
     long long kbase[9];
-    int NK, nbits;
-    size_t lds_bytes;
+    long long NK;
+    int nbits;
+    size_t lds_bytes;     // of the sweep kernel
+    bool sweep_ok;        // 4*NK counters fit the LDS
     bool ok;
 };
 
@@ -709,13 +1064,59 @@ HostScalars host_scalars(double fps, double t0) {
     const long long span = (long long)(vs * 1e6) + 2;
     const long long nk = span + 2 * slack;
     for (int c = 0; c < 9; ++c) h.kbase[c] = (long long)((double)h.offt[c] * 1e6) - slack;
-    h.ok = nk > 0 && nk <= 9600;    // 4*NK*4 B must fit 160 KiB of LDS with the scratch beside it
-    h.NK = (int)nk;
+    h.NK = nk;
+    h.ok = nk > 0 && nk <= ((long long)kMaxNB << kMaxShift);      // the two-level path's key range
+    h.sweep_ok = nk > 0 && nk <= 9600;    // 4*NK*4 B must fit 160 KiB of LDS with the scratch beside it
     int nb = 0;
     while ((1ll << nb) < nk) ++nb;
     h.nbits = nb;
-    h.lds_bytes = (size_t)(4 * h.NK + 256) * 4 + 3 * 128 * 4;
+    h.lds_bytes = (size_t)(4 * nk + 256) * 4 + 3 * 128 * 4;
     return h;
+}
+
+// geometry and capacities of the two-level path
+struct Plan {
+    int tpp, T, shift, NB, nb1, PB, capA, cap2;
+    size_t n_tab, n_bkt;                 // cntT / runoff entries; btot / bofs entries
+    size_t lds_tile, lds_sort;
+    size_t bytes;                        // workspace
+    bool ok;
+};
+
+Plan make_plan(const HostScalars &h, int B, int H, int W, int64_t total_events,
+               int64_t max_segment_events, int64_t max_tile_events) {
+    Plan p{};
+    const long long HW = (long long)H * W;
+    p.tpp = (int)((HW + kTilePix - 1) / kTilePix);
+    p.T = 2 * p.tpp;
+    int pb = 1;
+    while ((1ll << pb) < HW) ++pb;
+    p.PB = pb;
+    // coarse bucket width: the average bucket of the LARGEST segment stays <= 5120 records
+    int shift = kMaxShift;
+    while (shift > 0 && (double)max_segment_events * (double)(1 << shift) / (double)h.NK > 5120.0) --shift;
+    while (shift < kMaxShift && ((h.NK + (1ll << shift) - 1) >> shift) > kMaxNB) ++shift;
+    p.shift = shift;
+    p.NB = (int)((h.NK + (1ll << shift) - 1) >> shift);
+    int nb1 = 0;
+    while ((1 << nb1) < p.NB) ++nb1;
+    p.nb1 = nb1;
+    const double avg = (double)max_segment_events / (double)p.NB;
+    p.cap2 = avg > 1800.0 ? 12288 : 4096;
+    p.capA = (int)((max_tile_events + 255) / 256 * 256);
+    if (p.capA < 256) p.capA = 256;
+    p.ok = h.ok && p.T <= kMaxTiles && p.NB <= kMaxNB && p.capA <= kCapTile &&
+           shift + 2 + pb <= 32 && total_events < (1ll << 32) && B * 9 <= 65535;
+    p.n_bkt = (size_t)B * 9 * (size_t)p.NB;
+    p.n_tab = p.n_bkt * (size_t)p.T;
+    p.lds_tile = (size_t)(2 * p.capA + 2048) * 4 + (size_t)kTilePix * 8 +
+                 (size_t)(kTileThreads / 64) * p.NB * 4 + 2 * (kTileThreads / 64 + 1) * 4;
+    const size_t bins = (size_t)4 << shift;
+    p.lds_sort = (size_t)2 * p.cap2 * 4 + kSortWaves * bins * 4 + (size_t)3 * p.T * 4 + (kSortWaves + 1) * 4 +
+                 (p.cap2 >= kSortThreads * 13 ? 0 : (size_t)kSortThreads * 13 * 4);
+    p.bytes = (2 * p.n_tab + 2 * p.n_bkt + (size_t)B * 9 + 4 + (size_t)(total_events > 0 ? total_events : 0)) * 4;
+    if (p.lds_tile > 160 * 1024 || p.lds_sort > 160 * 1024) p.ok = false;
+    return p;
 }
 
 }  // namespace
@@ -723,35 +1124,36 @@ HostScalars host_scalars(double fps, double t0) {
 
 using namespace v2ce;
 
-extern "C" int v2ce_ldati_count(const float *vox, int B, int H, int W, int strategy,
-                                int64_t *seg_counts, int32_t *max_n, v2ce_stream_t stream) {
+extern "C" size_t v2ce_ldati_tile_ws_bytes(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    const long long tpp = ((long long)H * W + kTilePix - 1) / kTilePix;
+    return (size_t)2 * (size_t)B * (size_t)(2 * tpp) * 9 * 4;
+}
+
+extern "C" int v2ce_ldati_count(const float *vox, int B, int H, int W, int strategy, void *tile_ws,
+                                size_t tile_ws_bytes, int64_t *seg_offsets, int64_t *stats,
+                                v2ce_stream_t stream) {
     clear_error();
-    V2CE_REQUIRE(vox && seg_counts && max_n, V2CE_ERR_BAD_ARG, "v2ce_ldati_count: null pointer");
+    V2CE_REQUIRE(vox && tile_ws && seg_offsets && stats, V2CE_ERR_BAD_ARG, "v2ce_ldati_count: null pointer");
     V2CE_REQUIRE(B > 0 && H > 0 && W > 0 && (long long)H * W < (1ll << 30), V2CE_ERR_BAD_ARG,
                  "v2ce_ldati_count: bad shape B=%d H=%d W=%d", B, H, W);
     V2CE_REQUIRE(W <= 32767 && H <= 32767, V2CE_ERR_UNSUPPORTED,
                  "v2ce_ldati_count: x/y are int16 (LDATI.py:230-231)");
-    V2CE_REQUIRE(2 * B <= 65535, V2CE_ERR_UNSUPPORTED, "v2ce_ldati_count: B too large for one launch");
+    V2CE_REQUIRE(B <= 65535, V2CE_ERR_UNSUPPORTED, "v2ce_ldati_count: B too large for one launch");
     V2CE_REQUIRE(strategy == V2CE_STRATEGY_SLOPE || strategy == V2CE_STRATEGY_NONE, V2CE_ERR_UNSUPPORTED,
                  "v2ce_ldati_count: strategy %d not implemented", strategy);
+    V2CE_REQUIRE(tile_ws_bytes >= v2ce_ldati_tile_ws_bytes(B, H, W), V2CE_ERR_WORKSPACE,
+                 "v2ce_ldati_count: tile workspace %zu < %zu", tile_ws_bytes, v2ce_ldati_tile_ws_bytes(B, H, W));
     hipStream_t s = as_stream(stream);
-    V2CE_HIP_CHECK(hipMemsetAsync(seg_counts, 0, sizeof(int64_t) * 9 * (size_t)B, s));
-    V2CE_HIP_CHECK(hipMemsetAsync(max_n, 0, sizeof(int32_t), s));
     const int HW = H * W;
-    dim3 grid((HW + kCountPixPerBlock - 1) / kCountPixPerBlock, 2 * B);
-    hipLaunchKernelGGL(ldati_count_kernel, grid, dim3(256), 0, s, vox, HW,
-                       reinterpret_cast<unsigned long long *>(seg_counts), max_n, strategy);
-    V2CE_HIP_CHECK(hipGetLastError());
-    return V2CE_OK;
-}
-
-extern "C" int v2ce_ldati_scan(const int64_t *seg_counts, int B, int64_t *seg_offsets,
-                               v2ce_stream_t stream) {
-    clear_error();
-    V2CE_REQUIRE(seg_counts && seg_offsets && B > 0, V2CE_ERR_BAD_ARG, "v2ce_ldati_scan: bad argument");
-    hipLaunchKernelGGL(ldati_scan_kernel, dim3(1), dim3(256), 0, as_stream(stream),
-                       reinterpret_cast<const long long *>(seg_counts), B * 9,
-                       reinterpret_cast<long long *>(seg_offsets));
+    const int tpp = (HW + kTilePix - 1) / kTilePix, T = 2 * tpp;
+    unsigned *tc = static_cast<unsigned *>(tile_ws);
+    unsigned *tile_off = tc + (size_t)B * T * 9;
+    V2CE_HIP_CHECK(hipMemsetAsync(stats, 0, 4 * sizeof(int64_t), s));
+    hipLaunchKernelGGL(ldati_count_tiles_kernel, dim3(T, B), dim3(kTileThreads), 0, s, vox, HW, tpp, strategy, tc,
+                       reinterpret_cast<unsigned long long *>(stats));
+    hipLaunchKernelGGL(ldati_tile_scan_kernel, dim3(1), dim3(256), 0, s, tc, B, T, tile_off,
+                       reinterpret_cast<long long *>(seg_offsets), reinterpret_cast<unsigned long long *>(stats));
     V2CE_HIP_CHECK(hipGetLastError());
     return V2CE_OK;
 }
@@ -759,50 +1161,24 @@ extern "C" int v2ce_ldati_scan(const int64_t *seg_counts, int B, int64_t *seg_of
 extern "C" size_t v2ce_ldati_lds_bytes(double fps, double t0) {
     if (!(fps > 0)) return 0;
     const HostScalars h = host_scalars(fps, t0);
-    return h.ok ? h.lds_bytes : 0;
+    return h.sweep_ok ? h.lds_bytes : 0;
 }
-
-namespace {
-struct BucketPlan { int shift, NB, PB, blk_per_pol, wg_per_frame; size_t counters, tab, lds, bytes; };
-
-// coarse-bucket width: average bucket of the LARGEST segment ~ kSortCap/4 records, but never so
-// narrow that a workgroup's [9][NB] table exceeds its LDS budget
-BucketPlan bucket_plan(const HostScalars &h, int B, int H, int W, int64_t total_events,
-                       int64_t max_segment_events) {
-    BucketPlan bp{};
-    int shift = 0;
-    while (shift < 13 && (double)max_segment_events * (double)(2 << shift) / (double)h.NK <= kSortCap / 4) ++shift;
-    while (shift < 13 && (size_t)9 * ((h.NK + (1 << shift) - 1) >> shift) * 4 > 96 * 1024) ++shift;
-    int pb = 1;
-    while ((1ll << pb) < (long long)H * W) ++pb;
-    if (shift + 2 + pb > 32) shift = -1;              // the record must fit 32 bits
-    bp.shift = shift;
-    bp.PB = pb;
-    bp.NB = shift >= 0 ? (h.NK + (1 << shift) - 1) >> shift : 0;
-    bp.blk_per_pol = (H * W + kPixPerWg - 1) / kPixPerWg;
-    bp.wg_per_frame = 2 * bp.blk_per_pol;
-    bp.counters = (size_t)B * 9 * (size_t)bp.NB;
-    bp.tab = bp.counters * (size_t)bp.wg_per_frame;
-    bp.lds = (size_t)9 * bp.NB * 4;
-    bp.bytes = (2 * bp.counters + bp.tab + (size_t)B * 9 + (size_t)(total_events > 0 ? total_events : 0)) * 4;
-    return bp;
-}
-}  // namespace
 
 extern "C" size_t v2ce_ldati_workspace_bytes(int B, int H, int W, double fps, double t0,
-                                             int64_t total_events, int64_t max_segment_events) {
+                                             int64_t total_events, int64_t max_segment_events,
+                                             int64_t max_tile_events) {
     if (!(fps > 0) || B <= 0 || H <= 0 || W <= 0) return 0;
     const HostScalars h = host_scalars(fps, t0);
-    if (!h.ok) return 0;
-    const BucketPlan bp = bucket_plan(h, B, H, W, total_events, max_segment_events);
-    return bp.shift >= 0 ? bp.bytes : 0;
+    const Plan p = make_plan(h, B, H, W, total_events, max_segment_events, max_tile_events);
+    return p.ok ? p.bytes : 0;
 }
 
 extern "C" int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps, double t0,
                                int strategy, int rng_mode, const float *uniforms, int replay_max_n,
                                uint64_t seed, int64_t frame_base, const int64_t *seg_offsets,
                                const int64_t *frame_ts_add, int64_t *ts, int16_t *x, int16_t *y,
-                               int8_t *p, int64_t total_events, int64_t max_segment_events,
+                               int8_t *p, uint8_t *packed, int64_t total_events,
+                               int64_t max_segment_events, int64_t max_tile_events, const void *tile_ws,
                                void *workspace, size_t workspace_bytes, v2ce_stream_t stream) {
     clear_error();
     V2CE_REQUIRE(vox && seg_offsets, V2CE_ERR_BAD_ARG, "v2ce_ldati_emit: null pointer");
@@ -816,15 +1192,19 @@ extern "C" int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps
                  "v2ce_ldati_emit: strategy %d not implemented", strategy);
     V2CE_REQUIRE(rng_mode != V2CE_RNG_REPLAY || replay_max_n == 0 || uniforms != nullptr,
                  V2CE_ERR_BAD_ARG, "v2ce_ldati_emit: REPLAY mode needs the uniform tensor");
+    const bool soa = ts && x && y && p;
+    V2CE_REQUIRE(soa != (packed != nullptr) && (soa || !(ts || x || y || p)), V2CE_ERR_BAD_ARG,
+                 "v2ce_ldati_emit: give either the four SoA arrays or the packed buffer");
+    V2CE_REQUIRE(!packed || (reinterpret_cast<uintptr_t>(packed) & 3) == 0, V2CE_ERR_BAD_ARG,
+                 "v2ce_ldati_emit: packed must be 4-byte aligned");
     const HostScalars h = host_scalars(fps, t0);
-    V2CE_REQUIRE(h.ok, V2CE_ERR_UNSUPPORTED,
-                 "v2ce_ldati_emit: fps=%g t0=%g needs %d keys per bin; the LDS histogram holds 9600",
-                 fps, t0, h.NK);
+    V2CE_REQUIRE(h.ok, V2CE_ERR_UNSUPPORTED, "v2ce_ldati_emit: fps=%g t0=%g needs %lld keys per bin (max %d)",
+                 fps, t0, h.NK, kMaxNB << kMaxShift);
     LdatiParams P{};
     P.vox = vox; P.B = B; P.H = H; P.W = W; P.HW = H * W;
     P.fps = fps; P.VS = h.VS; P.VS2 = h.VS2; P.INV = h.INV; P.FPS = h.FPS;
     for (int c = 0; c < 9; ++c) { P.offt[c] = h.offt[c]; P.kbase[c] = h.kbase[c]; }
-    P.NK = h.NK; P.nbits = h.nbits;
+    P.NK = (int)h.NK; P.nbits = h.nbits;
     P.strategy = strategy;
     P.rng_mode = rng_mode; P.uniforms = uniforms; P.replay_max_n = replay_max_n;
     P.seed = seed; P.frame_base = frame_base;
@@ -832,44 +1212,69 @@ extern "C" int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps
     P.frame_ts_add = reinterpret_cast<const long long *>(frame_ts_add);
     P.ts = reinterpret_cast<long long *>(ts); P.x = x; P.y = y;
     P.p = reinterpret_cast<signed char *>(p);
+    P.packed = packed;
+    P.sweep_ok = h.sweep_ok ? 1 : 0;
     hipStream_t st = as_stream(stream);
-    V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ldati_emit_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)h.lds_bytes));
+    if (h.sweep_ok)
+        V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ldati_emit_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds_bytes));
     if (workspace != nullptr) {
-        // ---- bucketed path; segments with an oversized bucket fall through to the sweep kernel
-        V2CE_REQUIRE(total_events >= 0 && max_segment_events >= 0 && total_events < (1ll << 32),
-                     V2CE_ERR_BAD_ARG, "v2ce_ldati_emit: bad event counts");
-        const BucketPlan bp = bucket_plan(h, B, H, W, total_events, max_segment_events);
-        V2CE_REQUIRE(bp.shift >= 0, V2CE_ERR_UNSUPPORTED,
-                     "v2ce_ldati_emit: %d x %d pixels do not fit the 32-bit bucket record; pass workspace = NULL", H, W);
-        V2CE_REQUIRE(workspace_bytes >= bp.bytes, V2CE_ERR_WORKSPACE,
-                     "v2ce_ldati_emit: workspace %zu < %zu", workspace_bytes, bp.bytes);
-        V2CE_REQUIRE(bp.counters < (1ull << 31) && 2 * B <= 65535, V2CE_ERR_UNSUPPORTED,
-                     "v2ce_ldati_emit: too many buckets for one launch");
+        // ---- two-level path; segments with an oversized bucket fall through to the sweep kernel
+        V2CE_REQUIRE(tile_ws, V2CE_ERR_BAD_ARG, "v2ce_ldati_emit: the two-level path needs v2ce_ldati_count's tile workspace");
+        V2CE_REQUIRE(total_events >= 0 && max_segment_events >= 0 && max_tile_events >= 0, V2CE_ERR_BAD_ARG,
+                     "v2ce_ldati_emit: bad event counts");
+        const Plan pl = make_plan(h, B, H, W, total_events, max_segment_events, max_tile_events);
+        V2CE_REQUIRE(pl.ok, V2CE_ERR_UNSUPPORTED,
+                     "v2ce_ldati_emit: shape / density outside the two-level path (tiles %d, buckets %d, "
+                     "largest tile-bin %lld events); pass workspace = NULL", pl.T, pl.NB, (long long)max_tile_events);
+        V2CE_REQUIRE(workspace_bytes >= pl.bytes, V2CE_ERR_WORKSPACE, "v2ce_ldati_emit: workspace %zu < %zu",
+                     workspace_bytes, pl.bytes);
         unsigned *w = static_cast<unsigned *>(workspace);
-        P.key_shift = bp.shift; P.NB = bp.NB; P.PB = bp.PB;
-        P.blk_per_pol = bp.blk_per_pol; P.wg_per_frame = bp.wg_per_frame;
-        P.cbcount = w;
-        P.bofs = w + bp.counters;
-        P.wgtab = w + 2 * bp.counters;
-        P.seg_flag = reinterpret_cast<int *>(w + 2 * bp.counters + bp.tab);
-        P.temp = w + 2 * bp.counters + bp.tab + (size_t)B * 9;
-        P.cursor = nullptr;
-        V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ldati_bucket_pass_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bp.lds));
-        V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ldati_bucket_pass_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bp.lds));
-        dim3 grid(bp.blk_per_pol, 2 * B);
-        hipLaunchKernelGGL(ldati_bucket_pass_kernel<false>, grid, dim3(256), bp.lds, st, P);
-        hipLaunchKernelGGL(ldati_wgtab_scan_kernel, dim3((9 * bp.NB + 255) / 256, B), dim3(256), 0, st, P);
+        P.shift = pl.shift; P.NB = pl.NB; P.nb1 = pl.nb1; P.T = pl.T; P.tpp = pl.tpp; P.PB = pl.PB;
+        P.capA = pl.capA; P.cap2 = pl.cap2;
+        P.tile_off = static_cast<const unsigned *>(tile_ws) + (size_t)B * pl.T * 9;
+        P.cntT = w;
+        P.runoff = w + pl.n_tab;
+        P.btot = w + 2 * pl.n_tab;
+        P.bofs = P.btot + pl.n_bkt;
+        P.seg_flag = reinterpret_cast<int *>(P.bofs + pl.n_bkt);
+        P.status = P.seg_flag + (size_t)B * 9;
+        P.temp = reinterpret_cast<unsigned *>(P.status + 4);
+        V2CE_HIP_CHECK(hipMemsetAsync(P.status, 0, 4 * sizeof(int), st));
+        V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ldati_tile_pass_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_tile));
+        hipLaunchKernelGGL(ldati_tile_pass_kernel, dim3(pl.T, B), dim3(kTileThreads), pl.lds_tile, st, P);
         hipLaunchKernelGGL(ldati_bucket_scan_kernel, dim3(B * 9), dim3(256), 0, st, P);
-        hipLaunchKernelGGL(ldati_bucket_pass_kernel<true>, grid, dim3(256), bp.lds, st, P);
-        hipLaunchKernelGGL(ldati_bucket_sort_kernel, dim3((unsigned)bp.counters), dim3(256), 0, st, P);
+        if (packed) {
+            V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ldati_bucket_sort_kernel<true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_sort));
+            hipLaunchKernelGGL(ldati_bucket_sort_kernel<true>, dim3(pl.NB, B * 9), dim3(kSortThreads), pl.lds_sort, st, P);
+        } else {
+            V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ldati_bucket_sort_kernel<false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_sort));
+            hipLaunchKernelGGL(ldati_bucket_sort_kernel<false>, dim3(pl.NB, B * 9), dim3(kSortThreads), pl.lds_sort, st, P);
+        }
+    } else {
+        V2CE_REQUIRE(h.sweep_ok, V2CE_ERR_UNSUPPORTED,
+                     "v2ce_ldati_emit: fps=%g t0=%g needs %lld keys per bin; the sweep kernel's LDS histogram holds "
+                     "9600 -- pass a workspace (two-level path)", fps, t0, h.NK);
     }
     // segment-sweep kernel: every segment when there is no workspace, else only the flagged ones
-    hipLaunchKernelGGL(ldati_emit_kernel, dim3(B * 9), dim3(256), h.lds_bytes, st, P);
+    if (h.sweep_ok) hipLaunchKernelGGL(ldati_emit_kernel, dim3(B * 9), dim3(256), h.lds_bytes, st, P);
     V2CE_HIP_CHECK(hipGetLastError());
+    return V2CE_OK;
+}
+
+extern "C" int v2ce_ldati_status(const void *workspace, int B, int H, int W, double fps, double t0,
+                                 int64_t total_events, int64_t max_segment_events, int64_t max_tile_events,
+                                 const int32_t **status_dev) {
+    clear_error();
+    V2CE_REQUIRE(workspace && status_dev, V2CE_ERR_BAD_ARG, "v2ce_ldati_status: null pointer");
+    const HostScalars h = host_scalars(fps, t0);
+    const Plan pl = make_plan(h, B, H, W, total_events, max_segment_events, max_tile_events);
+    V2CE_REQUIRE(pl.ok, V2CE_ERR_UNSUPPORTED, "v2ce_ldati_status: no two-level plan for these arguments");
+    const unsigned *w = static_cast<const unsigned *>(workspace);
+    *status_dev = reinterpret_cast<const int32_t *>(w + 2 * pl.n_tab + 2 * pl.n_bkt + (size_t)B * 9);
     return V2CE_OK;
 }
 
@@ -886,6 +1291,22 @@ extern "C" int v2ce_events_pack(const int64_t *ts, const int16_t *x, const int16
     hipLaunchKernelGGL(events_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const long long *>(ts), x, y,
                        reinterpret_cast<const signed char *>(p), (long long)n, packed);
+    V2CE_HIP_CHECK(hipGetLastError());
+    return V2CE_OK;
+}
+
+extern "C" int v2ce_events_unpack(const uint8_t *packed, int64_t n, int64_t *ts, int16_t *x, int16_t *y,
+                                  int8_t *p, v2ce_stream_t stream) {
+    clear_error();
+    V2CE_REQUIRE(n >= 0, V2CE_ERR_BAD_ARG, "v2ce_events_unpack: negative n");
+    if (n == 0) return V2CE_OK;
+    V2CE_REQUIRE(ts && x && y && p && packed, V2CE_ERR_BAD_ARG, "v2ce_events_unpack: null pointer");
+    V2CE_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 3) == 0, V2CE_ERR_BAD_ARG,
+                 "v2ce_events_unpack: packed must be 4-byte aligned");
+    const long long blocks = (n + 255) / 256;
+    V2CE_REQUIRE(blocks < (1ll << 31), V2CE_ERR_UNSUPPORTED, "v2ce_events_unpack: too many events");
+    hipLaunchKernelGGL(events_unpack_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), packed,
+                       (long long)n, reinterpret_cast<long long *>(ts), x, y, reinterpret_cast<signed char *>(p));
     V2CE_HIP_CHECK(hipGetLastError());
     return V2CE_OK;
 }

@@ -22,8 +22,9 @@ ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 PRECISION_F32, PRECISION_F16X2 = 0, 1
 
 EXPORTS = [
-    "v2ce_version", "v2ce_last_error", "v2ce_ldati_count", "v2ce_ldati_scan",
-    "v2ce_ldati_lds_bytes", "v2ce_ldati_workspace_bytes", "v2ce_ldati_emit", "v2ce_events_pack", "v2ce_conv3d_fwd",
+    "v2ce_version", "v2ce_last_error", "v2ce_ldati_count", "v2ce_ldati_tile_ws_bytes", "v2ce_ldati_status",
+    "v2ce_ldati_lds_bytes", "v2ce_ldati_workspace_bytes", "v2ce_ldati_emit", "v2ce_events_pack", "v2ce_events_unpack",
+    "v2ce_conv3d_fwd",
     "v2ce_conv3d_variant", "v2ce_conv3d_variant_fused", "v2ce_pack_weights_f16x2", "v2ce_pack_weights_f16x2_bytes",
     "v2ce_pack_weights", "v2ce_sn_workspace_bytes", "v2ce_sn_power_iter", "v2ce_preprocess_pairs",
     "v2ce_voxelize_events", "v2ce_conv3d_fwd_pred", "v2ce_conv3d_fwd_sc", "v2ce_pack_pred_weights_f16x2", "v2ce_pack_pred_weights_f16x2_bytes",
@@ -65,15 +66,20 @@ def lib() -> ctypes.CDLL:
                                   ctypes.c_uint64, ctypes.c_size_t)
     L.v2ce_version.restype = ctypes.c_char_p
     L.v2ce_last_error.restype = ctypes.c_char_p
-    L.v2ce_ldati_count.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp]
-    L.v2ce_ldati_scan.argtypes = [vp, i32, vp, vp]
+    L.v2ce_ldati_count.argtypes = [vp, i32, i32, i32, i32, vp, sz, vp, vp, vp]
+    L.v2ce_ldati_tile_ws_bytes.argtypes = [i32, i32, i32]
+    L.v2ce_ldati_tile_ws_bytes.restype = sz
     L.v2ce_ldati_lds_bytes.argtypes = [f64, f64]
     L.v2ce_ldati_lds_bytes.restype = sz
     L.v2ce_ldati_emit.argtypes = [vp, i32, i32, i32, f64, f64, i32, i32, vp, i32, u64, i64, vp, vp,
-                                  vp, vp, vp, vp, i64, i64, vp, sz, vp]
-    L.v2ce_ldati_workspace_bytes.argtypes = [i32, i32, i32, f64, f64, i64, i64]
+                                  vp, vp, vp, vp, vp, i64, i64, i64, vp, vp, sz, vp]
+    L.v2ce_ldati_workspace_bytes.argtypes = [i32, i32, i32, f64, f64, i64, i64, i64]
     L.v2ce_ldati_workspace_bytes.restype = sz
+    L.v2ce_ldati_status.argtypes = [vp, i32, i32, i32, f64, f64, i64, i64, i64, ctypes.POINTER(vp)]
+    L.v2ce_ldati_status.restype = ctypes.c_int
     L.v2ce_events_pack.argtypes = [vp, vp, vp, vp, i64, vp, vp]
+    L.v2ce_events_unpack.argtypes = [vp, i64, vp, vp, vp, vp, vp]
+    L.v2ce_events_unpack.restype = ctypes.c_int
     L.v2ce_conv3d_fwd.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 13
     L.v2ce_pack_weights.argtypes = [vp, i32, i32, i32, vp, vp, vp]
     L.v2ce_pack_weights_f16x2.argtypes = [vp, i32, i32, i32, vp, vp, vp]
@@ -98,7 +104,7 @@ def lib() -> ctypes.CDLL:
     L.v2ce_sn_workspace_bytes.argtypes = [i32, i32]
     L.v2ce_sn_workspace_bytes.restype = sz
     L.v2ce_sn_power_iter.argtypes = [vp, vp, vp, i32, i32, vp, vp, sz, vp]
-    for name in ("v2ce_ldati_count", "v2ce_ldati_scan", "v2ce_ldati_emit", "v2ce_events_pack",
+    for name in ("v2ce_ldati_count", "v2ce_ldati_emit", "v2ce_events_pack",
                  "v2ce_conv3d_fwd", "v2ce_conv3d_variant", "v2ce_pack_weights", "v2ce_sn_power_iter"):
         getattr(L, name).restype = ctypes.c_int
     _LIB = L
