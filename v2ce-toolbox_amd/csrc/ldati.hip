@@ -32,20 +32,21 @@
 // operation (-ffp-contract=off, correctly rounded '/' and sqrt), in the reference's order.
 #include "common.h"
 
+#include <atomic>
 #include <cmath>
+#include <cstdlib>
 
 namespace v2ce {
 namespace {
 
 constexpr int kTilePix = 2048;        // pixels of one polarity plane per tile
-constexpr int kTileThreads = 512;     // 4 consecutive pixels per thread
-constexpr int kPixPerThread = kTilePix / kTileThreads;
 constexpr int kLocalBits = 11;        // log2(kTilePix)
+constexpr int kCountThreads = 512;
 constexpr int kMaxTiles = 512;        // tiles per frame (both polarities) the bucket sort indexes
 constexpr int kMaxNB = 512;           // coarse buckets per segment
 constexpr int kMaxShift = 8;          // fine-key bits
 constexpr int kCapTile = 15360;       // events of one (tile, bin) the tile pass can hold in LDS
-constexpr int kSortThreads = 512;
+constexpr int kSortThreads = 256;
 constexpr int kSortWaves = kSortThreads / 64;
 
 struct LdatiParams {
@@ -57,6 +58,7 @@ struct LdatiParams {
     float offt[9];     // f32(arange(0,1/fps,1/fps/9)[c]) + f32(t0)
     long long kbase[9];  // key = timestamp - kbase[c], clamped to [0, NK)
     int NK, nbits;
+    int ts32;          // every timestamp and key base fits int32: the f32 -> int conversions use 32 bits
     int strategy;      // V2CE_STRATEGY_*: NONE drops every multi-event voxel (LDATI.py:206-207,241)
     int rng_mode;
     const float *uniforms;
@@ -75,6 +77,7 @@ struct LdatiParams {
     int T, tpp;                   // tiles per frame (2*tpp), tiles per polarity plane
     int PB;                       // bits of a pixel index
     int capA, cap2;               // LDS capacities (records) of the tile pass / the bucket sort
+    int tbits;                    // binary-search steps over the tiles of a frame
     const unsigned *tile_off;     // [B][T][9] exclusive prefix of the tile counts inside the segment
     unsigned *cntT;               // [B*9][NB][T] records of tile t in the bucket
     unsigned *runoff;             // [B*9][NB][T] start of that run inside the tile's region
@@ -84,6 +87,7 @@ struct LdatiParams {
     int *seg_flag;                // [B*9] 1 = a bucket exceeds cap2 -> segment goes to the sweep kernel
     int *status;                  // [1] != 0: a flagged segment could not be swept (NK too large)
     int sweep_ok;
+    int dbg;                      // timing ablations (V2CE_LDATI_DBG), 0 in production
 };
 
 // ---- Philox4x32-10, counter (pixel, j>>2, p*9+c, frame), key = seed ---------------------------
@@ -179,6 +183,23 @@ __device__ __forceinline__ long long multi_ts(float k, float bb, float u, float 
     return (long long)t;
 }
 
+// the same, f32 -> i32 (bit-identical to the i64 conversion while |t| < 2^31: P.ts32) and the key
+__device__ __forceinline__ unsigned multi_key(float k, float bb, float u, float offt, int kbase32, const LdatiParams &P) {
+    float t;
+    if (k == 0.0f) {
+        t = (u / P.FPS) / 9.0f;
+    } else {
+        const float s = bb * bb + (2.0f * k) * u;
+        t = (-bb + __builtin_sqrtf(s)) / k;
+    }
+    t = t + offt;
+    t = t * 1e6f;
+    int key = (int)t - kbase32;
+    key = key < 0 ? 0 : key;
+    key = key >= P.NK ? P.NK - 1 : key;
+    return (unsigned)key;
+}
+
 __device__ __forceinline__ int key_of(long long T, long long kbase, int NK) {
     long long k = T - kbase;
     k = k < 0 ? 0 : k;
@@ -186,15 +207,93 @@ __device__ __forceinline__ int key_of(long long T, long long kbase, int NK) {
     return (int)k;
 }
 
-// ballot match-any: lanes with `has` and equal `key` form a peer group
-__device__ __forceinline__ unsigned long long match_key(bool has, int key, int nbits) {
-    unsigned long long peers = __ballot(has);
+// ballot match-any: lanes of `has_mask` with equal `key` form a peer group.  Returns the rank of
+// this lane inside its group (peers on lower lanes) and the group size.  ~5 VALU per key bit.
+__device__ __forceinline__ unsigned match_rank(unsigned key, int nbits, unsigned long long has_mask,
+                                               unsigned &npeers) {
+    unsigned mlo = 0, mhi = 0;                           // lanes that differ from this lane in some bit
     for (int b = 0; b < nbits; ++b) {
-        const bool bit = (key >> b) & 1;
-        const unsigned long long m = __ballot(has && bit);
-        peers &= bit ? m : ~m;
+        const int sel = __builtin_amdgcn_sbfe((int)key, b, 1);          // 0 or -1
+        const unsigned long long m = __ballot(sel != 0);
+        mlo |= (unsigned)m ^ (unsigned)sel;
+        mhi |= (unsigned)(m >> 32) ^ (unsigned)sel;
     }
-    return peers;
+    const unsigned plo = (unsigned)has_mask & ~mlo, phi = (unsigned)(has_mask >> 32) & ~mhi;
+    npeers = (unsigned)__popc(plo) + (unsigned)__popc(phi);
+    return __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+}
+
+// One 64-record batch of a stable counting sort: `slot` = this wave's running base of the lane's
+// bin (LDS, owned by the wave).  Returns base + rank; the last peer advances the base.
+__device__ __forceinline__ unsigned take_slots(bool has, unsigned key, int nbits, unsigned *slot) {
+    unsigned npeers;
+    const unsigned rank = match_rank(key, nbits, __ballot(has), npeers);
+    unsigned pos = 0;
+    if (has) {
+        const unsigned base = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __builtin_amdgcn_wave_barrier();
+        if (rank + 1 == npeers) __hip_atomic_store(slot, base + npeers, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        pos = base + rank;
+    }
+    __builtin_amdgcn_wave_barrier();
+    return pos;
+}
+
+// ---- ranks straight from LDS atomics ------------------------------------------------------------
+// On gfx950 one wave-instruction of ds_add_rtn_u32 serves the lanes that hit the same LDS word in
+// ascending lane order (tools/micro/lds_atomic_order.hip: 0 exceptions in 5.4e9 returned values),
+// so the returned value IS the stable rank and the ballot match-any (~4 VALU per key bit and batch)
+// is not needed.  That order is not an architectural promise: a probe kernel checks it on every
+// device the library runs on (enqueued once, in front of the first count call) and only then sets
+// g_lds_order_ok; until / unless it does, the kernels use the ballot ranks (identical results).
+__device__ int g_lds_order_ok = 0;
+__device__ unsigned g_lds_probe_bad = 0, g_lds_probe_done = 0;
+
+__global__ __launch_bounds__(256) void ldati_lds_order_probe_kernel(int iters) {
+    __shared__ unsigned tab[4][512];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    unsigned s = (blockIdx.x * 256 + threadIdx.x) * 2654435761u + 12345u;
+    unsigned nbad = 0;
+    for (int it = 0; it < iters; ++it) {
+        for (int i = lane; i < 512; i += 64) tab[wid][i] = 7u * i;
+        __builtin_amdgcn_wave_barrier();
+        s = s * 1664525u + 1013904223u;
+        const unsigned range = 1u << (it % 10);
+        const unsigned key = (s >> 9) & (range - 1u);
+        const bool act = ((s >> 5) & 7u) != 0u || (it & 1);
+        unsigned got = 0;
+        if (act) got = atomicAdd(&tab[wid][key], 1u);
+        unsigned np;
+        const unsigned want = 7u * key + match_rank(key, 9, __ballot(act), np);
+        if (act && got != want) ++nbad;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (nbad) atomicAdd(&g_lds_probe_bad, nbad);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned done = atomicAdd(&g_lds_probe_done, 1u);
+        if (done == gridDim.x - 1) {
+            __threadfence();
+            g_lds_order_ok = atomicAdd(&g_lds_probe_bad, 0u) == 0u ? 1 : 0;
+        }
+    }
+}
+
+// slot of one record in a stable counting sort batch: LDS-atomic rank when the device passed the
+// probe, ballot rank otherwise
+__device__ __forceinline__ unsigned take_slot(bool atomic_order, bool has, unsigned key, int nbits, unsigned *slot) {
+    if (atomic_order) return has ? atomicAdd(slot, 1u) : 0u;
+    return take_slots(has, key, nbits, slot);
+}
+
+// px / W for px < 2^24 (exact in f32) without an integer division
+__device__ __forceinline__ unsigned div_small(unsigned px, unsigned W, float rcpW) {
+    unsigned q = (unsigned)((float)px * rcpW);
+    const int r = (int)(px - q * W);
+    q += (r >= (int)W) ? 1u : 0u;
+    q -= (r < 0) ? 1u : 0u;
+    return q;
 }
 
 __device__ __forceinline__ void store_packed_bytes(unsigned char *dst, long long t, unsigned xx,
@@ -239,10 +338,36 @@ __device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned *part, 
     return part[wid] + incl - v;
 }
 
+// the same for two values per thread with one pair of barriers; `part` = 2*(NW+1) LDS words
+template <int NW>
+__device__ __forceinline__ void block_excl_scan2(unsigned a, unsigned e, unsigned *part, unsigned &a_ex,
+                                                 unsigned &e_ex, unsigned &a_tot, unsigned &e_tot) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const unsigned ia = wave_incl_scan(a, lane), ie = wave_incl_scan(e, lane);
+    if (lane == 63) { part[wid] = ia; part[NW + 1 + wid] = ie; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        unsigned *q = part + threadIdx.x * (NW + 1);
+        unsigned run = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const unsigned t = q[i];
+            q[i] = run;
+            run += t;
+        }
+        q[NW] = run;
+    }
+    __syncthreads();
+    a_tot = part[NW];
+    e_tot = part[2 * NW + 1];
+    a_ex = part[wid] + ia - a;
+    e_ex = part[NW + 1 + wid] + ie - e;
+}
+
 // ---------------------------------------------------------------------------------------------
 // count: workgroup per (frame, tile); events per (tile, bin); max count per voxel
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kTileThreads) void ldati_count_tiles_kernel(
+__global__ __launch_bounds__(kCountThreads) void ldati_count_tiles_kernel(
     const float *__restrict__ vox, int HW, int tpp, int strategy, unsigned *__restrict__ tc,
     unsigned long long *stats) {
     const int t = blockIdx.x, b = blockIdx.y, T = 2 * tpp;
@@ -254,8 +379,8 @@ __global__ __launch_bounds__(kTileThreads) void ldati_count_tiles_kernel(
     for (int i = 0; i < 9; ++i) cnt[i] = 0;
     int mx = 0;
 #pragma unroll
-    for (int q = 0; q < kPixPerThread; ++q) {
-        const int px = x0 + q * kTileThreads + threadIdx.x;      // any order: only sums are formed
+    for (int q = 0; q < kTilePix / kCountThreads; ++q) {
+        const int px = x0 + q * kCountThreads + threadIdx.x;      // any order: only sums are formed
         if (px < HW) {
             float yv[10];
 #pragma unroll
@@ -274,7 +399,7 @@ __global__ __launch_bounds__(kTileThreads) void ldati_count_tiles_kernel(
             }
         }
     }
-    __shared__ int red[kTileThreads / 64][10];
+    __shared__ int red[kCountThreads / 64][10];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
@@ -293,12 +418,12 @@ __global__ __launch_bounds__(kTileThreads) void ldati_count_tiles_kernel(
     if (threadIdx.x < 9) {
         unsigned s = 0;
 #pragma unroll
-        for (int w = 0; w < kTileThreads / 64; ++w) s += (unsigned)red[w][threadIdx.x];
+        for (int w = 0; w < kCountThreads / 64; ++w) s += (unsigned)red[w][threadIdx.x];
         tc[((long long)b * T + t) * 9 + threadIdx.x] = s;
     } else if (threadIdx.x == 9) {
         int m = 0;
 #pragma unroll
-        for (int w = 0; w < kTileThreads / 64; ++w) m = red[w][9] > m ? red[w][9] : m;
+        for (int w = 0; w < kCountThreads / 64; ++w) m = red[w][9] > m ? red[w][9] : m;
         if (m > 0) atomicMax(&stats[0], (unsigned long long)m);
     }
 }
@@ -378,17 +503,9 @@ __device__ __forceinline__ void handle_event(bool has, long long T, int px, int 
         if (has) atomicAdd(slot, 1u);
         return;
     }
-    const unsigned long long peers = match_key(has, key, P.nbits);
+    const unsigned slot_pos = take_slots(has, (unsigned)key, P.nbits, slot);
     if (has) {
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        const unsigned rank = (unsigned)__popcll(peers & lt);
-        const unsigned npeer = (unsigned)__popcll(peers);
-        const bool leader = lane == 63 - __clzll((long long)peers);
-        volatile unsigned *vs = slot;
-        const unsigned base = *vs;                 // every peer reads the running base ...
-        __builtin_amdgcn_wave_barrier();
-        if (leader) *vs = base + npeer;            // ... then the highest peer advances it
-        const long long pos = seg_lo + (long long)base + rank;
+        const long long pos = seg_lo + (long long)slot_pos;
         const int yy = px / P.W;
         if (P.packed) {
             store_packed_bytes(P.packed + pos * 13, T + ts_add, (unsigned)(px - yy * P.W) & 0xFFFFu,
@@ -400,7 +517,6 @@ __device__ __forceinline__ void handle_event(bool has, long long T, int px, int 
             P.p[pos] = pol;
         }
     }
-    __builtin_amdgcn_wave_barrier();
 }
 
 template <bool RANK>
@@ -570,18 +686,21 @@ __global__ __launch_bounds__(256) void ldati_emit_kernel(LdatiParams P) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// tile pass: workgroup per (frame, tile), 512 threads, 4 consecutive pixels per thread, bin by bin
+// tile pass: workgroup per (frame, tile), NT threads, PPT consecutive pixels per thread, bin by bin
 // ---------------------------------------------------------------------------------------------
 // LDS map (dynamic): S [capA] u32 | O [capA + 2048] u32 (aliased by the unit tables while the
-// timestamps are computed) | PT [2048] {k, bb} | hist [8][NB] u32 | misc
+// timestamps are computed) | PT [2048] {k, bb} | hist [NW][NB] u32 | misc
 extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
 
-__global__ __launch_bounds__(kTileThreads) void ldati_tile_pass_kernel(LdatiParams P) {
+template <int NT, int PPT>
+__global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
+    static_assert(NT * PPT == kTilePix, "tile geometry");
     const int t = blockIdx.x, b = blockIdx.y;
     const int pidx = t < P.tpp ? 1 : 0;
     const int x0 = (t < P.tpp ? t : t - P.tpp) * kTilePix;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    constexpr int NW = kTileThreads / 64;
+    constexpr int NW = NT / 64;
+    const bool atomic_order = __builtin_amdgcn_readfirstlane(g_lds_order_ok) != 0;
 
     unsigned *S = reinterpret_cast<unsigned *>(tile_smem);
     unsigned *O = S + P.capA;
@@ -593,15 +712,15 @@ __global__ __launch_bounds__(kTileThreads) void ldati_tile_pass_kernel(LdatiPara
 
     const float *plane0 = P.vox + (long long)(b * 2 + pidx) * 10 * P.HW;
     const unsigned frame = (unsigned)(P.frame_base + b);
-    const int lpx0 = tid * kPixPerThread;              // first local pixel of this thread
+    const int lpx0 = tid * PPT;                        // first local pixel of this thread
     const float eps = 1e-6f;
 
     // rolling relocation state per pixel: counts of bins c-1, c, c+1; debts after bins c, c+1
-    int nprev[kPixPerThread], ncur[kPixPerThread], nnext[kPixPerThread];
-    float dcur[kPixPerThread], dnext[kPixPerThread];
-    bool valid[kPixPerThread];
+    int nprev[PPT], ncur[PPT], nnext[PPT];
+    float dcur[PPT], dnext[PPT];
+    bool valid[PPT];
 #pragma unroll
-    for (int q = 0; q < kPixPerThread; ++q) {
+    for (int q = 0; q < PPT; ++q) {
         const int px = x0 + lpx0 + q;
         valid[q] = px < P.HW;
         const float y0 = valid[q] ? plane0[px] : 0.0f;
@@ -619,18 +738,18 @@ __global__ __launch_bounds__(kTileThreads) void ldati_tile_pass_kernel(LdatiPara
 
     for (int c = 0; c < 9; ++c) {
         // prefetch the voxels of bin c+2 (and bin 9 with it when c+2 == 8)
-        float ynn[kPixPerThread], y9[kPixPerThread];
+        float ynn[PPT], y9[PPT];
 #pragma unroll
-        for (int q = 0; q < kPixPerThread; ++q) {
+        for (int q = 0; q < PPT; ++q) {
             const int px = x0 + lpx0 + q;
             ynn[q] = (c + 2 <= 8 && valid[q]) ? plane0[(long long)(c + 2) * P.HW + px] : 0.0f;
             y9[q] = (c + 2 == 8 && valid[q]) ? plane0[(long long)9 * P.HW + px] : 0.0f;
         }
         // ---- P1: classify ------------------------------------------------------------------
         unsigned a_tot = 0, e_tot = 0;                  // per thread: singles | units << 12, multi events
-        unsigned a_q[kPixPerThread], e_q[kPixPerThread];
+        unsigned a_q[PPT], e_q[PPT];
 #pragma unroll
-        for (int q = 0; q < kPixPerThread; ++q) {
+        for (int q = 0; q < PPT; ++q) {
             const int n = valid[q] ? ncur[q] : 0;
             const bool single = n == 1;
             const bool multi = n >= 2 && P.strategy != V2CE_STRATEGY_NONE;
@@ -639,17 +758,17 @@ __global__ __launch_bounds__(kTileThreads) void ldati_tile_pass_kernel(LdatiPara
             a_tot += (single ? 1u : 0u) + (multi ? ((unsigned)(n + 3) >> 2) << 12 : 0u);
             e_tot += multi ? (unsigned)n : 0u;
         }
-        // ---- P2: workgroup scans in pixel order (thread-major, pixel-minor) ----------------
-        unsigned A_all, E_all;
-        const unsigned a_base = block_excl_scan<NW>(a_tot, part, &A_all);
-        const unsigned e_base = block_excl_scan<NW>(e_tot, part + NW + 1, &E_all);
+        // ---- P2: workgroup scans in pixel order (thread-major, pixel-minor).  Their first barrier
+        // also separates the previous bin's reads of O (P7) from this bin's unit tables.
+        unsigned a_base, e_base, A_all, E_all;
+        block_excl_scan2<NW>(a_tot, e_tot, part, a_base, e_base, A_all, E_all);
         const unsigned Ns = A_all & 0xFFFu, Um = A_all >> 12, Nm = E_all;
         const unsigned N = Ns + Nm;
         uint2 *MU = SL + Ns;
-        for (int i = tid; i < NW * P.NB; i += kTileThreads) hist[i] = 0;
+        for (int i = tid; i < NW * P.NB; i += NT) hist[i] = 0;
         // ---- P3: unit tables ----------------------------------------------------------------
 #pragma unroll
-        for (int q = 0; q < kPixPerThread; ++q) {
+        for (int q = 0; q < PPT; ++q) {
             const int n = valid[q] ? ncur[q] : 0;
             const unsigned local = (unsigned)(lpx0 + q);
             const unsigned ab = a_base + a_q[q];
@@ -669,13 +788,19 @@ __global__ __launch_bounds__(kTileThreads) void ldati_tile_pass_kernel(LdatiPara
             }
         }
         __syncthreads();
-        // ---- P4: timestamps, once, every lane busy -------------------------------------------
-        for (unsigned q = tid; q < Ns; q += kTileThreads) {
+        // ---- P4: timestamps, once, every lane busy; each record also counts in the histogram of
+        // the wave that will rank it (contiguous chunks of S, L records per wave) -----------------
+        const unsigned L = ((N + NT - 1) / NT) * 64;
+        const float invL = 1.0f / (float)(L ? L : 64u);
+        for (unsigned q = tid; q < Ns; q += NT) {
             const uint2 e = SL[q];
             const long long Tq = single_ts(__uint_as_float(e.x), P.fps, P.offt[c]);
-            S[q] = ((unsigned)key_of(Tq, P.kbase[c], P.NK) << 12) | e.y;
+            const unsigned key = (unsigned)key_of(Tq, P.kbase[c], P.NK);
+            S[q] = (key << 12) | e.y;
+            const unsigned w = (unsigned)(((float)q + 0.5f) * invL);
+            atomicAdd(&hist[__umul24(w, (unsigned)P.NB) + (key >> P.shift)], 1u);
         }
-        for (unsigned q = tid; q < Um; q += kTileThreads) {
+        for (unsigned q = tid; q < Um; q += NT) {
             const uint2 e = MU[q];
             const unsigned local = e.x & (kTilePix - 1), jb = (e.x >> kLocalBits) & 0x1FFFFu, cnt = e.x >> 28;
             const float2 kb = PT[local];
@@ -697,19 +822,17 @@ __global__ __launch_bounds__(kTileThreads) void ldati_tile_pass_kernel(LdatiPara
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 if ((unsigned)s < cnt) {
-                    const long long Tq = multi_ts(kb.x, kb.y, u[s], P.offt[c], P);
-                    S[Ns + e.y + s] = ((unsigned)key_of(Tq, P.kbase[c], P.NK) << 12) | (1u << kLocalBits) | local;
+                    const unsigned key = P.ts32 ? multi_key(kb.x, kb.y, u[s], P.offt[c], (int)P.kbase[c], P)
+                                                : (unsigned)key_of(multi_ts(kb.x, kb.y, u[s], P.offt[c], P), P.kbase[c], P.NK);
+                    const unsigned pos = Ns + e.y + s;
+                    S[pos] = (key << 12) | (1u << kLocalBits) | local;
+                    const unsigned w = (unsigned)(((float)pos + 0.5f) * invL);
+                    atomicAdd(&hist[__umul24(w, (unsigned)P.NB) + (key >> P.shift)], 1u);
                 }
             }
         }
         __syncthreads();
-        // ---- P5: per-wave histograms of the coarse bucket over contiguous chunks of S ----------
-        const unsigned L = ((N + kTileThreads - 1) / kTileThreads) * 64;      // chunk per wave
-        const unsigned lo = wid * L, hi = (lo + L < N) ? lo + L : N;
-        for (unsigned i = lo + lane; i < hi; i += 64)
-            atomicAdd(&hist[wid * P.NB + (S[i] >> (12 + P.shift))], 1u);
-        __syncthreads();
-        // bucket-major, wave-minor exclusive scan; the tile's bucket counts and run offsets
+        // ---- P5: bucket-major, wave-minor exclusive scan; the tile's bucket counts and run offsets
         {
             unsigned run = 0;
             if (tid < P.NB) {
@@ -732,34 +855,27 @@ __global__ __launch_bounds__(kTileThreads) void ldati_tile_pass_kernel(LdatiPara
         }
         __syncthreads();
         // ---- P6: stable ranks: ballot match-any inside a 64-record batch, running base in LDS ----
+        const unsigned lo = wid * L, hi = (lo + L < N) ? lo + L : N;
         for (unsigned i0 = lo; i0 < hi; i0 += 64) {
             const unsigned i = i0 + lane;
             const bool has = i < hi;
             const unsigned rec = has ? S[i] : 0u;
-            const int bucket = (int)(rec >> (12 + P.shift));
-            const unsigned long long peers = match_key(has, bucket, P.nb1);
+            const unsigned bucket = rec >> (12 + P.shift);
+            const unsigned pos = take_slot(atomic_order, has, bucket, P.nb1, &hist[wid * P.NB + bucket]);
             if (has) {
-                const unsigned long long lt = (1ull << lane) - 1ull;
-                const unsigned rank = (unsigned)__popcll(peers & lt);
-                unsigned *slot = &hist[wid * P.NB + bucket];
-                const unsigned base = *reinterpret_cast<volatile unsigned *>(slot);
-                __builtin_amdgcn_wave_barrier();
-                if (lane == 63 - __clzll((long long)peers))
-                    *reinterpret_cast<volatile unsigned *>(slot) = base + (unsigned)__popcll(peers);
                 const unsigned fine = (rec >> 12) & ((1u << P.shift) - 1u);
-                O[base + rank] = (fine << 12) | (rec & 0xFFFu);
+                O[pos] = (fine << 12) | (rec & 0xFFFu);
             }
-            __builtin_amdgcn_wave_barrier();
         }
         __syncthreads();
         // ---- P7: the tile's records of this bin leave as one contiguous run ---------------------
         {
             unsigned *dst = P.temp + P.seg_offsets[b * 9 + c] + P.tile_off[((long long)b * P.T + t) * 9 + c];
-            for (unsigned i = tid; i < N; i += kTileThreads) dst[i] = O[i];
+            for (unsigned i = tid; i < N; i += NT) dst[i] = O[i];
         }
         // ---- advance the relocation recurrence to bin c+2 ---------------------------------------
 #pragma unroll
-        for (int q = 0; q < kPixPerThread; ++q) {
+        for (int q = 0; q < PPT; ++q) {
             nprev[q] = ncur[q];
             ncur[q] = nnext[q];
             dcur[q] = dnext[q];
@@ -772,7 +888,7 @@ __global__ __launch_bounds__(kTileThreads) void ldati_tile_pass_kernel(LdatiPara
                 nnext[q] = ni;
             }
         }
-        __syncthreads();                                // S / O / hist are reused by the next bin
+        // no barrier here: the next bin touches O / hist / S only behind the barriers of its scans
     }
 }
 
@@ -808,14 +924,14 @@ __global__ __launch_bounds__(256) void ldati_bucket_scan_kernel(LdatiParams P) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// bucket sort: workgroup per (segment, bucket).  LDS map (dynamic):
-//   In [cap2] u32 | Out [cap2] u32 | hist [8][bins] u32 | tcnt/toff/tpre [T] | stage [512*13] u32
-// (stage aliases In when In is large enough)
+// bucket sort: workgroup (256 threads) per (segment, bucket), at most K records per thread, kept in
+// registers between the histogram and the rank phase.  LDS map (dynamic):
+//   Out [256*K] u32 | hist [4][bins] u32 | tcnt/toff [T] | tpre [T+1] | part | stage [256*13] u32
 // ---------------------------------------------------------------------------------------------
 extern __shared__ __attribute__((aligned(16))) unsigned char sort_smem[];
 
-template <bool PACKED>
-__global__ __launch_bounds__(kSortThreads) void ldati_bucket_sort_kernel(LdatiParams P) {
+template <bool PACKED, int K>
+__global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(LdatiParams P) {
     const int bucket = blockIdx.x, seg = blockIdx.y;
     const long long bi = (long long)seg * P.NB + bucket;
     const unsigned N = P.btot[bi];
@@ -823,52 +939,99 @@ __global__ __launch_bounds__(kSortThreads) void ldati_bucket_sort_kernel(LdatiPa
     const int b = seg / 9, c = seg - b * 9;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int bins = 4 << P.shift, nb2 = P.shift + 2;
+    const bool atomic_order = __builtin_amdgcn_readfirstlane(g_lds_order_ok) != 0;
 
-    unsigned *In = reinterpret_cast<unsigned *>(sort_smem);
-    unsigned *Out = In + P.cap2;
-    unsigned *hist = Out + P.cap2;
-    unsigned *tcnt = hist + kSortWaves * bins;
-    unsigned *toff = tcnt + P.T;
-    unsigned *tpre = toff + P.T;
-    unsigned *part = tpre + P.T;                         // [kSortWaves + 1]
-    unsigned *stage = (P.cap2 >= kSortThreads * 13) ? In : part + kSortWaves + 1;
+    unsigned *Out = reinterpret_cast<unsigned *>(sort_smem);
+    unsigned *hist = Out + kSortThreads * K;             // [kSortWaves][bins]
+    unsigned *ne_src = hist + kSortWaves * bins;         // [T] per non-empty tile: source index - flat index
+    unsigned *ne_info = ne_src + P.T;                    // [T] (polarity category << PB) | first pixel of the tile
+    unsigned *bits = ne_info + P.T;                      // [K*8] bit i = a tile's run starts at flat index i
+    unsigned *wpre = bits + K * 8;                       // [K*8] run starts below each 32-index word
+    unsigned *part = wpre + K * 8;                       // [kSortWaves + 1]
+    unsigned *stage = hist;                              // [256 * 13], 16-byte aligned; aliases the tables (dead in S5)
+    constexpr int kWords = K * 8;                        // 256*K / 32
 
-    // S0: this bucket's run in every tile, exclusive prefix over the tiles
-    {
-        unsigned v = 0;
-        if (tid < P.T) {
-            v = P.cntT[bi * P.T + tid];
-            tcnt[tid] = v;
-            toff[tid] = P.runoff[bi * P.T + tid] + P.tile_off[((long long)b * P.T + tid) * 9 + c];
+    // S0: this bucket's run in every tile (two consecutive tiles per thread); exclusive prefix of
+    // (records | non-empty << 16) over the tiles
+    unsigned cv[2] = {0u, 0u}, ov[2] = {0u, 0u};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int tt = 2 * tid + q;
+        if (tt < P.T) {
+            cv[q] = P.cntT[bi * P.T + tt];
+            ov[q] = P.runoff[bi * P.T + tt] + P.tile_off[((long long)b * P.T + tt) * 9 + c];
         }
-        unsigned tot;
-        const unsigned ex = block_excl_scan<kSortWaves>(v, part, &tot);
-        if (tid < P.T) tpre[tid] = ex;
     }
+    if (tid < kWords) bits[tid] = 0;
     for (int i = tid; i < kSortWaves * bins; i += kSortThreads) hist[i] = 0;
-    __syncthreads();
-    // S1: gather the runs in tile order (negative tiles first, each in pixel order) and widen the
-    // records to (fine | category | global pixel)
     {
-        const unsigned *seg_temp = P.temp + P.seg_offsets[seg];
-        for (int tt = wid; tt < P.T; tt += kSortWaves) {
-            const unsigned n = tcnt[tt];
-            const unsigned *src = seg_temp + toff[tt];
-            const unsigned dst = tpre[tt];
-            const unsigned pxb = (unsigned)(tt < P.tpp ? tt : tt - P.tpp) * kTilePix;
-            const unsigned catb = tt < P.tpp ? 0u : 2u;
-            for (unsigned i = lane; i < n; i += 64) {
-                const unsigned r = src[i];
-                const unsigned cat = catb + ((r >> kLocalBits) & 1u);
-                In[dst + i] = ((r >> 12) << (2 + P.PB)) | (cat << P.PB) | (pxb + (r & (kTilePix - 1)));
+        const unsigned f0 = cv[0] ? 0x10000u : 0u, f1 = cv[1] ? 0x10000u : 0u;
+        unsigned tot;
+        unsigned ex = block_excl_scan<kSortWaves>((cv[0] | f0) + (cv[1] | f1), part, &tot);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (cv[q]) {
+                const unsigned tt = 2u * tid + q, pre = ex & 0xFFFFu, j = ex >> 16;
+                const bool neg = tt < (unsigned)P.tpp;
+                ne_src[j] = ov[q] - pre;
+                ne_info[j] = ((neg ? 0u : 2u) << P.PB) | ((neg ? tt : tt - (unsigned)P.tpp) * kTilePix);
+                atomicOr(&bits[pre >> 5], 1u << (pre & 31u));
+                ex += cv[q] | 0x10000u;
             }
         }
     }
     __syncthreads();
-    // S2: per-wave histograms of (fine, category) over contiguous chunks
+    {
+        unsigned tot;
+        const unsigned ex = block_excl_scan<kSortWaves>(tid < kWords ? (unsigned)__popc(bits[tid]) : 0u, part, &tot);
+        if (tid < kWords) wpre[tid] = ex;
+    }
+    __syncthreads();
+    if (P.dbg & 4) return;
+    // S1: gather.  The bucket's records are the tiles' runs in tile order (negative tiles first,
+    // each in pixel order); wave w owns the contiguous flat range [lo, hi).  The tile of a flat
+    // index = number of run starts at or below it (bit table + word prefix); every lane issues all
+    // its loads before the first use.
     const unsigned L = ((N + kSortThreads - 1) / kSortThreads) * 64;
     const unsigned lo = wid * L, hi = (lo + L < N) ? lo + L : N;
-    for (unsigned i = lo + lane; i < hi; i += 64) atomicAdd(&hist[wid * bins + (In[i] >> P.PB)], 1u);
+    const unsigned *seg_temp = P.temp + P.seg_offsets[seg];
+    unsigned rec[K];
+    unsigned tinfo[K];
+    {
+        // branch-free and staged, so that every stage's LDS reads / global loads are issued back to
+        // back and waited for once: indices past the wave's range are clamped (their loads are valid
+        // and ignored)
+        unsigned bw[K], pw[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const unsigned i = min(lo + 64u * k + lane, N - 1u);
+            bw[k] = bits[i >> 5];
+            pw[k] = wpre[i >> 5];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const unsigned i = min(lo + 64u * k + lane, N - 1u);
+            const unsigned j = pw[k] + (unsigned)__popc(bw[k] & (0xFFFFFFFFu >> (31u - (i & 31u)))) - 1u;
+            tinfo[k] = ne_info[j];
+            bw[k] = ne_src[j];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const unsigned i = min(lo + 64u * k + lane, N - 1u);
+            rec[k] = (P.dbg & 2) ? i * 2654435761u : seg_temp[bw[k] + i];
+        }
+    }
+    if (P.dbg & 8) return;
+    // S2: widen to (fine | category | global pixel); per-wave histograms of (fine, category)
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const unsigned i = lo + 64u * k + lane;
+        if (i < hi) {
+            const unsigned r = rec[k];
+            rec[k] = ((r >> 12) << (2 + P.PB)) | (tinfo[k] + (((r >> kLocalBits) & 1u) << P.PB) + (r & (kTilePix - 1)));
+            atomicAdd(&hist[wid * bins + (rec[k] >> P.PB)], 1u);
+        }
+    }
     __syncthreads();
     // S3: bin-major, wave-minor exclusive scan
     {
@@ -891,35 +1054,32 @@ __global__ __launch_bounds__(kSortThreads) void ldati_bucket_sort_kernel(LdatiPa
     }
     __syncthreads();
     // S4: stable ranks
-    for (unsigned i0 = lo; i0 < hi; i0 += 64) {
-        const unsigned i = i0 + lane;
-        const bool has = i < hi;
-        const unsigned rec = has ? In[i] : 0u;
-        const int bin = (int)(rec >> P.PB);
-        const unsigned long long peers = match_key(has, bin, nb2);
-        if (has) {
-            const unsigned long long lt = (1ull << lane) - 1ull;
-            unsigned *slot = &hist[wid * bins + bin];
-            const unsigned base = *reinterpret_cast<volatile unsigned *>(slot);
-            __builtin_amdgcn_wave_barrier();
-            if (lane == 63 - __clzll((long long)peers))
-                *reinterpret_cast<volatile unsigned *>(slot) = base + (unsigned)__popcll(peers);
-            Out[base + (unsigned)__popcll(peers & lt)] = rec;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (lo + 64u * k < hi) {                         // wave-uniform
+            const unsigned i = lo + 64u * k + lane;
+            const bool has = i < hi;
+            const unsigned r = rec[k];
+            const unsigned bin = r >> P.PB;
+            const unsigned pos = take_slot(atomic_order, has, bin, nb2, &hist[wid * bins + bin]);
+            if (has) Out[pos] = r;
         }
-        __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
+    if (P.dbg & 1) return;
     // S5: decode and write the final records
     const long long g0 = P.seg_offsets[seg] + P.bofs[bi];                 // first global record
     const long long tbase = P.kbase[c] + ((long long)bucket << P.shift) +
                             (P.frame_ts_add ? P.frame_ts_add[b] : 0);
     const unsigned pmask = (1u << P.PB) - 1u;
     const unsigned W = (unsigned)P.W;
+    const float rcpW = 1.0f / (float)W;
+    const bool small = P.HW < (1 << 24);                 // pixel indices exact in f32
     if (!PACKED) {
         for (unsigned i = tid; i < N; i += kSortThreads) {
             const unsigned r = Out[i];
             const unsigned px = r & pmask, cat = (r >> P.PB) & 3u, fine = r >> (P.PB + 2);
-            const unsigned yy = px / W;
+            const unsigned yy = small ? div_small(px, W, rcpW) : px / W;
             P.ts[g0 + i] = tbase + fine;
             P.x[g0 + i] = (short)(px - yy * W);
             P.y[g0 + i] = (short)yy;
@@ -927,58 +1087,56 @@ __global__ __launch_bounds__(kSortThreads) void ldati_bucket_sort_kernel(LdatiPa
         }
         return;
     }
-    // groups of four records starting at a global record index that is a multiple of 4 are
-    // 13 whole dwords (52 bytes); only the first and the last group of a bucket can be partial
+    // Four records starting at a global record index that is a multiple of 4 are 13 whole dwords
+    // (52 bytes).  Per iteration the workgroup assembles 256 such groups (13 312 bytes, starting at a
+    // 16-byte aligned global address) in LDS and copies the image out 16 bytes per lane; only the
+    // two 16-byte pieces at the ends of the bucket are written byte by byte.
     const long long gN = g0 + N;
-    const long long G0 = g0 >> 2, G1 = (gN + 3) >> 2;
-    unsigned *out32 = reinterpret_cast<unsigned *>(P.packed);
+    const long long G0 = (g0 >> 2) & ~3ll, G1 = (gN + 3) >> 2;         // G0 % 4 == 0: 52*G0 % 16 == 0
+    const long long B0 = 13 * g0, B1 = 13 * gN;                         // this bucket's bytes
     for (long long Ga = G0; Ga < G1; Ga += kSortThreads) {
         const long long G = Ga + tid;
         if (G < G1) {
             unsigned A[4], Bh[4], C[4], D[4];
-            bool ok[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const long long i = 4 * G + q - g0;
-                ok[q] = i >= 0 && i < (long long)N;
-                const unsigned r = ok[q] ? Out[i] : 0u;
+                const unsigned r = (i >= 0 && i < (long long)N) ? Out[i] : 0u;
                 const unsigned px = r & pmask, cat = (r >> P.PB) & 3u, fine = r >> (P.PB + 2);
-                const unsigned yy = px / W;
+                const unsigned yy = small ? div_small(px, W, rcpW) : px / W;
                 const long long tq = tbase + fine;
                 A[q] = (unsigned)tq;
                 Bh[q] = (unsigned)((unsigned long long)tq >> 32);
                 C[q] = ((px - yy * W) & 0xFFFFu) | (yy << 16);
                 D[q] = cat >> 1;
             }
-            if (ok[0] && ok[1] && ok[2] && ok[3]) {
-                unsigned *d = stage + tid * 13;
-                d[0] = A[0]; d[1] = Bh[0]; d[2] = C[0];
-                d[3] = D[0] | (A[1] << 8);
-                d[4] = (A[1] >> 24) | (Bh[1] << 8);
-                d[5] = (Bh[1] >> 24) | (C[1] << 8);
-                d[6] = (C[1] >> 24) | (D[1] << 8) | (A[2] << 16);
-                d[7] = (A[2] >> 16) | (Bh[2] << 16);
-                d[8] = (Bh[2] >> 16) | (C[2] << 16);
-                d[9] = (C[2] >> 16) | (D[2] << 16) | (A[3] << 24);
-                d[10] = (A[3] >> 8) | (Bh[3] << 24);
-                d[11] = (Bh[3] >> 8) | (C[3] << 24);
-                d[12] = (C[3] >> 8) | (D[3] << 24);
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (ok[q])
-                        store_packed_bytes(P.packed + (4 * G + q) * 13,
-                                           (long long)(((unsigned long long)Bh[q] << 32) | A[q]),
-                                           C[q] & 0xFFFFu, C[q] >> 16, D[q]);
-            }
+            unsigned *d = stage + tid * 13;
+            d[0] = A[0]; d[1] = Bh[0]; d[2] = C[0];
+            d[3] = D[0] | (A[1] << 8);
+            d[4] = (A[1] >> 24) | (Bh[1] << 8);
+            d[5] = (Bh[1] >> 24) | (C[1] << 8);
+            d[6] = (C[1] >> 24) | (D[1] << 8) | (A[2] << 16);
+            d[7] = (A[2] >> 16) | (Bh[2] << 16);
+            d[8] = (Bh[2] >> 16) | (C[2] << 16);
+            d[9] = (C[2] >> 16) | (D[2] << 16) | (A[3] << 24);
+            d[10] = (A[3] >> 8) | (Bh[3] << 24);
+            d[11] = (Bh[3] >> 8) | (C[3] << 24);
+            d[12] = (C[3] >> 8) | (D[3] << 24);
         }
         __syncthreads();
         const long long left = G1 - Ga;
         const unsigned nG = left < kSortThreads ? (unsigned)left : (unsigned)kSortThreads;
-        for (unsigned d = tid; d < nG * 13; d += kSortThreads) {
-            const long long G = Ga + d / 13;
-            const bool partial = (G == G0 && (g0 & 3)) || (G == G1 - 1 && (gN & 3));
-            if (!partial) out32[Ga * 13 + d] = stage[d];
+        const unsigned nPieces = (nG * 52u + 15u) >> 4;
+        const long long img = 52 * Ga;                                   // global byte address of the image
+        for (unsigned q = tid; q < nPieces; q += kSortThreads) {
+            const long long lo_b = img + 16ll * q;
+            if (lo_b >= B0 && lo_b + 16 <= B1) {
+                *reinterpret_cast<uint4 *>(P.packed + lo_b) = reinterpret_cast<const uint4 *>(stage)[q];
+            } else {
+                const unsigned char *sb = reinterpret_cast<const unsigned char *>(stage) + 16u * q;
+                for (int k = 0; k < 16; ++k)
+                    if (lo_b + k >= B0 && lo_b + k < B1) P.packed[lo_b + k] = sb[k];
+            }
         }
         __syncthreads();
     }
@@ -1074,9 +1232,19 @@ HostScalars host_scalars(double fps, double t0) {
     return h;
 }
 
+// workgroup size of the tile pass (V2CE_LDATI_TILE_THREADS = 512 | 1024: kernel A/B runs)
+int tile_threads_choice() {
+    static const int v = [] {
+        const char *e = getenv("V2CE_LDATI_TILE_THREADS");
+        const int n = e ? atoi(e) : 0;
+        return n == 512 || n == 1024 ? n : 1024;
+    }();
+    return v;
+}
+
 // geometry and capacities of the two-level path
 struct Plan {
-    int tpp, T, shift, NB, nb1, PB, capA, cap2;
+    int tpp, T, shift, NB, nb1, PB, capA, cap2, tbits, tile_threads;
     size_t n_tab, n_bkt;                 // cntT / runoff entries; btot / bofs entries
     size_t lds_tile, lds_sort;
     size_t bytes;                        // workspace
@@ -1092,9 +1260,10 @@ Plan make_plan(const HostScalars &h, int B, int H, int W, int64_t total_events,
     int pb = 1;
     while ((1ll << pb) < HW) ++pb;
     p.PB = pb;
-    // coarse bucket width: the average bucket of the LARGEST segment stays <= 5120 records
+    // coarse bucket width: the average bucket of the LARGEST segment stays <= 0.65 x the 6144 records
+    // a sort workgroup holds (measured: the largest bucket is 1.05-1.6 x the average)
     int shift = kMaxShift;
-    while (shift > 0 && (double)max_segment_events * (double)(1 << shift) / (double)h.NK > 5120.0) --shift;
+    while (shift > 0 && (double)max_segment_events * (double)(1 << shift) / (double)h.NK > 3994.0) --shift;
     while (shift < kMaxShift && ((h.NK + (1ll << shift) - 1) >> shift) > kMaxNB) ++shift;
     p.shift = shift;
     p.NB = (int)((h.NK + (1ll << shift) - 1) >> shift);
@@ -1102,18 +1271,22 @@ Plan make_plan(const HostScalars &h, int B, int H, int W, int64_t total_events,
     while ((1 << nb1) < p.NB) ++nb1;
     p.nb1 = nb1;
     const double avg = (double)max_segment_events / (double)p.NB;
-    p.cap2 = avg > 1800.0 ? 12288 : 4096;
+    p.cap2 = avg > 1200.0 ? kSortThreads * 24 : kSortThreads * 8;
+    p.tbits = 0;
+    while ((1 << p.tbits) < p.T) ++p.tbits;
     p.capA = (int)((max_tile_events + 255) / 256 * 256);
     if (p.capA < 256) p.capA = 256;
     p.ok = h.ok && p.T <= kMaxTiles && p.NB <= kMaxNB && p.capA <= kCapTile &&
            shift + 2 + pb <= 32 && total_events < (1ll << 32) && B * 9 <= 65535;
     p.n_bkt = (size_t)B * 9 * (size_t)p.NB;
     p.n_tab = p.n_bkt * (size_t)p.T;
+    p.tile_threads = tile_threads_choice();
     p.lds_tile = (size_t)(2 * p.capA + 2048) * 4 + (size_t)kTilePix * 8 +
-                 (size_t)(kTileThreads / 64) * p.NB * 4 + 2 * (kTileThreads / 64 + 1) * 4;
+                 (size_t)(p.tile_threads / 64) * p.NB * 4 + 2 * (p.tile_threads / 64 + 1) * 4;
     const size_t bins = (size_t)4 << shift;
-    p.lds_sort = (size_t)2 * p.cap2 * 4 + kSortWaves * bins * 4 + (size_t)3 * p.T * 4 + (kSortWaves + 1) * 4 +
-                 (p.cap2 >= kSortThreads * 13 ? 0 : (size_t)kSortThreads * 13 * 4);
+    const size_t tables = kSortWaves * bins * 4 + (size_t)(2 * p.T) * 4 + (size_t)(2 * (p.cap2 / 32)) * 4 + (kSortWaves + 1) * 4;
+    const size_t stage = (size_t)kSortThreads * 13 * 4;
+    p.lds_sort = (size_t)p.cap2 * 4 + (tables > stage ? tables : stage);
     p.bytes = (2 * p.n_tab + 2 * p.n_bkt + (size_t)B * 9 + 4 + (size_t)(total_events > 0 ? total_events : 0)) * 4;
     if (p.lds_tile > 160 * 1024 || p.lds_sort > 160 * 1024) p.ok = false;
     return p;
@@ -1149,8 +1322,16 @@ extern "C" int v2ce_ldati_count(const float *vox, int B, int H, int W, int strat
     const int tpp = (HW + kTilePix - 1) / kTilePix, T = 2 * tpp;
     unsigned *tc = static_cast<unsigned *>(tile_ws);
     unsigned *tile_off = tc + (size_t)B * T * 9;
+    {   // once per device: check that LDS atomics return ranks in lane order (see g_lds_order_ok)
+        static std::atomic<unsigned long long> probed{0};
+        int dev = 0;
+        V2CE_HIP_CHECK(hipGetDevice(&dev));
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(probed.fetch_or(bit) & bit))
+            hipLaunchKernelGGL(ldati_lds_order_probe_kernel, dim3(64), dim3(256), 0, s, 200);
+    }
     V2CE_HIP_CHECK(hipMemsetAsync(stats, 0, 4 * sizeof(int64_t), s));
-    hipLaunchKernelGGL(ldati_count_tiles_kernel, dim3(T, B), dim3(kTileThreads), 0, s, vox, HW, tpp, strategy, tc,
+    hipLaunchKernelGGL(ldati_count_tiles_kernel, dim3(T, B), dim3(kCountThreads), 0, s, vox, HW, tpp, strategy, tc,
                        reinterpret_cast<unsigned long long *>(stats));
     hipLaunchKernelGGL(ldati_tile_scan_kernel, dim3(1), dim3(256), 0, s, tc, B, T, tile_off,
                        reinterpret_cast<long long *>(seg_offsets), reinterpret_cast<unsigned long long *>(stats));
@@ -1205,6 +1386,7 @@ extern "C" int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps
     P.fps = fps; P.VS = h.VS; P.VS2 = h.VS2; P.INV = h.INV; P.FPS = h.FPS;
     for (int c = 0; c < 9; ++c) { P.offt[c] = h.offt[c]; P.kbase[c] = h.kbase[c]; }
     P.NK = (int)h.NK; P.nbits = h.nbits;
+    P.ts32 = (fabs((double)h.offt[8]) + 1.0 / fps) * 1e6 < 2.0e9 ? 1 : 0;
     P.strategy = strategy;
     P.rng_mode = rng_mode; P.uniforms = uniforms; P.replay_max_n = replay_max_n;
     P.seed = seed; P.frame_base = frame_base;
@@ -1214,6 +1396,7 @@ extern "C" int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps
     P.p = reinterpret_cast<signed char *>(p);
     P.packed = packed;
     P.sweep_ok = h.sweep_ok ? 1 : 0;
+    { const char *e = getenv("V2CE_LDATI_DBG"); P.dbg = e ? atoi(e) : 0; }
     hipStream_t st = as_stream(stream);
     if (h.sweep_ok)
         V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ldati_emit_kernel),
@@ -1231,7 +1414,7 @@ extern "C" int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps
                      workspace_bytes, pl.bytes);
         unsigned *w = static_cast<unsigned *>(workspace);
         P.shift = pl.shift; P.NB = pl.NB; P.nb1 = pl.nb1; P.T = pl.T; P.tpp = pl.tpp; P.PB = pl.PB;
-        P.capA = pl.capA; P.cap2 = pl.cap2;
+        P.capA = pl.capA; P.cap2 = pl.cap2; P.tbits = pl.tbits;
         P.tile_off = static_cast<const unsigned *>(tile_ws) + (size_t)B * pl.T * 9;
         P.cntT = w;
         P.runoff = w + pl.n_tab;
@@ -1241,18 +1424,21 @@ extern "C" int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps
         P.status = P.seg_flag + (size_t)B * 9;
         P.temp = reinterpret_cast<unsigned *>(P.status + 4);
         V2CE_HIP_CHECK(hipMemsetAsync(P.status, 0, 4 * sizeof(int), st));
-        V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ldati_tile_pass_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_tile));
-        hipLaunchKernelGGL(ldati_tile_pass_kernel, dim3(pl.T, B), dim3(kTileThreads), pl.lds_tile, st, P);
+        {
+            auto tile_kernel = pl.tile_threads == 512 ? ldati_tile_pass_kernel<512, 4> : ldati_tile_pass_kernel<1024, 2>;
+            V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(tile_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_tile));
+            hipLaunchKernelGGL(tile_kernel, dim3(pl.T, B), dim3(pl.tile_threads), pl.lds_tile, st, P);
+        }
         hipLaunchKernelGGL(ldati_bucket_scan_kernel, dim3(B * 9), dim3(256), 0, st, P);
-        if (packed) {
-            V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ldati_bucket_sort_kernel<true>),
+        {
+            auto sort_kernel = packed ? (pl.cap2 > kSortThreads * 8 ? ldati_bucket_sort_kernel<true, 24>
+                                                                     : ldati_bucket_sort_kernel<true, 8>)
+                                      : (pl.cap2 > kSortThreads * 8 ? ldati_bucket_sort_kernel<false, 24>
+                                                                     : ldati_bucket_sort_kernel<false, 8>);
+            V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(sort_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_sort));
-            hipLaunchKernelGGL(ldati_bucket_sort_kernel<true>, dim3(pl.NB, B * 9), dim3(kSortThreads), pl.lds_sort, st, P);
-        } else {
-            V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ldati_bucket_sort_kernel<false>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_sort));
-            hipLaunchKernelGGL(ldati_bucket_sort_kernel<false>, dim3(pl.NB, B * 9), dim3(kSortThreads), pl.lds_sort, st, P);
+            hipLaunchKernelGGL(sort_kernel, dim3(pl.NB, B * 9), dim3(kSortThreads), pl.lds_sort, st, P);
         }
     } else {
         V2CE_REQUIRE(h.sweep_ok, V2CE_ERR_UNSUPPORTED,
