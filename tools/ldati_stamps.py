@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Phase shares of the LDATI tile pass / bucket sort from in-kernel s_memtime stamps (diagnostic
+library `make -C v2ce-toolbox_amd/csrc libv2ce_hip_stamp.so`; shares only, never quote its run time).
+    V2CE_HIP_LIB=v2ce-toolbox_amd/csrc/libv2ce_hip_stamp.so python tools/ldati_stamps.py [stress|sparse]"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from v2ce_toolbox_amd import hip, synth                         # noqa: E402
+from v2ce_toolbox_amd.LDATI import ldati_device                  # noqa: E402
+
+regime = sys.argv[1] if len(sys.argv) > 1 else "stress"
+vox = torch.from_numpy(synth.synthetic_voxels(24, 260, 346, seed=7, regime=regime)).cuda()
+L = hip.lib()
+buf = (ctypes.c_ulonglong * 32)()
+for _ in range(2):
+    ldati_device(vox, fps=30, seed=1)
+torch.cuda.synchronize()
+L.v2ce_debug_stamps(buf)
+for _ in range(3):
+    ldati_device(vox, fps=30, seed=1)
+torch.cuda.synchronize()
+L.v2ce_debug_stamps(buf)
+v = np.array(buf[:], dtype=np.float64)
+names_t = ["loop head/advance", "P1+scan", "hist zero+P3 tables+barrier", "P4 singles", "P4 multis", "barrier", "P5 scan", "P6 rank", "barrier", "P7 copy"]
+names_s = ["S0 setup", "S1 gather", "S2 widen+hist", "barrier", "S3 scan", "S4 rank", "barrier", "S5 emit"]
+for title, base, names in (("tile pass (wave 0 of every workgroup)", 0, names_t), ("bucket sort", 16, names_s)):
+    tot = v[base:base + len(names)].sum()
+    print(title)
+    for i, n in enumerate(names):
+        print(f"   {n:32s} {100 * v[base + i] / tot:6.1f} %")

@@ -158,8 +158,14 @@ def ldati_begin(y: torch.Tensor, t0=0, fps=30, *, rng: str = "philox", seed: Opt
         strat = {"slope": hip.STRATEGY_SLOPE, "none": hip.STRATEGY_NONE}[strategy]
         tile_ws = torch.empty(L.v2ce_ldati_tile_ws_bytes(B, H, W), dtype=torch.uint8, device=dev)
         meta = torch.empty(B * 9 + 1 + 4, dtype=torch.int64, device=dev)       # seg_offsets | stats
+        if profile is not None:    # HIP events on the launch stream around the count kernels
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record()
         hip.check(L.v2ce_ldati_count(y.data_ptr(), B, H, W, strat, tile_ws.data_ptr(), tile_ws.numel(),
                                      meta.data_ptr(), meta[B * 9 + 1:].data_ptr(), st), "v2ce_ldati_count")
+        if profile is not None:
+            c1.record()
+            profile.append(("count", c0, c1, 0))
         host = torch.empty(meta.shape, dtype=torch.int64, pin_memory=True)
         host.copy_(meta, non_blocking=True)
         ready = torch.cuda.Event()

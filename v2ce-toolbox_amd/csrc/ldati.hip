@@ -33,6 +33,7 @@
 #include "common.h"
 
 #include <atomic>
+#include <type_traits>
 #include <cmath>
 #include <cstdlib>
 
@@ -87,7 +88,6 @@ struct LdatiParams {
     int *seg_flag;                // [B*9] 1 = a bucket exceeds cap2 -> segment goes to the sweep kernel
     int *status;                  // [1] != 0: a flagged segment could not be swept (NK too large)
     int sweep_ok;
-    int dbg;                      // timing ablations (V2CE_LDATI_DBG), 0 in production
 };
 
 // ---- Philox4x32-10, counter (pixel, j>>2, p*9+c, frame), key = seed ---------------------------
@@ -248,6 +248,18 @@ __device__ __forceinline__ unsigned take_slots(bool has, unsigned key, int nbits
 // g_lds_order_ok; until / unless it does, the kernels use the ballot ranks (identical results).
 __device__ int g_lds_order_ok = 0;
 __device__ unsigned g_lds_probe_bad = 0, g_lds_probe_done = 0;
+
+// ---- in-kernel phase stamps (diagnostic build only: make STAMP=1) ---------------------------------
+#ifdef V2CE_STAMP
+__device__ unsigned long long g_stamp[32];
+#define STAMP_DECL unsigned long long st_last = __builtin_amdgcn_s_memtime(), st_acc[12] = {0}
+#define STAMP(i) do { const unsigned long long st_now = __builtin_amdgcn_s_memtime(); st_acc[i] += st_now - st_last; st_last = st_now; } while (0)
+#define STAMP_FLUSH(base, n) do { if (threadIdx.x == 0) for (int st_i = 0; st_i < (n); ++st_i) atomicAdd(&g_stamp[(base) + st_i], st_acc[st_i]); } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_FLUSH(base, n)
+#endif
 
 __global__ __launch_bounds__(256) void ldati_lds_order_probe_kernel(int iters) {
     __shared__ unsigned tab[4][512];
@@ -736,7 +748,9 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
         nprev[q] = 0;
     }
 
+    STAMP_DECL;
     for (int c = 0; c < 9; ++c) {
+        STAMP(0);
         // prefetch the voxels of bin c+2 (and bin 9 with it when c+2 == 8)
         float ynn[PPT], y9[PPT];
 #pragma unroll
@@ -762,6 +776,7 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
         // also separates the previous bin's reads of O (P7) from this bin's unit tables.
         unsigned a_base, e_base, A_all, E_all;
         block_excl_scan2<NW>(a_tot, e_tot, part, a_base, e_base, A_all, E_all);
+        STAMP(1);
         const unsigned Ns = A_all & 0xFFFu, Um = A_all >> 12, Nm = E_all;
         const unsigned N = Ns + Nm;
         uint2 *MU = SL + Ns;
@@ -788,6 +803,7 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
             }
         }
         __syncthreads();
+        STAMP(2);
         // ---- P4: timestamps, once, every lane busy; each record also counts in the histogram of
         // the wave that will rank it (contiguous chunks of S, L records per wave) -----------------
         const unsigned L = ((N + NT - 1) / NT) * 64;
@@ -800,6 +816,7 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
             const unsigned w = (unsigned)(((float)q + 0.5f) * invL);
             atomicAdd(&hist[__umul24(w, (unsigned)P.NB) + (key >> P.shift)], 1u);
         }
+        STAMP(3);
         for (unsigned q = tid; q < Um; q += NT) {
             const uint2 e = MU[q];
             const unsigned local = e.x & (kTilePix - 1), jb = (e.x >> kLocalBits) & 0x1FFFFu, cnt = e.x >> 28;
@@ -831,29 +848,35 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
                 }
             }
         }
+        STAMP(4);
         __syncthreads();
+        STAMP(5);
         // ---- P5: bucket-major, wave-minor exclusive scan; the tile's bucket counts and run offsets
         {
+            unsigned v[NW];
             unsigned run = 0;
             if (tid < P.NB) {
 #pragma unroll
+                for (int w = 0; w < NW; ++w) v[w] = hist[w * P.NB + tid];       // independent reads
+#pragma unroll
                 for (int w = 0; w < NW; ++w) {
-                    const unsigned v = hist[w * P.NB + tid];
-                    hist[w * P.NB + tid] = run;
-                    run += v;
+                    const unsigned t0 = v[w];
+                    v[w] = run;
+                    run += t0;
                 }
             }
             unsigned tot;
             const unsigned boff = block_excl_scan<NW>(run, part, &tot);
             if (tid < P.NB) {
 #pragma unroll
-                for (int w = 0; w < NW; ++w) hist[w * P.NB + tid] += boff;
+                for (int w = 0; w < NW; ++w) hist[w * P.NB + tid] = v[w] + boff;
                 const long long gi = ((long long)(b * 9 + c) * P.NB + tid) * P.T + t;
                 P.cntT[gi] = run;
                 P.runoff[gi] = boff;
             }
         }
         __syncthreads();
+        STAMP(6);
         // ---- P6: stable ranks: ballot match-any inside a 64-record batch, running base in LDS ----
         const unsigned lo = wid * L, hi = (lo + L < N) ? lo + L : N;
         for (unsigned i0 = lo; i0 < hi; i0 += 64) {
@@ -867,12 +890,15 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
                 O[pos] = (fine << 12) | (rec & 0xFFFu);
             }
         }
+        STAMP(7);
         __syncthreads();
+        STAMP(8);
         // ---- P7: the tile's records of this bin leave as one contiguous run ---------------------
         {
             unsigned *dst = P.temp + P.seg_offsets[b * 9 + c] + P.tile_off[((long long)b * P.T + t) * 9 + c];
             for (unsigned i = tid; i < N; i += NT) dst[i] = O[i];
         }
+        STAMP(9);
         // ---- advance the relocation recurrence to bin c+2 ---------------------------------------
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
@@ -890,6 +916,8 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
         }
         // no barrier here: the next bin touches O / hist / S only behind the barriers of its scans
     }
+    STAMP(0);
+    STAMP_FLUSH(0, 10);
 }
 
 // per segment: bucket totals over the tiles, exclusive offsets, oversize flag
@@ -951,27 +979,31 @@ __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(Ldat
     unsigned *stage = hist;                              // [256 * 13], 16-byte aligned; aliases the tables (dead in S5)
     constexpr int kWords = K * 8;                        // 256*K / 32
 
-    // S0: this bucket's run in every tile (two consecutive tiles per thread); exclusive prefix of
-    // (records | non-empty << 16) over the tiles
-    unsigned cv[2] = {0u, 0u}, ov[2] = {0u, 0u};
+    STAMP_DECL;
+    // S0 (wave 0; the other waves clear the histograms meanwhile): this bucket's run in every tile,
+    // TPL consecutive tiles per lane; exclusive prefix of (records | non-empty << 16) over the tiles
+    // by a wave scan; list of the non-empty tiles; bit table of the run starts and its word prefix.
+    if (wid == 0) {
+        auto setup = [&](auto tpl_c) {
+        constexpr int TPL = decltype(tpl_c)::value;
+        for (int i = lane; i < kWords; i += 64) bits[i] = 0;
+        unsigned cv[TPL], ov[TPL];
+        unsigned sum = 0;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int tt = 2 * tid + q;
-        if (tt < P.T) {
-            cv[q] = P.cntT[bi * P.T + tt];
-            ov[q] = P.runoff[bi * P.T + tt] + P.tile_off[((long long)b * P.T + tt) * 9 + c];
+        for (int q = 0; q < TPL; ++q) {
+            const int tt = lane * TPL + q;
+            cv[q] = 0u; ov[q] = 0u;
+            if (tt < P.T) {
+                cv[q] = P.cntT[bi * P.T + tt];
+                ov[q] = P.runoff[bi * P.T + tt] + P.tile_off[((long long)b * P.T + tt) * 9 + c];
+            }
+            sum += cv[q] | (cv[q] ? 0x10000u : 0u);
         }
-    }
-    if (tid < kWords) bits[tid] = 0;
-    for (int i = tid; i < kSortWaves * bins; i += kSortThreads) hist[i] = 0;
-    {
-        const unsigned f0 = cv[0] ? 0x10000u : 0u, f1 = cv[1] ? 0x10000u : 0u;
-        unsigned tot;
-        unsigned ex = block_excl_scan<kSortWaves>((cv[0] | f0) + (cv[1] | f1), part, &tot);
+        unsigned ex = wave_incl_scan(sum, lane) - sum;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < TPL; ++q) {
             if (cv[q]) {
-                const unsigned tt = 2u * tid + q, pre = ex & 0xFFFFu, j = ex >> 16;
+                const unsigned tt = (unsigned)(lane * TPL + q), pre = ex & 0xFFFFu, j = ex >> 16;
                 const bool neg = tt < (unsigned)P.tpp;
                 ne_src[j] = ov[q] - pre;
                 ne_info[j] = ((neg ? 0u : 2u) << P.PB) | ((neg ? tt : tt - (unsigned)P.tpp) * kTilePix);
@@ -979,15 +1011,30 @@ __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(Ldat
                 ex += cv[q] | 0x10000u;
             }
         }
+        // word prefix of the run starts: WPL consecutive words per lane
+        constexpr int WPL = (kWords + 63) / 64;
+        unsigned pc[WPL];
+        unsigned ps = 0;
+#pragma unroll
+        for (int q = 0; q < WPL; ++q) {
+            const int wd = lane * WPL + q;
+            pc[q] = wd < kWords ? (unsigned)__popc(bits[wd]) : 0u;
+            ps += pc[q];
+        }
+        unsigned pex = wave_incl_scan(ps, lane) - ps;
+#pragma unroll
+        for (int q = 0; q < WPL; ++q) {
+            const int wd = lane * WPL + q;
+            if (wd < kWords) wpre[wd] = pex;
+            pex += pc[q];
+        }
+        };
+        if (P.T <= 128) setup(std::integral_constant<int, 2>{}); else setup(std::integral_constant<int, kMaxTiles / 64>{});
+    } else {
+        for (int i = tid - 64; i < kSortWaves * bins; i += kSortThreads - 64) hist[i] = 0;
     }
     __syncthreads();
-    {
-        unsigned tot;
-        const unsigned ex = block_excl_scan<kSortWaves>(tid < kWords ? (unsigned)__popc(bits[tid]) : 0u, part, &tot);
-        if (tid < kWords) wpre[tid] = ex;
-    }
-    __syncthreads();
-    if (P.dbg & 4) return;
+    STAMP(0);
     // S1: gather.  The bucket's records are the tiles' runs in tile order (negative tiles first,
     // each in pixel order); wave w owns the contiguous flat range [lo, hi).  The tile of a flat
     // index = number of run starts at or below it (bit table + word prefix); every lane issues all
@@ -1018,10 +1065,10 @@ __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(Ldat
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const unsigned i = min(lo + 64u * k + lane, N - 1u);
-            rec[k] = (P.dbg & 2) ? i * 2654435761u : seg_temp[bw[k] + i];
+            rec[k] = seg_temp[bw[k] + i];
         }
     }
-    if (P.dbg & 8) return;
+    STAMP(1);
     // S2: widen to (fine | category | global pixel); per-wave histograms of (fine, category)
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -1032,7 +1079,9 @@ __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(Ldat
             atomicAdd(&hist[wid * bins + (rec[k] >> P.PB)], 1u);
         }
     }
+    STAMP(2);
     __syncthreads();
+    STAMP(3);
     // S3: bin-major, wave-minor exclusive scan
     {
         const int per = (bins + kSortThreads - 1) / kSortThreads;
@@ -1053,6 +1102,7 @@ __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(Ldat
         }
     }
     __syncthreads();
+    STAMP(4);
     // S4: stable ranks
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -1065,8 +1115,9 @@ __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(Ldat
             if (has) Out[pos] = r;
         }
     }
+    STAMP(5);
     __syncthreads();
-    if (P.dbg & 1) return;
+    STAMP(6);
     // S5: decode and write the final records
     const long long g0 = P.seg_offsets[seg] + P.bofs[bi];                 // first global record
     const long long tbase = P.kbase[c] + ((long long)bucket << P.shift) +
@@ -1140,6 +1191,8 @@ __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(Ldat
         }
         __syncthreads();
     }
+    STAMP(7);
+    STAMP_FLUSH(16, 8);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1396,7 +1449,6 @@ extern "C" int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps
     P.p = reinterpret_cast<signed char *>(p);
     P.packed = packed;
     P.sweep_ok = h.sweep_ok ? 1 : 0;
-    { const char *e = getenv("V2CE_LDATI_DBG"); P.dbg = e ? atoi(e) : 0; }
     hipStream_t st = as_stream(stream);
     if (h.sweep_ok)
         V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ldati_emit_kernel),
@@ -1463,6 +1515,15 @@ extern "C" int v2ce_ldati_status(const void *workspace, int B, int H, int W, dou
     *status_dev = reinterpret_cast<const int32_t *>(w + 2 * pl.n_tab + 2 * pl.n_bkt + (size_t)B * 9);
     return V2CE_OK;
 }
+
+#ifdef V2CE_STAMP
+extern "C" int v2ce_debug_stamps(unsigned long long *out32_host) {
+    unsigned long long zero[32] = {0};
+    if (hipMemcpyFromSymbol(out32_host, HIP_SYMBOL(g_stamp), sizeof(zero)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), zero, sizeof(zero)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
 
 extern "C" int v2ce_events_pack(const int64_t *ts, const int16_t *x, const int16_t *y,
                                 const int8_t *p, int64_t n, uint8_t *packed, v2ce_stream_t stream) {
