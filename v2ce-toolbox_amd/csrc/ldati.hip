@@ -45,7 +45,8 @@ constexpr int kLocalBits = 11;        // log2(kTilePix)
 constexpr int kCountThreads = 512;
 constexpr int kMaxTiles = 512;        // tiles per frame (both polarities) the bucket sort indexes
 constexpr int kMaxNB = 512;           // coarse buckets per segment
-constexpr int kMaxShift = 8;          // fine-key bits
+constexpr int kMaxShift = 8;          // log2 of the widest coarse bucket
+constexpr int kMaxSpanKeys = 128;     // timestamps a sort group spans at most (its histogram has 4x as many bins)
 constexpr int kCapTile = 15360;       // events of one (tile, bin) the tile pass can hold in LDS
 constexpr int kSortThreads = 256;
 constexpr int kSortWaves = kSortThreads / 64;
@@ -80,10 +81,12 @@ struct LdatiParams {
     int capA, cap2;               // LDS capacities (records) of the tile pass / the bucket sort
     int tbits;                    // binary-search steps over the tiles of a frame
     const unsigned *tile_off;     // [B][T][9] exclusive prefix of the tile counts inside the segment
-    unsigned *cntT;               // [B*9][NB][T] records of tile t in the bucket
-    unsigned *runoff;             // [B*9][NB][T] start of that run inside the tile's region
-    unsigned *btot;               // [B*9][NB]
-    unsigned *bofs;               // [B*9][NB] exclusive prefix inside the segment
+    unsigned *roff;               // [B*9][T][NB+1] per tile: exclusive prefix of its bucket counts (last = tile total)
+    unsigned *bofs;               // [B*9][NB+1] exclusive prefix of the bucket totals inside the segment
+    unsigned *groups;             // [B*9][NB] sort groups: first bucket | (end bucket << 16)
+    unsigned *ngroups;            // [B*9]
+    int span;                     // most coarse buckets a sort group may cover (key span <= kMaxSpanKeys)
+    int hist_bins;                // bins reserved per wave in the sort's LDS histogram
     unsigned *temp;               // [total events] 4-byte records (fine | multi | local pixel)
     int *seg_flag;                // [B*9] 1 = a bucket exceeds cap2 -> segment goes to the sweep kernel
     int *status;                  // [1] != 0: a flagged segment could not be swept (NK too large)
@@ -870,10 +873,11 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
             if (tid < P.NB) {
 #pragma unroll
                 for (int w = 0; w < NW; ++w) hist[w * P.NB + tid] = v[w] + boff;
-                const long long gi = ((long long)(b * 9 + c) * P.NB + tid) * P.T + t;
-                P.cntT[gi] = run;
-                P.runoff[gi] = boff;
             }
+            // the tile's row of the run table: one contiguous, coalesced store
+            unsigned *row = P.roff + ((long long)(b * 9 + c) * P.T + t) * (P.NB + 1);
+            if (tid < P.NB) row[tid] = boff;
+            if (tid == 0) row[P.NB] = N;
         }
         __syncthreads();
         STAMP(6);
@@ -885,10 +889,7 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
             const unsigned rec = has ? S[i] : 0u;
             const unsigned bucket = rec >> (12 + P.shift);
             const unsigned pos = take_slot(atomic_order, has, bucket, P.nb1, &hist[wid * P.NB + bucket]);
-            if (has) {
-                const unsigned fine = (rec >> 12) & ((1u << P.shift) - 1u);
-                O[pos] = (fine << 12) | (rec & 0xFFFu);
-            }
+            if (has) O[pos] = rec;
         }
         STAMP(7);
         __syncthreads();
@@ -920,32 +921,50 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
     STAMP_FLUSH(0, 10);
 }
 
-// per segment: bucket totals over the tiles, exclusive offsets, oversize flag
+// per segment: bucket totals over the tiles, their exclusive prefix, and the SORT GROUPS: maximal
+// runs of consecutive coarse buckets with at most cap2 records and at most `span` buckets (so that the
+// group's (key, category) histogram fits the sort workgroup).  Timestamps crowd towards the end of a
+// bin on real UNet output (small voxel values: the single event falls where the accumulated mass
+// crosses 1), so equal-width buckets differ by 20x in a segment; the groups even that out.  A single
+// coarse bucket beyond cap2 (degenerate ties) flags the segment for the sweep kernel.
 __global__ __launch_bounds__(256) void ldati_bucket_scan_kernel(LdatiParams P) {
     __shared__ unsigned part[8];
-    __shared__ unsigned big;
+    __shared__ unsigned tot_s[kMaxNB];
     const int seg = blockIdx.x, t = threadIdx.x;
-    if (t == 0) big = 0;
-    __syncthreads();
+    const unsigned *tab = P.roff + (long long)seg * P.T * (P.NB + 1);
+    unsigned *bofs = P.bofs + (long long)seg * (P.NB + 1);
     unsigned carry = 0;
     for (int b0 = 0; b0 < P.NB; b0 += 256) {            // NB <= 512: at most two rounds
         const int i = b0 + t;
         unsigned s = 0;
-        if (i < P.NB) {
-            const unsigned *row = P.cntT + ((long long)seg * P.NB + i) * P.T;
-            for (int tt = 0; tt < P.T; ++tt) s += row[tt];
-            if (s > (unsigned)P.cap2) atomicOr(&big, 1u);
-        }
+        if (i < P.NB)
+            for (int tt = 0; tt < P.T; ++tt) {
+                const unsigned *row = tab + (long long)tt * (P.NB + 1);
+                s += row[i + 1] - row[i];
+            }
         unsigned tot;
         const unsigned ex = block_excl_scan<4>(s, part, &tot);
         if (i < P.NB) {
-            P.btot[(long long)seg * P.NB + i] = s;
-            P.bofs[(long long)seg * P.NB + i] = carry + ex;
+            tot_s[i] = s;
+            bofs[i] = carry + ex;
         }
         carry += tot;
         __syncthreads();
     }
     if (t == 0) {
+        bofs[P.NB] = carry;
+        unsigned *grp = P.groups + (long long)seg * P.NB;
+        unsigned ng = 0, big = 0;
+        int i = 0;
+        while (i < P.NB) {
+            if (tot_s[i] == 0) { ++i; continue; }
+            const int start = i;
+            unsigned acc = 0;
+            while (i < P.NB && i - start < P.span && acc + tot_s[i] <= (unsigned)P.cap2) acc += tot_s[i++];
+            if (i == start) { big = 1; break; }
+            grp[ng++] = (unsigned)start | ((unsigned)i << 16);
+        }
+        P.ngroups[seg] = big ? 0u : ng;
         P.seg_flag[seg] = (int)big;
         if (big && !P.sweep_ok) atomicOr(reinterpret_cast<unsigned *>(P.status), 1u);
     }
@@ -960,18 +979,23 @@ extern __shared__ __attribute__((aligned(16))) unsigned char sort_smem[];
 
 template <bool PACKED, int K>
 __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(LdatiParams P) {
-    const int bucket = blockIdx.x, seg = blockIdx.y;
-    const long long bi = (long long)seg * P.NB + bucket;
-    const unsigned N = P.btot[bi];
-    if (N == 0 || P.seg_flag[seg]) return;               // uniform per workgroup
+    const int seg = blockIdx.y;
+    if (blockIdx.x >= P.ngroups[seg]) return;            // uniform per workgroup (flagged segments have no groups)
+    const unsigned grp = P.groups[(long long)seg * P.NB + blockIdx.x];
+    const int bk0 = (int)(grp & 0xFFFFu), bk1 = (int)(grp >> 16);           // coarse buckets [bk0, bk1)
+    const unsigned *bofs = P.bofs + (long long)seg * (P.NB + 1);
+    const unsigned N = bofs[bk1] - bofs[bk0];
+    const unsigned key0 = (unsigned)bk0 << P.shift;      // first key of the group
     const int b = seg / 9, c = seg - b * 9;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int bins = 4 << P.shift, nb2 = P.shift + 2;
+    const int bins = ((bk1 - bk0) << P.shift) * 4;       // (relative key, category); <= 4 * kMaxSpanKeys
+    int nb2 = 2;
+    while ((1 << nb2) < bins) ++nb2;
     const bool atomic_order = __builtin_amdgcn_readfirstlane(g_lds_order_ok) != 0;
 
     unsigned *Out = reinterpret_cast<unsigned *>(sort_smem);
     unsigned *hist = Out + kSortThreads * K;             // [kSortWaves][bins]
-    unsigned *ne_src = hist + kSortWaves * bins;         // [T] per non-empty tile: source index - flat index
+    unsigned *ne_src = hist + kSortWaves * P.hist_bins;  // [T] per non-empty tile: source index - flat index
     unsigned *ne_info = ne_src + P.T;                    // [T] (polarity category << PB) | first pixel of the tile
     unsigned *bits = ne_info + P.T;                      // [K*8] bit i = a tile's run starts at flat index i
     unsigned *wpre = bits + K * 8;                       // [K*8] run starts below each 32-index word
@@ -994,8 +1018,10 @@ __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(Ldat
             const int tt = lane * TPL + q;
             cv[q] = 0u; ov[q] = 0u;
             if (tt < P.T) {
-                cv[q] = P.cntT[bi * P.T + tt];
-                ov[q] = P.runoff[bi * P.T + tt] + P.tile_off[((long long)b * P.T + tt) * 9 + c];
+                const unsigned *row = P.roff + ((long long)seg * P.T + tt) * (P.NB + 1);
+                const unsigned r0 = row[bk0];
+                cv[q] = row[bk1] - r0;
+                ov[q] = r0 + P.tile_off[((long long)b * P.T + tt) * 9 + c];
             }
             sum += cv[q] | (cv[q] ? 0x10000u : 0u);
         }
@@ -1075,7 +1101,7 @@ __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(Ldat
         const unsigned i = lo + 64u * k + lane;
         if (i < hi) {
             const unsigned r = rec[k];
-            rec[k] = ((r >> 12) << (2 + P.PB)) | (tinfo[k] + (((r >> kLocalBits) & 1u) << P.PB) + (r & (kTilePix - 1)));
+            rec[k] = (((r >> 12) - key0) << (2 + P.PB)) | (tinfo[k] + (((r >> kLocalBits) & 1u) << P.PB) + (r & (kTilePix - 1)));
             atomicAdd(&hist[wid * bins + (rec[k] >> P.PB)], 1u);
         }
     }
@@ -1119,8 +1145,8 @@ __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(Ldat
     __syncthreads();
     STAMP(6);
     // S5: decode and write the final records
-    const long long g0 = P.seg_offsets[seg] + P.bofs[bi];                 // first global record
-    const long long tbase = P.kbase[c] + ((long long)bucket << P.shift) +
+    const long long g0 = P.seg_offsets[seg] + bofs[bk0];                  // first global record
+    const long long tbase = P.kbase[c] + (long long)key0 +
                             (P.frame_ts_add ? P.frame_ts_add[b] : 0);
     const unsigned pmask = (1u << P.PB) - 1u;
     const unsigned W = (unsigned)P.W;
@@ -1297,8 +1323,8 @@ int tile_threads_choice() {
 
 // geometry and capacities of the two-level path
 struct Plan {
-    int tpp, T, shift, NB, nb1, PB, capA, cap2, tbits, tile_threads;
-    size_t n_tab, n_bkt;                 // cntT / runoff entries; btot / bofs entries
+    int tpp, T, shift, NB, nb1, PB, capA, cap2, tbits, tile_threads, span;
+    size_t n_tab, n_bkt;                 // entries of roff; of bofs
     size_t lds_tile, lds_sort;
     size_t bytes;                        // workspace
     bool ok;
@@ -1313,34 +1339,38 @@ Plan make_plan(const HostScalars &h, int B, int H, int W, int64_t total_events,
     int pb = 1;
     while ((1ll << pb) < HW) ++pb;
     p.PB = pb;
-    // coarse bucket width: the average bucket of the LARGEST segment stays <= 0.65 x the 6144 records
-    // a sort workgroup holds (measured: the largest bucket is 1.05-1.6 x the average)
-    int shift = kMaxShift;
-    while (shift > 0 && (double)max_segment_events * (double)(1 << shift) / (double)h.NK > 3994.0) --shift;
+    // coarse (level 1) bucket width 2^shift us: at most 16 us, finer when the densest segment would
+    // put more than cap2/4 records into an average bucket, never finer than kMaxNB buckets allow.
+    // The sort groups (bucket scan kernel) merge consecutive buckets up to cap2 records.
+    p.cap2 = max_segment_events > 2048 ? kSortThreads * 24 : kSortThreads * 8;
+    int shift = 4;
+    while (shift > 0 && (double)max_segment_events * (double)(1 << shift) / (double)h.NK > p.cap2 / 4.0) --shift;
     while (shift < kMaxShift && ((h.NK + (1ll << shift) - 1) >> shift) > kMaxNB) ++shift;
     p.shift = shift;
     p.NB = (int)((h.NK + (1ll << shift) - 1) >> shift);
     int nb1 = 0;
     while ((1 << nb1) < p.NB) ++nb1;
     p.nb1 = nb1;
-    const double avg = (double)max_segment_events / (double)p.NB;
-    p.cap2 = avg > 1200.0 ? kSortThreads * 24 : kSortThreads * 8;
+    p.span = (kMaxSpanKeys >> shift) > 0 ? (kMaxSpanKeys >> shift) : 1;
     p.tbits = 0;
     while ((1 << p.tbits) < p.T) ++p.tbits;
     p.capA = (int)((max_tile_events + 255) / 256 * 256);
     if (p.capA < 256) p.capA = 256;
     p.ok = h.ok && p.T <= kMaxTiles && p.NB <= kMaxNB && p.capA <= kCapTile &&
-           shift + 2 + pb <= 32 && total_events < (1ll << 32) && B * 9 <= 65535;
-    p.n_bkt = (size_t)B * 9 * (size_t)p.NB;
+           pb <= 22 && total_events < (1ll << 32) && B * 9 <= 65535;
+    p.n_bkt = (size_t)B * 9 * (size_t)(p.NB + 1);
     p.n_tab = p.n_bkt * (size_t)p.T;
     p.tile_threads = tile_threads_choice();
     p.lds_tile = (size_t)(2 * p.capA + 2048) * 4 + (size_t)kTilePix * 8 +
                  (size_t)(p.tile_threads / 64) * p.NB * 4 + 2 * (p.tile_threads / 64 + 1) * 4;
-    const size_t bins = (size_t)4 << shift;
-    const size_t tables = kSortWaves * bins * 4 + (size_t)(2 * p.T) * 4 + (size_t)(2 * (p.cap2 / 32)) * 4 + (kSortWaves + 1) * 4;
+    const size_t bins = (size_t)4 * (size_t)(p.span << shift);          // <= 4 * max(kMaxSpanKeys, 2^shift)
+    const size_t hist_bins = bins > 4 * (size_t)kMaxSpanKeys ? bins : 4 * (size_t)kMaxSpanKeys;
+    const size_t tables = kSortWaves * hist_bins * 4 + (size_t)(2 * p.T) * 4 + (size_t)(2 * (p.cap2 / 32)) * 4 + (kSortWaves + 1) * 4;
     const size_t stage = (size_t)kSortThreads * 13 * 4;
     p.lds_sort = (size_t)p.cap2 * 4 + (tables > stage ? tables : stage);
-    p.bytes = (2 * p.n_tab + 2 * p.n_bkt + (size_t)B * 9 + 4 + (size_t)(total_events > 0 ? total_events : 0)) * 4;
+    // roff | bofs | groups [B*9*NB] | ngroups [B*9] | seg_flag [B*9] | status [4] | records
+    p.bytes = (p.n_tab + p.n_bkt + (size_t)B * 9 * p.NB + 2 * (size_t)B * 9 + 4 +
+               (size_t)(total_events > 0 ? total_events : 0)) * 4;
     if (p.lds_tile > 160 * 1024 || p.lds_sort > 160 * 1024) p.ok = false;
     return p;
 }
@@ -1468,11 +1498,13 @@ extern "C" int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps
         P.shift = pl.shift; P.NB = pl.NB; P.nb1 = pl.nb1; P.T = pl.T; P.tpp = pl.tpp; P.PB = pl.PB;
         P.capA = pl.capA; P.cap2 = pl.cap2; P.tbits = pl.tbits;
         P.tile_off = static_cast<const unsigned *>(tile_ws) + (size_t)B * pl.T * 9;
-        P.cntT = w;
-        P.runoff = w + pl.n_tab;
-        P.btot = w + 2 * pl.n_tab;
-        P.bofs = P.btot + pl.n_bkt;
-        P.seg_flag = reinterpret_cast<int *>(P.bofs + pl.n_bkt);
+        P.span = pl.span;
+        P.hist_bins = (4 * (pl.span << pl.shift)) > 4 * kMaxSpanKeys ? (4 * (pl.span << pl.shift)) : 4 * kMaxSpanKeys;
+        P.roff = w;
+        P.bofs = w + pl.n_tab;
+        P.groups = P.bofs + pl.n_bkt;
+        P.ngroups = P.groups + (size_t)B * 9 * pl.NB;
+        P.seg_flag = reinterpret_cast<int *>(P.ngroups + (size_t)B * 9);
         P.status = P.seg_flag + (size_t)B * 9;
         P.temp = reinterpret_cast<unsigned *>(P.status + 4);
         V2CE_HIP_CHECK(hipMemsetAsync(P.status, 0, 4 * sizeof(int), st));
@@ -1503,6 +1535,18 @@ extern "C" int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps
     return V2CE_OK;
 }
 
+extern "C" int v2ce_ldati_plan_info(int B, int H, int W, double fps, double t0, int64_t total_events,
+                                    int64_t max_segment_events, int64_t max_tile_events, int64_t *info) {
+    clear_error();
+    V2CE_REQUIRE(info && fps > 0 && B > 0 && H > 0 && W > 0, V2CE_ERR_BAD_ARG, "v2ce_ldati_plan_info: bad argument");
+    const HostScalars h = host_scalars(fps, t0);
+    const Plan pl = make_plan(h, B, H, W, total_events, max_segment_events, max_tile_events);
+    const int64_t v[10] = {pl.ok, pl.shift, pl.NB, pl.T, pl.capA, pl.cap2, (int64_t)pl.n_tab, (int64_t)pl.n_bkt,
+                           (int64_t)pl.lds_tile, (int64_t)pl.lds_sort};   // workspace layout: see v2ce_hip.h
+    for (int i = 0; i < 10; ++i) info[i] = v[i];
+    return V2CE_OK;
+}
+
 extern "C" int v2ce_ldati_status(const void *workspace, int B, int H, int W, double fps, double t0,
                                  int64_t total_events, int64_t max_segment_events, int64_t max_tile_events,
                                  const int32_t **status_dev) {
@@ -1512,7 +1556,7 @@ extern "C" int v2ce_ldati_status(const void *workspace, int B, int H, int W, dou
     const Plan pl = make_plan(h, B, H, W, total_events, max_segment_events, max_tile_events);
     V2CE_REQUIRE(pl.ok, V2CE_ERR_UNSUPPORTED, "v2ce_ldati_status: no two-level plan for these arguments");
     const unsigned *w = static_cast<const unsigned *>(workspace);
-    *status_dev = reinterpret_cast<const int32_t *>(w + 2 * pl.n_tab + 2 * pl.n_bkt + (size_t)B * 9);
+    *status_dev = reinterpret_cast<const int32_t *>(w + pl.n_tab + pl.n_bkt + (size_t)B * 9 * pl.NB + 2 * (size_t)B * 9);
     return V2CE_OK;
 }
 

@@ -22,7 +22,7 @@ ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 PRECISION_F32, PRECISION_F16X2 = 0, 1
 
 EXPORTS = [
-    "v2ce_version", "v2ce_last_error", "v2ce_ldati_count", "v2ce_ldati_tile_ws_bytes", "v2ce_ldati_status",
+    "v2ce_version", "v2ce_last_error", "v2ce_ldati_count", "v2ce_ldati_tile_ws_bytes", "v2ce_ldati_status", "v2ce_ldati_plan_info",
     "v2ce_ldati_lds_bytes", "v2ce_ldati_workspace_bytes", "v2ce_ldati_emit", "v2ce_events_pack", "v2ce_events_unpack",
     "v2ce_conv3d_fwd",
     "v2ce_conv3d_variant", "v2ce_conv3d_variant_fused", "v2ce_pack_weights_f16x2", "v2ce_pack_weights_f16x2_bytes",
@@ -77,6 +77,8 @@ def lib() -> ctypes.CDLL:
     L.v2ce_ldati_workspace_bytes.restype = sz
     L.v2ce_ldati_status.argtypes = [vp, i32, i32, i32, f64, f64, i64, i64, i64, ctypes.POINTER(vp)]
     L.v2ce_ldati_status.restype = ctypes.c_int
+    L.v2ce_ldati_plan_info.argtypes = [i32, i32, i32, f64, f64, i64, i64, i64, vp]
+    L.v2ce_ldati_plan_info.restype = ctypes.c_int
     L.v2ce_events_pack.argtypes = [vp, vp, vp, vp, i64, vp, vp]
     L.v2ce_events_unpack.argtypes = [vp, i64, vp, vp, vp, vp, vp]
     L.v2ce_events_unpack.restype = ctypes.c_int

@@ -209,7 +209,7 @@ def main(argv=None):
         torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group("nccl")
-    elif str(device).startswith("cuda"):
+    elif str(device).startswith("cuda") and torch.device(device).index is not None:
         # the C ABI launches on the current device's streams: make --device cuda:N the current one
         torch.cuda.set_device(torch.device(device))
     sources = [args.image_folder, args.input_video_path, args.npy_frames, args.synthetic or None]
