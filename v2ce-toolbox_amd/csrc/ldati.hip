@@ -783,7 +783,11 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
         const unsigned Ns = A_all & 0xFFFu, Um = A_all >> 12, Nm = E_all;
         const unsigned N = Ns + Nm;
         uint2 *MU = SL + Ns;
-        for (int i = tid; i < NW * P.NB; i += NT) hist[i] = 0;
+        // the records are ranked in NC contiguous chunks of L records, one wave each (a sparse tile
+        // needs few: the histogram work below is proportional to NC)
+        const unsigned NC = N > 256u * NW ? (unsigned)NW : (N + 255u) / 256u;
+        const unsigned L = NC ? ((N + 64u * NC - 1u) / (64u * NC)) * 64u : 64u;
+        for (unsigned i = tid; i < NC * P.NB; i += NT) hist[i] = 0;
         // ---- P3: unit tables ----------------------------------------------------------------
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
@@ -809,8 +813,7 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
         STAMP(2);
         // ---- P4: timestamps, once, every lane busy; each record also counts in the histogram of
         // the wave that will rank it (contiguous chunks of S, L records per wave) -----------------
-        const unsigned L = ((N + NT - 1) / NT) * 64;
-        const float invL = 1.0f / (float)(L ? L : 64u);
+        const float invL = 1.0f / (float)L;
         for (unsigned q = tid; q < Ns; q += NT) {
             const uint2 e = SL[q];
             const long long Tq = single_ts(__uint_as_float(e.x), P.fps, P.offt[c]);
@@ -860,7 +863,7 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
             unsigned run = 0;
             if (tid < P.NB) {
 #pragma unroll
-                for (int w = 0; w < NW; ++w) v[w] = hist[w * P.NB + tid];       // independent reads
+                for (int w = 0; w < NW; ++w) v[w] = (unsigned)w < NC ? hist[w * P.NB + tid] : 0u;   // independent reads
 #pragma unroll
                 for (int w = 0; w < NW; ++w) {
                     const unsigned t0 = v[w];
@@ -872,7 +875,8 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
             const unsigned boff = block_excl_scan<NW>(run, part, &tot);
             if (tid < P.NB) {
 #pragma unroll
-                for (int w = 0; w < NW; ++w) hist[w * P.NB + tid] = v[w] + boff;
+                for (int w = 0; w < NW; ++w)
+                    if ((unsigned)w < NC) hist[w * P.NB + tid] = v[w] + boff;
             }
             // the tile's row of the run table: one contiguous, coalesced store
             unsigned *row = P.roff + ((long long)(b * 9 + c) * P.T + t) * (P.NB + 1);
@@ -1311,14 +1315,16 @@ HostScalars host_scalars(double fps, double t0) {
     return h;
 }
 
-// workgroup size of the tile pass (V2CE_LDATI_TILE_THREADS = 512 | 1024: kernel A/B runs)
-int tile_threads_choice() {
+// workgroup size of the tile pass: 1024 threads (2 pixels each) for dense tiles, whose LDS footprint
+// allows one workgroup per CU anyway; 512 threads (4 pixels each, half the barrier traffic and
+// histogram rows) for sparse ones.  V2CE_LDATI_TILE_THREADS = 512 | 1024 overrides (kernel A/B runs).
+int tile_threads_choice(int64_t max_tile_events) {
     static const int v = [] {
         const char *e = getenv("V2CE_LDATI_TILE_THREADS");
         const int n = e ? atoi(e) : 0;
-        return n == 512 || n == 1024 ? n : 1024;
+        return n == 512 || n == 1024 ? n : 0;
     }();
-    return v;
+    return v ? v : (max_tile_events > 4096 ? 1024 : 512);
 }
 
 // geometry and capacities of the two-level path
@@ -1360,7 +1366,7 @@ Plan make_plan(const HostScalars &h, int B, int H, int W, int64_t total_events,
            pb <= 22 && total_events < (1ll << 32) && B * 9 <= 65535;
     p.n_bkt = (size_t)B * 9 * (size_t)(p.NB + 1);
     p.n_tab = p.n_bkt * (size_t)p.T;
-    p.tile_threads = tile_threads_choice();
+    p.tile_threads = tile_threads_choice(max_tile_events);
     p.lds_tile = (size_t)(2 * p.capA + 2048) * 4 + (size_t)kTilePix * 8 +
                  (size_t)(p.tile_threads / 64) * p.NB * 4 + 2 * (p.tile_threads / 64 + 1) * 4;
     const size_t bins = (size_t)4 * (size_t)(p.span << shift);          // <= 4 * max(kMaxSpanKeys, 2^shift)
