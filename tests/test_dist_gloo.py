@@ -1,5 +1,6 @@
-"""CPU, world_size 2 over gloo: the N>1 path -- variable-length event gather and the sequence
-sharding of v2ce.run (stage functions replaced by CPU stand-ins; index logic is the product's)."""
+"""CPU, world_size 2 and 4 over gloo: the N>1 paths of pipeline.run_clip -- batch sharding with the
+spectral-norm fast-forward, pano tile-per-rank with the all-to-all re-shard, the keyed
+variable-length gather (stage functions replaced by CPU stand-ins; index logic is the product's)."""
 import os
 import sys
 
@@ -12,20 +13,40 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _fake_events_from_voxels(pred_voxel, fps, stage2_batch_size=24, seed=0, rng="philox", first_pair=0):
-    """CPU stand-in for LDATI: one 13-byte record per frame-pair = (global pair index, checksum)."""
+def fake_stage2(fps):
+    """CPU stand-in for LDATI: per frame-pair k records (k = 1 + pair % 3) = (global pair index,
+    checksum of its voxels over the FULL width)."""
     from v2ce_toolbox_amd import glue
     from v2ce_toolbox_amd.LDATI import EVENT_DTYPE
-    L = pred_voxel.shape[0]
-    rec = np.zeros(L, EVENT_DTYPE)
-    for i in range(L):
-        rec["timestamp"][i] = glue.frame_offset_us(first_pair + i, fps)
-        rec["x"][i] = (first_pair + i) % 30000
-        rec["y"][i] = int(float(pred_voxel[i].double().sum()) * 10) % 30000
-    return [torch.from_numpy(np.frombuffer(rec.tobytes(), np.uint8).copy())], np.ones(L, np.int64)
+
+    def begin(vox, first_pair):
+        recs = []
+        for i in range(vox.shape[0]):
+            g = first_pair + i
+            r = np.zeros(1 + g % 3, EVENT_DTYPE)
+            r["timestamp"] = glue.frame_offset_us(g, fps)
+            r["x"] = g % 30000
+            r["y"] = int(float(vox[i].double().sum()) * 10) % 30000
+            r["polarity"] = vox.shape[-1] % 100
+            recs.append(r)
+        return torch.from_numpy(np.frombuffer(np.concatenate(recs).tobytes(), np.uint8).copy())
+
+    def finish(handle):
+        return handle, None
+    return begin, finish
 
 
-def _worker(rank, world, port, n_frames, infer_type, bs, q):
+def _single(n_frames, infer_type, bs, wf):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_product_glue import FakeModel
+    from v2ce_toolbox_amd import synth
+    from v2ce_toolbox_amd import v2ce as cli
+    frames = synth.synthetic_frames(n_frames, 8, wf, seed=3)
+    return cli.run(frames, FakeModel(), infer_type=infer_type, width=12, height=8, batch_size=bs, device="cpu",
+                   stage2=fake_stage2(30))
+
+
+def _worker(rank, world, port, n_frames, infer_type, bs, wf, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -34,43 +55,46 @@ def _worker(rank, world, port, n_frames, infer_type, bs, q):
         from test_product_glue import FakeModel
         from v2ce_toolbox_amd import v2ce as cli
         from v2ce_toolbox_amd import synth
-        cli.events_from_voxels = _fake_events_from_voxels
-        frames = synth.synthetic_frames(n_frames, 8, 20, seed=3)
+        frames = synth.synthetic_frames(n_frames, 8, wf, seed=3)
         out = cli.run(frames, FakeModel(), infer_type=infer_type, width=12, height=8, batch_size=bs,
-                      device="cpu")
+                      device="cpu", stage2=fake_stage2(30))
         # also exercise the raw gather with ragged (and empty) payloads
         payload = torch.full((rank * 5,), rank + 1, dtype=torch.uint8)
         g = __import__("v2ce_toolbox_amd.dist", fromlist=["x"]).gather_events(payload, dst=0)
+        assert (out is None) == (rank != 0)
         if rank == 0:
             q.put((out.tobytes(), g.numpy().tolist()))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_frames,infer_type,bs", [(53, "center", 1), (53, "pano", 2), (49, "center", 2)])
-def test_world2_equals_single_process(n_frames, infer_type, bs):
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from test_product_glue import FakeModel
-    from v2ce_toolbox_amd import synth
-    from v2ce_toolbox_amd import v2ce as cli
-    frames = synth.synthetic_frames(n_frames, 8, 20, seed=3)
-    orig = cli.events_from_voxels
-    cli.events_from_voxels = _fake_events_from_voxels
-    try:
-        single = cli.run(frames, FakeModel(), infer_type=infer_type, width=12, height=8, batch_size=bs,
-                         device="cpu")
-    finally:
-        cli.events_from_voxels = orig
+CASES = [
+    # world, frames, infer_type, batch, frame width
+    (2, 53, "center", 1, 20),      # batch sharding, overlapped last sequence
+    (2, 53, "pano", 2, 20),        # pano, 2 tiles (12 + partial 8): one tile per rank
+    (2, 49, "center", 2, 20),
+    (4, 53, "pano", 2, 40),        # 4 tiles (last partial: 40 = 3*12 + 4): BASELINE config 4's split
+    (4, 85, "pano", 1, 20),        # 2 tiles on 4 ranks: two groups of two, batches sharded over the groups
+    (2, 53, "pano", 1, 40),        # 4 tiles on 2 ranks: not a multiple -> batch sharding, tiles serial
+    (4, 37, "center", 1, 20),      # more ranks than batches for some (3 batches on 4 ranks)
+]
+
+
+@pytest.mark.parametrize("world,n_frames,infer_type,bs,wf", CASES)
+def test_world_equals_single_process(world, n_frames, infer_type, bs, wf):
+    single = _single(n_frames, infer_type, bs, wf)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + n_frames
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_frames, infer_type, bs, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + n_frames + 7 * world + wf
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, infer_type, bs, wf, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got, gathered = q.get(timeout=120)
+    got, gathered = q.get(timeout=180)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     assert got == single.tobytes()
-    assert len(single) == n_frames - 1
-    assert gathered == [2] * 5
+    pairs = np.frombuffer(got, single.dtype)["x"]
+    assert sorted(set(pairs.tolist())) == list(range(n_frames - 1))       # every frame-pair, in order
+    assert np.all(np.diff(pairs) >= 0)
+    assert gathered == sum(([r + 1] * (5 * r) for r in range(world)), [])

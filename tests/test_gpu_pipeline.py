@@ -81,3 +81,28 @@ def test_device_preprocess_bit_exact(gold_dir):
     fr = synth.synthetic_frames(17, 260, 346, seed=5, pattern="noise")
     got = glue.image_pre_processing_device(torch.from_numpy(fr).cuda()).cpu().numpy()
     assert got.tobytes() == OG.preprocess(fr).tobytes()
+
+
+@pytest.mark.parametrize("infer_type,wf", [("center", 48), ("pano", 112)])
+def test_pipelined_run_equals_serial_composition(infer_type, wf):
+    """pipeline.run_clip (copy-in / compute / copy-out streams, LDATI per batch, emit of batch k-1
+    behind the model of batch k) == the reference's serial structure (whole clip through the model,
+    then LDATI over the whole clip): same bytes."""
+    from v2ce_toolbox_amd import v2ce as cli
+    frames = synth.synthetic_frames(70, 32, wf, seed=9)
+    got = cli.run(frames, load_model(), infer_type=infer_type, width=48, height=32, batch_size=2, fps=30, seed=3)
+    vox = glue.video_to_voxels(load_model(), frames=frames, infer_type=infer_type, width=48, height=32, batch_size=2)
+    packed, counts = cli.events_from_voxels(vox, 30, 24, 3, "philox")
+    want = cli.download_events(packed)
+    assert len(got) == len(want) == int(counts.sum()) and len(got) > 1000
+    assert got.tobytes() == want.tobytes()
+
+
+def test_explicit_device_index(tmp_path):
+    """--device cuda:0 spelled out (the C ABI launches on the current device's streams)."""
+    out = tmp_path / "o"
+    cmd = [sys.executable, os.path.join(ROOT, "v2ce.py"), "--synthetic", "17", "--height", "32", "--width", "48",
+           "--synthetic_weights", "0", "-o", str(out), "--device", "cuda:0", "--write_event_frame_video", "false"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(np.load(out / "synthetic17-ceil_10-fps_30-events.npz")["event_stream"]) > 0

@@ -14,7 +14,7 @@ its call; ``fast_forward`` does that (the u/v trajectory never depends on the in
 """
 from __future__ import annotations
 
-from typing import List, Optional, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -51,6 +51,80 @@ def gather_events(packed: torch.Tensor, dst: int = 0, group=None) -> Optional[to
     if rank != dst:
         return None
     return torch.cat([recv[r][:sizes[r]] for r in range(world)])
+
+
+_SUBGROUPS = {}
+
+
+def subgroup(size: int, rank: int, world: int):
+    """Process group of the `size` consecutive ranks that contain `rank` (ranks [g*size, (g+1)*size)).
+    Every rank creates every group (torch.distributed requires it); cached per (size, world)."""
+    key = (size, world)
+    if key not in _SUBGROUPS:
+        _SUBGROUPS[key] = [dist.new_group(list(range(g * size, (g + 1) * size))) for g in range(world // size)]
+    return _SUBGROUPS[key][rank // size]
+
+
+def all_to_all_v(outputs: List[torch.Tensor], inputs: List[torch.Tensor], group=None) -> None:
+    """Variable-size all-to-all inside `group`: inputs[j] goes to group rank j, outputs[j] comes from
+    it.  RCCL: one grouped send/recv (``dist.all_to_all``); gloo has no all-to-all, so the CPU tests
+    take the same exchange as batched point-to-point operations."""
+    if dist.get_backend(group) == "nccl":
+        dist.all_to_all(outputs, inputs, group=group)
+        return
+    me = dist.get_rank(group)
+    outputs[me].copy_(inputs[me])
+    ops = []
+    for j in range(dist.get_world_size(group)):
+        if j == me:
+            continue
+        peer = dist.get_global_rank(group, j) if group is not None else j
+        ops.append(dist.P2POp(dist.isend, inputs[j], peer, group=group))
+        ops.append(dist.P2POp(dist.irecv, outputs[j], peer, group=group))
+    for req in dist.batch_isend_irecv(ops) if ops else []:
+        req.wait()
+
+
+def tiles_to_pairs(part: torch.Tensor, widths: Sequence[int], tile_index: int, group) -> Tuple[torch.Tensor, int]:
+    """Re-shard one batch from W-tiles to frame-pairs (pano): this rank holds tile
+    `tile_index` of all P frame-pairs, part [P,2,10,H,widths[tile_index]]; afterwards it holds ALL
+    tiles, concatenated on the width, of its contiguous share of the pairs (LDATI sorts a (frame, bin)
+    segment over the full width, LDATI.py:296-297).  Returns ([P_r,2,10,H,sum(widths)], first pair)."""
+    n = len(widths)
+    P = part.shape[0]
+    ranges = [shard_range(P, r, n) for r in range(n)]
+    lo, hi = ranges[tile_index]
+    inputs = [part[a:b].contiguous() for a, b in ranges]
+    outputs = [torch.empty((hi - lo,) + tuple(part.shape[1:-1]) + (w,), dtype=part.dtype, device=part.device)
+               for w in widths]
+    all_to_all_v(outputs, inputs, group)
+    return torch.cat(outputs, dim=-1), lo
+
+
+def gather_segments(local: torch.Tensor, segments, dst: int = 0, group=None) -> Optional[torch.Tensor]:
+    """Gather byte buffers that consist of keyed segments: `local` = this rank's segments back to back,
+    `segments` = [(order key, bytes)] in that order.  `dst` gets all segments of all ranks in key
+    order (the keys are (batch, position in the batch): global frame-pair order); None elsewhere.
+    One object all-gather of the (small) tables + the padded gather of ``gather_events``."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    tables = [None] * world
+    dist.all_gather_object(tables, list(segments), group=group)
+    sizes = [sum(n for _, n in t) for t in tables]
+    longest = max(max(sizes), 1)
+    send = torch.zeros(longest, dtype=torch.uint8, device=local.device)
+    send[:local.numel()] = local
+    recv = [torch.empty(longest, dtype=torch.uint8, device=local.device) for _ in range(world)] if rank == dst else None
+    dist.gather(send, recv, dst=dst, group=group)
+    if rank != dst:
+        return None
+    pieces = []
+    for r, t in enumerate(tables):
+        off = 0
+        for key, n in t:
+            pieces.append((key, recv[r][off:off + n]))
+            off += n
+    pieces.sort(key=lambda kv: kv[0])
+    return torch.cat([p for _, p in pieces]) if pieces else torch.empty(0, dtype=torch.uint8, device=local.device)
 
 
 def fast_forward(model, global_call_index: int) -> None:

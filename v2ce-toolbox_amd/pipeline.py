@@ -1,0 +1,312 @@
+"""The driver loop of the hot path: frames in host memory -> packed events in host memory.
+
+Replaces the serial structure of ``/root/reference/v2ce.py:131-209,338-367`` (the whole clip
+through the model, voxel grids to host numpy and back, LDATI over the whole clip, per-frame D2H,
+``np.concatenate``) by a per-batch pipeline on three HIP streams:
+
+* copy-in stream : u8 frames of batch k+1, pinned staging -> HBM (4x fewer PCIe bytes than f32 pairs),
+* main stream    : preprocess (``v2ce_preprocess_pairs``) -> V2ce3d -> LDATI count of batch k; the
+                   emit phase of batch k-1 is enqueued BEHIND the model of batch k, so the one host
+                   synchronisation LDATI needs (reading the segment table) never drains the GPU,
+* copy-out stream: packed 13-byte records of batch k-1 -> one growing pinned host buffer, which is
+                   returned as the structured array (no host-side concatenation).
+
+The counter-based Philox draws make LDATI independent of the chunking, so a batch of sequences is
+also the LDATI chunk (``rng='torch'`` keeps the reference's --stage2_batch_size chunks over the whole
+clip: ``v2ce.events_from_voxels``).
+
+Multi-GPU (one process per GPU, ``torch.distributed``):
+
+* ``shard='batches'``: contiguous blocks of batches per rank, no data-path collective; each rank
+  fast-forwards its spectral-norm state to the global model-call index of its first batch.
+* ``shard='tiles'`` (pano, world a multiple of the tile count; BASELINE config 4): rank g of a group
+  runs tile g of every batch of the group (global call index batch*tiles + g), then one all-to-all
+  re-shards from W-tiles to frame-pairs so every rank runs full-width LDATI on its pairs.
+* either way ONE variable-length gather of the packed records to rank 0 at the end
+  (``dist.gather_segments``).
+"""
+from __future__ import annotations
+
+import collections
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import dist as vdist
+from . import glue
+
+EVENT_BYTES = 13
+
+
+@dataclass
+class BatchPlan:
+    index: int                 # batch index: the reference makes calls_per_batch model calls for it
+    seqs: List[int]            # sequence indices
+    starts: List[int]          # first frame of each sequence
+    drop: int                  # frame-pairs dropped at the start of the LAST sequence (v2ce.py:229-232)
+    first_pair: int            # global index of the first kept frame-pair
+    n_pairs: int               # kept frame-pairs
+
+
+def plan_batches(frame_count: int, seq_len: int, batch_size: int) -> List[BatchPlan]:
+    """v2ce.py:149-154,179-190,211-239 as a plan: batches of `batch_size` sequences; of the overlapped
+    last sequence only the last `mode` pairs are kept."""
+    sequence_num, mode, starts = glue.sequence_plan(frame_count, seq_len)
+    plans = []
+    for bi, s0 in enumerate(range(0, sequence_num, batch_size)):
+        seqs = list(range(s0, min(s0 + batch_size, sequence_num)))
+        drop = seq_len - mode if (mode != 0 and seqs[-1] == sequence_num - 1) else 0
+        plans.append(BatchPlan(bi, seqs, [int(starts[s]) for s in seqs], drop, s0 * seq_len,
+                               len(seqs) * seq_len - drop))
+    return plans
+
+
+def pano_tiles(full_width: int, width: int):
+    """v2ce.py:103-111,121-122: (lo, hi, keep) per tile; keep = trailing output columns kept (0 = all).
+    The exact-division test is the reference's hard-coded ``% 346`` (v2ce.py:104)."""
+    patch_num = int(np.ceil(full_width / width))
+    exact_div = full_width % 346 == 0
+    rem = full_width % width
+    tiles = []
+    for i in range(patch_num):
+        if i == patch_num - 1 and not exact_div:
+            tiles.append((full_width - width, full_width, rem))
+        else:
+            tiles.append((i * width, (i + 1) * width, 0))
+    return tiles
+
+
+def resized_width(frames: np.ndarray, height: int) -> int:
+    """v2ce.py:57: width after cv2.resize to `height` rows."""
+    return int(frames.shape[2] / frames.shape[1] * height)
+
+
+class EventSink:
+    """Packed records of successive batches -> one pinned host buffer, filled by asynchronous D2H
+    copies on a copy stream; ``result()`` returns it as the structured array."""
+
+    def __init__(self, device, total_pairs: int, to_host: bool = True):
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda" and to_host   # else: keep the device / CPU tensors
+        self.total_pairs = max(int(total_pairs), 1)
+        self.buf: Optional[torch.Tensor] = None
+        self.used = 0
+        self.pairs_seen = 0
+        self.stream = torch.cuda.Stream(device=self.device) if self.cuda else None
+        self.inflight = collections.deque()
+        self.cpu_parts: List[torch.Tensor] = []
+
+    def _reserve(self, nbytes: int):
+        need = self.used + nbytes
+        if self.buf is not None and need <= self.buf.numel():
+            return
+        # size from the event rate seen so far, with headroom; growth is geometric
+        rate = (need / max(self.pairs_seen, 1)) if self.pairs_seen else 0
+        cap = max(int(rate * self.total_pairs * 1.25) + (1 << 20), need, 2 * (self.buf.numel() if self.buf is not None else 0))
+        new = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
+        if self.buf is not None and self.used:
+            self.stream.synchronize()
+            new[:self.used].copy_(self.buf[:self.used])
+        self.buf = new
+
+    def push(self, packed: torch.Tensor, n_pairs: int, keep=()):
+        """`packed` was produced on the current stream of its device."""
+        n = int(packed.numel())
+        self.pairs_seen += n_pairs
+        if not self.cuda:
+            self.cpu_parts.append(packed)
+            return
+        self.pairs_seen = max(self.pairs_seen, 1)
+        self._reserve(n)
+        if n:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self.stream):
+                self.stream.wait_event(ready)
+                self.buf[self.used:self.used + n].copy_(packed, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(self.stream)
+            self.inflight.append((done, packed, keep))
+        self.used += n
+        while self.inflight and self.inflight[0][0].query():
+            self.inflight.popleft()
+
+    def tensor(self) -> torch.Tensor:
+        """The pushed buffers back to back, where they live (multi-GPU: on the device, for the gather)."""
+        assert not self.cuda
+        return torch.cat(self.cpu_parts) if self.cpu_parts else torch.empty(0, dtype=torch.uint8, device=self.device)
+
+    def result(self, dtype) -> np.ndarray:
+        if not self.cuda:
+            return np.ascontiguousarray(self.tensor().cpu().numpy()).view(dtype)
+        if self.buf is None:
+            return np.empty(0, dtype)
+        self.stream.synchronize()
+        self.inflight.clear()
+        return self.buf[:self.used].numpy().view(dtype)
+
+
+class FrameFeeder:
+    """u8 frames of one batch: pageable numpy -> pinned staging (two slots) -> HBM on a copy stream."""
+
+    def __init__(self, frames: np.ndarray, seq_len: int, device, height: int):
+        self.frames, self.seq_len, self.device = frames, seq_len, torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        # device preprocessing needs u8 frames that the reference's resize leaves untouched
+        self.device_pre = (self.cuda and frames.dtype == np.uint8 and frames.shape[1] == height
+                           and resized_width(frames, height) == frames.shape[2])
+        self.height = height
+        self.stream = torch.cuda.Stream(device=self.device) if self.cuda else None
+        self.slots = [None, None]
+        self.slot_events = [None, None]
+        self.n = 0
+
+    def submit(self, bp: BatchPlan):
+        """Start moving the batch's frames; returns a handle for ``take``."""
+        if not self.device_pre:
+            units = np.stack([glue.image_pre_processing(self.frames[s:s + self.seq_len + 1], self.height)
+                              for s in bp.starts])
+            t = torch.from_numpy(units)
+            return ("units", t.to(self.device, non_blocking=True) if self.cuda else t, None)
+        k = self.n % 2
+        self.n += 1
+        b, L1 = len(bp.starts), self.seq_len + 1
+        shape = (b * L1,) + self.frames.shape[1:]
+        if self.slots[k] is None or self.slots[k].shape[0] < shape[0]:
+            self.slots[k] = torch.empty((max(shape[0], 1),) + shape[1:], dtype=torch.uint8, pin_memory=True)
+        if self.slot_events[k] is not None:
+            self.slot_events[k].synchronize()               # the H2D that last read this slot
+        host = self.slots[k][:shape[0]]
+        hv = host.numpy()
+        for i, s in enumerate(bp.starts):
+            hv[i * L1:(i + 1) * L1] = self.frames[s:s + L1]
+        with torch.cuda.stream(self.stream):
+            dev = host.to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self.slot_events[k] = ev
+        return ("u8", dev, ev)
+
+    def take(self, handle, bp: BatchPlan) -> torch.Tensor:
+        """[b,16,2,H,W'] f32 units on the device (main stream)."""
+        kind, t, ev = handle
+        if kind == "units":
+            return t
+        main = torch.cuda.current_stream(self.device)
+        main.wait_event(ev)
+        t.record_stream(main)
+        b, L1 = len(bp.starts), self.seq_len + 1
+        units = [glue.image_pre_processing_device(t[i * L1:(i + 1) * L1]) for i in range(b)]
+        return torch.stack(units) if b > 1 else units[0][None]
+
+
+def _voxels_of_batch(pred: torch.Tensor, bp: BatchPlan, seq_len: int) -> torch.Tensor:
+    """[b,16,20,H,W] -> kept frame-pairs [n_pairs,2,10,H,W] (v2ce.py:211-239 for this batch)."""
+    H, W = pred.shape[-2:]
+    vox = pred.reshape(-1, 2, 10, H, W)
+    if bp.drop:
+        keep = vox.shape[0] - seq_len
+        vox = torch.cat([vox[:keep], vox[keep + bp.drop:]])
+    return vox
+
+
+def default_stage2(fps, seed):
+    """LDATI on the HIP device, split in begin (count, enqueued now) / finish (emit, later)."""
+    from .LDATI import ldati_begin
+
+    def begin(vox, first_pair):
+        add = torch.tensor([glue.frame_offset_us(first_pair + j, fps) for j in range(vox.shape[0])],
+                           dtype=torch.int64, device=vox.device)
+        return ldati_begin(vox, fps=fps, seed=seed, frame_base=first_pair, frame_ts_add=add)
+
+    def finish(pending):
+        ev = pending.finish()
+        return ev.packed(), ev
+    return begin, finish
+
+
+def run_clip(frames: np.ndarray, model, *, infer_type="center", seq_len=16, width=346, height=260,
+             batch_size=1, fps=30, seed=0, device="cuda", stage2=None, dtype=None,
+             rank=0, world=1, group=None) -> Optional[np.ndarray]:
+    """frames [N,H,W] uint8 -> event_stream (structured array) on rank 0, None elsewhere.
+
+    stage2: optional (begin, finish) pair replacing LDATI (CPU stand-ins in the tests):
+    begin(vox, first_pair) -> handle; finish(handle) -> (packed uint8 tensor, keepalive)."""
+    from .LDATI import EVENT_DTYPE
+    dtype = dtype or EVENT_DTYPE
+    begin, finish = stage2 or default_stage2(fps, seed)
+    plans = plan_batches(len(frames), seq_len, batch_size)
+    fw = resized_width(frames, height)
+    tiles = pano_tiles(fw, width) if infer_type == "pano" else None
+    if infer_type not in ("center", "pano"):
+        raise ValueError(f"Invalid infer_type {infer_type}")
+    calls_per_batch = len(tiles) if tiles else 1
+    tile_parallel = bool(tiles) and len(tiles) > 1 and world > 1 and world % len(tiles) == 0
+    if tile_parallel:
+        n_groups = world // len(tiles)
+        grp_index, tile_index = divmod(rank, len(tiles))
+        grp = vdist.subgroup(len(tiles), rank, world)
+        lo_b, hi_b = vdist.shard_range(len(plans), grp_index, n_groups)
+    else:
+        grp, tile_index = None, None
+        lo_b, hi_b = vdist.shard_range(len(plans), rank, world)
+    mine = plans[lo_b:hi_b]
+    total_pairs = sum(bp.n_pairs for bp in mine)
+    feeder = FrameFeeder(frames, seq_len, device, height)
+    sink = EventSink(device, total_pairs, to_host=world == 1)
+    base_calls = int(getattr(model, "calls", 0))            # the reference keeps advancing one model
+    segments = []                                          # (order key, bytes) of every pushed buffer
+    statuses = []
+    pending = None                                         # (stage-2 handle, order key, pairs)
+
+    def flush(p):
+        handle, key, n_pairs = p
+        packed, keep = finish(handle)
+        sink.push(packed, n_pairs, keep)
+        segments.append((key, int(packed.numel())))
+        if hasattr(keep, "check"):
+            statuses.append(keep)
+
+    handle = feeder.submit(mine[0]) if mine else None
+    with torch.no_grad():
+        for i, bp in enumerate(mine):
+            units = feeder.take(handle, bp)
+            handle = feeder.submit(mine[i + 1]) if i + 1 < len(mine) else None
+            if not tile_parallel:
+                vdist.fast_forward(model, base_calls + bp.index * calls_per_batch)
+                if infer_type == "center":
+                    pred = glue.infer_center_image_unit(model, units, width)
+                else:
+                    pred = glue.infer_pano_image_unit(model, units, width)
+                vox, first_pair, key = _voxels_of_batch(pred, bp, seq_len), bp.first_pair, (bp.index, 0)
+            else:
+                # one tile per rank of the group; reference call index of (batch, tile)
+                vdist.fast_forward(model, base_calls + bp.index * calls_per_batch + tile_index)
+                lo, hi, keep_cols = tiles[tile_index]
+                pred = model(units[..., lo:hi].float().contiguous())
+                if keep_cols:
+                    pred = pred[..., -keep_cols:]
+                part = _voxels_of_batch(pred, bp, seq_len)                       # [P,2,10,H,wt]
+                widths = [(k if k else width) for _, _, k in tiles]
+                vox, p_lo = vdist.tiles_to_pairs(part, widths, tile_index, grp)  # [P_r,2,10,H,W_full]
+                first_pair, key = bp.first_pair + p_lo, (bp.index, tile_index)
+            nxt = (begin(vox, first_pair), key, int(vox.shape[0]))
+            if pending is not None:
+                flush(pending)
+            pending = nxt
+        if pending is not None:
+            flush(pending)
+    for ev in statuses:
+        ev.check()
+    if world == 1:
+        return sink.result(dtype)
+    out = vdist.gather_segments(sink.tensor(), segments, dst=0, group=group)
+    if out is None:
+        return None
+    if out.is_cuda:                                        # one D2H pass on rank 0
+        host = torch.empty(out.numel(), dtype=torch.uint8, pin_memory=True)
+        host.copy_(out)
+        return host.numpy().view(dtype)
+    return np.ascontiguousarray(out.numpy()).view(dtype)

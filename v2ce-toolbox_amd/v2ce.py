@@ -7,8 +7,10 @@ Flags, defaults, output file name (``{name}-ceil_{ceil}-fps_{fps}[-suffix]-event
 LDATI, the whole clip goes through LDATI in chunks on the device, and the per-frame timestamp
 offset (v2ce.py:365) is fused into the emit kernel.
 
-Under ``torchrun`` (WORLD_SIZE > 1) sequences are sharded over ranks in contiguous blocks and the
-packed events are gathered to rank 0 over RCCL (``dist.py``); rank 0 writes the file.
+Under ``torchrun`` (WORLD_SIZE > 1) batches of sequences are sharded over ranks in contiguous blocks
+(pano with a world size that is a multiple of the tile count: one tile per GPU + all-to-all
+re-shard, ``pipeline.py``) and the packed events are gathered to rank 0 over RCCL (``dist.py``);
+rank 0 writes the file.
 """
 from __future__ import annotations
 
@@ -146,56 +148,28 @@ def download_events(packed_list) -> np.ndarray:
 
 
 def run(frames: np.ndarray, model, infer_type="center", seq_len=16, width=346, height=260,
-        batch_size=1, fps=30, stage2_batch_size=24, seed=0, rng="philox", device="cuda") -> np.ndarray:
-    """frames [N,H,W] uint8 -> event_stream (numpy structured array, v2ce.py:368)."""
+        batch_size=1, fps=30, stage2_batch_size=24, seed=0, rng="philox", device="cuda",
+        stage2=None) -> Optional[np.ndarray]:
+    """frames [N,H,W] uint8 -> event_stream (numpy structured array, v2ce.py:368) on rank 0.
+
+    Default (counter-based Philox draws): the per-batch pipeline of ``pipeline.run_clip`` (H2D,
+    UNet + LDATI, D2H overlapped; under torch.distributed sharded over GPUs).  ``rng='torch'``
+    reproduces the reference's structure instead -- the whole clip through the model, then LDATI in
+    chunks of --stage2_batch_size with one dense torch.rand per chunk (LDATI.py:169-171) -- because
+    that draw order depends on the chunking."""
+    from . import pipeline
     rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
     world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
-    if world == 1:
+    if rng == "torch":
+        if world > 1:
+            raise NotImplementedError("rng='torch' replays the reference's single-process draw order; run it on one GPU")
         vox = glue.video_to_voxels(model, frames=frames, infer_type=infer_type, seq_len=seq_len,
                                    width=width, height=height, batch_size=batch_size, device=device)
         packed, _ = events_from_voxels(vox, fps, stage2_batch_size, seed, rng)
         return download_events(packed)
-    return _run_sharded(frames, model, infer_type, seq_len, width, height, batch_size, fps,
-                        stage2_batch_size, seed, rng, device, rank, world)
-
-
-def _run_sharded(frames, model, infer_type, seq_len, width, height, batch_size, fps, stage2_batch_size,
-                 seed, rng, device, rank, world) -> Optional[np.ndarray]:
-    """Sequences in contiguous blocks per rank.  The reference makes one model call per
-    batch of `batch_size` sequences (per tile in pano mode); each rank fast-forwards its
-    spectral-norm state to the global call index of its first batch."""
-    sequence_num, mode, starts = glue.sequence_plan(len(frames), seq_len)
-    n_batches = -(-sequence_num // batch_size)
-    lo_b, hi_b = vdist.shard_range(n_batches, rank, world)
-    calls_per_batch = 1
-    if infer_type == "pano":
-        fw = int(frames.shape[2] / frames.shape[1] * height)
-        calls_per_batch = int(np.ceil(fw / width))
-    vdist.fast_forward(model, lo_b * calls_per_batch)
-    packed = [torch.empty(0, dtype=torch.uint8, device=device)]
-    if hi_b > lo_b:
-        preds = []
-        for bi in range(lo_b, hi_b):
-            seqs = range(bi * batch_size, min((bi + 1) * batch_size, sequence_num))
-            units = [glue.image_pre_processing(frames[int(starts[s]):int(starts[s]) + seq_len + 1], height)
-                     for s in seqs]
-            batch = torch.from_numpy(np.stack(units)).to(device)
-            pred = (glue.infer_center_image_unit if infer_type == "center"
-                    else glue.infer_pano_image_unit)(model, batch, width)
-            preds.append(pred)
-        out_w = preds[0].shape[-1]
-        vox = torch.cat([p.reshape(-1, 2, 10, height, out_w) for p in preds])
-        first_seq = lo_b * batch_size
-        first_pair = first_seq * seq_len
-        owns_last = hi_b == n_batches
-        if owns_last and mode != 0:      # overlapped last sequence: keep its last `mode` pairs
-            keep = vox.shape[0] - seq_len
-            vox = torch.cat([vox[:keep], vox[keep + seq_len - mode:]])
-        packed, _ = events_from_voxels(vox, fps, stage2_batch_size, seed, rng, first_pair=first_pair)
-    out = vdist.gather_events(torch.cat(packed), dst=0)
-    if rank != 0:
-        return None
-    return download_events([out]) if out.is_cuda else np.ascontiguousarray(out.numpy()).view(EVENT_DTYPE)
+    return pipeline.run_clip(frames, model, infer_type=infer_type, seq_len=seq_len, width=width, height=height,
+                             batch_size=batch_size, fps=fps, seed=seed, device=device, stage2=stage2,
+                             dtype=EVENT_DTYPE, rank=rank, world=world)
 
 
 def main(argv=None):
