@@ -1,21 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark: end-to-end frame-pairs/s (V2ce3d UNet + LDATI) at 346x260.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload e2e|ldati_stress|ldati_sparse]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload e2e|pano|ldati_stress|ldati_sparse|voxelize]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    (`python bench.py --gpus N` without torchrun starts the N ranks itself, as child processes)
 
 A "step" is one pass of the hot path over one batch resident in HBM: `--batch` (default 4, the
 BASELINE.json configs[1] "batch=4 sliding frame-pairs" case) 16-pair sequences of preprocessed
-346x260 frames -> V2ce3d -> LDATI (count, scan, emit with the per-frame offset fused, pack) -> the
-packed event records on the device.  With N > 1 every rank processes its own contiguous block of
-sequences (weak scaling, no data-path collective) and the packed events are gathered to rank 0
-over RCCL inside the timed region.  Rank 0 prints ONE JSON line.
+346x260 frames -> V2ce3d -> LDATI (count, emit with the per-frame offset fused, packed 13-byte
+records) on the device.  The loop is software-pipelined exactly like the product driver
+(pipeline.run_clip): LDATI's emit phase of step k-1 is enqueued behind the model of step k, so the
+host's read of the segment table never drains the GPU; all K steps complete inside the timed region.
+With N > 1 every rank processes its own contiguous block of sequences (weak scaling, no data-path
+collective) and the packed events are gathered to rank 0 over RCCL inside the timed region.
+`--workload pano` is BASELINE config 4 (1384x260, batch 8): one 346-wide tile per GPU of a 4-rank
+group, all-to-all re-shard from W-tiles to frame-pairs, full-width LDATI, gather.
+Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import platform
 import sys
 import time
 
@@ -26,7 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from v2ce_toolbox_amd import synth                                   # noqa: E402
-from v2ce_toolbox_amd.LDATI import ldati_device                      # noqa: E402
+from v2ce_toolbox_amd.LDATI import ldati_begin, ldati_device         # noqa: E402
 from v2ce_toolbox_amd.v2ce_3d import V2ce3d                          # noqa: E402
 from v2ce_toolbox_amd import dist as vdist                           # noqa: E402
 from v2ce_toolbox_amd import glue                                    # noqa: E402
@@ -38,6 +45,7 @@ PEAK_F16_MATRIX_TFLOPS = 16 * PEAK_F32_MATRIX_TFLOPS   # same table: f32 MFMA = 
 PEAK_SPLIT_TFLOPS = PEAK_F16_MATRIX_TFLOPS / 3
 PEAK_HBM_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FLOP_PER_PAIR = 135.58e9
+DTYPE_NOTE = {"f32": "f32", "f16x2": "f32-as-f16x2 (operands split hi/lo in fp16, 3 MFMAs per product, f32 accumulate)"}
 
 
 def make_inputs(batch, first_seq, device):
@@ -49,25 +57,45 @@ def make_inputs(batch, first_seq, device):
     return torch.from_numpy(np.stack(xs)).to(device)
 
 
-def cpu_baseline(pairs=4):
-    """The oracle (CPU restatement: torch-CPU stage 1 on all cores + scalar C LDATI) on a bounded
-    sample of the same workload: one 346x260 sequence slice of `pairs` frame-pairs."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or "unknown"
+
+
+def cpu_baseline():
+    """The oracle (CPU restatement) on a bounded sample of the same workloads, as BASELINE.md 3 plans:
+    config C1 (one 17-frame 346x260 sequence = 16 frame-pairs: torch-CPU stage 1 on the host cores +
+    scalar C LDATI) and a slice of one C5 stress chunk through the C LDATI oracle."""
     from oracle import ldati as O
     from oracle import unet as U
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    threads = min(64, cores)                     # more threads than this slow the oneDNN convs down
+    torch.set_num_threads(threads)
     sd = synth.make_state_dict(0)
-    fr = synth.synthetic_frames(pairs + 1, H, W, seed=1000)
+    fr = synth.synthetic_frames(SEQ + 1, H, W, seed=1000)
     x = torch.from_numpy(glue.image_pre_processing(fr)[None])
     t0 = time.perf_counter()
-    vox = U.forward(sd, x).contiguous().numpy().reshape(pairs, 2, 10, H, W)
+    vox = U.forward(sd, x).contiguous().numpy().reshape(SEQ, 2, 10, H, W)
     t1 = time.perf_counter()
     seg, ts, _, _, _ = O.emit_soa(vox, fps=30, seed=1)
     t2 = time.perf_counter()
-    return {"value": pairs / (t2 - t0), "unit": "frame-pairs/s", "cores": cores, "kind": "port",
-            "sample": f"{pairs} frame-pairs (one 346x260 sequence slice): oracle stage 1 on torch-CPU "
-                      f"{t1 - t0:.1f} s ({cores} threads) + scalar C LDATI {t2 - t1:.1f} s (1 thread), "
-                      f"{int(seg.sum())} events"}
+    c5_pairs = 4
+    vs = synth.synthetic_voxels(c5_pairs, H, W, seed=7, regime="stress")
+    t3 = time.perf_counter()
+    seg5, _, _, _, _ = O.emit_soa(vs, fps=30, seed=1)
+    t4 = time.perf_counter()
+    return {"value": SEQ / (t2 - t0), "unit": "frame-pairs/s", "cores": threads, "kind": "port",
+            "cpu": f"{cpu_model()} ({cores} logical cores on the box)",
+            "sample": f"C1: one 346x260 sequence (16 frame-pairs): oracle stage 1 on torch-CPU {t1 - t0:.1f} s "
+                      f"({threads} threads) + scalar C LDATI {t2 - t1:.1f} s (1 thread), {int(seg.sum())} events",
+            "c5_ldati": {"value": int(seg5.sum()) / (t4 - t3) / 1e6, "unit": "Mevents/s", "cores": 1,
+                         "sample": f"{c5_pairs} of the 24 frame-pairs of the C5 stress chunk (6*U[0,1) voxels), "
+                                   f"{int(seg5.sum())} events, scalar C oracle {t4 - t3:.1f} s"}}
 
 
 def bench_voxelize(args, device, rank, world):
@@ -139,20 +167,60 @@ def self_launch(n_gpus: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def fresh_model(precision, device):
+    m = V2ce3d(precision=precision)
+    m.load_state_dict(synth.make_state_dict(0))
+    return m.eval().to(device)
+
+
+def host_to_host(args, device, steps):
+    """SURVEY 8d's end-to-end INCLUDING the host hand-over, through the product driver
+    (pipeline.run_clip): u8 frames in host memory -> packed events in pinned host memory, for a clip of
+    steps x batch sequences.  H2D / compute / D2H overlap on three streams."""
+    from v2ce_toolbox_amd import pipeline
+    n_seq = steps * args.batch
+    base = synth.synthetic_frames(SEQ + 1, H, W, seed=1000)
+    frames = np.concatenate([base[:SEQ]] * n_seq + [base[SEQ:SEQ + 1]])          # n_seq*16 + 1 frames
+    model = fresh_model(args.precision, device)
+    kw = dict(infer_type="center", batch_size=args.batch, fps=30, seed=0x5EED, device=str(device), reuse_output=True)
+    # warm-up clip of the same length: device / pinned allocators, and the page-locked output buffer,
+    # which a process keeps between clips (reuse_output; locking 1.9 GB costs ~140 ms once)
+    pipeline.run_clip(frames, model, **kw)
+    torch.cuda.synchronize()
+    trace = {} if os.environ.get("V2CE_TRACE") else None
+    t0 = time.perf_counter()
+    ev = pipeline.run_clip(frames, model, trace=trace, **kw)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if trace is not None:
+        print("host_to_host trace (s):", {k: (round(v, 4) if not isinstance(v, list) else v) for k, v in trace.items()},
+              "total", round(dt, 4), file=sys.stderr)
+    pairs = n_seq * SEQ
+    return {"value": pairs / dt, "unit": "frame-pairs/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
+            "mevents_per_s": len(ev) / dt / 1e6, "h2d_bytes_per_step": int(args.batch * (SEQ + 1) * H * W),
+            "d2h_bytes_per_step": int(len(ev) * 13 / steps),
+            "what": "u8 frames in host memory -> event_stream array in pinned host memory through pipeline.run_clip "
+                    "(copy-in / compute / copy-out streams); second clip of the process: the page-locked output "
+                    "buffer is reused (the first clip additionally pays ~70 us per MB to lock it)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=4, help="16-pair sequences per step per GPU")
-    ap.add_argument("--workload", default="e2e", choices=["e2e", "ldati_stress", "ldati_sparse", "voxelize"])
+    ap.add_argument("--batch", type=int, default=None, help="16-pair sequences per step per GPU (default 4; pano 8)")
+    ap.add_argument("--workload", default="e2e", choices=["e2e", "pano", "ldati_stress", "ldati_sparse", "voxelize"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="f16x2", choices=["f32", "f16x2"],
                     help="stage-1 3x3x3 conv arithmetic: f16x2 = f32 operands split into two fp16 halves, 3 fp16 "
                          "MFMAs per product, f32 accumulation (error vs f64 equals the exact path's: "
                          "profiles/r01_d_precision_report.json); f32 = exact f32 MFMA")
     ap.add_argument("--no-exact-f32", action="store_true", help="skip the extra exact-f32 measurement")
+    ap.add_argument("--no-host-to-host", action="store_true", help="skip the host-to-host (PCIe-inclusive) measurement")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 8 if args.workload == "pano" else 4
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` outside torchrun: start the N ranks as CHILD processes (one per
@@ -169,78 +237,110 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-
-    b = args.batch
-    pairs_per_step = b * SEQ
-    first_pair = rank * pairs_per_step                       # contiguous block of sequences per rank
-    fps = 30
-    ts_add = torch.tensor([glue.frame_offset_us(first_pair + i, fps) for i in range(pairs_per_step)],
-                          dtype=torch.int64, device=device)
-    model = None
-    if args.workload == "e2e":
-        model = V2ce3d(precision=args.precision)
-        model.load_state_dict(synth.make_state_dict(0))
-        model = model.eval().to(device)
-        x = make_inputs(b, rank * b, device)
-        vox_fixed = None
-    else:
-        regime = "stress" if args.workload == "ldati_stress" else "sparse"
-        pairs_per_step = 24                                   # reference stage-2 chunk (v2ce.py:302)
-        first_pair = rank * pairs_per_step
-        ts_add = ts_add[:1].repeat(pairs_per_step) * 0
-        vox_fixed = torch.from_numpy(synth.synthetic_voxels(pairs_per_step, H, W, seed=7 + rank,
-                                                            regime=regime)).to(device)
-    ldati_prof = []
-    gather_bytes = [0]
     if args.workload == "voxelize":
         return bench_voxelize(args, device, rank, world)
 
-    def step(profile):
-        if model is not None:
+    b, fps = args.batch, 30
+    model, x, vox_fixed = None, None, None
+    pano_tiles = 4
+    tile_parallel = args.workload == "pano" and world % pano_tiles == 0
+    if args.workload == "e2e":
+        pairs_per_rank = b * SEQ
+        first_pair = rank * pairs_per_rank                       # contiguous block of sequences per rank
+        model = fresh_model(args.precision, device)
+        x = make_inputs(b, rank * b, device)
+    elif args.workload == "pano":
+        # 1384x260 = four 346-wide tiles (v2ce.py:103-126 makes one model call per tile).  A group of
+        # four ranks shares a batch (one tile each); other world sizes give every rank its own batch
+        # and run the four tiles one after the other like the reference.
+        grp_index, tile_index = divmod(rank, pano_tiles) if tile_parallel else (rank, None)
+        grp = vdist.subgroup(pano_tiles, rank, world) if tile_parallel else None
+        model = fresh_model(args.precision, device)
+        xs = [make_inputs(b, (grp_index * pano_tiles + t) * b, device)
+              for t in ([tile_index] if tile_parallel else range(pano_tiles))]
+        pairs_per_rank = b * SEQ // pano_tiles if tile_parallel else b * SEQ      # full-width pairs LDATI sees
+        first_pair = grp_index * b * SEQ
+    else:
+        regime = "stress" if args.workload == "ldati_stress" else "sparse"
+        pairs_per_rank = 24                                   # reference stage-2 chunk (v2ce.py:302)
+        first_pair = rank * pairs_per_rank
+        vox_fixed = torch.from_numpy(synth.synthetic_voxels(pairs_per_rank, H, W, seed=7 + rank, regime=regime)).to(device)
+    # per-frame offsets int(i*1/fps*1e6) (v2ce.py:365) of every global frame-pair index, uploaded once
+    offsets = torch.tensor([glue.frame_offset_us(i, fps) for i in range((world + 1) * max(b, 8) * SEQ)],
+                           dtype=torch.int64).to(device)
+    ldati_prof, conv_prof = [], []
+    gather_bytes = [0]
+    n_events = [0]
+
+    def front(profile):
+        """Stage 1 + LDATI count of one step; returns the pending LDATI call."""
+        fp = first_pair
+        if args.workload == "e2e":
             model.profile = [] if profile else None
-            vox = model(x).view(pairs_per_step, 2, 10, H, W)
+            vox = model(x).view(pairs_per_rank, 2, 10, H, W)
+            conv_prof.extend(model.profile or [])
+        elif args.workload == "pano":
+            model.profile = [] if profile else None
+            if tile_parallel:
+                part = model(xs[0]).view(b * SEQ, 2, 10, H, W)
+                vox, lo = vdist.tiles_to_pairs(part, [W] * pano_tiles, tile_index, grp)
+                fp = first_pair + lo
+            else:
+                vox = torch.cat([model(xt).view(b * SEQ, 2, 10, H, W) for xt in xs], dim=-1)
+            conv_prof.extend(model.profile or [])
         else:
             vox = vox_fixed
-        ev = ldati_device(vox, fps=fps, seed=0x5EED, frame_base=first_pair, frame_ts_add=ts_add,
-                          profile=ldati_prof if profile else None)
+        add = offsets[fp:fp + vox.shape[0]] if model is not None else None
+        return ldati_begin(vox, fps=fps, seed=0x5EED, frame_base=fp, frame_ts_add=add,
+                           profile=ldati_prof if profile else None)
+
+    def back(pending):
+        ev = pending.finish()
         packed = ev.packed()
+        n_events[0] += ev.num_events
         if world > 1:
             out = vdist.gather_events(packed, dst=0)
             if rank == 0:
                 gather_bytes[0] = int(out.numel())
-        conv_prof = model.profile if (model is not None and profile) else []
-        return ev.num_events, conv_prof
+        return packed
 
-    for _ in range(args.warmup):
-        step(True)            # same code path as the timed steps (warms the HIP event pool too)
+    def run_steps(k, profile):
+        pending = None
+        for _ in range(k):
+            nxt = front(profile)
+            if pending is not None:
+                back(pending)
+            pending = nxt
+        if pending is not None:
+            back(pending)
+
+    run_steps(args.warmup, True)            # same code path as the timed steps (warms the HIP event pool too)
     ldati_prof.clear()
+    conv_prof.clear()
+    n_events[0] = 0
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    events = 0
-    conv_events = []
-    for _ in range(args.steps):
-        n, cp = step(True)
-        events += n
-        conv_events += cp
+    run_steps(args.steps, True)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    events = float(n_events[0])
     if world > 1:
-        t = torch.tensor([dt, float(events)], dtype=torch.float64, device=device)
+        t = torch.tensor([dt, events], dtype=torch.float64, device=device)
         tmax = t.clone()
         torch.distributed.all_reduce(tmax[:1], op=torch.distributed.ReduceOp.MAX)
         torch.distributed.all_reduce(t[1:], op=torch.distributed.ReduceOp.SUM)
         dt, events = float(tmax[0]), float(t[1])
-    total_pairs = world * pairs_per_step * args.steps
+    total_pairs = world * pairs_per_rank * args.steps            # pano: full-width (1384-column) frame-pairs
 
     # ---- per-kernel HIP-event timings collected inside the timed region
     per = {}
-    for name, flops, e0, e1 in conv_events:
+    for name, flops, e0, e1 in conv_prof:
         d = per.setdefault(name, [0.0, 0.0, 0])
         d[0] += e0.elapsed_time(e1) * 1e-3
         d[1] += flops
@@ -257,11 +357,12 @@ def main():
                  "count_ms": 1e3 * cnt_t / em_n,
                  "achieved_GBps": em_bytes / em_t / 1e9, "frac_hbm_peak": em_bytes / em_t / 1e9 / PEAK_HBM_GBS,
                  "algorithmic_bytes_per_launch": em_bytes / em_n}
-    if args.workload == "e2e":
+    if model is not None:
         name = max(per, key=lambda k: per[k][0])
         v = per[name]
         split = "f16x2" in name
         peak = PEAK_SPLIT_TFLOPS if split else PEAK_F32_MATRIX_TFLOPS
+        ws3 = [q[1] / q[0] / 1e12 / PEAK_SPLIT_TFLOPS for k, q in per.items() if "ws_kernel<3," in k]
         roofline = {"bound": "mfma", "kernel": name, "achieved": v[1] / v[0] / 1e12,
                     "peak": peak, "unit": "TFLOP/s",
                     "frac": v[1] / v[0] / 1e12 / peak, "traffic": None,
@@ -269,7 +370,8 @@ def main():
                     "peak_note": ("algorithmic (f32-equivalent) FLOP; the kernel executes 3 fp16 MFMAs per product, so "
                                   f"peak = dense fp16 MFMA peak {PEAK_F16_MATRIX_TFLOPS:.0f} / 3") if split else
                                  "dense f32 MFMA peak",
-                    "all_conv_tflops": sum(x[1] for x in per.values()) / sum(x[0] for x in per.values()) / 1e12}
+                    "all_conv_tflops": sum(q[1] for q in per.values()) / sum(q[0] for q in per.values()) / 1e12,
+                    "min_3x3x3_split_variant_frac": min(ws3) if ws3 else None}
     else:
         roofline = {"bound": "hbm", "kernel": "v2ce_ldati_count + v2ce_ldati_emit (count_tiles, tile_scan, tile_pass, bucket_scan, bucket_sort)",
                     "achieved": ldati["achieved_GBps"],
@@ -281,9 +383,9 @@ def main():
     # launch, or null when no summary for this workload is committed
     try:
         import glob
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*{args.workload}_pmc_traffic.json")))
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{args.workload}_pmc_traffic.json")))
         pmc = json.load(open(files[-1]))
-        if args.workload == "e2e":
+        if model is not None:
             key = roofline["kernel"].replace(" ", "")
             roofline["traffic"] = pmc[key]["traffic_bytes"]
         else:   # all ldati_* kernels of one call
@@ -293,45 +395,52 @@ def main():
         pass
 
     if rank == 0:
+        workloads = {"e2e": f"346x260 center, batch={b} sequences x 16 frame-pairs per GPU, "
+                            "V2ce3d (synthetic weights seed 0) + LDATI (Philox), inputs resident in HBM",
+                     "pano": f"1384x260 pano (4 tiles of 346), batch={b} sequences x 16 frame-pairs per 4-GPU group: "
+                             + ("one tile per GPU, all-to-all re-shard W-tiles -> frame-pairs, full-width LDATI"
+                                if tile_parallel else "every rank runs the 4 tiles of its own batch serially (world not a multiple of 4)")
+                             + "; inputs resident in HBM; value counts full-width frame-pairs",
+                     "ldati_stress": "LDATI only, 24 frame-pairs of 6*U[0,1) voxels (C5 stress)",
+                     "ldati_sparse": "LDATI only, 24 frame-pairs of relu(0.8*randn) voxels"}
         line = {
-            "metric": "frame-pairs/sec end-to-end (UNet+LDATI), 346x260",
+            "metric": "frame-pairs/sec end-to-end (UNet+LDATI), 346x260" if args.workload != "pano" else
+                      "frame-pairs/sec end-to-end (UNet+LDATI), 1384x260 pano",
             "value": total_pairs / dt, "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "f32" else "f32-as-f16x2 (operands split hi/lo in fp16, 3 MFMAs per product, f32 accumulate)",
-            "data": "synthetic",
-            "config": {"workload": {"e2e": f"346x260 center, batch={b} sequences x 16 frame-pairs per GPU, "
-                                           "V2ce3d (synthetic weights seed 0) + LDATI (Philox), inputs resident in HBM",
-                                    "ldati_stress": "LDATI only, 24 frame-pairs of 6*U[0,1) voxels (C5 stress)",
-                                    "ldati_sparse": "LDATI only, 24 frame-pairs of relu(0.8*randn) voxels"}[args.workload],
-                       "frame_pairs_per_step_per_gpu": pairs_per_step, "fps": fps,
-                       "parallelism": f"dp{world} over sequences"},
+            "dtype": DTYPE_NOTE[args.precision], "data": "synthetic",
+            "config": {"workload": workloads[args.workload], "frame_pairs_per_step_per_gpu": pairs_per_rank, "fps": fps,
+                       "parallelism": (f"tile-per-GPU groups of 4 x {world // pano_tiles} over batches" if tile_parallel
+                                       else f"dp{world} over sequences")},
             "mevents_per_s": events / dt / 1e6, "events_per_pair": events / total_pairs,
-            "stage1_mfma_frac_e2e": (FLOP_PER_PAIR * total_pairs / dt / 1e12 / world /
+            "stage1_mfma_frac_e2e": ((FLOP_PER_PAIR * (pano_tiles if args.workload == "pano" else 1)) * total_pairs / dt / 1e12 / world /
                                      (PEAK_F32_MATRIX_TFLOPS if args.precision == "f32" else PEAK_SPLIT_TFLOPS))
-            if args.workload == "e2e" else None,
+            if model is not None else None,
             "roofline": roofline, "ldati": ldati, "kernels": kernels,
         }
         if world > 1:
             line["gathered_bytes_per_step"] = gather_bytes[0]
-        if world == 1 and args.workload == "e2e" and args.precision != "f32" and not args.no_exact_f32:
-            # the same step with exact f32 MFMA arithmetic in every conv, for reference (not `value`)
-            del model
-            m32 = V2ce3d(precision="f32")
-            m32.load_state_dict(synth.make_state_dict(0))
-            m32 = m32.eval().to(device)
+            line["rccl_world"] = world
+        if world == 1 and args.workload == "e2e":
+            if not args.no_host_to_host:
+                line["host_to_host"] = host_to_host(args, device, max(args.steps, 4))
+            if args.precision != "f32" and not args.no_exact_f32:
+                # the same step with exact f32 MFMA arithmetic in every conv, for reference (not `value`)
+                model = None
+                m32 = fresh_model("f32", device)
 
-            def step32():
-                vox = m32(x).view(pairs_per_step, 2, 10, H, W)
-                return ldati_device(vox, fps=fps, seed=0x5EED, frame_base=first_pair, frame_ts_add=ts_add).packed()
-            step32()
-            torch.cuda.synchronize()
-            t32 = time.perf_counter()
-            for _ in range(3):
+                def step32():
+                    vox = m32(x).view(pairs_per_rank, 2, 10, H, W)
+                    return ldati_device(vox, fps=fps, seed=0x5EED, frame_base=first_pair).packed()
                 step32()
-            torch.cuda.synchronize()
-            t32 = (time.perf_counter() - t32) / 3
-            line["exact_f32"] = {"value": pairs_per_step / t32, "unit": "frame-pairs/s", "ms_per_step": 1e3 * t32, "steps": 3}
+                torch.cuda.synchronize()
+                t32 = time.perf_counter()
+                for _ in range(3):
+                    step32()
+                torch.cuda.synchronize()
+                t32 = (time.perf_counter() - t32) / 3
+                line["exact_f32"] = {"value": pairs_per_rank / t32, "unit": "frame-pairs/s", "ms_per_step": 1e3 * t32, "steps": 3}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

@@ -101,8 +101,8 @@ int v2ce_ldati_status(const void *workspace, int B, int H, int W, double fps, do
 /* The two-level plan v2ce_ldati_emit would use (introspection for tools/tests): info [10] = {ok, fine-key
  * bits (shift), coarse buckets per segment, tiles per frame, tile-pass capacity, sort capacity, entries
  * of the per-tile tables, entries of the per-bucket tables, LDS bytes of the tile pass, of the sort}.
- * Workspace layout (u32 units): roff [n_tab = B*9*T*(NB+1)] | bofs [n_bkt = B*9*(NB+1)] | groups [B*9*NB] |
- * ngroups [B*9] | seg_flag [B*9] | status [4] | records [total]. */
+ * Workspace layout (u32 units): bofs [n_bkt = B*9*(NB+1)] | groups [B*9*NB] | ngroups [B*9] | seg_flag [B*9] |
+ * status [4] | records [total] | roff [n_tab = B*9*T*(NB+1)] as u16. */
 int v2ce_ldati_plan_info(int B, int H, int W, double fps, double t0, int64_t total_events,
                          int64_t max_segment_events, int64_t max_tile_events, int64_t *info);
 

@@ -5,8 +5,9 @@ batch-4 grids that bench.py times (the small-plane tests of test_gpu_unet.py cho
 * C1/C2 B=1: one 17-frame 346x260 sequence through the DEFAULT path (precision f16x2, fused head and
   shortcuts) against oracle/unet.py on the host CPU, final output and the 11 per-block
   intermediates (reference forward: scripts/unet_2layer.py:335-379), 1e-5 abs + 1e-5 rel.
-* C2 B=4 x T=16: the default path against the exact-f32 HIP path at 2e-6 * max|ref| per tensor
-  (cheap, catches tile / round / grid-walk bugs a B=1 run cannot).
+* C2 B=4 x T=16: the default path against the exact-f32 HIP path at the same bar (both accumulate in
+  f32 in different orders: at K = 13824 that alone is ~1e-5 relative; cheap, catches tile / round /
+  grid-walk bugs a B=1 run cannot: those are errors of the size of the values).
 * C1 CLI: ``python v2ce.py --synthetic 17 -b 1`` at 346x260: the npz is byte-equal to oracle LDATI
   applied to the (oracle-checked) voxels with the offsets of v2ce.py:365.
 """
@@ -101,15 +102,17 @@ def test_c2_batch4_default_vs_exact_f32():
     m = fresh_model("f16x2")
     fused = m(x).cpu()                                                # call 1, fused launches
     assert fused.shape == (4, 16, 20, H, W)
-    mag = float(ref_out.abs().max())
-    assert float((fused - ref_out).abs().max()) <= 2e-6 * max(mag, 1.0), "fused default vs exact f32"
+    assert excess(fused.numpy(), ref_out.numpy()) <= TOL, "fused default vs exact f32"
     m2 = fresh_model("f16x2")
     out, inter = m2(x, return_intermediates=True)
+    bad = {}
     for k, v in inter.items():
-        r = ref_inter[k]
-        d = float((v.cpu() - r).abs().max())
-        assert d <= 2e-6 * max(float(r.abs().max()), 1.0), (k, d)
-    assert float((out.cpu() - ref_out).abs().max()) <= 2e-6 * max(mag, 1.0)
+        r = ref_inter[k].numpy()
+        e = excess(v.cpu().numpy(), r)
+        if e > inter_tol(r):
+            bad[k] = (e, inter_tol(r))
+    assert not bad, bad
+    assert excess(out.cpu().numpy(), ref_out.numpy()) <= TOL
 
 
 def test_c1_cli_full_size_byte_equal(tmp_path, c1_case):

@@ -32,7 +32,7 @@ hip.lib().v2ce_ldati_plan_info(B, 260, 346, 30.0, 0.0, total, max_seg, max_tile,
 ok, shift, NB, T, capA, cap2, n_tab, n_bkt, lds_t, lds_s = list(info)
 print("plan: ok", ok, "shift", shift, "NB", NB, "T", T, "capA", capA, "cap2", cap2, "lds", lds_t, lds_s)
 w = ws.view(torch.int32).cpu().numpy()
-o = n_tab
+o = 0
 bofs = w[o:o + n_bkt].reshape(B * 9, NB + 1); o += n_bkt
 groups = w[o:o + B * 9 * NB].reshape(B * 9, NB); o += B * 9 * NB
 ngroups = w[o:o + B * 9]; o += B * 9

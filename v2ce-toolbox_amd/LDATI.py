@@ -115,6 +115,25 @@ def _check_fps(fps) -> None:
                            f"does not have 9 elements (reference LDATI.py:163 raises as well)")
 
 
+class _PinnedPool:
+    """Small pinned int64 buffers for the segment-table read-back, recycled by hand: the allocator's
+    own pinned cache cannot reuse a block while an asynchronous copy into it is pending and would call
+    hipHostMalloc (which synchronises the device) on every pipelined call."""
+
+    def __init__(self):
+        self.free = {}
+
+    def get(self, n: int) -> torch.Tensor:
+        lst = self.free.setdefault(n, [])
+        return lst.pop() if lst else torch.empty(n, dtype=torch.int64, pin_memory=True)
+
+    def put(self, t: torch.Tensor) -> None:
+        self.free.setdefault(int(t.numel()), []).append(t)
+
+
+_PINNED = _PinnedPool()
+
+
 class PendingLdati:
     """An LDATI call whose count phase is enqueued (``ldati_begin``).  ``finish()`` waits for the
     segment table -- the one host synchronisation inherent to a variable-length output --, allocates
@@ -166,7 +185,7 @@ def ldati_begin(y: torch.Tensor, t0=0, fps=30, *, rng: str = "philox", seed: Opt
         if profile is not None:
             c1.record()
             profile.append(("count", c0, c1, 0))
-        host = torch.empty(meta.shape, dtype=torch.int64, pin_memory=True)
+        host = _PINNED.get(int(meta.numel()))
         host.copy_(meta, non_blocking=True)
         ready = torch.cuda.Event()
         ready.record()
@@ -182,7 +201,8 @@ def _ldati_finish(q: PendingLdati) -> DeviceEvents:
     L = hip.lib()
     st = hip.stream_ptr(dev)
     q.ready.synchronize()                              # the one sync
-    host = q.host.numpy()
+    host = q.host.numpy().copy()
+    _PINNED.put(q.host)
     offs = host[:B * 9 + 1]
     max_n, max_tile, max_seg, total = (int(v) for v in host[B * 9 + 1:])
     segc = np.diff(offs).reshape(B, 9)

@@ -81,7 +81,7 @@ struct LdatiParams {
     int capA, cap2;               // LDS capacities (records) of the tile pass / the bucket sort
     int tbits;                    // binary-search steps over the tiles of a frame
     const unsigned *tile_off;     // [B][T][9] exclusive prefix of the tile counts inside the segment
-    unsigned *roff;               // [B*9][T][NB+1] per tile: exclusive prefix of its bucket counts (last = tile total)
+    unsigned short *roff;         // [B*9][T][NB+1] per tile: exclusive prefix of its bucket counts (last = tile total <= kCapTile)
     unsigned *bofs;               // [B*9][NB+1] exclusive prefix of the bucket totals inside the segment
     unsigned *groups;             // [B*9][NB] sort groups: first bucket | (end bucket << 16)
     unsigned *ngroups;            // [B*9]
@@ -879,9 +879,9 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
                     if ((unsigned)w < NC) hist[w * P.NB + tid] = v[w] + boff;
             }
             // the tile's row of the run table: one contiguous, coalesced store
-            unsigned *row = P.roff + ((long long)(b * 9 + c) * P.T + t) * (P.NB + 1);
-            if (tid < P.NB) row[tid] = boff;
-            if (tid == 0) row[P.NB] = N;
+            unsigned short *row = P.roff + ((long long)(b * 9 + c) * P.T + t) * (P.NB + 1);
+            if (tid < P.NB) row[tid] = (unsigned short)boff;
+            if (tid == 0) row[P.NB] = (unsigned short)N;
         }
         __syncthreads();
         STAMP(6);
@@ -935,7 +935,7 @@ __global__ __launch_bounds__(256) void ldati_bucket_scan_kernel(LdatiParams P) {
     __shared__ unsigned part[8];
     __shared__ unsigned tot_s[kMaxNB];
     const int seg = blockIdx.x, t = threadIdx.x;
-    const unsigned *tab = P.roff + (long long)seg * P.T * (P.NB + 1);
+    const unsigned short *tab = P.roff + (long long)seg * P.T * (P.NB + 1);
     unsigned *bofs = P.bofs + (long long)seg * (P.NB + 1);
     unsigned carry = 0;
     for (int b0 = 0; b0 < P.NB; b0 += 256) {            // NB <= 512: at most two rounds
@@ -943,8 +943,8 @@ __global__ __launch_bounds__(256) void ldati_bucket_scan_kernel(LdatiParams P) {
         unsigned s = 0;
         if (i < P.NB)
             for (int tt = 0; tt < P.T; ++tt) {
-                const unsigned *row = tab + (long long)tt * (P.NB + 1);
-                s += row[i + 1] - row[i];
+                const unsigned short *row = tab + (long long)tt * (P.NB + 1);
+                s += (unsigned)row[i + 1] - (unsigned)row[i];
             }
         unsigned tot;
         const unsigned ex = block_excl_scan<4>(s, part, &tot);
@@ -1022,9 +1022,9 @@ __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(Ldat
             const int tt = lane * TPL + q;
             cv[q] = 0u; ov[q] = 0u;
             if (tt < P.T) {
-                const unsigned *row = P.roff + ((long long)seg * P.T + tt) * (P.NB + 1);
+                const unsigned short *row = P.roff + ((long long)seg * P.T + tt) * (P.NB + 1);
                 const unsigned r0 = row[bk0];
-                cv[q] = row[bk1] - r0;
+                cv[q] = (unsigned)row[bk1] - r0;
                 ov[q] = r0 + P.tile_off[((long long)b * P.T + tt) * 9 + c];
             }
             sum += cv[q] | (cv[q] ? 0x10000u : 0u);
@@ -1346,11 +1346,12 @@ Plan make_plan(const HostScalars &h, int B, int H, int W, int64_t total_events,
     while ((1ll << pb) < HW) ++pb;
     p.PB = pb;
     // coarse (level 1) bucket width 2^shift us: at most 16 us, finer when the densest segment would
-    // put more than cap2/4 records into an average bucket, never finer than kMaxNB buckets allow.
-    // The sort groups (bucket scan kernel) merge consecutive buckets up to cap2 records.
+    // put more than cap2/20 records into an AVERAGE bucket (on real UNet output the fullest bucket of a
+    // segment holds ~20x the average: timestamps crowd at the end of a bin), never finer than kMaxNB
+    // buckets allow.  The sort groups (bucket scan kernel) merge consecutive buckets up to cap2 records.
     p.cap2 = max_segment_events > 2048 ? kSortThreads * 24 : kSortThreads * 8;
     int shift = 4;
-    while (shift > 0 && (double)max_segment_events * (double)(1 << shift) / (double)h.NK > p.cap2 / 4.0) --shift;
+    while (shift > 0 && (double)max_segment_events * (double)(1 << shift) / (double)h.NK > p.cap2 / 20.0) --shift;
     while (shift < kMaxShift && ((h.NK + (1ll << shift) - 1) >> shift) > kMaxNB) ++shift;
     p.shift = shift;
     p.NB = (int)((h.NK + (1ll << shift) - 1) >> shift);
@@ -1374,9 +1375,9 @@ Plan make_plan(const HostScalars &h, int B, int H, int W, int64_t total_events,
     const size_t tables = kSortWaves * hist_bins * 4 + (size_t)(2 * p.T) * 4 + (size_t)(2 * (p.cap2 / 32)) * 4 + (kSortWaves + 1) * 4;
     const size_t stage = (size_t)kSortThreads * 13 * 4;
     p.lds_sort = (size_t)p.cap2 * 4 + (tables > stage ? tables : stage);
-    // roff | bofs | groups [B*9*NB] | ngroups [B*9] | seg_flag [B*9] | status [4] | records
-    p.bytes = (p.n_tab + p.n_bkt + (size_t)B * 9 * p.NB + 2 * (size_t)B * 9 + 4 +
-               (size_t)(total_events > 0 ? total_events : 0)) * 4;
+    // bofs | groups [B*9*NB] | ngroups [B*9] | seg_flag [B*9] | status [4] | records (u32) | roff (u16)
+    p.bytes = (p.n_bkt + (size_t)B * 9 * p.NB + 2 * (size_t)B * 9 + 4 +
+               (size_t)(total_events > 0 ? total_events : 0)) * 4 + ((p.n_tab * 2 + 3) / 4) * 4;
     if (p.lds_tile > 160 * 1024 || p.lds_sort > 160 * 1024) p.ok = false;
     return p;
 }
@@ -1506,13 +1507,13 @@ extern "C" int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps
         P.tile_off = static_cast<const unsigned *>(tile_ws) + (size_t)B * pl.T * 9;
         P.span = pl.span;
         P.hist_bins = (4 * (pl.span << pl.shift)) > 4 * kMaxSpanKeys ? (4 * (pl.span << pl.shift)) : 4 * kMaxSpanKeys;
-        P.roff = w;
-        P.bofs = w + pl.n_tab;
+        P.bofs = w;
         P.groups = P.bofs + pl.n_bkt;
         P.ngroups = P.groups + (size_t)B * 9 * pl.NB;
         P.seg_flag = reinterpret_cast<int *>(P.ngroups + (size_t)B * 9);
         P.status = P.seg_flag + (size_t)B * 9;
         P.temp = reinterpret_cast<unsigned *>(P.status + 4);
+        P.roff = reinterpret_cast<unsigned short *>(P.temp + (size_t)total_events);
         V2CE_HIP_CHECK(hipMemsetAsync(P.status, 0, 4 * sizeof(int), st));
         {
             auto tile_kernel = pl.tile_threads == 512 ? ldati_tile_pass_kernel<512, 4> : ldati_tile_pass_kernel<1024, 2>;
@@ -1562,7 +1563,7 @@ extern "C" int v2ce_ldati_status(const void *workspace, int B, int H, int W, dou
     const Plan pl = make_plan(h, B, H, W, total_events, max_segment_events, max_tile_events);
     V2CE_REQUIRE(pl.ok, V2CE_ERR_UNSUPPORTED, "v2ce_ldati_status: no two-level plan for these arguments");
     const unsigned *w = static_cast<const unsigned *>(workspace);
-    *status_dev = reinterpret_cast<const int32_t *>(w + pl.n_tab + pl.n_bkt + (size_t)B * 9 * pl.NB + 2 * (size_t)B * 9);
+    *status_dev = reinterpret_cast<const int32_t *>(w + pl.n_bkt + (size_t)B * 9 * pl.NB + 2 * (size_t)B * 9);
     return V2CE_OK;
 }
 

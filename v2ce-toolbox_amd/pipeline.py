@@ -83,11 +83,20 @@ def resized_width(frames: np.ndarray, height: int) -> int:
     return int(frames.shape[2] / frames.shape[1] * height)
 
 
+_OUT_CACHE = {"buf": None}     # page-locked output buffer kept between clips (reuse_output=True)
+
+
 class EventSink:
     """Packed records of successive batches -> one pinned host buffer, filled by asynchronous D2H
-    copies on a copy stream; ``result()`` returns it as the structured array."""
+    copies on a copy stream; ``result()`` returns it as the structured array.
 
-    def __init__(self, device, total_pairs: int, to_host: bool = True):
+    Page-locking the buffer is the slow part of a short clip (~70 us per MB, i.e. ~140 ms for the
+    1.9 GB of 640 frame-pairs, against ~55 GB/s of D2H): with ``reuse=True`` the buffer is kept in the
+    process and handed out again, so only the first clip pays for it -- the returned array then
+    ALIASES that buffer and is overwritten by the next clip (copy it to keep it)."""
+
+    def __init__(self, device, total_pairs: int, to_host: bool = True, reuse: bool = False):
+        self.reuse = reuse
         self.device = torch.device(device)
         self.cuda = self.device.type == "cuda" and to_host   # else: keep the device / CPU tensors
         self.total_pairs = max(int(total_pairs), 1)
@@ -105,7 +114,13 @@ class EventSink:
         # size from the event rate seen so far, with headroom; growth is geometric
         rate = (need / max(self.pairs_seen, 1)) if self.pairs_seen else 0
         cap = max(int(rate * self.total_pairs * 1.25) + (1 << 20), need, 2 * (self.buf.numel() if self.buf is not None else 0))
-        new = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
+        cached = _OUT_CACHE["buf"] if self.reuse else None
+        if cached is not None and cached is not self.buf and cached.numel() >= need:
+            new = cached
+        else:
+            new = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
+            if self.reuse:
+                _OUT_CACHE["buf"] = new
         if self.buf is not None and self.used:
             self.stream.synchronize()
             new[:self.used].copy_(self.buf[:self.used])
@@ -212,13 +227,14 @@ def _voxels_of_batch(pred: torch.Tensor, bp: BatchPlan, seq_len: int) -> torch.T
     return vox
 
 
-def default_stage2(fps, seed):
-    """LDATI on the HIP device, split in begin (count, enqueued now) / finish (emit, later)."""
+def default_stage2(fps, seed, total_pairs, device):
+    """LDATI on the HIP device, split in begin (count, enqueued now) / finish (emit, later).  The
+    per-frame offsets int(i*1/fps*1e6) (v2ce.py:365) of the whole clip go to the device once."""
     from .LDATI import ldati_begin
+    offsets = torch.tensor([glue.frame_offset_us(i, fps) for i in range(total_pairs)], dtype=torch.int64).to(device)
 
     def begin(vox, first_pair):
-        add = torch.tensor([glue.frame_offset_us(first_pair + j, fps) for j in range(vox.shape[0])],
-                           dtype=torch.int64, device=vox.device)
+        add = offsets[first_pair:first_pair + vox.shape[0]]
         return ldati_begin(vox, fps=fps, seed=seed, frame_base=first_pair, frame_ts_add=add)
 
     def finish(pending):
@@ -229,15 +245,16 @@ def default_stage2(fps, seed):
 
 def run_clip(frames: np.ndarray, model, *, infer_type="center", seq_len=16, width=346, height=260,
              batch_size=1, fps=30, seed=0, device="cuda", stage2=None, dtype=None,
-             rank=0, world=1, group=None) -> Optional[np.ndarray]:
+             rank=0, world=1, group=None, trace: Optional[dict] = None,
+             reuse_output: bool = False) -> Optional[np.ndarray]:
     """frames [N,H,W] uint8 -> event_stream (structured array) on rank 0, None elsewhere.
 
     stage2: optional (begin, finish) pair replacing LDATI (CPU stand-ins in the tests):
     begin(vox, first_pair) -> handle; finish(handle) -> (packed uint8 tensor, keepalive)."""
     from .LDATI import EVENT_DTYPE
     dtype = dtype or EVENT_DTYPE
-    begin, finish = stage2 or default_stage2(fps, seed)
     plans = plan_batches(len(frames), seq_len, batch_size)
+    begin, finish = stage2 or default_stage2(fps, seed, len(frames) - 1, device)
     fw = resized_width(frames, height)
     tiles = pano_tiles(fw, width) if infer_type == "pano" else None
     if infer_type not in ("center", "pano"):
@@ -255,25 +272,40 @@ def run_clip(frames: np.ndarray, model, *, infer_type="center", seq_len=16, widt
     mine = plans[lo_b:hi_b]
     total_pairs = sum(bp.n_pairs for bp in mine)
     feeder = FrameFeeder(frames, seq_len, device, height)
-    sink = EventSink(device, total_pairs, to_host=world == 1)
+    sink = EventSink(device, total_pairs, to_host=world == 1, reuse=reuse_output)
     base_calls = int(getattr(model, "calls", 0))            # the reference keeps advancing one model
+    import time as _time
+
+    def tick(name, t0):
+        if trace is not None:
+            trace[name] = trace.get(name, 0.0) + _time.perf_counter() - t0
+            trace.setdefault("list:" + name, []).append(round(1e3 * (_time.perf_counter() - t0), 2))
+        return _time.perf_counter()
+
     segments = []                                          # (order key, bytes) of every pushed buffer
     statuses = []
     pending = None                                         # (stage-2 handle, order key, pairs)
 
     def flush(p):
         handle, key, n_pairs = p
+        t_f = _time.perf_counter()
         packed, keep = finish(handle)
+        t_f = tick("flush.finish", t_f)
         sink.push(packed, n_pairs, keep)
+        tick("flush.push", t_f)
         segments.append((key, int(packed.numel())))
         if hasattr(keep, "check"):
             statuses.append(keep)
 
+
     handle = feeder.submit(mine[0]) if mine else None
     with torch.no_grad():
         for i, bp in enumerate(mine):
+            tt = _time.perf_counter()
             units = feeder.take(handle, bp)
+            tt = tick("take", tt)
             handle = feeder.submit(mine[i + 1]) if i + 1 < len(mine) else None
+            tt = tick("submit", tt)
             if not tile_parallel:
                 vdist.fast_forward(model, base_calls + bp.index * calls_per_batch)
                 if infer_type == "center":
@@ -292,9 +324,12 @@ def run_clip(frames: np.ndarray, model, *, infer_type="center", seq_len=16, widt
                 widths = [(k if k else width) for _, _, k in tiles]
                 vox, p_lo = vdist.tiles_to_pairs(part, widths, tile_index, grp)  # [P_r,2,10,H,W_full]
                 first_pair, key = bp.first_pair + p_lo, (bp.index, tile_index)
+            tt = tick("model", tt)
             nxt = (begin(vox, first_pair), key, int(vox.shape[0]))
+            tt = tick("begin", tt)
             if pending is not None:
                 flush(pending)
+            tt = tick("flush", tt)
             pending = nxt
         if pending is not None:
             flush(pending)
