@@ -33,6 +33,11 @@ extern "C" {
 
 #define V2CE_STRATEGY_SLOPE 0 /* additional_events_strategy='slope' (the CLI's, v2ce.py:356) */
 #define V2CE_STRATEGY_NONE 1  /* 'none': voxels with more than one event emit nothing (LDATI.py:241) */
+#define V2CE_STRATEGY_RANDOM 2 /* 'random': the raw uniform is the time offset, in SECONDS (LDATI.py:173-174) */
+
+#define V2CE_POOL_NONE 0
+#define V2CE_POOL_AVG 1      /* nn.AvgPool2d(k, stride 1, padding k//2) of the counts before the slope (LDATI.py:181) */
+#define V2CE_POOL_WEIGHTED 2 /* 3x3 [[1,2,1],[2,4,2],[1,2,1]]/16 conv, zero padding (LDATI.py:178-180) */
 
 #define V2CE_ACT_NONE 0
 #define V2CE_ACT_RELU 1   /* torch.relu / nn.ReLU           (submodules.py:105,232) */
@@ -59,8 +64,17 @@ const char *v2ce_last_error(void);
  * total events).  stats [4] i64 = {max count of any voxel (LDATI.py:169 max_n), most events of one
  * (2048-pixel tile, bin), largest segment, total events}.  tile_ws (>= v2ce_ldati_tile_ws_bytes):
  * per-tile counts and offsets, consumed by v2ce_ldati_emit's two-level path. */
+/* The keyword options of sample_voxel_statistical (LDATI.py:126).  NULL = the CLI's call (v2ce.py:356):
+ * additional_events_strategy='slope', pooling_type='none', bidirectional=False. */
+typedef struct {
+    int32_t strategy;            /* V2CE_STRATEGY_* (additional_events_strategy) */
+    int32_t bidirectional;       /* y_relocate(bidirectional=True), LDATI.py:107-122 */
+    int32_t pooling_type;        /* V2CE_POOL_*; only shapes the 'slope' strategy */
+    int32_t pooling_kernel_size; /* 'avg' only; odd, 1..15 */
+} v2ce_ldati_options;
+
 size_t v2ce_ldati_tile_ws_bytes(int B, int H, int W);
-int v2ce_ldati_count(const float *vox, int B, int H, int W, int strategy, void *tile_ws,
+int v2ce_ldati_count(const float *vox, int B, int H, int W, const v2ce_ldati_options *options, void *tile_ws,
                      size_t tile_ws_bytes, int64_t *seg_offsets, int64_t *stats, v2ce_stream_t stream);
 
 /* Bytes of LDS the sweep (fallback) kernel needs per workgroup for this fps/t0; 0 = the key range
@@ -82,12 +96,18 @@ size_t v2ce_ldati_lds_bytes(double fps, double t0);
  * path: > 512 tiles per frame, > 15360 events in one tile-bin) + the tile_ws of v2ce_ldati_count
  * select the two-level path (tile pass -> coarse buckets -> LDS counting sort -> coalesced output);
  * workspace NULL runs the one-workgroup-per-segment sweep for every segment (no scratch, slower,
- * needs v2ce_ldati_lds_bytes != 0).  Both produce bit-identical output.  Segments with a coarse
- * bucket beyond the LDS capacity (degenerate ties) go to the sweep kernel inside the same call; if
- * the sweep cannot hold this fps either, the device status word (v2ce_ldati_status) becomes 1. */
-size_t v2ce_ldati_workspace_bytes(int B, int H, int W, double fps, double t0, int64_t total_events,
-                                  int64_t max_segment_events, int64_t max_tile_events);
-int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps, double t0, int strategy, int rng_mode,
+ * needs v2ce_ldati_lds_bytes != 0).  Both produce bit-identical output.  Coarse buckets beyond the LDS
+ * capacity of a sort workgroup (degenerate ties) are ordered by a dedicated, slower kernel inside the
+ * same call; the device status word (v2ce_ldati_status) stays 0 unless an internal limit is hit.
+ * Options: bidirectional relocation and the pooled slope (a pre-pass writes {k, b} per voxel) run on the
+ * two-level path (workspace required); 'random' spreads the timestamps of a bin over a whole second, far
+ * beyond the bucket machinery's key range: it takes a generic path (tile pass writing one 64-bit key per
+ * event, a library radix sort -- rocPRIM --, decode), workspace required. */
+size_t v2ce_ldati_workspace_bytes(int B, int H, int W, double fps, double t0, const v2ce_ldati_options *options,
+                                  int64_t total_events, int64_t max_segment_events, int64_t max_tile_events,
+                                  int packed_output);
+int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps, double t0,
+                    const v2ce_ldati_options *options, int rng_mode,
                     const float *uniforms, int replay_max_n, uint64_t seed, int64_t frame_base,
                     const int64_t *seg_offsets, const int64_t *frame_ts_add, int64_t *ts,
                     int16_t *x, int16_t *y, int8_t *p, uint8_t *packed, int64_t total_events,
@@ -95,16 +115,17 @@ int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps, double t0
                     void *workspace, size_t workspace_bytes, v2ce_stream_t stream);
 /* Device address of the status word (int32) inside a workspace used with the same arguments. */
 int v2ce_ldati_status(const void *workspace, int B, int H, int W, double fps, double t0,
-                      int64_t total_events, int64_t max_segment_events, int64_t max_tile_events,
-                      const int32_t **status_dev);
+                      const v2ce_ldati_options *options, int64_t total_events, int64_t max_segment_events,
+                      int64_t max_tile_events, const int32_t **status_dev);
 
 /* The two-level plan v2ce_ldati_emit would use (introspection for tools/tests): info [10] = {ok, fine-key
  * bits (shift), coarse buckets per segment, tiles per frame, tile-pass capacity, sort capacity, entries
  * of the per-tile tables, entries of the per-bucket tables, LDS bytes of the tile pass, of the sort}.
- * Workspace layout (u32 units): bofs [n_bkt = B*9*(NB+1)] | groups [B*9*NB] | ngroups [B*9] | seg_flag [B*9] |
- * status [4] | records [total] | roff [n_tab = B*9*T*(NB+1)] as u16. */
-int v2ce_ldati_plan_info(int B, int H, int W, double fps, double t0, int64_t total_events,
-                         int64_t max_segment_events, int64_t max_tile_events, int64_t *info);
+ * Workspace layout (u32 units): bofs [n_bkt = B*9*(NB+1)] | groups [B*9*NB] | big_list [B*9*NB] | ngroups [B*9] |
+ * seg_flag [B*9] | status [4] = {status, number of big buckets, -, -} | records [total] |
+ * roff [n_tab = B*9*T*(NB+1)] as u16. */
+int v2ce_ldati_plan_info(int B, int H, int W, double fps, double t0, const v2ce_ldati_options *options,
+                         int64_t total_events, int64_t max_segment_events, int64_t max_tile_events, int64_t *info);
 
 /* SoA <-> packed 13-byte records {i8 timestamp, i2 x, i2 y, i1 polarity}: the numpy recarray layout
  * of LDATI.py:308-309 (numpy.core.records.fromarrays, itemsize 13).  packed: n*13 bytes. */

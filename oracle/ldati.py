@@ -1,8 +1,8 @@
 """ctypes front-end of the C LDATI oracle (TEST INFRASTRUCTURE -- see oracle/__init__.py).
 
 ``sample_voxel_statistical_oracle`` mirrors the reference call
-``scripts/LDATI.py:126 sample_voxel_statistical`` for the options ``v2ce.py:356`` uses
-(``'slope'``, pooling ``'none'``, ``bidirectional=False``) and returns the same list of packed
+``scripts/LDATI.py:126 sample_voxel_statistical`` for every option value (``additional_events_strategy`` in 'slope' / 'none' / 'random', ``pooling_type`` in
+'none' / 'avg' / 'weighted', ``bidirectional``) and returns the same list of packed
 recarrays, but in the *stable* tie order (reference ``argsort`` is only stable for segments of
 >= 32768 events; see ``canonicalize``).
 """
@@ -45,6 +45,17 @@ def lib() -> ctypes.CDLL:
             ctypes.POINTER(ctypes.c_int16), ctypes.POINTER(ctypes.c_int16),
             ctypes.POINTER(ctypes.c_int8)]
         L.v2ce_oracle_ldati_emit.restype = ctypes.c_int
+        L.v2ce_oracle_ldati_count2.argtypes = [f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                               i64p, ctypes.POINTER(ctypes.c_int32)]
+        L.v2ce_oracle_ldati_count2.restype = ctypes.c_int
+        L.v2ce_oracle_ldati_emit2.argtypes = [
+            f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double,
+            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, f32p, ctypes.c_int, ctypes.c_uint64,
+            ctypes.c_int64, i64p, i64p, ctypes.POINTER(ctypes.c_int16), ctypes.POINTER(ctypes.c_int16),
+            ctypes.POINTER(ctypes.c_int8)]
+        L.v2ce_oracle_ldati_emit2.restype = ctypes.c_int
+        L.v2ce_oracle_relocate2.argtypes = [f32p, ctypes.c_int64, ctypes.c_int, i64p, f32p]
+        L.v2ce_oracle_relocate2.restype = None
         L.v2ce_oracle_philox_fill.argtypes = [f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_uint64, ctypes.c_int64]
         L.v2ce_oracle_philox_fill.restype = None
@@ -79,18 +90,29 @@ def relocate(y10: np.ndarray):
     return n, d
 
 
-STRATEGY = {"slope": 0, "none": 1}
+STRATEGY = {"slope": 0, "none": 1, "random": 2}
+POOLING = {"none": 0, "avg": 1, "weighted": 2}
 
 
-def count(vox: np.ndarray, strategy="slope"):
+def relocate2(y10: np.ndarray, bidirectional=False):
+    """relocate with the bidirectional option (LDATI.py:107-122)."""
+    y10 = np.ascontiguousarray(y10, dtype=np.float32)
+    n = np.zeros(9, np.int64)
+    d = np.zeros(9, np.float32)
+    lib().v2ce_oracle_relocate2(_p(y10, ctypes.c_float), 1, int(bidirectional), _p(n, ctypes.c_int64),
+                                _p(d, ctypes.c_float))
+    return n, d
+
+
+def count(vox: np.ndarray, strategy="slope", bidirectional=False):
     """vox [B,2,10,H,W] f32 -> (seg_counts [B,9] i64, max_n)."""
     vox = np.ascontiguousarray(vox, dtype=np.float32)
     B, P, C, H, W = vox.shape
     assert P == 2 and C == 10
     seg = np.zeros((B, 9), np.int64)
     mx = ctypes.c_int32(0)
-    rc = lib().v2ce_oracle_ldati_count(_p(vox, ctypes.c_float), B, H, W, STRATEGY[strategy], _p(seg, ctypes.c_int64),
-                                       ctypes.byref(mx))
+    rc = lib().v2ce_oracle_ldati_count2(_p(vox, ctypes.c_float), B, H, W, STRATEGY[strategy], int(bidirectional),
+                                        _p(seg, ctypes.c_int64), ctypes.byref(mx))
     assert rc == 0
     return seg, int(mx.value)
 
@@ -101,13 +123,14 @@ def philox_uniforms(B, H, W, max_n, seed, frame_base=0) -> np.ndarray:
     return out
 
 
-def emit_soa(vox, fps=30, t0=0.0, uniforms=None, seed=0, frame_base=0, strategy="slope"):
+def emit_soa(vox, fps=30, t0=0.0, uniforms=None, seed=0, frame_base=0, strategy="slope", bidirectional=False,
+             pooling_type="none", pooling_kernel_size=3):
     """Run count + emit.  ``uniforms`` (dense [B,2,9,H,W,max_n] f32) selects REPLAY mode, else
     Philox with ``seed``.  Returns (seg_counts [B,9], ts, x, y, p)."""
     check_arange_len(fps)
     vox = np.ascontiguousarray(vox, dtype=np.float32)
     B, _, _, H, W = vox.shape
-    seg, max_n = count(vox, strategy)
+    seg, max_n = count(vox, strategy, bidirectional)
     offs = np.zeros(B * 9 + 1, np.int64)
     np.cumsum(seg.reshape(-1), out=offs[1:])
     total = int(offs[-1])
@@ -123,11 +146,12 @@ def emit_soa(vox, fps=30, t0=0.0, uniforms=None, seed=0, frame_base=0, strategy=
         mode, uptr = RNG_REPLAY, _p(uniforms, ctypes.c_float)
     else:
         replay_max_n, mode, uptr = 0, RNG_PHILOX, None
-    rc = lib().v2ce_oracle_ldati_emit(_p(vox, ctypes.c_float), B, H, W, float(fps), float(t0), STRATEGY[strategy], mode,
-                                      uptr, replay_max_n, int(seed), int(frame_base),
-                                      _p(offs, ctypes.c_int64), _p(ts, ctypes.c_int64),
-                                      _p(x, ctypes.c_int16), _p(y, ctypes.c_int16),
-                                      _p(p, ctypes.c_int8))
+    rc = lib().v2ce_oracle_ldati_emit2(_p(vox, ctypes.c_float), B, H, W, float(fps), float(t0), STRATEGY[strategy],
+                                       int(bidirectional), POOLING[pooling_type], int(pooling_kernel_size), mode,
+                                       uptr, replay_max_n, int(seed), int(frame_base),
+                                       _p(offs, ctypes.c_int64), _p(ts, ctypes.c_int64),
+                                       _p(x, ctypes.c_int16), _p(y, ctypes.c_int16),
+                                       _p(p, ctypes.c_int8))
     if rc != 0:
         raise RuntimeError(f"v2ce_oracle_ldati_emit failed: {rc}")
     return seg, ts, x, y, p
@@ -139,11 +163,13 @@ def pack(ts, x, y, p) -> np.recarray:
     return rec.view(np.recarray)
 
 
-def sample_voxel_statistical_oracle(y, t0=0, fps=30, uniforms=None, seed=0, frame_base=0, strategy="slope"):
+def sample_voxel_statistical_oracle(y, t0=0, fps=30, uniforms=None, seed=0, frame_base=0, strategy="slope",
+                                    bidirectional=False, pooling_type="none", pooling_kernel_size=3):
     """Oracle twin of ``sample_voxel_statistical`` (LDATI.py:126): list[B] of packed recarrays."""
     vox = np.asarray(y, dtype=np.float32)
     seg, ts, x, yy, p = emit_soa(vox, fps=fps, t0=t0, uniforms=uniforms, seed=seed,
-                                 frame_base=frame_base, strategy=strategy)
+                                 frame_base=frame_base, strategy=strategy, bidirectional=bidirectional,
+                                 pooling_type=pooling_type, pooling_kernel_size=pooling_kernel_size)
     per_frame = seg.sum(axis=1)
     ends = np.cumsum(per_frame)
     out = []

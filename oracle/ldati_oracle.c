@@ -35,6 +35,45 @@ void v2ce_oracle_relocate(const float *y10, int64_t stride, int64_t n[9], float 
 }
 
 /* ---------------------------------------------------------------------------------------------
+ * bidirectional=True -- LDATI.py:107-122.  Bins 0..3 run the forward recurrence; bins 8,7,6 run
+ * backwards from bless = y[9]: tendency = bless; n = floor((y + bless) + 1e-6);
+ * bless = max(0, (y - n) + bless); bin 5 merges both: tendency = bless - debt, n = ceil((y + bless) - debt);
+ * bin 4 is never written by the reference (range(4) / range(8, 5, -1) / 5) and stays 0.
+ * f32 arithmetic operation by operation; tendency is stored into an f64 tensor (kept as f32 here).
+ * ------------------------------------------------------------------------------------------- */
+void v2ce_oracle_relocate2(const float *y10, int64_t stride, int bidirectional, int64_t n[9], float tend[9]) {
+    if (!bidirectional) {
+        v2ce_oracle_relocate(y10, stride, n, tend);
+        return;
+    }
+    const float eps = (float)1e-6;
+    float d = 0.0f;
+    for (int i = 0; i < 9; ++i) { n[i] = 0; tend[i] = 0.0f; }
+    for (int i = 0; i < 4; ++i) {                 /* LDATI.py:96-103 with from_left_until = 4 */
+        float r = y10[i * stride] - d;
+        float c = ceilf(r - eps);
+        d = c - r;
+        n[i] = (int64_t)c;
+        tend[i] = d;
+    }
+    float bless = y10[9 * stride];                /* LDATI.py:108 */
+    for (int i = 8; i > 5; --i) {                 /* LDATI.py:109-117 */
+        const float ys = y10[i * stride];
+        tend[i] = bless;
+        float t = ys + bless;
+        t = floorf(t + eps);
+        bless = (ys - t) + bless;
+        bless = bless < 0.0f ? 0.0f : bless;      /* torch.clamp(min=0) */
+        n[i] = (int64_t)t;
+    }
+    {                                             /* LDATI.py:119-122, i = C//2 = 5 */
+        const float ys = y10[5 * stride];
+        tend[5] = bless - d;
+        n[5] = (int64_t)ceilf((ys + bless) - d);
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------
  * Philox4x32-10 (Salmon et al., SC'11), counter = (pixel, j>>2, p*9+c, frame), key = seed.
  * The j&3-th output word gives the uniform (word >> 8) * 2^-24, the same 24-bit convention as
  * torch's CPU uniform_real_distribution<float>.
@@ -80,8 +119,8 @@ void v2ce_oracle_philox_fill(float *out, int B, int H, int W, int max_n, uint64_
 }
 
 /* --------------------------------------------------------------------------------------------- */
-int v2ce_oracle_ldati_count(const float *vox, int B, int H, int W, int strategy, int64_t *seg_counts,
-                            int32_t *max_n) {
+int v2ce_oracle_ldati_count2(const float *vox, int B, int H, int W, int strategy, int bidirectional,
+                             int64_t *seg_counts, int32_t *max_n) {
     const int64_t HW = (int64_t)H * W;
     int64_t mx = 0;
     for (int b = 0; b < B; ++b) {
@@ -92,7 +131,7 @@ int v2ce_oracle_ldati_count(const float *vox, int B, int H, int W, int strategy,
             for (int64_t px = 0; px < HW; ++px) {
                 int64_t n[9];
                 float d[9];
-                v2ce_oracle_relocate(base + px, HW, n, d);
+                v2ce_oracle_relocate2(base + px, HW, bidirectional, n, d);
                 for (int c = 0; c < 9; ++c) {
                     /* pick_elements keeps n==1 singles and the first n draws of n>=2 voxels
                      * (LDATI.py:228,236-239); n<=0 contributes nothing. */
@@ -106,6 +145,11 @@ int v2ce_oracle_ldati_count(const float *vox, int B, int H, int W, int strategy,
     /* torch.max of the int64 count tensor; negative maxima cannot size a tensor */
     *max_n = (int32_t)(mx < 0 ? 0 : mx);
     return 0;
+}
+
+int v2ce_oracle_ldati_count(const float *vox, int B, int H, int W, int strategy, int64_t *seg_counts,
+                            int32_t *max_n) {
+    return v2ce_oracle_ldati_count2(vox, B, H, W, strategy, 0, seg_counts, max_n);
 }
 
 /* stable merge sort of an index permutation by key */
@@ -127,6 +171,38 @@ int v2ce_oracle_ldati_emit(const float *vox, int B, int H, int W, double fps, do
                            int strategy, int rng_mode, const float *uniforms, int replay_max_n, uint64_t seed,
                            int64_t frame_base, const int64_t *seg_offsets, int64_t *ts_out,
                            int16_t *x_out, int16_t *y_out, int8_t *p_out) {
+    return v2ce_oracle_ldati_emit2(vox, B, H, W, fps, t0, strategy, 0, V2CE_ORACLE_POOL_NONE, 3, rng_mode, uniforms,
+                                   replay_max_n, seed, frame_base, seg_offsets, ts_out, x_out, y_out, p_out);
+}
+
+/* Pooled counts of one (frame, polarity) plane stack for the slope -- LDATI.py:177-182.
+ * 'weighted': F.conv2d with [[1,2,1],[2,4,2],[1,2,1]]/16, padding 1 (zeros); 'avg': nn.AvgPool2d(k,
+ * stride 1, padding k//2), count_include_pad: sum / (k*k).  The counts are integers and the weights
+ * powers of two over 16, so every partial sum is exact in f32 whatever the summation order. */
+static void pool_plane(const int64_t *nn /* [HW][9] */, int H, int W, int pooling, int k, float *yp /* [HW][9] */) {
+    static const float w3[3][3] = {{1, 2, 1}, {2, 4, 2}, {1, 2, 1}};
+    const int r = pooling == V2CE_ORACLE_POOL_WEIGHTED ? 1 : k / 2;
+    for (int h = 0; h < H; ++h)
+        for (int w = 0; w < W; ++w)
+            for (int c = 0; c < 9; ++c) {
+                float acc = 0.0f;
+                for (int dh = -r; dh <= r; ++dh)
+                    for (int dw = -r; dw <= r; ++dw) {
+                        const int hh = h + dh, ww = w + dw;
+                        if (hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
+                        const float v = (float)nn[((int64_t)hh * W + ww) * 9 + c];
+                        acc += pooling == V2CE_ORACLE_POOL_WEIGHTED ? v * (w3[dh + 1][dw + 1] / 16.0f) : v;
+                    }
+                if (pooling == V2CE_ORACLE_POOL_AVG) acc = acc / (float)(k * k);
+                yp[((int64_t)h * W + w) * 9 + c] = acc;
+            }
+}
+
+int v2ce_oracle_ldati_emit2(const float *vox, int B, int H, int W, double fps, double t0,
+                            int strategy, int bidirectional, int pooling, int pooling_k,
+                            int rng_mode, const float *uniforms, int replay_max_n, uint64_t seed,
+                            int64_t frame_base, const int64_t *seg_offsets, int64_t *ts_out,
+                            int16_t *x_out, int16_t *y_out, int8_t *p_out) {
     if (rng_mode == V2CE_ORACLE_RNG_REPLAY && uniforms == NULL && replay_max_n > 0) return -1;
     const int64_t HW = (int64_t)H * W;
 
@@ -142,13 +218,15 @@ int v2ce_oracle_ldati_emit(const float *vox, int B, int H, int W, double fps, do
 
     int64_t *nn = (int64_t *)malloc((size_t)(2 * HW * 9) * sizeof(int64_t));
     float *dd = (float *)malloc((size_t)(2 * HW * 9) * sizeof(float));
-    if (!nn || !dd) { free(nn); free(dd); return -2; }
+    float *yp = pooling != V2CE_ORACLE_POOL_NONE ? (float *)malloc((size_t)(2 * HW * 9) * sizeof(float)) : NULL;
+    if (!nn || !dd || (pooling != V2CE_ORACLE_POOL_NONE && !yp)) { free(nn); free(dd); free(yp); return -2; }
 
     for (int b = 0; b < B; ++b) {
         for (int p = 0; p < 2; ++p) {
             const float *base = vox + ((int64_t)(b * 2 + p) * 10) * HW;
             for (int64_t px = 0; px < HW; ++px)
-                v2ce_oracle_relocate(base + px, HW, nn + (p * HW + px) * 9, dd + (p * HW + px) * 9);
+                v2ce_oracle_relocate2(base + px, HW, bidirectional, nn + (p * HW + px) * 9, dd + (p * HW + px) * 9);
+            if (yp) pool_plane(nn + (int64_t)p * HW * 9, H, W, pooling, pooling_k, yp + (int64_t)p * HW * 9);
         }
         for (int c = 0; c < 9; ++c) {
             const int64_t seg_lo = seg_offsets[(int64_t)b * 9 + c];
@@ -186,12 +264,22 @@ int v2ce_oracle_ldati_emit(const float *vox, int B, int H, int W, double fps, do
                     const int64_t *n = nn + (p * HW + px) * 9;
                     const int64_t nc = n[c];
                     if (nc < 2 || strategy == V2CE_ORACLE_STRATEGY_NONE) continue;
-                    /* slope: reflect pad + [-1,0,1] conv -- LDATI.py:25,30,39; (3*sxy-0)/6 :45 */
-                    const int64_t nl = c == 0 ? n[1] : n[c - 1];
-                    const int64_t nr = c == 8 ? n[7] : n[c + 1];
-                    const float sxy = (float)nr - (float)nl;
+                    /* slope: reflect pad + [-1,0,1] conv -- LDATI.py:25,30,39; (3*sxy-0)/6 :45; on the
+                     * pooled counts when pooling is on (LDATI.py:177-188) */
+                    float fl, fr, fc;
+                    if (yp) {
+                        const float *q = yp + (p * HW + px) * 9;
+                        fl = c == 0 ? q[1] : q[c - 1];
+                        fr = c == 8 ? q[7] : q[c + 1];
+                        fc = q[c];
+                    } else {
+                        fl = (float)(c == 0 ? n[1] : n[c - 1]);
+                        fr = (float)(c == 8 ? n[7] : n[c + 1]);
+                        fc = (float)nc;
+                    }
+                    const float sxy = fr - fl;
                     const float k0 = (3.0f * sxy) / 6.0f;
-                    const float k = (k0 / VS2) / ((float)nc + (float)1e-8);  /* LDATI.py:188 */
+                    const float k = (k0 / VS2) / (fc + (float)1e-8);         /* LDATI.py:188 */
                     const float bb = INV - (VS * k) / 2.0f;                  /* LDATI.py:190 */
                     for (int64_t j = 0; j < nc; ++j) {
                         float u;
@@ -205,7 +293,9 @@ int v2ce_oracle_ldati_emit(const float *vox, int B, int H, int W, double fps, do
                                                            (uint32_t)(frame_base + b));
                         }
                         float t;
-                        if (k == 0.0f) {
+                        if (strategy == V2CE_ORACLE_STRATEGY_RANDOM) {
+                            t = u;                                          /* LDATI.py:173-174 */
+                        } else if (k == 0.0f) {
                             t = (u / FPS) / 9.0f;                           /* LDATI.py:196 */
                         } else {
                             const float s = bb * bb + (2.0f * k) * u;       /* LDATI.py:195 */
@@ -235,11 +325,12 @@ int v2ce_oracle_ldati_emit(const float *vox, int B, int H, int W, double fps, do
             continue;
         overflow:
             free(ets); free(ex); free(ey); free(ep); free(idx); free(tmp);
-            free(nn); free(dd);
+            free(nn); free(dd); free(yp);
             return -3; /* seg_offsets inconsistent with the voxels */
         }
     }
     free(nn);
     free(dd);
+    free(yp);
     return 0;
 }

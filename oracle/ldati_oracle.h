@@ -22,6 +22,11 @@ extern "C" {
 
 #define V2CE_ORACLE_STRATEGY_SLOPE 0 /* additional_events_strategy='slope' */
 #define V2CE_ORACLE_STRATEGY_NONE 1  /* 'none': only single-event voxels emit (LDATI.py:206-207,241) */
+#define V2CE_ORACLE_STRATEGY_RANDOM 2 /* 'random': the raw uniform IS the time offset in seconds (LDATI.py:173-174) */
+
+#define V2CE_ORACLE_POOL_NONE 0
+#define V2CE_ORACLE_POOL_AVG 1      /* nn.AvgPool2d(k, stride 1, padding k//2) of the counts (LDATI.py:181) */
+#define V2CE_ORACLE_POOL_WEIGHTED 2 /* 3x3 [[1,2,1],[2,4,2],[1,2,1]]/16 conv, zero padding (LDATI.py:178-180) */
 
 #define V2CE_ORACLE_RNG_REPLAY 0 /* uniforms read from a dense [B,2,9,H,W,max_n] tensor      */
 #define V2CE_ORACLE_RNG_PHILOX 1 /* Philox4x32-10, counter (pixel, j>>2, p*9+c, frame), key seed */
@@ -43,6 +48,17 @@ int v2ce_oracle_ldati_emit(const float *vox, int B, int H, int W, double fps, do
                            int strategy, int rng_mode, const float *uniforms, int replay_max_n, uint64_t seed,
                            int64_t frame_base, const int64_t *seg_offsets, int64_t *ts,
                            int16_t *x, int16_t *y, int8_t *p);
+
+/* The same with the remaining options of sample_voxel_statistical (LDATI.py:126): bidirectional
+ * relocation (LDATI.py:107-122), pooled counts for the slope (LDATI.py:177-182), 'random' strategy. */
+void v2ce_oracle_relocate2(const float *y10, int64_t stride, int bidirectional, int64_t n[9], float tend[9]);
+int v2ce_oracle_ldati_count2(const float *vox, int B, int H, int W, int strategy, int bidirectional,
+                             int64_t *seg_counts, int32_t *max_n);
+int v2ce_oracle_ldati_emit2(const float *vox, int B, int H, int W, double fps, double t0,
+                            int strategy, int bidirectional, int pooling, int pooling_k,
+                            int rng_mode, const float *uniforms, int replay_max_n, uint64_t seed,
+                            int64_t frame_base, const int64_t *seg_offsets, int64_t *ts,
+                            int16_t *x, int16_t *y, int8_t *p);
 
 /* Materialise the Philox uniforms as the dense [B,2,9,H,W,max_n] tensor the reference would have
  * drawn with torch.rand (used only by oracle/make_goldens.py to feed the reference). */

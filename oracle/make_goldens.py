@@ -144,10 +144,10 @@ def gen_unet():
 
 
 # --------------------------------------------------------------------------------------------- G3
-def run_ref_ldati(vox, fps, t0, seed, ieee_sqrt=False, strategy="slope"):
+def run_ref_ldati(vox, fps, t0, seed, ieee_sqrt=False, strategy="slope", **opts):
     with RandCapture() as cap:
         torch.manual_seed(seed)
-        kw = dict(t0=t0, fps=fps, additional_events_strategy=strategy)
+        kw = dict(t0=t0, fps=fps, additional_events_strategy=strategy, **opts)
         if ieee_sqrt:
             with IeeeSqrt():
                 res = REF_LDATI.sample_voxel_statistical(torch.from_numpy(vox), **kw)
@@ -184,6 +184,44 @@ def gen_ldati_small():
                             fps=np.float64(fps), t0=np.float64(t0), lens=lens,
                             events=np.frombuffer(ev.tobytes(), np.uint8))
         print(f"G3 {name}: B={B} HxW={H}x{W} fps={fps} t0={t0} max_n={u.shape[-1]} events={lens}")
+
+
+def gen_ldati_options():
+    """G3 for the remaining option values of sample_voxel_statistical (LDATI.py:126):
+    bidirectional relocation, pooled slope, 'random' strategy."""
+    cases = {
+        "bidir": (synth.synthetic_voxels(2, 12, 14, seed=31, regime="stress"), 30, 0, dict(bidirectional=True)),
+        "bidir_sparse": (synth.synthetic_voxels(3, 12, 14, seed=32, regime="sparse"), 25, 0.25, dict(bidirectional=True)),
+        "avg3": (synth.synthetic_voxels(2, 12, 14, seed=33, regime="stress"), 30, 0, dict(pooling_type="avg")),
+        "avg5": (synth.synthetic_voxels(2, 9, 11, seed=34, regime="stress"), 60, 0,
+                 dict(pooling_type="avg", pooling_kernel_size=5)),
+        "weighted": (synth.synthetic_voxels(2, 12, 14, seed=35, regime="stress"), 30, 0, dict(pooling_type="weighted")),
+        "random": (synth.synthetic_voxels(2, 12, 14, seed=36, regime="stress"), 30, 0,
+                   dict(additional_events_strategy="random")),
+        "bidir_weighted": (synth.synthetic_voxels(2, 12, 14, seed=37, regime="stress"), 30, 0,
+                           dict(bidirectional=True, pooling_type="weighted")),
+    }
+    for name, (vox, fps, t0, opts) in cases.items():
+        opts = dict(opts)
+        strategy = opts.pop("additional_events_strategy", "slope")
+        for seed in range(200, 260):
+            res, u = run_ref_ldati(vox, fps, t0, seed, strategy=strategy, **opts)
+            res_ieee, _ = run_ref_ldati(vox, fps, t0, seed, ieee_sqrt=True, strategy=strategy, **opts)
+            if all(events_equal(a, b) for a, b in zip(res, res_ieee)):
+                break
+        else:
+            raise AssertionError(f"{name}: MKL-VML sqrt and IEEE sqrt disagree for every seed tried")
+        B, _, _, H, W = vox.shape
+        u = u.reshape(B, 2, 9, H, W, -1)
+        lens = np.array([len(r) for r in res], np.int64)
+        ev = np.concatenate([np.asarray(r) for r in res])
+        np.savez_compressed(os.path.join(GOLD, f"ldati_g3_opt_{name}.npz"), vox=vox, uniforms=u,
+                            fps=np.float64(fps), t0=np.float64(t0), lens=lens,
+                            events=np.frombuffer(ev.tobytes(), np.uint8),
+                            strategy=np.array(strategy), bidirectional=np.array(bool(opts.get("bidirectional", False))),
+                            pooling_type=np.array(opts.get("pooling_type", "none")),
+                            pooling_kernel_size=np.array(int(opts.get("pooling_kernel_size", 3))))
+        print(f"G3 option {name}: seed {seed} B={B} HxW={H}x{W} fps={fps} t0={t0} max_n={u.shape[-1]} events={lens}")
 
 
 # --------------------------------------------------------------------------------------------- G4
@@ -367,13 +405,15 @@ def gen_voxelize():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["unet", "ldati", "large", "kat", "glue", "voxelize"]
+    which = sys.argv[1:] or ["unet", "ldati", "options", "large", "kat", "glue", "voxelize"]
     if "voxelize" in which:
         gen_voxelize()
     if "unet" in which:
         gen_unet()
     if "ldati" in which:
         gen_ldati_small()
+    if "options" in which:
+        gen_ldati_options()
     if "large" in which:
         gen_ldati_large()
     if "kat" in which:

@@ -29,12 +29,14 @@ def test_library_exports_every_declared_symbol():
 
 def test_argument_validation_without_gpu():
     L = hip.lib()
-    assert L.v2ce_ldati_count(None, 1, 4, 4, 0, None, 0, None, None, None) == -1
+    assert L.v2ce_ldati_count(None, 1, 4, 4, None, None, 0, None, None, None) == -1
     assert b"null" in L.v2ce_last_error()
     assert L.v2ce_ldati_lds_bytes(30.0, 0.0) > 0
     assert L.v2ce_ldati_lds_bytes(5.0, 0.0) == 0          # bin too wide for the sweep kernel's LDS histogram ...
-    assert L.v2ce_ldati_workspace_bytes(1, 260, 346, 5.0, 0.0, 100000, 20000, 500) > 0     # ... the two-level path runs
-    assert L.v2ce_ldati_workspace_bytes(1, 260, 346, 30.0, 0.0, 10 ** 7, 10 ** 6, 20000) == 0   # tile-bin beyond LDS
+    assert L.v2ce_ldati_workspace_bytes(1, 260, 346, 5.0, 0.0, None, 100000, 20000, 500, 1) > 0     # ... the two-level path runs
+    assert L.v2ce_ldati_workspace_bytes(1, 260, 346, 30.0, 0.0, None, 10 ** 7, 10 ** 6, 20000, 1) == 0   # tile-bin beyond LDS
+    rnd = hip.LdatiOptions(strategy=hip.STRATEGY_RANDOM, bidirectional=0, pooling_type=0, pooling_kernel_size=3)
+    assert L.v2ce_ldati_workspace_bytes(1, 260, 346, 30.0, 0.0, ctypes.byref(rnd), 100000, 20000, 500, 1) > 16 * 100000
     assert L.v2ce_ldati_tile_ws_bytes(24, 260, 346) == 2 * 24 * 88 * 9 * 4
     assert L.v2ce_sn_workspace_bytes(512, 13824) >= 4 * (512 + 13824)
     d = hip.ConvDesc(B=1, T=16, C0=64, H0=130, W0=173, C1=0, Hin=130, Win=173, Cout=64, Hout=130,

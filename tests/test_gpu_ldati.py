@@ -14,13 +14,13 @@ pytestmark = pytest.mark.gpu
 
 
 def hip_events(vox, fps=30, t0=0, uniforms=None, seed=None, frame_base=0, frame_ts_add=None, path="bucket",
-               strategy="slope", layout="packed"):
+               strategy="slope", layout="packed", **opts):
     from v2ce_toolbox_amd.LDATI import ldati_device
     y = torch.from_numpy(np.ascontiguousarray(vox)).cuda()
     u = None if uniforms is None else torch.from_numpy(np.ascontiguousarray(uniforms)).cuda()
     add = None if frame_ts_add is None else torch.from_numpy(frame_ts_add).cuda()
     ev = ldati_device(y, t0=t0, fps=fps, uniforms=u, seed=seed, frame_base=frame_base, frame_ts_add=add,
-                      path=path, strategy=strategy, layout=layout)
+                      path=path, strategy=strategy, layout=layout, **opts)
     torch.cuda.synchronize()
     ev.check()
     return ev
@@ -50,6 +50,41 @@ def test_replay_matches_reference_golden_and_oracle(gold_dir, name, path):
     assert np.array_equal(mine["timestamp"], ref["timestamp"])
     assert O.canonicalize(mine, ev.seg_counts.reshape(-1)).tobytes() == \
         O.canonicalize(ref, ev.seg_counts.reshape(-1)).tobytes()
+
+
+OPTION_CASES = ["bidir", "bidir_sparse", "avg3", "avg5", "weighted", "random", "bidir_weighted"]
+
+
+@pytest.mark.parametrize("layout", ["packed", "soa"])
+@pytest.mark.parametrize("name", OPTION_CASES)
+def test_option_goldens(gold_dir, name, layout):
+    """bidirectional (LDATI.py:107-122), pooling (:177-182), 'random' (:173-174): the
+    reference's own output for the same voxels and uniforms (REPLAY), and the oracle bit for bit."""
+    z = np.load(os.path.join(gold_dir, f"ldati_g3_opt_{name}.npz"))
+    vox, u, fps, t0 = z["vox"], z["uniforms"], float(z["fps"]), float(z["t0"])
+    ref = np.frombuffer(z["events"].tobytes(), O.EVENT_DTYPE)
+    opts = dict(bidirectional=bool(z["bidirectional"]), pooling_type=str(z["pooling_type"]),
+                pooling_kernel_size=int(z["pooling_kernel_size"]))
+    strategy = str(z["strategy"])
+    ev = hip_events(vox, fps, t0, uniforms=u, strategy=strategy, layout=layout, **opts)
+    soa_equal(ev, *O.emit_soa(vox, fps=fps, t0=t0, uniforms=u, strategy=strategy, **opts))
+    mine = np.concatenate(ev.to_recarrays())
+    assert np.array_equal(ev.frame_counts, z["lens"])
+    assert np.array_equal(mine["timestamp"], ref["timestamp"])
+    assert O.canonicalize(mine, ev.seg_counts.reshape(-1)).tobytes() == \
+        O.canonicalize(ref, ev.seg_counts.reshape(-1)).tobytes()
+
+
+@pytest.mark.parametrize("opts", [dict(bidirectional=True), dict(pooling_type="weighted"),
+                                  dict(pooling_type="avg", pooling_kernel_size=5), dict(strategy="random"),
+                                  dict(bidirectional=True, pooling_type="avg")])
+def test_options_philox_full_size(opts):
+    """The options at 346x260 (several tiles per frame, halo of the pooling window across tile and
+    image borders) against the oracle, Philox draws."""
+    vox = synth.synthetic_voxels(2, 260, 346, seed=41, regime="sparse")
+    strategy = opts.pop("strategy", "slope")
+    want = O.emit_soa(vox, fps=30, seed=123, frame_base=2, strategy=strategy, **opts)
+    soa_equal(hip_events(vox, seed=123, frame_base=2, strategy=strategy, **opts), *want)
 
 
 def test_hand_kat(gold_dir):
@@ -127,9 +162,9 @@ def test_dense_tile_falls_back_to_sweep():
     soa_equal(hip_events(vox, seed=21), *want)
 
 
-def test_degenerate_ties_take_the_sweep_fallback():
+def test_degenerate_ties_take_the_big_bucket_kernel():
     """Constant voxels: every pixel emits identical timestamps, so one (segment, key) bucket holds
-    far more records than the LDS sort capacity; the flagged segments go through the sweep kernel
+    far more records than a sort workgroup's LDS; those buckets are ordered by the big-bucket kernel
     and the output is still the stable order."""
     vox = np.full((2, 2, 10, 120, 130), 0.5, np.float32)      # singles at identical times
     vox[1, :, 3] = 2.0                                        # plus multi-event voxels in one bin
@@ -174,11 +209,11 @@ def test_option_errors():
     y = torch.zeros(1, 2, 10, 4, 4, device="cuda")
     with pytest.raises(AssertionError):
         sample_voxel_statistical(y, pooling_type="bogus")
-    with pytest.raises(NotImplementedError):
-        sample_voxel_statistical(y, bidirectional=True)
-    with pytest.raises(NotImplementedError):
-        sample_voxel_statistical(y, additional_events_strategy="random")
-    assert len(sample_voxel_statistical(y, additional_events_strategy="none")) == 1
+    with pytest.raises(AssertionError):
+        sample_voxel_statistical(y, additional_events_strategy="bogus")
+    for kw in (dict(bidirectional=True), dict(additional_events_strategy="random"), dict(pooling_type="avg"),
+               dict(additional_events_strategy="none")):
+        assert len(sample_voxel_statistical(y, **kw)) == 1
     with pytest.raises(Exception):
         sample_voxel_statistical(torch.zeros(1, 2, 10, 4, 4))      # CPU tensor: no CPU path
 

@@ -317,6 +317,47 @@ def test_conv3d_split_half_dynamic_range(mag):
     assert np.abs(got - want).max() <= 2e-6 * ref_mag
 
 
+@pytest.mark.parametrize("outlier", [1e4, 1e6, 1e8])
+def test_conv3d_split_half_single_outlier(outlier):
+    """ONE huge activation among O(1) values: the tensor-wide power-of-two
+    pre-scale is set by the outlier, so the O(1) values sit `r = log2(outlier)` binades below the
+    maximum; their lo half goes fp16-subnormal beyond r = 17 and keeps 22 - (r - 17) bits.  Outputs
+    whose receptive field misses the outlier are checked at the north_star bar (1e-5 abs + 1e-5 rel);
+    the print shows the measured error for the record (documented bound: include/v2ce_hip.h)."""
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1, 32, 4, 24, 30, generator=g)
+    x[0, 5, 2, 12, 15] = outlier
+    w = torch.randn(64, 32, 3, 3, 3, generator=g) * (2.0 / (32 * 27)) ** 0.5
+    one, zero = torch.ones(64), torch.zeros(64)
+    got = hip_conv_split(x, w, one, zero, 1, 0, tracked=True)
+    want = ref_conv(x, w, one, zero, 3, 1, 0)
+    far = np.ones(want.shape, bool)
+    far[:, :, 1:4, 11:14, 14:17] = False                       # outputs that see the outlier
+    err = np.abs(got - want)
+    excess_far = (err - TOL * np.abs(want))[far].max()
+    rel_near = (err / np.abs(want).clip(1e-30))[~far].max()
+    print(f"outlier {outlier:g}: max |err| away from it {err[far].max():.3e}, max rel err at it {rel_near:.3e}")
+    assert rel_near <= 1e-5
+    if outlier <= 1e6:
+        assert excess_far <= TOL, excess_far
+    else:          # 27 binades: ~12 bits left for the O(1) values -- the documented limit of one scale per tensor
+        assert excess_far <= 5e-3
+
+
+def test_conv3d_split_half_heavy_tail():
+    """Heavy-tailed activations (Student-t, 2 degrees of freedom: max/median ~ 1e3..1e4) stay at the bar."""
+    g = torch.Generator().manual_seed(12)
+    z = torch.randn(1, 64, 3, 20, 26, generator=g)
+    chi = (torch.randn(z.shape, generator=g) ** 2 + torch.randn(z.shape, generator=g) ** 2) / 2
+    x = z / chi.sqrt().clamp_min(1e-3)
+    w = torch.randn(64, 64, 3, 3, 3, generator=g) * (2.0 / (64 * 27)) ** 0.5
+    one, zero = torch.ones(64), torch.zeros(64)
+    got = hip_conv_split(x, w, one, zero, 1, 0, tracked=True)
+    want = ref_conv(x, w, one, zero, 3, 1, 0)
+    assert float(x.abs().max() / x.abs().median()) > 300
+    assert_close(got, want, "heavy tail")
+
+
 def test_conv3d_records_output_absmax():
     from v2ce_toolbox_amd.v2ce_3d import V2ce3d
     g = torch.Generator().manual_seed(3)

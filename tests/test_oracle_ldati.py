@@ -35,6 +35,39 @@ def test_oracle_matches_reference_golden(gold_dir, name):
     assert np.array_equal(ref["timestamp"], mine["timestamp"])
 
 
+OPTION_CASES = ["bidir", "bidir_sparse", "avg3", "avg5", "weighted", "random", "bidir_weighted"]
+
+
+def load_opt(gold_dir, name):
+    z = np.load(os.path.join(gold_dir, f"ldati_g3_opt_{name}.npz"))
+    ev = np.frombuffer(z["events"].tobytes(), O.EVENT_DTYPE)
+    opts = dict(strategy=str(z["strategy"]), bidirectional=bool(z["bidirectional"]),
+                pooling_type=str(z["pooling_type"]), pooling_kernel_size=int(z["pooling_kernel_size"]))
+    return z["vox"], z["uniforms"], float(z["fps"]), float(z["t0"]), z["lens"], ev, opts
+
+
+@pytest.mark.parametrize("name", OPTION_CASES)
+def test_oracle_matches_reference_option_goldens(gold_dir, name):
+    """bidirectional (LDATI.py:107-122), pooling (:177-182), 'random' (:173-174) against the
+    reference's own output for the same voxels and uniforms."""
+    vox, u, fps, t0, lens, ref, opts = load_opt(gold_dir, name)
+    seg, ts, x, y, p = O.emit_soa(vox, fps=fps, t0=t0, uniforms=u, **opts)
+    mine = np.asarray(O.pack(ts, x, y, p))
+    assert np.array_equal(seg.sum(axis=1), lens)
+    assert np.array_equal(ref["timestamp"], mine["timestamp"])
+    a = O.canonicalize(ref, seg.reshape(-1))
+    b = O.canonicalize(mine, seg.reshape(-1))
+    assert a.tobytes() == b.tobytes()
+
+
+def test_bidirectional_relocation_quirks():
+    """bin 4 is never written by the reference's bidirectional branch (stays 0); bin 8's tendency is y[9]."""
+    y = np.array([3.6122, 5.5396, 1.5710, 5.0188, 1.3165, 2.8533, 1.7283, 1.4550, 5.8432, 2.1986], np.float32)
+    n, tend = O.relocate2(y, bidirectional=True)
+    assert n.tolist() == [4, 6, 1, 5, 0, 3, 2, 1, 8]
+    assert tend[4] == 0 and tend[8] == y[9] and tend[5] < 0
+
+
 def test_hand_kat(gold_dir):
     kat = json.load(open(os.path.join(gold_dir, "ldati_kat.json")))["hand"]
     vox = np.array(kat["vox"], np.float32).reshape(kat["shape"])

@@ -28,17 +28,17 @@ B = 64
 max_n, max_tile, max_seg, total = (int(v) for v in host[B * 9 + 1:])
 print("max_n", max_n, "max_tile", max_tile, "max_seg", max_seg, "total", total)
 info = (ctypes.c_int64 * 10)()
-hip.lib().v2ce_ldati_plan_info(B, 260, 346, 30.0, 0.0, total, max_seg, max_tile, info)
+hip.lib().v2ce_ldati_plan_info(B, 260, 346, 30.0, 0.0, None, total, max_seg, max_tile, info)
 ok, shift, NB, T, capA, cap2, n_tab, n_bkt, lds_t, lds_s = list(info)
 print("plan: ok", ok, "shift", shift, "NB", NB, "T", T, "capA", capA, "cap2", cap2, "lds", lds_t, lds_s)
 w = ws.view(torch.int32).cpu().numpy()
 o = 0
 bofs = w[o:o + n_bkt].reshape(B * 9, NB + 1); o += n_bkt
-groups = w[o:o + B * 9 * NB].reshape(B * 9, NB); o += B * 9 * NB
+groups = w[o:o + B * 9 * NB].reshape(B * 9, NB); o += 2 * B * 9 * NB
 ngroups = w[o:o + B * 9]; o += B * 9
 flag = w[o:o + B * 9]
 btot = np.diff(bofs, axis=1)
-print("flagged segments:", int(flag.sum()), "of", B * 9, " bucket max", int(btot.max()), "mean", float(btot.mean()))
+print("big buckets:", int(w[o + B * 9 + 1]), " segments", B * 9, " bucket max", int(btot.max()), "mean", float(btot.mean()))
 print("sort groups: total", int(ngroups.sum()), "per segment max", int(ngroups.max()), "mean", float(ngroups.mean()))
 sizes = []
 for sgm in range(B * 9):

@@ -4,7 +4,8 @@
 type (list of packed numpy recarrays, ``scripts/LDATI.py:308``); everything is computed by the HIP
 kernels of ``csrc/ldati.hip`` through the C ABI (``include/v2ce_hip.h``).  No CPU path exists.
 
-Differences from the reference, all deliberate (DESIGN.md "Stage 2"):
+All option values of the reference signature are implemented (bidirectional relocation, pooled
+slope, 'none' / 'random' strategies).  Differences from the reference, all deliberate:
 
 * Random draws.  The reference draws one dense ``torch.rand([B,2,9,H,W,max_n])`` (LDATI.py:171).
   ``rng='torch'`` does exactly that on the tensor's device and replays it (same consumption of the
@@ -151,7 +152,8 @@ class PendingLdati:
 def ldati_begin(y: torch.Tensor, t0=0, fps=30, *, rng: str = "philox", seed: Optional[int] = None,
                 frame_base: int = 0, uniforms: Optional[torch.Tensor] = None,
                 frame_ts_add: Optional[torch.Tensor] = None, profile: Optional[list] = None,
-                path: str = "bucket", strategy: str = "slope", layout: str = "packed") -> PendingLdati:
+                path: str = "bucket", strategy: str = "slope", layout: str = "packed",
+                bidirectional: bool = False, pooling_type: str = "none", pooling_kernel_size: int = 3) -> PendingLdati:
     """Enqueue the count phase of LDATI on y [B,2,10,H,W] (HIP device) and start the asynchronous
     copy of the segment table to pinned host memory."""
     if y.dim() != 5 or y.shape[1] != 2 or y.shape[2] != 10:
@@ -174,13 +176,20 @@ def ldati_begin(y: torch.Tensor, t0=0, fps=30, *, rng: str = "philox", seed: Opt
         st = hip.stream_ptr(dev)
         if path == "sweep" and L.v2ce_ldati_lds_bytes(float(fps), float(t0)) == 0:
             raise hip.V2ceHipError(f"fps={fps}, t0={t0}: time bin too wide for the sweep kernel's LDS key histogram")
-        strat = {"slope": hip.STRATEGY_SLOPE, "none": hip.STRATEGY_NONE}[strategy]
+        opts = hip.LdatiOptions(
+            strategy={"slope": hip.STRATEGY_SLOPE, "none": hip.STRATEGY_NONE, "random": hip.STRATEGY_RANDOM}[strategy],
+            bidirectional=int(bool(bidirectional)),
+            pooling_type={"none": hip.POOL_NONE, "avg": hip.POOL_AVG, "weighted": hip.POOL_WEIGHTED}[pooling_type],
+            pooling_kernel_size=int(pooling_kernel_size))
+        plain = strategy != "random" and not bidirectional and (pooling_type == "none" or strategy != "slope")
+        if path == "sweep" and not plain:
+            raise hip.V2ceHipError("path='sweep' covers forward relocation without pooling ('slope' / 'none')")
         tile_ws = torch.empty(L.v2ce_ldati_tile_ws_bytes(B, H, W), dtype=torch.uint8, device=dev)
         meta = torch.empty(B * 9 + 1 + 4, dtype=torch.int64, device=dev)       # seg_offsets | stats
         if profile is not None:    # HIP events on the launch stream around the count kernels
             c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             c0.record()
-        hip.check(L.v2ce_ldati_count(y.data_ptr(), B, H, W, strat, tile_ws.data_ptr(), tile_ws.numel(),
+        hip.check(L.v2ce_ldati_count(y.data_ptr(), B, H, W, ctypes.byref(opts), tile_ws.data_ptr(), tile_ws.numel(),
                                      meta.data_ptr(), meta[B * 9 + 1:].data_ptr(), st), "v2ce_ldati_count")
         if profile is not None:
             c1.record()
@@ -190,7 +199,7 @@ def ldati_begin(y: torch.Tensor, t0=0, fps=30, *, rng: str = "philox", seed: Opt
         ready = torch.cuda.Event()
         ready.record()
     return PendingLdati(y=y, t0=t0, fps=fps, rng=rng, seed=seed, frame_base=frame_base, uniforms=uniforms,
-                        frame_ts_add=frame_ts_add, profile=profile, path=path, strat=strat, layout=layout,
+                        frame_ts_add=frame_ts_add, profile=profile, path=path, opts=opts, plain=plain, layout=layout,
                         tile_ws=tile_ws, meta=meta, host=host, ready=ready)
 
 
@@ -240,16 +249,17 @@ def _ldati_finish(q: PendingLdati) -> DeviceEvents:
             add_ptr = frame_ts_add.data_ptr()
         ws_bytes = 0
         if q.path == "bucket":     # two-level path; "sweep" = one workgroup per segment
-            ws_bytes = L.v2ce_ldati_workspace_bytes(B, H, W, float(fps), float(t0), total, max_seg, max_tile)
+            ws_bytes = L.v2ce_ldati_workspace_bytes(B, H, W, float(fps), float(t0), ctypes.byref(q.opts), total, max_seg,
+                                                    max_tile, int(q.layout == "packed"))
             if ws_bytes:
                 ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-            elif L.v2ce_ldati_lds_bytes(float(fps), float(t0)) == 0:
+            elif not q.plain or L.v2ce_ldati_lds_bytes(float(fps), float(t0)) == 0:
                 raise hip.V2ceHipError(f"LDATI: fps={fps}, t0={t0}, {H}x{W}, {max_tile} events in one tile-bin: outside "
                                        "both the two-level path and the sweep kernel")
         if q.profile is not None:    # HIP events on the launch stream around the emit kernels
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        hip.check(L.v2ce_ldati_emit(y.data_ptr(), B, H, W, float(fps), float(t0), q.strat, mode, u_ptr,
+        hip.check(L.v2ce_ldati_emit(y.data_ptr(), B, H, W, float(fps), float(t0), ctypes.byref(q.opts), mode, u_ptr,
                                     int(replay_max_n), int(seed or 0) & (2 ** 64 - 1), int(q.frame_base),
                                     q.meta.data_ptr(), add_ptr, ptrs[0], ptrs[1], ptrs[2], ptrs[3], ptrs[4],
                                     total, max_seg, max_tile, q.tile_ws.data_ptr(), hip.ptr(ws), int(ws_bytes), st),
@@ -260,8 +270,8 @@ def _ldati_finish(q: PendingLdati) -> DeviceEvents:
             q.profile.append(("emit", e0, e1, 80 * B * H * W + 13 * total))
         if ws is not None:
             sp = ctypes.c_void_p()
-            hip.check(L.v2ce_ldati_status(ws.data_ptr(), B, H, W, float(fps), float(t0), total, max_seg, max_tile,
-                                          ctypes.byref(sp)), "v2ce_ldati_status")
+            hip.check(L.v2ce_ldati_status(ws.data_ptr(), B, H, W, float(fps), float(t0), ctypes.byref(q.opts), total, max_seg,
+                                          max_tile, ctypes.byref(sp)), "v2ce_ldati_status")
             off = (sp.value - ws.data_ptr())
             ev._status = ws[off:off + 4].view(torch.int32)
     ev._keepalive = (y, keep, frame_ts_add, q.meta, q.tile_ws, ws)
@@ -283,17 +293,15 @@ def sample_voxel_statistical(y, t0=0, fps=30, pooling_type="none", pooling_kerne
     """Drop-in for ``scripts/LDATI.py:126``: y [B,2,10,H,W] -> list[B] of packed recarrays
     ``[('timestamp','<i8'),('x','<i2'),('y','<i2'),('polarity','i1')]``.
 
-    Supports the option values the reference CLI uses (v2ce.py:356); the other values of the
-    reference's option strings raise NotImplementedError.
-    """
+    Every option value of the reference is covered: ``additional_events_strategy`` 'slope' (the CLI's,
+    v2ce.py:356), 'none', 'random' (LDATI.py:173-174: raw uniforms as offsets in seconds);
+    ``pooling_type`` 'none' / 'avg' / 'weighted' with ``pooling_kernel_size`` (LDATI.py:177-182; only
+    shapes 'slope'); ``bidirectional`` relocation (LDATI.py:107-122)."""
     assert pooling_type in ["avg", "weighted", "none"]                     # LDATI.py:135
     assert additional_events_strategy in ["none", "random", "slope"]       # LDATI.py:136
-    if pooling_type != "none" or additional_events_strategy == "random" or bidirectional:
-        raise NotImplementedError(
-            "the HIP path implements pooling_type='none', additional_events_strategy in "
-            "{'slope' (v2ce.py:356), 'none'}, bidirectional=False")
     ev = ldati_device(y, t0=t0, fps=fps, rng=rng, seed=seed, frame_base=frame_base, uniforms=uniforms,
-                      strategy=additional_events_strategy)
+                      strategy=additional_events_strategy, bidirectional=bidirectional,
+                      pooling_type=pooling_type, pooling_kernel_size=pooling_kernel_size)
     if strict_reference_errors and ev.max_n == 0:
         raise RuntimeError("max(): Expected reduction dim to be specified for input.numel() == 0 "
                            "(reference LDATI.py:200 raises on an event-free chunk)")

@@ -34,6 +34,9 @@
 
 #include <atomic>
 #include <type_traits>
+
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
 #include <cmath>
 #include <cstdlib>
 
@@ -62,6 +65,9 @@ struct LdatiParams {
     int NK, nbits;
     int ts32;          // every timestamp and key base fits int32: the f32 -> int conversions use 32 bits
     int strategy;      // V2CE_STRATEGY_*: NONE drops every multi-event voxel (LDATI.py:206-207,241)
+    int bidir;         // bidirectional relocation (LDATI.py:107-122)
+    const float2 *kbb; // pooled slope parameters {k, b} [B][2][9][HW] (LDATI.py:177-190), or null
+    unsigned long long *keys;     // generic path ('random'): one 64-bit sort key per event, or null
     int rng_mode;
     const float *uniforms;
     int replay_max_n;
@@ -85,6 +91,8 @@ struct LdatiParams {
     unsigned *bofs;               // [B*9][NB+1] exclusive prefix of the bucket totals inside the segment
     unsigned *groups;             // [B*9][NB] sort groups: first bucket | (end bucket << 16)
     unsigned *ngroups;            // [B*9]
+    unsigned *big_list;           // [B*9*NB] coarse buckets beyond cap2: (segment << 16) | bucket
+    unsigned *nbig;               // [1] their number
     int span;                     // most coarse buckets a sort group may cover (key span <= kMaxSpanKeys)
     int hist_bins;                // bins reserved per wave in the sort's LDS histogram
     unsigned *temp;               // [total events] 4-byte records (fine | multi | local pixel)
@@ -153,6 +161,55 @@ __device__ __forceinline__ void load_bins(const float *plane0, long long HW, int
     }
 }
 
+// all nine bins of one pixel at once: counts and tendencies (LDATI.py:94-106, or :107-122 when bidir)
+__device__ __forceinline__ void relocate_all(const float (&yv)[10], bool bidir, int (&n)[9], float (&tend)[9]) {
+    const float eps = 1e-6f;
+    float d = 0.0f;
+    if (!bidir) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const float r = yv[i] - d;
+            const float cc = ceilf(r - eps);
+            d = cc - r;
+            n[i] = (int)cc;
+            tend[i] = d;
+        }
+        n[8] += (int)(yv[9] - d);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float r = yv[i] - d;
+        const float cc = ceilf(r - eps);
+        d = cc - r;
+        n[i] = (int)cc;
+        tend[i] = d;
+    }
+    n[4] = 0;                                  // never written by the reference's bidirectional branch
+    tend[4] = 0.0f;
+    float bless = yv[9];
+#pragma unroll
+    for (int i = 8; i > 5; --i) {
+        tend[i] = bless;
+        float t = yv[i] + bless;
+        t = floorf(t + eps);
+        bless = (yv[i] - t) + bless;
+        bless = bless < 0.0f ? 0.0f : bless;
+        n[i] = (int)t;
+    }
+    tend[5] = bless - d;
+    n[5] = (int)ceilf((yv[5] + bless) - d);
+}
+
+// a[c] for a wave-uniform c without dynamic register indexing
+template <typename T>
+__device__ __forceinline__ T pick9(const T (&a)[9], int c) {
+    T v = a[0];
+#pragma unroll
+    for (int i = 1; i < 9; ++i) v = c == i ? a[i] : v;
+    return v;
+}
+
 // single-event timestamp, all f64 (LDATI.py:156-165)
 __device__ __forceinline__ long long single_ts(float debt, double fps, float offt) {
     double t = (double)debt / fps / 9.0;
@@ -175,7 +232,9 @@ __device__ __forceinline__ void slope_params(int n_l, int n_c, int n_r, int c, c
 __device__ __forceinline__ long long multi_ts(float k, float bb, float u, float offt,
                                               const LdatiParams &P) {
     float t;
-    if (k == 0.0f) {
+    if (P.strategy == V2CE_STRATEGY_RANDOM) {
+        t = u;                                    // LDATI.py:173-174: the raw uniform, in seconds
+    } else if (k == 0.0f) {
         t = (u / P.FPS) / 9.0f;
     } else {
         const float s = bb * bb + (2.0f * k) * u;
@@ -189,7 +248,9 @@ __device__ __forceinline__ long long multi_ts(float k, float bb, float u, float 
 // the same, f32 -> i32 (bit-identical to the i64 conversion while |t| < 2^31: P.ts32) and the key
 __device__ __forceinline__ unsigned multi_key(float k, float bb, float u, float offt, int kbase32, const LdatiParams &P) {
     float t;
-    if (k == 0.0f) {
+    if (P.strategy == V2CE_STRATEGY_RANDOM) {
+        t = u;
+    } else if (k == 0.0f) {
         t = (u / P.FPS) / 9.0f;
     } else {
         const float s = bb * bb + (2.0f * k) * u;
@@ -383,7 +444,7 @@ __device__ __forceinline__ void block_excl_scan2(unsigned a, unsigned e, unsigne
 // count: workgroup per (frame, tile); events per (tile, bin); max count per voxel
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kCountThreads) void ldati_count_tiles_kernel(
-    const float *__restrict__ vox, int HW, int tpp, int strategy, unsigned *__restrict__ tc,
+    const float *__restrict__ vox, int HW, int tpp, int strategy, int bidir, unsigned *__restrict__ tc,
     unsigned long long *stats) {
     const int t = blockIdx.x, b = blockIdx.y, T = 2 * tpp;
     const int pidx = t < tpp ? 1 : 0;                 // negative tiles first (LDATI.py:289)
@@ -400,15 +461,12 @@ __global__ __launch_bounds__(kCountThreads) void ldati_count_tiles_kernel(
             float yv[10];
 #pragma unroll
             for (int i = 0; i < 10; ++i) yv[i] = plane0[(long long)i * HW + px];
-            const float eps = 1e-6f;
-            float d = 0.0f;
+            int nn[9];
+            float td[9];
+            relocate_all(yv, bidir != 0, nn, td);
 #pragma unroll
             for (int i = 0; i < 9; ++i) {
-                const float r = yv[i] - d;
-                const float cc = ceilf(r - eps);
-                d = cc - r;
-                int ni = (int)cc;
-                if (i == 8) ni += (int)(yv[9] - d);
+                const int ni = nn[i];
                 cnt[i] += (strategy == V2CE_STRATEGY_NONE) ? (ni == 1) : (ni > 0 ? ni : 0);
                 mx = ni > mx ? ni : mx;
             }
@@ -578,7 +636,12 @@ __device__ __forceinline__ void sweep_multis(int b, int c, int pidx, int cat, si
         relocate_bins(cur, c, last, n_l, n_c, n_r, debt);
         const int m = (valid && n_c >= 2) ? n_c : 0;
         float k, bb;
-        slope_params(n_l, n_c, n_r, c, P, k, bb);
+        if (P.kbb) {
+            const float2 kq = valid ? P.kbb[((long long)(b * 2 + pidx) * 9 + c) * P.HW + px] : make_float2(0.0f, 0.0f);
+            k = kq.x; bb = kq.y;
+        } else {
+            slope_params(n_l, n_c, n_r, c, P, k, bb);
+        }
         // exclusive wave scan of m -> first event index of each pixel inside this batch
         int incl = m;
 #pragma unroll
@@ -707,7 +770,7 @@ __global__ __launch_bounds__(256) void ldati_emit_kernel(LdatiParams P) {
 // timestamps are computed) | PT [2048] {k, bb} | hist [NW][NB] u32 | misc
 extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
 
-template <int NT, int PPT>
+template <int NT, int PPT, bool BIDIR>
 __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
     static_assert(NT * PPT == kTilePix, "tile geometry");
     const int t = blockIdx.x, b = blockIdx.y;
@@ -730,25 +793,38 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
     const int lpx0 = tid * PPT;                        // first local pixel of this thread
     const float eps = 1e-6f;
 
-    // rolling relocation state per pixel: counts of bins c-1, c, c+1; debts after bins c, c+1
+    // relocation state per pixel: counts of bins c-1, c, c+1; tendency ("debt") of bin c.  Forward
+    // relocation rolls along the bins (the voxels of bin c+2 are fetched while bin c is processed);
+    // the bidirectional variant (LDATI.py:107-122) needs all ten voxels first and keeps all nine bins.
     int nprev[PPT], ncur[PPT], nnext[PPT];
     float dcur[PPT], dnext[PPT];
     bool valid[PPT];
+    int nA[BIDIR ? PPT : 1][9];
+    float tA[BIDIR ? PPT : 1][9];
 #pragma unroll
     for (int q = 0; q < PPT; ++q) {
         const int px = x0 + lpx0 + q;
         valid[q] = px < P.HW;
-        const float y0 = valid[q] ? plane0[px] : 0.0f;
-        const float y1 = valid[q] ? plane0[(long long)P.HW + px] : 0.0f;
-        float r = y0 - 0.0f;
-        float cc = ceilf(r - eps);
-        dcur[q] = cc - r;
-        ncur[q] = (int)cc;
-        r = y1 - dcur[q];
-        cc = ceilf(r - eps);
-        dnext[q] = cc - r;
-        nnext[q] = (int)cc;
-        nprev[q] = 0;
+        if (BIDIR) {
+            float yv[10];
+#pragma unroll
+            for (int i = 0; i < 10; ++i) yv[i] = valid[q] ? plane0[(long long)i * P.HW + px] : 0.0f;
+            relocate_all(yv, true, nA[q], tA[q]);
+            nprev[q] = ncur[q] = nnext[q] = 0;
+            dcur[q] = dnext[q] = 0.0f;
+        } else {
+            const float y0 = valid[q] ? plane0[px] : 0.0f;
+            const float y1 = valid[q] ? plane0[(long long)P.HW + px] : 0.0f;
+            float r = y0 - 0.0f;
+            float cc = ceilf(r - eps);
+            dcur[q] = cc - r;
+            ncur[q] = (int)cc;
+            r = y1 - dcur[q];
+            cc = ceilf(r - eps);
+            dnext[q] = cc - r;
+            nnext[q] = (int)cc;
+            nprev[q] = 0;
+        }
     }
 
     STAMP_DECL;
@@ -759,8 +835,14 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
             const int px = x0 + lpx0 + q;
-            ynn[q] = (c + 2 <= 8 && valid[q]) ? plane0[(long long)(c + 2) * P.HW + px] : 0.0f;
-            y9[q] = (c + 2 == 8 && valid[q]) ? plane0[(long long)9 * P.HW + px] : 0.0f;
+            ynn[q] = (!BIDIR && c + 2 <= 8 && valid[q]) ? plane0[(long long)(c + 2) * P.HW + px] : 0.0f;
+            y9[q] = (!BIDIR && c + 2 == 8 && valid[q]) ? plane0[(long long)9 * P.HW + px] : 0.0f;
+            if (BIDIR) {
+                nprev[q] = c > 0 ? pick9(nA[q], c - 1) : 0;
+                ncur[q] = pick9(nA[q], c);
+                nnext[q] = c < 8 ? pick9(nA[q], c + 1) : 0;
+                dcur[q] = pick9(tA[q], c);
+            }
         }
         // ---- P1: classify ------------------------------------------------------------------
         unsigned a_tot = 0, e_tot = 0;                  // per thread: singles | units << 12, multi events
@@ -798,7 +880,12 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
                 SL[ab & 0xFFFu] = make_uint2(__float_as_uint(dcur[q]), local);
             } else if (n >= 2 && P.strategy != V2CE_STRATEGY_NONE) {
                 float k, bb;
-                slope_params(nprev[q], n, nnext[q], c, P, k, bb);
+                if (P.kbb) {                         // pooled counts (LDATI.py:177-190): from the pre-pass
+                    const float2 kq = P.kbb[((long long)(b * 2 + pidx) * 9 + c) * P.HW + (x0 + lpx0 + q)];
+                    k = kq.x; bb = kq.y;
+                } else {
+                    slope_params(nprev[q], n, nnext[q], c, P, k, bb);
+                }
                 PT[local] = make_float2(k, bb);
                 const unsigned u0 = ab >> 12, ev0 = e_base + e_q[q];
                 const unsigned units = (unsigned)(n + 3) >> 2;
@@ -820,7 +907,7 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
             const unsigned key = (unsigned)key_of(Tq, P.kbase[c], P.NK);
             S[q] = (key << 12) | e.y;
             const unsigned w = (unsigned)(((float)q + 0.5f) * invL);
-            atomicAdd(&hist[__umul24(w, (unsigned)P.NB) + (key >> P.shift)], 1u);
+            if (!P.keys) atomicAdd(&hist[__umul24(w, (unsigned)P.NB) + (key >> P.shift)], 1u);
         }
         STAMP(3);
         for (unsigned q = tid; q < Um; q += NT) {
@@ -850,13 +937,25 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
                     const unsigned pos = Ns + e.y + s;
                     S[pos] = (key << 12) | (1u << kLocalBits) | local;
                     const unsigned w = (unsigned)(((float)pos + 0.5f) * invL);
-                    atomicAdd(&hist[__umul24(w, (unsigned)P.NB) + (key >> P.shift)], 1u);
+                    if (!P.keys) atomicAdd(&hist[__umul24(w, (unsigned)P.NB) + (key >> P.shift)], 1u);
                 }
             }
         }
         STAMP(4);
         __syncthreads();
         STAMP(5);
+        if (P.keys) {
+            // generic path (key range beyond the bucket machinery: 'random'): one 64-bit key per event,
+            // (segment | timestamp - bin start | category | pixel), sorted by a library radix sort
+            unsigned long long *dst = P.keys + P.seg_offsets[b * 9 + c] + P.tile_off[((long long)b * P.T + t) * 9 + c];
+            const unsigned long long seg_bits = (unsigned long long)(b * 9 + c) << 44;
+            for (unsigned i = tid; i < N; i += NT) {
+                const unsigned r = S[i];
+                const unsigned cat = (pidx ? 0u : 2u) + ((r >> kLocalBits) & 1u);
+                dst[i] = seg_bits | ((unsigned long long)(r >> 12) << 24) | ((unsigned long long)cat << 22) |
+                         (unsigned long long)((unsigned)x0 + (r & (kTilePix - 1)));
+            }
+        } else {
         // ---- P5: bucket-major, wave-minor exclusive scan; the tile's bucket counts and run offsets
         {
             unsigned v[NW];
@@ -904,9 +1003,11 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
             for (unsigned i = tid; i < N; i += NT) dst[i] = O[i];
         }
         STAMP(9);
+        }
         // ---- advance the relocation recurrence to bin c+2 ---------------------------------------
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
+            if (BIDIR) continue;
             nprev[q] = ncur[q];
             ncur[q] = nnext[q];
             dcur[q] = dnext[q];
@@ -930,7 +1031,8 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
 // group's (key, category) histogram fits the sort workgroup).  Timestamps crowd towards the end of a
 // bin on real UNet output (small voxel values: the single event falls where the accumulated mass
 // crosses 1), so equal-width buckets differ by 20x in a segment; the groups even that out.  A single
-// coarse bucket beyond cap2 (degenerate ties) flags the segment for the sweep kernel.
+// coarse bucket beyond cap2 (degenerate ties: constant images; bidirectional relocation puts every
+// single of bin 8 with y[9] = 0 at the same microsecond) goes to the big-bucket kernel's list.
 __global__ __launch_bounds__(256) void ldati_bucket_scan_kernel(LdatiParams P) {
     __shared__ unsigned part[8];
     __shared__ unsigned tot_s[kMaxNB];
@@ -958,19 +1060,22 @@ __global__ __launch_bounds__(256) void ldati_bucket_scan_kernel(LdatiParams P) {
     if (t == 0) {
         bofs[P.NB] = carry;
         unsigned *grp = P.groups + (long long)seg * P.NB;
-        unsigned ng = 0, big = 0;
+        unsigned ng = 0;
         int i = 0;
         while (i < P.NB) {
             if (tot_s[i] == 0) { ++i; continue; }
+            if (tot_s[i] > (unsigned)P.cap2) {
+                P.big_list[atomicAdd(P.nbig, 1u)] = ((unsigned)seg << 16) | (unsigned)i;
+                ++i;
+                continue;
+            }
             const int start = i;
             unsigned acc = 0;
             while (i < P.NB && i - start < P.span && acc + tot_s[i] <= (unsigned)P.cap2) acc += tot_s[i++];
-            if (i == start) { big = 1; break; }
             grp[ng++] = (unsigned)start | ((unsigned)i << 16);
         }
-        P.ngroups[seg] = big ? 0u : ng;
-        P.seg_flag[seg] = (int)big;
-        if (big && !P.sweep_ok) atomicOr(reinterpret_cast<unsigned *>(P.status), 1u);
+        P.ngroups[seg] = ng;
+        P.seg_flag[seg] = 0;
     }
 }
 
@@ -1226,6 +1331,152 @@ __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(Ldat
 }
 
 // ---------------------------------------------------------------------------------------------
+// big buckets: a coarse bucket with more records than a sort workgroup holds in LDS (degenerate ties).
+// One workgroup per listed bucket: histogram of (fine key, category) over all its records (any
+// order), exclusive scan, then ONE wave walks the records in input order (tiles ascending, pixel order
+// inside a run) and takes stable slots 64 at a time; the records go straight to their final place.
+// Rare and slow on purpose; keeps the two-level path complete for any input.
+// ---------------------------------------------------------------------------------------------
+template <bool PACKED>
+__global__ __launch_bounds__(256) void ldati_big_bucket_kernel(LdatiParams P) {
+    __shared__ unsigned hist[4 << kMaxShift];
+    __shared__ unsigned part[5];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const bool atomic_order = __builtin_amdgcn_readfirstlane(g_lds_order_ok) != 0;
+    const int bins = 4 << P.shift, nb2 = P.shift + 2;
+    const unsigned nbig = *P.nbig;
+    for (unsigned idx = blockIdx.x; idx < nbig; idx += gridDim.x) {
+        const unsigned e = P.big_list[idx];
+        const int seg = (int)(e >> 16), bucket = (int)(e & 0xFFFFu);
+        const int b = seg / 9, c = seg - b * 9;
+        const unsigned *bofs = P.bofs + (long long)seg * (P.NB + 1);
+        const long long g0 = P.seg_offsets[seg] + bofs[bucket];
+        const unsigned key0 = (unsigned)bucket << P.shift;
+        const long long tbase = P.kbase[c] + (long long)key0 + (P.frame_ts_add ? P.frame_ts_add[b] : 0);
+        const unsigned *seg_temp = P.temp + P.seg_offsets[seg];
+        for (int i = tid; i < bins; i += 256) hist[i] = 0;
+        __syncthreads();
+        for (int tt = 0; tt < P.T; ++tt) {
+            const unsigned short *row = P.roff + ((long long)seg * P.T + tt) * (P.NB + 1);
+            const unsigned r0 = row[bucket], len = (unsigned)row[bucket + 1] - r0;
+            const unsigned *src = seg_temp + P.tile_off[((long long)b * P.T + tt) * 9 + c] + r0;
+            const unsigned catb = tt < P.tpp ? 0u : 2u;
+            for (unsigned j = tid; j < len; j += 256) {
+                const unsigned r = src[j];
+                atomicAdd(&hist[(((r >> 12) - key0) << 2) | (catb + ((r >> kLocalBits) & 1u))], 1u);
+            }
+        }
+        __syncthreads();
+        {
+            const int per = (bins + 255) / 256;
+            const int b0 = tid * per, b1 = (b0 + per < bins) ? b0 + per : bins;
+            unsigned s = 0;
+            for (int q = b0; q < b1; ++q) s += hist[q];
+            unsigned tot;
+            unsigned run = block_excl_scan<4>(s, part, &tot);
+            for (int q = b0; q < b1; ++q) {
+                const unsigned v = hist[q];
+                hist[q] = run;
+                run += v;
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            for (int tt = 0; tt < P.T; ++tt) {
+                const unsigned short *row = P.roff + ((long long)seg * P.T + tt) * (P.NB + 1);
+                const unsigned r0 = row[bucket], len = (unsigned)row[bucket + 1] - r0;
+                const unsigned *src = seg_temp + P.tile_off[((long long)b * P.T + tt) * 9 + c] + r0;
+                const unsigned catb = tt < P.tpp ? 0u : 2u;
+                const unsigned pxb = (unsigned)(tt < P.tpp ? tt : tt - P.tpp) * kTilePix;
+                for (unsigned j0 = 0; j0 < len; j0 += 64) {
+                    const unsigned j = j0 + lane;
+                    const bool has = j < len;
+                    const unsigned r = has ? src[j] : 0u;
+                    const unsigned cat = catb + ((r >> kLocalBits) & 1u);
+                    const unsigned fine = has ? (r >> 12) - key0 : 0u;
+                    const unsigned bin = (fine << 2) | cat;
+                    const unsigned pos = take_slot(atomic_order, has, bin, nb2, &hist[bin]);
+                    if (has) {
+                        const unsigned px = pxb + (r & (kTilePix - 1));
+                        const unsigned yy = px / (unsigned)P.W;
+                        const long long g = g0 + pos;
+                        if (PACKED) {
+                            store_packed_bytes(P.packed + g * 13, tbase + fine, (px - yy * P.W) & 0xFFFFu, yy & 0xFFFFu, cat >> 1);
+                        } else {
+                            P.ts[g] = tbase + fine;
+                            P.x[g] = (short)(px - yy * P.W);
+                            P.y[g] = (short)yy;
+                            P.p[g] = (signed char)(cat >> 1);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pooled slope parameters (LDATI.py:177-190): thread per (frame, polarity, pixel).  The counts of the
+// k x k neighbourhood are recomputed from the voxels (zero padding outside the image), pooled --
+// 'weighted': [[1,2,1],[2,4,2],[1,2,1]]/16; 'avg': sum / k^2 -- and turned into {k, b} per bin.
+// Counts are integers and the weights powers of two over 16: every partial sum is exact in f32.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ldati_pool_slope_kernel(LdatiParams P, int pooling, int pool_k, float2 *kbb) {
+    const int px = blockIdx.x * 256 + threadIdx.x, bp = blockIdx.y;
+    if (px >= P.HW) return;
+    const int h = px / P.W, w = px - h * P.W;
+    const int r = pooling == V2CE_POOL_WEIGHTED ? 1 : pool_k / 2;
+    const float *plane0 = P.vox + (long long)bp * 10 * P.HW;
+    float acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) acc[i] = 0.0f;
+    for (int dh = -r; dh <= r; ++dh)
+        for (int dw = -r; dw <= r; ++dw) {
+            const int hh = h + dh, ww = w + dw;
+            if (hh < 0 || hh >= P.H || ww < 0 || ww >= P.W) continue;
+            float yv[10];
+#pragma unroll
+            for (int i = 0; i < 10; ++i) yv[i] = plane0[(long long)i * P.HW + hh * P.W + ww];
+            int nn[9];
+            float td[9];
+            relocate_all(yv, P.bidir != 0, nn, td);
+            const float wt = pooling == V2CE_POOL_WEIGHTED ? (float)((2 - (dh < 0 ? -dh : dh)) * (2 - (dw < 0 ? -dw : dw))) / 16.0f : 1.0f;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) acc[i] += (float)nn[i] * wt;
+        }
+    if (pooling == V2CE_POOL_AVG) {
+        const float div = (float)(pool_k * pool_k);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) acc[i] = acc[i] / div;
+    }
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+        const float fl = c == 0 ? acc[1] : acc[c - 1], fr = c == 8 ? acc[7] : acc[c + 1];
+        const float sxy = fr - fl;
+        const float k0 = (3.0f * sxy) / 6.0f;
+        const float k = (k0 / P.VS2) / (acc[c] + 1e-8f);
+        const float bb = P.INV - (P.VS * k) / 2.0f;
+        kbb[((long long)bp * 9 + c) * P.HW + px] = make_float2(k, bb);
+    }
+}
+
+// generic path: sorted 64-bit keys -> SoA events
+__global__ __launch_bounds__(256) void ldati_keys_decode_kernel(LdatiParams P, const unsigned long long *keys, long long n,
+                                                                long long *ts, short *x, short *y, signed char *pp) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long k = keys[i];
+    const int seg = (int)(k >> 44), b = seg / 9, c = seg - b * 9;
+    const unsigned rel = (unsigned)(k >> 24) & 0xFFFFFu, cat = (unsigned)(k >> 22) & 3u, px = (unsigned)k & 0x3FFFFFu;
+    const unsigned yy = px / (unsigned)P.W;
+    ts[i] = P.kbase[c] + (long long)rel + (P.frame_ts_add ? P.frame_ts_add[b] : 0);
+    x[i] = (short)(px - yy * P.W);
+    y[i] = (short)yy;
+    pp[i] = (signed char)(cat >> 1);
+}
+
+// ---------------------------------------------------------------------------------------------
 // pack / unpack kernels: SoA <-> 13-byte records
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void events_pack_kernel(const long long *__restrict__ ts,
@@ -1289,7 +1540,7 @@ struct HostScalars {
     bool ok;
 };
 
-HostScalars host_scalars(double fps, double t0) {
+HostScalars host_scalars(double fps, double t0, bool bidir = false, bool random = false) {
     HostScalars h{};
     const double vs = 1.0 / fps / 9.0;
     h.VS = (float)vs;
@@ -1303,11 +1554,18 @@ HostScalars host_scalars(double fps, double t0) {
     const double ulp_us = top * 1.1920929e-7 * 1e6;      // one f32 ulp of the largest time, in us
     const long long slack = 16 + (long long)(8.0 * ulp_us);
     const long long span = (long long)(vs * 1e6) + 2;
-    const long long nk = span + 2 * slack;
-    for (int c = 0; c < 9; ++c) h.kbase[c] = (long long)((double)h.offt[c] * 1e6) - slack;
+    // forward relocation: every timestamp lies in its bin.  Bidirectional (LDATI.py:107-122): a single
+    // event's tendency lies in (-1, 2) bin widths (bin 5: bless - debt; bin 8: y[9] < 2 when n == 1).
+    // 'random' (LDATI.py:173-174): the multi-event offsets are raw uniforms in SECONDS.
+    const long long before = bidir ? span : 0;
+    const long long after = (random ? 1000000 : 0) + (bidir ? span : 0);
+    const long long nk = before + span + after + 2 * slack;
+    for (int c = 0; c < 9; ++c) h.kbase[c] = (long long)((double)h.offt[c] * 1e6) - slack - before;
     h.NK = nk;
-    h.ok = nk > 0 && nk <= ((long long)kMaxNB << kMaxShift);      // the two-level path's key range
-    h.sweep_ok = nk > 0 && nk <= 9600;    // 4*NK*4 B must fit 160 KiB of LDS with the scratch beside it
+    // the two-level path's key range; the generic ('random') path only needs 20-bit keys
+    h.ok = nk > 0 && (random ? nk < (1ll << 20) : nk <= ((long long)kMaxNB << kMaxShift));
+    // sweep kernel: 4*NK*4 B must fit 160 KiB of LDS with the scratch beside it; forward relocation only
+    h.sweep_ok = nk > 0 && nk <= 9600 && !bidir && !random;
     int nb = 0;
     while ((1ll << nb) < nk) ++nb;
     h.nbits = nb;
@@ -1375,8 +1633,9 @@ Plan make_plan(const HostScalars &h, int B, int H, int W, int64_t total_events,
     const size_t tables = kSortWaves * hist_bins * 4 + (size_t)(2 * p.T) * 4 + (size_t)(2 * (p.cap2 / 32)) * 4 + (kSortWaves + 1) * 4;
     const size_t stage = (size_t)kSortThreads * 13 * 4;
     p.lds_sort = (size_t)p.cap2 * 4 + (tables > stage ? tables : stage);
-    // bofs | groups [B*9*NB] | ngroups [B*9] | seg_flag [B*9] | status [4] | records (u32) | roff (u16)
-    p.bytes = (p.n_bkt + (size_t)B * 9 * p.NB + 2 * (size_t)B * 9 + 4 +
+    // bofs | groups [B*9*NB] | big_list [B*9*NB] | ngroups [B*9] | seg_flag [B*9] | status [4] (status, nbig) |
+    // records (u32) | roff (u16)
+    p.bytes = (p.n_bkt + 2 * (size_t)B * 9 * p.NB + 2 * (size_t)B * 9 + 4 +
                (size_t)(total_events > 0 ? total_events : 0)) * 4 + ((p.n_tab * 2 + 3) / 4) * 4;
     if (p.lds_tile > 160 * 1024 || p.lds_sort > 160 * 1024) p.ok = false;
     return p;
@@ -1387,13 +1646,67 @@ Plan make_plan(const HostScalars &h, int B, int H, int W, int64_t total_events,
 
 using namespace v2ce;
 
+namespace {
+struct Opts { int strategy, bidir, pooling, pool_k; };
+
+// NULL options = the CLI's call (v2ce.py:356): 'slope', no pooling, forward relocation
+int read_options(const v2ce_ldati_options *o, Opts &out, const char *who) {
+    out = Opts{V2CE_STRATEGY_SLOPE, 0, V2CE_POOL_NONE, 3};
+    if (!o) return V2CE_OK;
+    out = Opts{o->strategy, o->bidirectional != 0, o->pooling_type, o->pooling_kernel_size};
+    V2CE_REQUIRE(out.strategy == V2CE_STRATEGY_SLOPE || out.strategy == V2CE_STRATEGY_NONE || out.strategy == V2CE_STRATEGY_RANDOM,
+                 V2CE_ERR_BAD_ARG, "%s: bad strategy %d", who, out.strategy);
+    V2CE_REQUIRE(out.pooling == V2CE_POOL_NONE || out.pooling == V2CE_POOL_AVG || out.pooling == V2CE_POOL_WEIGHTED,
+                 V2CE_ERR_BAD_ARG, "%s: bad pooling_type %d", who, out.pooling);
+    V2CE_REQUIRE(out.pooling != V2CE_POOL_AVG || (out.pool_k >= 1 && out.pool_k <= 15 && (out.pool_k & 1)), V2CE_ERR_UNSUPPORTED,
+                 "%s: pooling_kernel_size %d (odd sizes 1..15: nn.AvgPool2d with padding k//2 keeps H x W only for odd k)",
+                 who, out.pool_k);
+    if (out.strategy != V2CE_STRATEGY_SLOPE) out.pooling = V2CE_POOL_NONE;      // pooling only shapes the slope (LDATI.py:175)
+    return V2CE_OK;
+}
+
+// workspace of one emit call: the two-level part (or the generic part for 'random'), then the pooled
+// slope parameters
+struct Layout {
+    Plan plan;
+    bool generic;
+    size_t main_bytes, keys_bytes, sort_temp_bytes, soa_bytes, kbb_bytes, bytes;
+    bool ok;
+};
+
+Layout make_layout(const HostScalars &h, const Opts &o, int B, int H, int W, int64_t total, int64_t max_seg,
+                   int64_t max_tile, bool packed_out) {
+    Layout L{};
+    L.generic = o.strategy == V2CE_STRATEGY_RANDOM;
+    L.plan = make_plan(h, B, H, W, total, max_seg, max_tile);
+    const size_t n = (size_t)(total > 0 ? total : 0);
+    if (L.generic) {
+        // the tile pass still runs (in its key-writing mode): it needs the tile geometry and LDS plan
+        L.ok = h.ok && L.plan.T <= kMaxTiles && L.plan.capA <= kCapTile && L.plan.PB <= 22 && B * 9 <= 65535 &&
+               total < (1ll << 32) && L.plan.lds_tile <= 160 * 1024;
+        L.main_bytes = 16;                                            // status words
+        L.keys_bytes = 2 * ((n * 8 + 15) / 16) * 16;
+        size_t tb = 0;
+        if (n) (void)rocprim::radix_sort_keys(nullptr, tb, (unsigned long long *)nullptr, (unsigned long long *)nullptr, n, 0, 60);
+        L.sort_temp_bytes = (tb + 15) / 16 * 16;
+        L.soa_bytes = packed_out ? ((n * 13 + 15) / 16) * 16 + 64 : 0;
+    } else {
+        L.ok = L.plan.ok;
+        L.main_bytes = (L.plan.bytes + 15) / 16 * 16;
+    }
+    L.kbb_bytes = o.pooling != V2CE_POOL_NONE ? (size_t)B * 2 * 9 * (size_t)H * W * 8 : 0;
+    L.bytes = L.main_bytes + L.keys_bytes + L.sort_temp_bytes + L.soa_bytes + L.kbb_bytes;
+    return L;
+}
+}  // namespace
+
 extern "C" size_t v2ce_ldati_tile_ws_bytes(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
     const long long tpp = ((long long)H * W + kTilePix - 1) / kTilePix;
     return (size_t)2 * (size_t)B * (size_t)(2 * tpp) * 9 * 4;
 }
 
-extern "C" int v2ce_ldati_count(const float *vox, int B, int H, int W, int strategy, void *tile_ws,
+extern "C" int v2ce_ldati_count(const float *vox, int B, int H, int W, const v2ce_ldati_options *options, void *tile_ws,
                                 size_t tile_ws_bytes, int64_t *seg_offsets, int64_t *stats,
                                 v2ce_stream_t stream) {
     clear_error();
@@ -1403,8 +1716,8 @@ extern "C" int v2ce_ldati_count(const float *vox, int B, int H, int W, int strat
     V2CE_REQUIRE(W <= 32767 && H <= 32767, V2CE_ERR_UNSUPPORTED,
                  "v2ce_ldati_count: x/y are int16 (LDATI.py:230-231)");
     V2CE_REQUIRE(B <= 65535, V2CE_ERR_UNSUPPORTED, "v2ce_ldati_count: B too large for one launch");
-    V2CE_REQUIRE(strategy == V2CE_STRATEGY_SLOPE || strategy == V2CE_STRATEGY_NONE, V2CE_ERR_UNSUPPORTED,
-                 "v2ce_ldati_count: strategy %d not implemented", strategy);
+    Opts o;
+    if (int rc = read_options(options, o, "v2ce_ldati_count")) return rc;
     V2CE_REQUIRE(tile_ws_bytes >= v2ce_ldati_tile_ws_bytes(B, H, W), V2CE_ERR_WORKSPACE,
                  "v2ce_ldati_count: tile workspace %zu < %zu", tile_ws_bytes, v2ce_ldati_tile_ws_bytes(B, H, W));
     hipStream_t s = as_stream(stream);
@@ -1421,7 +1734,9 @@ extern "C" int v2ce_ldati_count(const float *vox, int B, int H, int W, int strat
             hipLaunchKernelGGL(ldati_lds_order_probe_kernel, dim3(64), dim3(256), 0, s, 200);
     }
     V2CE_HIP_CHECK(hipMemsetAsync(stats, 0, 4 * sizeof(int64_t), s));
-    hipLaunchKernelGGL(ldati_count_tiles_kernel, dim3(T, B), dim3(kCountThreads), 0, s, vox, HW, tpp, strategy, tc,
+    // 'random' emits like 'slope' (every draw of a multi-event voxel); 'none' only the singles
+    const int count_strategy = o.strategy == V2CE_STRATEGY_NONE ? V2CE_STRATEGY_NONE : V2CE_STRATEGY_SLOPE;
+    hipLaunchKernelGGL(ldati_count_tiles_kernel, dim3(T, B), dim3(kCountThreads), 0, s, vox, HW, tpp, count_strategy, o.bidir, tc,
                        reinterpret_cast<unsigned long long *>(stats));
     hipLaunchKernelGGL(ldati_tile_scan_kernel, dim3(1), dim3(256), 0, s, tc, B, T, tile_off,
                        reinterpret_cast<long long *>(seg_offsets), reinterpret_cast<unsigned long long *>(stats));
@@ -1435,17 +1750,19 @@ extern "C" size_t v2ce_ldati_lds_bytes(double fps, double t0) {
     return h.sweep_ok ? h.lds_bytes : 0;
 }
 
-extern "C" size_t v2ce_ldati_workspace_bytes(int B, int H, int W, double fps, double t0,
+extern "C" size_t v2ce_ldati_workspace_bytes(int B, int H, int W, double fps, double t0, const v2ce_ldati_options *options,
                                              int64_t total_events, int64_t max_segment_events,
-                                             int64_t max_tile_events) {
+                                             int64_t max_tile_events, int packed_output) {
     if (!(fps > 0) || B <= 0 || H <= 0 || W <= 0) return 0;
-    const HostScalars h = host_scalars(fps, t0);
-    const Plan p = make_plan(h, B, H, W, total_events, max_segment_events, max_tile_events);
-    return p.ok ? p.bytes : 0;
+    Opts o;
+    if (read_options(options, o, "v2ce_ldati_workspace_bytes")) return 0;
+    const HostScalars h = host_scalars(fps, t0, o.bidir, o.strategy == V2CE_STRATEGY_RANDOM);
+    const Layout L = make_layout(h, o, B, H, W, total_events, max_segment_events, max_tile_events, packed_output != 0);
+    return L.ok ? L.bytes : 0;
 }
 
 extern "C" int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps, double t0,
-                               int strategy, int rng_mode, const float *uniforms, int replay_max_n,
+                               const v2ce_ldati_options *options, int rng_mode, const float *uniforms, int replay_max_n,
                                uint64_t seed, int64_t frame_base, const int64_t *seg_offsets,
                                const int64_t *frame_ts_add, int64_t *ts, int16_t *x, int16_t *y,
                                int8_t *p, uint8_t *packed, int64_t total_events,
@@ -1459,8 +1776,8 @@ extern "C" int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps
     V2CE_REQUIRE(fps > 0, V2CE_ERR_BAD_ARG, "v2ce_ldati_emit: fps must be positive");
     V2CE_REQUIRE(rng_mode == V2CE_RNG_REPLAY || rng_mode == V2CE_RNG_PHILOX, V2CE_ERR_BAD_ARG,
                  "v2ce_ldati_emit: bad rng_mode %d", rng_mode);
-    V2CE_REQUIRE(strategy == V2CE_STRATEGY_SLOPE || strategy == V2CE_STRATEGY_NONE, V2CE_ERR_UNSUPPORTED,
-                 "v2ce_ldati_emit: strategy %d not implemented", strategy);
+    Opts o;
+    if (int rc = read_options(options, o, "v2ce_ldati_emit")) return rc;
     V2CE_REQUIRE(rng_mode != V2CE_RNG_REPLAY || replay_max_n == 0 || uniforms != nullptr,
                  V2CE_ERR_BAD_ARG, "v2ce_ldati_emit: REPLAY mode needs the uniform tensor");
     const bool soa = ts && x && y && p;
@@ -1468,7 +1785,8 @@ extern "C" int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps
                  "v2ce_ldati_emit: give either the four SoA arrays or the packed buffer");
     V2CE_REQUIRE(!packed || (reinterpret_cast<uintptr_t>(packed) & 3) == 0, V2CE_ERR_BAD_ARG,
                  "v2ce_ldati_emit: packed must be 4-byte aligned");
-    const HostScalars h = host_scalars(fps, t0);
+    const bool random = o.strategy == V2CE_STRATEGY_RANDOM;
+    const HostScalars h = host_scalars(fps, t0, o.bidir, random);
     V2CE_REQUIRE(h.ok, V2CE_ERR_UNSUPPORTED, "v2ce_ldati_emit: fps=%g t0=%g needs %lld keys per bin (max %d)",
                  fps, t0, h.NK, kMaxNB << kMaxShift);
     LdatiParams P{};
@@ -1476,8 +1794,8 @@ extern "C" int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps
     P.fps = fps; P.VS = h.VS; P.VS2 = h.VS2; P.INV = h.INV; P.FPS = h.FPS;
     for (int c = 0; c < 9; ++c) { P.offt[c] = h.offt[c]; P.kbase[c] = h.kbase[c]; }
     P.NK = (int)h.NK; P.nbits = h.nbits;
-    P.ts32 = (fabs((double)h.offt[8]) + 1.0 / fps) * 1e6 < 2.0e9 ? 1 : 0;
-    P.strategy = strategy;
+    P.ts32 = (fabs((double)h.offt[8]) + 1.0 + 1.0 / fps) * 1e6 < 2.0e9 ? 1 : 0;
+    P.strategy = o.strategy; P.bidir = o.bidir;
     P.rng_mode = rng_mode; P.uniforms = uniforms; P.replay_max_n = replay_max_n;
     P.seed = seed; P.frame_base = frame_base;
     P.seg_offsets = reinterpret_cast<const long long *>(seg_offsets);
@@ -1491,36 +1809,83 @@ extern "C" int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps
         V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ldati_emit_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds_bytes));
     if (workspace != nullptr) {
-        // ---- two-level path; segments with an oversized bucket fall through to the sweep kernel
         V2CE_REQUIRE(tile_ws, V2CE_ERR_BAD_ARG, "v2ce_ldati_emit: the two-level path needs v2ce_ldati_count's tile workspace");
         V2CE_REQUIRE(total_events >= 0 && max_segment_events >= 0 && max_tile_events >= 0, V2CE_ERR_BAD_ARG,
                      "v2ce_ldati_emit: bad event counts");
-        const Plan pl = make_plan(h, B, H, W, total_events, max_segment_events, max_tile_events);
-        V2CE_REQUIRE(pl.ok, V2CE_ERR_UNSUPPORTED,
+        const Layout L = make_layout(h, o, B, H, W, total_events, max_segment_events, max_tile_events, packed != nullptr);
+        const Plan &pl = L.plan;
+        V2CE_REQUIRE(L.ok, V2CE_ERR_UNSUPPORTED,
                      "v2ce_ldati_emit: shape / density outside the two-level path (tiles %d, buckets %d, "
                      "largest tile-bin %lld events); pass workspace = NULL", pl.T, pl.NB, (long long)max_tile_events);
-        V2CE_REQUIRE(workspace_bytes >= pl.bytes, V2CE_ERR_WORKSPACE, "v2ce_ldati_emit: workspace %zu < %zu",
-                     workspace_bytes, pl.bytes);
+        V2CE_REQUIRE(workspace_bytes >= L.bytes, V2CE_ERR_WORKSPACE, "v2ce_ldati_emit: workspace %zu < %zu",
+                     workspace_bytes, L.bytes);
+        unsigned char *wb = static_cast<unsigned char *>(workspace);
         unsigned *w = static_cast<unsigned *>(workspace);
         P.shift = pl.shift; P.NB = pl.NB; P.nb1 = pl.nb1; P.T = pl.T; P.tpp = pl.tpp; P.PB = pl.PB;
         P.capA = pl.capA; P.cap2 = pl.cap2; P.tbits = pl.tbits;
         P.tile_off = static_cast<const unsigned *>(tile_ws) + (size_t)B * pl.T * 9;
         P.span = pl.span;
         P.hist_bins = (4 * (pl.span << pl.shift)) > 4 * kMaxSpanKeys ? (4 * (pl.span << pl.shift)) : 4 * kMaxSpanKeys;
-        P.bofs = w;
-        P.groups = P.bofs + pl.n_bkt;
-        P.ngroups = P.groups + (size_t)B * 9 * pl.NB;
-        P.seg_flag = reinterpret_cast<int *>(P.ngroups + (size_t)B * 9);
-        P.status = P.seg_flag + (size_t)B * 9;
-        P.temp = reinterpret_cast<unsigned *>(P.status + 4);
-        P.roff = reinterpret_cast<unsigned short *>(P.temp + (size_t)total_events);
-        V2CE_HIP_CHECK(hipMemsetAsync(P.status, 0, 4 * sizeof(int), st));
-        {
-            auto tile_kernel = pl.tile_threads == 512 ? ldati_tile_pass_kernel<512, 4> : ldati_tile_pass_kernel<1024, 2>;
+        if (L.kbb_bytes) {
+            // pooled slope parameters first (LDATI.py:177-190)
+            float2 *kbb = reinterpret_cast<float2 *>(wb + L.bytes - L.kbb_bytes);
+            hipLaunchKernelGGL(ldati_pool_slope_kernel, dim3((P.HW + 255) / 256, 2 * B), dim3(256), 0, st, P, o.pooling,
+                               o.pool_k, kbb);
+            P.kbb = kbb;
+        }
+        auto launch_tile_pass = [&]() -> int {
+            auto tile_kernel = o.bidir ? (pl.tile_threads == 512 ? ldati_tile_pass_kernel<512, 4, true> : ldati_tile_pass_kernel<1024, 2, true>)
+                                       : (pl.tile_threads == 512 ? ldati_tile_pass_kernel<512, 4, false> : ldati_tile_pass_kernel<1024, 2, false>);
             V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(tile_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_tile));
             hipLaunchKernelGGL(tile_kernel, dim3(pl.T, B), dim3(pl.tile_threads), pl.lds_tile, st, P);
+            return V2CE_OK;
+        };
+        if (L.generic) {
+            // ---- generic path ('random': timestamps spread over a second): tile pass in key mode, one
+            // library radix sort of the 60-bit keys, decode (+ pack)
+            P.status = reinterpret_cast<int *>(wb);
+            V2CE_HIP_CHECK(hipMemsetAsync(P.status, 0, 4 * sizeof(int), st));
+            unsigned long long *kA = reinterpret_cast<unsigned long long *>(wb + L.main_bytes);
+            unsigned long long *kB = reinterpret_cast<unsigned long long *>(wb + L.main_bytes + L.keys_bytes / 2);
+            void *tmp = wb + L.main_bytes + L.keys_bytes;
+            P.keys = kA;
+            if (int rc = launch_tile_pass()) return rc;
+            if (total_events > 0) {
+                size_t tb = L.sort_temp_bytes;
+                V2CE_HIP_CHECK(rocprim::radix_sort_keys(tmp, tb, kA, kB, (size_t)total_events, 0, 60, st));
+                long long *ts2 = P.ts;
+                short *x2 = P.x, *y2 = P.y;
+                signed char *p2 = P.p;
+                if (packed) {
+                    unsigned char *sb = wb + L.main_bytes + L.keys_bytes + L.sort_temp_bytes;
+                    ts2 = reinterpret_cast<long long *>(sb);
+                    x2 = reinterpret_cast<short *>(sb + 8 * (size_t)total_events);
+                    y2 = x2 + total_events;
+                    p2 = reinterpret_cast<signed char *>(y2 + total_events);
+                }
+                const long long blocks = (total_events + 255) / 256;
+                hipLaunchKernelGGL(ldati_keys_decode_kernel, dim3((unsigned)blocks), dim3(256), 0, st, P, kB,
+                                   (long long)total_events, ts2, x2, y2, p2);
+                if (packed)
+                    hipLaunchKernelGGL(events_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ts2, x2, y2, p2,
+                                       (long long)total_events, packed);
+            }
+            V2CE_HIP_CHECK(hipGetLastError());
+            return V2CE_OK;
         }
+        // ---- two-level path; segments with an oversized bucket fall through to the sweep kernel
+        P.bofs = w;
+        P.groups = P.bofs + pl.n_bkt;
+        P.big_list = P.groups + (size_t)B * 9 * pl.NB;
+        P.ngroups = P.big_list + (size_t)B * 9 * pl.NB;
+        P.seg_flag = reinterpret_cast<int *>(P.ngroups + (size_t)B * 9);
+        P.status = P.seg_flag + (size_t)B * 9;
+        P.nbig = reinterpret_cast<unsigned *>(P.status + 1);
+        P.temp = reinterpret_cast<unsigned *>(P.status + 4);
+        P.roff = reinterpret_cast<unsigned short *>(P.temp + (size_t)total_events);
+        V2CE_HIP_CHECK(hipMemsetAsync(P.status, 0, 4 * sizeof(int), st));
+        if (int rc = launch_tile_pass()) return rc;
         hipLaunchKernelGGL(ldati_bucket_scan_kernel, dim3(B * 9), dim3(256), 0, st, P);
         {
             auto sort_kernel = packed ? (pl.cap2 > kSortThreads * 8 ? ldati_bucket_sort_kernel<true, 24>
@@ -1531,22 +1896,28 @@ extern "C" int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_sort));
             hipLaunchKernelGGL(sort_kernel, dim3(pl.NB, B * 9), dim3(kSortThreads), pl.lds_sort, st, P);
         }
+        if (packed) hipLaunchKernelGGL(ldati_big_bucket_kernel<true>, dim3(256), dim3(256), 0, st, P);
+        else hipLaunchKernelGGL(ldati_big_bucket_kernel<false>, dim3(256), dim3(256), 0, st, P);
+        V2CE_HIP_CHECK(hipGetLastError());
+        return V2CE_OK;
     } else {
-        V2CE_REQUIRE(h.sweep_ok, V2CE_ERR_UNSUPPORTED,
-                     "v2ce_ldati_emit: fps=%g t0=%g needs %lld keys per bin; the sweep kernel's LDS histogram holds "
-                     "9600 -- pass a workspace (two-level path)", fps, t0, h.NK);
+        V2CE_REQUIRE(h.sweep_ok && o.pooling == V2CE_POOL_NONE, V2CE_ERR_UNSUPPORTED,
+                     "v2ce_ldati_emit: the sweep kernel (workspace = NULL) covers forward relocation without pooling at "
+                     "key ranges <= 9600 (fps=%g t0=%g needs %lld keys per bin): pass a workspace", fps, t0, h.NK);
     }
-    // segment-sweep kernel: every segment when there is no workspace, else only the flagged ones
-    if (h.sweep_ok) hipLaunchKernelGGL(ldati_emit_kernel, dim3(B * 9), dim3(256), h.lds_bytes, st, P);
+    // segment-sweep kernel (workspace = NULL): every segment
+    hipLaunchKernelGGL(ldati_emit_kernel, dim3(B * 9), dim3(256), h.lds_bytes, st, P);
     V2CE_HIP_CHECK(hipGetLastError());
     return V2CE_OK;
 }
 
-extern "C" int v2ce_ldati_plan_info(int B, int H, int W, double fps, double t0, int64_t total_events,
-                                    int64_t max_segment_events, int64_t max_tile_events, int64_t *info) {
+extern "C" int v2ce_ldati_plan_info(int B, int H, int W, double fps, double t0, const v2ce_ldati_options *options,
+                                    int64_t total_events, int64_t max_segment_events, int64_t max_tile_events, int64_t *info) {
     clear_error();
     V2CE_REQUIRE(info && fps > 0 && B > 0 && H > 0 && W > 0, V2CE_ERR_BAD_ARG, "v2ce_ldati_plan_info: bad argument");
-    const HostScalars h = host_scalars(fps, t0);
+    Opts o;
+    if (int rc = read_options(options, o, "v2ce_ldati_plan_info")) return rc;
+    const HostScalars h = host_scalars(fps, t0, o.bidir, o.strategy == V2CE_STRATEGY_RANDOM);
     const Plan pl = make_plan(h, B, H, W, total_events, max_segment_events, max_tile_events);
     const int64_t v[10] = {pl.ok, pl.shift, pl.NB, pl.T, pl.capA, pl.cap2, (int64_t)pl.n_tab, (int64_t)pl.n_bkt,
                            (int64_t)pl.lds_tile, (int64_t)pl.lds_sort};   // workspace layout: see v2ce_hip.h
@@ -1555,15 +1926,22 @@ extern "C" int v2ce_ldati_plan_info(int B, int H, int W, double fps, double t0, 
 }
 
 extern "C" int v2ce_ldati_status(const void *workspace, int B, int H, int W, double fps, double t0,
-                                 int64_t total_events, int64_t max_segment_events, int64_t max_tile_events,
-                                 const int32_t **status_dev) {
+                                 const v2ce_ldati_options *options, int64_t total_events, int64_t max_segment_events,
+                                 int64_t max_tile_events, const int32_t **status_dev) {
     clear_error();
     V2CE_REQUIRE(workspace && status_dev, V2CE_ERR_BAD_ARG, "v2ce_ldati_status: null pointer");
-    const HostScalars h = host_scalars(fps, t0);
+    Opts o;
+    if (int rc = read_options(options, o, "v2ce_ldati_status")) return rc;
+    const bool random = o.strategy == V2CE_STRATEGY_RANDOM;
+    const HostScalars h = host_scalars(fps, t0, o.bidir, random);
     const Plan pl = make_plan(h, B, H, W, total_events, max_segment_events, max_tile_events);
-    V2CE_REQUIRE(pl.ok, V2CE_ERR_UNSUPPORTED, "v2ce_ldati_status: no two-level plan for these arguments");
     const unsigned *w = static_cast<const unsigned *>(workspace);
-    *status_dev = reinterpret_cast<const int32_t *>(w + pl.n_bkt + (size_t)B * 9 * pl.NB + 2 * (size_t)B * 9);
+    if (random) {
+        *status_dev = reinterpret_cast<const int32_t *>(w);
+        return V2CE_OK;
+    }
+    V2CE_REQUIRE(pl.ok, V2CE_ERR_UNSUPPORTED, "v2ce_ldati_status: no two-level plan for these arguments");
+    *status_dev = reinterpret_cast<const int32_t *>(w + pl.n_bkt + 2 * (size_t)B * 9 * pl.NB + 2 * (size_t)B * 9);
     return V2CE_OK;
 }
 

@@ -17,7 +17,8 @@ CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.environ.get("V2CE_HIP_LIB", os.path.join(CSRC, "libv2ce_hip.so"))   # override: kernel A/B builds
 
 RNG_REPLAY, RNG_PHILOX = 0, 1
-STRATEGY_SLOPE, STRATEGY_NONE = 0, 1
+STRATEGY_SLOPE, STRATEGY_NONE, STRATEGY_RANDOM = 0, 1, 2
+POOL_NONE, POOL_AVG, POOL_WEIGHTED = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 PRECISION_F32, PRECISION_F16X2 = 0, 1
 
@@ -36,6 +37,11 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "B", "T", "C0", "H0", "W0", "C1", "Hin", "Win", "Cout", "Hout", "Wout", "ksize",
         "stride_hw", "act", "tile_t", "tile_h", "tile_w", "precision")]
+
+
+class LdatiOptions(ctypes.Structure):
+    """``v2ce_ldati_options`` (include/v2ce_hip.h): the keyword options of sample_voxel_statistical."""
+    _fields_ = [(n, ctypes.c_int32) for n in ("strategy", "bidirectional", "pooling_type", "pooling_kernel_size")]
 
 
 class V2ceHipError(RuntimeError):
@@ -66,18 +72,19 @@ def lib() -> ctypes.CDLL:
                                   ctypes.c_uint64, ctypes.c_size_t)
     L.v2ce_version.restype = ctypes.c_char_p
     L.v2ce_last_error.restype = ctypes.c_char_p
-    L.v2ce_ldati_count.argtypes = [vp, i32, i32, i32, i32, vp, sz, vp, vp, vp]
+    op = ctypes.POINTER(LdatiOptions)
+    L.v2ce_ldati_count.argtypes = [vp, i32, i32, i32, op, vp, sz, vp, vp, vp]
     L.v2ce_ldati_tile_ws_bytes.argtypes = [i32, i32, i32]
     L.v2ce_ldati_tile_ws_bytes.restype = sz
     L.v2ce_ldati_lds_bytes.argtypes = [f64, f64]
     L.v2ce_ldati_lds_bytes.restype = sz
-    L.v2ce_ldati_emit.argtypes = [vp, i32, i32, i32, f64, f64, i32, i32, vp, i32, u64, i64, vp, vp,
+    L.v2ce_ldati_emit.argtypes = [vp, i32, i32, i32, f64, f64, op, i32, vp, i32, u64, i64, vp, vp,
                                   vp, vp, vp, vp, vp, i64, i64, i64, vp, vp, sz, vp]
-    L.v2ce_ldati_workspace_bytes.argtypes = [i32, i32, i32, f64, f64, i64, i64, i64]
+    L.v2ce_ldati_workspace_bytes.argtypes = [i32, i32, i32, f64, f64, op, i64, i64, i64, i32]
     L.v2ce_ldati_workspace_bytes.restype = sz
-    L.v2ce_ldati_status.argtypes = [vp, i32, i32, i32, f64, f64, i64, i64, i64, ctypes.POINTER(vp)]
+    L.v2ce_ldati_status.argtypes = [vp, i32, i32, i32, f64, f64, op, i64, i64, i64, ctypes.POINTER(vp)]
     L.v2ce_ldati_status.restype = ctypes.c_int
-    L.v2ce_ldati_plan_info.argtypes = [i32, i32, i32, f64, f64, i64, i64, i64, vp]
+    L.v2ce_ldati_plan_info.argtypes = [i32, i32, i32, f64, f64, op, i64, i64, i64, vp]
     L.v2ce_ldati_plan_info.restype = ctypes.c_int
     L.v2ce_events_pack.argtypes = [vp, vp, vp, vp, i64, vp, vp]
     L.v2ce_events_unpack.argtypes = [vp, i64, vp, vp, vp, vp, vp]
