@@ -141,6 +141,12 @@ int v2ce_events_unpack(const uint8_t *packed, int64_t n, int64_t *ts, int16_t *x
  * ---------------------------------------------------------------------------------------------- */
 int v2ce_preprocess_pairs(const uint8_t *frames, int N, int H, int W, float mean, float stdv,
                           float *units, v2ce_stream_t stream);
+/* The same for frames of another size: v2ce.py:57 cv2.resize(img, (out_w, out_h)) (bilinear, half-pixel
+ * centres, edge clamp) of x = u8/255 first; units [N-1][2][out_h][out_w].  Restates the host path
+ * (glue._resize_bilinear) operation by operation (bit-identical to it; OpenCV itself is not installed in
+ * the build image, so the equality with cv2's own rounding is unpinned). */
+int v2ce_preprocess_pairs_resize(const uint8_t *frames, int N, int H, int W, int out_h, int out_w, float mean,
+                                 float stdv, float *units, v2ce_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Stage 1 -- V2ce3d building blocks.  Replaces the ATen ops behind scripts/unet_2layer.py:335-379,

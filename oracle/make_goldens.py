@@ -369,6 +369,39 @@ def gen_glue():
     print("G7: center", outs["center"].shape, "pano", outs["pano"].shape)
 
 
+# --------------------------------------------------------------------------------------------- G9
+def gen_event_frames():
+    """The frames the reference's write_event_frame_video (v2ce.py:241-280) hands to cv2.VideoWriter, with
+    the container replaced by a recorder (cv2 is absent here; cvtColor RGB2BGR = channel reversal)."""
+    ref = import_reference_v2ce()
+    cv2 = sys.modules["cv2"]
+    got = []
+
+    class Recorder:
+        def __init__(self, path, fourcc, fps, size):
+            got.append({"fps": fps, "size": size, "frames": []})
+
+        def write(self, frame):
+            got[-1]["frames"].append(frame.copy())
+
+        def release(self):
+            pass
+    cv2.VideoWriter = Recorder
+    cv2.VideoWriter_fourcc = lambda *a: 0
+    cv2.COLOR_RGB2BGR = 4
+    cv2.cvtColor = lambda img, code: img[..., ::-1]
+    rng = np.random.default_rng(9)
+    vox = (rng.gamma(0.3, 1.2, (6, 2, 10, 9, 14)) * (rng.random((6, 2, 10, 9, 14)) < 0.4)).astype(np.float32)
+    out = {"vox": vox}
+    for name, keep, ceil, pct in (("rgb", True, 10, 98), ("gray", False, 10, 98), ("rgb_ceil", True, 2, 90)):
+        ref.write_event_frame_video(vox, "unused.mp4", 30, ceil, pct, keep)
+        out[f"bgr_{name}"] = np.stack(got[-1]["frames"])
+        out[f"args_{name}"] = np.array([int(keep), ceil, pct], np.int64)
+        assert got[-1]["size"] == (14, 9)
+    np.savez_compressed(os.path.join(GOLD, "event_frames_g9.npz"), **out)
+    print("G9:", {k: v.shape for k, v in out.items()})
+
+
 # --------------------------------------------------------------------------------------------- G8
 def reference_voxelizer():
     """gen_discretized_event_volume + its two helpers, compiled from the reference source file at
@@ -405,7 +438,9 @@ def gen_voxelize():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["unet", "ldati", "options", "large", "kat", "glue", "voxelize"]
+    which = sys.argv[1:] or ["unet", "ldati", "options", "large", "kat", "glue", "voxelize", "event_frames"]
+    if "event_frames" in which:
+        gen_event_frames()
     if "voxelize" in which:
         gen_voxelize()
     if "unet" in which:

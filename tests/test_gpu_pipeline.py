@@ -44,11 +44,13 @@ def test_cli_end_to_end(tmp_path):
     out = tmp_path / "out"
     cmd = [sys.executable, os.path.join(ROOT, "v2ce.py"), "--synthetic", "20", "--height", "32",
            "--width", "48", "--synthetic_weights", "0", "-o", str(out), "-b", "2", "--seed", "11",
-           "--write_event_frame_video", "false", "--stage2_batch_size", "7", "--out_name_suffix", "t"]
+           "--write_event_frame_video", "true", "--stage2_batch_size", "7", "--out_name_suffix", "t"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     path = out / "synthetic20-ceil_10-fps_30-t-events.npz"
     assert path.exists()
+    ef_stem = out / "center-synthetic20-ceil_10-fps_30-t-pred_ef_rgb"
+    assert ef_stem.with_suffix(".mp4").exists() or ef_stem.with_suffix(".npz").exists()
     ev = np.load(path)["event_stream"]
     assert ev.dtype == O.EVENT_DTYPE and ev.dtype.itemsize == 13
     # rebuild the expectation stage-wise
@@ -62,6 +64,10 @@ def test_cli_end_to_end(tmp_path):
         seqs += list(U.forward(sd, torch.from_numpy(x)).numpy())
     want_vox = np.stack([seqs[s][j] for s, j in OG.merged_pair_sources(20)]).reshape(19, 2, 10, 32, 48)
     assert np.all(np.abs(vox - want_vox) <= TOL + TOL * np.abs(want_vox))
+    if ef_stem.with_suffix(".npz").exists():                         # no OpenCV: the frames themselves
+        from v2ce_toolbox_amd import pipeline, v2ce
+        want_ef = v2ce.event_frame_images(pipeline.event_frame_sums(torch.from_numpy(vox)).numpy(), 10, 98, True)
+        assert np.load(ef_stem.with_suffix(".npz"))["event_frames"].tobytes() == want_ef.tobytes()
     exp = []
     for i0 in range(0, 19, 7):
         recs = O.sample_voxel_statistical_oracle(vox[i0:i0 + 7], fps=30, seed=11, frame_base=i0)
@@ -106,3 +112,15 @@ def test_explicit_device_index(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert len(np.load(out / "synthetic17-ceil_10-fps_30-events.npz")["event_stream"]) > 0
+
+
+@pytest.mark.parametrize("shape,height", [((5, 130, 173), 260), ((4, 480, 640), 260), ((3, 100, 37), 64), ((3, 260, 346), 260),
+                                          ((3, 480, 505), 480)])
+def test_device_resize_matches_host_path(shape, height):
+    """f3: v2ce_preprocess_pairs_resize == glue.image_pre_processing (the host restatement of
+    cv2.resize + Normalize, v2ce.py:45-64) bit for bit, up- and down-scaling, also the W-1 width case."""
+    fr = synth.synthetic_frames(*shape, seed=13, pattern="noise")
+    want = glue.image_pre_processing(fr, height=height)
+    got = glue.image_pre_processing_device(torch.from_numpy(fr).cuda(), height).cpu().numpy()
+    assert got.shape == want.shape
+    assert got.tobytes() == want.tobytes()

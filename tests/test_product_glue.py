@@ -88,3 +88,29 @@ def test_shard_range():
             assert all(a[1] == b[0] for a, b in zip(got, got[1:]))
             sizes = [hi - lo for lo, hi in got]
             assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.parametrize("name", ["rgb", "gray", "rgb_ceil"])
+def test_event_frames_match_reference(gold_dir, name):
+    """Golden G9: the uint8 frames the reference's write_event_frame_video (v2ce.py:241-280) hands to
+    cv2.VideoWriter (BGR), from the same voxel grid, through the product's reduction + image code."""
+    from v2ce_toolbox_amd import pipeline, v2ce
+    z = np.load(os.path.join(gold_dir, "event_frames_g9.npz"))
+    keep, ceil, pct = (int(v) for v in z[f"args_{name}"])
+    sums = pipeline.event_frame_sums(torch.from_numpy(z["vox"])).numpy()
+    rgb = v2ce.event_frame_images(sums, ceil, pct, bool(keep))
+    assert rgb.dtype == np.uint8
+    assert rgb[..., ::-1].tobytes() == z[f"bgr_{name}"].tobytes()
+
+
+def test_event_frame_writer_without_opencv(tmp_path, gold_dir):
+    from v2ce_toolbox_amd import pipeline, v2ce
+    z = np.load(os.path.join(gold_dir, "event_frames_g9.npz"))
+    sums = pipeline.event_frame_sums(torch.from_numpy(z["vox"])).numpy()
+    path = v2ce.write_event_frame_video(sums, str(tmp_path / "a-pred_ef_rgb.mp4"), 30, 10, 98, True)
+    try:
+        import cv2  # noqa: F401
+        assert path.endswith(".mp4") and os.path.getsize(path) > 0
+    except ImportError:
+        assert path.endswith(".npz")
+        assert np.load(path)["event_frames"][..., ::-1].tobytes() == z["bgr_rgb"].tobytes()

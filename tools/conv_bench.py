@@ -49,10 +49,33 @@ def run(name, B=4, T=16, iters=5, tile=(0, 0, 0)):
                      precision=1 if split else 0)
     lib = hip.lib()
 
+    fuse = os.environ.get("FUSE", "") if split and k == 3 else ""
+    if fuse == "sc":           # the block's 1x1x1 shortcut on the same launch (v2ce_conv3d_fwd_sc)
+        wd32 = torch.randn(Cout, C0 + C1, 1, 1, 1, device=dev) * 0.1
+        wd = torch.empty(2 * wd32.numel() + 4, dtype=torch.float16, device=dev)
+        hip.check(lib.v2ce_pack_weights_f16x2(wd32.data_ptr(), Cout, C0 + C1, 1, None, wd.data_ptr(), hip.stream_ptr()), "pack")
+        ysc = torch.empty_like(y)
+    if fuse == "pred":         # the 1x1x1 head on the same launch (v2ce_conv3d_fwd_pred)
+        wp32 = torch.randn(20, 32, device=dev) * 0.1
+        tab = torch.empty(lib.v2ce_pack_pred_weights_f16x2_bytes() // 2, dtype=torch.float16, device=dev)
+        hip.check(lib.v2ce_pack_pred_weights_f16x2(wp32.data_ptr(), 20, 32, tab.data_ptr(), hip.stream_ptr()), "pack")
+        pb = torch.zeros(32, device=dev)
+        yp = torch.empty(B, T, 20, Ho, Wo, device=dev)
+        res = torch.randn_like(y)
+
     def call():
-        hip.check(lib.v2ce_conv3d_fwd(ctypes.byref(d), x0.data_ptr(), hip.ptr(x1), hip.ptr(hmap), hip.ptr(wmap),
-                                      w.data_ptr(), sc.data_ptr(), sh.data_ptr(), None, y.data_ptr(),
-                                      None, None, None, hip.stream_ptr()), "conv")
+        if fuse == "sc":
+            hip.check(lib.v2ce_conv3d_fwd_sc(ctypes.byref(d), x0.data_ptr(), hip.ptr(x1), hip.ptr(hmap), hip.ptr(wmap),
+                                             w.data_ptr(), sc.data_ptr(), sh.data_ptr(), y.data_ptr(), None, None, None,
+                                             wd.data_ptr(), sc.data_ptr(), sh.data_ptr(), ysc.data_ptr(), hip.stream_ptr()), "conv_sc")
+        elif fuse == "pred":
+            hip.check(lib.v2ce_conv3d_fwd_pred(ctypes.byref(d), x0.data_ptr(), hip.ptr(x1), hip.ptr(hmap), hip.ptr(wmap),
+                                               w.data_ptr(), sc.data_ptr(), sh.data_ptr(), res.data_ptr(), None, None, None, None,
+                                               tab.data_ptr(), pb.data_ptr(), 20, yp.data_ptr(), hip.stream_ptr()), "conv_pred")
+        else:
+            hip.check(lib.v2ce_conv3d_fwd(ctypes.byref(d), x0.data_ptr(), hip.ptr(x1), hip.ptr(hmap), hip.ptr(wmap),
+                                          w.data_ptr(), sc.data_ptr(), sh.data_ptr(), None, y.data_ptr(),
+                                          None, None, None, hip.stream_ptr()), "conv")
     call()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -63,7 +86,7 @@ def run(name, B=4, T=16, iters=5, tile=(0, 0, 0)):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     fl = 2.0 * B * T * Ho * Wo * Cout * (C0 + C1) * k ** 3
-    return hip.conv_variant(d, hmap is not None), ms, fl / ms / 1e9
+    return hip.conv_variant(d, hmap is not None, {'sc': 2, 'pred': 1}.get(fuse, 0)), ms, fl / ms / 1e9
 
 
 if __name__ == "__main__":

@@ -48,19 +48,27 @@ def image_pre_processing(images: np.ndarray, height: int = 260) -> np.ndarray:
     return ((units - MEAN) / STD).astype(np.float32)       # transforms.Normalize: sub then div, f32
 
 
-def image_pre_processing_device(frames: torch.Tensor) -> torch.Tensor:
-    """Device twin of ``image_pre_processing`` for frames already at the target height:
-    frames [N,H,W] uint8 on the device -> [N-1,2,H,W] f32 (bit-identical to the host path)."""
+def image_pre_processing_device(frames: torch.Tensor, height: Optional[int] = None) -> torch.Tensor:
+    """Device twin of ``image_pre_processing``: frames [N,H,W] uint8 on the device -> [N-1,2,height,W']
+    f32, W' = int(W/H*height) (v2ce.py:57), bit-identical to the host path (identity resize when the
+    size already matches, bilinear otherwise)."""
     from . import hip
     if not frames.is_cuda or frames.dtype != torch.uint8 or frames.dim() != 3:
         raise hip.V2ceHipError("image_pre_processing_device: expected a uint8 [N,H,W] device tensor")
     frames = frames.contiguous()
     n, h, w = frames.shape
-    units = torch.empty((n - 1, 2, h, w), dtype=torch.float32, device=frames.device)
+    oh = h if height is None else int(height)
+    ow = int(w / h * oh)
+    units = torch.empty((n - 1, 2, oh, ow), dtype=torch.float32, device=frames.device)
     with torch.cuda.device(frames.device):
-        hip.check(hip.lib().v2ce_preprocess_pairs(frames.data_ptr(), n, h, w, float(MEAN), float(STD),
-                                                  units.data_ptr(), hip.stream_ptr(frames.device)),
-                  "v2ce_preprocess_pairs")
+        if (oh, ow) == (h, w):
+            hip.check(hip.lib().v2ce_preprocess_pairs(frames.data_ptr(), n, h, w, float(MEAN), float(STD),
+                                                      units.data_ptr(), hip.stream_ptr(frames.device)),
+                      "v2ce_preprocess_pairs")
+        else:
+            hip.check(hip.lib().v2ce_preprocess_pairs_resize(frames.data_ptr(), n, h, w, oh, ow, float(MEAN), float(STD),
+                                                             units.data_ptr(), hip.stream_ptr(frames.device)),
+                      "v2ce_preprocess_pairs_resize")
     return units
 
 
@@ -139,12 +147,9 @@ def video_to_voxels(model, frames: Optional[np.ndarray] = None, read_frames=None
     out_width = width
     for seq_idx, start in enumerate(starts):
         images = np.asarray(read_frames(range(int(start), int(start) + seq_len + 1)))
-        if (images.dtype == np.uint8 and images.shape[1] == height and str(device).startswith("cuda")
-                and int(images.shape[2] / images.shape[1] * height) == images.shape[2]):
-            # no resize needed (the reference's target width int(W/H*height), v2ce.py:57, can be W-1
-            # through float rounding even when H == height: those clips take the host path):
-            # ship the u8 frames (4x fewer PCIe bytes) and normalise on the device
-            units = image_pre_processing_device(torch.from_numpy(images).to(device, non_blocking=True))
+        if images.dtype == np.uint8 and str(device).startswith("cuda"):
+            # ship the u8 frames (4x fewer PCIe bytes); resize (v2ce.py:57) and normalise on the device
+            units = image_pre_processing_device(torch.from_numpy(images).to(device, non_blocking=True), height)
             pending.append(units[None])
         else:
             units = image_pre_processing(images, height=height)

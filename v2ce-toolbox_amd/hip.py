@@ -27,7 +27,7 @@ EXPORTS = [
     "v2ce_ldati_lds_bytes", "v2ce_ldati_workspace_bytes", "v2ce_ldati_emit", "v2ce_events_pack", "v2ce_events_unpack",
     "v2ce_conv3d_fwd",
     "v2ce_conv3d_variant", "v2ce_conv3d_variant_fused", "v2ce_pack_weights_f16x2", "v2ce_pack_weights_f16x2_bytes",
-    "v2ce_pack_weights", "v2ce_sn_workspace_bytes", "v2ce_sn_power_iter", "v2ce_preprocess_pairs",
+    "v2ce_pack_weights", "v2ce_sn_workspace_bytes", "v2ce_sn_power_iter", "v2ce_preprocess_pairs", "v2ce_preprocess_pairs_resize",
     "v2ce_voxelize_events", "v2ce_conv3d_fwd_pred", "v2ce_conv3d_fwd_sc", "v2ce_pack_pred_weights_f16x2", "v2ce_pack_pred_weights_f16x2_bytes",
 ]
 
@@ -100,6 +100,8 @@ def lib() -> ctypes.CDLL:
     L.v2ce_conv3d_variant_fused.restype = ctypes.c_int
     L.v2ce_preprocess_pairs.argtypes = [vp, i32, i32, i32, ctypes.c_float, ctypes.c_float, vp, vp]
     L.v2ce_preprocess_pairs.restype = ctypes.c_int
+    L.v2ce_preprocess_pairs_resize.argtypes = [vp, i32, i32, i32, i32, i32, ctypes.c_float, ctypes.c_float, vp, vp]
+    L.v2ce_preprocess_pairs_resize.restype = ctypes.c_int
     L.v2ce_voxelize_events.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp]
     L.v2ce_voxelize_events.restype = ctypes.c_int
     L.v2ce_conv3d_fwd_pred.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 14 + [i32, vp, vp]

@@ -169,9 +169,8 @@ class FrameFeeder:
     def __init__(self, frames: np.ndarray, seq_len: int, device, height: int):
         self.frames, self.seq_len, self.device = frames, seq_len, torch.device(device)
         self.cuda = self.device.type == "cuda"
-        # device preprocessing needs u8 frames that the reference's resize leaves untouched
-        self.device_pre = (self.cuda and frames.dtype == np.uint8 and frames.shape[1] == height
-                           and resized_width(frames, height) == frames.shape[2])
+        # u8 frames go to the device as they are (4x fewer PCIe bytes); resize + normalisation happen there
+        self.device_pre = self.cuda and frames.dtype == np.uint8
         self.height = height
         self.stream = torch.cuda.Stream(device=self.device) if self.cuda else None
         self.slots = [None, None]
@@ -213,7 +212,7 @@ class FrameFeeder:
         main.wait_event(ev)
         t.record_stream(main)
         b, L1 = len(bp.starts), self.seq_len + 1
-        units = [glue.image_pre_processing_device(t[i * L1:(i + 1) * L1]) for i in range(b)]
+        units = [glue.image_pre_processing_device(t[i * L1:(i + 1) * L1], self.height) for i in range(b)]
         return torch.stack(units) if b > 1 else units[0][None]
 
 
@@ -243,14 +242,31 @@ def default_stage2(fps, seed, total_pairs, device):
     return begin, finish
 
 
+def event_frame_sums(vox: torch.Tensor) -> torch.Tensor:
+    """[P,2,10,H,W] -> [P,3,H,W]: the per-polarity sums over the ten bins (np.sum(axis=2), v2ce.py:255)
+    and the sum over all twenty planes (np.sum(axis=(1,2)), v2ce.py:259), each accumulated in f32 in
+    the plane order numpy uses, so the uint8 frames derived from them equal the reference's."""
+    planes = vox.reshape(vox.shape[0], 20, *vox.shape[3:])
+    out = torch.empty((vox.shape[0], 3, *vox.shape[3:]), dtype=torch.float32, device=vox.device)
+    for c, idx in enumerate((range(0, 10), range(10, 20), range(0, 20))):
+        acc = planes[:, idx[0]]
+        for j in idx[1:]:
+            acc = acc + planes[:, j]
+        out[:, c] = acc
+    return out
+
+
 def run_clip(frames: np.ndarray, model, *, infer_type="center", seq_len=16, width=346, height=260,
              batch_size=1, fps=30, seed=0, device="cuda", stage2=None, dtype=None,
              rank=0, world=1, group=None, trace: Optional[dict] = None,
-             reuse_output: bool = False) -> Optional[np.ndarray]:
+             reuse_output: bool = False, event_frames: Optional[list] = None) -> Optional[np.ndarray]:
     """frames [N,H,W] uint8 -> event_stream (structured array) on rank 0, None elsewhere.
 
     stage2: optional (begin, finish) pair replacing LDATI (CPU stand-ins in the tests):
-    begin(vox, first_pair) -> handle; finish(handle) -> (packed uint8 tensor, keepalive)."""
+    begin(vox, first_pair) -> handle; finish(handle) -> (packed uint8 tensor, keepalive).
+    event_frames: a list that receives, per batch, (first pair, event_frame_sums(voxels)) on the device
+    -- the reduction the reference's event-frame video starts from (v2ce.py:254-260); single-process
+    runs only."""
     from .LDATI import EVENT_DTYPE
     dtype = dtype or EVENT_DTYPE
     plans = plan_batches(len(frames), seq_len, batch_size)
@@ -325,6 +341,8 @@ def run_clip(frames: np.ndarray, model, *, infer_type="center", seq_len=16, widt
                 vox, p_lo = vdist.tiles_to_pairs(part, widths, tile_index, grp)  # [P_r,2,10,H,W_full]
                 first_pair, key = bp.first_pair + p_lo, (bp.index, tile_index)
             tt = tick("model", tt)
+            if event_frames is not None:
+                event_frames.append((first_pair, event_frame_sums(vox)))
             nxt = (begin(vox, first_pair), key, int(vox.shape[0]))
             tt = tick("begin", tt)
             if pending is not None:

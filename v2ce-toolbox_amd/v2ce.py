@@ -147,9 +147,47 @@ def download_events(packed_list) -> np.ndarray:
     return host.numpy().view(EVENT_DTYPE)
 
 
+def event_frame_images(efs: np.ndarray, ceil, upper_bound_percentile=98, keep_polarity=True) -> np.ndarray:
+    """v2ce.py:253-269,275-276: efs [L,3,H,W] = pipeline.event_frame_sums (per-polarity sums over the ten
+    bins, and the sum of all twenty planes) -> uint8 RGB frames [L,H,W,3]: the two polarities in red and
+    green (or their sum in grey), clipped at min(percentile of the non-zero values, ceil), scaled to 255."""
+    L, _, H, W = efs.shape
+    if keep_polarity:
+        efs = np.concatenate([efs[:, :2], np.zeros((L, 1, H, W))], axis=1)   # float64 like the reference's zeros
+    else:
+        efs = np.repeat(efs[:, 2:3], 3, axis=1)
+    nz = efs.flatten()
+    nz = nz[nz > 0]
+    upper = min(np.percentile(nz, upper_bound_percentile), ceil)
+    logger.info(f"Upper bound of the event frame value during video writing: {upper}")
+    efs = np.clip(efs, 0, upper) / upper
+    return (np.moveaxis(efs, 1, -1) * 255).astype(np.uint8)
+
+
+def write_event_frame_video(efs: np.ndarray, ef_video_path, fps, ceil, upper_bound_percentile=98, keep_polarity=True):
+    """v2ce.py:241-280.  The frames are computed here; the mp4 container needs OpenCV (cv2.VideoWriter,
+    'mp4v'), which the build image lacks -- then the same uint8 frames are written next to it as
+    ``<stem>.npz`` (key ``event_frames``, RGB)."""
+    frames = event_frame_images(efs, ceil, upper_bound_percentile, keep_polarity)
+    try:
+        import cv2
+    except ImportError:
+        alt = op.splitext(ef_video_path)[0] + ".npz"
+        np.savez_compressed(alt, event_frames=frames, fps=np.float64(fps))
+        logger.warning(f"OpenCV is not installed: event frames written to {alt} instead of {ef_video_path}")
+        return alt
+    H, W = frames.shape[1:3]
+    video = cv2.VideoWriter(ef_video_path, cv2.VideoWriter_fourcc(*"mp4v"), fps, (W, H))
+    for fr in frames:
+        video.write(cv2.cvtColor(fr, cv2.COLOR_RGB2BGR))
+    video.release()
+    logger.info(f"Event frame video written to {ef_video_path}")
+    return ef_video_path
+
+
 def run(frames: np.ndarray, model, infer_type="center", seq_len=16, width=346, height=260,
         batch_size=1, fps=30, stage2_batch_size=24, seed=0, rng="philox", device="cuda",
-        stage2=None) -> Optional[np.ndarray]:
+        stage2=None, event_frames: Optional[list] = None) -> Optional[np.ndarray]:
     """frames [N,H,W] uint8 -> event_stream (numpy structured array, v2ce.py:368) on rank 0.
 
     Default (counter-based Philox draws): the per-batch pipeline of ``pipeline.run_clip`` (H2D,
@@ -165,11 +203,15 @@ def run(frames: np.ndarray, model, infer_type="center", seq_len=16, width=346, h
             raise NotImplementedError("rng='torch' replays the reference's single-process draw order; run it on one GPU")
         vox = glue.video_to_voxels(model, frames=frames, infer_type=infer_type, seq_len=seq_len,
                                    width=width, height=height, batch_size=batch_size, device=device)
+        if event_frames is not None:
+            from .pipeline import event_frame_sums
+            event_frames.append((0, event_frame_sums(vox)))
         packed, _ = events_from_voxels(vox, fps, stage2_batch_size, seed, rng)
         return download_events(packed)
     return pipeline.run_clip(frames, model, infer_type=infer_type, seq_len=seq_len, width=width, height=height,
                              batch_size=batch_size, fps=fps, seed=seed, device=device, stage2=stage2,
-                             dtype=EVENT_DTYPE, rank=rank, world=world)
+                             dtype=EVENT_DTYPE, rank=rank, world=world,
+                             event_frames=event_frames if world == 1 else None)
 
 
 def main(argv=None):
@@ -213,10 +255,18 @@ def main(argv=None):
         model = model.eval().to(device)
     else:
         model = get_trained_mode(args.model_path, device, args.precision)
-    if args.write_event_frame_video:
-        logger.warning("event-frame mp4 (v2ce.py:241-280) needs OpenCV and is outside the hot path: skipped")
+    efs = [] if (args.write_event_frame_video and world == 1) else None
+    if args.write_event_frame_video and world > 1:
+        logger.warning("the event-frame video (v2ce.py:241-280) is written by single-process runs only: skipped")
     event_stream = run(frames, model, args.infer_type, args.seq_len, args.width, args.height,
-                       args.batch_size, args.fps, args.stage2_batch_size, args.seed, args.rng, device)
+                       args.batch_size, args.fps, args.stage2_batch_size, args.seed, args.rng, device,
+                       event_frames=efs)
+    if efs:
+        ef = torch.cat([t for _, t in sorted(efs, key=lambda kv: kv[0])]).cpu().numpy()
+        vis_color = "rgb" if args.vis_keep_polarity else "gray"
+        os.makedirs(args.out_folder, exist_ok=True)
+        write_event_frame_video(ef, op.join(args.out_folder, f"{args.infer_type}-{output_name}-pred_ef_{vis_color}.mp4"),
+                                args.fps, args.ceil, args.upper_bound_percentile, args.vis_keep_polarity)
     if event_stream is not None:
         logger.info(f"Generated event stream shape: , {event_stream.shape}")
         path = op.join(args.out_folder, f"{output_name}-events.npz")
