@@ -186,12 +186,26 @@ size_t v2ce_pack_weights_f16x2_bytes(int Cout, int Cin, int k3);
 int v2ce_pack_weights_f16x2(const float *w, int Cout, int Cin, int k3, const float *sigma, void *w_f16x2,
                             v2ce_stream_t stream);
 
-/* Range tracking (all three may be NULL): y_absmax [1] device float, zeroed by the caller, receives
- * max |y| of the launch by atomic max.  x0_absmax / x1_absmax [1] are the slots the launches that
- * produced x0 / x1 wrote (any upper bound of max |x| works); the split-half kernel derives its
- * power-of-two activation pre-scale from them on the device, so no magnitude can overflow fp16.
- * With x0_absmax NULL the split-half kernel uses the fixed pre-scale 16 and requires |x| < 4094.
- * Ignored (inputs) by the exact-f32 kernels; both precisions record y_absmax. */
+/* Range tracking (all three may be NULL): y_absmax [2] device floats, zeroed by the caller: [0] receives
+ * max |y| of the launch by atomic max; [1] receives the split-half launch's RANGE GUARD value E (below;
+ * exact-f32 launches leave it 0; v2ce_conv3d_fwd_pred with y == NULL writes only [1]).
+ * x0_absmax / x1_absmax [1] are the slots the launches that produced x0 / x1 wrote (any upper bound of
+ * max |x| works); the split-half kernel derives its power-of-two activation pre-scale from them on the
+ * device, so no magnitude can overflow fp16.  With x0_absmax NULL the split-half kernel uses the fixed
+ * pre-scale 16 and requires |x| < 4094.  Ignored (inputs) by the exact-f32 kernels; both precisions
+ * record y_absmax[0].
+ *
+ * Range guard.  One power-of-two scale per tensor puts max |x| (max |w|) in [2^14, 2^15); an element
+ * more than ~18 binades below the maximum has an fp16-subnormal lo half and is represented to 2^-25 of
+ * the SCALED range instead of to 2^-22 relative.  The kernel reports the worst case this can cost one
+ * of its outputs:  E = max_co |scale[co]| * K * 2^-25 * (max|w| / x_scale + max|x| / w_scale),
+ * K = Cin * ksize^3 (fused shortcut: the larger of the two convs' values).  E <= V2CE_RANGE_GUARD_LIMIT
+ * guarantees the split-half result within that absolute distance of the exact-f32 kernels' for this
+ * layer, whatever the distribution of the values (synthetic weights, 346x260: max E 3e-7); the host
+ * model accumulates the maximum over a clip and repeats the clip on the exact-f32 kernels when it is
+ * exceeded (v2ce_3d.V2ce3d.range_guard_value, glue.run_guarded).  The bound is a worst case: a single
+ * 1e4 outlier among O(1) activations trips it, although the measured error there is still < 1e-6. */
+#define V2CE_RANGE_GUARD_LIMIT 2.5e-6f
 int v2ce_conv3d_fwd(const v2ce_conv3d_desc *desc, const float *x0, const float *x1,
                     const int32_t *hmap, const int32_t *wmap, const float *w_packed,
                     const float *scale, const float *shift, const float *residual, float *y,

@@ -8,6 +8,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from oracle import glue as OG
 from oracle import unet as U
 from v2ce_toolbox_amd import synth
 
@@ -190,7 +191,7 @@ def hip_conv_split(x0, w, scale, shift, stride, act, x1=None, up_to=None, residu
     torch.nn.Module.__init__(m)
     m._maps = {}
     m.precision = "f16x2" if tracked else "f32"
-    m._prep = {"absmax": torch.zeros(4, device="cuda")}
+    m._prep = {"absmax": torch.zeros((4, 2), device="cuda")}
     m._slot = 0
     wq = V2ce3d._pack(m, w.cuda().contiguous(), split=True)
     x0d = to_btchw(x0).cuda()
@@ -204,6 +205,7 @@ def hip_conv_split(x0, w, scale, shift, stride, act, x1=None, up_to=None, residu
                      residual=None if residual is None else to_btchw(residual).cuda(), up_to=up_to,
                      split=True)
     torch.cuda.synchronize()
+    hip_conv_split.guard = float(y.absmax[1])               # the launch's range-guard bound
     return y.permute(0, 2, 1, 3, 4).cpu().numpy()
 
 
@@ -338,6 +340,12 @@ def test_conv3d_split_half_single_outlier(outlier):
     rel_near = (err / np.abs(want).clip(1e-30))[~far].max()
     print(f"outlier {outlier:g}: max |err| away from it {err[far].max():.3e}, max rel err at it {rel_near:.3e}")
     assert rel_near <= 1e-5
+    # the guard bound is a worst case: it already trips at 1e4 (measured error still < 1e-6), so every
+    # case whose error can exceed the bar is routed to the exact-f32 kernels (test_range_guard_*)
+    from v2ce_toolbox_amd.v2ce_3d import V2ce3d
+    print(f"guard bound {hip_conv_split.guard:.3e}")
+    assert hip_conv_split.guard > V2ce3d.RANGE_GUARD_LIMIT
+    assert hip_conv_split.guard >= err[far].max()
     if outlier <= 1e6:
         assert excess_far <= TOL, excess_far
     else:          # 27 binades: ~12 bits left for the O(1) values -- the documented limit of one scale per tensor
@@ -358,6 +366,65 @@ def test_conv3d_split_half_heavy_tail():
     assert_close(got, want, "heavy tail")
 
 
+def test_range_guard_quiet_on_ordinary_activations():
+    """N(0,1) activations, He-scaled weights: the bound stays two orders of magnitude under the limit and
+    above the measured error."""
+    from v2ce_toolbox_amd.v2ce_3d import V2ce3d
+    g = torch.Generator().manual_seed(13)
+    for cin, cout in ((32, 64), (256, 128)):
+        x = torch.randn(1, cin, 3, 12, 14, generator=g)
+        w = torch.randn(cout, cin, 3, 3, 3, generator=g) * (2.0 / (cin * 27)) ** 0.5
+        one, zero = torch.ones(cout), torch.zeros(cout)
+        got = hip_conv_split(x, w, one, zero, 1, 0, tracked=True)
+        assert 0 < hip_conv_split.guard < V2ce3d.RANGE_GUARD_LIMIT / 10, hip_conv_split.guard
+        assert_close(got, ref_conv(x, w, one, zero, 3, 1, 0), "guard quiet")
+
+
+def test_range_guard_reroutes_adversarial_model_to_exact_f32(caplog):
+    """a checkpoint whose first encoder block emits one channel at 3e6 next to O(1)
+    channels (a 22-binade range inside one tensor).  The split-half launches report it, and the guarded
+    entry point (glue.video_to_voxels -> run_guarded) returns what the exact-f32 model returns, bit for
+    bit, with the spectral-norm trajectory of a single pass; ordinary weights do not trip."""
+    import logging
+    from v2ce_toolbox_amd import glue
+    from v2ce_toolbox_amd.v2ce_3d import V2ce3d
+    frames = synth.synthetic_frames(18, 32, 48, seed=4)
+    sd = synth.make_state_dict(0)
+    bad = {k: v.clone() for k, v in sd.items()}
+    bad["UNet.encoders.0.downsample.0.bias"][3] = 3e6
+
+    def model(state, precision):
+        m = V2ce3d(precision=precision)
+        m.load_state_dict(state, strict=True)
+        return m.eval().to("cuda")
+
+    m = model(sd, "f16x2")
+    glue.video_to_voxels(m, frames=frames, width=48, height=32, batch_size=2)
+    quiet = m.range_guard_value()
+    assert quiet == 0.0                                   # run_guarded consumed it ...
+    m(torch.from_numpy(OG.preprocess(frames[:17])[None]).cuda())
+    ordinary = m.range_guard_value()
+    print(f"ordinary weights: guard bound {ordinary:.3e}")
+    assert 0 < ordinary < V2ce3d.RANGE_GUARD_LIMIT         # ... and a plain forward shows the ordinary level
+
+    mg, mx = model(bad, "f16x2"), model(bad, "f32")
+    with caplog.at_level(logging.WARNING, logger="V2CE"):
+        got = glue.video_to_voxels(mg, frames=frames, width=48, height=32, batch_size=2)
+    assert any("range guard" in r.message for r in caplog.records)
+    want = glue.video_to_voxels(mx, frames=frames, width=48, height=32, batch_size=2)
+    assert torch.equal(got, want)
+    assert mg.calls == mx.calls and mg.precision == "f16x2"
+    for (n, p), (_, q) in zip(mg.named_parameters(), mx.named_parameters()):
+        if n.endswith(("weight_u", "weight_v")):
+            assert torch.equal(p, q), n
+    # without the guard the split-half result is outside the bar here: the reroute is needed
+    raw = model(bad, "f16x2")(torch.from_numpy(OG.preprocess(frames[:17])[None]).cuda())
+    ex = model(bad, "f32")(torch.from_numpy(OG.preprocess(frames[:17])[None]).cuda())
+    d = (raw - ex).abs()
+    print(f"unguarded split-half vs exact on the adversarial checkpoint: max abs {float(d.max()):.3e}, "
+          f"max rel {float((d / ex.abs().clamp_min(1e-30)).max()):.3e}")
+
+
 def test_conv3d_records_output_absmax():
     from v2ce_toolbox_amd.v2ce_3d import V2ce3d
     g = torch.Generator().manual_seed(3)
@@ -367,12 +434,12 @@ def test_conv3d_records_output_absmax():
         m = V2ce3d.__new__(V2ce3d)
         torch.nn.Module.__init__(m)
         m._maps, m.precision, m._slot = {}, "f16x2", 0
-        m._prep = {"absmax": torch.zeros(4, device="cuda")}
+        m._prep = {"absmax": torch.zeros((4, 2), device="cuda")}
         xd = to_btchw(x).cuda()
         xd.absmax = xd.abs().max().reshape(1)
         wp = V2ce3d._pack(m, w.cuda().contiguous(), split=split)
         y = V2ce3d._conv(m, xd, None, wp, torch.ones(32).cuda(), torch.zeros(32).cuda(), 32, 3, 1, 2, split=split, track=True)
-        assert float(y.absmax) == float(y.abs().max())
+        assert float(y.absmax[0]) == float(y.abs().max())
 
 
 def test_v2ce3d_split_half_matches_reference_three_calls(gold_dir):

@@ -64,11 +64,13 @@ struct ConvParams {
     // split-half path (conv3d_f16x2_ws_kernel): weights as fp16 hi/lo planes [2][K3][Cin/16][Cout][16]
     // followed by { max |w|, power-of-two pre-scale } as two floats (pack_weights_f16x2_kernel)
     const _Float16 *wq;
-    // dynamic range tracking: y_absmax (may be null) receives max |y| of this launch by atomic max;
+    // dynamic range tracking: y_absmax[0] (may be null) receives max |y| of this launch by atomic max,
+    // y_absmax[1] the split-half kernel's range-guard bound (see conv3d_f16x2_ws_kernel);
     // x0_absmax / x1_absmax (may be null) are the slots the producers of x0 / x1 wrote -- the
     // split-half kernel derives its power-of-two activation pre-scale from them
     const float *x0_absmax, *x1_absmax;
     float *y_absmax;
+    float *guard;                 // = y_absmax + 1
     // fused 1x1x1 head behind a 32-channel conv (v2ce_conv3d_fwd_pred): pred_y[o] = relu(pred_w[o][:] . y + pred_b[o])
     const _Float16 *pred_w;       // table of v2ce_pack_pred_weights_f16x2 (A fragments hi/lo + pre-scale)
     const float *pred_b;          // [32], zero padded
@@ -648,10 +650,31 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
 
     const float w_scale = reinterpret_cast<const float *>(P.wq + 2 * wplane)[1];
     float x_scale = kActScale;
+    float am = 4094.0f;
     if (P.x0_absmax) {
-        float am = *P.x0_absmax;
+        am = *P.x0_absmax;
         if (P.x1_absmax) am = fmaxf(am, *P.x1_absmax);
         x_scale = pow2_prescale(am);
+    }
+    // Range guard (y_absmax[1]): a bound on what the one-scale-per-tensor split can cost this launch's
+    // outputs.  An operand whose scaled magnitude is below 2^-3 has an fp16-SUBNORMAL lo half: hi + lo
+    // then misses it by up to 2^-25 (scaled), instead of by 2^-22 relative.  Worst case over a K-term
+    // dot product, times the folded BatchNorm scale:
+    //   E = max|scale| * K * 2^-25 * (max|w| / x_scale + max|x| / w_scale)
+    // (first term: activations flushed, second: weights flushed).  The host compares E with its limit
+    // after the run (v2ce_3d.V2ce3d.range_guard_value) and repeats the clip on the exact-f32 kernels.
+    if (P.guard && blockIdx.x == 0 && wave == 0) {
+        auto bound = [&](const float *scale, const _Float16 *wq, long long plane_halves, int K) {
+            float sm = 0.0f;
+            for (int co = lane; co < P.Cout; co += 64) sm = fmaxf(sm, fabsf(scale[co]));
+#pragma unroll
+            for (int o = 32; o; o >>= 1) sm = fmaxf(sm, __shfl_xor(sm, o));
+            const float *tail = reinterpret_cast<const float *>(wq + 2 * plane_halves);
+            return sm * (float)K * 0x1p-25f * (tail[0] / x_scale + am / tail[1]);
+        };
+        float E = bound(P.scale, P.wq, wplane, P.Cin * K3);
+        if (FUSE == 2) E = fmaxf(E, bound(P.sc_scale, P.sc_w, (long long)CG * P.Cout * 16, P.Cin));
+        if (lane == 0) *P.guard = E;
     }
 
     int vb = blockIdx.x;
@@ -1241,6 +1264,8 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
     P.Win = d.Win; P.Cin = d.C0 + d.C1; P.Cout = d.Cout; P.Hout = d.Hout; P.Wout = d.Wout;
     P.act = d.act;
     P.x0_absmax = x0_absmax; P.x1_absmax = d.C1 > 0 ? x1_absmax : nullptr; P.y_absmax = y_absmax;
+    P.guard = y_absmax ? y_absmax + 1 : nullptr;
+    if (pred_w && !y) P.y_absmax = nullptr;      // no y is materialised: only the guard value is reported
     P.pred_w = static_cast<const _Float16 *>(pred_w); P.pred_b = pred_b; P.pred_cout = pred_cout; P.pred_y = pred_y;
     P.sc_w = static_cast<const _Float16 *>(sc_w); P.sc_scale = sc_scale; P.sc_shift = sc_shift; P.sc_y = sc_y;
     if (sc_w) {

@@ -72,6 +72,36 @@ def image_pre_processing_device(frames: torch.Tensor, height: Optional[int] = No
     return units
 
 
+def run_guarded(model, fn, group=None):
+    """fn() (a whole clip through ``model``) under the split-half range guard (include/v2ce_hip.h,
+    VERDICT r1 #7): if a convolution reported a guard bound above the limit -- activations whose dynamic
+    range one scale per tensor does not cover at the 1e-5 bar -- the spectral-norm state is rewound and
+    fn() runs again on the exact-f32 kernels; the result is then that of precision='f32'.  The decision
+    is the maximum over the ranks of ``group`` (every rank must take the same branch: fn may contain
+    collectives).  Models without the guard (test stand-ins) run fn() once."""
+    if not hasattr(model, "range_guard_value") or getattr(model, "precision", None) != "f16x2":
+        return fn()
+    snap = model.sn_snapshot()
+    model.range_guard_value()                              # clear what earlier calls left
+    out = fn()
+    worst = model.range_guard_value()
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and \
+            torch.distributed.get_world_size(group) > 1:
+        dev = next(model.parameters()).device
+        t = torch.tensor([worst], dtype=torch.float32, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=group)
+        worst = float(t.item())
+    if worst <= model.RANGE_GUARD_LIMIT:
+        return out
+    import logging
+    logging.getLogger("V2CE").warning(
+        f"split-half range guard: bound {worst:.3e} > {model.RANGE_GUARD_LIMIT:.1e}; repeating the clip on the exact-f32 kernels")
+    del out
+    model.sn_restore(snap)
+    with model.exact_f32():
+        return fn()
+
+
 def sequence_plan(frame_count: int, seq_len: int = 16):
     """v2ce.py:149-154 -> (sequence_num, mode, starting_indexes)."""
     if frame_count < seq_len + 1:
@@ -135,7 +165,13 @@ def video_to_voxels(model, frames: Optional[np.ndarray] = None, read_frames=None
                     infer_type: str = "center", seq_len: int = 16, width: int = 346, height: int = 260,
                     batch_size: int = 1, device="cuda") -> torch.Tensor:
     """v2ce.py:131-209.  `frames` [N,H,W] uint8, or `read_frames(range)` + `frame_count` for a
-    streaming source.  Returns the merged voxel grid [N-1,2,10,height,W'] on the device."""
+    streaming source (re-readable: the range guard may run the clip twice, see run_guarded).  Returns the
+    merged voxel grid [N-1,2,10,height,W'] on the device."""
+    return run_guarded(model, lambda: _video_to_voxels(model, frames, read_frames, frame_count, infer_type,
+                                                       seq_len, width, height, batch_size, device))
+
+
+def _video_to_voxels(model, frames, read_frames, frame_count, infer_type, seq_len, width, height, batch_size, device):
     assert frames is not None or (read_frames is not None and frame_count is not None)
     if frames is not None:
         frame_count = len(frames)

@@ -201,17 +201,27 @@ def run(frames: np.ndarray, model, infer_type="center", seq_len=16, width=346, h
     if rng == "torch":
         if world > 1:
             raise NotImplementedError("rng='torch' replays the reference's single-process draw order; run it on one GPU")
-        vox = glue.video_to_voxels(model, frames=frames, infer_type=infer_type, seq_len=seq_len,
-                                   width=width, height=height, batch_size=batch_size, device=device)
-        if event_frames is not None:
-            from .pipeline import event_frame_sums
-            event_frames.append((0, event_frame_sums(vox)))
-        packed, _ = events_from_voxels(vox, fps, stage2_batch_size, seed, rng)
-        return download_events(packed)
-    return pipeline.run_clip(frames, model, infer_type=infer_type, seq_len=seq_len, width=width, height=height,
-                             batch_size=batch_size, fps=fps, seed=seed, device=device, stage2=stage2,
-                             dtype=EVENT_DTYPE, rank=rank, world=world,
-                             event_frames=event_frames if world == 1 else None)
+
+        def clip():
+            vox = glue.video_to_voxels(model, frames=frames, infer_type=infer_type, seq_len=seq_len,
+                                       width=width, height=height, batch_size=batch_size, device=device)
+            if event_frames is not None:
+                from .pipeline import event_frame_sums
+                del event_frames[:]
+                event_frames.append((0, event_frame_sums(vox)))
+            packed, _ = events_from_voxels(vox, fps, stage2_batch_size, seed, rng)
+            return download_events(packed)
+    else:
+        def clip():
+            if event_frames is not None:
+                del event_frames[:]
+            return pipeline.run_clip(frames, model, infer_type=infer_type, seq_len=seq_len, width=width, height=height,
+                                     batch_size=batch_size, fps=fps, seed=seed, device=device, stage2=stage2,
+                                     dtype=EVENT_DTYPE, rank=rank, world=world,
+                                     event_frames=event_frames if world == 1 else None)
+    # the split-half convolutions report a dynamic-range bound; beyond its limit the clip is repeated on
+    # the exact-f32 kernels (glue.run_guarded)
+    return glue.run_guarded(model, clip)
 
 
 def main(argv=None):

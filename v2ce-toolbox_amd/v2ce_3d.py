@@ -237,7 +237,9 @@ class V2ce3d(nn.Module):
         P["sigma"] = torch.empty(1, dtype=torch.float32, device=dev)
         # one max-|y| slot per conv launch of a forward pass (split-half path: the consumer derives its
         # power-of-two activation pre-scale from the producer's slot, all on the device)
-        P["absmax"] = torch.zeros(64, dtype=torch.float32, device=dev)
+        # (+ the launch's range-guard value in the second float, include/v2ce_hip.h)
+        P["absmax"] = torch.zeros((64, 2), dtype=torch.float32, device=dev)
+        P["guard"] = torch.zeros(1, dtype=torch.float32, device=dev)     # max guard value since the last read
         self._prep = P
 
     def _split(self, cin, cout, ksize=3, stride=1) -> bool:
@@ -283,7 +285,7 @@ class V2ce3d(nn.Module):
                          precision=hip.PRECISION_F16X2 if split else hip.PRECISION_F32)
         a0 = a1 = ay = None
         if track or split:         # range tracking for the split-half consumers (device side only)
-            ay = y.absmax = self._prep["absmax"][self._slot:self._slot + 1]
+            ay = y.absmax = self._prep["absmax"][self._slot]              # [max |y|, range-guard value]
             self._slot += 1
             if split:          # untracked inputs (None) select the kernel's fixed pre-scale
                 a0 = getattr(x0, "absmax", None)
@@ -298,7 +300,7 @@ class V2ce3d(nn.Module):
             hip.check(hip.lib().v2ce_conv3d_fwd_pred(ctypes.byref(d), x0.data_ptr(), hip.ptr(x1),
                                                      hip.ptr(hmap), hip.ptr(wmap), w_packed.data_ptr(),
                                                      scale.data_ptr(), shift.data_ptr(), hip.ptr(residual),
-                                                     None, hip.ptr(a0), hip.ptr(a1), None,
+                                                     None, hip.ptr(a0), hip.ptr(a1), hip.ptr(ay),
                                                      tab.data_ptr(), pbias.data_ptr(), pcout, y.data_ptr(),
                                                      hip.stream_ptr(x0.device)),
                       "v2ce_conv3d_fwd_pred")
@@ -451,6 +453,49 @@ class V2ce3d(nn.Module):
         else:
             out = self._conv(h, None, *P["pred"], self.out_channels, 1, 1, hip.ACT_RELU)   # :374
         self.calls += 1
+        if self.precision == "f16x2":
+            torch.maximum(P["guard"], P["absmax"][:, 1].max().reshape(1), out=P["guard"])
         if return_intermediates:
             return out, inter
         return out
+
+    # ---- range guard of the split-half path (include/v2ce_hip.h "Range guard") ---------------
+    RANGE_GUARD_LIMIT = 2.5e-6
+
+    def range_guard_value(self, reset: bool = True) -> float:
+        """Largest per-launch guard bound E reported by the split-half convolutions since the last reset
+        (synchronises).  E <= RANGE_GUARD_LIMIT: every layer's output is provably within that distance
+        of the exact-f32 kernels'.  Larger: the activations' dynamic range is beyond what one scale per
+        tensor covers -- repeat on ``exact_f32()`` (glue.run_guarded does)."""
+        if self._prep is None or self.precision != "f16x2":
+            return 0.0
+        v = float(self._prep["guard"].item())
+        if reset:
+            self._prep["guard"].zero_()
+        return v
+
+    def sn_snapshot(self):
+        """The state a forward call mutates (spectral-norm u / v of the 12 SN layers, call counter)."""
+        st = [(p, p.detach().clone()) for n, p in self.named_parameters() if n.endswith(("weight_u", "weight_v"))]
+        return st, self.calls
+
+    def sn_restore(self, snap):
+        st, calls = snap
+        with torch.no_grad():
+            for p, v in st:
+                p.copy_(v)
+        self.calls = calls
+
+    def exact_f32(self):
+        """Context manager: run on the exact-f32 kernels (precision 'f32'), then switch back."""
+        model = self
+
+        class _Exact:
+            def __enter__(self):
+                self.prev = model.precision
+                model.precision, model._prep = "f32", None
+
+            def __exit__(self, *exc):
+                model.precision, model._prep = self.prev, None
+                return False
+        return _Exact()
