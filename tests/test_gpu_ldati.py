@@ -236,3 +236,23 @@ def test_full_size_properties():
     n0 = int(ev.frame_counts[0])
     _, ots, ox, oy, op = O.emit_soa(vox[:1], seed=5)
     assert np.array_equal(ts[:n0], ots) and np.array_equal(x[:n0], ox) and np.array_equal(p[:n0], op)
+
+
+def test_sparse_tile_kernel_equals_per_bin_kernel(monkeypatch):
+    """The one-pass sparse tile kernel (tiles with <= 4096 events over the nine bins) and the per-bin
+    tile kernel are two implementations of the same pass: same bytes with the sparse kernel disabled
+    (V2CE_LDATI_NO_SPARSE), on frames that mix empty, sparse and dense tiles, and both equal the oracle."""
+    rng = np.random.default_rng(21)
+    H, W = 96, 160                                               # 8 tiles per polarity plane
+    y = np.zeros((3, 2, 10, H, W), np.float32)
+    y[:, :, :, :40] = np.maximum(0.25 * rng.standard_normal((3, 2, 10, 40, W)), 0).astype(np.float32)   # sparse rows
+    y[:, :, :, 60:80] = (3.0 * rng.random((3, 2, 10, 20, W))).astype(np.float32)                        # dense rows
+    want = O.emit_soa(y, fps=30, seed=9, frame_base=2)
+    outs = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("V2CE_LDATI_NO_SPARSE", "1")
+        ev = hip_events(y, seed=9, frame_base=2)
+        soa_equal(ev, *want)
+        outs.append(ev.packed().cpu().numpy().tobytes())
+    assert outs[0] == outs[1]

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Phase shares of the LDATI tile pass / bucket sort from in-kernel s_memtime stamps (diagnostic
 library `make -C v2ce-toolbox_amd/csrc libv2ce_hip_stamp.so`; shares only, never quote its run time).
-    V2CE_HIP_LIB=v2ce-toolbox_amd/csrc/libv2ce_hip_stamp.so python tools/ldati_stamps.py [stress|sparse]"""
+    V2CE_HIP_LIB=v2ce-toolbox_amd/csrc/libv2ce_hip_stamp.so python tools/ldati_stamps.py [stress|sparse|e2e]"""
 import ctypes
 import os
 import sys
@@ -14,7 +14,17 @@ from v2ce_toolbox_amd import hip, synth                         # noqa: E402
 from v2ce_toolbox_amd.LDATI import ldati_device                  # noqa: E402
 
 regime = sys.argv[1] if len(sys.argv) > 1 else "stress"
-vox = torch.from_numpy(synth.synthetic_voxels(24, 260, 346, seed=7, regime=regime)).cuda()
+if regime == "e2e":        # the voxels bench.py's e2e step hands to LDATI: V2ce3d on 4 synthetic sequences
+    from oracle import glue as OG
+    from v2ce_toolbox_amd.v2ce_3d import V2ce3d
+    m = V2ce3d()
+    m.load_state_dict(synth.make_state_dict(0), strict=True)
+    m = m.eval().cuda()
+    x = np.stack([OG.preprocess(synth.synthetic_frames(17, 260, 346, seed=1000 + s)) for s in range(4)])
+    vox = m(torch.from_numpy(x).cuda()).view(64, 2, 10, 260, 346).contiguous()
+    del m
+else:
+    vox = torch.from_numpy(synth.synthetic_voxels(24, 260, 346, seed=7, regime=regime)).cuda()
 L = hip.lib()
 buf = (ctypes.c_ulonglong * 32)()
 for _ in range(2):

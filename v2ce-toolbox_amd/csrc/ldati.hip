@@ -51,6 +51,9 @@ constexpr int kMaxNB = 512;           // coarse buckets per segment
 constexpr int kMaxShift = 8;          // log2 of the widest coarse bucket
 constexpr int kMaxSpanKeys = 128;     // timestamps a sort group spans at most (its histogram has 4x as many bins)
 constexpr int kCapTile = 15360;       // events of one (tile, bin) the tile pass can hold in LDS
+constexpr int kSparseCap = 4096;      // events of one tile over all nine bins the sparse tile kernel holds
+constexpr int kSparseThreads = 512;
+constexpr size_t kSparseLds = (size_t)(2 * kSparseCap + kSparseThreads * 5 + 34) * 4 + 9 * 8;
 constexpr int kSortThreads = 256;
 constexpr int kSortWaves = kSortThreads / 64;
 
@@ -87,6 +90,8 @@ struct LdatiParams {
     int capA, cap2;               // LDS capacities (records) of the tile pass / the bucket sort
     int tbits;                    // binary-search steps over the tiles of a frame
     const unsigned *tile_off;     // [B][T][9] exclusive prefix of the tile counts inside the segment
+    const unsigned *tc;           // [B][T][9] the tile counts themselves
+    int sparse_cap;               // tiles with at most this many events (all nine bins) go to the sparse tile kernel; 0 = none
     unsigned short *roff;         // [B*9][T][NB+1] per tile: exclusive prefix of its bucket counts (last = tile total <= kCapTile)
     unsigned *bofs;               // [B*9][NB+1] exclusive prefix of the bucket totals inside the segment
     unsigned *groups;             // [B*9][NB] sort groups: first bucket | (end bucket << 16)
@@ -501,54 +506,64 @@ __global__ __launch_bounds__(kCountThreads) void ldati_count_tiles_kernel(
     }
 }
 
-// One workgroup: tile counts -> exclusive tile offsets inside each segment; segment counts ->
-// exclusive segment offsets; stats = {max_n (set by the count kernel), largest (tile, bin) count,
-// largest segment, total}.
+// Tile counts -> exclusive tile offsets inside each segment, one wave per segment (the segment count
+// lands in seg_offsets[seg]; the largest (tile, bin) and segment counts in stats[1], stats[2]).
 __global__ __launch_bounds__(256) void ldati_tile_scan_kernel(const unsigned *__restrict__ tc, int B,
                                                               int T, unsigned *__restrict__ tile_off,
                                                               long long *seg_offsets,
                                                               unsigned long long *stats) {
-    __shared__ long long part[256];
-    __shared__ unsigned long long mx_tile, mx_seg;
-    const int t = threadIdx.x, n = B * 9;
-    if (t == 0) { mx_tile = 0; mx_seg = 0; }
-    __syncthreads();
-    // phase 1: per segment, scan over the tiles (the segment count lands in seg_offsets[seg] for now)
-    unsigned long long my_tile = 0, my_seg = 0;
-    for (int seg = t; seg < n; seg += 256) {
-        const int b = seg / 9, c = seg - b * 9;
-        unsigned run = 0;
-        for (int tt = 0; tt < T; ++tt) {
-            const long long i = ((long long)b * T + tt) * 9 + c;
-            const unsigned v = tc[i];
-            tile_off[i] = run;
-            run += v;
-            my_tile = v > my_tile ? v : my_tile;
-        }
-        seg_offsets[seg] = run;
-        my_seg = run > my_seg ? run : my_seg;
+    const int lane = threadIdx.x & 63, seg = blockIdx.x * 4 + (threadIdx.x >> 6), n = B * 9;
+    if (seg >= n) return;
+    const int b = seg / 9, c = seg - b * 9;
+    unsigned run = 0, mx = 0;
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        const int tt = t0 + lane;
+        const long long i = ((long long)b * T + tt) * 9 + c;
+        const unsigned v = tt < T ? tc[i] : 0u;
+        const unsigned incl = wave_incl_scan(v, lane);
+        if (tt < T) tile_off[i] = run + incl - v;
+        run += __shfl(incl, 63);
+        mx = v > mx ? v : mx;
     }
-    atomicMax(&mx_tile, my_tile);
-    atomicMax(&mx_seg, my_seg);
-    __syncthreads();
-    // phase 2: exclusive scan of the n segment counts
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+        const unsigned m = __shfl_xor(mx, o);
+        mx = m > mx ? m : mx;
+    }
+    if (lane == 0) {
+        seg_offsets[seg] = run;
+        atomicMax(&stats[1], (unsigned long long)mx);
+        atomicMax(&stats[2], (unsigned long long)run);
+    }
+}
+
+// One workgroup: segment counts -> exclusive segment offsets (seg_offsets[n] = stats[3] = total).
+__global__ __launch_bounds__(256) void ldati_seg_scan_kernel(int n, long long *seg_offsets, unsigned long long *stats) {
+    __shared__ long long part[256];
+    const int t = threadIdx.x;
     const int per = (n + 255) / 256;
     const int lo = t * per, hi = (lo + per < n) ? lo + per : n;
     long long s = 0;
     for (int i = lo; i < hi; ++i) s += seg_offsets[i];
     part[t] = s;
     __syncthreads();
-    if (t == 0) {
-        long long run = 0;
-        for (int i = 0; i < 256; ++i) {
-            const long long v = part[i];
-            part[i] = run;
-            run += v;
+    if (t < 64) {                                   // 256 partials: four per lane of one wave
+        long long v[4], sum = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = part[4 * t + j]; sum += v[j]; }
+        long long incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const long long u = __shfl_up(incl, o);
+            if (t >= o) incl += u;
         }
-        seg_offsets[n] = run;
-        stats[1] = mx_tile;
-        stats[2] = mx_seg;
-        stats[3] = (unsigned long long)run;
+        long long run = incl - sum;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { part[4 * t + j] = run; run += v[j]; }
+        if (t == 63) {
+            seg_offsets[n] = incl;
+            stats[3] = (unsigned long long)incl;
+        }
     }
     __syncthreads();
     long long run = part[t];
@@ -774,6 +789,13 @@ template <int NT, int PPT, bool BIDIR>
 __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
     static_assert(NT * PPT == kTilePix, "tile geometry");
     const int t = blockIdx.x, b = blockIdx.y;
+    if (P.sparse_cap) {                                 // the sparse tile kernel owns the lightly populated tiles
+        const unsigned *tcr = P.tc + ((long long)b * P.T + t) * 9;
+        unsigned ntot = 0;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) ntot += tcr[c];
+        if (ntot <= (unsigned)P.sparse_cap) return;
+    }
     const int pidx = t < P.tpp ? 1 : 0;
     const int x0 = (t < P.tpp ? t : t - P.tpp) * kTilePix;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1026,6 +1048,242 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
     STAMP_FLUSH(0, 10);
 }
 
+// ---------------------------------------------------------------------------------------------
+// sparse tile pass: the same job as ldati_tile_pass_kernel for tiles with at most kSparseCap events
+// over ALL NINE bins (real UNet output: ~2000 per 2048-pixel tile; the per-bin kernel spends its
+// time in ~60 barriers and 18 workgroup scans for ~230 records per bin there).  One pass, 8 barriers:
+//   1. all ten voxels of the thread's four pixels (one float4 per plane), relocation in registers
+//   2. single events and multi-event (pixel, bin) pairs appended to two LDS lists (from both ends of
+//      one 32 KB area), re-read densely: every lane computes a timestamp
+//   3. records (bin-major combined key | multi | local pixel) appended unordered; u16 histogram
+//      over the 9 * NB (bin, coarse bucket) cells by packed LDS atomics
+//   4. in-place exclusive scan of the histogram; placement by a second packed atomic
+//   5. inside each cell (mostly 0-2 records) the records are ordered by local pixel: the order the
+//      bucket sort's stable ranks need (equal (timestamp, category) => ascending pixel)
+//   6. nine coalesced runs + nine rows of the run table, exactly what the per-bin kernel writes.
+// LDS: list area / records S + O (32 KB) | packed histogram (10 KB) | scalars.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kSparseThreads) void ldati_tile_sparse_kernel(LdatiParams P) {
+    constexpr int NT = kSparseThreads, NW = NT / 64, PPT = kTilePix / NT;
+    constexpr int HWORDS = NT * 5;                       // 10 cells per thread >= 9 * kMaxNB + 1
+    const int t = blockIdx.x, b = blockIdx.y;
+    const unsigned *tcr = P.tc + ((long long)b * P.T + t) * 9;
+    unsigned ntot = 0;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) ntot += tcr[c];
+    if (ntot > (unsigned)P.sparse_cap) return;          // dense tile: ldati_tile_pass_kernel handles it
+    const int pidx = t < P.tpp ? 1 : 0;
+    const int x0 = (t < P.tpp ? t : t - P.tpp) * kTilePix;
+    const int tid = threadIdx.x;
+
+    unsigned *S = reinterpret_cast<unsigned *>(tile_smem);          // [kSparseCap] records (unordered, later final)
+    unsigned *O = S + kSparseCap;                                   // [kSparseCap] records placed by cell
+    uint2 *SL = reinterpret_cast<uint2 *>(S);                       // singles list, grows up: {debt bits, local | c << 11}
+    unsigned *MPtop = S + 2 * kSparseCap;                           // multi list, grows down: {info, k, bb}
+    unsigned *hist = S + 2 * kSparseCap;                            // [HWORDS] two u16 cells per word
+    unsigned *misc = hist + HWORDS;                                 // cursors, scan partials, bin starts, per-bin scalars
+    unsigned *cur = misc;                                           // [0] singles, [1] multi pairs, [2] records
+    unsigned *part = misc + 4;                                      // [NW + 1]
+    unsigned *binstart = part + 10;                                 // [10]
+    float *offt_s = reinterpret_cast<float *>(binstart + 10);       // [9]
+    long long *kbase_s = reinterpret_cast<long long *>(offt_s + 10);   // [9], 8-byte aligned (kSparseLds)
+    static_assert(NW + 1 <= 10 && ((2 * kSparseCap + HWORDS + 34) & 1) == 0, "sparse LDS map");
+    long long dst_off[9];                                           // where the tile's nine runs go
+#pragma unroll
+    for (int c = 0; c < 9; ++c)
+        dst_off[c] = P.seg_offsets[b * 9 + c] + (long long)P.tile_off[((long long)b * P.T + t) * 9 + c];
+
+    const float *plane0 = P.vox + (long long)(b * 2 + pidx) * 10 * P.HW;
+    const unsigned frame = (unsigned)(P.frame_base + b);
+    const int lpx0 = tid * PPT;
+    const unsigned NKS = (unsigned)P.NB << P.shift;                 // key stride between bins (>= NK)
+
+    // ---- 1: loads (all in flight at once), then the LDS tables are cleared under them
+    float yv[PPT][10];
+    {
+        const int px = x0 + lpx0;
+        if ((P.HW & 3) == 0 && px + PPT <= P.HW) {
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                const float4 v = *reinterpret_cast<const float4 *>(plane0 + (long long)i * P.HW + px);
+                yv[0][i] = v.x; yv[1][i] = v.y; yv[2][i] = v.z; yv[3][i] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < PPT; ++q)
+#pragma unroll
+                for (int i = 0; i < 10; ++i) yv[q][i] = (px + q < P.HW) ? plane0[(long long)i * P.HW + px + q] : 0.0f;
+        }
+    }
+    for (int i = tid; i < HWORDS; i += NT) hist[i] = 0;
+    if (tid < 4) cur[tid] = 0;
+    if (tid < 9) { offt_s[tid] = P.offt[tid]; kbase_s[tid] = P.kbase[tid]; }
+    __syncthreads();
+
+    // ---- 2a: classify; append to the lists
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+        int nn[9];
+        float td[9];
+        relocate_all(yv[q], P.bidir != 0, nn, td);
+        const unsigned local = (unsigned)(lpx0 + q);
+        const bool valid = x0 + lpx0 + q < P.HW;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            const int n = valid ? nn[c] : 0;
+            if (n == 1) {
+                const unsigned i = atomicAdd(&cur[0], 1u);
+                SL[i] = make_uint2(__float_as_uint(td[c]), local | ((unsigned)c << kLocalBits));
+            } else if (n >= 2 && P.strategy != V2CE_STRATEGY_NONE) {
+                float k, bb;
+                if (P.kbb) {
+                    const float2 kq = P.kbb[((long long)(b * 2 + pidx) * 9 + c) * P.HW + (x0 + lpx0 + q)];
+                    k = kq.x; bb = kq.y;
+                } else {
+                    slope_params(c > 0 ? nn[c - 1] : 0, n, c < 8 ? nn[c + 1] : 0, c, P, k, bb);
+                }
+                const unsigned m = atomicAdd(&cur[1], 1u);
+                unsigned *e = MPtop - 3 * (m + 1);
+                e[0] = local | ((unsigned)c << kLocalBits) | ((unsigned)n << 15);
+                e[1] = __float_as_uint(k);
+                e[2] = __float_as_uint(bb);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 2b: the lists move to registers (they share their LDS with the records)
+    const unsigned Ns = cur[0], Nmp = cur[1];
+    constexpr int SPT = kSparseCap / NT, MPT = kSparseCap / 2 / NT;    // most list entries per thread
+    uint2 sl[SPT];
+    unsigned mi[MPT];
+    float mk[MPT], mb[MPT];
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) sl[j] = (unsigned)(tid + j * NT) < Ns ? SL[tid + j * NT] : make_uint2(0u, 0u);
+#pragma unroll
+    for (int j = 0; j < MPT; ++j) {
+        const unsigned m = (unsigned)(tid + j * NT);
+        const unsigned *e = MPtop - 3 * (m + 1);
+        mi[j] = m < Nmp ? e[0] : 0u;
+        mk[j] = m < Nmp ? __uint_as_float(e[1]) : 0.0f;
+        mb[j] = m < Nmp ? __uint_as_float(e[2]) : 0.0f;
+    }
+    __syncthreads();
+    // ---- 3: timestamps -> records, cell histogram
+    auto put = [&](unsigned idx, unsigned c, unsigned key, unsigned multi, unsigned local) {
+        const unsigned ck = c * NKS + key;
+        const unsigned g = ck >> P.shift;
+        atomicAdd(&hist[g >> 1], 1u << ((g & 1u) * 16u));
+        S[idx] = (ck << 12) | (multi << kLocalBits) | local;
+    };
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) {
+        if ((unsigned)(tid + j * NT) < Ns) {
+            const unsigned c = sl[j].y >> kLocalBits;
+            const long long Tq = single_ts(__uint_as_float(sl[j].x), P.fps, offt_s[c]);
+            const unsigned key = (unsigned)key_of(Tq, kbase_s[c], P.NK);
+            put(atomicAdd(&cur[2], 1u), c, key, 0u, sl[j].y & (kTilePix - 1));
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < MPT; ++j) {
+        if ((unsigned)(tid + j * NT) < Nmp) {
+            const unsigned local = mi[j] & (kTilePix - 1), c = (mi[j] >> kLocalBits) & 15u, n = mi[j] >> 15;
+            const unsigned px = (unsigned)x0 + local;
+            const unsigned i0 = atomicAdd(&cur[2], n);
+            const float offt = offt_s[c];
+            const long long kb64 = kbase_s[c];
+            for (unsigned jb = 0; 4u * jb < n; ++jb) {
+                const unsigned left = n - 4u * jb, cnt = left < 4u ? left : 4u;
+                float u[4];
+                if (P.rng_mode == V2CE_RNG_REPLAY) {
+                    const long long ub = (((long long)(b * 2 + pidx) * 9 + c) * P.HW + px) * P.replay_max_n;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const int jj = (int)(4u * jb) + s;
+                        u[s] = ((unsigned)s < cnt && jj < P.replay_max_n) ? P.uniforms[ub + jj] : 0.0f;
+                    }
+                } else {
+                    unsigned o[4];
+                    philox4(P.seed, px, jb, (unsigned)pidx * 9u + c, frame, o);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) u[s] = u24(o[s]);
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    if ((unsigned)s < cnt) {
+                        const unsigned key = P.ts32 ? multi_key(mk[j], mb[j], u[s], offt, (int)kb64, P)
+                                                    : (unsigned)key_of(multi_ts(mk[j], mb[j], u[s], offt, P), kb64, P.NK);
+                        put(i0 + 4u * jb + s, c, key, 1u, local);
+                    }
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned N = cur[2];
+    if (N != ntot) {                                     // cannot happen: the count kernel saw the same voxels
+        if (tid == 0) atomicExch(reinterpret_cast<unsigned *>(P.status), 3u);
+        return;
+    }
+    // ---- 4: exclusive scan of the cells, in place (thread: cells 10 tid .. 10 tid + 9)
+    {
+        unsigned w[5], cnt[10], run = 0;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) w[j] = hist[tid * 5 + j];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            cnt[j] = (w[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+            const unsigned v = cnt[j];
+            cnt[j] = run;
+            run += v;
+        }
+        unsigned tot;
+        const unsigned ex = block_excl_scan<NW>(run, part, &tot);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) hist[tid * 5 + j] = (cnt[2 * j] + ex) | ((cnt[2 * j + 1] + ex) << 16);
+    }
+    __syncthreads();
+    auto cell = [&](unsigned g) { return (hist[g >> 1] >> ((g & 1u) * 16u)) & 0xFFFFu; };
+    // placement: the cell's word advances from its start to its end
+    for (unsigned i = tid; i < N; i += NT) {
+        const unsigned rec = S[i];
+        const unsigned g = rec >> (12 + P.shift);
+        const unsigned old = atomicAdd(&hist[g >> 1], 1u << ((g & 1u) * 16u));
+        O[(old >> ((g & 1u) * 16u)) & 0xFFFFu] = rec;
+    }
+    __syncthreads();
+    if (tid < 10) binstart[tid] = tid == 9 ? N : (tid ? cell((unsigned)tid * (unsigned)P.NB - 1u) : 0u);
+    // ---- 5: order inside the cells: by local pixel (ties: by arrival, any fixed order is right)
+    for (unsigned i = tid; i < N; i += NT) {
+        const unsigned rec = O[i];
+        const unsigned g = rec >> (12 + P.shift);
+        const unsigned lo = g ? cell(g - 1) : 0u, hi = cell(g);
+        unsigned r = lo;
+        if (hi - lo > 1u) {
+            const unsigned me = rec & (kTilePix - 1);
+            for (unsigned j = lo; j < hi; ++j) {
+                const unsigned o = O[j] & (kTilePix - 1);
+                r += (o < me || (o == me && j < i)) ? 1u : 0u;
+            }
+        }
+        S[r] = rec;
+    }
+    __syncthreads();
+    // ---- 6: nine runs of records, nine rows of the run table
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+        const unsigned bs = binstart[c], Nc = binstart[c + 1] - bs;
+        const unsigned strip = ((unsigned)c * NKS) << 12;
+        unsigned *dst = P.temp + dst_off[c];
+        for (unsigned i = tid; i < Nc; i += NT) dst[i] = S[bs + i] - strip;
+        unsigned short *row = P.roff + ((long long)(b * 9 + c) * P.T + t) * (P.NB + 1);
+        for (int k = tid; k < P.NB; k += NT) {
+            const unsigned g = (unsigned)c * (unsigned)P.NB + (unsigned)k;
+            row[k] = (unsigned short)((g ? cell(g - 1) : 0u) - bs);
+        }
+        if (tid == 0) row[P.NB] = (unsigned short)Nc;
+    }
+}
+
 // per segment: bucket totals over the tiles, their exclusive prefix, and the SORT GROUPS: maximal
 // runs of consecutive coarse buckets with at most cap2 records and at most `span` buckets (so that the
 // group's (key, category) histogram fits the sort workgroup).  Timestamps crowd towards the end of a
@@ -1033,46 +1291,60 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
 // crosses 1), so equal-width buckets differ by 20x in a segment; the groups even that out.  A single
 // coarse bucket beyond cap2 (degenerate ties: constant images; bidirectional relocation puts every
 // single of bin 8 with y[9] = 0 at the same microsecond) goes to the big-bucket kernel's list.
-__global__ __launch_bounds__(256) void ldati_bucket_scan_kernel(LdatiParams P) {
-    __shared__ unsigned part[8];
-    __shared__ unsigned tot_s[kMaxNB];
+__global__ __launch_bounds__(512) void ldati_bucket_scan_kernel(LdatiParams P) {
+    __shared__ unsigned part[9];
+    __shared__ unsigned pre[kMaxNB + 2];               // sums of the tiles' run starts, then the bucket prefix
     const int seg = blockIdx.x, t = threadIdx.x;
     const unsigned short *tab = P.roff + (long long)seg * P.T * (P.NB + 1);
     unsigned *bofs = P.bofs + (long long)seg * (P.NB + 1);
-    unsigned carry = 0;
-    for (int b0 = 0; b0 < P.NB; b0 += 256) {            // NB <= 512: at most two rounds
-        const int i = b0 + t;
+    // a bucket's total = sum over the tiles of (start of the next bucket - its start) = difference of the
+    // column sums: one load per tile and thread (NB + 1 <= 513 columns, 512 threads + one straggler)
+    for (int i = t; i <= P.NB; i += 512) {
         unsigned s = 0;
-        if (i < P.NB)
-            for (int tt = 0; tt < P.T; ++tt) {
-                const unsigned short *row = tab + (long long)tt * (P.NB + 1);
-                s += (unsigned)row[i + 1] - (unsigned)row[i];
-            }
-        unsigned tot;
-        const unsigned ex = block_excl_scan<4>(s, part, &tot);
-        if (i < P.NB) {
-            tot_s[i] = s;
-            bofs[i] = carry + ex;
-        }
-        carry += tot;
-        __syncthreads();
+#pragma unroll 8
+        for (int tt = 0; tt < P.T; ++tt) s += (unsigned)tab[(long long)tt * (P.NB + 1) + i];
+        pre[i] = s;
     }
+    __syncthreads();
+    const unsigned tot_i = t < P.NB ? pre[t + 1] - pre[t] : 0u;
+    unsigned total;
+    const unsigned ex = block_excl_scan<8>(tot_i, part, &total);      // barriers inside: pre[] is free afterwards
+    if (t < P.NB) bofs[t] = ex;
+    if (t == 0) bofs[P.NB] = total;
+    __syncthreads();
+    if (t < P.NB) pre[t] = ex;
+    if (t == 0) pre[P.NB] = total;
+    __syncthreads();
     if (t == 0) {
-        bofs[P.NB] = carry;
+        // greedy groups: from `start`, the farthest end with <= cap2 records and <= span buckets (binary
+        // search on the prefix); a bucket beyond cap2 on its own goes to the big-bucket list
         unsigned *grp = P.groups + (long long)seg * P.NB;
         unsigned ng = 0;
         int i = 0;
         while (i < P.NB) {
-            if (tot_s[i] == 0) { ++i; continue; }
-            if (tot_s[i] > (unsigned)P.cap2) {
+            const unsigned base = pre[i];
+            if (base == total) break;                                  // nothing but empty buckets left
+            if (pre[i + 1] == base) {                                  // skip a run of empty buckets
+                int lo = i + 1, hi = P.NB;                             // first j > i with pre[j] > base
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (pre[mid] > base) hi = mid; else lo = mid + 1;
+                }
+                i = lo - 1;
+                continue;
+            }
+            if (pre[i + 1] - base > (unsigned)P.cap2) {
                 P.big_list[atomicAdd(P.nbig, 1u)] = ((unsigned)seg << 16) | (unsigned)i;
                 ++i;
                 continue;
             }
-            const int start = i;
-            unsigned acc = 0;
-            while (i < P.NB && i - start < P.span && acc + tot_s[i] <= (unsigned)P.cap2) acc += tot_s[i++];
-            grp[ng++] = (unsigned)start | ((unsigned)i << 16);
+            int lo = i + 1, hi = i + P.span < P.NB ? i + P.span : P.NB;   // largest e in [lo, hi] with pre[e] - base <= cap2
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (pre[mid] - base <= (unsigned)P.cap2) lo = mid; else hi = mid - 1;
+            }
+            grp[ng++] = (unsigned)i | ((unsigned)lo << 16);
+            i = lo;
         }
         P.ngroups[seg] = ng;
         P.seg_flag[seg] = 0;
@@ -1738,8 +2010,10 @@ extern "C" int v2ce_ldati_count(const float *vox, int B, int H, int W, const v2c
     const int count_strategy = o.strategy == V2CE_STRATEGY_NONE ? V2CE_STRATEGY_NONE : V2CE_STRATEGY_SLOPE;
     hipLaunchKernelGGL(ldati_count_tiles_kernel, dim3(T, B), dim3(kCountThreads), 0, s, vox, HW, tpp, count_strategy, o.bidir, tc,
                        reinterpret_cast<unsigned long long *>(stats));
-    hipLaunchKernelGGL(ldati_tile_scan_kernel, dim3(1), dim3(256), 0, s, tc, B, T, tile_off,
+    hipLaunchKernelGGL(ldati_tile_scan_kernel, dim3((B * 9 + 3) / 4), dim3(256), 0, s, tc, B, T, tile_off,
                        reinterpret_cast<long long *>(seg_offsets), reinterpret_cast<unsigned long long *>(stats));
+    hipLaunchKernelGGL(ldati_seg_scan_kernel, dim3(1), dim3(256), 0, s, B * 9, reinterpret_cast<long long *>(seg_offsets),
+                       reinterpret_cast<unsigned long long *>(stats));
     V2CE_HIP_CHECK(hipGetLastError());
     return V2CE_OK;
 }
@@ -1824,6 +2098,10 @@ extern "C" int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps
         P.shift = pl.shift; P.NB = pl.NB; P.nb1 = pl.nb1; P.T = pl.T; P.tpp = pl.tpp; P.PB = pl.PB;
         P.capA = pl.capA; P.cap2 = pl.cap2; P.tbits = pl.tbits;
         P.tile_off = static_cast<const unsigned *>(tile_ws) + (size_t)B * pl.T * 9;
+        P.tc = static_cast<const unsigned *>(tile_ws);
+        // lightly populated tiles (all nine bins <= kSparseCap events) take the one-pass sparse kernel; it needs
+        // the nine bins' keys side by side in 20 bits
+        P.sparse_cap = (!L.generic && 9ll * ((long long)pl.NB << pl.shift) < (1ll << 20) && !getenv("V2CE_LDATI_NO_SPARSE")) ? kSparseCap : 0;
         P.span = pl.span;
         P.hist_bins = (4 * (pl.span << pl.shift)) > 4 * kMaxSpanKeys ? (4 * (pl.span << pl.shift)) : 4 * kMaxSpanKeys;
         if (L.kbb_bytes) {
@@ -1885,8 +2163,13 @@ extern "C" int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps
         P.temp = reinterpret_cast<unsigned *>(P.status + 4);
         P.roff = reinterpret_cast<unsigned short *>(P.temp + (size_t)total_events);
         V2CE_HIP_CHECK(hipMemsetAsync(P.status, 0, 4 * sizeof(int), st));
+        if (P.sparse_cap) {
+            V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ldati_tile_sparse_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSparseLds));
+            hipLaunchKernelGGL(ldati_tile_sparse_kernel, dim3(pl.T, B), dim3(kSparseThreads), kSparseLds, st, P);
+        }
         if (int rc = launch_tile_pass()) return rc;
-        hipLaunchKernelGGL(ldati_bucket_scan_kernel, dim3(B * 9), dim3(256), 0, st, P);
+        hipLaunchKernelGGL(ldati_bucket_scan_kernel, dim3(B * 9), dim3(512), 0, st, P);
         {
             auto sort_kernel = packed ? (pl.cap2 > kSortThreads * 8 ? ldati_bucket_sort_kernel<true, 24>
                                                                      : ldati_bucket_sort_kernel<true, 8>)
