@@ -64,7 +64,9 @@ def ref_conv(x0, w, scale, shift, ksize, stride, act, x1=None, up_to=None, resid
 
 CONV_CASES = [
     # B, T, Cin, Cout, H, W, k, s, act, residual
-    (1, 4, 2, 32, 20, 28, 3, 1, 2, False),      # head-like (Cin=2)
+    (1, 4, 2, 32, 20, 28, 3, 1, 2, False),      # head-like (Cin=2): the dedicated head kernel
+    (2, 5, 2, 32, 37, 71, 3, 1, 2, False),      # head kernel, ragged in T, H and W (4 x 4 x 32 boxes), batch 2
+    (1, 3, 2, 32, 9, 33, 3, 1, 1, True),        # head kernel with a residual and ReLU
     (2, 3, 32, 64, 19, 23, 3, 2, 1, False),     # encoder conv1 (stride 2, odd sizes)
     (1, 16, 64, 64, 9, 11, 3, 1, 1, True),      # conv2 + residual + relu
     (1, 2, 32, 64, 19, 23, 1, 2, 0, False),     # strided 1x1 shortcut

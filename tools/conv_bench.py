@@ -63,6 +63,8 @@ def run(name, B=4, T=16, iters=5, tile=(0, 0, 0)):
         yp = torch.empty(B, T, 20, Ho, Wo, device=dev)
         res = torch.randn_like(y)
 
+    res_plain = torch.randn_like(y) if os.environ.get("RES") else None      # RES=1: with a residual (the blocks' conv2)
+
     def call():
         if fuse == "sc":
             hip.check(lib.v2ce_conv3d_fwd_sc(ctypes.byref(d), x0.data_ptr(), hip.ptr(x1), hip.ptr(hmap), hip.ptr(wmap),
@@ -74,7 +76,7 @@ def run(name, B=4, T=16, iters=5, tile=(0, 0, 0)):
                                                tab.data_ptr(), pb.data_ptr(), 20, yp.data_ptr(), hip.stream_ptr()), "conv_pred")
         else:
             hip.check(lib.v2ce_conv3d_fwd(ctypes.byref(d), x0.data_ptr(), hip.ptr(x1), hip.ptr(hmap), hip.ptr(wmap),
-                                          w.data_ptr(), sc.data_ptr(), sh.data_ptr(), None, y.data_ptr(),
+                                          w.data_ptr(), sc.data_ptr(), sh.data_ptr(), hip.ptr(res_plain), y.data_ptr(),
                                           None, None, None, hip.stream_ptr()), "conv")
     call()
     torch.cuda.synchronize()

@@ -983,6 +983,133 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Head convolution (unet_2layer.py:341: Conv3d(2, 32, 3, padding 1) + LeakyReLU): Cin = 2 makes it a
+// K = 54 problem that writes 16x what it reads -- bound by the 32-channel output stream (HBM), not
+// by arithmetic.  The generic exact-f32 kernel stages 2-channel chunks through its channel-chunked
+// LDS pipeline and reaches 1 TB/s of output (0.73 ms per 64 frame-pairs).  Here: lane = one output
+// position holding all 32 channels in 16 packed-f32 accumulators; per tap one ds_read_b32 of the
+// 2-channel halo box (8 KB of LDS) feeds 16 v_pk_fma_f32 whose weights are scalar operands (the
+// 54 x 32 table is read with s_load: it is the same for every lane); a channel's 64 positions leave
+// as one 256-byte store.  ~50 VGPRs, so eight waves per SIMD cover the LDS / store latencies.
+// (A one-pass v_mfma_f32_32x32x2_f32 version -- weights in 27 registers, one ds_read_b32 per MFMA --
+// measured 0.53 ms: 188 registers, two waves per SIMD, every MFMA waits for its LDS operand.)
+// Measured 0.42 ms per 64 frame-pairs; without the stores 0.26, with 2 of the 54 taps 0.37: the 737 MB
+// output stream (32 planes, 256-byte pieces) is the bound at ~2 TB/s.
+// f32 FMA chain over the 54 terms; the order differs from the generic kernel's: 1e-7 relative.
+// ---------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int kHeadTT = 2, kHeadTH = 2, kHeadTW = 64;       // wave = (time step, row), lane = column
+__global__ __launch_bounds__(256) void conv3d_head_kernel(ConvParams P) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int TT = kHeadTT, TH = kHeadTH, TW = kHeadTW;
+    constexpr int HT = TT + 2, HH = TH + 2, HWd = TW + 2, PLANE = HT * HH * HWd;
+    static_assert(TT * TH == 4, "one wave per (time step, row)");
+    __shared__ float halo[2 * PLANE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // workgroups are dealt round-robin over the 8 XCDs: XCD x walks the contiguous range [x n/8, (x+1) n/8)
+    // of boxes, so the boxes that share output cache lines (rows are not 128-byte aligned) and halo
+    // rows meet in one L2
+    int bid = (int)(blockIdx.x & 7) * P.per_xcd + (int)(blockIdx.x >> 3);
+    if (bid >= P.n_spatial) return;
+    const int iw = bid % P.nW; bid /= P.nW;
+    const int ih = bid % P.nH; bid /= P.nH;
+    const int it = bid % P.nT;
+    const int b = bid / P.nT;
+    const int t0 = it * TT, h0 = ih * TH, w0 = iw * TW;
+
+    // halo box: rows of HWd consecutive floats (one row per (channel, ht, hh)), coalesced along W
+    const float *xb = P.x0 + (long long)b * P.T * 2 * (P.H0 * P.W0);
+    for (int row = wave; row < 2 * HT * HH; row += 4) {
+        const int ci = row / (HT * HH), r = row - ci * (HT * HH);
+        const int ht = r / HH, hh = r - ht * HH;
+        const int t = t0 + ht - 1, h = h0 + hh - 1;
+        const bool rok = t >= 0 && t < P.T && h >= 0 && h < P.H0;
+        const float *src = xb + ((long long)(rok ? t : 0) * 2 + ci) * (P.H0 * P.W0) + (rok ? h : 0) * P.W0;
+        for (int ww = lane; ww < HWd; ww += 64) {
+            const int w = w0 + ww - 1;
+            halo[row * HWd + ww] = (rok && w >= 0 && w < P.W0) ? src[w] : 0.0f;
+        }
+    }
+    __syncthreads();
+
+    const int tt = wave / TH, th = wave - tt * TH;
+    const float *hp = halo + (tt * HH + th) * HWd + lane;   // (tt, th, tw = lane) in the halo box
+    f32x2 acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = f32x2{0.0f, 0.0f};
+    // weights [kk = ci * 27 + tap][32]: the same for every lane => SGPR operands of the packed FMAs.  Written
+    // as explicit s_load_dwordx16 pairs, one tap ahead (ping-pong A / B): left to the compiler, the 1728
+    // uniform loads are hoisted to the top and spilled into VGPR lanes (2 v_readlane per FMA).  The waits are
+    // asm statements that "modify" the registers, so no FMA can be scheduled above its wait.
+    typedef float f32x16s __attribute__((ext_vector_type(16)));
+    f32x16s wA0, wA1, wB0, wB1;
+    const float *wptr = P.wp;
+    // (x rides through the load statement so that the FMAs reading it are issued after the loads, not before)
+#define V2CE_SLOAD(lo_, hi_, kk_)                                                                                      \
+    asm volatile("s_load_dwordx16 %0, %3, %4\n\ts_load_dwordx16 %1, %3, %5" : "=&s"(lo_), "=&s"(hi_), "+v"(x)          \
+                 : "s"(wptr), "n"((kk_) * 128), "n"((kk_) * 128 + 64))
+#define V2CE_SWAIT(lo_, hi_) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(lo_), "+s"(hi_))
+    {
+        float x = 0.0f;
+        V2CE_SLOAD(wA0, wA1, 0);
+    }
+    step_loop<0, 54>([&](auto kc) {
+        constexpr int kk = decltype(kc)::value;
+        constexpr int off = (kk / 27) * PLANE + (((kk % 27) / 9) * HH + ((kk % 27) / 3) % 3) * HWd + (kk % 3);
+        float x = hp[off];
+        if constexpr (kk % 2 == 0) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(wA0), "+s"(wA1), "+v"(x));
+            if constexpr (kk + 1 < 54) V2CE_SLOAD(wB0, wB1, kk + 1);
+            const f32x2 xx{x, x};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                acc[j] = __builtin_elementwise_fma(f32x2{wA0[2 * j], wA0[2 * j + 1]}, xx, acc[j]);
+                acc[8 + j] = __builtin_elementwise_fma(f32x2{wA1[2 * j], wA1[2 * j + 1]}, xx, acc[8 + j]);
+            }
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(wB0), "+s"(wB1), "+v"(x));
+            if constexpr (kk + 1 < 54) V2CE_SLOAD(wA0, wA1, kk + 1);
+            const f32x2 xx{x, x};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                acc[j] = __builtin_elementwise_fma(f32x2{wB0[2 * j], wB0[2 * j + 1]}, xx, acc[j]);
+                acc[8 + j] = __builtin_elementwise_fma(f32x2{wB1[2 * j], wB1[2 * j + 1]}, xx, acc[8 + j]);
+            }
+        }
+        // pin the tap's FMAs between its wait and the next tap's loads: instruction selection is free to sink
+        // them below every (volatile) asm otherwise -- and did, spilling all 54 taps' weights
+        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
+                     "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]), "+v"(acc[13]),
+                     "+v"(acc[14]), "+v"(acc[15]));
+    });
+#undef V2CE_SLOAD
+#undef V2CE_SWAIT
+
+    const int t = t0 + tt, h = h0 + th, w = w0 + lane;
+    const bool ok = t < P.T && h < P.Hout && w < P.Wout;
+    const int hw = P.Hout * P.Wout;
+    const long long seq = (long long)P.T * P.Cout * hw;
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(P.y + b * seq, 0, (int)(seq * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(P.res ? P.res + b * seq : P.scale), 0, P.res ? (int)(seq * 4) : 0, 0x00020000);
+    const unsigned vo = ok ? (unsigned)(((t * P.Cout) * hw + h * P.Wout + w) * 4) : kOOB;
+    const float slope = act_slope(P.act);
+    const float *__restrict__ scale = P.scale;
+    const float *__restrict__ shift = P.shift;
+    float ymax = 0.0f;
+#pragma unroll
+    for (int co = 0; co < 32; ++co) {
+        float v = acc[co >> 1][co & 1] * scale[co] + shift[co];
+        if (P.res) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, vo, co * hw * 4, 0));
+        v = apply_act(v, slope);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, vo, co * hw * 4, 0);
+        ymax = fmaxf(ymax, ok ? fabsf(v) : 0.0f);
+    }
+    if (P.y_absmax) absmax_commit(ymax, P.y_absmax);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side: tile choice + dispatch
 // ---------------------------------------------------------------------------------------------
 struct Tile { int tt, th, tw; };
@@ -1326,6 +1453,22 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
         return launch_f16x2_ws<3, 2, 1, 1, 1, 3>(P, d, st);
     }
     V2CE_REQUIRE(d.precision == V2CE_PRECISION_F32, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd: precision %d", d.precision);
+    if (d.ksize == 3 && s == 1 && d.C0 == 2 && d.C1 == 0 && d.Cout == 32 && !hmap && !wmap && d.tile_t <= 0 &&
+        (long long)d.T * d.Cout * d.Hout * d.Wout < (1ll << 29)) {
+        // the UNet's head: dedicated one-pass kernel (conv3d_head_kernel)
+        if (g_name_out) {
+            snprintf(g_name_out, g_name_cap, "conv3d_head_kernel");
+            return V2CE_OK;
+        }
+        P.nT = (d.T + kHeadTT - 1) / kHeadTT; P.nH = (d.Hout + kHeadTH - 1) / kHeadTH; P.nW = (d.Wout + kHeadTW - 1) / kHeadTW;
+        P.n_spatial = d.B * P.nT * P.nH * P.nW;
+        P.per_xcd = (P.n_spatial + 7) / 8;
+        const long long blocks = 8ll * P.per_xcd;
+        V2CE_REQUIRE((long long)d.B * P.nT * P.nH * P.nW < (1ll << 30), V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd(head): too many tiles");
+        hipLaunchKernelGGL(conv3d_head_kernel, dim3((unsigned)blocks), dim3(256), 0, st, P);
+        V2CE_HIP_CHECK(hipGetLastError());
+        return V2CE_OK;
+    }
     // CK per (ksize, stride): sized so 2 workgroups share a CU's 160 KiB of LDS
     // fewer positions per workgroup when the launch would otherwise leave CUs idle
     const long long pos_total = (long long)d.B * d.T * d.Hout * d.Wout;
