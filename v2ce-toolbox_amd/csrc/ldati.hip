@@ -51,7 +51,7 @@ constexpr int kMaxNB = 512;           // coarse buckets per segment
 constexpr int kMaxShift = 8;          // log2 of the widest coarse bucket
 constexpr int kMaxSpanKeys = 128;     // timestamps a sort group spans at most (its histogram has 4x as many bins)
 constexpr int kCapTile = 15360;       // events of one (tile, bin) the tile pass can hold in LDS
-constexpr int kSparseCap = 4096;      // events of one tile over all nine bins the sparse tile kernel holds
+constexpr int kSparseCap = 8192;      // events of one tile over all nine bins the sparse tile kernel holds
 constexpr int kSparseThreads = 512;
 constexpr size_t kSparseLds = (size_t)(2 * kSparseCap + kSparseThreads * 5 + 34) * 4 + 9 * 8;
 constexpr int kSortThreads = 256;
