@@ -85,11 +85,19 @@ def build_parser():
 
 
 def read_image_folder(folder, max_frame_num):
-    """v2ce.py:325-326,172-174: sorted *.png, read as grayscale."""
-    from PIL import Image
+    """v2ce.py:325-326,172-174: sorted *.png, read as grayscale: with ``cv2.imread(p, IMREAD_GRAYSCALE)`` like the
+    reference where OpenCV is installed, else with PIL.  8-bit grayscale files give identical arrays either way;
+    COLOUR files differ by up to +-1 grey level (OpenCV's PNG reader converts with libpng's rgb_to_gray, PIL with
+    the ITU-R 601 integer transform), which the model turns into ~1e-3 voxel differences: convert such folders to
+    grayscale once if bit-reproducibility against a cv2 machine matters."""
     paths = sorted(op.join(folder, f) for f in os.listdir(folder) if f.endswith(".png"))[:max_frame_num]
     logger.info(f"Now processing {folder}, Found {len(paths)} images.")
-    return np.stack([np.asarray(Image.open(p).convert("L")) for p in paths], axis=0)
+    try:
+        import cv2
+        return np.stack([cv2.imread(p, cv2.IMREAD_GRAYSCALE) for p in paths], axis=0)
+    except ImportError:
+        from PIL import Image
+        return np.stack([np.asarray(Image.open(p).convert("L")) for p in paths], axis=0)
 
 
 def read_video(path, max_frame_num):
