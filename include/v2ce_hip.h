@@ -271,6 +271,21 @@ size_t v2ce_sn_workspace_bytes(int rows, int cols);
 int v2ce_sn_power_iter(float *u, float *v, const float *w_bar, int rows, int cols, float *sigma,
                        void *workspace, size_t workspace_bytes, v2ce_stream_t stream);
 
+/* The same for ALL spectral-norm layers of a forward pass in five launches, with the split-half weight
+ * re-pack (v2ce_pack_weights_f16x2 of w_bar / sigma, incl. its {max |w/sigma|, pre-scale} tail) fused behind it:
+ * replaces 12 x (v2ce_sn_power_iter + v2ce_pack_weights_f16x2) = 84 launches.  Results are bit-identical to the
+ * per-layer calls.  layers: HOST array (passed to the kernels by value), at most 16 entries; cols = Cin * k3,
+ * Cin % 16 == 0; packed = buffer of v2ce_pack_weights_f16x2_bytes(rows, Cin, k3). */
+typedef struct {
+    const float *w_bar;   /* [rows][cols] */
+    float *u, *v;         /* [rows], [cols]: updated in place */
+    void *packed;         /* out */
+    int32_t rows, cols, k3, reserved;
+} v2ce_sn_layer;
+size_t v2ce_sn_batch_workspace_bytes(const v2ce_sn_layer *layers, int n);
+int v2ce_sn_update_batch(const v2ce_sn_layer *layers, int n, void *workspace, size_t workspace_bytes,
+                         v2ce_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

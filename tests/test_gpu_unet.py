@@ -521,3 +521,29 @@ def test_precision_report_vs_f64_truth():
     print(json.dumps(rep))
     for k in ("cpu_f32_oracle", "hip_f32", "hip_f16x2"):
         assert rep[k]["max_excess_over_1e-5_bar"] <= TOL, (k, rep[k])
+
+
+def test_batched_spectral_norm_equals_per_layer_calls():
+    """v2ce_sn_update_batch (all 12 layers in five launches) against 12 x (v2ce_sn_power_iter +
+    v2ce_pack_weights_f16x2): same u / v / packed weights / outputs, bit for bit, over three calls."""
+    from v2ce_toolbox_amd.v2ce_3d import V2ce3d
+    x = torch.from_numpy(OG.preprocess(synth.synthetic_frames(17, 32, 48, seed=6))[None]).cuda()
+    ms = []
+    for batched in (True, False):
+        m = V2ce3d(precision="f16x2")
+        m.load_state_dict(synth.make_state_dict(0), strict=True)
+        m = m.eval().to("cuda")
+        m._prepare()
+        assert m._prep["sn_batch"] is not None
+        if not batched:
+            m._prep["sn_batch"] = None
+        ms.append(m)
+    for _ in range(3):
+        ya, yb = ms[0](x), ms[1](x)
+        assert torch.equal(ya, yb)
+    for (n, p), (_, q) in zip(ms[0].named_parameters(), ms[1].named_parameters()):
+        if n.endswith(("weight_u", "weight_v")):
+            assert torch.equal(p, q), n
+    for k in ("res0", "res1", "dec0", "dec3"):
+        for cn in ("conv1_w", "conv2_w"):
+            assert torch.equal(ms[0]._prep[k][cn], ms[1]._prep[k][cn]), (k, cn)

@@ -36,4 +36,16 @@ inline hipStream_t as_stream(v2ce_stream_t s) { return reinterpret_cast<hipStrea
 
 constexpr int kWave = 64;  // gfx950 wavefront
 
+// power of two s with  amax * s  in [2^14, 2^15): the hi halves use the top of the fp16 range (max
+// 65504) and the lo halves stay normal for every element within 2^-15 of the maximum
+__host__ __device__ __forceinline__ float pow2_prescale(float amax) {
+    if (!(amax > 0.0f)) return 1.0f;
+    int e;
+    frexpf(amax, &e);                       // amax = m * 2^e, m in [0.5, 1)
+    int k = 15 - e;
+    k = k < -100 ? -100 : (k > 100 ? 100 : k);
+    return ldexpf(1.0f, k);
+}
+
+
 }  // namespace v2ce

@@ -89,17 +89,6 @@ struct ConvParams {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr float kActScale = 16.0f;      // pre-scale when the caller tracks no range: |x| < 4094 required
 
-// power of two s with  amax * s  in [2^14, 2^15): the hi halves use the top of the fp16 range (max
-// 65504) and the lo halves stay normal for every element within 2^-15 of the maximum
-__host__ __device__ __forceinline__ float pow2_prescale(float amax) {
-    if (!(amax > 0.0f)) return 1.0f;
-    int e;
-    frexpf(amax, &e);                       // amax = m * 2^e, m in [0.5, 1)
-    int k = 15 - e;
-    k = k < -100 ? -100 : (k > 100 ? 100 : k);
-    return ldexpf(1.0f, k);
-}
-
 template <int KS, int S, int CO_FR, int PO_FR, int CK, int EPT>
 struct ConvCfg {
     static constexpr int K3 = KS * KS * KS;

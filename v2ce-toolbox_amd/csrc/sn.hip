@@ -95,6 +95,154 @@ __global__ __launch_bounds__(1024) void sn_finalize_kernel(const float *__restri
     if (threadIdx.x == 0) sigma[0] = (float)dot;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// All spectral-norm layers of a forward pass in FIVE launches (v2ce_sn_update_batch) instead of seven per
+// layer: the per-layer sequence is launch-bound (84 launches, 1.25 ms alone) and, overlapped with the
+// encoder, its many small workgroups keep taking CUs away from the persistent conv kernels, which need a
+// whole CU each and walk their tiles statically (measured: 0.9 ms per forward).  Same arithmetic and
+// summation orders as the kernels above; max |W| rides on the W v pass (max |W / sigma| = max |W| / |sigma|:
+// correctly rounded division is monotone), so the weights are read three times, not four.
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxBatch = 16;
+struct SnLayer {
+    const float *w;
+    float *u, *v;
+    _Float16 *packed;           // v2ce_pack_weights_f16x2 buffer: hi plane | lo plane | {max |w/sigma|, pre-scale}
+    double *part;               // [kRowChunks][cols]
+    float *t, *s, *rowmax, *sigma;
+    int rows, cols, k3, cin;
+};
+struct SnBatch {
+    SnLayer L[kMaxBatch];
+    int n;
+    int col_blk[kMaxBatch + 1];   // prefix of ceil(cols / 256)
+    int row_blk[kMaxBatch + 1];   // prefix of rows
+    int el_blk[kMaxBatch + 1];    // prefix of ceil(rows * cols / 256)
+};
+
+__device__ __forceinline__ int find_layer(const int *prefix, int n, int b) {
+    int l = 0;
+    while (l + 1 < n && b >= prefix[l + 1]) ++l;
+    return l;
+}
+
+__global__ __launch_bounds__(256) void sn_batch_wt_u_kernel(SnBatch B) {
+    const int l = find_layer(B.col_blk, B.n, blockIdx.x);
+    const SnLayer &P = B.L[l];
+    const int j = (blockIdx.x - B.col_blk[l]) * 256 + threadIdx.x;
+    if (j >= P.cols) return;
+    const int per = (P.rows + kRowChunks - 1) / kRowChunks;
+    const int lo = blockIdx.y * per, hi = (lo + per < P.rows) ? lo + per : P.rows;
+    double s = 0.0;
+#pragma unroll 4
+    for (int i = lo; i < hi; ++i) s += (double)P.w[(long long)i * P.cols + j] * (double)P.u[i];
+    P.part[(long long)blockIdx.y * P.cols + j] = s;
+}
+
+__global__ __launch_bounds__(1024) void sn_batch_normalize_kernel(SnBatch B) {
+    __shared__ double sh[16];
+    const SnLayer &P = B.L[blockIdx.x];
+    const int n = P.cols;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        double a = 0.0;
+#pragma unroll
+        for (int c = 0; c < kRowChunks; ++c) a += P.part[(long long)c * n + i];
+        const float ti = (float)a;
+        P.t[i] = ti;
+        s += (double)ti * (double)ti;
+    }
+    __syncthreads();
+    const float norm = (float)sqrt(block_sum(s, sh));
+    const float den = norm + 1e-12f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) P.v[i] = P.t[i] / den;
+}
+
+__global__ __launch_bounds__(256) void sn_batch_w_v_kernel(SnBatch B) {
+    __shared__ double sh[4];
+    __shared__ float mx[4];
+    const int l = find_layer(B.row_blk, B.n, blockIdx.x);
+    const SnLayer &P = B.L[l];
+    const int r = blockIdx.x - B.row_blk[l];
+    const float *row = P.w + (long long)r * P.cols;
+    double acc = 0.0;
+    float m = 0.0f;
+    for (int j = threadIdx.x; j < P.cols; j += 256) {
+        const float wv = row[j];
+        acc += (double)wv * (double)P.v[j];
+        m = fmaxf(m, fabsf(wv));
+    }
+    const double tot = block_sum(acc, sh);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) mx[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        P.s[r] = (float)tot;
+        P.rowmax[r] = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3]));
+    }
+}
+
+__global__ __launch_bounds__(1024) void sn_batch_finalize_kernel(SnBatch B) {
+    __shared__ double sh[16];
+    __shared__ float mxs[16];
+    const SnLayer &P = B.L[blockIdx.x];
+    const int n = P.rows;
+    double q = 0.0;
+    float m = 0.0f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        q += (double)P.s[i] * (double)P.s[i];
+        m = fmaxf(m, P.rowmax[i]);
+    }
+    const float norm = (float)sqrt(block_sum(q, sh));
+    const float den = norm + 1e-12f;
+    double d = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float ui = P.s[i] / den;
+        P.u[i] = ui;
+        d += (double)ui * (double)P.s[i];
+    }
+    const double dot = block_sum(d, sh);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) mxs[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = fmaxf(m, mxs[i]);
+        const float sg = (float)dot;
+        P.sigma[0] = sg;
+        float *tail = reinterpret_cast<float *>(P.packed + 2ll * P.rows * P.cols);
+        const float am = fabsf(m / sg);                        // = max |w / sigma| of weights_absmax_kernel
+        tail[0] = am;
+        tail[1] = pow2_prescale(am);
+    }
+}
+
+// the body of pack_weights_f16x2_kernel (conv3d.hip) for every layer of the batch
+__global__ __launch_bounds__(256) void sn_batch_pack_kernel(SnBatch B) {
+    const int l = find_layer(B.el_blk, B.n, blockIdx.x);
+    const SnLayer &P = B.L[l];
+    const long long n = (long long)P.rows * P.cols;
+    const long long i = (long long)(blockIdx.x - B.el_blk[l]) * 256 + threadIdx.x;   // ((tap*CG + cg)*Cout + co)*16 + j
+    if (i >= n) return;
+    const float *tail = reinterpret_cast<const float *>(P.packed + 2 * n);
+    const float w_scale = tail[1];
+    const int j = (int)(i & 15);
+    long long r = i >> 4;
+    const int co = (int)(r % P.rows); r /= P.rows;
+    const int CG = P.cin / 16;
+    const int cg = (int)(r % CG);
+    const int tap = (int)(r / CG);
+    float v = P.w[((long long)co * P.cin + cg * 16 + j) * P.k3 + tap];
+    v = v / P.sigma[0];
+    v *= w_scale;
+    const _Float16 h = (_Float16)v;
+    P.packed[i] = h;
+    P.packed[n + i] = (_Float16)(v - (float)h);
+}
+
 }  // namespace
 }  // namespace v2ce
 
@@ -123,6 +271,57 @@ extern "C" int v2ce_sn_power_iter(float *u, float *v, const float *w_bar, int ro
     hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(1024), 0, st, part, cols, t, v);
     hipLaunchKernelGGL(sn_w_v_kernel, dim3(rows), dim3(256), 0, st, w_bar, v, cols, s);
     hipLaunchKernelGGL(sn_finalize_kernel, dim3(1), dim3(1024), 0, st, s, rows, u, sigma);
+    V2CE_HIP_CHECK(hipGetLastError());
+    return V2CE_OK;
+}
+
+static size_t sn_batch_layer_bytes(int rows, int cols) {
+    // part f64 [kRowChunks][cols] | t [cols] | s [rows] | rowmax [rows] | sigma [4]
+    return (size_t)kRowChunks * cols * 8 + ((size_t)cols + 2 * (size_t)rows + 4) * 4;
+}
+
+extern "C" size_t v2ce_sn_batch_workspace_bytes(const v2ce_sn_layer *layers, int n) {
+    if (!layers || n <= 0 || n > kMaxBatch) return 0;
+    size_t b = 0;
+    for (int l = 0; l < n; ++l) b += (sn_batch_layer_bytes(layers[l].rows, layers[l].cols) + 15) / 16 * 16;
+    return b;
+}
+
+extern "C" int v2ce_sn_update_batch(const v2ce_sn_layer *layers, int n, void *workspace, size_t workspace_bytes,
+                                    v2ce_stream_t stream) {
+    clear_error();
+    V2CE_REQUIRE(layers && workspace && n > 0 && n <= kMaxBatch, V2CE_ERR_BAD_ARG, "v2ce_sn_update_batch: 1..%d layers", kMaxBatch);
+    V2CE_REQUIRE(workspace_bytes >= v2ce_sn_batch_workspace_bytes(layers, n), V2CE_ERR_WORKSPACE,
+                 "v2ce_sn_update_batch: workspace %zu < %zu", workspace_bytes, v2ce_sn_batch_workspace_bytes(layers, n));
+    SnBatch B{};
+    B.n = n;
+    unsigned char *ws = static_cast<unsigned char *>(workspace);
+    for (int l = 0; l < n; ++l) {
+        const v2ce_sn_layer &in = layers[l];
+        V2CE_REQUIRE(in.w_bar && in.u && in.v && in.packed && in.rows > 0 && in.cols > 0 && (in.k3 == 27 || in.k3 == 1) &&
+                     in.cols % in.k3 == 0 && (in.cols / in.k3) % 16 == 0, V2CE_ERR_BAD_ARG,
+                     "v2ce_sn_update_batch: layer %d: bad argument", l);
+        SnLayer &o = B.L[l];
+        o.w = in.w_bar; o.u = in.u; o.v = in.v; o.packed = static_cast<_Float16 *>(in.packed);
+        o.rows = in.rows; o.cols = in.cols; o.k3 = in.k3; o.cin = in.cols / in.k3;
+        o.part = reinterpret_cast<double *>(ws);
+        o.t = reinterpret_cast<float *>(o.part + (size_t)kRowChunks * in.cols);
+        o.s = o.t + in.cols;
+        o.rowmax = o.s + in.rows;
+        o.sigma = o.rowmax + in.rows;
+        ws += (sn_batch_layer_bytes(in.rows, in.cols) + 15) / 16 * 16;
+        B.col_blk[l + 1] = B.col_blk[l] + (in.cols + 255) / 256;
+        B.row_blk[l + 1] = B.row_blk[l] + in.rows;
+        const long long el = (long long)in.rows * in.cols;
+        V2CE_REQUIRE(B.el_blk[l] + (el + 255) / 256 < (1ll << 31), V2CE_ERR_UNSUPPORTED, "v2ce_sn_update_batch: too large");
+        B.el_blk[l + 1] = B.el_blk[l] + (int)((el + 255) / 256);
+    }
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(sn_batch_wt_u_kernel, dim3(B.col_blk[n], kRowChunks), dim3(256), 0, st, B);
+    hipLaunchKernelGGL(sn_batch_normalize_kernel, dim3(n), dim3(1024), 0, st, B);
+    hipLaunchKernelGGL(sn_batch_w_v_kernel, dim3(B.row_blk[n]), dim3(256), 0, st, B);
+    hipLaunchKernelGGL(sn_batch_finalize_kernel, dim3(n), dim3(1024), 0, st, B);
+    hipLaunchKernelGGL(sn_batch_pack_kernel, dim3(B.el_blk[n]), dim3(256), 0, st, B);
     V2CE_HIP_CHECK(hipGetLastError());
     return V2CE_OK;
 }

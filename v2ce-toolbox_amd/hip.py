@@ -27,7 +27,8 @@ EXPORTS = [
     "v2ce_ldati_lds_bytes", "v2ce_ldati_workspace_bytes", "v2ce_ldati_emit", "v2ce_events_pack", "v2ce_events_unpack",
     "v2ce_conv3d_fwd",
     "v2ce_conv3d_variant", "v2ce_conv3d_variant_fused", "v2ce_pack_weights_f16x2", "v2ce_pack_weights_f16x2_bytes",
-    "v2ce_pack_weights", "v2ce_sn_workspace_bytes", "v2ce_sn_power_iter", "v2ce_preprocess_pairs", "v2ce_preprocess_pairs_resize",
+    "v2ce_pack_weights", "v2ce_sn_workspace_bytes", "v2ce_sn_power_iter", "v2ce_sn_batch_workspace_bytes", "v2ce_sn_update_batch",
+    "v2ce_preprocess_pairs", "v2ce_preprocess_pairs_resize",
     "v2ce_voxelize_events", "v2ce_conv3d_fwd_pred", "v2ce_conv3d_fwd_sc", "v2ce_pack_pred_weights_f16x2", "v2ce_pack_pred_weights_f16x2_bytes",
 ]
 
@@ -37,6 +38,12 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "B", "T", "C0", "H0", "W0", "C1", "Hin", "Win", "Cout", "Hout", "Wout", "ksize",
         "stride_hw", "act", "tile_t", "tile_h", "tile_w", "precision")]
+
+
+class SnLayer(ctypes.Structure):
+    """``v2ce_sn_layer`` (include/v2ce_hip.h): one spectral-norm layer of v2ce_sn_update_batch."""
+    _fields_ = [("w_bar", ctypes.c_void_p), ("u", ctypes.c_void_p), ("v", ctypes.c_void_p), ("packed", ctypes.c_void_p),
+                ("rows", ctypes.c_int32), ("cols", ctypes.c_int32), ("k3", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class LdatiOptions(ctypes.Structure):
@@ -115,6 +122,10 @@ def lib() -> ctypes.CDLL:
     L.v2ce_sn_workspace_bytes.argtypes = [i32, i32]
     L.v2ce_sn_workspace_bytes.restype = sz
     L.v2ce_sn_power_iter.argtypes = [vp, vp, vp, i32, i32, vp, vp, sz, vp]
+    L.v2ce_sn_batch_workspace_bytes.argtypes = [ctypes.POINTER(SnLayer), i32]
+    L.v2ce_sn_batch_workspace_bytes.restype = sz
+    L.v2ce_sn_update_batch.argtypes = [ctypes.POINTER(SnLayer), i32, vp, sz, vp]
+    L.v2ce_sn_update_batch.restype = ctypes.c_int
     for name in ("v2ce_ldati_count", "v2ce_ldati_emit", "v2ce_events_pack",
                  "v2ce_conv3d_fwd", "v2ce_conv3d_variant", "v2ce_pack_weights", "v2ce_sn_power_iter"):
         getattr(L, name).restype = ctypes.c_int

@@ -16,6 +16,7 @@ reference runs it under ``torch.no_grad()`` in eval mode, ``v2ce.py:41,66``).
 from __future__ import annotations
 
 import ctypes
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -235,6 +236,19 @@ class V2ce3d(nn.Module):
                 P[f"{name}{i}"] = d
         P["sn_ws"] = torch.empty(max(sn_ws, 16), dtype=torch.uint8, device=dev)
         P["sigma"] = torch.empty(1, dtype=torch.float32, device=dev)
+        P["sn_batch"] = None
+        if self.precision == "f16x2":
+            # all 12 spectral-norm layers in one v2ce_sn_update_batch call (five launches instead of 84)
+            inners = [(getattr(blk, cn).module, P[f"{name}{i}"][cn + "_w"])
+                      for name, blocks in (("res", self.UNet.resblocks), ("dec", self.UNet.decoders))
+                      for i, blk in enumerate(blocks) if blk.sn for cn in ("conv1", "conv2")]
+            arr = (hip.SnLayer * len(inners))()
+            for e, (m, out) in zip(arr, inners):
+                e.w_bar, e.u, e.v, e.packed = m.weight_bar.data_ptr(), m.weight_u.data_ptr(), m.weight_v.data_ptr(), out.data_ptr()
+                e.rows, e.cols, e.k3 = m.weight_bar.shape[0], m.weight_bar[0].numel(), 27
+            nb = hip.lib().v2ce_sn_batch_workspace_bytes(arr, len(inners))
+            if nb:
+                P["sn_batch"] = (arr, len(inners), torch.empty(nb, dtype=torch.uint8, device=dev))
         # one max-|y| slot per conv launch of a forward pass (split-half path: the consumer derives its
         # power-of-two activation pre-scale from the producer's slot, all on the device)
         # (+ the launch's range-guard value in the second float, include/v2ce_hip.h)
@@ -367,20 +381,24 @@ class V2ce3d(nn.Module):
 
     def _launch_sn(self):
         """One power iteration + re-pack for all 12 spectral-norm layers (the trajectory does not depend
-        on the input), enqueued on a side stream so that it overlaps the head conv and the four
-        (non-SN) encoder blocks; `_await_sn` joins it in front of the first SN block."""
+        on the input): one batched call in line; with V2CE_SN_SIDE_STREAM=1 on a side stream that `_await_sn`
+        joins behind the head conv (experiment, slower)."""
         dev = self.UNet.head.conv3d.weight.device
         main = torch.cuda.current_stream(dev)
         if getattr(self, "_sn_stream", None) is None or self._sn_stream.device != dev:
             self._sn_stream = torch.cuda.Stream(device=dev)
         side = self._sn_stream
+        if not os.environ.get("V2CE_SN_SIDE_STREAM"):
+            # default: in line, in front of the head convolution (0.29 ms of kernels; measured cost in the forward
+            # pass 0.59 ms -- the re-packed weights and the three passes over W also cool L2 / MALL for the
+            # convolutions).  The side stream measured 0.64-0.75 ms overlapped with the head only and 0.66-0.94
+            # overlapped with the encoder: see _forward.
+            self._sn_all()
+            self._sn_event = None
+            return
         side.wait_stream(main)                   # the previous call's convs are done with the packed weights
         with torch.cuda.stream(side):
-            for name, blocks in (("res", self.UNet.resblocks), ("dec", self.UNet.decoders)):
-                for i, blk in enumerate(blocks):
-                    d = self._prep[f"{name}{i}"]
-                    self._sn_weight(blk.conv1.module, d["conv1_w"])
-                    self._sn_weight(blk.conv2.module, d["conv2_w"])
+            self._sn_all()
             self._sn_event = torch.cuda.Event()
             self._sn_event.record(side)
 
@@ -398,14 +416,25 @@ class V2ce3d(nn.Module):
         with torch.cuda.device(self.UNet.head.conv3d.weight.device):
             self._advance_spectral_norm()
 
-    def _advance_spectral_norm(self):
-        if self._prep is None:
-            self._prepare()
+    def _sn_all(self):
+        """One power iteration + re-pack for all spectral-norm layers on the current stream."""
+        batch = self._prep["sn_batch"]
+        if batch is not None:
+            arr, n, ws = batch
+            dev = ws.device
+            hip.check(hip.lib().v2ce_sn_update_batch(arr, n, ws.data_ptr(), ws.numel(), hip.stream_ptr(dev)),
+                      "v2ce_sn_update_batch")
+            return
         for name, blocks in (("res", self.UNet.resblocks), ("dec", self.UNet.decoders)):
             for i, blk in enumerate(blocks):
                 d = self._prep[f"{name}{i}"]
                 self._sn_weight(blk.conv1.module, d["conv1_w"])
                 self._sn_weight(blk.conv2.module, d["conv2_w"])
+
+    def _advance_spectral_norm(self):
+        if self._prep is None:
+            self._prepare()
+        self._sn_all()
         self.calls += 1
 
     # ---- forward ------------------------------------------------------------------------------
@@ -434,6 +463,12 @@ class V2ce3d(nn.Module):
         h = self._conv(x, None, *P["head"], BASE, 3, 1, hip.ACT_LEAKY,           # unet_2layer.py:341
                        track=self.precision == "f16x2")
         inter["head"] = h
+        # The spectral-norm stream overlaps the head convolution only (both are many small workgroups; the head
+        # is bound by its output stream, the power iterations by reading W).  The persistent residual-block
+        # kernels need a whole CU per workgroup and walk their tiles statically: side-stream workgroups that
+        # sit on a CU when such a kernel starts delay that CU's whole share (measured: 0.29 ms of spectral-norm
+        # work cost 0.66 ms when it overlapped the encoder).
+        self._await_sn()
         skips = []
         for i, blk in enumerate(U.encoders):                                     # :345-347
             skips.append(h)
