@@ -270,6 +270,7 @@ def main():
                            dtype=torch.int64).to(device)
     ldati_prof, conv_prof = [], []
     gather_bytes = [0]
+    gathers = []
     n_events = [0]
 
     def front(profile):
@@ -299,9 +300,13 @@ def main():
         packed = ev.packed()
         n_events[0] += ev.num_events
         if world > 1:
-            out = vdist.gather_events(packed, dst=0)
-            if rank == 0:
-                gather_bytes[0] = int(out.numel())
+            # rank 0 receives every rank's records of this step over RCCL on a communication stream; the byte
+            # counts it needs are read one step later, so no rank waits on its compute stream
+            gathers.append(vdist.EventGather(packed, dst=0))
+            if len(gathers) > 1:
+                out = gathers.pop(0).finish()
+                if rank == 0:
+                    gather_bytes[0] = int(sum(o.numel() for o in out))
         return packed
 
     def run_steps(k, profile):
@@ -313,6 +318,10 @@ def main():
             pending = nxt
         if pending is not None:
             back(pending)
+        while gathers:                                          # the last step's gather
+            out = gathers.pop(0).finish()
+            if rank == 0:
+                gather_bytes[0] = int(sum(o.numel() for o in out))
 
     run_steps(args.warmup, True)            # same code path as the timed steps (warms the HIP event pool too)
     ldati_prof.clear()

@@ -60,9 +60,14 @@ def _worker(rank, world, port, n_frames, infer_type, bs, wf, q):
                       device="cpu", stage2=fake_stage2(30))
         # also exercise the raw gather with ragged (and empty) payloads
         payload = torch.full((rank * 5,), rank + 1, dtype=torch.uint8)
-        g = __import__("v2ce_toolbox_amd.dist", fromlist=["x"]).gather_events(payload, dst=0)
-        assert (out is None) == (rank != 0)
+        vd = __import__("v2ce_toolbox_amd.dist", fromlist=["x"])
+        g = vd.gather_events(payload, dst=0)
+        # the split (begin / finish) form bench.py pipelines: two gathers in flight, finished in order
+        h1, h2 = vd.EventGather(payload, dst=0), vd.EventGather(payload + 1, dst=0)
+        g1, g2 = h1.finish(), h2.finish()
+        assert (out is None) == (rank != 0) and (g1 is None) == (rank != 0)
         if rank == 0:
+            assert torch.equal(torch.cat(g1), g) and torch.equal(torch.cat(g2), g + 1)
             q.put((out.tobytes(), g.numpy().tolist()))
     finally:
         dist.destroy_process_group()

@@ -53,6 +53,73 @@ def gather_events(packed: torch.Tensor, dst: int = 0, group=None) -> Optional[to
     return torch.cat([recv[r][:sizes[r]] for r in range(world)])
 
 
+class EventGather:
+    """``gather_events`` split in two so that no rank ever waits on its compute stream (bench.py's
+    per-step gather; a driver that streams results to rank 0 batch by batch would use it the same way):
+
+    ``begin``  -- on a communication stream that waits only for the event recorded behind the producer of
+                  `packed`: all_gather of the byte counts, copied to pinned host memory.
+    ``finish`` -- the host waits for that copy alone (typically one step later, long done), then enqueues the
+                  padded ``gather`` on the communication stream.  Returns the list of per-rank buffers on
+                  `dst` (not concatenated, not waited for: synchronise before reading), None elsewhere."""
+
+    _streams = {}
+
+    def __init__(self, packed: torch.Tensor, dst: int = 0, group=None):
+        self.packed, self.dst, self.group = packed, dst, group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.cuda = packed.is_cuda
+        n = torch.tensor([packed.numel()], dtype=torch.int64)
+        if self.cuda:
+            dev = packed.device
+            if dev not in EventGather._streams:
+                EventGather._streams[dev] = torch.cuda.Stream(device=dev)
+            self.stream = EventGather._streams[dev]
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(dev))
+            self.stream.wait_event(ready)
+            with torch.cuda.stream(self.stream):
+                packed.record_stream(self.stream)
+                sizes = torch.empty(self.world, dtype=torch.int64, device=dev)
+                dist.all_gather_into_tensor(sizes, n.to(dev), group=group)
+                self.sizes_host = torch.empty(self.world, dtype=torch.int64).pin_memory()
+                self.sizes_host.copy_(sizes, non_blocking=True)
+                self.sizes_ready = torch.cuda.Event()
+                self.sizes_ready.record(self.stream)
+        else:
+            sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(self.world)]
+            dist.all_gather(sizes, n, group=group)
+            self.sizes_host = torch.cat(sizes)
+
+    def finish(self):
+        if self.cuda:
+            self.sizes_ready.synchronize()
+        sizes = [int(v) for v in self.sizes_host.tolist()]
+        longest = max(max(sizes), 1)
+        ctx = torch.cuda.stream(self.stream) if self.cuda else _NullCtx()
+        with ctx:
+            send = torch.zeros(longest, dtype=torch.uint8, device=self.packed.device)
+            send[:self.packed.numel()] = self.packed
+            recv = [torch.empty(longest, dtype=torch.uint8, device=self.packed.device) for _ in range(self.world)] \
+                if self.rank == self.dst else None
+            dist.gather(send, recv, dst=self.dst, group=self.group)
+            if self.cuda:
+                self.done = torch.cuda.Event()
+                self.done.record(self.stream)
+        self.packed = None
+        if self.rank != self.dst:
+            return None
+        return [recv[r][:sizes[r]] for r in range(self.world)]
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 _SUBGROUPS = {}
 
 
