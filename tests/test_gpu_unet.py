@@ -40,7 +40,7 @@ def hip_conv(x0, w, scale, shift, ksize, stride, act, x1=None, up_to=None, resid
     wp = V2ce3d._pack(m, wd)
     y = V2ce3d._conv(m, to_btchw(x0).cuda(), None if x1 is None else to_btchw(x1).cuda(), wp,
                      scale.cuda().contiguous(), shift.cuda().contiguous(), w.shape[0], ksize, stride,
-                     act, residual=None if residual is None else to_btchw(residual).cuda(), up_to=up_to)
+                     act, residual=None if residual is None else to_btchw(residual).cuda(), up_to=up_to, dense_out=True)
     torch.cuda.synchronize()
     return y.permute(0, 2, 1, 3, 4).cpu().numpy()
 
@@ -205,7 +205,7 @@ def hip_conv_split(x0, w, scale, shift, stride, act, x1=None, up_to=None, residu
     y = V2ce3d._conv(m, x0d, x1d, wq,
                      scale.cuda().contiguous(), shift.cuda().contiguous(), w.shape[0], ksize, stride, act,
                      residual=None if residual is None else to_btchw(residual).cuda(), up_to=up_to,
-                     split=True)
+                     split=True, dense_out=True)
     torch.cuda.synchronize()
     hip_conv_split.guard = float(y.absmax[1])               # the launch's range-guard bound
     return y.permute(0, 2, 1, 3, 4).cpu().numpy()
@@ -547,3 +547,59 @@ def test_batched_spectral_norm_equals_per_layer_calls():
     for k in ("res0", "res1", "dec0", "dec3"):
         for cn in ("conv1_w", "conv2_w"):
             assert torch.equal(ms[0]._prep[k][cn], ms[1]._prep[k][cn]), (k, cn)
+
+
+def _padded(x_ncdhw, pitch):
+    """[N,C,D,H,W] CPU tensor -> device [B,T,C,H,pitch] with NaN in the padding columns and .lw = W."""
+    x = to_btchw(x_ncdhw)
+    out = torch.full(tuple(x.shape[:-1]) + (pitch,), float("nan"))
+    out[..., :x.shape[-1]] = x
+    out = out.cuda()
+    out.lw = x.shape[-1]
+    return out
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_conv3d_row_pitch(split):
+    """Activations with a row pitch > width (v2ce_conv3d_desc.W0_pitch / Win_pitch / Wout_pitch): sources,
+    residual and output padded to 96-float rows, NaN in every padding column (never read), virtual
+    upsample + concat, 3x3x3 stride 1 and stride 2, 1x1x1; values equal the dense launch bit for bit."""
+    from v2ce_toolbox_amd import hip
+    from v2ce_toolbox_amd.v2ce_3d import V2ce3d
+    g = torch.Generator().manual_seed(31)
+    m = V2ce3d.__new__(V2ce3d)
+    torch.nn.Module.__init__(m)
+    m._maps, m.precision, m._slot = {}, "f16x2" if split else "f32", 0
+    m._prep = {"absmax": torch.zeros((16, 2), device="cuda")}
+    for (c0, c1, cout, k, s, use_res) in ((32, 0, 64, 3, 1, True), (32, 16, 32, 3, 1, False), (32, 0, 64, 3, 2, False),
+                                          (32, 16, 64, 1, 1, False)):
+        H, W = 9, 70
+        x0 = torch.randn(1, c0, 3, (H + 1) // 2 if c1 else H, (W + 1) // 2 if c1 else W, generator=g)
+        x1 = torch.randn(1, c1, 3, H, W, generator=g) if c1 else None
+        w = torch.randn(cout, c0 + c1, k, k, k, generator=g) * 0.05
+        Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
+        res = torch.randn(1, cout, 3, Ho, Wo, generator=g) if use_res else None
+        scale, shift = (torch.rand(cout, generator=g) + 0.5).cuda(), torch.randn(cout, generator=g).cuda()
+        wp = V2ce3d._pack(m, w.cuda().contiguous(), split=split)
+        outs = []
+        for padded in (False, True):
+            m._slot = 0
+            m._prep["absmax"].zero_()
+            if padded:
+                a0 = _padded(x0, 96 if not c1 else 64)
+                a1 = None if x1 is None else _padded(x1, 96)
+                r = None if res is None else _padded(res, V2ce3d._pitch(Wo))
+            else:
+                a0, a1 = to_btchw(x0).cuda(), None if x1 is None else to_btchw(x1).cuda()
+                r = None if res is None else to_btchw(res).cuda()
+            if split:
+                a0.absmax = torch.nan_to_num(a0).abs().max().reshape(1)
+                if a1 is not None:
+                    a1.absmax = torch.nan_to_num(a1).abs().max().reshape(1)
+            y = V2ce3d._conv(m, a0, a1, wp, scale, shift, cout, k, s, hip.ACT_RELU, residual=r,
+                             up_to=(H, W) if c1 else None, split=split, track=True, dense_out=not padded)
+            assert y.shape[-1] == (V2ce3d._pitch(Wo) if padded else Wo) and y.lw == Wo
+            outs.append((y[..., :Wo].contiguous(), float(y.absmax[0])))
+        assert not torch.isnan(outs[1][0]).any()
+        assert torch.equal(outs[0][0], outs[1][0]), (c0, c1, cout, k, s)
+        assert outs[0][1] == outs[1][1] == float(outs[0][0].abs().max())

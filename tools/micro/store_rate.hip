@@ -59,12 +59,12 @@ __global__ __launch_bounds__(256) void probe(float *y, long long cstride, int ro
 }
 
 template <int MODE>
-void run(const char *name, int blocks, int waves_active, float *y, unsigned long long *out, int pre_mfma = 0) {
-    const long long cstride = 260 * 346;   // floats between channel planes
+void run(const char *name, int blocks, int waves_active, float *y, unsigned long long *out, int pre_mfma = 0, int rowstride = 346) {
+    const long long cstride = 260 * (long long)rowstride;   // floats between channel planes
     std::vector<unsigned long long> h(blocks * 8);
     for (int rep = 0; rep < 2; ++rep) {
         hipMemset(out, 0, blocks * 8 * sizeof(unsigned long long));
-        hipLaunchKernelGGL(probe<MODE>, dim3(blocks), dim3(256), 0, 0, y, cstride, 346, out, waves_active, pre_mfma);
+        hipLaunchKernelGGL(probe<MODE>, dim3(blocks), dim3(256), 0, 0, y, cstride, rowstride, out, waves_active, pre_mfma);
         hipDeviceSynchronize();
     }
     hipMemcpy(h.data(), out, h.size() * 8, hipMemcpyDeviceToHost);
@@ -82,6 +82,9 @@ int main() {
         run<0>("dword/lane, 2 planes x 128 B per instr", blocks, 4, y, out, pre);
         run<1>("dwordx4/lane, 8 planes x 128 B per instr", blocks, 4, y, out, pre);
         run<3>("dwordx4/lane, contiguous 1 KiB per instr", blocks, 4, y, out, pre);
+        // the same pieces with rows padded to 352 floats: every 128-byte piece is one aligned cache line
+        run<0>("dword/lane, 2 planes x 128 B, pitch 352", blocks, 4, y, out, pre, 352);
+        run<1>("dwordx4/lane, 8 planes x 128 B, pitch 352", blocks, 4, y, out, pre, 352);
     }
     return 0;
 }

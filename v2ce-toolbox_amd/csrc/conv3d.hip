@@ -50,6 +50,7 @@ struct ConvParams {
     const float *wp, *scale, *shift, *res;
     float *y;
     int B, T, C0, H0, W0, C1, Hin, Win, Cin, Cout, Hout, Wout;
+    int W0p, Winp, Woutp;         // row pitches (floats) of x0, x1 and of y / residual / sc_y (>= the logical widths)
     int act;
     int TT, TH, TW;       // output box
     int nT, nH, nW;       // boxes per dimension
@@ -137,8 +138,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &P, f32x16 (&acc)
                                               float inv_scale) {
     const float *__restrict__ scale = P.scale;
     const float *__restrict__ shift = P.shift;
-    const long long seq = (long long)P.T * P.Cout * (P.Hout * P.Wout);
-    const int cstride4 = P.Hout * P.Wout * 4;
+    const long long seq = (long long)P.T * P.Cout * (P.Hout * P.Woutp);
+    const int cstride4 = P.Hout * P.Woutp * 4;
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(P.y ? P.y + b * seq : const_cast<float *>(P.scale), 0,
                                                                           P.y ? (int)(seq * 4) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(
@@ -285,8 +286,8 @@ __device__ __forceinline__ void pred_epilogue(const ConvParams &P, const f32x16 
 template <int CO_FR, int PO_FR>
 __device__ __forceinline__ void conv_epilogue_stream(const ConvParams &P, const f32x16 (&acc)[CO_FR][PO_FR],
                                                      const int (&poff)[PO_FR], int co0, int half, int b) {
-    const long long ybase = (long long)b * P.T * P.Cout * (P.Hout * P.Wout);
-    const int cstride = P.Hout * P.Wout;
+    const long long ybase = (long long)b * P.T * P.Cout * (P.Hout * P.Woutp);
+    const int cstride = P.Hout * P.Woutp;
     const float slope = act_slope(P.act);
     float ymax = 0.0f;
 #pragma unroll
@@ -320,7 +321,7 @@ template <int EPT>
 __device__ __forceinline__ void halo_offsets(const ConvParams &P, int tin0, int hin0, int win0,
                                              bool src1, int tid, unsigned (&goff)[EPT], int gs = 1) {
     const int Cs = src1 ? P.C1 : P.C0;
-    const int Hs = src1 ? P.Hin : P.H0, Ws = src1 ? P.Win : P.W0;
+    const int Hs = src1 ? P.Hin : P.H0, Ws = src1 ? P.Winp : P.W0p;      // row pitch of the source
     const bool mapped = !src1 && P.hmap != nullptr;
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
@@ -366,16 +367,16 @@ __device__ __forceinline__ void issue_chunk(const ConvParams &P, DmaState<EPT, W
         D.cur_src = want_src;
         halo_offsets<EPT>(P, tin0, hin0, win0, want_src == 1, wave * 64 + (int)(threadIdx.x & 63), D.goff);
         if (want_src == 0) {
-            const long long seq = (long long)P.T * P.C0 * (P.H0 * P.W0);
+            const long long seq = (long long)P.T * P.C0 * (P.H0 * P.W0p);
             D.rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x0 + b * seq), 0,
                                                         (int)(seq * 4), 0x00020000);
-            D.src_cstride4 = P.H0 * P.W0 * 4;
+            D.src_cstride4 = P.H0 * P.W0p * 4;
             D.src_cbase = 0;
         } else {
-            const long long seq = (long long)P.T * P.C1 * (P.Hin * P.Win);
+            const long long seq = (long long)P.T * P.C1 * (P.Hin * P.Winp);
             D.rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x1 + b * seq), 0,
                                                         (int)(seq * 4), 0x00020000);
-            D.src_cstride4 = P.Hin * P.Win * 4;
+            D.src_cstride4 = P.Hin * P.Winp * 4;
             D.src_cbase = P.C0;
         }
     }
@@ -483,7 +484,7 @@ __global__ __launch_bounds__(256, MW) void conv3d_kernel(ConvParams P) {
             hoff[f] = (tt * P.HH + th * S) * P.HWd + tw * S;
             const int t = t0 + tt, h = h0 + th, w = w0 + tw;
             if (t < P.T && h < P.Hout && w < P.Wout)
-                poff[f] = (t * P.Cout) * (P.Hout * P.Wout) + h * P.Wout + w;
+                poff[f] = (t * P.Cout) * (P.Hout * P.Woutp) + h * P.Woutp + w;
         }
     }
 
@@ -690,14 +691,14 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
                 cur_src = want_src;
                 halo_offsets<EPT>(P, L.t0 - PAD, L.h0 * S - PAD, L.w0 * S - PAD, want_src == 1, ptid, goff, GS);
                 if (want_src == 0) {
-                    const long long seq = (long long)P.T * P.C0 * (P.H0 * P.W0);
+                    const long long seq = (long long)P.T * P.C0 * (P.H0 * P.W0p);
                     rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x0 + L.b * seq), 0, (int)(seq * 4), 0x00020000);
-                    src_cstride4 = P.H0 * P.W0 * 4;
+                    src_cstride4 = P.H0 * P.W0p * 4;
                     src_cbase = 0;
                 } else {
-                    const long long seq = (long long)P.T * P.C1 * (P.Hin * P.Win);
+                    const long long seq = (long long)P.T * P.C1 * (P.Hin * P.Winp);
                     rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x1 + L.b * seq), 0, (int)(seq * 4), 0x00020000);
-                    src_cstride4 = P.Hin * P.Win * 4;
+                    src_cstride4 = P.Hin * P.Winp * 4;
                     src_cbase = P.C0;
                 }
             }
@@ -946,7 +947,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
                 const int tw = rem - th * P.TW;
                 const int t = T.t0 + tt, h = T.h0 + th, w = T.w0 + tw;
                 if (t < P.T && h < P.Hout && w < P.Wout)
-                    poff[f] = (t * P.Cout) * (P.Hout * P.Wout) + h * P.Wout + w;
+                    poff[f] = (t * P.Cout) * (P.Hout * P.Woutp) + h * P.Woutp + w;
             }
         }
         if constexpr (FUSE == 1) {                              // 32-channel conv with the fused 1x1x1 head
@@ -1007,13 +1008,13 @@ __global__ __launch_bounds__(256) void conv3d_head_kernel(ConvParams P) {
     const int t0 = it * TT, h0 = ih * TH, w0 = iw * TW;
 
     // halo box: rows of HWd consecutive floats (one row per (channel, ht, hh)), coalesced along W
-    const float *xb = P.x0 + (long long)b * P.T * 2 * (P.H0 * P.W0);
+    const float *xb = P.x0 + (long long)b * P.T * 2 * (P.H0 * P.W0p);
     for (int row = wave; row < 2 * HT * HH; row += 4) {
         const int ci = row / (HT * HH), r = row - ci * (HT * HH);
         const int ht = r / HH, hh = r - ht * HH;
         const int t = t0 + ht - 1, h = h0 + hh - 1;
         const bool rok = t >= 0 && t < P.T && h >= 0 && h < P.H0;
-        const float *src = xb + ((long long)(rok ? t : 0) * 2 + ci) * (P.H0 * P.W0) + (rok ? h : 0) * P.W0;
+        const float *src = xb + ((long long)(rok ? t : 0) * 2 + ci) * (P.H0 * P.W0p) + (rok ? h : 0) * P.W0p;
         for (int ww = lane; ww < HWd; ww += 64) {
             const int w = w0 + ww - 1;
             halo[row * HWd + ww] = (rok && w >= 0 && w < P.W0) ? src[w] : 0.0f;
@@ -1076,12 +1077,12 @@ __global__ __launch_bounds__(256) void conv3d_head_kernel(ConvParams P) {
 
     const int t = t0 + tt, h = h0 + th, w = w0 + lane;
     const bool ok = t < P.T && h < P.Hout && w < P.Wout;
-    const int hw = P.Hout * P.Wout;
+    const int hw = P.Hout * P.Woutp;
     const long long seq = (long long)P.T * P.Cout * hw;
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(P.y + b * seq, 0, (int)(seq * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(P.res ? P.res + b * seq : P.scale), 0, P.res ? (int)(seq * 4) : 0, 0x00020000);
-    const unsigned vo = ok ? (unsigned)(((t * P.Cout) * hw + h * P.Wout + w) * 4) : kOOB;
+    const unsigned vo = ok ? (unsigned)(((t * P.Cout) * hw + h * P.Woutp + w) * 4) : kOOB;
     const float slope = act_slope(P.act);
     const float *__restrict__ scale = P.scale;
     const float *__restrict__ shift = P.shift;
@@ -1368,8 +1369,11 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
     V2CE_REQUIRE(d.Hout == (d.Hin + 2 * pad - d.ksize) / s + 1 && d.Wout == (d.Win + 2 * pad - d.ksize) / s + 1,
                  V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd: output size %dx%d inconsistent", d.Hout, d.Wout);
     V2CE_REQUIRE(d.Cout % 4 == 0, V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd: Cout %% 4 != 0");
-    const long long seq_in0 = (long long)d.T * d.C0 * d.H0 * d.W0, seq_in1 = (long long)d.T * d.C1 * d.Hin * d.Win;
-    const long long seq_out = (long long)d.T * d.Cout * d.Hout * d.Wout;
+    const int W0p = d.W0_pitch > 0 ? d.W0_pitch : d.W0, Winp = d.Win_pitch > 0 ? d.Win_pitch : d.Win;
+    const int Woutp = d.Wout_pitch > 0 ? d.Wout_pitch : d.Wout;
+    V2CE_REQUIRE(W0p >= d.W0 && Winp >= d.Win && Woutp >= d.Wout, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd: a row pitch is smaller than its width");
+    const long long seq_in0 = (long long)d.T * d.C0 * d.H0 * W0p, seq_in1 = (long long)d.T * d.C1 * d.Hin * Winp;
+    const long long seq_out = (long long)d.T * d.Cout * d.Hout * Woutp;
     V2CE_REQUIRE(seq_in0 < (1ll << 29) && seq_in1 < (1ll << 29) && seq_out < (1ll << 29),
                  V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd: a single sequence exceeds the 2 GiB buffer-descriptor range");
 
@@ -1378,6 +1382,7 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
     P.shift = shift; P.res = residual; P.y = y;
     P.B = d.B; P.T = d.T; P.C0 = d.C0; P.H0 = d.H0; P.W0 = d.W0; P.C1 = d.C1; P.Hin = d.Hin;
     P.Win = d.Win; P.Cin = d.C0 + d.C1; P.Cout = d.Cout; P.Hout = d.Hout; P.Wout = d.Wout;
+    P.W0p = W0p; P.Winp = Winp; P.Woutp = Woutp;
     P.act = d.act;
     P.x0_absmax = x0_absmax; P.x1_absmax = d.C1 > 0 ? x1_absmax : nullptr; P.y_absmax = y_absmax;
     P.guard = y_absmax ? y_absmax + 1 : nullptr;

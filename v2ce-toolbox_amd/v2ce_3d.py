@@ -280,23 +280,40 @@ class V2ce3d(nn.Module):
         return self._maps[key]
 
     # ---- kernels ------------------------------------------------------------------------------
+    @staticmethod
+    def _pitch(w: int) -> int:
+        """Row pitch of an intermediate activation of width w: rows of at least 64 floats are padded to a multiple
+        of 32 floats, so that the 32-position pieces the conv kernels store and gather are whole cache lines
+        (346 -> 352, 173 -> 192, 87 -> 96; tools/micro/store_rate.hip).  V2CE_ACT_PITCH=0 disables it."""
+        if w < 64 or os.environ.get("V2CE_ACT_PITCH", "1") == "0":
+            return w
+        return (w + 31) // 32 * 32
+
     def _conv(self, x0, x1, w_packed, scale, shift, cout, ksize, stride, act, residual=None,
-              up_to=None, split=False, track=False, pred=None, sc=None):
+              up_to=None, split=False, track=False, pred=None, sc=None, dense_out=False):
         """x0 [B,T,C0,H0,W0] (optionally nearest-upsampled to ``up_to``), x1 [B,T,C1,Hin,Win]."""
-        B, T, C0, H0, W0 = x0.shape
+        # activations between the layers are [B,T,C,H,pitch] with the logical width in `.lw` (see _pitch)
+        B, T, C0, H0, W0p = x0.shape
+        W0 = getattr(x0, "lw", W0p)
         Hin, Win = up_to if up_to is not None else (H0, W0)
         hmap = wmap = None
         if (Hin, Win) != (H0, W0):
             hmap, wmap = self._map(H0, Hin, x0.device), self._map(W0, Win, x0.device)
         C1 = 0 if x1 is None else x1.shape[2]
+        Winp = Win if x1 is None else x1.shape[4]
+        assert x1 is None or getattr(x1, "lw", Winp) == Win
         pad = ksize // 2
         Hout = (Hin + 2 * pad - ksize) // stride + 1
         Wout = (Win + 2 * pad - ksize) // stride + 1
-        y = torch.empty((B, T, cout, Hout, Wout), dtype=torch.float32, device=x0.device)
+        Woutp = self._pitch(Wout) if dense_out is False else Wout
+        assert residual is None or residual.shape[4] == Woutp
+        y = torch.empty((B, T, cout, Hout, Woutp), dtype=torch.float32, device=x0.device)
+        y.lw = Wout
         d = hip.ConvDesc(B=B, T=T, C0=C0, H0=H0, W0=W0, C1=C1, Hin=Hin, Win=Win, Cout=cout,
                          Hout=Hout, Wout=Wout, ksize=ksize, stride_hw=stride, act=act,
                          tile_t=0, tile_h=0, tile_w=0,
-                         precision=hip.PRECISION_F16X2 if split else hip.PRECISION_F32)
+                         precision=hip.PRECISION_F16X2 if split else hip.PRECISION_F32,
+                         W0_pitch=W0p, Win_pitch=Winp, Wout_pitch=Woutp)
         a0 = a1 = ay = None
         if track or split:         # range tracking for the split-half consumers (device side only)
             ay = y.absmax = self._prep["absmax"][self._slot]              # [max |y|, range-guard value]
@@ -321,6 +338,7 @@ class V2ce3d(nn.Module):
         elif sc is not None:           # fused 1x1x1 shortcut: second output tensor
             sc_w, sc_scale, sc_shift = sc
             y_sc = torch.empty_like(y)
+            y_sc.lw = Wout
             hip.check(hip.lib().v2ce_conv3d_fwd_sc(ctypes.byref(d), x0.data_ptr(), hip.ptr(x1),
                                                    hip.ptr(hmap), hip.ptr(wmap), w_packed.data_ptr(),
                                                    scale.data_ptr(), shift.data_ptr(), y.data_ptr(),
@@ -462,7 +480,7 @@ class V2ce3d(nn.Module):
         inter = OrderedDict()
         h = self._conv(x, None, *P["head"], BASE, 3, 1, hip.ACT_LEAKY,           # unet_2layer.py:341
                        track=self.precision == "f16x2")
-        inter["head"] = h
+        inter["head"] = h[..., :h.lw]
         # The spectral-norm stream overlaps the head convolution only (both are many small workgroups; the head
         # is bound by its output stream, the power iterations by reading W).  The persistent residual-block
         # kernels need a whole CU per workgroup and walk their tiles statically: side-stream workgroups that
@@ -473,20 +491,20 @@ class V2ce3d(nn.Module):
         for i, blk in enumerate(U.encoders):                                     # :345-347
             skips.append(h)
             h = self._block(blk, P[f"enc{i}"], h)
-            inter[f"enc{i}"] = h
+            inter[f"enc{i}"] = h[..., :h.lw]
         for i, blk in enumerate(U.resblocks):                                    # :349-350
             h = self._block(blk, P[f"res{i}"], h)
-            inter[f"res{i}"] = h
+            inter[f"res{i}"] = h[..., :h.lw]
         fuse = P["pred_fused"] if not return_intermediates else None
         for i, (blk, skip) in enumerate(zip(U.decoders, reversed(skips))):       # :357-365
             last = i == len(U.decoders) - 1
-            h = self._block(blk, P[f"dec{i}"], h, skip, up_to=(skip.shape[3], skip.shape[4]),
+            h = self._block(blk, P[f"dec{i}"], h, skip, up_to=(skip.shape[3], getattr(skip, "lw", skip.shape[4])),
                             pred=fuse if last else None)
-            inter[f"dec{i}"] = h
+            inter[f"dec{i}"] = h[..., :getattr(h, "lw", h.shape[4])]
         if fuse is not None:
             out = h                                                               # pred rode on dec3.conv2
         else:
-            out = self._conv(h, None, *P["pred"], self.out_channels, 1, 1, hip.ACT_RELU)   # :374
+            out = self._conv(h, None, *P["pred"], self.out_channels, 1, 1, hip.ACT_RELU, dense_out=True)   # :374
         self.calls += 1
         if self.precision == "f16x2":
             torch.maximum(P["guard"], P["absmax"][:, 1].max().reshape(1), out=P["guard"])
