@@ -251,7 +251,8 @@ int v2ce_conv3d_fwd_sc(const v2ce_conv3d_desc *desc, const float *x0, const floa
  * CO_FR,PO_FR,CK,EPT>", as it appears demangled in rocprofv3 traces); mapped != 0 means hmap/wmap
  * would be non-NULL.  Launches nothing.  Used by bench.py to attribute event timings. */
 int v2ce_conv3d_variant(const v2ce_conv3d_desc *desc, int mapped, char *name, size_t cap);
-/* Same for the fused entry points: fuse = 1 (v2ce_conv3d_fwd_pred), 2 (v2ce_conv3d_fwd_sc), 0 (plain). */
+/* Same for the fused entry points: fuse = 1 (v2ce_conv3d_fwd_pred), 2 (v2ce_conv3d_fwd_sc), 0 (plain); + 4 when the
+ * launch has a residual (the kernels are instantiated per case: the last template argument). */
 int v2ce_conv3d_variant_fused(const v2ce_conv3d_desc *desc, int mapped, int fuse, char *name, size_t cap);
 
 /* Weight re-layout [Cout][Cin][k^3] -> [Cin][k^3][Cout], optionally divided elementwise by

@@ -88,7 +88,8 @@ def run(name, B=4, T=16, iters=5, tile=(0, 0, 0)):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     fl = 2.0 * B * T * Ho * Wo * Cout * (C0 + C1) * k ** 3
-    return hip.conv_variant(d, hmap is not None, {'sc': 2, 'pred': 1}.get(fuse, 0)), ms, fl / ms / 1e9
+    has_res = fuse == 'pred' or (fuse == '' and res_plain is not None)
+    return hip.conv_variant(d, hmap is not None, {'sc': 2, 'pred': 1}.get(fuse, 0) + (4 if has_res else 0)), ms, fl / ms / 1e9
 
 
 if __name__ == "__main__":

@@ -132,7 +132,15 @@ __device__ __forceinline__ float apply_act(float t, float slope) { return fmaxf(
 // scalar branches): loads and stores are buffer operations whose per-lane offset is pushed out of
 // range for masked lanes (the hardware range check returns 0 / drops the store), the channel offset
 // rides in the scalar offset.  Requires Cout % 32 == 0, sequences < 2 GiB, y not aliasing the inputs.
-template <int CO_FR, int PO_FR, bool CHECK_CO = false, bool KEEP = false>
+// RES: 0 = no residual, 1 = residual (both decided at compile time), 2 = P.res checked at run time.
+// The vector-memory counter of gfx9 is shared by loads and stores and drains in issue order, so a wait for a
+// load also waits for every store issued before it.  The run-time form (a uniform branch around each batch of
+// loads, then s_waitcnt vmcnt(0)) therefore pays the write-acknowledge latency of the previous batch's stores
+// 4 * CO_FR times per tile even when there is no residual (in-kernel stamps: 25 k -> 16 k cycles on
+// dec3.conv1).  RES 0 has no wait inside the loop; RES 1 issues the loads of batch i+1 in front of the stores
+// of batch i (and all scale / shift loads in front of everything), so a wait covers only stores that are two
+// batches old.
+template <int CO_FR, int PO_FR, bool CHECK_CO = false, bool KEEP = false, int RES = 2>
 __device__ __forceinline__ void conv_epilogue(const ConvParams &P, f32x16 (&acc)[CO_FR][PO_FR],
                                               const int (&poff)[PO_FR], int co0, int half, int b,
                                               float inv_scale) {
@@ -142,8 +150,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &P, f32x16 (&acc)
     const int cstride4 = P.Hout * P.Woutp * 4;
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(P.y ? P.y + b * seq : const_cast<float *>(P.scale), 0,
                                                                           P.y ? (int)(seq * 4) : 0, 0x00020000);
+    const bool has_res = RES == 1 || (RES == 2 && P.res != nullptr);
     const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(P.res ? P.res + b * seq : P.scale), 0, P.res ? (int)(seq * 4) : 0, 0x00020000);
+        const_cast<float *>(has_res ? P.res + b * seq : P.scale), 0, has_res ? (int)(seq * 4) : 0, 0x00020000);
     const int cbase = co0 + 4 * half;                      // this lane's channel for (q, r) = (0, 0)
     const float slope = act_slope(P.act);
     unsigned vo[PO_FR], vmask[PO_FR];
@@ -152,36 +161,58 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &P, f32x16 (&acc)
         vo[f] = poff[f] >= 0 ? (unsigned)(poff[f] * 4 + cbase * cstride4) : kOOB;
         vmask[f] = poff[f] >= 0 ? 0x7fffffffu : 0u;        // |v| of a masked lane counts as 0
     }
-    unsigned ymax = 0u;                                    // max |y| as a bit pattern (non-negative floats order as integers)
+    auto load_res = [&](int step, float (&rv)[4][PO_FR]) {  // batch `step` = (q, r4): 4 channels x PO_FR positions
+        const int q = step >> 2, r4 = step & 3;
 #pragma unroll
-    for (int q = 0; q < CO_FR; ++q) {
-        float sc[16], sh[16];
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int f = 0; f < PO_FR; ++f) {
+                const bool cok = !CHECK_CO || cbase + q * 32 + k + 8 * r4 < P.Cout;
+                rv[k][f] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    rs_r, cok ? vo[f] : kOOB, (q * 32 + k + 8 * r4) * cstride4, 0));
+            }
+    };
+    float rva[4][PO_FR], rvb[4][PO_FR];
+    if constexpr (RES == 1) load_res(0, rva);
+    float sc[RES == 1 ? CO_FR : 1][16], sh[RES == 1 ? CO_FR : 1][16];
+    auto load_affine = [&](int q, float (&scq)[16], float (&shq)[16]) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             int co = cbase + q * 32 + (r & 3) + 8 * (r >> 2);
             if (CHECK_CO) co = co < P.Cout ? co : P.Cout - 1;
-            sc[r] = scale[co] * inv_scale;
-            sh[r] = shift[co];
+            scq[r] = scale[co] * inv_scale;
+            shq[r] = shift[co];
         }
+    };
+    if constexpr (RES == 1) {
+#pragma unroll
+        for (int q = 0; q < CO_FR; ++q) load_affine(q, sc[q], sh[q]);
+    }
+    unsigned ymax = 0u;                                    // max |y| as a bit pattern (non-negative floats order as integers)
+#pragma unroll
+    for (int q = 0; q < CO_FR; ++q) {
+        float (&scq)[16] = sc[RES == 1 ? q : 0];
+        float (&shq)[16] = sh[RES == 1 ? q : 0];
+        if constexpr (RES != 1) load_affine(q, scq, shq);
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
-            float rv[4][PO_FR];
+            const int step = q * 4 + r4;
+            float (&rv)[4][PO_FR] = (step & 1) ? rvb : rva;
+            if constexpr (RES == 1) {
+                if (step + 1 < 4 * CO_FR) load_res(step + 1, (step & 1) ? rva : rvb);
+            } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+                for (int k = 0; k < 4; ++k)
 #pragma unroll
-                for (int f = 0; f < PO_FR; ++f) {
-                    rv[k][f] = 0.0f;
-                    const bool cok = !CHECK_CO || cbase + q * 32 + k + 8 * r4 < P.Cout;
-                    if (P.res)                                  // uniform
-                        rv[k][f] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                            rs_r, cok ? vo[f] : kOOB, (q * 32 + k + 8 * r4) * cstride4, 0));
-                }
+                    for (int f = 0; f < PO_FR; ++f) rv[k][f] = 0.0f;
+                if (RES == 2 && has_res) load_res(step, rv);            // uniform
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int r = 4 * r4 + k;
 #pragma unroll
                 for (int f = 0; f < PO_FR; ++f) {
-                    float v = acc[q][f][r] * sc[r] + sh[r];
+                    float v = acc[q][f][r] * scq[r] + shq[r];
                     v += rv[k][f];
                     v = apply_act(v, slope);
                     const bool cok = !CHECK_CO || cbase + q * 32 + k + 8 * r4 < P.Cout;
@@ -595,7 +626,8 @@ __global__ __launch_bounds__(256, MW) void conv3d_kernel(ConvParams P) {
 // LDS: 2 x 64 B of pieces per halo element (up to 1280 elements: 512-position boxes).
 // ---------------------------------------------------------------------------------------------
 // FUSE: 0 = plain, 1 = fused 1x1x1 head (pred_epilogue), 2 = fused 1x1x1 shortcut (second accumulator set)
-template <int KS, int S, int WCO, int CO_FR, int PO_FR, int NA, int FUSE = 0>
+// RES: residual known at compile time (0 = none, 1 = present) or checked at run time (2), see conv_epilogue
+template <int KS, int S, int WCO, int CO_FR, int PO_FR, int NA, int FUSE = 0, int RES = 2>
 __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
 #if defined(__HIP_DEVICE_COMPILE__)
     // KS = 1: the "halo box" is the output box itself (positions gathered with stride S), one tap
@@ -952,17 +984,17 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
         }
         if constexpr (FUSE == 1) {                              // 32-channel conv with the fused 1x1x1 head
             static_assert(KS == 3 && S == 1 && WCO == 1 && CO_FR == 1, "the fused head rides on a 32-channel tile");
-            conv_epilogue<CO_FR, PO_FR, true, true>(P, acc, poff, co0, half, T.b, inv_scale);
+            conv_epilogue<CO_FR, PO_FR, true, true, RES>(P, acc, poff, co0, half, T.b, inv_scale);
             pred_epilogue<PO_FR>(P, acc, wpo * PO_FR * 32, lane, T.b, T.t0, T.h0, T.w0);
         } else {
-            conv_epilogue<CO_FR, PO_FR, true>(P, acc, poff, co0, half, T.b, inv_scale);   // Cout need not fill the last channel tile
+            conv_epilogue<CO_FR, PO_FR, true, false, RES>(P, acc, poff, co0, half, T.b, inv_scale);   // Cout need not fill the last channel tile
         }
         if constexpr (SC) {                                     // shortcut: bn_d(conv_d x), no activation, no residual
             ConvParams Q = P;
             Q.scale = P.sc_scale; Q.shift = P.sc_shift; Q.res = nullptr; Q.y = P.sc_y; Q.act = V2CE_ACT_NONE;
             Q.y_absmax = nullptr;
             const float wd_scale = reinterpret_cast<const float *>(P.sc_w + 2 * wplane_d)[1];
-            conv_epilogue<CO_FR, PO_FR, true>(Q, accd, poff, co0, half, T.b, 1.0f / (x_scale * wd_scale));
+            conv_epilogue<CO_FR, PO_FR, true, false, 0>(Q, accd, poff, co0, half, T.b, 1.0f / (x_scale * wd_scale));
         }
         if (gc == CG) STAMP(0, 4);
         vb += (int)gridDim.x;
@@ -1199,13 +1231,13 @@ __global__ __launch_bounds__(256) void weights_absmax_kernel(const float *__rest
     if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned *>(tail), __float_as_uint(m));
 }
 
-template <int KS, int S, int WCO, int CO_FR, int PO_FR, int NA, int FUSE = 0>
+template <int KS, int S, int WCO, int CO_FR, int PO_FR, int NA, int FUSE = 0, int RES = 2>
 int launch_f16x2_ws(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream) {
     static_assert(27 % NA == 0 && NA >= 2, "the A-fragment ring must divide the 27 taps");
     constexpr int CO_TILE = WCO * CO_FR * 32, POS_TILE = (4 / WCO) * PO_FR * 32;
     constexpr int MAX_PLANE = 1280;         // 128 B of LDS per halo element; 5 elements per producer lane
     if (g_name_out) {
-        snprintf(g_name_out, g_name_cap, "conv3d_f16x2_ws_kernel<%d,%d,%d,%d,%d,%d,%d>", KS, S, WCO, CO_FR, PO_FR, NA, FUSE);
+        snprintf(g_name_out, g_name_cap, "conv3d_f16x2_ws_kernel<%d,%d,%d,%d,%d,%d,%d,%d>", KS, S, WCO, CO_FR, PO_FR, NA, FUSE, RES);
         return V2CE_OK;
     }
     Tile t{d.tile_t, d.tile_h, d.tile_w};
@@ -1228,7 +1260,7 @@ int launch_f16x2_ws(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream)
     const int chs = (P.plane + 63) & ~63;
     const size_t lds = (size_t)chs * (2 * 4 * 16);
     V2CE_REQUIRE(lds <= 160 * 1024, V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd(f16x2 ws): %zu B of LDS", lds);
-    auto kern = conv3d_f16x2_ws_kernel<KS, S, WCO, CO_FR, PO_FR, NA, FUSE>;
+    auto kern = conv3d_f16x2_ws_kernel<KS, S, WCO, CO_FR, PO_FR, NA, FUSE, RES>;
     V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 #ifdef V2CE_STAMP
@@ -1429,18 +1461,23 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
         if (s == 1) {
             // measured (tools/conv_bench.py, TF-equivalent): 128 channels x 256 positions per workgroup
             // 390-450; 64 x 512: 370-430 (64 x 256: 248-358); 32 x 512: 300-350 (32 x 256: 114-205)
-            if (small_co && P.pred_w) return launch_f16x2_ws<3, 1, 1, 1, 4, 3, 1>(P, d, st);
-            if (small_co && P.sc_w) return launch_f16x2_ws<3, 1, 1, 1, 4, 3, 2>(P, d, st);
-            if (small_co) return launch_f16x2_ws<3, 1, 1, 1, 4, 3>(P, d, st);
-            if (d.Cout >= 128) return launch_f16x2_ws<3, 1, 2, 2, 4, 3>(P, d, st);
-            return launch_f16x2_ws<3, 1, 1, 2, 4, 3>(P, d, st);
+            // no residual: a compile-time property (conv_epilogue RES 0: +2-6 %); with a residual the pipelined
+            // form (RES 1) pays on the 32-channel tiles only (+3 %; the two-fragment-row tiles lose 6-12 % to its
+            // registers), the others keep the run-time form
+#define V2CE_WS_RES(R_, ...) (P.res ? launch_f16x2_ws<__VA_ARGS__, R_>(P, d, st) : launch_f16x2_ws<__VA_ARGS__, 0>(P, d, st))
+            if (small_co && P.pred_w) return V2CE_WS_RES(1, 3, 1, 1, 1, 4, 3, 1);
+            if (small_co && P.sc_w) return launch_f16x2_ws<3, 1, 1, 1, 4, 3, 2, 0>(P, d, st);
+            if (small_co) return V2CE_WS_RES(1, 3, 1, 1, 1, 4, 3, 0);
+            if (d.Cout >= 128) return V2CE_WS_RES(2, 3, 1, 2, 2, 4, 3, 0);
+            return V2CE_WS_RES(2, 3, 1, 1, 2, 4, 3, 0);
+#undef V2CE_WS_RES
         }
         // stride 2: the halo box is ~4x the output box, so 128-position boxes; one 32-channel fragment
         // row per wave measured best (Cout >= 128: 300-320; Cout = 64: 245)
         if (P.sc_w) {
-            if (d.Cout >= 128) return launch_f16x2_ws<3, 2, 4, 1, 4, 3, 2>(P, d, st);
-            if (!small_co) return launch_f16x2_ws<3, 2, 2, 1, 2, 3, 2>(P, d, st);
-            return launch_f16x2_ws<3, 2, 1, 1, 1, 3, 2>(P, d, st);
+            if (d.Cout >= 128) return launch_f16x2_ws<3, 2, 4, 1, 4, 3, 2, 0>(P, d, st);
+            if (!small_co) return launch_f16x2_ws<3, 2, 2, 1, 2, 3, 2, 0>(P, d, st);
+            return launch_f16x2_ws<3, 2, 1, 1, 1, 3, 2, 0>(P, d, st);
         }
         if (d.Cout >= 128) return launch_f16x2_ws<3, 2, 4, 1, 4, 3>(P, d, st);
         if (!small_co) return launch_f16x2_ws<3, 2, 2, 1, 2, 3>(P, d, st);
@@ -1579,7 +1616,9 @@ extern "C" int v2ce_pack_pred_weights_f16x2(const float *w, int cout, int cin, v
     return V2CE_OK;
 }
 
-extern "C" int v2ce_conv3d_variant_fused(const v2ce_conv3d_desc *desc, int mapped, int fuse, char *name, size_t cap) {
+extern "C" int v2ce_conv3d_variant_fused(const v2ce_conv3d_desc *desc, int mapped, int fuse_in, char *name, size_t cap) {
+    const int fuse = fuse_in & 3;
+    const bool with_res = (fuse_in & 4) != 0;
     V2CE_REQUIRE(name && cap > 0, V2CE_ERR_BAD_ARG, "v2ce_conv3d_variant: no buffer");
     name[0] = '\0';
     g_name_out = name;
@@ -1587,7 +1626,7 @@ extern "C" int v2ce_conv3d_variant_fused(const v2ce_conv3d_desc *desc, int mappe
     static const int32_t dummy_map = 0;
     static const float dummy = 0.0f;
     const int32_t *m = mapped ? &dummy_map : nullptr;
-    const int rc = conv3d_dispatch(desc, nullptr, nullptr, m, m, nullptr, nullptr, nullptr, nullptr,
+    const int rc = conv3d_dispatch(desc, nullptr, nullptr, m, m, nullptr, nullptr, nullptr, with_res ? &dummy : nullptr,
                                    nullptr, nullptr, nullptr, nullptr, nullptr,
                                    fuse == 1 ? &dummy : nullptr, fuse == 1 ? &dummy : nullptr, fuse == 1 ? 1 : 0,
                                    fuse == 1 ? const_cast<float *>(&dummy) : nullptr,

@@ -360,7 +360,8 @@ class V2ce3d(nn.Module):
                 flops += 2.0 * B * T * Hout * Wout * pred[2] * cout
             if sc is not None:
                 flops += 2.0 * B * T * Hout * Wout * cout * (C0 + C1)
-            prof.append((hip.conv_variant(d, hmap is not None, 1 if pred is not None else (2 if sc is not None else 0)),
+            prof.append((hip.conv_variant(d, hmap is not None, (1 if pred is not None else (2 if sc is not None else 0)) +
+                                          (4 if residual is not None else 0)),
                          flops, e0, e1))
         if sc is not None:
             return y, y_sc
