@@ -174,7 +174,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &P, f32x16 (&acc)
     };
     float rva[4][PO_FR], rvb[4][PO_FR];
     if constexpr (RES == 1) load_res(0, rva);
-    float sc[RES == 1 ? CO_FR : 1][16], sh[RES == 1 ? CO_FR : 1][16];
+    constexpr bool HOIST = RES == 1 && CO_FR == 1;
+    float sc[HOIST ? CO_FR : 1][16], sh[HOIST ? CO_FR : 1][16];
     auto load_affine = [&](int q, float (&scq)[16], float (&shq)[16]) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -184,16 +185,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &P, f32x16 (&acc)
             shq[r] = shift[co];
         }
     };
-    if constexpr (RES == 1) {
+    if constexpr (HOIST) {
 #pragma unroll
         for (int q = 0; q < CO_FR; ++q) load_affine(q, sc[q], sh[q]);
     }
     unsigned ymax = 0u;                                    // max |y| as a bit pattern (non-negative floats order as integers)
 #pragma unroll
     for (int q = 0; q < CO_FR; ++q) {
-        float (&scq)[16] = sc[RES == 1 ? q : 0];
-        float (&shq)[16] = sh[RES == 1 ? q : 0];
-        if constexpr (RES != 1) load_affine(q, scq, shq);
+        float (&scq)[16] = sc[HOIST ? q : 0];
+        float (&shq)[16] = sh[HOIST ? q : 0];
+        if constexpr (!HOIST) load_affine(q, scq, shq);
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
             const int step = q * 4 + r4;
