@@ -64,20 +64,24 @@ def run(name, B=4, T=16, iters=5, tile=(0, 0, 0)):
         res = torch.randn_like(y)
 
     res_plain = torch.randn_like(y) if os.environ.get("RES") else None      # RES=1: with a residual (the blocks' conv2)
+    track = bool(os.environ.get("TRACK"))                                    # TRACK=1: range tracking like in the network
+    ax0 = x0.abs().max().reshape(1) if track else None
+    ax1 = x1.abs().max().reshape(1) if track and x1 is not None else None
+    ay = torch.zeros(2, device=dev) if track else None
 
     def call():
         if fuse == "sc":
             hip.check(lib.v2ce_conv3d_fwd_sc(ctypes.byref(d), x0.data_ptr(), hip.ptr(x1), hip.ptr(hmap), hip.ptr(wmap),
-                                             w.data_ptr(), sc.data_ptr(), sh.data_ptr(), y.data_ptr(), None, None, None,
+                                             w.data_ptr(), sc.data_ptr(), sh.data_ptr(), y.data_ptr(), hip.ptr(ax0), hip.ptr(ax1), hip.ptr(ay),
                                              wd.data_ptr(), sc.data_ptr(), sh.data_ptr(), ysc.data_ptr(), hip.stream_ptr()), "conv_sc")
         elif fuse == "pred":
             hip.check(lib.v2ce_conv3d_fwd_pred(ctypes.byref(d), x0.data_ptr(), hip.ptr(x1), hip.ptr(hmap), hip.ptr(wmap),
-                                               w.data_ptr(), sc.data_ptr(), sh.data_ptr(), res.data_ptr(), None, None, None, None,
+                                               w.data_ptr(), sc.data_ptr(), sh.data_ptr(), res.data_ptr(), None, hip.ptr(ax0), hip.ptr(ax1), hip.ptr(ay),
                                                tab.data_ptr(), pb.data_ptr(), 20, yp.data_ptr(), hip.stream_ptr()), "conv_pred")
         else:
             hip.check(lib.v2ce_conv3d_fwd(ctypes.byref(d), x0.data_ptr(), hip.ptr(x1), hip.ptr(hmap), hip.ptr(wmap),
                                           w.data_ptr(), sc.data_ptr(), sh.data_ptr(), hip.ptr(res_plain), y.data_ptr(),
-                                          None, None, None, hip.stream_ptr()), "conv")
+                                          hip.ptr(ax0), hip.ptr(ax1), hip.ptr(ay), hip.stream_ptr()), "conv")
     call()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
