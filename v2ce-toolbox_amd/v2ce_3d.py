@@ -259,12 +259,12 @@ class V2ce3d(nn.Module):
     def _split(self, cin, cout, ksize=3, stride=1) -> bool:
         """Split-half arithmetic for a conv of a residual block?  All of them have Cin % 16 == 0 and
         Cout % 32 == 0.  Every 3x3x3 conv; of the 1x1x1 shortcuts the strided ones and those with
-        >= 128 output channels (measured: 0.21 vs 0.35 ms, strided 0.12 vs 0.35); the two stride-1
-        shortcuts with 64 / 32 output channels are HBM-bound and faster on the exact-f32 kernel
-        (0.35 vs 0.47, 0.49 vs 0.81 ms)."""
+        >= 64 output channels (measured: >= 128 channels 0.21 vs 0.35 ms, strided 0.12 vs 0.35, the 192 -> 64
+        one 0.40 vs 0.53 since the epilogue rework); only a 32-channel stride-1 shortcut (fused into conv1
+        in this network anyway) is faster on the exact-f32 kernel."""
         if self.precision != "f16x2":
             return False
-        return ksize == 3 or stride == 2 or cout >= 128
+        return ksize == 3 or stride == 2 or cout >= 64
 
     def _fuse_shortcut(self, blk) -> bool:
         """Ride the block's 1x1x1 shortcut on conv1's launch (v2ce_conv3d_fwd_sc)?  Possible where conv1's
