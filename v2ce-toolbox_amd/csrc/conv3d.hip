@@ -1469,7 +1469,21 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
             if (small_co && P.pred_w) return V2CE_WS_RES(1, 3, 1, 1, 1, 4, 3, 1);
             if (small_co && P.sc_w) return launch_f16x2_ws<3, 1, 1, 1, 4, 3, 2, 0>(P, d, st);
             if (small_co) return V2CE_WS_RES(1, 3, 1, 1, 1, 4, 3, 0);
-            if (d.Cout >= 128) return V2CE_WS_RES(2, 3, 1, 2, 2, 4, 3, 0);
+            if (d.Cout >= 128) {
+                // 256- or 192-position boxes (4 or 3 position fragments per wave): whichever needs fewer
+                // (workgroup rounds x box size).  17x22 planes: (16,2,8) boxes use 87 % of the MFMA lanes and
+                // 448 virtual blocks are 1.75 rounds over 256 CUs; (1,17,11) boxes use 97 % and make exactly 2
+                // rounds of 3/4 the size: 25 % less MFMA time on the five 512-channel launches
+                auto cost = [&](int pos_tile) {
+                    const Tile t = choose_tile(d.T, d.Hout, d.Wout, 3, 1, pos_tile, 1280);
+                    const long long nsp = (long long)d.B * ((d.T + t.tt - 1) / t.tt) * ((d.Hout + t.th - 1) / t.th) *
+                                          ((d.Wout + t.tw - 1) / t.tw);
+                    const long long blocks = 8 * ((nsp + 7) / 8) * ((d.Cout + 127) / 128);
+                    return ((blocks + 255) / 256) * pos_tile;
+                };
+                if (d.tile_t <= 0 && cost(192) < cost(256)) return V2CE_WS_RES(2, 3, 1, 2, 2, 3, 3, 0);
+                return V2CE_WS_RES(2, 3, 1, 2, 2, 4, 3, 0);
+            }
             return V2CE_WS_RES(2, 3, 1, 1, 2, 4, 3, 0);
 #undef V2CE_WS_RES
         }
