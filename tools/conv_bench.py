@@ -15,6 +15,7 @@ LAYERS = {   # name: (C0, lvl0, C1, lvl_in, Cout, ksize, stride)
     "enc0.conv2": (64, 1, 0, 1, 64, 3, 1), "enc1.conv1": (64, 1, 0, 1, 128, 3, 2),
     "res0.conv1": (512, 4, 0, 4, 512, 3, 1), "enc0.conv1": (32, 0, 0, 0, 64, 3, 2), "enc3.conv1": (256, 3, 0, 3, 512, 3, 2), "dec1.conv1": (256, 3, 128, 2, 128, 3, 1),
     "dec2.conv1": (128, 2, 64, 1, 64, 3, 1), "dec0.conv1": (512, 4, 256, 3, 256, 3, 1), "dec1.conv2": (128, 2, 0, 2, 128, 3, 1),
+    "enc2.conv1": (128, 2, 0, 2, 256, 3, 2), "enc2.conv2": (256, 3, 0, 3, 256, 3, 1), "enc1.conv2": (128, 2, 0, 2, 128, 3, 1),
     "dec3.conv1": (64, 1, 32, 0, 32, 3, 1), "dec3.conv2": (32, 0, 0, 0, 32, 3, 1),
     "dec2.down": (128, 2, 64, 1, 64, 1, 1), "dec1.down": (256, 3, 128, 2, 128, 1, 1), "res0.down": (512, 4, 0, 4, 512, 1, 1),
     "enc1.down": (64, 1, 0, 1, 128, 1, 2), "enc3.down": (256, 3, 0, 3, 512, 1, 2), "dec3.down": (64, 1, 32, 0, 32, 1, 1), "pred": (32, 0, 0, 0, 20, 1, 1), "enc0.down": (32, 0, 0, 0, 64, 1, 2),

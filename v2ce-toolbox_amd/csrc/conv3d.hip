@@ -1162,6 +1162,21 @@ Tile choose_tile(int T, int Ho, int Wo, int ks, int s, int pos_tile, int max_pla
     return best;
 }
 
+// Box override for in-network sweeps (tools/box_sweep.py): V2CE_BOX_<Ho>x<Wo>_<stride>_<positions>=tt,th,tw.
+// Sweeps of 5-6 candidate boxes per layer class INSIDE the network (bench.py, +-0.05 ms of 23.7 ms per step)
+// found the lane-efficiency search's choices within noise of the best everywhere -- while the same candidates
+// timed on isolated layers (tools/tile_probe.py: one kernel in a loop, inputs resident in L2, another power
+// state) had differed by 8-16 % and ranked the other way round on the 130x173 layers.  No table, therefore.
+Tile measured_box(int T, int Ho, int Wo, int s, int pos_tile) {
+    char key[64];
+    snprintf(key, sizeof key, "V2CE_BOX_%dx%d_%d_%d", Ho, Wo, s, pos_tile);
+    if (const char *e = getenv(key)) {
+        Tile t{0, 0, 0};
+        if (sscanf(e, "%d,%d,%d", &t.tt, &t.th, &t.tw) == 3 && t.tt > 0 && t.th > 0 && t.tw > 0 && t.tt * t.th * t.tw <= pos_tile) return t;
+    }
+    return Tile{0, 0, 0};
+}
+
 thread_local char *g_name_out = nullptr;   // non-null: report the variant instead of launching
 thread_local size_t g_name_cap = 0;
 
@@ -1242,7 +1257,13 @@ int launch_f16x2_ws(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream)
         return V2CE_OK;
     }
     Tile t{d.tile_t, d.tile_h, d.tile_w};
-    if (t.tt <= 0 || t.th <= 0 || t.tw <= 0) t = choose_tile(d.T, d.Hout, d.Wout, KS, KS == 1 ? 1 : S, POS_TILE, MAX_PLANE);
+    if (t.tt <= 0 || t.th <= 0 || t.tw <= 0) {
+        t = choose_tile(d.T, d.Hout, d.Wout, KS, KS == 1 ? 1 : S, POS_TILE, MAX_PLANE);
+        if (KS == 3) {
+            const Tile m = measured_box(d.T, d.Hout, d.Wout, S, POS_TILE);
+            if (m.tt > 0) t = m;
+        }
+    }
     P.TT = t.tt; P.TH = t.th; P.TW = t.tw;
     P.n_pos = t.tt * t.th * t.tw;
     if (KS == 1) { P.HT = t.tt; P.HH = t.th; P.HWd = t.tw; }          // the gathered box is the output box
@@ -1481,7 +1502,8 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
                     const long long blocks = 8 * ((nsp + 7) / 8) * ((d.Cout + 127) / 128);
                     return ((blocks + 255) / 256) * pos_tile;
                 };
-                if (d.tile_t <= 0 && cost(192) < cost(256)) return V2CE_WS_RES(2, 3, 1, 2, 2, 3, 3, 0);
+                const bool po3 = d.tile_t > 0 ? d.tile_t * d.tile_h * d.tile_w <= 192 : cost(192) < cost(256);
+                if (po3) return V2CE_WS_RES(2, 3, 1, 2, 2, 3, 3, 0);
                 return V2CE_WS_RES(2, 3, 1, 2, 2, 4, 3, 0);
             }
             return V2CE_WS_RES(2, 3, 1, 1, 2, 4, 3, 0);
