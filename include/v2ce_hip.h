@@ -178,7 +178,18 @@ typedef struct {
      * of 32 floats the 32-position pieces a wave stores / gathers are whole 128-byte cache lines: the store
      * path is 1.75x faster than on rows of 346 floats (tools/micro/store_rate.hip). */
     int32_t W0_pitch, Win_pitch, Wout_pitch;
+    /* Activation layout of x0, x1, y, residual and sc_y (pred_y is always planar):
+     *   V2CE_LAYOUT_PLANAR  [B][T][C][H][pitch]           -- the reference's own layout; exact-f32 kernels
+     *   V2CE_LAYOUT_C16     [B][T][C/16][H][pitch][16]    -- channel groups of 16 innermost; split-half kernels
+     * The split-half kernels REQUIRE C16 (all channel counts are multiples of 16 there): a 16-channel chunk of a
+     * halo element is then one 64-byte cache line (four 16-byte loads instead of sixteen dword loads from sixteen
+     * planes), and a lane's four consecutive output channels are one 16-byte store: -5.8 % on the forward pass.
+     * The exact-f32 kernels require PLANAR, with one bridge: the 2-channel head convolution (C0 == 2, Cout == 32,
+     * 3x3x3) reads the planar network input and writes y in the layout named here. */
+    int32_t layout;
 } v2ce_conv3d_desc;
+#define V2CE_LAYOUT_PLANAR 0
+#define V2CE_LAYOUT_C16 1
 
 /* V2CE_PRECISION_F16X2 (3x3x3 kernels, channel counts multiples of 16): every operand is split into
  * two fp16 numbers (22 bits) and each k-step is three v_mfma_f32_32x32x16_f16 with f32 accumulation;

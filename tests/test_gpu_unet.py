@@ -202,13 +202,15 @@ def hip_conv_split(x0, w, scale, shift, stride, act, x1=None, up_to=None, residu
         x0d.absmax = x0d.abs().max().reshape(1)
         if x1d is not None:
             x1d.absmax = x1d.abs().max().reshape(1)
-    y = V2ce3d._conv(m, x0d, x1d, wq,
+    # the split-half kernels take and produce the channels-last-16 layout
+    c16 = V2ce3d.to_c16
+    y = V2ce3d._conv(m, c16(x0d), None if x1d is None else c16(x1d), wq,
                      scale.cuda().contiguous(), shift.cuda().contiguous(), w.shape[0], ksize, stride, act,
-                     residual=None if residual is None else to_btchw(residual).cuda(), up_to=up_to,
+                     residual=None if residual is None else c16(to_btchw(residual).cuda()), up_to=up_to,
                      split=True, dense_out=True)
     torch.cuda.synchronize()
     hip_conv_split.guard = float(y.absmax[1])               # the launch's range-guard bound
-    return y.permute(0, 2, 1, 3, 4).cpu().numpy()
+    return V2ce3d.to_planar(y).permute(0, 2, 1, 3, 4).cpu().numpy()
 
 
 SPLIT_CASES = [
@@ -440,7 +442,8 @@ def test_conv3d_records_output_absmax():
         xd = to_btchw(x).cuda()
         xd.absmax = xd.abs().max().reshape(1)
         wp = V2ce3d._pack(m, w.cuda().contiguous(), split=split)
-        y = V2ce3d._conv(m, xd, None, wp, torch.ones(32).cuda(), torch.zeros(32).cuda(), 32, 3, 1, 2, split=split, track=True)
+        y = V2ce3d._conv(m, V2ce3d.to_c16(xd) if split else xd, None, wp, torch.ones(32).cuda(), torch.zeros(32).cuda(), 32, 3, 1, 2,
+                         split=split, track=True, dense_out=True)
         assert float(y.absmax[0]) == float(y.abs().max())
 
 
@@ -596,10 +599,38 @@ def test_conv3d_row_pitch(split):
                 a0.absmax = torch.nan_to_num(a0).abs().max().reshape(1)
                 if a1 is not None:
                     a1.absmax = torch.nan_to_num(a1).abs().max().reshape(1)
+                a0, a1, r = (None if v is None else V2ce3d.to_c16(v) for v in (a0, a1, r))   # padding columns travel along
             y = V2ce3d._conv(m, a0, a1, wp, scale, shift, cout, k, s, hip.ACT_RELU, residual=r,
                              up_to=(H, W) if c1 else None, split=split, track=True, dense_out=not padded)
-            assert y.shape[-1] == (V2ce3d._pitch(Wo) if padded else Wo) and y.lw == Wo
-            outs.append((y[..., :Wo].contiguous(), float(y.absmax[0])))
+            assert y.shape[4] == (V2ce3d._pitch(Wo) if padded else Wo) and y.lw == Wo
+            outs.append((V2ce3d.to_planar(y).contiguous(), float(y.absmax[0])))
         assert not torch.isnan(outs[1][0]).any()
         assert torch.equal(outs[0][0], outs[1][0]), (c0, c1, cout, k, s)
         assert outs[0][1] == outs[1][1] == float(outs[0][0].abs().max())
+
+
+@pytest.mark.parametrize("case", [(32, 64, 2, 19, 23), (64, 128, 2, 9, 14), (96, 32, 1, 12, 40), (256, 512, 2, 7, 9)])
+def test_conv3d_fused_shortcut_vs_f64(case):
+    """v2ce_conv3d_fwd_sc: the block's conv1 (3x3x3, BN, ReLU) and its 1x1x1 shortcut (BN, no activation) from
+    one launch, against the two convolutions evaluated separately in f64."""
+    from v2ce_toolbox_amd import hip
+    from v2ce_toolbox_amd.v2ce_3d import V2ce3d
+    cin, cout, s, H, W = case
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(2, cin, 3, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) * (2.0 / (cin * 27)) ** 0.5
+    wd = torch.randn(cout, cin, 1, 1, 1, generator=g) * (1.0 / cin) ** 0.5
+    sc1, sh1 = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    sc2, sh2 = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    m = V2ce3d.__new__(V2ce3d)
+    torch.nn.Module.__init__(m)
+    m._maps, m.precision, m._slot = {}, "f16x2", 0
+    m._prep = {"absmax": torch.zeros((4, 2), device="cuda")}
+    xd = to_btchw(x).cuda()
+    xd.absmax = xd.abs().max().reshape(1)
+    y, ysc = V2ce3d._conv(m, V2ce3d.to_c16(xd), None, V2ce3d._pack(m, w.cuda().contiguous(), split=True),
+                          sc1.cuda(), sh1.cuda(), cout, 3, s, hip.ACT_RELU, split=True, dense_out=True,
+                          sc=(V2ce3d._pack(m, wd.cuda().contiguous(), split=True), sc2.cuda(), sh2.cuda()))
+    torch.cuda.synchronize()
+    assert_close(V2ce3d.to_planar(y).permute(0, 2, 1, 3, 4).cpu().numpy(), ref_conv(x, w, sc1, sh1, 3, s, 1), "conv1")
+    assert_close(V2ce3d.to_planar(ysc).permute(0, 2, 1, 3, 4).cpu().numpy(), ref_conv(x, wd, sc2, sh2, 1, s, 0), "shortcut")

@@ -47,7 +47,7 @@ def run(name, B=4, T=16, iters=5, tile=(0, 0, 0)):
     y = torch.empty(B, T, Cout, Ho, Wo, device=dev)
     d = hip.ConvDesc(B=B, T=T, C0=C0, H0=H0, W0=W0, C1=C1, Hin=Hin, Win=Win, Cout=Cout, Hout=Ho, Wout=Wo,
                      ksize=k, stride_hw=s, act=1, tile_t=tile[0], tile_h=tile[1], tile_w=tile[2],
-                     precision=1 if split else 0)
+                     precision=1 if split else 0, layout=1 if split else 0)   # same bytes, random data: only the layout flag differs
     lib = hip.lib()
 
     fuse = os.environ.get("FUSE", "") if split and k == 3 else ""

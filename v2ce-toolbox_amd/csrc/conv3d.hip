@@ -51,6 +51,8 @@ struct ConvParams {
     float *y;
     int B, T, C0, H0, W0, C1, Hin, Win, Cin, Cout, Hout, Wout;
     int W0p, Winp, Woutp;         // row pitches (floats) of x0, x1 and of y / residual / sc_y (>= the logical widths)
+    int c16;                      // activation layout of x0, x1, y, residual, sc_y: 0 = planar [B][T][C][H][Wp],
+                                  // 1 = channel groups of 16 innermost [B][T][C/16][H][Wp][16] (V2CE_LAYOUT_C16)
     int act;
     int TT, TH, TW;       // output box
     int nT, nH, nW;       // boxes per dimension
@@ -140,14 +142,19 @@ __device__ __forceinline__ float apply_act(float t, float slope) { return fmaxf(
 // dec3.conv1).  RES 0 has no wait inside the loop; RES 1 issues the loads of batch i+1 in front of the stores
 // of batch i (and all scale / shift loads in front of everything), so a wait covers only stores that are two
 // batches old.
-template <int CO_FR, int PO_FR, bool CHECK_CO = false, bool KEEP = false, int RES = 2>
+// C16: y / residual in the channels-last-16 layout; poff[f] is then the BYTE offset of the position's 64-byte
+// group inside channel group 0 of its time step (or < 0), and the four channels (r & 3) a lane holds per r >> 2
+// are 16 contiguous bytes: one 16-byte store / residual load per (r >> 2, fragment) instead of four dwords.
+template <int CO_FR, int PO_FR, bool CHECK_CO = false, bool KEEP = false, int RES = 2, bool C16 = false>
 __device__ __forceinline__ void conv_epilogue(const ConvParams &P, f32x16 (&acc)[CO_FR][PO_FR],
                                               const int (&poff)[PO_FR], int co0, int half, int b,
                                               float inv_scale) {
+    typedef float f32x4q __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x4q __attribute__((ext_vector_type(4)));
     const float *__restrict__ scale = P.scale;
     const float *__restrict__ shift = P.shift;
     const long long seq = (long long)P.T * P.Cout * (P.Hout * P.Woutp);
-    const int cstride4 = P.Hout * P.Woutp * 4;
+    const int cstride4 = P.Hout * P.Woutp * 4;             // planar: bytes between channels; C16: x 16 = bytes between groups
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(P.y ? P.y + b * seq : const_cast<float *>(P.scale), 0,
                                                                           P.y ? (int)(seq * 4) : 0, 0x00020000);
     const bool has_res = RES == 1 || (RES == 2 && P.res != nullptr);
@@ -158,19 +165,34 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &P, f32x16 (&acc)
     unsigned vo[PO_FR], vmask[PO_FR];
 #pragma unroll
     for (int f = 0; f < PO_FR; ++f) {
-        vo[f] = poff[f] >= 0 ? (unsigned)(poff[f] * 4 + cbase * cstride4) : kOOB;
+        if (C16) vo[f] = poff[f] >= 0 ? (unsigned)(poff[f] + 16 * half) : kOOB;
+        else vo[f] = poff[f] >= 0 ? (unsigned)(poff[f] * 4 + cbase * cstride4) : kOOB;
         vmask[f] = poff[f] >= 0 ? 0x7fffffffu : 0u;        // |v| of a masked lane counts as 0
     }
+    // scalar (wave-uniform) byte offset of batch (q, r4) = channels cbase + 32 q + 8 r4 + {0..3}
+    auto soff = [&](int q, int r4, int k) -> int {
+        if (C16) return (co0 / 16 + 2 * q + (r4 >> 1)) * (cstride4 * 16) + 32 * (r4 & 1);
+        return (q * 32 + k + 8 * r4) * cstride4;
+    };
     auto load_res = [&](int step, float (&rv)[4][PO_FR]) {  // batch `step` = (q, r4): 4 channels x PO_FR positions
         const int q = step >> 2, r4 = step & 3;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
+        if constexpr (C16) {
+            const bool cok = !CHECK_CO || co0 + q * 32 + 8 * r4 < P.Cout;
 #pragma unroll
             for (int f = 0; f < PO_FR; ++f) {
-                const bool cok = !CHECK_CO || cbase + q * 32 + k + 8 * r4 < P.Cout;
-                rv[k][f] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                    rs_r, cok ? vo[f] : kOOB, (q * 32 + k + 8 * r4) * cstride4, 0));
+                const f32x4q v = __builtin_bit_cast(f32x4q, __builtin_amdgcn_raw_buffer_load_b128(rs_r, cok ? vo[f] : kOOB, soff(q, r4, 0), 0));
+                rv[0][f] = v[0]; rv[1][f] = v[1]; rv[2][f] = v[2]; rv[3][f] = v[3];
             }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int f = 0; f < PO_FR; ++f) {
+                    const bool cok = !CHECK_CO || cbase + q * 32 + k + 8 * r4 < P.Cout;
+                    rv[k][f] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                        rs_r, cok ? vo[f] : kOOB, soff(q, r4, k), 0));
+                }
+        }
     };
     float rva[4][PO_FR], rvb[4][PO_FR];
     if constexpr (RES == 1) load_res(0, rva);
@@ -208,6 +230,33 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &P, f32x16 (&acc)
                     for (int f = 0; f < PO_FR; ++f) rv[k][f] = 0.0f;
                 if (RES == 2 && has_res) load_res(step, rv);            // uniform
             }
+            if constexpr (C16) {
+                const bool cok = !CHECK_CO || co0 + q * 32 + 8 * r4 < P.Cout;
+#pragma unroll
+                for (int f = 0; f < PO_FR; ++f) {
+                    f32x4q out;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int r = 4 * r4 + k;
+                        float v = acc[q][f][r] * scq[r] + shq[r];
+                        v += rv[k][f];
+                        v = apply_act(v, slope);
+                        out[k] = v;
+                        const unsigned av = __builtin_bit_cast(unsigned, v) & (cok ? vmask[f] : 0u);
+                        if (KEEP) acc[q][f][r] = __builtin_bit_cast(float, av == 0u ? 0u : __builtin_bit_cast(unsigned, v));
+                        ymax = av > ymax ? av : ymax;
+                    }
+                    if (!KEEP || P.y) {                         // uniform: a fused head may not want y itself
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4q, out),
+                                                               rs_y, cok ? vo[f] : kOOB, soff(q, r4, 0), 0);
+                        // A 16-byte store reads its data registers for several cycles after issue; a VALU write to
+                        // them in the next slot corrupts dword 1 of lanes 12-15 / 28-31 (seen on gfx950: the
+                        // compiler's hazard table exempts stores with an SGPR soffset).  The data registers stay
+                        // live through this statement, so nothing can overwrite them before the wait states.
+                        asm volatile("s_nop 1" : "+v"(out));
+                    }
+                }
+            } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int r = 4 * r4 + k;
@@ -219,11 +268,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &P, f32x16 (&acc)
                     const bool cok = !CHECK_CO || cbase + q * 32 + k + 8 * r4 < P.Cout;
                     if (!KEEP || P.y)                           // uniform: a fused head may not want y itself
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, cok ? vo[f] : kOOB,
-                                                              (q * 32 + k + 8 * r4) * cstride4, 0);
+                                                              soff(q, r4, k), 0);
                     const unsigned av = __builtin_bit_cast(unsigned, v) & (cok ? vmask[f] : 0u);
                     if (KEEP) acc[q][f][r] = __builtin_bit_cast(float, av == 0u ? 0u : __builtin_bit_cast(unsigned, v));
                     ymax = av > ymax ? av : ymax;
                 }
+            }
             }
         }
     }
@@ -349,7 +399,9 @@ __device__ __forceinline__ void conv_epilogue_stream(const ConvParams &P, const 
 // byte offsets (relative to the sequence base of the source tensor) of this thread's halo elements;
 // kOOB = zero padding (hardware range check of the buffer load supplies the zero).
 // Element r of the halo plane <-> LDS offset r inside the channel.
-template <int EPT>
+// C16: the same for the channels-last-16 layout -- byte offset of the element's 64-byte channel group inside
+// channel group 0 of its time step (the chunk's group adds (group) * Hs * Ws * 64).
+template <int EPT, bool C16 = false>
 __device__ __forceinline__ void halo_offsets(const ConvParams &P, int tin0, int hin0, int win0,
                                              bool src1, int tid, unsigned (&goff)[EPT], int gs = 1) {
     const int Cs = src1 ? P.C1 : P.C0;
@@ -368,7 +420,8 @@ __device__ __forceinline__ void halo_offsets(const ConvParams &P, int tin0, int 
             if (t >= 0 && t < P.T && h >= 0 && h < P.Hin && w >= 0 && w < P.Win) {
                 const int hs = mapped ? P.hmap[h] : h;
                 const int ws = mapped ? P.wmap[w] : w;
-                off = 4u * (unsigned)((t * Cs) * (Hs * Ws) + hs * Ws + ws);
+                off = C16 ? 4u * (unsigned)((t * Cs) * (Hs * Ws)) + 64u * (unsigned)(hs * Ws + ws)
+                          : 4u * (unsigned)((t * Cs) * (Hs * Ws) + hs * Ws + ws);
             }
         }
         goff[i] = off;
@@ -722,7 +775,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
             const int want_src = ci0 < P.C0 ? 0 : 1;
             if (want_src != cur_src) {   // uniform; at most twice per tile
                 cur_src = want_src;
-                halo_offsets<EPT>(P, L.t0 - PAD, L.h0 * S - PAD, L.w0 * S - PAD, want_src == 1, ptid, goff, GS);
+                halo_offsets<EPT, true>(P, L.t0 - PAD, L.h0 * S - PAD, L.w0 * S - PAD, want_src == 1, ptid, goff, GS);
                 if (want_src == 0) {
                     const long long seq = (long long)P.T * P.C0 * (P.H0 * P.W0p);
                     rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x0 + L.b * seq), 0, (int)(seq * 4), 0x00020000);
@@ -738,10 +791,15 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
 #pragma unroll
             for (int i = 0; i < EPT; ++i) {
                 if ((wave - 4) * 64 + 256 * i < P.plane) {            // wave-uniform
+                    // the chunk is one 16-channel group: the element's 64 bytes in four 16-byte loads (one cache
+                    // line per element; the planar layout needs 16 loads from 16 lines)
+                    typedef float f32x4g __attribute__((ext_vector_type(4)));
 #pragma unroll
-                    for (int ci = 0; ci < CK; ++ci)
-                        R[ci][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                            rs_in, goff[i], (ci0 + ci - src_cbase) * src_cstride4, 0));
+                    for (int k4 = 0; k4 < CK / 4; ++k4) {
+                        const f32x4g v = __builtin_bit_cast(f32x4g, __builtin_amdgcn_raw_buffer_load_b128(
+                            rs_in, goff[i], ((ci0 - src_cbase) / 16) * (src_cstride4 * 16) + 16 * k4, 0));
+                        R[4 * k4][i] = v[0]; R[4 * k4 + 1][i] = v[1]; R[4 * k4 + 2][i] = v[2]; R[4 * k4 + 3][i] = v[3];
+                    }
                 }
             }
         };
@@ -979,23 +1037,23 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
                 const int th = rem / P.TW;
                 const int tw = rem - th * P.TW;
                 const int t = T.t0 + tt, h = T.h0 + th, w = T.w0 + tw;
-                if (t < P.T && h < P.Hout && w < P.Wout)
-                    poff[f] = (t * P.Cout) * (P.Hout * P.Woutp) + h * P.Woutp + w;
+                if (t < P.T && h < P.Hout && w < P.Wout)      // channels-last-16: byte offset of the position's group
+                    poff[f] = 4 * ((t * P.Cout) * (P.Hout * P.Woutp)) + 64 * (h * P.Woutp + w);
             }
         }
         if constexpr (FUSE == 1) {                              // 32-channel conv with the fused 1x1x1 head
             static_assert(KS == 3 && S == 1 && WCO == 1 && CO_FR == 1, "the fused head rides on a 32-channel tile");
-            conv_epilogue<CO_FR, PO_FR, true, true, RES>(P, acc, poff, co0, half, T.b, inv_scale);
+            conv_epilogue<CO_FR, PO_FR, true, true, RES, true>(P, acc, poff, co0, half, T.b, inv_scale);
             pred_epilogue<PO_FR>(P, acc, wpo * PO_FR * 32, lane, T.b, T.t0, T.h0, T.w0);
         } else {
-            conv_epilogue<CO_FR, PO_FR, true, false, RES>(P, acc, poff, co0, half, T.b, inv_scale);   // Cout need not fill the last channel tile
+            conv_epilogue<CO_FR, PO_FR, true, false, RES, true>(P, acc, poff, co0, half, T.b, inv_scale);   // Cout need not fill the last channel tile
         }
         if constexpr (SC) {                                     // shortcut: bn_d(conv_d x), no activation, no residual
             ConvParams Q = P;
             Q.scale = P.sc_scale; Q.shift = P.sc_shift; Q.res = nullptr; Q.y = P.sc_y; Q.act = V2CE_ACT_NONE;
             Q.y_absmax = nullptr;
             const float wd_scale = reinterpret_cast<const float *>(P.sc_w + 2 * wplane_d)[1];
-            conv_epilogue<CO_FR, PO_FR, true, false, 0>(Q, accd, poff, co0, half, T.b, 1.0f / (x_scale * wd_scale));
+            conv_epilogue<CO_FR, PO_FR, true, false, 0, true>(Q, accd, poff, co0, half, T.b, 1.0f / (x_scale * wd_scale));
         }
         if (gc == CG) STAMP(0, 4);
         vb += (int)gridDim.x;
@@ -1115,18 +1173,43 @@ __global__ __launch_bounds__(256) void conv3d_head_kernel(ConvParams P) {
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(P.y + b * seq, 0, (int)(seq * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(P.res ? P.res + b * seq : P.scale), 0, P.res ? (int)(seq * 4) : 0, 0x00020000);
-    const unsigned vo = ok ? (unsigned)(((t * P.Cout) * hw + h * P.Woutp + w) * 4) : kOOB;
     const float slope = act_slope(P.act);
     const float *__restrict__ scale = P.scale;
     const float *__restrict__ shift = P.shift;
     float ymax = 0.0f;
+    if (P.c16) {
+        // channels-last-16 output (what the residual blocks' kernels gather): the lane's 32 channels are two
+        // 64-byte groups, eight 16-byte stores
+        typedef float f32x4h __attribute__((ext_vector_type(4)));
+        typedef unsigned u32x4h __attribute__((ext_vector_type(4)));
+        const unsigned vo = ok ? (unsigned)(4 * ((t * P.Cout) * hw) + 64 * (h * P.Woutp + w)) : kOOB;
 #pragma unroll
-    for (int co = 0; co < 32; ++co) {
-        float v = acc[co >> 1][co & 1] * scale[co] + shift[co];
-        if (P.res) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, vo, co * hw * 4, 0));
-        v = apply_act(v, slope);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, vo, co * hw * 4, 0);
-        ymax = fmaxf(ymax, ok ? fabsf(v) : 0.0f);
+        for (int c4 = 0; c4 < 8; ++c4) {
+            const int so = (c4 >> 2) * (hw * 64) + 16 * (c4 & 3);
+            f32x4h r{0.0f, 0.0f, 0.0f, 0.0f}, o;
+            if (P.res) r = __builtin_bit_cast(f32x4h, __builtin_amdgcn_raw_buffer_load_b128(rs_r, vo, so, 0));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int co = 4 * c4 + k;
+                float v = acc[co >> 1][co & 1] * scale[co] + shift[co];
+                v += r[k];
+                v = apply_act(v, slope);
+                o[k] = v;
+                ymax = fmaxf(ymax, ok ? fabsf(v) : 0.0f);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4h, o), rs_y, vo, so, 0);
+            asm volatile("s_nop 1" : "+v"(o));           // store-data hazard of 16-byte stores, see conv_epilogue
+        }
+    } else {
+        const unsigned vo = ok ? (unsigned)(((t * P.Cout) * hw + h * P.Woutp + w) * 4) : kOOB;
+#pragma unroll
+        for (int co = 0; co < 32; ++co) {
+            float v = acc[co >> 1][co & 1] * scale[co] + shift[co];
+            if (P.res) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_r, vo, co * hw * 4, 0));
+            v = apply_act(v, slope);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, vo, co * hw * 4, 0);
+            ymax = fmaxf(ymax, ok ? fabsf(v) : 0.0f);
+        }
     }
     if (P.y_absmax) absmax_commit(ymax, P.y_absmax);
 #endif
@@ -1437,6 +1520,8 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
     P.B = d.B; P.T = d.T; P.C0 = d.C0; P.H0 = d.H0; P.W0 = d.W0; P.C1 = d.C1; P.Hin = d.Hin;
     P.Win = d.Win; P.Cin = d.C0 + d.C1; P.Cout = d.Cout; P.Hout = d.Hout; P.Wout = d.Wout;
     P.W0p = W0p; P.Winp = Winp; P.Woutp = Woutp;
+    P.c16 = d.layout == V2CE_LAYOUT_C16 ? 1 : 0;
+    V2CE_REQUIRE(d.layout == V2CE_LAYOUT_PLANAR || d.layout == V2CE_LAYOUT_C16, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd: layout %d", d.layout);
     P.act = d.act;
     P.x0_absmax = x0_absmax; P.x1_absmax = d.C1 > 0 ? x1_absmax : nullptr; P.y_absmax = y_absmax;
     P.guard = y_absmax ? y_absmax + 1 : nullptr;
@@ -1465,6 +1550,8 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
         V2CE_REQUIRE(P.Cin % 16 == 0 && (d.C1 == 0 || d.C0 % 16 == 0) && d.Cout % 32 == 0,
                      V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd(f16x2): needs input channel counts that are multiples "
                      "of 16 and an output channel count that is a multiple of 32");
+        V2CE_REQUIRE(P.c16, V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd(f16x2): the split-half kernels take and produce activations "
+                     "in the channels-last-16 layout (desc.layout = V2CE_LAYOUT_C16)");
         P.wq = reinterpret_cast<const _Float16 *>(w_packed);
         V2CE_REQUIRE(x0_absmax || !x1_absmax, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd(f16x2): x1_absmax without x0_absmax");
         V2CE_REQUIRE(d.C1 == 0 || !x0_absmax || x1_absmax, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd(f16x2): x0_absmax without x1_absmax");
@@ -1537,6 +1624,8 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
         V2CE_HIP_CHECK(hipGetLastError());
         return V2CE_OK;
     }
+    V2CE_REQUIRE(!P.c16, V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd(f32): the exact-f32 kernels take planar activations "
+                 "(desc.layout = V2CE_LAYOUT_PLANAR); only the 2-channel head convolution can write the channels-last-16 layout");
     // CK per (ksize, stride): sized so 2 workgroups share a CU's 160 KiB of LDS
     // fewer positions per workgroup when the launch would otherwise leave CUs idle
     const long long pos_total = (long long)d.B * d.T * d.Hout * d.Wout;

@@ -281,6 +281,27 @@ class V2ce3d(nn.Module):
 
     # ---- kernels ------------------------------------------------------------------------------
     @staticmethod
+    def to_c16(x: torch.Tensor) -> torch.Tensor:
+        """Planar [B,T,C,H,W] -> channels-last-16 [B,T,C/16,H,W,16] (copy; tests and callers of the raw kernels)."""
+        B, T, C, H, W = x.shape
+        y = x.reshape(B, T, C // 16, 16, H, W).permute(0, 1, 2, 4, 5, 3).contiguous()
+        y.lw, y.c16 = getattr(x, "lw", W), True
+        if hasattr(x, "absmax"):
+            y.absmax = x.absmax
+        return y
+
+    @staticmethod
+    def to_planar(x: torch.Tensor) -> torch.Tensor:
+        """Channels-last-16 -> planar [B,T,C,H,lw] (copy, padding columns dropped)."""
+        if not getattr(x, "c16", False):
+            return x[..., :getattr(x, "lw", x.shape[4])]
+        B, T, G, H, Wp, _ = x.shape
+        y = x.permute(0, 1, 2, 5, 3, 4).reshape(B, T, G * 16, H, Wp)[..., :getattr(x, "lw", Wp)].contiguous()
+        if hasattr(x, "absmax"):
+            y.absmax = x.absmax
+        return y
+
+    @staticmethod
     def _pitch(w: int) -> int:
         """Row pitch of an intermediate activation of width w: rows of at least 64 floats are padded to a multiple
         of 32 floats, so that the 32-position pieces the conv kernels store and gather are whole cache lines
@@ -292,14 +313,24 @@ class V2ce3d(nn.Module):
     def _conv(self, x0, x1, w_packed, scale, shift, cout, ksize, stride, act, residual=None,
               up_to=None, split=False, track=False, pred=None, sc=None, dense_out=False):
         """x0 [B,T,C0,H0,W0] (optionally nearest-upsampled to ``up_to``), x1 [B,T,C1,Hin,Win]."""
-        # activations between the layers are [B,T,C,H,pitch] with the logical width in `.lw` (see _pitch)
-        B, T, C0, H0, W0p = x0.shape
+        # activations between the layers are [B,T,C,H,pitch] (planar) or [B,T,C/16,H,pitch,16] (`.c16`: what the
+        # split-half kernels take and produce, include/v2ce_hip.h V2CE_LAYOUT_C16), logical width in `.lw` (see _pitch)
+        head_bridge = (not split and self.precision == "f16x2" and ksize == 3 and stride == 1 and x1 is None
+                       and x0.dim() == 5 and x0.shape[2] == 2 and cout == 32 and pred is None and not dense_out)
+        c16 = split or head_bridge
+        if not c16 and getattr(x0, "c16", False):        # exact-f32 kernels read planar tensors (test / intermediates paths)
+            x0 = self.to_planar(x0)
+        if split:
+            assert getattr(x0, "c16", False) and (x1 is None or getattr(x1, "c16", False)) and \
+                (residual is None or getattr(residual, "c16", False)), "split-half launches take channels-last-16 activations"
+        B, T, _, H0, W0p = x0.shape[:5]
+        C0 = x0.shape[2] * (16 if getattr(x0, "c16", False) else 1)
         W0 = getattr(x0, "lw", W0p)
         Hin, Win = up_to if up_to is not None else (H0, W0)
         hmap = wmap = None
         if (Hin, Win) != (H0, W0):
             hmap, wmap = self._map(H0, Hin, x0.device), self._map(W0, Win, x0.device)
-        C1 = 0 if x1 is None else x1.shape[2]
+        C1 = 0 if x1 is None else x1.shape[2] * (16 if getattr(x1, "c16", False) else 1)
         Winp = Win if x1 is None else x1.shape[4]
         assert x1 is None or getattr(x1, "lw", Winp) == Win
         pad = ksize // 2
@@ -307,13 +338,15 @@ class V2ce3d(nn.Module):
         Wout = (Win + 2 * pad - ksize) // stride + 1
         Woutp = self._pitch(Wout) if dense_out is False else Wout
         assert residual is None or residual.shape[4] == Woutp
-        y = torch.empty((B, T, cout, Hout, Woutp), dtype=torch.float32, device=x0.device)
-        y.lw = Wout
+        y = torch.empty((B, T, cout // 16, Hout, Woutp, 16) if c16 else (B, T, cout, Hout, Woutp),
+                        dtype=torch.float32, device=x0.device)
+        y.lw, y.c16 = Wout, c16
         d = hip.ConvDesc(B=B, T=T, C0=C0, H0=H0, W0=W0, C1=C1, Hin=Hin, Win=Win, Cout=cout,
                          Hout=Hout, Wout=Wout, ksize=ksize, stride_hw=stride, act=act,
                          tile_t=0, tile_h=0, tile_w=0,
                          precision=hip.PRECISION_F16X2 if split else hip.PRECISION_F32,
-                         W0_pitch=W0p, Win_pitch=Winp, Wout_pitch=Woutp)
+                         W0_pitch=W0p, Win_pitch=Winp, Wout_pitch=Woutp,
+                         layout=hip.LAYOUT_C16 if c16 else hip.LAYOUT_PLANAR)
         a0 = a1 = ay = None
         if track or split:         # range tracking for the split-half consumers (device side only)
             ay = y.absmax = self._prep["absmax"][self._slot]              # [max |y|, range-guard value]
@@ -338,7 +371,7 @@ class V2ce3d(nn.Module):
         elif sc is not None:           # fused 1x1x1 shortcut: second output tensor
             sc_w, sc_scale, sc_shift = sc
             y_sc = torch.empty_like(y)
-            y_sc.lw = Wout
+            y_sc.lw, y_sc.c16 = Wout, c16
             hip.check(hip.lib().v2ce_conv3d_fwd_sc(ctypes.byref(d), x0.data_ptr(), hip.ptr(x1),
                                                    hip.ptr(hmap), hip.ptr(wmap), w_packed.data_ptr(),
                                                    scale.data_ptr(), shift.data_ptr(), y.data_ptr(),
@@ -481,7 +514,7 @@ class V2ce3d(nn.Module):
         inter = OrderedDict()
         h = self._conv(x, None, *P["head"], BASE, 3, 1, hip.ACT_LEAKY,           # unet_2layer.py:341
                        track=self.precision == "f16x2")
-        inter["head"] = h[..., :h.lw]
+        inter["head"] = self.to_planar(h) if return_intermediates else None
         # The spectral-norm stream overlaps the head convolution only (both are many small workgroups; the head
         # is bound by its output stream, the power iterations by reading W).  The persistent residual-block
         # kernels need a whole CU per workgroup and walk their tiles statically: side-stream workgroups that
@@ -492,16 +525,16 @@ class V2ce3d(nn.Module):
         for i, blk in enumerate(U.encoders):                                     # :345-347
             skips.append(h)
             h = self._block(blk, P[f"enc{i}"], h)
-            inter[f"enc{i}"] = h[..., :h.lw]
+            inter[f"enc{i}"] = self.to_planar(h) if return_intermediates else None
         for i, blk in enumerate(U.resblocks):                                    # :349-350
             h = self._block(blk, P[f"res{i}"], h)
-            inter[f"res{i}"] = h[..., :h.lw]
+            inter[f"res{i}"] = self.to_planar(h) if return_intermediates else None
         fuse = P["pred_fused"] if not return_intermediates else None
         for i, (blk, skip) in enumerate(zip(U.decoders, reversed(skips))):       # :357-365
             last = i == len(U.decoders) - 1
             h = self._block(blk, P[f"dec{i}"], h, skip, up_to=(skip.shape[3], getattr(skip, "lw", skip.shape[4])),
                             pred=fuse if last else None)
-            inter[f"dec{i}"] = h[..., :getattr(h, "lw", h.shape[4])]
+            inter[f"dec{i}"] = self.to_planar(h) if return_intermediates else None
         if fuse is not None:
             out = h                                                               # pred rode on dec3.conv2
         else:
