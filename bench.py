@@ -433,7 +433,7 @@ def main():
             line["rccl_world"] = world
         if world == 1 and args.workload == "e2e":
             if not args.no_host_to_host:
-                line["host_to_host"] = host_to_host(args, device, max(args.steps, 4))
+                line["host_to_host"] = host_to_host(args, device, max(args.steps, 16))   # >= 16 batches (1025 frames): the drain of the last batch (0.5 ms LDATI + 152 MB D2H) is a fixed ~7 ms
             if args.precision != "f32" and not args.no_exact_f32:
                 # the same step with exact f32 MFMA arithmetic in every conv, for reference (not `value`)
                 model = None
