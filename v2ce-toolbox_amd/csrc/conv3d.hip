@@ -1085,7 +1085,7 @@ __global__ __launch_bounds__(256) void conv3d_head_kernel(ConvParams P) {
     constexpr int TT = kHeadTT, TH = kHeadTH, TW = kHeadTW;
     constexpr int HT = TT + 2, HH = TH + 2, HWd = TW + 2, PLANE = HT * HH * HWd;
     static_assert(TT * TH == 4, "one wave per (time step, row)");
-    __shared__ float halo[2 * PLANE];
+    __shared__ float halo[2 * PLANE > 4096 ? 2 * PLANE : 4096];   // halo box, then 4 KB per wave for the output transpose
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // workgroups are dealt round-robin over the 8 XCDs: XCD x walks the contiguous range [x n/8, (x+1) n/8)
     // of boxes, so the boxes that share output cache lines (rows are not 128-byte aligned) and halo
@@ -1183,11 +1183,48 @@ __global__ __launch_bounds__(256) void conv3d_head_kernel(ConvParams P) {
         typedef float f32x4h __attribute__((ext_vector_type(4)));
         typedef unsigned u32x4h __attribute__((ext_vector_type(4)));
         const unsigned vo = ok ? (unsigned)(4 * ((t * P.Cout) * hw) + 64 * (h * P.Woutp + w)) : kOOB;
+        if (!P.res) {
+            // The wave's 64 positions x 16 channels of a group are 4 KB of contiguous memory.  Stored from the
+            // MFMA-free layout (lane = position) every instruction would touch 64 lines with 16 bytes each; through
+            // LDS (the halo box is dead by now) lane L of store j writes bytes [1024 j + 16 L, + 16): whole lines.
+            __syncthreads();                                 // every wave is done reading the halo box
+            f32x4h *tr = reinterpret_cast<f32x4h *>(halo) + wave * 256;          // 4 KB per wave
+            const int wlast = P.Wout - w0;                   // positions of this row inside the tensor (wave-uniform)
+            const bool row_ok = t < P.T && h < P.Hout;
+            const unsigned vrow = (unsigned)(4 * ((t * P.Cout) * hw) + 64 * (h * P.Woutp + w0));
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    f32x4h o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int co = 16 * g + 4 * c4 + k;
+                        float v = acc[co >> 1][co & 1] * scale[co] + shift[co];
+                        v = apply_act(v, slope);
+                        o[k] = v;
+                        ymax = fmaxf(ymax, ok ? fabsf(v) : 0.0f);
+                    }
+                    tr[lane * 4 + c4] = o;                   // position-major: element `lane`, quarter c4
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int q = 64 * j + lane;             // 16-byte piece q of the 4 KB: position q >> 2, quarter q & 3
+                    f32x4h o = tr[q];
+                    const bool pok = row_ok && (q >> 2) < wlast;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4h, o), rs_y, pok ? vrow + 16u * (unsigned)q : kOOB,
+                                                           g * (hw * 64), 0);
+                    asm volatile("s_nop 1" : "+v"(o));       // store-data hazard of 16-byte stores, see conv_epilogue
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else {
 #pragma unroll
         for (int c4 = 0; c4 < 8; ++c4) {
             const int so = (c4 >> 2) * (hw * 64) + 16 * (c4 & 3);
             f32x4h r{0.0f, 0.0f, 0.0f, 0.0f}, o;
-            if (P.res) r = __builtin_bit_cast(f32x4h, __builtin_amdgcn_raw_buffer_load_b128(rs_r, vo, so, 0));
+            r = __builtin_bit_cast(f32x4h, __builtin_amdgcn_raw_buffer_load_b128(rs_r, vo, so, 0));
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int co = 4 * c4 + k;
@@ -1199,6 +1236,7 @@ __global__ __launch_bounds__(256) void conv3d_head_kernel(ConvParams P) {
             }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4h, o), rs_y, vo, so, 0);
             asm volatile("s_nop 1" : "+v"(o));           // store-data hazard of 16-byte stores, see conv_epilogue
+        }
         }
     } else {
         const unsigned vo = ok ? (unsigned)(((t * P.Cout) * hw + h * P.Woutp + w) * 4) : kOOB;
