@@ -428,6 +428,9 @@ def main():
             if model is not None else None,
             "roofline": roofline, "ldati": ldati, "kernels": kernels,
         }
+        if model is not None and args.precision == "f16x2":
+            # the split-half range guard over the timed steps: worst per-launch bound vs its limit
+            line["range_guard"] = {"worst_bound": model.range_guard_value(), "limit": model.RANGE_GUARD_LIMIT}
         if world > 1:
             line["gathered_bytes_per_step"] = gather_bytes[0]
             line["rccl_world"] = world
