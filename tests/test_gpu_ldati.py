@@ -247,6 +247,8 @@ def test_sparse_tile_kernel_equals_per_bin_kernel(monkeypatch):
     y = np.zeros((3, 2, 10, H, W), np.float32)
     y[:, :, :, :40] = np.maximum(0.25 * rng.standard_normal((3, 2, 10, 40, W)), 0).astype(np.float32)   # sparse rows
     y[:, :, :, 60:80] = (3.0 * rng.random((3, 2, 10, 20, W))).astype(np.float32)                        # dense rows
+    # rows whose tiles hold about as many events as the sparse kernel's capacity (8192): both sides of the branch
+    y[:, :, :, 40:60] = np.maximum(1.0 * rng.standard_normal((3, 2, 10, 20, W)), 0).astype(np.float32)
     want = O.emit_soa(y, fps=30, seed=9, frame_base=2)
     outs = []
     for off in (False, True):
