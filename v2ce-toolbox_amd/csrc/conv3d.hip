@@ -825,16 +825,25 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
                 if ((wave - 4) * 64 + 256 * i < P.plane) {            // wave-uniform (lanes past the plane write padding)
 #pragma unroll
                     for (int hg = 0; hg < 2; ++hg) {
-                        f16x8 vh, vl;
+                        // hi = f16(x s), lo = f16(x s - hi): four mixed-precision FMAs per pair of values (x s is exact,
+                        // s a power of two, and x s - hi is exact in f32, so this is bit-identical to multiply, convert,
+                        // convert back, subtract, convert -- which the compiler emitted for most pairs: 6 instructions)
+                        typedef unsigned u32x4c __attribute__((ext_vector_type(4)));
+                        u32x4c ph, pl;
 #pragma unroll
-                        for (int c = 0; c < 8; ++c) {
-                            const float v = R[8 * hg + c][i] * x_scale;
-                            const _Float16 hh = (_Float16)v;
-                            vh[c] = hh;
-                            vl[c] = (_Float16)(v - (float)hh);
+                        for (int c2 = 0; c2 < 4; ++c2) {
+                            const float xa = R[8 * hg + 2 * c2][i], xb = R[8 * hg + 2 * c2 + 1][i];
+                            unsigned h, l;
+                            asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
+                                "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
+                                "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
+                                "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                                : "=&v"(h), "=&v"(l) : "v"(xa), "v"(xb), "v"(x_scale));
+                            ph[c2] = h;
+                            pl[c2] = l;
                         }
-                        qb[hg * chs + r] = vh;
-                        qb[(2 + hg) * chs + r] = vl;
+                        qb[hg * chs + r] = __builtin_bit_cast(f16x8, ph);
+                        qb[(2 + hg) * chs + r] = __builtin_bit_cast(f16x8, pl);
                     }
                 }
             }
