@@ -118,7 +118,7 @@ struct SnBatch {
     int n;
     int col_blk[kMaxBatch + 1];   // prefix of ceil(cols / 256)
     int row_blk[kMaxBatch + 1];   // prefix of rows
-    int el_blk[kMaxBatch + 1];    // prefix of ceil(rows * cols / 256)
+    int el_blk[kMaxBatch + 1];    // prefix of (rows / 32) * (Cin / 16): pack workgroups
 };
 
 __device__ __forceinline__ int find_layer(const int *prefix, int n, int b) {
@@ -140,17 +140,25 @@ __global__ __launch_bounds__(256) void sn_batch_wt_u_kernel(SnBatch B) {
     P.part[(long long)blockIdx.y * P.cols + j] = s;
 }
 
+// t[j] = sum of the row-chunk partials, all layers' columns in parallel (one workgroup per layer spent 54 us here)
+__global__ __launch_bounds__(256) void sn_batch_colsum_kernel(SnBatch B) {
+    const int l = find_layer(B.col_blk, B.n, blockIdx.x);
+    const SnLayer &P = B.L[l];
+    const int i = (blockIdx.x - B.col_blk[l]) * 256 + threadIdx.x;
+    if (i >= P.cols) return;
+    double a = 0.0;
+#pragma unroll
+    for (int c = 0; c < kRowChunks; ++c) a += P.part[(long long)c * P.cols + i];
+    P.t[i] = (float)a;
+}
+
 __global__ __launch_bounds__(1024) void sn_batch_normalize_kernel(SnBatch B) {
     __shared__ double sh[16];
     const SnLayer &P = B.L[blockIdx.x];
     const int n = P.cols;
     double s = 0.0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        double a = 0.0;
-#pragma unroll
-        for (int c = 0; c < kRowChunks; ++c) a += P.part[(long long)c * n + i];
-        const float ti = (float)a;
-        P.t[i] = ti;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {          // same order of summation as sn_normalize_kernel
+        const float ti = P.t[i];
         s += (double)ti * (double)ti;
     }
     __syncthreads();
@@ -220,27 +228,39 @@ __global__ __launch_bounds__(1024) void sn_batch_finalize_kernel(SnBatch B) {
     }
 }
 
-// the body of pack_weights_f16x2_kernel (conv3d.hip) for every layer of the batch
+// pack_weights_f16x2_kernel's (conv3d.hip) values for every layer of the batch, with both sides coalesced: a
+// workgroup takes 32 output channels x one 16-channel group -- 32 runs of 16 * k3 contiguous floats of W -- and
+// writes, per tap and plane, the 32 x 16 halves that are contiguous in the packed layout [plane][tap][cg][co][16]
+// (the element-wise form read W with a stride of k3 floats per lane: 162 us for 151 MB).
 __global__ __launch_bounds__(256) void sn_batch_pack_kernel(SnBatch B) {
+    extern __shared__ _Float16 pk_smem[];               // [2][k3][32][16] halves
     const int l = find_layer(B.el_blk, B.n, blockIdx.x);
     const SnLayer &P = B.L[l];
+    const int CG = P.cin / 16, k3 = P.k3, run = 16 * k3;
+    const int blk = blockIdx.x - B.el_blk[l];            // (co block, cg)
+    const int cg = blk % CG, co0 = (blk / CG) * 32;
     const long long n = (long long)P.rows * P.cols;
-    const long long i = (long long)(blockIdx.x - B.el_blk[l]) * 256 + threadIdx.x;   // ((tap*CG + cg)*Cout + co)*16 + j
-    if (i >= n) return;
     const float *tail = reinterpret_cast<const float *>(P.packed + 2 * n);
-    const float w_scale = tail[1];
-    const int j = (int)(i & 15);
-    long long r = i >> 4;
-    const int co = (int)(r % P.rows); r /= P.rows;
-    const int CG = P.cin / 16;
-    const int cg = (int)(r % CG);
-    const int tap = (int)(r / CG);
-    float v = P.w[((long long)co * P.cin + cg * 16 + j) * P.k3 + tap];
-    v = v / P.sigma[0];
-    v *= w_scale;
-    const _Float16 h = (_Float16)v;
-    P.packed[i] = h;
-    P.packed[n + i] = (_Float16)(v - (float)h);
+    const float w_scale = tail[1], sigma = P.sigma[0];
+    _Float16 *hi = pk_smem, *lo = pk_smem + k3 * 512;
+    for (int e = threadIdx.x; e < 32 * run; e += 256) {
+        const int col = e / run, rem = e - col * run;    // rem = j * k3 + tap
+        const int j = rem / k3, tap = rem - j * k3;
+        float v = P.w[((long long)(co0 + col) * P.cin + cg * 16) * k3 + rem];
+        v = v / sigma;
+        v *= w_scale;
+        const _Float16 h = (_Float16)v;
+        hi[(tap * 32 + col) * 16 + j] = h;
+        lo[(tap * 32 + col) * 16 + j] = (_Float16)(v - (float)h);
+    }
+    __syncthreads();
+    // per tap: 512 halves = 256 dwords of each plane, contiguous at ((tap * CG + cg) * rows + co0) * 16
+    const unsigned *hi32 = reinterpret_cast<const unsigned *>(hi), *lo32 = reinterpret_cast<const unsigned *>(lo);
+    for (int tap = 0; tap < k3; ++tap) {
+        const long long o = (((long long)tap * CG + cg) * P.rows + co0) * 16;       // halves
+        reinterpret_cast<unsigned *>(P.packed + o)[threadIdx.x] = hi32[tap * 256 + threadIdx.x];
+        reinterpret_cast<unsigned *>(P.packed + n + o)[threadIdx.x] = lo32[tap * 256 + threadIdx.x];
+    }
 }
 
 }  // namespace
@@ -312,16 +332,19 @@ extern "C" int v2ce_sn_update_batch(const v2ce_sn_layer *layers, int n, void *wo
         ws += (sn_batch_layer_bytes(in.rows, in.cols) + 15) / 16 * 16;
         B.col_blk[l + 1] = B.col_blk[l] + (in.cols + 255) / 256;
         B.row_blk[l + 1] = B.row_blk[l] + in.rows;
-        const long long el = (long long)in.rows * in.cols;
-        V2CE_REQUIRE(B.el_blk[l] + (el + 255) / 256 < (1ll << 31), V2CE_ERR_UNSUPPORTED, "v2ce_sn_update_batch: too large");
-        B.el_blk[l + 1] = B.el_blk[l] + (int)((el + 255) / 256);
+        V2CE_REQUIRE(in.rows % 32 == 0 && in.k3 * 2048 <= 64 * 1024, V2CE_ERR_UNSUPPORTED,
+                     "v2ce_sn_update_batch: layer %d: rows %% 32 != 0 or k3 too large", l);
+        B.el_blk[l + 1] = B.el_blk[l] + (in.rows / 32) * (in.cols / in.k3 / 16);        // pack: (32 output channels, 16-channel group)
     }
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(sn_batch_wt_u_kernel, dim3(B.col_blk[n], kRowChunks), dim3(256), 0, st, B);
+    hipLaunchKernelGGL(sn_batch_colsum_kernel, dim3(B.col_blk[n]), dim3(256), 0, st, B);
     hipLaunchKernelGGL(sn_batch_normalize_kernel, dim3(n), dim3(1024), 0, st, B);
     hipLaunchKernelGGL(sn_batch_w_v_kernel, dim3(B.row_blk[n]), dim3(256), 0, st, B);
     hipLaunchKernelGGL(sn_batch_finalize_kernel, dim3(n), dim3(1024), 0, st, B);
-    hipLaunchKernelGGL(sn_batch_pack_kernel, dim3(B.el_blk[n]), dim3(256), 0, st, B);
+    int k3max = 1;
+    for (int l = 0; l < n; ++l) k3max = layers[l].k3 > k3max ? layers[l].k3 : k3max;
+    hipLaunchKernelGGL(sn_batch_pack_kernel, dim3(B.el_blk[n]), dim3(256), (size_t)k3max * 2048, st, B);
     V2CE_HIP_CHECK(hipGetLastError());
     return V2CE_OK;
 }
