@@ -5,6 +5,6 @@ import csv,glob
 f=glob.glob('gpurun_out/kt_tmp/*/*kernel_stats.csv')[0]
 for r in csv.DictReader(open(f)):
     n=r['Name']
-    if 'ldati' in n or 'events' in n:
+    if 'ldati' in n or 'events' in n or 'sn_' in n:
         print(f"{n[:100]:100s} n={r['Calls']:>4s} avg={float(r['AverageNs'])/1e3:9.1f}us")
 PY

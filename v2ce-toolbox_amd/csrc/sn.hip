@@ -176,7 +176,8 @@ __global__ __launch_bounds__(256) void sn_batch_w_v_kernel(SnBatch B) {
     const float *row = P.w + (long long)r * P.cols;
     double acc = 0.0;
     float m = 0.0f;
-    for (int j = threadIdx.x; j < P.cols; j += 256) {
+#pragma unroll 6
+    for (int j = threadIdx.x; j < P.cols; j += 256) {       // (several loads in flight; the sum's order is unchanged)
         const float wv = row[j];
         acc += (double)wv * (double)P.v[j];
         m = fmaxf(m, fabsf(wv));
@@ -232,34 +233,51 @@ __global__ __launch_bounds__(1024) void sn_batch_finalize_kernel(SnBatch B) {
 // workgroup takes 32 output channels x one 16-channel group -- 32 runs of 16 * k3 contiguous floats of W -- and
 // writes, per tap and plane, the 32 x 16 halves that are contiguous in the packed layout [plane][tap][cg][co][16]
 // (the element-wise form read W with a stride of k3 floats per lane: 162 us for 151 MB).
+// K3 > 0: every layer of the batch has that kernel volume (the index arithmetic is then multiply-shift instead of two
+// integer divisions per element, which made the kernel VALU-bound: 150 us)
+template <int K3>
 __global__ __launch_bounds__(256) void sn_batch_pack_kernel(SnBatch B) {
     extern __shared__ _Float16 pk_smem[];               // [2][k3][32][16] halves
     const int l = find_layer(B.el_blk, B.n, blockIdx.x);
     const SnLayer &P = B.L[l];
-    const int CG = P.cin / 16, k3 = P.k3, run = 16 * k3;
+    const int CG = P.cin / 16, k3 = K3 > 0 ? K3 : P.k3, run = 16 * k3;
     const int blk = blockIdx.x - B.el_blk[l];            // (co block, cg)
     const int cg = blk % CG, co0 = (blk / CG) * 32;
     const long long n = (long long)P.rows * P.cols;
     const float *tail = reinterpret_cast<const float *>(P.packed + 2 * n);
     const float w_scale = tail[1], sigma = P.sigma[0];
-    _Float16 *hi = pk_smem, *lo = pk_smem + k3 * 512;
-    for (int e = threadIdx.x; e < 32 * run; e += 256) {
-        const int col = e / run, rem = e - col * run;    // rem = j * k3 + tap
-        const int j = rem / k3, tap = rem - j * k3;
-        float v = P.w[((long long)(co0 + col) * P.cin + cg * 16) * k3 + rem];
-        v = v / sigma;
-        v *= w_scale;
-        const _Float16 h = (_Float16)v;
-        hi[(tap * 32 + col) * 16 + j] = h;
-        lo[(tap * 32 + col) * 16 + j] = (_Float16)(v - (float)h);
+    // (a tap's 512 halves are padded by one dword: consecutive lanes hold consecutive taps, 1 KiB apart = one LDS bank)
+    _Float16 *hi = pk_smem, *lo = pk_smem + k3 * 514;
+    constexpr int U = 6;                                 // loads in flight per thread (two workgroups per CU: latency-bound otherwise)
+    for (int e0 = threadIdx.x; e0 < 32 * run; e0 += 256 * U) {
+        float vv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + 256 * u;
+            const int col = e / run, rem = e - col * run;
+            vv[u] = e < 32 * run ? P.w[((long long)(co0 + col) * P.cin + cg * 16) * k3 + rem] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + 256 * u;
+            if (e < 32 * run) {
+                const int col = e / run, rem = e - col * run;    // rem = j * k3 + tap
+                const int j = rem / k3, tap = rem - j * k3;
+                float v = vv[u] / sigma;
+                v *= w_scale;
+                const _Float16 h = (_Float16)v;
+                hi[tap * 514 + col * 16 + j] = h;
+                lo[tap * 514 + col * 16 + j] = (_Float16)(v - (float)h);
+            }
+        }
     }
     __syncthreads();
     // per tap: 512 halves = 256 dwords of each plane, contiguous at ((tap * CG + cg) * rows + co0) * 16
     const unsigned *hi32 = reinterpret_cast<const unsigned *>(hi), *lo32 = reinterpret_cast<const unsigned *>(lo);
     for (int tap = 0; tap < k3; ++tap) {
         const long long o = (((long long)tap * CG + cg) * P.rows + co0) * 16;       // halves
-        reinterpret_cast<unsigned *>(P.packed + o)[threadIdx.x] = hi32[tap * 256 + threadIdx.x];
-        reinterpret_cast<unsigned *>(P.packed + n + o)[threadIdx.x] = lo32[tap * 256 + threadIdx.x];
+        reinterpret_cast<unsigned *>(P.packed + o)[threadIdx.x] = hi32[tap * 257 + threadIdx.x];
+        reinterpret_cast<unsigned *>(P.packed + n + o)[threadIdx.x] = lo32[tap * 257 + threadIdx.x];
     }
 }
 
@@ -332,7 +350,7 @@ extern "C" int v2ce_sn_update_batch(const v2ce_sn_layer *layers, int n, void *wo
         ws += (sn_batch_layer_bytes(in.rows, in.cols) + 15) / 16 * 16;
         B.col_blk[l + 1] = B.col_blk[l] + (in.cols + 255) / 256;
         B.row_blk[l + 1] = B.row_blk[l] + in.rows;
-        V2CE_REQUIRE(in.rows % 32 == 0 && in.k3 * 2048 <= 64 * 1024, V2CE_ERR_UNSUPPORTED,
+        V2CE_REQUIRE(in.rows % 32 == 0 && in.k3 * 2056 <= 64 * 1024, V2CE_ERR_UNSUPPORTED,
                      "v2ce_sn_update_batch: layer %d: rows %% 32 != 0 or k3 too large", l);
         B.el_blk[l + 1] = B.el_blk[l] + (in.rows / 32) * (in.cols / in.k3 / 16);        // pack: (32 output channels, 16-channel group)
     }
@@ -343,8 +361,13 @@ extern "C" int v2ce_sn_update_batch(const v2ce_sn_layer *layers, int n, void *wo
     hipLaunchKernelGGL(sn_batch_w_v_kernel, dim3(B.row_blk[n]), dim3(256), 0, st, B);
     hipLaunchKernelGGL(sn_batch_finalize_kernel, dim3(n), dim3(1024), 0, st, B);
     int k3max = 1;
-    for (int l = 0; l < n; ++l) k3max = layers[l].k3 > k3max ? layers[l].k3 : k3max;
-    hipLaunchKernelGGL(sn_batch_pack_kernel, dim3(B.el_blk[n]), dim3(256), (size_t)k3max * 2048, st, B);
+    bool all27 = true;
+    for (int l = 0; l < n; ++l) {
+        k3max = layers[l].k3 > k3max ? layers[l].k3 : k3max;
+        all27 = all27 && layers[l].k3 == 27;
+    }
+    if (all27) hipLaunchKernelGGL(sn_batch_pack_kernel<27>, dim3(B.el_blk[n]), dim3(256), (size_t)27 * 2056, st, B);
+    else hipLaunchKernelGGL(sn_batch_pack_kernel<0>, dim3(B.el_blk[n]), dim3(256), (size_t)k3max * 2056, st, B);
     V2CE_HIP_CHECK(hipGetLastError());
     return V2CE_OK;
 }
