@@ -282,6 +282,39 @@ int v2ce_pack_weights(const float *w, int Cout, int Cin, int k3, const float *si
 int v2ce_voxelize_events(const int64_t *ts, const int16_t *x, const int16_t *y, const int8_t *p, int64_t n,
                          int bins, int H, int W, float *volume, int64_t *t_range, v2ce_stream_t stream);
 
+/* Ablation samplers of the reference's stage-2 study, csrc/sampler.hip:
+ *   V2CE_SAMPLER_RANDOM / _EVEN  sample_voxel_baseline(random=True / even=True) of
+ *                                train/scripts/stage2/sample_methods/random_even_sample.py:115-169
+ *   V2CE_SAMPLER_PURE_SLOPE      sample_voxel_statistical of .../pure_slope_sample.py:57-149 (pooling 'none')
+ * vox [B][2][10][H][W] f32 (read only: the pure-slope reference folds bin 9 into bin 8 IN the caller's tensor,
+ * here the fold happens in registers).  Per voxel: floor(y) events + one more with probability frac(y).  Output per
+ * frame in the order of np.sort(order='timestamp') = lexicographic (timestamp, x, y, polarity); frames back to back.
+ * Random draws: V2CE_RNG_REPLAY reads u_int [B][2][10][H][W][replay_M] (times of the floor(y) events; replay_M >=
+ * max floor(y)), u_dec and u_bern [B][2][10][H][W] (time of / Bernoulli draw for the fractional event: it exists iff
+ * u_bern < frac(y)); V2CE_RNG_PHILOX draws them from Philox4x32-10, counter (pixel, j >> 2, 32*kind + 10*P + c,
+ * frame_base + b), kind 0 / 1 / 2 = u_int / u_dec / u_bern, key = seed.  _EVEN reads u_bern only.
+ * Two-phase like LDATI: count -> the caller reads frame_counts [B] (int64, device) and max_int, allocates the SoA
+ * outputs and the workspace -> emit.  status [1] (device int32) != 0: a timestamp fell outside the frame's key range
+ * (NaN or inf from a degenerate slope; the reference's output is platform-defined there). */
+#define V2CE_SAMPLER_RANDOM 0
+#define V2CE_SAMPLER_EVEN 1
+#define V2CE_SAMPLER_PURE_SLOPE 2
+typedef struct {
+    int mode;     /* V2CE_SAMPLER_* */
+    int rng_mode; /* V2CE_RNG_* */
+    double fps, t0;
+    uint64_t seed;
+    int frame_base;
+    int replay_M;
+    const float *u_int, *u_dec, *u_bern;
+} v2ce_sampler_options;
+int v2ce_sampler_count(const float *vox, int B, int H, int W, const v2ce_sampler_options *options,
+                       int64_t *frame_counts, int32_t *max_int, v2ce_stream_t stream);
+size_t v2ce_sampler_workspace_bytes(int64_t total_events);
+int v2ce_sampler_emit(const float *vox, int B, int H, int W, const v2ce_sampler_options *options, int64_t total_events,
+                      int64_t *ts, int16_t *x, int16_t *y, int8_t *p, void *workspace, size_t workspace_bytes,
+                      int32_t *status, v2ce_stream_t stream);
+
 /* One spectral-norm power iteration (spectral_norm.py:19-31), in place on u [rows], v [cols]:
  *   v = W^T u / (|W^T u| + 1e-12); u = W v / (|W v| + 1e-12); sigma = u . (W v)
  * w_bar [rows][cols] f32; sigma [1] f32 out; workspace >= v2ce_sn_workspace_bytes(rows, cols). */

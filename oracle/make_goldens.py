@@ -14,6 +14,8 @@ Golden sets:
   G5 ldati_kat.json   hand known-answer re-derived from the reference here
   G7 glue_g7.npz      v2ce.py video_to_voxels (center + pano) through a stub-imported v2ce.py,
                       sequence plans and per-frame offsets
+  G10 sampler_g10_*   the ablation samplers of train/scripts/stage2/sample_methods (random / even baseline,
+                      pure slope): voxels, every random draw of the call, events
   G8 voxelize_g8.npz  the reference voxeliser gen_discretized_event_volume (its three function
                       definitions are compiled here straight from the reference file: the module
                       itself imports h5py / numba / plotly, absent from this image) on reference
@@ -222,6 +224,109 @@ def gen_ldati_options():
                             pooling_type=np.array(opts.get("pooling_type", "none")),
                             pooling_kernel_size=np.array(int(opts.get("pooling_kernel_size", 3))))
         print(f"G3 option {name}: seed {seed} B={B} HxW={H}x{W} fps={fps} t0={t0} max_n={u.shape[-1]} events={lens}")
+
+
+# --------------------------------------------------------------------------------------------- G10
+class DrawCapture:
+    """Records every torch.rand of the reference call and routes torch.bernoulli(p) through a recorded
+    uniform draw (u < p: what torch's CPU kernel computes per element from its own generator), so that
+    all random draws of a sampler call become data of the fixture."""
+
+    def __enter__(self):
+        self.rand0, self.bern0 = torch.rand, torch.bernoulli
+        self.rands, self.berns = [], []
+
+        def rand(*a, **k):
+            r = self.rand0(*a, **k)
+            self.rands.append(r.clone())
+            return r
+
+        def bern(p):
+            u = self.rand0(p.shape)
+            self.berns.append(u.clone())
+            return (u < p).to(p.dtype)
+        torch.rand, torch.bernoulli = rand, bern
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand, torch.bernoulli = self.rand0, self.bern0
+
+
+def reference_sample_methods():
+    """The two ablation samplers, imported from the reference (h5py, which random_even_sample.py imports
+    and never uses, is absent here: stubbed)."""
+    sys.path.insert(0, "/root/reference/train/scripts/stage2")
+    sys.modules.setdefault("h5py", types.ModuleType("h5py"))
+    from sample_methods import random_even_sample as RE, pure_slope_sample as PS
+    return RE, PS
+
+
+def gen_sample_methods():
+    """G10: sample_voxel_baseline (random / even) and the pure-slope sampler."""
+    from oracle import sample_methods as OS
+    RE, PS = reference_sample_methods()
+    cases = {
+        "random": ("baseline", synth.synthetic_voxels(2, 12, 14, seed=41, regime="stress"), 30, 0, dict(random=True)),
+        "random_sparse": ("baseline", synth.synthetic_voxels(3, 9, 11, seed=42, regime="sparse"), 25, 0.25, dict(random=True)),
+        "even": ("baseline", synth.synthetic_voxels(2, 12, 14, seed=43, regime="stress"), 30, 0, dict(even=True)),
+        "even_frac": ("baseline", synth.synthetic_voxels(2, 9, 11, seed=44, regime="frac"), 60, 0, dict(even=True)),
+        "slope": ("pure_slope", synth.synthetic_voxels(2, 12, 14, seed=45, regime="stress"), 30, 0, {}),
+        "slope_sparse": ("pure_slope", synth.synthetic_voxels(3, 9, 11, seed=46, regime="sparse"), 25, 0.25, {}),
+        "slope_ragged": ("pure_slope", synth.synthetic_voxels(1, 1, 67, seed=47, regime="stress"), 24, 0, {}),
+    }
+    for name, (kind, vox, fps, t0, opts) in cases.items():
+        B, _, _, H, W = vox.shape
+
+        def run(seed, ieee):
+            with DrawCapture() as cap:
+                torch.manual_seed(seed)
+                y = torch.from_numpy(vox.copy())
+                fn = (lambda: RE.sample_voxel_baseline(y, t0=t0, fps=fps, **opts)) if kind == "baseline" else \
+                     (lambda: PS.sample_voxel_statistical(y, t0=t0, fps=fps))
+                if ieee:
+                    with IeeeSqrt():
+                        res = fn()
+                else:
+                    res = fn()
+            return res, cap
+
+        for seed in range(300, 360):
+            res, cap = run(seed, False)
+            res_ieee, _ = run(seed, True)
+            if all(events_equal(a, b) for a, b in zip(res, res_ieee)):
+                break
+        else:
+            raise AssertionError(f"{name}: MKL-VML sqrt and IEEE sqrt disagree for every seed tried")
+        # the Bernoulli draws arrive plane by plane in pick_and_sort's order: frame, bin, negative (P index 1) first
+        u_bern = np.empty((B, 2, 10, H, W), np.float32)
+        it = iter(cap.berns)
+        for b in range(B):
+            for c in range(10):
+                for pi in (1, 0):
+                    u_bern[b, pi, c] = next(it).numpy()
+        rands = [r.numpy() for r in cap.rands]
+        if kind == "baseline" and opts.get("even"):
+            assert not rands
+            u_int, u_dec = np.zeros((B, 2, 10, H, W, 0), np.float32), np.zeros((B, 2, 10, H, W), np.float32)
+        elif kind == "baseline":
+            u_int, u_dec = rands[0].reshape(B, 2, 10, H, W, -1), rands[1].reshape(B, 2, 10, H, W)
+        else:
+            u_dec, u_int = rands[0].reshape(B, 2, 10, H, W), rands[1].reshape(B, 2, 10, H, W, -1)
+        lens = np.array([len(r) for r in res], np.int64)
+        ev = np.concatenate([np.asarray(r) for r in res])
+        assert ev.dtype.itemsize == 13
+        # the oracle is pinned right here as well
+        if kind == "baseline":
+            mine = OS.sample_voxel_baseline(vox, t0, fps, u_int=u_int, u_dec=u_dec, u_bern=u_bern, **opts)
+        else:
+            mine = OS.sample_voxel_pure_slope(vox, t0, fps, u_int=u_int, u_dec=u_dec, u_bern=u_bern)
+        assert all(events_equal(a, b) for a, b in zip(res, mine)), name
+        np.savez_compressed(os.path.join(GOLD, f"sampler_g10_{name}.npz"), vox=vox, kind=np.array(kind),
+                            mode=np.array("even" if opts.get("even") else "random" if opts.get("random") else "slope"),
+                            fps=np.float64(fps), t0=np.float64(t0), u_int=u_int, u_dec=u_dec, u_bern=u_bern,
+                            lens=lens, events=np.frombuffer(ev.tobytes(), np.uint8))
+        print(f"G10 {name}: seed {seed} B={B} HxW={H}x{W} fps={fps} t0={t0} M={u_int.shape[-1]} events={lens}")
+
 
 
 # --------------------------------------------------------------------------------------------- G4
@@ -438,7 +543,7 @@ def gen_voxelize():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["unet", "ldati", "options", "large", "kat", "glue", "voxelize", "event_frames"]
+    which = sys.argv[1:] or ["unet", "ldati", "options", "large", "kat", "glue", "voxelize", "event_frames", "samplers"]
     if "event_frames" in which:
         gen_event_frames()
     if "voxelize" in which:
@@ -455,3 +560,5 @@ if __name__ == "__main__":
         gen_kat()
     if "glue" in which:
         gen_glue()
+    if "samplers" in which:
+        gen_sample_methods()

@@ -1,0 +1,59 @@
+"""CPU: the restatement of the two ablation samplers (oracle/sample_methods.py) against G10, the
+outputs of the reference's own random_even_sample.py / pure_slope_sample.py with every random draw recorded."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import sample_methods as OS
+
+CASES = sorted(os.path.basename(p)[len("sampler_g10_"):-4]
+               for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "sampler_g10_*.npz")))
+
+
+def run_oracle(z):
+    kw = dict(u_int=z["u_int"], u_dec=z["u_dec"], u_bern=z["u_bern"])
+    if str(z["kind"]) == "baseline":
+        mode = str(z["mode"])
+        return OS.sample_voxel_baseline(z["vox"], float(z["t0"]), float(z["fps"]), even=mode == "even",
+                                        random=mode == "random", **kw)
+    return OS.sample_voxel_pure_slope(z["vox"], float(z["t0"]), float(z["fps"]), **kw)
+
+
+def test_fixture_set_complete():
+    assert {"random", "random_sparse", "even", "even_frac", "slope", "slope_sparse", "slope_ragged"} <= set(CASES)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_equals_reference(gold_dir, name):
+    z = np.load(os.path.join(gold_dir, f"sampler_g10_{name}.npz"))
+    res = run_oracle(z)
+    assert [len(r) for r in res] == z["lens"].tolist()
+    got = np.concatenate([np.asarray(r) for r in res])
+    assert got.dtype.itemsize == 13
+    assert got.tobytes() == z["events"].tobytes()
+
+
+def test_output_order_is_lexicographic(gold_dir):
+    """np.sort(order='timestamp') of the reference breaks timestamp ties by (x, y, polarity): the even sampler's
+    goldens are full of ties (every first event of a bin sits on the bin's start)."""
+    z = np.load(os.path.join(gold_dir, "sampler_g10_even.npz"))
+    ev = np.frombuffer(z["events"].tobytes(), OS.EVENT_DTYPE)
+    lo = 0
+    ties = 0
+    for n in z["lens"]:
+        f = ev[lo:lo + n]
+        key = np.stack([f["timestamp"], f["x"].astype(np.int64), f["y"].astype(np.int64), f["polarity"].astype(np.int64)])
+        order = np.lexsort(key[::-1])
+        assert np.array_equal(order, np.arange(n))
+        ties += int((np.diff(f["timestamp"]) == 0).sum())
+        lo += n
+    assert ties > 1000
+
+
+def test_pure_slope_does_not_touch_the_input(gold_dir):
+    z = np.load(os.path.join(gold_dir, "sampler_g10_slope_sparse.npz"))
+    vox = z["vox"].copy()
+    run_oracle(z)
+    assert np.array_equal(vox, z["vox"])

@@ -94,7 +94,8 @@ class DeviceEvents:
         """Raise if the device reported a segment it could not order (a coarse bucket beyond the LDS
         capacity at an fps whose key range the sweep fallback cannot hold).  Synchronises."""
         if self._status is not None and int(self._status.item()) != 0:
-            raise hip.V2ceHipError("LDATI: a (frame, bin) segment has more equal-time events than the LDS sort "
+            raise hip.V2ceHipError(getattr(self, "_status_message", None) or
+                                   "LDATI: a (frame, bin) segment has more equal-time events than the LDS sort "
                                    "holds and the key range of this fps exceeds the sweep kernel's histogram")
 
     def to_recarrays(self) -> List[np.recarray]:

@@ -30,6 +30,7 @@ EXPORTS = [
     "v2ce_pack_weights", "v2ce_sn_workspace_bytes", "v2ce_sn_power_iter", "v2ce_sn_batch_workspace_bytes", "v2ce_sn_update_batch",
     "v2ce_preprocess_pairs", "v2ce_preprocess_pairs_resize",
     "v2ce_voxelize_events", "v2ce_conv3d_fwd_pred", "v2ce_conv3d_fwd_sc", "v2ce_pack_pred_weights_f16x2", "v2ce_pack_pred_weights_f16x2_bytes",
+    "v2ce_sampler_count", "v2ce_sampler_workspace_bytes", "v2ce_sampler_emit",
 ]
 
 
@@ -52,6 +53,16 @@ class SnLayer(ctypes.Structure):
 class LdatiOptions(ctypes.Structure):
     """``v2ce_ldati_options`` (include/v2ce_hip.h): the keyword options of sample_voxel_statistical."""
     _fields_ = [(n, ctypes.c_int32) for n in ("strategy", "bidirectional", "pooling_type", "pooling_kernel_size")]
+
+
+class SamplerOptions(ctypes.Structure):
+    """``v2ce_sampler_options`` (include/v2ce_hip.h): the ablation samplers of SURVEY 8f4."""
+    _fields_ = [("mode", ctypes.c_int32), ("rng_mode", ctypes.c_int32), ("fps", ctypes.c_double), ("t0", ctypes.c_double),
+                ("seed", ctypes.c_uint64), ("frame_base", ctypes.c_int32), ("replay_M", ctypes.c_int32),
+                ("u_int", ctypes.c_void_p), ("u_dec", ctypes.c_void_p), ("u_bern", ctypes.c_void_p)]
+
+
+SAMPLER_RANDOM, SAMPLER_EVEN, SAMPLER_PURE_SLOPE = 0, 1, 2
 
 
 class V2ceHipError(RuntimeError):
@@ -129,6 +140,13 @@ def lib() -> ctypes.CDLL:
     L.v2ce_sn_batch_workspace_bytes.restype = sz
     L.v2ce_sn_update_batch.argtypes = [ctypes.POINTER(SnLayer), i32, vp, sz, vp]
     L.v2ce_sn_update_batch.restype = ctypes.c_int
+    so = ctypes.POINTER(SamplerOptions)
+    L.v2ce_sampler_count.argtypes = [vp, i32, i32, i32, so, vp, vp, vp]
+    L.v2ce_sampler_count.restype = ctypes.c_int
+    L.v2ce_sampler_workspace_bytes.argtypes = [i64]
+    L.v2ce_sampler_workspace_bytes.restype = sz
+    L.v2ce_sampler_emit.argtypes = [vp, i32, i32, i32, so, i64, vp, vp, vp, vp, vp, sz, vp, vp]
+    L.v2ce_sampler_emit.restype = ctypes.c_int
     for name in ("v2ce_ldati_count", "v2ce_ldati_emit", "v2ce_events_pack",
                  "v2ce_conv3d_fwd", "v2ce_conv3d_variant", "v2ce_pack_weights", "v2ce_sn_power_iter"):
         getattr(L, name).restype = ctypes.c_int
