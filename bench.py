@@ -234,8 +234,12 @@ def main():
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     device = torch.device(f"cuda:{local}")
     torch.cuda.set_device(device)
-    if world > 1:
+    # V2CE_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL init, per-step EventGather, barriers, reductions)
+    # with a world of one -- how that path is exercised on a 1-GPU box (under torchrun --nproc-per-node 1)
+    dist_on = world > 1 or os.environ.get("V2CE_BENCH_FORCE_DIST") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     if args.workload == "voxelize":
         return bench_voxelize(args, device, rank, world)
@@ -299,7 +303,7 @@ def main():
         ev = pending.finish()
         packed = ev.packed()
         n_events[0] += ev.num_events
-        if world > 1:
+        if dist_on:
             # rank 0 receives every rank's records of this step over RCCL on a communication stream; the byte
             # counts it needs are read one step later, so no rank waits on its compute stream
             gathers.append(vdist.EventGather(packed, dst=0))
@@ -328,18 +332,18 @@ def main():
     conv_prof.clear()
     n_events[0] = 0
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run_steps(args.steps, True)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     events = float(n_events[0])
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt, events], dtype=torch.float64, device=device)
         tmax = t.clone()
         torch.distributed.all_reduce(tmax[:1], op=torch.distributed.ReduceOp.MAX)
@@ -431,7 +435,7 @@ def main():
         if model is not None and args.precision == "f16x2":
             # the split-half range guard over the timed steps: worst per-launch bound vs its limit
             line["range_guard"] = {"worst_bound": model.range_guard_value(), "limit": model.RANGE_GUARD_LIMIT}
-        if world > 1:
+        if dist_on:
             line["gathered_bytes_per_step"] = gather_bytes[0]
             line["rccl_world"] = world
         if world == 1 and args.workload == "e2e":
@@ -456,7 +460,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
-    if world > 1:
+    if dist_on:
         torch.distributed.destroy_process_group()
 
 

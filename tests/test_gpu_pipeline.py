@@ -124,3 +124,20 @@ def test_device_resize_matches_host_path(shape, height):
     got = glue.image_pre_processing_device(torch.from_numpy(fr).cuda(), height).cpu().numpy()
     assert got.shape == want.shape
     assert got.tobytes() == want.tobytes()
+
+
+def test_bench_rccl_path_world_of_one():
+    """bench.py's multi-rank code path (RCCL init, per-step EventGather on the communication stream, barriers,
+    reductions) under torchrun with a world of one -- what a 1-GPU box can exercise of `--gpus N`."""
+    import json
+    env = dict(os.environ, V2CE_BENCH_FORCE_DIST="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-host-to-host", "--no-exact-f32"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["rccl_world"] == 1
+    # the records of one step (13 bytes each; the spectral-norm state moves on from step to step, so not exactly the mean)
+    assert line["gathered_bytes_per_step"] % 13 == 0
+    assert abs(line["gathered_bytes_per_step"] / (13 * line["events_per_pair"] * 64) - 1) < 0.05
