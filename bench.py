@@ -196,9 +196,21 @@ def host_to_host(args, device, steps):
         print("host_to_host trace (s):", {k: (round(v, 4) if not isinstance(v, list) else v) for k, v in trace.items()},
               "total", round(dt, 4), file=sys.stderr)
     pairs = n_seq * SEQ
+    # the box's own device -> pinned-host copy rate for one step's records: on boxes where it is below
+    # d2h_bytes_per_step / GPU step time, the copy-out stream (not the GPU) paces the pipeline
+    nbytes = int(len(ev) * 13 / steps)
+    src = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    dst = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+    best = float("inf")
+    for _ in range(4):
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - c0)
     return {"value": pairs / dt, "unit": "frame-pairs/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
             "mevents_per_s": len(ev) / dt / 1e6, "h2d_bytes_per_step": int(args.batch * (SEQ + 1) * H * W),
-            "d2h_bytes_per_step": int(len(ev) * 13 / steps),
+            "d2h_bytes_per_step": nbytes, "d2h_copy_gb_per_s": nbytes / best / 1e9, "d2h_copy_ms_per_step": 1e3 * best,
             "what": "u8 frames in host memory -> event_stream array in pinned host memory through pipeline.run_clip "
                     "(copy-in / compute / copy-out streams); second clip of the process: the page-locked output "
                     "buffer is reused (the first clip additionally pays ~70 us per MB to lock it)"}
