@@ -74,6 +74,9 @@ struct ConvParams {
     const float *x0_absmax, *x1_absmax;
     float *y_absmax;
     float *guard;                 // = y_absmax + 1
+#ifdef V2CE_ABLATE_EPI
+    int ablate;                   // diagnostic build: skip the epilogue of this launch (tools/epi_ablate.sh)
+#endif
     // fused 1x1x1 head behind a 32-channel conv (v2ce_conv3d_fwd_pred): pred_y[o] = relu(pred_w[o][:] . y + pred_b[o])
     const _Float16 *pred_w;       // table of v2ce_pack_pred_weights_f16x2 (A fragments hi/lo + pre-scale)
     const float *pred_b;          // [32], zero padded
@@ -1050,6 +1053,19 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
                     poff[f] = 4 * ((t * P.Cout) * (P.Hout * P.Woutp)) + 64 * (h * P.Woutp + w);
             }
         }
+#ifdef V2CE_ABLATE_EPI   // diagnostic build only: what the step would cost if the epilogue were free (nothing is written)
+        if (P.ablate) {
+            float sink = 0.0f;
+#pragma unroll
+            for (int q = 0; q < CO_FR; ++q)
+#pragma unroll
+                for (int f = 0; f < PO_FR; ++f) {
+                    sink += acc[q][f][0];
+                    if constexpr (SC) sink += accd[q][f][0];
+                }
+            if (sink == 12345.678f && poff[0] >= 0) P.y[0] = sink;
+        } else
+#endif
         if constexpr (FUSE == 1) {                              // 32-channel conv with the fused 1x1x1 head
             static_assert(KS == 3 && S == 1 && WCO == 1 && CO_FR == 1, "the fused head rides on a 32-channel tile");
             conv_epilogue<CO_FR, PO_FR, true, true, RES, true>(P, acc, poff, co0, half, T.b, inv_scale);
@@ -1057,6 +1073,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
         } else {
             conv_epilogue<CO_FR, PO_FR, true, false, RES, true>(P, acc, poff, co0, half, T.b, inv_scale);   // Cout need not fill the last channel tile
         }
+#ifdef V2CE_ABLATE_EPI
+        if (!P.ablate)
+#endif
         if constexpr (SC) {                                     // shortcut: bn_d(conv_d x), no activation, no residual
             ConvParams Q = P;
             Q.scale = P.sc_scale; Q.shift = P.sc_shift; Q.res = nullptr; Q.y = P.sc_y; Q.act = V2CE_ACT_NONE;
@@ -1582,6 +1601,9 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
     P.act = d.act;
     P.x0_absmax = x0_absmax; P.x1_absmax = d.C1 > 0 ? x1_absmax : nullptr; P.y_absmax = y_absmax;
     P.guard = y_absmax ? y_absmax + 1 : nullptr;
+#ifdef V2CE_ABLATE_EPI
+    { const char *e = getenv("V2CE_ABLATE_EPI"); P.ablate = e && e[0] == '1'; }
+#endif
     if (pred_w && !y) P.y_absmax = nullptr;      // no y is materialised: only the guard value is reported
     P.pred_w = static_cast<const _Float16 *>(pred_w); P.pred_b = pred_b; P.pred_cout = pred_cout; P.pred_y = pred_y;
     P.sc_w = static_cast<const _Float16 *>(sc_w); P.sc_scale = sc_scale; P.sc_shift = sc_shift; P.sc_y = sc_y;
