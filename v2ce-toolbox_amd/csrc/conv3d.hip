@@ -93,7 +93,7 @@ struct ConvParams {
 };
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-constexpr float kActScale = 16.0f;      // pre-scale when the caller tracks no range: |x| < 4094 required
+[[maybe_unused]] constexpr float kActScale = 16.0f;      // pre-scale when the caller tracks no range: |x| < 4094 required
 
 template <int KS, int S, int CO_FR, int PO_FR, int CK, int EPT>
 struct ConvCfg {
@@ -506,7 +506,7 @@ __device__ __forceinline__ void step_loop(F &&f) {
     }
 }
 
-extern __shared__ __attribute__((aligned(16))) unsigned char conv_smem[];
+[[maybe_unused]] extern __shared__ __attribute__((aligned(16))) unsigned char conv_smem[];
 
 // LDS-DMA double-buffered direct convolution (see the file header).
 //   per chunk of CK input channels:  halo  [CK][chs]            (chs = plane rounded up to 64)
