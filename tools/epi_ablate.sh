@@ -8,8 +8,9 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 export V2CE_HIP_LIB=$PWD/v2ce-toolbox_amd/csrc/libv2ce_hip_ablate.so
 for i in 1 2; do
-  python tools/fwd_only.py 2>&1 | tail -1
-  ABLATE=1 python tools/fwd_only.py 2>&1 | tail -1
+  for m in 0 1 2 3; do echo -n "ABLATE=$m  "; ABLATE=$m python tools/fwd_only.py 2>&1 | tail -1; done
 done
-export ABLATE=1
-N=4 rocprofv3 --kernel-trace --stats -d gpurun_out/abl -o abl -- python3 tools/fwd_only.py > gpurun_out/abl.log 2>&1
+if [ -n "$PROFILE_MODE" ]; then
+  export ABLATE=$PROFILE_MODE
+  N=4 rocprofv3 --kernel-trace --stats -d gpurun_out/abl -o abl -- python3 tools/fwd_only.py > gpurun_out/abl.log 2>&1
+fi

@@ -15,11 +15,11 @@ x = bench.make_inputs(4, 0, dev)
 for _ in range(3):
     model(x)
 torch.cuda.synchronize()
-if os.environ.get("ABLATE") == "1":
+if os.environ.get("ABLATE", "0") != "0":      # 1 = no epilogue, 2 = stores dropped by the range check, 3 = residual loads dropped
     # from here on the diagnostic library skips every conv epilogue; the activation buffers (same addresses: the
     # caching allocator replays the allocation sequence) and the absmax table keep the values of the last real forward,
     # so the MFMAs chew on realistic data (all-zero operands would run ~25 % faster on this power-limited chip)
-    os.environ["V2CE_ABLATE_EPI"] = "1"
+    os.environ["V2CE_ABLATE_EPI"] = os.environ["ABLATE"]
     model._prep["absmax"].zero_ = lambda: None
 t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 t0.record()

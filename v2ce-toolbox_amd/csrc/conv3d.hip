@@ -172,6 +172,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &P, f32x16 (&acc)
         else vo[f] = poff[f] >= 0 ? (unsigned)(poff[f] * 4 + cbase * cstride4) : kOOB;
         vmask[f] = poff[f] >= 0 ? 0x7fffffffu : 0u;        // |v| of a masked lane counts as 0
     }
+#ifdef V2CE_ABLATE_EPI   // diagnostic build: 2 = every store is issued but dropped by the range check, 3 = every residual load
+    unsigned vo_st[PO_FR], vo_ld[PO_FR];
+#pragma unroll
+    for (int f = 0; f < PO_FR; ++f) {
+        vo_st[f] = P.ablate == 2 ? kOOB : vo[f];
+        vo_ld[f] = P.ablate == 3 ? kOOB : vo[f];
+    }
+#define V2CE_VO_ST vo_st
+#define V2CE_VO_LD vo_ld
+#else
+#define V2CE_VO_ST vo
+#define V2CE_VO_LD vo
+#endif
     // scalar (wave-uniform) byte offset of batch (q, r4) = channels cbase + 32 q + 8 r4 + {0..3}
     auto soff = [&](int q, int r4, int k) -> int {
         if (C16) return (co0 / 16 + 2 * q + (r4 >> 1)) * (cstride4 * 16) + 32 * (r4 & 1);
@@ -183,7 +196,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &P, f32x16 (&acc)
             const bool cok = !CHECK_CO || co0 + q * 32 + 8 * r4 < P.Cout;
 #pragma unroll
             for (int f = 0; f < PO_FR; ++f) {
-                const f32x4q v = __builtin_bit_cast(f32x4q, __builtin_amdgcn_raw_buffer_load_b128(rs_r, cok ? vo[f] : kOOB, soff(q, r4, 0), 0));
+                const f32x4q v = __builtin_bit_cast(f32x4q, __builtin_amdgcn_raw_buffer_load_b128(rs_r, cok ? V2CE_VO_LD[f] : kOOB, soff(q, r4, 0), 0));
                 rv[0][f] = v[0]; rv[1][f] = v[1]; rv[2][f] = v[2]; rv[3][f] = v[3];
             }
         } else {
@@ -193,7 +206,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &P, f32x16 (&acc)
                 for (int f = 0; f < PO_FR; ++f) {
                     const bool cok = !CHECK_CO || cbase + q * 32 + k + 8 * r4 < P.Cout;
                     rv[k][f] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                        rs_r, cok ? vo[f] : kOOB, soff(q, r4, k), 0));
+                        rs_r, cok ? V2CE_VO_LD[f] : kOOB, soff(q, r4, k), 0));
                 }
         }
     };
@@ -251,7 +264,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &P, f32x16 (&acc)
                     }
                     if (!KEEP || P.y) {                         // uniform: a fused head may not want y itself
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4q, out),
-                                                               rs_y, cok ? vo[f] : kOOB, soff(q, r4, 0), 0);
+                                                               rs_y, cok ? V2CE_VO_ST[f] : kOOB, soff(q, r4, 0), 0);
                         // A 16-byte store reads its data registers for several cycles after issue; a VALU write to
                         // them in the next slot corrupts dword 1 of lanes 12-15 / 28-31 (seen on gfx950: the
                         // compiler's hazard table exempts stores with an SGPR soffset).  The data registers stay
@@ -270,7 +283,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &P, f32x16 (&acc)
                     v = apply_act(v, slope);
                     const bool cok = !CHECK_CO || cbase + q * 32 + k + 8 * r4 < P.Cout;
                     if (!KEEP || P.y)                           // uniform: a fused head may not want y itself
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, cok ? vo[f] : kOOB,
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_y, cok ? V2CE_VO_ST[f] : kOOB,
                                                               soff(q, r4, k), 0);
                     const unsigned av = __builtin_bit_cast(unsigned, v) & (cok ? vmask[f] : 0u);
                     if (KEEP) acc[q][f][r] = __builtin_bit_cast(float, av == 0u ? 0u : __builtin_bit_cast(unsigned, v));
@@ -281,6 +294,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &P, f32x16 (&acc)
         }
     }
     if (P.y_absmax) absmax_commit(__builtin_bit_cast(float, ymax), P.y_absmax);
+#undef V2CE_VO_ST
+#undef V2CE_VO_LD
 }
 
 // Fused 1x1x1 head (the UNet's `pred` layer, unet_2layer.py:374) behind a 32-channel conv: the
@@ -1054,7 +1069,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
             }
         }
 #ifdef V2CE_ABLATE_EPI   // diagnostic build only: what the step would cost if the epilogue were free (nothing is written)
-        if (P.ablate) {
+        if (P.ablate == 1) {
             float sink = 0.0f;
 #pragma unroll
             for (int q = 0; q < CO_FR; ++q)
@@ -1074,7 +1089,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
             conv_epilogue<CO_FR, PO_FR, true, false, RES, true>(P, acc, poff, co0, half, T.b, inv_scale);   // Cout need not fill the last channel tile
         }
 #ifdef V2CE_ABLATE_EPI
-        if (!P.ablate)
+        if (P.ablate != 1)
 #endif
         if constexpr (SC) {                                     // shortcut: bn_d(conv_d x), no activation, no residual
             ConvParams Q = P;
@@ -1602,7 +1617,7 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
     P.x0_absmax = x0_absmax; P.x1_absmax = d.C1 > 0 ? x1_absmax : nullptr; P.y_absmax = y_absmax;
     P.guard = y_absmax ? y_absmax + 1 : nullptr;
 #ifdef V2CE_ABLATE_EPI
-    { const char *e = getenv("V2CE_ABLATE_EPI"); P.ablate = e && e[0] == '1'; }
+    { const char *e = getenv("V2CE_ABLATE_EPI"); P.ablate = e ? atoi(e) : 0; }
 #endif
     if (pred_w && !y) P.y_absmax = nullptr;      // no y is materialised: only the guard value is reported
     P.pred_w = static_cast<const _Float16 *>(pred_w); P.pred_b = pred_b; P.pred_cout = pred_cout; P.pred_y = pred_y;
