@@ -166,6 +166,8 @@ def gen_ldati_small():
         "stress": (synth.synthetic_voxels(2, 12, 14, seed=23, regime="stress"), 30, 0),
         "t0fps60": (synth.synthetic_voxels(2, 9, 11, seed=24, regime="stress"), 60, 0.5),
         "ragged": (synth.synthetic_voxels(1, 1, 67, seed=25, regime="stress"), 24, 0),
+        # a time bin of 11 111 us: more keys than the sweep kernel's LDS histogram holds (two-level path only)
+        "fps10": (synth.synthetic_voxels(2, 9, 11, seed=27, regime="stress"), 10, 0),
     }
     # additional_events_strategy='none' (only single-event voxels emit, LDATI.py:206-207,241)
     cases["none"] = (synth.synthetic_voxels(2, 12, 14, seed=26, regime="stress"), 30, 0)

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import ldati as O
-from v2ce_toolbox_amd import synth
+from v2ce_toolbox_amd import hip, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -46,6 +46,22 @@ def test_replay_matches_reference_golden_and_oracle(gold_dir, name, path):
     soa_equal(ev, *O.emit_soa(vox, fps=fps, t0=t0, uniforms=u, strategy=strategy))
     # vs the reference's own output: exact up to the tie order its unstable argsort leaves open
     mine = np.concatenate(ev.to_recarrays()) if ev.num_events else np.empty(0, O.EVENT_DTYPE)
+    assert np.array_equal(ev.frame_counts, z["lens"])
+    assert np.array_equal(mine["timestamp"], ref["timestamp"])
+    assert O.canonicalize(mine, ev.seg_counts.reshape(-1)).tobytes() == \
+        O.canonicalize(ref, ev.seg_counts.reshape(-1)).tobytes()
+
+
+def test_low_fps_reference_golden(gold_dir):
+    """G3 fps10: the reference's own output at 10 fps (11 111 us per bin: beyond the sweep kernel's LDS key histogram,
+    so the two-level path alone serves it)."""
+    z = np.load(os.path.join(gold_dir, "ldati_g3_fps10.npz"))
+    vox, u, fps, t0 = z["vox"], z["uniforms"], float(z["fps"]), float(z["t0"])
+    assert hip.lib().v2ce_ldati_lds_bytes(fps, t0) == 0
+    ref = np.frombuffer(z["events"].tobytes(), O.EVENT_DTYPE)
+    ev = hip_events(vox, fps, t0, uniforms=u)
+    soa_equal(ev, *O.emit_soa(vox, fps=fps, t0=t0, uniforms=u))
+    mine = np.concatenate(ev.to_recarrays())
     assert np.array_equal(ev.frame_counts, z["lens"])
     assert np.array_equal(mine["timestamp"], ref["timestamp"])
     assert O.canonicalize(mine, ev.seg_counts.reshape(-1)).tobytes() == \

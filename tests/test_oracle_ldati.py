@@ -10,7 +10,7 @@ import pytest
 from oracle import ldati as O
 from v2ce_toolbox_amd import synth
 
-CASES = ["sparse", "frac", "stress", "t0fps60", "ragged", "none"]
+CASES = ["sparse", "frac", "stress", "t0fps60", "ragged", "none", "fps10"]
 
 
 def load_g3(gold_dir, name):
