@@ -130,9 +130,14 @@ def test_bench_rccl_path_world_of_one():
     """bench.py's multi-rank code path (RCCL init, per-step EventGather on the communication stream, barriers,
     reductions) under torchrun with a world of one -- what a 1-GPU box can exercise of `--gpus N`."""
     import json
+    import socket
+    with socket.socket() as sock:                 # a free rendezvous port
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     env = dict(os.environ, V2CE_BENCH_FORCE_DIST="1")
+    env.pop("MASTER_PORT", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
            "--no-cpu-baseline", "--no-host-to-host", "--no-exact-f32"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
