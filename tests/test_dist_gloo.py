@@ -82,6 +82,8 @@ CASES = [
     (4, 85, "pano", 1, 20),        # 2 tiles on 4 ranks: two groups of two, batches sharded over the groups
     (2, 53, "pano", 1, 40),        # 4 tiles on 2 ranks: not a multiple -> batch sharding, tiles serial
     (4, 37, "center", 1, 20),      # more ranks than batches for some (3 batches on 4 ranks)
+    (8, 277, "center", 2, 20),     # the scaling bench's largest world: 9 batches of 2 sequences on 8 ranks
+    (8, 149, "pano", 1, 40),       # 4 tiles on 8 ranks: two tile groups of four, batches dealt to the groups
 ]
 
 
@@ -90,7 +92,10 @@ def test_world_equals_single_process(world, n_frames, infer_type, bs, wf):
     single = _single(n_frames, infer_type, bs, wf)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + n_frames + 7 * world + wf
+    import socket
+    with socket.socket() as sock:                 # a free rendezvous port
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, infer_type, bs, wf, q)) for r in range(world)]
     for p in procs:
         p.start()
