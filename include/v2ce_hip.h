@@ -187,6 +187,12 @@ typedef struct {
      * The exact-f32 kernels require PLANAR, with one bridge: the 2-channel head convolution (C0 == 2, Cout == 32,
      * 3x3x3) reads the planar network input and writes y in the layout named here. */
     int32_t layout;
+    /* Range-tracking slots per BATCH ELEMENT: 0 = y_absmax / x0_absmax / x1_absmax are one slot per tensor (below);
+     * s >= 2 = element b of the batch uses the slot at + b * s floats (y_absmax then spans B * s floats: max |y| of
+     * element b at [b * s], its range-guard value at [b * s + 1]).  Every sequence then gets its own power-of-two
+     * pre-scale, so its result is bit-identical whatever else shares the launch (batch-invariant numerics: what lets
+     * one reference batch be sharded over GPUs sequence by sequence). */
+    int32_t absmax_batch_stride;
 } v2ce_conv3d_desc;
 #define V2CE_LAYOUT_PLANAR 0
 #define V2CE_LAYOUT_C16 1

@@ -1,6 +1,8 @@
-"""CPU, world_size 2 and 4 over gloo: the N>1 paths of pipeline.run_clip -- batch sharding with the
-spectral-norm fast-forward, pano tile-per-rank with the all-to-all re-shard, the keyed
-variable-length gather (stage functions replaced by CPU stand-ins; index logic is the product's)."""
+"""CPU, world_size 2 / 4 / 8 over gloo: the N>1 paths of pipeline.run_clip -- every batch's sequences shared
+out over the ranks in lockstep (a rank may sit a batch out and catches its spectral-norm state up), pano
+tile-per-rank with the all-to-all re-shard (shares of ZERO frame-pairs included), the streamed per-batch
+variable-length gather (stage functions replaced by CPU stand-ins; index logic is the product's).  The same
+cases through ``dist.ThreadWorld`` (N ranks on N threads, the single-GPU emulation of the GPU tests)."""
 import os
 import sys
 
@@ -29,6 +31,8 @@ def fake_stage2(fps):
             r["y"] = int(float(vox[i].double().sum()) * 10) % 30000
             r["polarity"] = vox.shape[-1] % 100
             recs.append(r)
+        if not recs:
+            return torch.empty(0, dtype=torch.uint8)
         return torch.from_numpy(np.frombuffer(np.concatenate(recs).tobytes(), np.uint8).copy())
 
     def finish(handle):
@@ -83,7 +87,11 @@ CASES = [
     (2, 53, "pano", 1, 40),        # 4 tiles on 2 ranks: not a multiple -> batch sharding, tiles serial
     (4, 37, "center", 1, 20),      # more ranks than batches for some (3 batches on 4 ranks)
     (8, 277, "center", 2, 20),     # the scaling bench's largest world: 9 batches of 2 sequences on 8 ranks
-    (8, 149, "pano", 1, 40),       # 4 tiles on 8 ranks: two tile groups of four, batches dealt to the groups
+    (8, 149, "pano", 1, 40),       # 4 tiles on 8 ranks: two tile groups of four, one sequence per batch: a group idles
+    (4, 50, "pano", 1, 40),        # 49 pairs: the overlapped last sequence keeps ONE pair < 4 tiles: empty LDATI shares
+    (8, 51, "pano", 2, 40),        # two tile groups; last batch keeps 2 pairs
+    (8, 277, "center", 16, 20),    # BASELINE config 3's shape: a big batch shared out over 8 ranks (16 + 2 sequences)
+    (2, 17, "center", 4, 20),      # one sequence, two ranks
 ]
 
 
@@ -108,3 +116,24 @@ def test_world_equals_single_process(world, n_frames, infer_type, bs, wf):
     assert sorted(set(pairs.tolist())) == list(range(n_frames - 1))       # every frame-pair, in order
     assert np.all(np.diff(pairs) >= 0)
     assert gathered == sum(([r + 1] * (5 * r) for r in range(world)), [])
+
+
+@pytest.mark.parametrize("world,n_frames,infer_type,bs,wf", CASES)
+def test_thread_world_equals_single_process(world, n_frames, infer_type, bs, wf):
+    """dist.ThreadWorld (N ranks on N threads of this process) through the same driver."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_product_glue import FakeModel
+    from v2ce_toolbox_amd import dist as vd
+    from v2ce_toolbox_amd import synth
+    from v2ce_toolbox_amd import v2ce as cli
+    single = _single(n_frames, infer_type, bs, wf)
+    frames = synth.synthetic_frames(n_frames, 8, wf, seed=3)
+    models = [FakeModel() for _ in range(world)]
+    outs = vd.ThreadWorld(world).run(
+        lambda comm: cli.run(frames, models[comm.rank], infer_type=infer_type, width=12, height=8, batch_size=bs,
+                             device="cpu", stage2=fake_stage2(30), comm=comm))
+    assert all(o is None for o in outs[1:])
+    assert outs[0].tobytes() == single.tobytes()
+    ref = FakeModel()
+    _ = cli.run(frames, ref, infer_type=infer_type, width=12, height=8, batch_size=bs, device="cpu", stage2=fake_stage2(30))
+    assert all(m.calls == ref.calls for m in models)        # every rank's model ends where the single run's does

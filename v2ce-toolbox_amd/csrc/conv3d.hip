@@ -74,6 +74,9 @@ struct ConvParams {
     const float *x0_absmax, *x1_absmax;
     float *y_absmax;
     float *guard;                 // = y_absmax + 1
+    int amax_bs;                  // floats between the slots of consecutive batch elements (desc.absmax_batch_stride);
+                                  // 0 = one slot per tensor.  With a stride every sequence of the batch carries its own
+                                  // range and pre-scale, so its result does not depend on what else is in the batch
 #ifdef V2CE_ABLATE_EPI
     int ablate;                   // diagnostic build: skip the epilogue of this launch (tools/epi_ablate.sh)
 #endif
@@ -293,7 +296,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &P, f32x16 (&acc)
             }
         }
     }
-    if (P.y_absmax) absmax_commit(__builtin_bit_cast(float, ymax), P.y_absmax);
+    if (P.y_absmax) absmax_commit(__builtin_bit_cast(float, ymax), P.y_absmax + b * P.amax_bs);
 #undef V2CE_VO_ST
 #undef V2CE_VO_LD
 }
@@ -411,7 +414,7 @@ __device__ __forceinline__ void conv_epilogue_stream(const ConvParams &P, const 
             }
         }
     }
-    if (P.y_absmax) absmax_commit(ymax, P.y_absmax);
+    if (P.y_absmax) absmax_commit(ymax, P.y_absmax + b * P.amax_bs);
 }
 
 // byte offsets (relative to the sequence base of the source tensor) of this thread's halo elements;
@@ -743,13 +746,15 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
     };
 
     const float w_scale = reinterpret_cast<const float *>(P.wq + 2 * wplane)[1];
-    float x_scale = kActScale;
-    float am = 4094.0f;
-    if (P.x0_absmax) {
-        am = *P.x0_absmax;
-        if (P.x1_absmax) am = fmaxf(am, *P.x1_absmax);
-        x_scale = pow2_prescale(am);
-    }
+    // max |x| of batch element b as its producers recorded it (one slot per element with amax_bs > 0, else one per
+    // tensor); without tracking the fixed pre-scale kActScale applies (|x| < 4094 required)
+    auto amax_of = [&](int b) -> float {
+        if (!P.x0_absmax) return 4094.0f;
+        float am = P.x0_absmax[b * P.amax_bs];
+        if (P.x1_absmax) am = fmaxf(am, P.x1_absmax[b * P.amax_bs]);
+        return am;
+    };
+    auto scale_of = [&](int b) -> float { return P.x0_absmax ? pow2_prescale(amax_of(b)) : kActScale; };
     // Range guard (y_absmax[1]): a bound on what the one-scale-per-tensor split can cost this launch's
     // outputs.  An operand whose scaled magnitude is below 2^-3 has an fp16-SUBNORMAL lo half: hi + lo
     // then misses it by up to 2^-25 (scaled), instead of by 2^-22 relative.  Worst case over a K-term
@@ -757,18 +762,25 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
     //   E = max|scale| * K * 2^-25 * (max|w| / x_scale + max|x| / w_scale)
     // (first term: activations flushed, second: weights flushed).  The host compares E with its limit
     // after the run (v2ce_3d.V2ce3d.range_guard_value) and repeats the clip on the exact-f32 kernels.
+    // With per-element slots every batch element reports its own bound (slot b, second float).
     if (P.guard && blockIdx.x == 0 && wave == 0) {
-        auto bound = [&](const float *scale, const _Float16 *wq, long long plane_halves, int K) {
+        auto smax = [&](const float *scale) {
             float sm = 0.0f;
             for (int co = lane; co < P.Cout; co += 64) sm = fmaxf(sm, fabsf(scale[co]));
 #pragma unroll
             for (int o = 32; o; o >>= 1) sm = fmaxf(sm, __shfl_xor(sm, o));
-            const float *tail = reinterpret_cast<const float *>(wq + 2 * plane_halves);
-            return sm * (float)K * 0x1p-25f * (tail[0] / x_scale + am / tail[1]);
+            return sm;
         };
-        float E = bound(P.scale, P.wq, wplane, P.Cin * K3);
-        if (FUSE == 2) E = fmaxf(E, bound(P.sc_scale, P.sc_w, (long long)CG * P.Cout * 16, P.Cin));
-        if (lane == 0) *P.guard = E;
+        const float sm = smax(P.scale), smd = FUSE == 2 ? smax(P.sc_scale) : 0.0f;
+        const float *tail = reinterpret_cast<const float *>(P.wq + 2 * wplane);
+        const float *taild = reinterpret_cast<const float *>(P.sc_w + 2 * (long long)CG * P.Cout * 16);
+        const int nb = P.amax_bs ? P.B : 1;
+        for (int b = lane; b < nb; b += 64) {
+            const float am = amax_of(b), xs = scale_of(b);
+            float E = sm * (float)(P.Cin * K3) * 0x1p-25f * (tail[0] / xs + am / tail[1]);
+            if (FUSE == 2) E = fmaxf(E, smd * (float)P.Cin * 0x1p-25f * (taild[0] / xs + am / taild[1]));
+            P.guard[b * P.amax_bs] = E;
+        }
     }
 
     int vb = blockIdx.x;
@@ -785,6 +797,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
         // chunk, most of it waiting for their own loads, and set the pace of every layer).  The load
         // cursor (tile, chunk) therefore runs two chunks ahead of the conversion, across tiles.
         const int ptid = tid - 256;
+        float x_scale = scale_of(T.b);                      // pre-scale of the tile being converted
         unsigned goff[EPT];
         float R0[CK][EPT], R1[CK][EPT];
         __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x0), 0, 0, 0x00020000);
@@ -875,6 +888,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
                 cgC = 0;
                 vb += (int)gridDim.x;
                 moreC = next_tile(vb, T);
+                if (moreC) x_scale = scale_of(T.b);
             }
         };
         STAMP(1, 0);
@@ -909,7 +923,6 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
     const int lo_off = (int)(2 * wplane);                  // bytes from the hi plane to the lo plane
     const int tap_stride = CG * P.Cout * 32;               // bytes between taps
     const int cg_stride = P.Cout * 32;                     // bytes between 16-channel groups
-    const float inv_scale = 1.0f / (x_scale * w_scale);     // a power of two: exact
     constexpr bool SC = FUSE == 2;
     static_assert(!SC || (KS == 3 && CO_FR == 1), "the fused shortcut needs a second accumulator set: 32-channel wave tiles");
     const long long wplane_d = (long long)CG * P.Cout * 16;                  // halves per plane of the shortcut weights
@@ -934,6 +947,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
     bool more = true;
     while (more) {
         const int co0 = T.co_t * CO_TILE + wco * CO_FR * 32;     // this wave's first channel
+        const float x_scale = scale_of(T.b);
+        const float inv_scale = 1.0f / (x_scale * w_scale);      // a power of two: exact
         int bhb[PO_FR];
 #pragma unroll
         for (int f = 0; f < PO_FR; ++f) {
@@ -1292,7 +1307,7 @@ __global__ __launch_bounds__(256) void conv3d_head_kernel(ConvParams P) {
             ymax = fmaxf(ymax, ok ? fabsf(v) : 0.0f);
         }
     }
-    if (P.y_absmax) absmax_commit(ymax, P.y_absmax);
+    if (P.y_absmax) absmax_commit(ymax, P.y_absmax + b * P.amax_bs);
 #endif
 }
 
@@ -1616,6 +1631,8 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
     P.act = d.act;
     P.x0_absmax = x0_absmax; P.x1_absmax = d.C1 > 0 ? x1_absmax : nullptr; P.y_absmax = y_absmax;
     P.guard = y_absmax ? y_absmax + 1 : nullptr;
+    P.amax_bs = d.absmax_batch_stride;
+    V2CE_REQUIRE(P.amax_bs == 0 || P.amax_bs >= 2, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd: absmax_batch_stride must be 0 or >= 2");
 #ifdef V2CE_ABLATE_EPI
     { const char *e = getenv("V2CE_ABLATE_EPI"); P.ablate = e ? atoi(e) : 0; }
 #endif
@@ -1722,7 +1739,9 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
                  "(desc.layout = V2CE_LAYOUT_PLANAR); only the 2-channel head convolution can write the channels-last-16 layout");
     // CK per (ksize, stride): sized so 2 workgroups share a CU's 160 KiB of LDS
     // fewer positions per workgroup when the launch would otherwise leave CUs idle
-    const long long pos_total = (long long)d.B * d.T * d.Hout * d.Wout;
+    // (decided per SEQUENCE, as for a batch of four: the choice sets CK and with it the summation order, which
+    // must not depend on how many sequences share the launch -- a sequence's result is the same in any batch)
+    const long long pos_total = 4ll * d.T * d.Hout * d.Wout;
     const int co_tiles = small_co ? 1 : (d.Cout + 63) / 64;
     const bool small_pos = (pos_total / 512) * co_tiles < 512;
 #define V2CE_CK_OK(CK) V2CE_REQUIRE(d.C1 == 0 || d.C0 % (CK) == 0, V2CE_ERR_UNSUPPORTED, \

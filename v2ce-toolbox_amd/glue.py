@@ -72,12 +72,12 @@ def image_pre_processing_device(frames: torch.Tensor, height: Optional[int] = No
     return units
 
 
-def run_guarded(model, fn, group=None):
+def run_guarded(model, fn, comm=None):
     """fn() (a whole clip through ``model``) under the split-half range guard (include/v2ce_hip.h,
     VERDICT r1 #7): if a convolution reported a guard bound above the limit -- activations whose dynamic
     range one scale per tensor does not cover at the 1e-5 bar -- the spectral-norm state is rewound and
     fn() runs again on the exact-f32 kernels; the result is then that of precision='f32'.  The decision
-    is the maximum over the ranks of ``group`` (every rank must take the same branch: fn may contain
+    is the maximum over the ranks of ``comm`` (every rank must take the same branch: fn may contain
     collectives).  Models without the guard (test stand-ins) run fn() once."""
     if not hasattr(model, "range_guard_value") or getattr(model, "precision", None) != "f16x2":
         return fn()
@@ -85,12 +85,10 @@ def run_guarded(model, fn, group=None):
     model.range_guard_value()                              # clear what earlier calls left
     out = fn()
     worst = model.range_guard_value()
-    if torch.distributed.is_available() and torch.distributed.is_initialized() and \
-            torch.distributed.get_world_size(group) > 1:
-        dev = next(model.parameters()).device
-        t = torch.tensor([worst], dtype=torch.float32, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=group)
-        worst = float(t.item())
+    if comm is None:
+        from . import dist as vdist
+        comm = vdist.default_comm()
+    worst = comm.max_float(worst, device=next(model.parameters()).device)
     if worst <= model.RANGE_GUARD_LIMIT:
         return out
     import logging

@@ -41,7 +41,8 @@ class ConvDesc(ctypes.Structure):
     """``v2ce_conv3d_desc`` (include/v2ce_hip.h)."""
     _fields_ = [(n, ctypes.c_int32) for n in (
         "B", "T", "C0", "H0", "W0", "C1", "Hin", "Win", "Cout", "Hout", "Wout", "ksize",
-        "stride_hw", "act", "tile_t", "tile_h", "tile_w", "precision", "W0_pitch", "Win_pitch", "Wout_pitch", "layout")]
+        "stride_hw", "act", "tile_t", "tile_h", "tile_w", "precision", "W0_pitch", "Win_pitch", "Wout_pitch", "layout",
+        "absmax_batch_stride")]
 
 
 class SnLayer(ctypes.Structure):

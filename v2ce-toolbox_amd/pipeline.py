@@ -15,15 +15,17 @@ The counter-based Philox draws make LDATI independent of the chunking, so a batc
 also the LDATI chunk (``rng='torch'`` keeps the reference's --stage2_batch_size chunks over the whole
 clip: ``v2ce.events_from_voxels``).
 
-Multi-GPU (one process per GPU, ``torch.distributed``):
+Multi-GPU (one process per GPU, ``torch.distributed``; ``dist.py``):
 
-* ``shard='batches'``: contiguous blocks of batches per rank, no data-path collective; each rank
-  fast-forwards its spectral-norm state to the global model-call index of its first batch.
-* ``shard='tiles'`` (pano, world a multiple of the tile count; BASELINE config 4): rank g of a group
-  runs tile g of every batch of the group (global call index batch*tiles + g), then one all-to-all
-  re-shards from W-tiles to frame-pairs so every rank runs full-width LDATI on its pairs.
-* either way ONE variable-length gather of the packed records to rank 0 at the end
-  (``dist.gather_segments``).
+* every rank walks ALL batches in lockstep and takes a contiguous share of each batch's SEQUENCES (BASELINE config
+  3: ``-b 32`` on 8 GPUs = four sequences per GPU per model call); no data-path collective, the spectral-norm
+  iteration of call k happens on every rank at step k, and a sequence's result does not depend on the batch it is
+  launched in (per-element range slots);
+* pano with a world that is a multiple of the tile count (BASELINE config 4): rank g of a tile group runs tile g
+  (reference call index batch*tiles + g), then one all-to-all re-shards W-tiles -> frame-pairs so every rank
+  runs full-width LDATI on its pairs; sequences are shared out over the groups;
+* the packed records stream to rank 0 batch by batch (``dist.StreamedGather`` on a communication stream; rank
+  order inside a step is frame-pair order), straight into the pinned host buffer of the clip.
 """
 from __future__ import annotations
 
@@ -126,8 +128,8 @@ class EventSink:
             new[:self.used].copy_(self.buf[:self.used])
         self.buf = new
 
-    def push(self, packed: torch.Tensor, n_pairs: int, keep=()):
-        """`packed` was produced on the current stream of its device."""
+    def push(self, packed: torch.Tensor, n_pairs: int, keep=(), src_stream=None):
+        """`packed` was produced on `src_stream` (default: the current stream of its device)."""
         n = int(packed.numel())
         self.pairs_seen += n_pairs
         if not self.cuda:
@@ -137,7 +139,7 @@ class EventSink:
         self._reserve(n)
         if n:
             ready = torch.cuda.Event()
-            ready.record(torch.cuda.current_stream(self.device))
+            ready.record(src_stream if src_stream is not None else torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.stream):
                 self.stream.wait_event(ready)
                 self.buf[self.used:self.used + n].copy_(packed, non_blocking=True)
@@ -256,12 +258,22 @@ def event_frame_sums(vox: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def shard_of_batch(bp: BatchPlan, seq_len: int, part: int, parts: int) -> BatchPlan:
+    """The contiguous share `part` of `parts` of a batch's sequences as a plan of its own (may be empty):
+    only the batch's LAST sequence is the overlapped one, so only the share that holds it drops pairs."""
+    lo, hi = vdist.shard_range(len(bp.seqs), part, parts)
+    drop = bp.drop if (hi == len(bp.seqs) and hi > lo) else 0
+    return BatchPlan(bp.index, bp.seqs[lo:hi], bp.starts[lo:hi], drop, bp.first_pair + lo * seq_len,
+                     (hi - lo) * seq_len - drop)
+
+
 def run_clip(frames: np.ndarray, model, *, infer_type="center", seq_len=16, width=346, height=260,
              batch_size=1, fps=30, seed=0, device="cuda", stage2=None, dtype=None,
-             rank=0, world=1, group=None, trace: Optional[dict] = None,
+             comm=None, trace: Optional[dict] = None,
              reuse_output: bool = False, event_frames: Optional[list] = None) -> Optional[np.ndarray]:
     """frames [N,H,W] uint8 -> event_stream (structured array) on rank 0, None elsewhere.
 
+    comm: ``dist.TorchComm`` / ``dist.ThreadComm`` / ``dist.LocalComm`` (default: from torch.distributed).
     stage2: optional (begin, finish) pair replacing LDATI (CPU stand-ins in the tests):
     begin(vox, first_pair) -> handle; finish(handle) -> (packed uint8 tensor, keepalive).
     event_frames: a list that receives, per batch, (first pair, event_frame_sums(voxels)) on the device
@@ -269,26 +281,37 @@ def run_clip(frames: np.ndarray, model, *, infer_type="center", seq_len=16, widt
     runs only."""
     from .LDATI import EVENT_DTYPE
     dtype = dtype or EVENT_DTYPE
+    comm = comm or vdist.default_comm()
+    rank, world = comm.rank, comm.world
+    if infer_type not in ("center", "pano"):
+        raise ValueError(f"Invalid infer_type {infer_type}")
     plans = plan_batches(len(frames), seq_len, batch_size)
     begin, finish = stage2 or default_stage2(fps, seed, len(frames) - 1, device)
     fw = resized_width(frames, height)
     tiles = pano_tiles(fw, width) if infer_type == "pano" else None
-    if infer_type not in ("center", "pano"):
-        raise ValueError(f"Invalid infer_type {infer_type}")
     calls_per_batch = len(tiles) if tiles else 1
     tile_parallel = bool(tiles) and len(tiles) > 1 and world > 1 and world % len(tiles) == 0
     if tile_parallel:
-        n_groups = world // len(tiles)
-        grp_index, tile_index = divmod(rank, len(tiles))
-        grp = vdist.subgroup(len(tiles), rank, world)
-        lo_b, hi_b = vdist.shard_range(len(plans), grp_index, n_groups)
+        # groups of len(tiles) ranks: rank g of a group runs tile g; the batch's sequences are shared out over the groups
+        seq_part, tile_index = divmod(rank, len(tiles))
+        seq_parts = world // len(tiles)
+        grp = comm.tile_group(len(tiles))
+        widths = [(k if k else width) for _, _, k in tiles]
     else:
-        grp, tile_index = None, None
-        lo_b, hi_b = vdist.shard_range(len(plans), rank, world)
-    mine = plans[lo_b:hi_b]
-    total_pairs = sum(bp.n_pairs for bp in mine)
+        seq_part, seq_parts, tile_index, grp = rank, world, None, None
+    mine = [shard_of_batch(bp, seq_len, seq_part, seq_parts) for bp in plans]
     feeder = FrameFeeder(frames, seq_len, device, height)
-    sink = EventSink(device, total_pairs, to_host=world == 1, reuse=reuse_output)
+    # rank 0 owns the host buffer of the whole clip; the other ranks only feed the gather
+    sink = EventSink(device, len(frames) - 1, reuse=reuse_output) if rank == 0 else None
+    gather = None
+    if world > 1:
+        step_pairs = collections.deque(bp.n_pairs for bp in plans)
+
+        def on_pieces(pieces, stream):
+            n = step_pairs.popleft()
+            for k, p in enumerate(pieces):                  # rank order = frame-pair order inside a step
+                sink.push(p, n if k == 0 else 0, src_stream=stream)
+        gather = comm.streamed_gather(on_pieces if rank == 0 else None, dst=0)
     base_calls = int(getattr(model, "calls", 0))            # the reference keeps advancing one model
     import time as _time
 
@@ -298,52 +321,68 @@ def run_clip(frames: np.ndarray, model, *, infer_type="center", seq_len=16, widt
             trace.setdefault("list:" + name, []).append(round(1e3 * (_time.perf_counter() - t0), 2))
         return _time.perf_counter()
 
-    segments = []                                          # (order key, bytes) of every pushed buffer
-    statuses = []
-    pending = None                                         # (stage-2 handle, order key, pairs)
+    status = {"acc": None, "msg": None}                     # device-side OR of the LDATI status words of the clip
+    pending = None                                          # (stage-2 handle, pairs)
 
     def flush(p):
-        handle, key, n_pairs = p
+        handle, n_pairs = p
         t_f = _time.perf_counter()
-        packed, keep = finish(handle)
+        if handle is None:                                  # this rank had no pairs in that batch
+            packed, keep = torch.empty(0, dtype=torch.uint8, device=device), None
+        else:
+            packed, keep = finish(handle)
         t_f = tick("flush.finish", t_f)
-        sink.push(packed, n_pairs, keep)
+        st = getattr(keep, "_status", None)
+        if st is not None:                                  # 4 bytes folded on the stream; the event object is not retained
+            if status["acc"] is None:
+                status["acc"] = torch.zeros_like(st)
+            torch.maximum(status["acc"], st, out=status["acc"])
+            status["msg"] = getattr(keep, "_status_message", None) or status["msg"]
+        if gather is not None:
+            gather.submit(packed)
+        else:
+            sink.push(packed, n_pairs, keep)
         tick("flush.push", t_f)
-        segments.append((key, int(packed.numel())))
-        if hasattr(keep, "check"):
-            statuses.append(keep)
 
+    def next_nonempty(i):
+        while i < len(mine) and not mine[i].seqs:
+            i += 1
+        return i
 
-    handle = feeder.submit(mine[0]) if mine else None
+    nxt_i = next_nonempty(0)
+    handle = feeder.submit(mine[nxt_i]) if nxt_i < len(mine) else None
     with torch.no_grad():
         for i, bp in enumerate(mine):
             tt = _time.perf_counter()
-            units = feeder.take(handle, bp)
-            tt = tick("take", tt)
-            handle = feeder.submit(mine[i + 1]) if i + 1 < len(mine) else None
-            tt = tick("submit", tt)
-            if not tile_parallel:
-                vdist.fast_forward(model, base_calls + bp.index * calls_per_batch)
-                if infer_type == "center":
-                    pred = glue.infer_center_image_unit(model, units, width)
+            vox, first_pair = None, bp.first_pair
+            if bp.seqs:
+                units = feeder.take(handle, bp)
+                tt = tick("take", tt)
+                nxt_i = next_nonempty(i + 1)
+                handle = feeder.submit(mine[nxt_i]) if nxt_i < len(mine) else None
+                tt = tick("submit", tt)
+                # call index of this batch in the reference's schedule (one spectral-norm iteration per call);
+                # ranks that sat a batch out catch up here
+                vdist.fast_forward(model, base_calls + bp.index * calls_per_batch + (tile_index or 0))
+                if not tile_parallel:
+                    if infer_type == "center":
+                        pred = glue.infer_center_image_unit(model, units, width)
+                    else:
+                        pred = glue.infer_pano_image_unit(model, units, width)
+                    vox = _voxels_of_batch(pred, bp, seq_len)
                 else:
-                    pred = glue.infer_pano_image_unit(model, units, width)
-                vox, first_pair, key = _voxels_of_batch(pred, bp, seq_len), bp.first_pair, (bp.index, 0)
-            else:
-                # one tile per rank of the group; reference call index of (batch, tile)
-                vdist.fast_forward(model, base_calls + bp.index * calls_per_batch + tile_index)
-                lo, hi, keep_cols = tiles[tile_index]
-                pred = model(units[..., lo:hi].float().contiguous())
-                if keep_cols:
-                    pred = pred[..., -keep_cols:]
-                part = _voxels_of_batch(pred, bp, seq_len)                       # [P,2,10,H,wt]
-                widths = [(k if k else width) for _, _, k in tiles]
-                vox, p_lo = vdist.tiles_to_pairs(part, widths, tile_index, grp)  # [P_r,2,10,H,W_full]
-                first_pair, key = bp.first_pair + p_lo, (bp.index, tile_index)
+                    lo, hi, keep_cols = tiles[tile_index]
+                    pred = model(units[..., lo:hi].float().contiguous())
+                    if keep_cols:
+                        pred = pred[..., -keep_cols:]
+                    part = _voxels_of_batch(pred, bp, seq_len)                          # [P,2,10,H,wt]
+                    vox, p_lo = comm.tiles_to_pairs(part, widths, tile_index, grp)       # [P_r,2,10,H,W_full]
+                    first_pair += p_lo
             tt = tick("model", tt)
-            if event_frames is not None:
+            if event_frames is not None and vox is not None:
                 event_frames.append((first_pair, event_frame_sums(vox)))
-            nxt = (begin(vox, first_pair), key, int(vox.shape[0]))
+            nxt = (begin(vox, first_pair) if vox is not None and vox.shape[0] else None,
+                   0 if vox is None else int(vox.shape[0]))
             tt = tick("begin", tt)
             if pending is not None:
                 flush(pending)
@@ -351,15 +390,12 @@ def run_clip(frames: np.ndarray, model, *, infer_type="center", seq_len=16, widt
             pending = nxt
         if pending is not None:
             flush(pending)
-    for ev in statuses:
-        ev.check()
-    if world == 1:
-        return sink.result(dtype)
-    out = vdist.gather_segments(sink.tensor(), segments, dst=0, group=group)
-    if out is None:
-        return None
-    if out.is_cuda:                                        # one D2H pass on rank 0
-        host = torch.empty(out.numel(), dtype=torch.uint8, pin_memory=True)
-        host.copy_(out)
-        return host.numpy().view(dtype)
-    return np.ascontiguousarray(out.numpy()).view(dtype)
+        # every rank leaves the model where the single-process run leaves it
+        vdist.fast_forward(model, base_calls + len(plans) * calls_per_batch)
+    if gather is not None:
+        gather.drain()
+    if status["acc"] is not None and int(status["acc"].item()) != 0:
+        from . import hip
+        raise hip.V2ceHipError(status["msg"] or "LDATI: a (frame, bin) segment could not be ordered on the device "
+                               "(more equal-time events than the LDS sort holds at an fps beyond the sweep kernel's histogram)")
+    return sink.result(dtype) if rank == 0 else None

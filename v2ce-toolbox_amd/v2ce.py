@@ -7,10 +7,10 @@ Flags, defaults, output file name (``{name}-ceil_{ceil}-fps_{fps}[-suffix]-event
 LDATI, the whole clip goes through LDATI in chunks on the device, and the per-frame timestamp
 offset (v2ce.py:365) is fused into the emit kernel.
 
-Under ``torchrun`` (WORLD_SIZE > 1) batches of sequences are sharded over ranks in contiguous blocks
-(pano with a world size that is a multiple of the tile count: one tile per GPU + all-to-all
-re-shard, ``pipeline.py``) and the packed events are gathered to rank 0 over RCCL (``dist.py``);
-rank 0 writes the file.
+Under ``torchrun`` (WORLD_SIZE > 1) the sequences of every batch are shared out over the ranks (``-b 32`` on
+8 GPUs: four sequences per GPU per model call; pano with a world size that is a multiple of the tile count:
+one tile per GPU + all-to-all re-shard, ``pipeline.py``) and the packed events stream to rank 0 over RCCL
+batch by batch (``dist.py``); rank 0 writes the file.
 """
 from __future__ import annotations
 
@@ -128,7 +128,7 @@ def events_from_voxels(pred_voxel: torch.Tensor, fps, stage2_batch_size=24, seed
     uniform tensor exactly like the reference's --stage2_batch_size (LDATI.py:169-171)."""
     L = pred_voxel.shape[0]
     chunk = stage2_batch_size if rng == "torch" else max(stage2_batch_size, 96)
-    packed, counts = [], []
+    packed, counts, status = [], [], None
     for i in range(0, L, chunk):
         part = pred_voxel[i:i + chunk]
         add = torch.tensor([glue.frame_offset_us(first_pair + i + j, fps) for j in range(part.shape[0])],
@@ -136,6 +136,12 @@ def events_from_voxels(pred_voxel: torch.Tensor, fps, stage2_batch_size=24, seed
         ev = ldati_device(part, fps=fps, rng=rng, seed=seed, frame_base=first_pair + i, frame_ts_add=add)
         packed.append(ev.packed())
         counts.append(ev.frame_counts)
+        if ev._status is not None:                             # device status words of the chunks, folded on the stream
+            status = ev._status.clone() if status is None else torch.maximum(status, ev._status)
+    if status is not None and int(status.item()) != 0:         # (the caller downloads next: this wait costs nothing extra)
+        from . import hip
+        raise hip.V2ceHipError("LDATI: a (frame, bin) segment could not be ordered on the device (more equal-time events "
+                               "than the LDS sort holds at an fps beyond the sweep kernel's histogram)")
     return packed, np.concatenate(counts)
 
 
@@ -195,7 +201,7 @@ def write_event_frame_video(efs: np.ndarray, ef_video_path, fps, ceil, upper_bou
 
 def run(frames: np.ndarray, model, infer_type="center", seq_len=16, width=346, height=260,
         batch_size=1, fps=30, stage2_batch_size=24, seed=0, rng="philox", device="cuda",
-        stage2=None, event_frames: Optional[list] = None) -> Optional[np.ndarray]:
+        stage2=None, event_frames: Optional[list] = None, comm=None) -> Optional[np.ndarray]:
     """frames [N,H,W] uint8 -> event_stream (numpy structured array, v2ce.py:368) on rank 0.
 
     Default (counter-based Philox draws): the per-batch pipeline of ``pipeline.run_clip`` (H2D,
@@ -204,8 +210,8 @@ def run(frames: np.ndarray, model, infer_type="center", seq_len=16, width=346, h
     chunks of --stage2_batch_size with one dense torch.rand per chunk (LDATI.py:169-171) -- because
     that draw order depends on the chunking."""
     from . import pipeline
-    rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
-    world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+    comm = comm or vdist.default_comm(force=os.environ.get("V2CE_FORCE_DIST") == "1")
+    world = comm.world
     if rng == "torch":
         if world > 1:
             raise NotImplementedError("rng='torch' replays the reference's single-process draw order; run it on one GPU")
@@ -225,11 +231,11 @@ def run(frames: np.ndarray, model, infer_type="center", seq_len=16, width=346, h
                 del event_frames[:]
             return pipeline.run_clip(frames, model, infer_type=infer_type, seq_len=seq_len, width=width, height=height,
                                      batch_size=batch_size, fps=fps, seed=seed, device=device, stage2=stage2,
-                                     dtype=EVENT_DTYPE, rank=rank, world=world,
+                                     dtype=EVENT_DTYPE, comm=comm,
                                      event_frames=event_frames if world == 1 else None)
     # the split-half convolutions report a dynamic-range bound; beyond its limit the clip is repeated on
     # the exact-f32 kernels (glue.run_guarded)
-    return glue.run_guarded(model, clip)
+    return glue.run_guarded(model, clip, comm=comm)
 
 
 def main(argv=None):
@@ -237,7 +243,10 @@ def main(argv=None):
     logging.basicConfig(level=getattr(logging, args.log_level.upper()))
     world = int(os.environ.get("WORLD_SIZE", 1))
     device = args.device
-    if world > 1:
+    # V2CE_FORCE_DIST=1: take the torch.distributed code path (RCCL init, streamed gather, reductions) with a world
+    # of one -- how a 1-GPU box exercises it (under torchrun --nproc-per-node 1)
+    dist_on = world > 1 or os.environ.get("V2CE_FORCE_DIST") == "1"
+    if dist_on:
         local = int(os.environ.get("LOCAL_RANK", 0))
         device = f"cuda:{local}"
         torch.cuda.set_device(local)
@@ -290,7 +299,7 @@ def main(argv=None):
         path = op.join(args.out_folder, f"{output_name}-events.npz")
         np.savez(path, event_stream=event_stream)
         print(path)
-    if world > 1:
+    if dist_on:
         torch.distributed.destroy_process_group()
 
 

@@ -252,7 +252,9 @@ class V2ce3d(nn.Module):
         # one max-|y| slot per conv launch of a forward pass (split-half path: the consumer derives its
         # power-of-two activation pre-scale from the producer's slot, all on the device)
         # (+ the launch's range-guard value in the second float, include/v2ce_hip.h)
-        P["absmax"] = torch.zeros((64, 2), dtype=torch.float32, device=dev)
+        # -- per BATCH ELEMENT (desc.absmax_batch_stride = 2): a sequence's pre-scales, and with them its result, do
+        # not depend on what else is in the batch; sized per batch size in _forward
+        P["absmax"] = torch.zeros((64, 1, 2), dtype=torch.float32, device=dev)
         P["guard"] = torch.zeros(1, dtype=torch.float32, device=dev)     # max guard value since the last read
         self._prep = P
 
@@ -346,10 +348,13 @@ class V2ce3d(nn.Module):
                          tile_t=0, tile_h=0, tile_w=0,
                          precision=hip.PRECISION_F16X2 if split else hip.PRECISION_F32,
                          W0_pitch=W0p, Win_pitch=Winp, Wout_pitch=Woutp,
-                         layout=hip.LAYOUT_C16 if c16 else hip.LAYOUT_PLANAR)
+                         layout=hip.LAYOUT_C16 if c16 else hip.LAYOUT_PLANAR,
+                         # [slot][B][2] table: one range slot per batch element (callers of the raw kernels that
+                         # keep a [slot][2] table get one slot per tensor)
+                         absmax_batch_stride=2 if self._prep["absmax"].dim() == 3 else 0)
         a0 = a1 = ay = None
         if track or split:         # range tracking for the split-half consumers (device side only)
-            ay = y.absmax = self._prep["absmax"][self._slot]              # [max |y|, range-guard value]
+            ay = y.absmax = self._prep["absmax"][self._slot]              # [B] x [max |y|, range-guard value]
             self._slot += 1
             if split:          # untracked inputs (None) select the kernel's fixed pre-scale
                 a0 = getattr(x0, "absmax", None)
@@ -509,7 +514,10 @@ class V2ce3d(nn.Module):
         P, U = self._prep, self.UNet
         self._slot = 0
         if self.precision == "f16x2":
-            P["absmax"].zero_()
+            if P["absmax"].shape[1] != x.shape[0]:
+                P["absmax"] = torch.zeros((64, x.shape[0], 2), dtype=torch.float32, device=x.device)
+            else:
+                P["absmax"].zero_()
         self._launch_sn()
         inter = OrderedDict()
         h = self._conv(x, None, *P["head"], BASE, 3, 1, hip.ACT_LEAKY,           # unet_2layer.py:341
@@ -541,7 +549,7 @@ class V2ce3d(nn.Module):
             out = self._conv(h, None, *P["pred"], self.out_channels, 1, 1, hip.ACT_RELU, dense_out=True)   # :374
         self.calls += 1
         if self.precision == "f16x2":
-            torch.maximum(P["guard"], P["absmax"][:, 1].max().reshape(1), out=P["guard"])
+            torch.maximum(P["guard"], P["absmax"][:, :, 1].max().reshape(1), out=P["guard"])
         if return_intermediates:
             return out, inter
         return out
