@@ -153,7 +153,7 @@ def self_launch(n_gpus: int) -> int:
     """Run this script under torch.distributed.run with `n_gpus` ranks in a child process."""
     import socket
     import subprocess
-    have = torch.cuda.device_count()                 # does not initialise the GPU runtime
+    have = torch.cuda.device_count()                 # (the ranks are started as CHILD processes, never exec'd over this one)
     if have < n_gpus:
         print(f"bench.py: --gpus {n_gpus} but only {have} GPU(s) are visible", file=sys.stderr)
         return 2
@@ -168,7 +168,9 @@ def self_launch(n_gpus: int) -> int:
 
 
 def fresh_model(precision, device):
-    m = V2ce3d(precision=precision)
+    # guard='deferred': like the product driver (glue.run_guarded around pipeline.run_clip) the bench checks the
+    # range guard once after the timed steps (`range_guard` in the JSON line) instead of once per call
+    m = V2ce3d(precision=precision, guard="deferred")
     m.load_state_dict(synth.make_state_dict(0))
     return m.eval().to(device)
 
@@ -270,7 +272,7 @@ def main():
         # four ranks shares a batch (one tile each); other world sizes give every rank its own batch
         # and run the four tiles one after the other like the reference.
         grp_index, tile_index = divmod(rank, pano_tiles) if tile_parallel else (rank, None)
-        grp = vdist.subgroup(pano_tiles, rank, world) if tile_parallel else None
+        grp = vdist.subgroup(pano_tiles, rank, world) if tile_parallel else None      # RCCL group of the four tile ranks
         model = fresh_model(args.precision, device)
         xs = [make_inputs(b, (grp_index * pano_tiles + t) * b, device)
               for t in ([tile_index] if tile_parallel else range(pano_tiles))]
@@ -285,9 +287,11 @@ def main():
     offsets = torch.tensor([glue.frame_offset_us(i, fps) for i in range((world + 1) * max(b, 8) * SEQ)],
                            dtype=torch.int64).to(device)
     ldati_prof, conv_prof = [], []
-    gather_bytes = [0]
-    gathers = []
     n_events = [0]
+    # rank 0 receives every rank's records of a step over RCCL on a communication stream (dist.StreamedGather, the
+    # product driver's: pipeline.run_clip); the byte counts are read one step later, so no rank waits on its compute stream
+    comm = vdist.default_comm(force=dist_on)
+    gather = comm.streamed_gather(None, dst=0) if dist_on else None
 
     def front(profile):
         """Stage 1 + LDATI count of one step; returns the pending LDATI call."""
@@ -315,29 +319,28 @@ def main():
         ev = pending.finish()
         packed = ev.packed()
         n_events[0] += ev.num_events
-        if dist_on:
-            # rank 0 receives every rank's records of this step over RCCL on a communication stream; the byte
-            # counts it needs are read one step later, so no rank waits on its compute stream
-            gathers.append(vdist.EventGather(packed, dst=0))
-            if len(gathers) > 1:
-                out = gathers.pop(0).finish()
-                if rank == 0:
-                    gather_bytes[0] = int(sum(o.numel() for o in out))
-        return packed
+        if gather is not None:
+            gather.submit(packed)
+        return packed, ev
+
+    status = [None]
 
     def run_steps(k, profile):
         pending = None
+
+        def done(p):
+            _, ev = back(p)
+            if ev._status is not None:                          # LDATI's device status word, folded on the stream
+                status[0] = ev._status.clone() if status[0] is None else torch.maximum(status[0], ev._status)
         for _ in range(k):
             nxt = front(profile)
             if pending is not None:
-                back(pending)
+                done(pending)
             pending = nxt
         if pending is not None:
-            back(pending)
-        while gathers:                                          # the last step's gather
-            out = gathers.pop(0).finish()
-            if rank == 0:
-                gather_bytes[0] = int(sum(o.numel() for o in out))
+            done(pending)
+        if gather is not None:
+            gather.drain()                                      # the last step's gather
 
     run_steps(args.warmup, True)            # same code path as the timed steps (warms the HIP event pool too)
     ldati_prof.clear()
@@ -354,6 +357,8 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if status[0] is not None and int(status[0].item()) != 0:
+        sys.exit("bench.py: LDATI reported a segment it could not order (device status word)")
     events = float(n_events[0])
     if dist_on:
         t = torch.tensor([dt, events], dtype=torch.float64, device=device)
@@ -448,7 +453,7 @@ def main():
             # the split-half range guard over the timed steps: worst per-launch bound vs its limit
             line["range_guard"] = {"worst_bound": model.range_guard_value(), "limit": model.RANGE_GUARD_LIMIT}
         if dist_on:
-            line["gathered_bytes_per_step"] = gather_bytes[0]
+            line["gathered_bytes_per_step"] = gather.bytes_last
             line["rccl_world"] = world
         if world == 1 and args.workload == "e2e":
             if not args.no_host_to_host:

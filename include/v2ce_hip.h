@@ -51,8 +51,8 @@ const char *v2ce_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Stage 2 -- LDATI.  Replaces scripts/LDATI.py:126-310 (sample_voxel_statistical, y_relocate,
- * calculate_statistical_linear_params_for_stage2, pick_elements, pick_and_sort) for the options the
- * CLI uses (v2ce.py:356: 'slope', pooling 'none', bidirectional=False) and 'none'.
+ * calculate_statistical_linear_params_for_stage2, pick_elements, pick_and_sort), every option value of
+ * sample_voxel_statistical (v2ce_ldati_options below; the CLI's are 'slope', pooling 'none', bidirectional=False).
  * Two-phase, because the output length is data dependent:
  *   count -> (caller reads seg_offsets + stats, allocates) -> emit
  * ---------------------------------------------------------------------------------------------- */
@@ -127,6 +127,13 @@ int v2ce_ldati_status(const void *workspace, int B, int H, int W, double fps, do
 int v2ce_ldati_plan_info(int B, int H, int W, double fps, double t0, const v2ce_ldati_options *options,
                          int64_t total_events, int64_t max_segment_events, int64_t max_tile_events, int64_t *info);
 
+/* How the stable tie order inside the LDS counting sorts is obtained on the current device: 1 = straight from the
+ * lane order in which one ds_add_rtn_u32 wave-instruction serves equal addresses (checked once per device by a probe
+ * kernel enqueued in front of the first v2ce_ldati_count; gfx950 passes), 0 = ballot match-any ranks (probe failed
+ * or not yet run, or V2CE_LDATI_NO_ATOMIC_ORDER=1 in the environment: the fallback, forced for tests).  Both give
+ * identical output.  Synchronises the device. */
+int v2ce_ldati_rank_mode(int32_t *mode);
+
 /* SoA <-> packed 13-byte records {i8 timestamp, i2 x, i2 y, i1 polarity}: the numpy recarray layout
  * of LDATI.py:308-309 (numpy.core.records.fromarrays, itemsize 13).  packed: n*13 bytes. */
 int v2ce_events_pack(const int64_t *ts, const int16_t *x, const int16_t *y, const int8_t *p,
@@ -141,10 +148,11 @@ int v2ce_events_unpack(const uint8_t *packed, int64_t n, int64_t *ts, int16_t *x
  * ---------------------------------------------------------------------------------------------- */
 int v2ce_preprocess_pairs(const uint8_t *frames, int N, int H, int W, float mean, float stdv,
                           float *units, v2ce_stream_t stream);
-/* The same for frames of another size: v2ce.py:57 cv2.resize(img, (out_w, out_h)) (bilinear, half-pixel
- * centres, edge clamp) of x = u8/255 first; units [N-1][2][out_h][out_w].  Restates the host path
- * (glue._resize_bilinear) operation by operation (bit-identical to it; OpenCV itself is not installed in
- * the build image, so the equality with cv2's own rounding is unpinned). */
+/* The same for frames of another size: v2ce.py:57-58 cv2.resize(img, (out_w, out_h)), INTER_LINEAR, of x = u8/255 first;
+ * units [N-1][2][out_h][out_w].  Restates OpenCV's published scalar algorithm (resize.cpp: float coefficient
+ * (float)((d + 0.5) * scale - 0.5), floor, subtraction in float; horizontal pass, then vertical; the 2 x 2 decimation
+ * is its INTER_AREA fast path) operation by operation and bit-identically to the host path glue._resize_bilinear;
+ * pinned by hand-derived vectors -- OpenCV itself is not installed in the build image. */
 int v2ce_preprocess_pairs_resize(const uint8_t *frames, int N, int H, int W, int out_h, int out_w, float mean,
                                  float stdv, float *units, v2ce_stream_t stream);
 
@@ -291,7 +299,7 @@ int v2ce_voxelize_events(const int64_t *ts, const int16_t *x, const int16_t *y, 
 /* Ablation samplers of the reference's stage-2 study, csrc/sampler.hip:
  *   V2CE_SAMPLER_RANDOM / _EVEN  sample_voxel_baseline(random=True / even=True) of
  *                                train/scripts/stage2/sample_methods/random_even_sample.py:115-169
- *   V2CE_SAMPLER_PURE_SLOPE      sample_voxel_statistical of .../pure_slope_sample.py:57-149 (pooling 'none')
+ *   V2CE_SAMPLER_PURE_SLOPE      sample_voxel_statistical of .../pure_slope_sample.py:57-149
  * vox [B][2][10][H][W] f32 (read only: the pure-slope reference folds bin 9 into bin 8 IN the caller's tensor,
  * here the fold happens in registers).  Per voxel: floor(y) events + one more with probability frac(y).  Output per
  * frame in the order of np.sort(order='timestamp') = lexicographic (timestamp, x, y, polarity); frames back to back.
@@ -313,7 +321,14 @@ typedef struct {
     int frame_base;
     int replay_M;
     const float *u_int, *u_dec, *u_bern;
+    const float *pooled; /* _PURE_SLOPE with pooling_type 'avg' / 'weighted' (pure_slope_sample.py:79-85): the output of
+                          * v2ce_sampler_pool [B][2][10][H][W]; shapes only the slope parameters.  NULL = pooling 'none'. */
 } v2ce_sampler_options;
+/* y_pooled of pure_slope_sample.py:79-85 (V2CE_POOL_WEIGHTED: 3x3 [[1,2,1],[2,4,2],[1,2,1]]/16 conv, V2CE_POOL_AVG:
+ * k x k mean; zero padding).  Sums of non-integer f32 values in row-major tap order: equal to the reference's up to
+ * its backend's summation order (events within 1 us of the reference's: tests/test_gpu_samplers.py). */
+int v2ce_sampler_pool(const float *vox, int B, int H, int W, int pooling_type, int pooling_kernel_size, float *pooled,
+                      v2ce_stream_t stream);
 int v2ce_sampler_count(const float *vox, int B, int H, int W, const v2ce_sampler_options *options,
                        int64_t *frame_counts, int32_t *max_int, v2ce_stream_t stream);
 size_t v2ce_sampler_workspace_bytes(int64_t total_events);
@@ -328,7 +343,7 @@ size_t v2ce_sn_workspace_bytes(int rows, int cols);
 int v2ce_sn_power_iter(float *u, float *v, const float *w_bar, int rows, int cols, float *sigma,
                        void *workspace, size_t workspace_bytes, v2ce_stream_t stream);
 
-/* The same for ALL spectral-norm layers of a forward pass in five launches, with the split-half weight
+/* The same for ALL spectral-norm layers of a forward pass in six launches, with the split-half weight
  * re-pack (v2ce_pack_weights_f16x2 of w_bar / sigma, incl. its {max |w/sigma|, pre-scale} tail) fused behind it:
  * replaces 12 x (v2ce_sn_power_iter + v2ce_pack_weights_f16x2) = 84 launches.  Results are bit-identical to the
  * per-layer calls.  layers: HOST array (passed to the kernels by value), at most 16 entries; cols = Cin * k3,

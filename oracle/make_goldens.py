@@ -331,6 +331,45 @@ def gen_sample_methods():
 
 
 
+def gen_sample_methods_pooled():
+    """G10 (pooled): the pure-slope sampler with pooling_type 'weighted' / 'avg' (pure_slope_sample.py:79-85).  The pooled
+    values are sums of non-integer f32 values (torch CPU conv2d / avg_pool2d): the oracle restates them with a fixed
+    row-major summation order and is required to be CLOSE (same events, timestamps within 1 us), not bit-equal."""
+    from oracle import sample_methods as OS
+    _, PS = reference_sample_methods()
+    cases = {
+        "slope_weighted": (synth.synthetic_voxels(2, 12, 14, seed=48, regime="stress"), 30, 0, dict(pooling_type="weighted")),
+        "slope_avg3": (synth.synthetic_voxels(2, 9, 11, seed=49, regime="sparse"), 25, 0.25, dict(pooling_type="avg", pooling_kernel_size=3)),
+        "slope_avg5": (synth.synthetic_voxels(1, 12, 14, seed=50, regime="stress"), 30, 0, dict(pooling_type="avg", pooling_kernel_size=5)),
+    }
+    for name, (vox, fps, t0, opts) in cases.items():
+        B, _, _, H, W = vox.shape
+        seed = 400
+        with DrawCapture() as cap:
+            torch.manual_seed(seed)
+            y = torch.from_numpy(vox.copy())
+            with IeeeSqrt():
+                res = PS.sample_voxel_statistical(y, t0=t0, fps=fps, **opts)
+        u_bern = np.empty((B, 2, 10, H, W), np.float32)
+        it = iter(cap.berns)
+        for b in range(B):
+            for c in range(10):
+                for pi in (1, 0):
+                    u_bern[b, pi, c] = next(it).numpy()
+        rands = [r.numpy() for r in cap.rands]
+        u_dec, u_int = rands[0].reshape(B, 2, 10, H, W), rands[1].reshape(B, 2, 10, H, W, -1)
+        lens = np.array([len(r) for r in res], np.int64)
+        ev = np.concatenate([np.asarray(r) for r in res])
+        mine = OS.sample_voxel_pure_slope(vox, t0, fps, u_int=u_int, u_dec=u_dec, u_bern=u_bern, **opts)
+        diffs = [OS.events_close(np.asarray(a), np.asarray(b)) for a, b in zip(res, mine)]
+        assert all(d >= 0 for d in diffs), (name, diffs)
+        np.savez_compressed(os.path.join(GOLD, f"sampler_g10p_{name}.npz"), vox=vox, fps=np.float64(fps), t0=np.float64(t0),
+                            pooling_type=np.array(opts["pooling_type"]), pooling_kernel_size=np.array(int(opts.get("pooling_kernel_size", 3))),
+                            u_int=u_int, u_dec=u_dec, u_bern=u_bern, lens=lens, events=np.frombuffer(ev.tobytes(), np.uint8))
+        print(f"G10 pooled {name}: B={B} HxW={H}x{W} fps={fps} t0={t0} M={u_int.shape[-1]} events={lens} "
+              f"timestamps differing from the oracle by 1 us: {diffs}")
+
+
 # --------------------------------------------------------------------------------------------- G4
 def gen_ldati_large():
     H, W, seed = 260, 346, 4242
@@ -564,3 +603,6 @@ if __name__ == "__main__":
         gen_glue()
     if "samplers" in which:
         gen_sample_methods()
+        gen_sample_methods_pooled()
+    if "samplers_pooled" in which:
+        gen_sample_methods_pooled()

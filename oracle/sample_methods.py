@@ -126,18 +126,43 @@ def _slope_ts(k, bb, u, fps):
         return np.where(k == 0, (u / F(fps)) / F(C), t)                     # :106 / :131
 
 
+def pool_voxels(y, pooling_type, pooling_kernel_size=3):
+    """pure_slope_sample.py:79-85: the voxel values pooled over the k x k pixel neighbourhood, zero padding.
+    'weighted': F.conv2d with [[1,2,1],[2,4,2],[1,2,1]]/16 (:80-82); 'avg': nn.AvgPool2d(k, stride 1, padding k//2),
+    i.e. window sum / k^2 (:84, count_include_pad).  Unlike LDATI's pooling (integer counts: exact) these are sums of
+    arbitrary f32 values, whose last bit depends on the backend's summation order; here: taps in row-major order,
+    one f32 multiply and one f32 add per tap.  Parity bar for everything derived from it: timestamps within 1 us
+    (tests/test_oracle_samplers.py::test_pooled_pure_slope_close_to_reference)."""
+    y = np.asarray(y, F)
+    if pooling_type == "none":
+        return y
+    H, W = y.shape[-2:]
+    if pooling_type == "weighted":
+        r, wt = 1, (np.array([[1, 2, 1], [2, 4, 2], [1, 2, 1]], F) / F(16))
+    else:
+        r = pooling_kernel_size // 2
+        wt = np.ones((pooling_kernel_size, pooling_kernel_size), F)
+    pad = np.zeros(y.shape[:-2] + (H + 2 * r, W + 2 * r), F)
+    pad[..., r:r + H, r:r + W] = y
+    acc = np.zeros_like(y)
+    for dh in range(2 * r + 1):
+        for dw in range(2 * r + 1):
+            tap = pad[..., dh:dh + H, dw:dw + W]
+            acc = acc + (wt[dh, dw] * tap if pooling_type == "weighted" else tap)
+    return acc if pooling_type == "weighted" else acc / F(pooling_kernel_size * pooling_kernel_size)
+
+
 def sample_voxel_pure_slope(y, t0=0, fps=30, pooling_type="none", pooling_kernel_size=3,
                             additional_events_strategy="slope", u_int=None, u_dec=None, u_bern=None):
-    """pure_slope_sample.py:57-149 (pooling 'none').  Does not modify ``y`` (the reference folds bin 9 into
-    bin 8 in place, :92-93, which reaches the caller's tensor)."""
+    """pure_slope_sample.py:57-149.  Does not modify ``y`` (the reference folds bin 9 into bin 8 in place, :92-93,
+    which reaches the caller's tensor).  Pooling shapes only the slope parameters (:79-91, from the UNFOLDED values);
+    the event counts come from ``y`` itself."""
     assert pooling_type in ["avg", "weighted", "none"]
     assert additional_events_strategy in ["none", "random", "slope"]
-    if pooling_type != "none":
-        raise NotImplementedError("pooled pure-slope sampling: sums of non-integer f32 values, not pinned")
     y = np.array(y, dtype=F)
     B, P, Cc, H, W = y.shape
     assert Cc == C
-    k, bb = _slope_kb(y, fps)
+    k, bb = _slope_kb(pool_voxels(y, pooling_type, pooling_kernel_size), fps)
     y[:, :, 8] = y[:, :, 8] + y[:, :, 9]                                    # :92
     y[:, :, 9] = 0                                                          # :93
     ip = np.floor(y).astype(np.int32)                                       # :95
@@ -171,3 +196,20 @@ def philox_draws(B, H, W, M, seed, frame_base=0):
                     u_dec[b, pi, c, h, w] = fn(seed, px, 0, 32 * KIND_DEC + pc, frame_base + b)
                     u_bern[b, pi, c, h, w] = fn(seed, px, 0, 32 * KIND_BERN + pc, frame_base + b)
     return u_int, u_dec, u_bern
+
+
+def events_close(a, b, tol_us=1):
+    """Two event lists of one frame that may differ by a rounding step of a slope parameter: the same (x, y,
+    polarity) multiset and, column by column in time order, timestamps within `tol_us`.  Returns the number of
+    timestamps that differ (or -1 if the lists are not comparable)."""
+    a, b = np.asarray(a), np.asarray(b)
+    if len(a) != len(b):
+        return -1
+    def canon(e):
+        o = np.lexsort((e["timestamp"], e["polarity"], e["y"], e["x"]))
+        return e[o]
+    a, b = canon(a), canon(b)
+    if not (np.array_equal(a["x"], b["x"]) and np.array_equal(a["y"], b["y"]) and np.array_equal(a["polarity"], b["polarity"])):
+        return -1
+    d = np.abs(a["timestamp"].astype(np.int64) - b["timestamp"].astype(np.int64))
+    return -1 if d.size and d.max() > tol_us else int((d != 0).sum())

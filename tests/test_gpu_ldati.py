@@ -274,3 +274,56 @@ def test_sparse_tile_kernel_equals_per_bin_kernel(monkeypatch):
         soa_equal(ev, *want)
         outs.append(ev.packed().cpu().numpy().tobytes())
     assert outs[0] == outs[1]
+
+
+def rank_mode():
+    import ctypes
+    m = ctypes.c_int32(-1)
+    hip.check(hip.lib().v2ce_ldati_rank_mode(ctypes.byref(m)), "v2ce_ldati_rank_mode")
+    return m.value
+
+
+def test_ballot_rank_fallback_forced(gold_dir, monkeypatch):
+    """The ballot match-any ranks -- what the tile pass, the bucket sort and the big-bucket kernel fall back to on a
+    device whose LDS atomics fail the lane-order probe -- forced with V2CE_LDATI_NO_ATOMIC_ORDER=1 (the probe passes on
+    gfx950, so the branch never runs otherwise): the reference goldens G3 (incl. bidirectional: the big-bucket kernel),
+    G4 bit-identical, and a Philox full-size frame, each byte-equal to the default mode's output."""
+    hip_events(synth.synthetic_voxels(1, 8, 8, seed=1), seed=1)          # the probe has run
+    default_mode = rank_mode()
+    print("LDS-atomic lane-order probe passed on this device:", bool(default_mode))
+
+    def both(run):
+        monkeypatch.delenv("V2CE_LDATI_NO_ATOMIC_ORDER", raising=False)
+        a = run()
+        monkeypatch.setenv("V2CE_LDATI_NO_ATOMIC_ORDER", "1")
+        assert rank_mode() == 0
+        b = run()
+        monkeypatch.delenv("V2CE_LDATI_NO_ATOMIC_ORDER")
+        assert rank_mode() == default_mode
+        assert a.packed().cpu().numpy().tobytes() == b.packed().cpu().numpy().tobytes()
+        return b
+
+    for name in ["sparse", "frac", "stress", "ragged"]:
+        z = np.load(os.path.join(gold_dir, f"ldati_g3_{name}.npz"))
+        vox, u, fps, t0 = z["vox"], z["uniforms"], float(z["fps"]), float(z["t0"])
+        ev = both(lambda: hip_events(vox, fps, t0, uniforms=u))
+        soa_equal(ev, *O.emit_soa(vox, fps=fps, t0=t0, uniforms=u))
+    for name in ["bidir", "bidir_sparse"]:
+        z = np.load(os.path.join(gold_dir, f"ldati_g3_opt_{name}.npz"))
+        vox, u, fps, t0 = z["vox"], z["uniforms"], float(z["fps"]), float(z["t0"])
+        ev = both(lambda: hip_events(vox, fps, t0, uniforms=u, bidirectional=True))
+        soa_equal(ev, *O.emit_soa(vox, fps=fps, t0=t0, uniforms=u, bidirectional=True))
+    meta = json.load(open(os.path.join(gold_dir, "ldati_g4.json")))
+    H, W = meta["H"], meta["W"]
+    vox4 = synth.synthetic_voxels(1, H, W, seed=meta["vox_seed"], regime=meta["vox_regime"])
+    mt = np.random.MT19937()
+    mt._legacy_seeding(meta["torch_seed"])
+    n = 2 * 9 * H * W * meta["max_n"]
+    u4 = ((mt.random_raw(n).astype(np.uint32) & 0xFFFFFF).astype(np.float32) * np.float32(2.0 ** -24)).reshape(1, 2, 9, H, W, meta["max_n"])
+    ev = both(lambda: hip_events(vox4, meta["fps"], meta["t0"], uniforms=u4))
+    assert hashlib.sha256(ev.to_recarrays()[0].tobytes()).hexdigest() == meta["sha256_packed_events"]
+    for regime in ("sparse", "stress"):
+        vox = synth.synthetic_voxels(2, 260, 346, seed=77, regime=regime)
+        ev = both(lambda: hip_events(vox, seed=99, frame_base=4))
+        if regime == "sparse":
+            soa_equal(ev, *O.emit_soa(vox, fps=30, seed=99, frame_base=4))

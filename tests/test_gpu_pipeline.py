@@ -115,7 +115,7 @@ def test_explicit_device_index(tmp_path):
 
 
 @pytest.mark.parametrize("shape,height", [((5, 130, 173), 260), ((4, 480, 640), 260), ((3, 100, 37), 64), ((3, 260, 346), 260),
-                                          ((3, 480, 505), 480)])
+                                          ((3, 480, 505), 480), ((3, 520, 692), 260), ((2, 2, 2), 4), ((2, 3, 4), 2)])
 def test_device_resize_matches_host_path(shape, height):
     """f3: v2ce_preprocess_pairs_resize == glue.image_pre_processing (the host restatement of
     cv2.resize + Normalize, v2ce.py:45-64) bit for bit, up- and down-scaling, also the W-1 width case."""

@@ -133,3 +133,28 @@ def test_full_size_frame_properties():
         assert np.all(np.diff(key) >= 0)
         assert r["x"].min() >= 0 and r["x"].max() < 346 and r["y"].min() >= 0 and r["y"].max() < 260
         assert r["timestamp"].min() >= -1 and r["timestamp"].max() < 33400
+
+
+@pytest.mark.parametrize("name", ["slope_weighted", "slope_avg3", "slope_avg5"])
+def test_pooled_pure_slope(gold_dir, name):
+    """VERDICT r2 missing #4: pure_slope_sample.py:79-85 on the device (v2ce_sampler_pool + the pooled slope): the
+    reference's own events (goldens G10p) with timestamps within 1 us -- the one float path of stage 2 whose last bit
+    is the reference's convolution backend's --, and the oracle (same summation order) bit for bit; Philox at a
+    larger size as well."""
+    z = np.load(os.path.join(gold_dir, f"sampler_g10p_{name}.npz"))
+    opts = dict(pooling_type=str(z["pooling_type"]), pooling_kernel_size=int(z["pooling_kernel_size"]))
+    draws = dict(u_int=z["u_int"], u_dec=z["u_dec"], u_bern=z["u_bern"])
+    res = run_device(z["vox"], "pure_slope", "slope", float(z["t0"]), float(z["fps"]), **draws, **opts)
+    assert [len(r) for r in res] == z["lens"].tolist()
+    ref = np.frombuffer(z["events"].tobytes(), OS.EVENT_DTYPE)
+    lo = 0
+    for r in res:
+        d = OS.events_close(np.asarray(r), ref[lo:lo + len(r)])
+        assert 0 <= d <= len(r) // 1000, d
+        lo += len(r)
+    same(res, OS.sample_voxel_pure_slope(z["vox"], float(z["t0"]), float(z["fps"]), **draws, **opts))
+    vox = synth.synthetic_voxels(2, 33, 47, seed=5, regime="stress")
+    M = int(max(np.floor(vox).max(), np.floor(vox[:, :, 8] + vox[:, :, 9]).max()))
+    u_int, u_dec, u_bern = OS.philox_draws(2, 33, 47, M, seed=9, frame_base=3)
+    want = OS.sample_voxel_pure_slope(vox, 0, 30, u_int=u_int, u_dec=u_dec, u_bern=u_bern, **opts)
+    same(run_device(vox, "pure_slope", "slope", 0, 30, seed=9, frame_base=3, **opts), want)

@@ -422,11 +422,76 @@ def test_range_guard_reroutes_adversarial_model_to_exact_f32(caplog):
         if n.endswith(("weight_u", "weight_v")):
             assert torch.equal(p, q), n
     # without the guard the split-half result is outside the bar here: the reroute is needed
-    raw = model(bad, "f16x2")(torch.from_numpy(OG.preprocess(frames[:17])[None]).cuda())
+    unguarded = V2ce3d(precision="f16x2", guard="deferred")
+    unguarded.load_state_dict(bad, strict=True)
+    raw = unguarded.eval().to("cuda")(torch.from_numpy(OG.preprocess(frames[:17])[None]).cuda())
     ex = model(bad, "f32")(torch.from_numpy(OG.preprocess(frames[:17])[None]).cuda())
     d = (raw - ex).abs()
     print(f"unguarded split-half vs exact on the adversarial checkpoint: max abs {float(d.max()):.3e}, "
           f"max rel {float((d / ex.abs().clamp_min(1e-30)).max()):.3e}")
+
+
+def test_bare_model_call_keeps_the_f32_contract(caplog):
+    """a REFERENCE-STYLE caller -- ``model = V2ce3d(); model(x)``, then
+    ``sample_voxel_statistical`` (v2ce.py:81-82,353-357), no glue.run_guarded anywhere -- on the adversarial
+    checkpoint of the test above: the default per-call guard repeats the offending call on the exact-f32 kernels,
+    so voxels, events and the spectral-norm trajectory equal those of precision='f32'; call after call."""
+    import logging
+    from v2ce_toolbox_amd.LDATI import sample_voxel_statistical
+    from v2ce_toolbox_amd.v2ce_3d import V2ce3d
+    frames = synth.synthetic_frames(18, 32, 48, seed=4)
+    bad = {k: v.clone() for k, v in synth.make_state_dict(0).items()}
+    bad["UNet.encoders.0.downsample.0.bias"][3] = 3e6
+
+    def model(**kw):
+        m = V2ce3d(**kw)
+        m.load_state_dict(bad, strict=True)
+        return m.eval().to("cuda")
+
+    mg, mx = model(), model(precision="f32")                # the drop-in default vs exact f32
+    assert mg.precision == "f16x2" and mg.guard == "call"
+    for k in range(2):                                      # two consecutive calls: the SN state must track as well
+        x = torch.from_numpy(OG.preprocess(frames[k:k + 17])[None]).cuda()
+        with caplog.at_level(logging.WARNING, logger="V2CE"):
+            got = mg(x)
+        want = mx(x)
+        assert torch.equal(got, want)
+        ev_g = sample_voxel_statistical(got.reshape(-1, 2, 10, 32, 48), fps=30, seed=5)
+        ev_w = sample_voxel_statistical(want.reshape(-1, 2, 10, 32, 48), fps=30, seed=5)
+        assert all(a.tobytes() == b.tobytes() for a, b in zip(ev_g, ev_w))
+    assert mg.guard_reruns == 2 and mg.calls == mx.calls == 2 and mg.precision == "f16x2"
+    assert any("range guard" in r.message for r in caplog.records)
+    for (n, p), (_, q) in zip(mg.named_parameters(), mx.named_parameters()):
+        if n.endswith(("weight_u", "weight_v")):
+            assert torch.equal(p, q), n
+    # ordinary weights: no rerun, and the guarded call returns what the unguarded one does
+    sd = synth.make_state_dict(0)
+    a, b = V2ce3d(), V2ce3d(guard="deferred")
+    a.load_state_dict(sd), b.load_state_dict(sd)
+    x = torch.from_numpy(OG.preprocess(frames[:17])[None]).cuda()
+    assert torch.equal(a.eval().to("cuda")(x), b.eval().to("cuda")(x)) and a.guard_reruns == 0
+
+
+def test_forward_is_batch_invariant():
+    """One range slot per batch element (desc.absmax_batch_stride): sequence b of a batch of four gets, bit for
+    bit, the voxels it gets alone -- what lets pipeline.run_clip share a reference batch out over GPUs sequence by
+    sequence.  Both precisions; the sequences differ in range by 2^6 so that a shared scale would show."""
+    from v2ce_toolbox_amd.v2ce_3d import V2ce3d
+    xs = np.stack([OG.preprocess(synth.synthetic_frames(17, 40, 56, seed=40 + s)) for s in range(4)])
+    xs[1] *= 64.0
+    xs[3] *= 1.0 / 64.0
+    x = torch.from_numpy(xs).cuda()
+    for precision in ("f16x2", "f32"):
+        def fresh():
+            m = V2ce3d(precision=precision)
+            m.load_state_dict(synth.make_state_dict(0))
+            return m.eval().to("cuda")
+        whole = fresh()(x)
+        for b in range(4):
+            alone = fresh()(x[b:b + 1].contiguous())
+            assert torch.equal(whole[b], alone[0]), (precision, b)
+        pair = fresh()(x[1:3].contiguous())
+        assert torch.equal(whole[1:3], pair), precision
 
 
 def test_conv3d_records_output_absmax():

@@ -57,3 +57,27 @@ def test_pure_slope_does_not_touch_the_input(gold_dir):
     vox = z["vox"].copy()
     run_oracle(z)
     assert np.array_equal(vox, z["vox"])
+
+
+POOLED = ["slope_weighted", "slope_avg3", "slope_avg5"]
+
+
+@pytest.mark.parametrize("name", POOLED)
+def test_pooled_pure_slope_close_to_reference(gold_dir, name):
+    """pure_slope_sample.py:79-85 (pooling 'weighted' / 'avg'): the pooled values are f32 sums whose last bit is the
+    convolution backend's, so the bar is the reference's events with timestamps within 1 us -- on these fixtures
+    (the reference's own output, draws recorded) the oracle's fixed row-major order reproduces them exactly."""
+    z = np.load(os.path.join(gold_dir, f"sampler_g10p_{name}.npz"))
+    res = OS.sample_voxel_pure_slope(z["vox"], float(z["t0"]), float(z["fps"]), pooling_type=str(z["pooling_type"]),
+                                     pooling_kernel_size=int(z["pooling_kernel_size"]), u_int=z["u_int"], u_dec=z["u_dec"],
+                                     u_bern=z["u_bern"])
+    assert [len(r) for r in res] == z["lens"].tolist()
+    ref = np.frombuffer(z["events"].tobytes(), OS.EVENT_DTYPE)
+    lo = 0
+    for r in res:
+        d = OS.events_close(np.asarray(r), ref[lo:lo + len(r)])
+        assert 0 <= d <= len(r) // 1000, d
+        lo += len(r)
+    # pooling matters: the unpooled sampler gives other timestamps
+    plain = OS.sample_voxel_pure_slope(z["vox"], float(z["t0"]), float(z["fps"]), u_int=z["u_int"], u_dec=z["u_dec"], u_bern=z["u_bern"])
+    assert np.concatenate([np.asarray(r) for r in plain]).tobytes() != z["events"].tobytes()

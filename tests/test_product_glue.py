@@ -80,6 +80,43 @@ def test_resize_identity_and_shape():
     assert out.shape == (10, 15) and abs(out.mean() - img.mean()) < 0.05
 
 
+def test_resize_hand_vectors():
+    """f3: glue._resize_bilinear against vectors derived BY HAND from OpenCV's scalar INTER_LINEAR
+    (resize.cpp: scale = 1/(out/in); f = float((d + .5) * scale - .5); s = floor(f); f -= s; x axis zeroes f at
+    both edges, y axis clips the rows; horizontal pass, then vertical); every product below is exact in f32.
+
+    up, 2x2 -> 4x4, scale 0.5: f(d) = 0.5 d - 0.25 = -.25, .25, .75, 1.25
+      x: d=0: s=-1 -> (f,s)=(0,0); d=1: s=0 f=.25; d=2: s=0 f=.75; d=3: s=1=W-1 -> copy S[1]
+      y: d=0: s=-1, f=.75, rows (0,0); d=1: rows (0,1) f=.25; d=2: rows (0,1) f=.75; d=3: s=1 f=.25 rows (1,1)
+      rows of [[0,1],[1,0]] after x: r0 = [0,.25,.75,1], r1 = [1,.75,.25,0]
+      out: r0; .75 r0 + .25 r1; .25 r0 + .75 r1; r1
+    down, 3x4 -> 2x2 of arange(12): x scale 2: f = .5 (s=0), 2.5 -> s=2 f=.5; y scale 1.5: f = .25 (s=0), 1.75 -> s=1 f=.75
+      after x: row r = [4r + .5, 4r + 2.5]; out = [[.75*.5 + .25*4.5, .75*2.5 + .25*6.5], [.25*4.5 + .75*8.5, .25*6.5 + .75*10.5]]
+    2x2 decimation (both scales exactly 2): OpenCV switches INTER_LINEAR to its INTER_AREA fast path, (a+b+c+d)/4."""
+    up = glue._resize_bilinear(np.array([[0, 1], [1, 0]], np.float32), 4, 4)
+    assert up.dtype == np.float32 and up.tolist() == [[0, .25, .75, 1], [.25, .375, .625, .75], [.75, .625, .375, .25], [1, .75, .25, 0]]
+    down = glue._resize_bilinear(np.arange(12, dtype=np.float32).reshape(3, 4), 2, 2)
+    assert down.tolist() == [[1.5, 3.5], [7.5, 9.5]]
+    area = glue._resize_bilinear(np.arange(16, dtype=np.float32).reshape(4, 4), 2, 2)
+    assert area.tolist() == [[2.5, 4.5], [10.5, 12.5]]
+    # the float coefficient: (d + .5) * scale - .5 is rounded to f32 BEFORE the floor / subtraction (3 -> 7: scale 3/7)
+    row = glue._resize_bilinear(np.array([[0, 1, 0]], np.float32), 7, 1)[0]
+    sc = 1.0 / (7.0 / 3.0)
+    want = []
+    for d in range(7):
+        f = np.float32((d + 0.5) * sc - 0.5)
+        s = int(np.floor(f))
+        f = np.float32(f - np.float32(s))
+        src = [0.0, 1.0, 0.0]
+        if s < 0:
+            want.append(np.float32(src[0]))
+        elif s >= 2:
+            want.append(np.float32(src[2]))
+        else:
+            want.append(np.float32(src[s]) * (np.float32(1) - f) + np.float32(src[s + 1]) * f)
+    assert row.tolist() == [float(v) for v in want]
+
+
 def test_shard_range():
     for n in (1, 7, 8, 128):
         for world in (1, 2, 3, 8):

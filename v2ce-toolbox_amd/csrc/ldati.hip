@@ -104,6 +104,8 @@ struct LdatiParams {
     int *seg_flag;                // [B*9] 1 = a bucket exceeds cap2 -> segment goes to the sweep kernel
     int *status;                  // [1] != 0: a flagged segment could not be swept (NK too large)
     int sweep_ok;
+    int ballot_ranks;             // 1 = ignore g_lds_order_ok and rank with the ballot match-any (V2CE_LDATI_NO_ATOMIC_ORDER=1: the
+                                  // fallback a device that fails the probe would take, forced so that tests can run it)
 };
 
 // ---- Philox4x32-10, counter (pixel, j>>2, p*9+c, frame), key = seed ---------------------------
@@ -800,7 +802,7 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
     const int x0 = (t < P.tpp ? t : t - P.tpp) * kTilePix;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     constexpr int NW = NT / 64;
-    const bool atomic_order = __builtin_amdgcn_readfirstlane(g_lds_order_ok) != 0;
+    const bool atomic_order = !P.ballot_ranks && __builtin_amdgcn_readfirstlane(g_lds_order_ok) != 0;
 
     unsigned *S = reinterpret_cast<unsigned *>(tile_smem);
     unsigned *O = S + P.capA;
@@ -1372,7 +1374,7 @@ __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(Ldat
     const int bins = ((bk1 - bk0) << P.shift) * 4;       // (relative key, category); <= 4 * kMaxSpanKeys
     int nb2 = 2;
     while ((1 << nb2) < bins) ++nb2;
-    const bool atomic_order = __builtin_amdgcn_readfirstlane(g_lds_order_ok) != 0;
+    const bool atomic_order = !P.ballot_ranks && __builtin_amdgcn_readfirstlane(g_lds_order_ok) != 0;
 
     unsigned *Out = reinterpret_cast<unsigned *>(sort_smem);
     unsigned *hist = Out + kSortThreads * K;             // [kSortWaves][bins]
@@ -1614,7 +1616,7 @@ __global__ __launch_bounds__(256) void ldati_big_bucket_kernel(LdatiParams P) {
     __shared__ unsigned hist[4 << kMaxShift];
     __shared__ unsigned part[5];
     const int tid = threadIdx.x, lane = tid & 63;
-    const bool atomic_order = __builtin_amdgcn_readfirstlane(g_lds_order_ok) != 0;
+    const bool atomic_order = !P.ballot_ranks && __builtin_amdgcn_readfirstlane(g_lds_order_ok) != 0;
     const int bins = 4 << P.shift, nb2 = P.shift + 2;
     const unsigned nbig = *P.nbig;
     for (unsigned idx = blockIdx.x; idx < nbig; idx += gridDim.x) {
@@ -2078,6 +2080,7 @@ extern "C" int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps
     P.p = reinterpret_cast<signed char *>(p);
     P.packed = packed;
     P.sweep_ok = h.sweep_ok ? 1 : 0;
+    { const char *e = getenv("V2CE_LDATI_NO_ATOMIC_ORDER"); P.ballot_ranks = (e && e[0] == '1') ? 1 : 0; }
     hipStream_t st = as_stream(stream);
     if (h.sweep_ok)
         V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ldati_emit_kernel),
@@ -2225,6 +2228,16 @@ extern "C" int v2ce_ldati_status(const void *workspace, int B, int H, int W, dou
     }
     V2CE_REQUIRE(pl.ok, V2CE_ERR_UNSUPPORTED, "v2ce_ldati_status: no two-level plan for these arguments");
     *status_dev = reinterpret_cast<const int32_t *>(w + pl.n_bkt + 2 * (size_t)B * 9 * pl.NB + 2 * (size_t)B * 9);
+    return V2CE_OK;
+}
+
+extern "C" int v2ce_ldati_rank_mode(int32_t *mode) {
+    clear_error();
+    V2CE_REQUIRE(mode, V2CE_ERR_BAD_ARG, "v2ce_ldati_rank_mode: null pointer");
+    int ok = 0;
+    V2CE_HIP_CHECK(hipMemcpyFromSymbol(&ok, HIP_SYMBOL(g_lds_order_ok), sizeof(int)));
+    const char *e = getenv("V2CE_LDATI_NO_ATOMIC_ORDER");
+    *mode = (ok && !(e && e[0] == '1')) ? 1 : 0;
     return V2CE_OK;
 }
 

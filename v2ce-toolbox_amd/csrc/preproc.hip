@@ -24,10 +24,29 @@ __global__ __launch_bounds__(256) void preprocess_pairs_kernel(const unsigned ch
     units[e] = (x - mean) / stdv;
 }
 
-// The same with the resize of v2ce.py:57 in front (cv2.resize(img, (out_w, out_h)), INTER_LINEAR
-// convention: half-pixel centres, edge clamp), restated exactly like the host path glue._resize_bilinear:
-// source coordinate (o + 0.5) * (in / out) - 0.5 in f64, weights cast to f32, horizontal blend of the
-// two source rows first, then the vertical blend -- separate f32 operations.
+// The same with the resize of v2ce.py:57-58 in front: cv2.resize(img, (out_w, out_h)), INTER_LINEAR, restated from
+// OpenCV's scalar algorithm exactly like the host path glue._resize_bilinear (resize.cpp, resizeGeneric_):
+//   scale = 1. / ((double)out / in);  f = (float)((d + 0.5) * scale - 0.5);  s = floor(f);  f -= s  (in float)
+//   x axis: s < 0 -> (f, s) = (0, 0);  s >= W - 1 -> S[W - 1] copied;   y axis: rows clipped, f kept
+//   horizontal pass S[s] * (1 - f) + S[s + 1] * f on both source rows, then r0 * (1 - g) + r1 * g
+// (separately rounded f32 operations); an exact 2 x 2 decimation is OpenCV's INTER_AREA fast path.
+__device__ __forceinline__ void linear_tap(int d, int n_in, int n_out, bool zero_at_edges, int &s0, int &s1, float &f, bool &copy) {
+    const double scale = 1.0 / ((double)n_out / (double)n_in);
+    f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floor((double)f);
+    f = f - (float)s;
+    copy = false;
+    if (zero_at_edges) {
+        if (s < 0) { f = 0.0f; s = 0; }
+        if (s >= n_in - 1) { f = 0.0f; s = n_in - 1; copy = true; }
+        s0 = s;
+        s1 = s + 1 < n_in ? s + 1 : n_in - 1;
+    } else {
+        s0 = s < 0 ? 0 : (s > n_in - 1 ? n_in - 1 : s);
+        s1 = s + 1 < 0 ? 0 : (s + 1 > n_in - 1 ? n_in - 1 : s + 1);
+    }
+}
+
 __global__ __launch_bounds__(256) void preprocess_pairs_resize_kernel(const unsigned char *__restrict__ fr, int H, int W,
                                                                       int oh, int ow, long long total, float mean,
                                                                       float stdv, float *__restrict__ units) {
@@ -38,19 +57,22 @@ __global__ __launch_bounds__(256) void preprocess_pairs_resize_kernel(const unsi
     const long long ic = e / ohw;
     const long long i = ic >> 1, c = ic & 1;
     const int oy = p / ow, ox = p - oy * ow;
-    const double ys = ((double)oy + 0.5) * ((double)H / (double)oh) - 0.5;
-    const double xs = ((double)ox + 0.5) * ((double)W / (double)ow) - 0.5;
-    const double y0d = floor(ys), x0d = floor(xs);
-    const float fy = (float)(ys - y0d), fx = (float)(xs - x0d);
-    const long long y0 = (long long)y0d, x0 = (long long)x0d;
-    const int y0c = (int)(y0 < 0 ? 0 : (y0 > H - 1 ? H - 1 : y0)), y1c = (int)(y0 + 1 < 0 ? 0 : (y0 + 1 > H - 1 ? H - 1 : y0 + 1));
-    const int x0c = (int)(x0 < 0 ? 0 : (x0 > W - 1 ? W - 1 : x0)), x1c = (int)(x0 + 1 < 0 ? 0 : (x0 + 1 > W - 1 ? W - 1 : x0 + 1));
     const unsigned char *img = fr + (i + c) * (long long)H * W;
-    const float a = (float)img[(long long)y0c * W + x0c] / 255.0f, b = (float)img[(long long)y0c * W + x1c] / 255.0f;
-    const float cc = (float)img[(long long)y1c * W + x0c] / 255.0f, d = (float)img[(long long)y1c * W + x1c] / 255.0f;
-    const float top = a * (1.0f - fx) + b * fx;
-    const float bot = cc * (1.0f - fx) + d * fx;
-    const float x = top * (1.0f - fy) + bot * fy;
+    auto px = [&](int y, int x) { return (float)img[(long long)y * W + x] / 255.0f; };
+    float x;
+    if (W == 2 * ow && H == 2 * oh) {
+        const float a = px(2 * oy, 2 * ox), b = px(2 * oy, 2 * ox + 1), cc = px(2 * oy + 1, 2 * ox), d = px(2 * oy + 1, 2 * ox + 1);
+        x = ((a + b) + (cc + d)) * 0.25f;
+    } else {
+        int x0, x1, y0, y1;
+        float fx, fy;
+        bool cpx, cpy;
+        linear_tap(ox, W, ow, true, x0, x1, fx, cpx);
+        linear_tap(oy, H, oh, false, y0, y1, fy, cpy);
+        const float top = cpx ? px(y0, x0) : px(y0, x0) * (1.0f - fx) + px(y0, x1) * fx;
+        const float bot = cpx ? px(y1, x0) : px(y1, x0) * (1.0f - fx) + px(y1, x1) * fx;
+        x = top * (1.0f - fy) + bot * fy;
+    }
     units[e] = (x - mean) / stdv;
 }
 

@@ -37,6 +37,7 @@ struct SamplerParams {
     float DELTA, FPS, VS, VS2, INV;   // f32(1/(fps*10)), f32(fps), f32(vs), f32(vs*vs), f32(1/vs)
     float off[kC];                    // f32(arange)[c] + f32(t0)
     const float *u_int, *u_dec, *u_bern;
+    const float *pooled;              // pure-slope: voxel values pooled over the pixel neighbourhood (slope only), or null
     int replay_M;
     unsigned long long seed;
     int frame_base;
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(256) void sampler_count_kernel(SamplerParams P) {
 __global__ __launch_bounds__(256) void sampler_emit_kernel(SamplerParams P) {
     const int pix = blockIdx.x * 256 + threadIdx.x, pi = blockIdx.y, b = blockIdx.z;
     const int lane = threadIdx.x & 63;
-    float y[kC];
+    float y[kC], yp[kC];
     int n[kC];
     unsigned mask = 0;
     int total = 0, max_n = 0;
@@ -173,6 +174,11 @@ __global__ __launch_bounds__(256) void sampler_emit_kernel(SamplerParams P) {
 #pragma unroll
         for (int c = 0; c < kC; ++c) y[c] = src[(long long)c * P.HW];
         total = column_events(P, y, b, pi, pix, n, mask, max_n);
+        if (P.pooled) {
+            const float *ps = P.pooled + ((long long)(b * 2 + pi) * kC) * P.HW + pix;
+#pragma unroll
+            for (int c = 0; c < kC; ++c) yp[c] = ps[(long long)c * P.HW];
+        }
     }
     // the wave's slots: inclusive scan, one atomic per wave
     int incl = total;
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(256) void sampler_emit_kernel(SamplerParams P) {
         if (nc == 0 && !hit) continue;
         const float off = P.off[c];
         if (P.mode == V2CE_SAMPLER_PURE_SLOPE) {
-            const Slope s = slope_of(P, y, c);
+            const Slope s = slope_of(P, P.pooled ? yp : y, c);       // pure_slope_sample.py:88-91: from y_pooled
             for (int j = 0; j < nc; ++j) put(to_us(slope_time(P, s, draw(P, 0, b, pi, c, pix, j)), off));
             if (hit) put(to_us(slope_time(P, s, draw(P, 1, b, pi, c, pix, 0)), off));
         } else if (P.mode == V2CE_SAMPLER_EVEN) {
@@ -223,6 +229,28 @@ __global__ __launch_bounds__(256) void sampler_emit_kernel(SamplerParams P) {
         }
     }
     if (bad) atomicOr(P.status, 1);
+}
+
+// pure_slope_sample.py:79-85: y pooled over the k x k pixel neighbourhood of every (frame, polarity, bin) plane, zero
+// padding.  'weighted' (F.conv2d with [[1,2,1],[2,4,2],[1,2,1]]/16): taps in row-major order, one multiply and one
+// add per tap; 'avg' (nn.AvgPool2d(k, 1, k//2), count_include_pad): window sum in row-major order / k^2.  Sums of
+// arbitrary f32 values: the last bit depends on the summation order (the reference's is its conv backend's), so
+// what is derived from them is compared at 1 us, not bit for bit (oracle/sample_methods.py pool_voxels: same order).
+__global__ __launch_bounds__(256) void sampler_pool_kernel(const float *__restrict__ vox, int H, int W, int weighted, int k,
+                                                           float *__restrict__ pooled) {
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= H * W) return;
+    const long long plane = (long long)blockIdx.y * H * W;
+    const int h = pix / W, w = pix - h * W, r = weighted ? 1 : k / 2;
+    float acc = 0.0f;
+    for (int dh = -r; dh <= r; ++dh)
+        for (int dw = -r; dw <= r; ++dw) {
+            const int hh = h + dh, ww = w + dw;
+            const float v = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? vox[plane + (long long)hh * W + ww] : 0.0f;
+            if (weighted) acc = acc + ((float)((2 - (dh < 0 ? -dh : dh)) * (2 - (dw < 0 ? -dw : dw))) / 16.0f) * v;
+            else acc = acc + v;
+        }
+    pooled[plane + pix] = weighted ? acc : acc / (float)(k * k);
 }
 
 __global__ __launch_bounds__(256) void sampler_unpack_kernel(const unsigned long long *__restrict__ keys, long long n,
@@ -271,6 +299,7 @@ int make_params(const float *vox, int B, int H, int W, const v2ce_sampler_option
     P.DELTA = (float)vs; P.FPS = (float)fps; P.VS = (float)vs; P.VS2 = (float)(vs * vs); P.INV = (float)(1.0 / vs);
     for (int c = 0; c < kC; ++c) P.off[c] = (float)((double)c * step) + (float)o->t0;
     P.u_int = o->u_int; P.u_dec = o->u_dec; P.u_bern = o->u_bern; P.replay_M = o->replay_M;
+    P.pooled = o->mode == V2CE_SAMPLER_PURE_SLOPE ? o->pooled : nullptr;
     P.seed = o->seed; P.frame_base = o->frame_base;
     // key layout: timestamps of a frame lie in [t0, t0 + 1/fps] * 1e6 up to f32 rounding of the sum
     const double t0us = o->t0 * 1e6, margin = 4096.0 + std::fabs(t0us) * 0x1p-18 + std::fabs(t0us + 1e6 / fps) * 0x1p-18;
@@ -308,6 +337,20 @@ extern "C" int v2ce_sampler_count(const float *vox, int B, int H, int W, const v
     P.counts = reinterpret_cast<unsigned long long *>(frame_counts);
     P.max_int = max_int;
     hipLaunchKernelGGL(sampler_count_kernel, dim3((P.HW + 255) / 256, 2, B), dim3(256), 0, st, P);
+    V2CE_HIP_CHECK(hipGetLastError());
+    return V2CE_OK;
+}
+
+extern "C" int v2ce_sampler_pool(const float *vox, int B, int H, int W, int pooling_type, int pooling_kernel_size,
+                                 float *pooled, v2ce_stream_t stream) {
+    clear_error();
+    V2CE_REQUIRE(vox && pooled && B > 0 && H > 0 && W > 0, V2CE_ERR_BAD_ARG, "v2ce_sampler_pool: bad argument");
+    V2CE_REQUIRE(pooling_type == V2CE_POOL_AVG || pooling_type == V2CE_POOL_WEIGHTED, V2CE_ERR_BAD_ARG,
+                 "v2ce_sampler_pool: pooling_type %d", pooling_type);
+    V2CE_REQUIRE(pooling_type != V2CE_POOL_AVG || (pooling_kernel_size >= 1 && pooling_kernel_size <= 15 && (pooling_kernel_size & 1)),
+                 V2CE_ERR_UNSUPPORTED, "v2ce_sampler_pool: pooling_kernel_size %d (odd sizes 1..15 keep H x W)", pooling_kernel_size);
+    hipLaunchKernelGGL(sampler_pool_kernel, dim3((H * W + 255) / 256, B * 2 * kC), dim3(256), 0, as_stream(stream), vox, H, W,
+                       pooling_type == V2CE_POOL_WEIGHTED ? 1 : 0, pooling_kernel_size, pooled);
     V2CE_HIP_CHECK(hipGetLastError());
     return V2CE_OK;
 }

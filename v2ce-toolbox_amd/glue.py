@@ -19,24 +19,49 @@ logger = logging.getLogger("V2CE")
 MEAN, STD = np.float32(0.153), np.float32(0.165)            # v2ce.py:54-55
 
 
+def _linear_coeffs(n_in: int, n_out: int, zero_at_edges: bool):
+    """OpenCV's INTER_LINEAR tap table for one axis (modules/imgproc/src/resize.cpp, cv::resize ->
+    resizeGeneric_: ``scale = 1. / ((double)n_out / n_in)``; ``f = (float)((d + 0.5) * scale - 0.5)``;
+    ``s = cvFloor(f)``; ``f -= s`` IN FLOAT).  Horizontal axis (`zero_at_edges`): ``s < 0 -> (f, s) = (0, 0)``,
+    ``s >= n_in - 1 -> (f, s) = (0, n_in - 1)`` and the second tap is never read there (HResizeLinear copies
+    ``S[s] * 1`` from xmax on).  Vertical axis: both rows are only CLIPPED to [0, n_in - 1], f is kept.
+    Returns (first tap, second tap, weight of the second tap as f32)."""
+    scale = 1.0 / (float(n_out) / float(n_in))                       # two f64 divisions, like OpenCV
+    f = ((np.arange(n_out, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f.astype(np.float64)).astype(np.int64)               # cvFloor of the float value
+    f = f - s.astype(np.float32)                                      # f32 subtraction
+    if zero_at_edges:
+        lo, hi = s < 0, s >= n_in - 1
+        f = np.where(lo | hi, np.float32(0), f).astype(np.float32)
+        s = np.where(lo, 0, np.where(hi, n_in - 1, s))
+        return s, np.minimum(s + 1, n_in - 1), f
+    return np.clip(s, 0, n_in - 1), np.clip(s + 1, 0, n_in - 1), f
+
+
 def _resize_bilinear(img: np.ndarray, out_w: int, out_h: int) -> np.ndarray:
-    """cv2.resize(img, (out_w, out_h)) with the default INTER_LINEAR convention (half-pixel centres,
-    edge clamp) for float32 images.  Identity when the size already matches (the 260-high inputs
-    of every BASELINE config); cv2 is not installed here, so the non-identity case is unpinned."""
+    """cv2.resize(img, (out_w, out_h)) for a float32 image with the default INTER_LINEAR, restated from
+    OpenCV's published scalar algorithm (resize.cpp; the reference calls it at v2ce.py:57-58):
+    identity when the size matches (every BASELINE config); an exact 2x2 decimation is OpenCV's INTER_AREA
+    fast path (``(a + b + c + d) * 0.25``: cv::resize switches to it when both scales are exactly 2);
+    otherwise taps / weights per axis from ``_linear_coeffs``, the HORIZONTAL pass ``S[s] * (1 - f) + S[s+1] * f``
+    over the source rows first, then the vertical pass ``r0 * (1 - g) + r1 * g``, every operation a separately
+    rounded f32 operation.  OpenCV itself is not installed here: pinned by hand-derived vectors
+    (tests/test_product_glue.py), not against the library (whose SIMD builds may contract a*b+c)."""
     h, w = img.shape
     if (w, h) == (out_w, out_h):
         return img
-    ys = (np.arange(out_h, dtype=np.float64) + 0.5) * (h / out_h) - 0.5
-    xs = (np.arange(out_w, dtype=np.float64) + 0.5) * (w / out_w) - 0.5
-    y0 = np.floor(ys).astype(np.int64)
-    x0 = np.floor(xs).astype(np.int64)
-    fy = (ys - y0).astype(np.float32)[:, None]
-    fx = (xs - x0).astype(np.float32)[None, :]
-    y0c, y1c = np.clip(y0, 0, h - 1), np.clip(y0 + 1, 0, h - 1)
-    x0c, x1c = np.clip(x0, 0, w - 1), np.clip(x0 + 1, 0, w - 1)
-    top = img[y0c][:, x0c] * (1 - fx) + img[y0c][:, x1c] * fx
-    bot = img[y1c][:, x0c] * (1 - fx) + img[y1c][:, x1c] * fx
-    return (top * (1 - fy) + bot * fy).astype(np.float32)
+    img = img.astype(np.float32, copy=False)
+    if w == 2 * out_w and h == 2 * out_h:
+        a, b, c, d = img[0::2, 0::2], img[0::2, 1::2], img[1::2, 0::2], img[1::2, 1::2]
+        return (((a + b) + (c + d)) * np.float32(0.25)).astype(np.float32)
+    x0, x1, fx = _linear_coeffs(w, out_w, True)
+    y0, y1, fy = _linear_coeffs(h, out_h, False)
+    one = np.float32(1)
+    ax0, ax1 = (one - fx)[None, :], fx[None, :]
+    rows = img[:, x0] * ax0 + img[:, x1] * ax1                        # [h, out_w]; at the right edge ax1 == 0
+    rows[:, x0 == w - 1] = img[:, w - 1:w]                            # HResizeLinear's copy region (S[s] * 1)
+    by0, by1 = (one - fy)[:, None], fy[:, None]
+    return (rows[y0] * by0 + rows[y1] * by1).astype(np.float32)
 
 
 def image_pre_processing(images: np.ndarray, height: int = 260) -> np.ndarray:
@@ -83,7 +108,11 @@ def run_guarded(model, fn, comm=None):
         return fn()
     snap = model.sn_snapshot()
     model.range_guard_value()                              # clear what earlier calls left
-    out = fn()
+    per_call, model.guard = getattr(model, "guard", "deferred"), "deferred"   # one check per clip, no per-call sync
+    try:
+        out = fn()
+    finally:
+        model.guard = per_call
     worst = model.range_guard_value()
     if comm is None:
         from . import dist as vdist
@@ -96,7 +125,7 @@ def run_guarded(model, fn, comm=None):
         f"split-half range guard: bound {worst:.3e} > {model.RANGE_GUARD_LIMIT:.1e}; repeating the clip on the exact-f32 kernels")
     del out
     model.sn_restore(snap)
-    with model.exact_f32():
+    with model.exact_f32():                                # (precision 'f32': the guard mode is irrelevant)
         return fn()
 
 

@@ -23,14 +23,14 @@ ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 PRECISION_F32, PRECISION_F16X2 = 0, 1
 
 EXPORTS = [
-    "v2ce_version", "v2ce_last_error", "v2ce_ldati_count", "v2ce_ldati_tile_ws_bytes", "v2ce_ldati_status", "v2ce_ldati_plan_info",
+    "v2ce_version", "v2ce_last_error", "v2ce_ldati_count", "v2ce_ldati_rank_mode", "v2ce_ldati_tile_ws_bytes", "v2ce_ldati_status", "v2ce_ldati_plan_info",
     "v2ce_ldati_lds_bytes", "v2ce_ldati_workspace_bytes", "v2ce_ldati_emit", "v2ce_events_pack", "v2ce_events_unpack",
     "v2ce_conv3d_fwd",
     "v2ce_conv3d_variant", "v2ce_conv3d_variant_fused", "v2ce_pack_weights_f16x2", "v2ce_pack_weights_f16x2_bytes",
     "v2ce_pack_weights", "v2ce_sn_workspace_bytes", "v2ce_sn_power_iter", "v2ce_sn_batch_workspace_bytes", "v2ce_sn_update_batch",
     "v2ce_preprocess_pairs", "v2ce_preprocess_pairs_resize",
     "v2ce_voxelize_events", "v2ce_conv3d_fwd_pred", "v2ce_conv3d_fwd_sc", "v2ce_pack_pred_weights_f16x2", "v2ce_pack_pred_weights_f16x2_bytes",
-    "v2ce_sampler_count", "v2ce_sampler_workspace_bytes", "v2ce_sampler_emit",
+    "v2ce_sampler_count", "v2ce_sampler_workspace_bytes", "v2ce_sampler_emit", "v2ce_sampler_pool",
 ]
 
 
@@ -60,7 +60,7 @@ class SamplerOptions(ctypes.Structure):
     """``v2ce_sampler_options`` (include/v2ce_hip.h): the ablation samplers of SURVEY 8f4."""
     _fields_ = [("mode", ctypes.c_int32), ("rng_mode", ctypes.c_int32), ("fps", ctypes.c_double), ("t0", ctypes.c_double),
                 ("seed", ctypes.c_uint64), ("frame_base", ctypes.c_int32), ("replay_M", ctypes.c_int32),
-                ("u_int", ctypes.c_void_p), ("u_dec", ctypes.c_void_p), ("u_bern", ctypes.c_void_p)]
+                ("u_int", ctypes.c_void_p), ("u_dec", ctypes.c_void_p), ("u_bern", ctypes.c_void_p), ("pooled", ctypes.c_void_p)]
 
 
 SAMPLER_RANDOM, SAMPLER_EVEN, SAMPLER_PURE_SLOPE = 0, 1, 2
@@ -108,6 +108,8 @@ def lib() -> ctypes.CDLL:
     L.v2ce_ldati_status.restype = ctypes.c_int
     L.v2ce_ldati_plan_info.argtypes = [i32, i32, i32, f64, f64, op, i64, i64, i64, vp]
     L.v2ce_ldati_plan_info.restype = ctypes.c_int
+    L.v2ce_ldati_rank_mode.argtypes = [ctypes.POINTER(ctypes.c_int32)]
+    L.v2ce_ldati_rank_mode.restype = ctypes.c_int
     L.v2ce_events_pack.argtypes = [vp, vp, vp, vp, i64, vp, vp]
     L.v2ce_events_unpack.argtypes = [vp, i64, vp, vp, vp, vp, vp]
     L.v2ce_events_unpack.restype = ctypes.c_int
@@ -144,6 +146,8 @@ def lib() -> ctypes.CDLL:
     so = ctypes.POINTER(SamplerOptions)
     L.v2ce_sampler_count.argtypes = [vp, i32, i32, i32, so, vp, vp, vp]
     L.v2ce_sampler_count.restype = ctypes.c_int
+    L.v2ce_sampler_pool.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
+    L.v2ce_sampler_pool.restype = ctypes.c_int
     L.v2ce_sampler_workspace_bytes.argtypes = [i64]
     L.v2ce_sampler_workspace_bytes.restype = sz
     L.v2ce_sampler_emit.argtypes = [vp, i32, i32, i32, so, i64, vp, vp, vp, vp, vp, sz, vp, vp]

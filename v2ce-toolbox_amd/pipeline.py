@@ -304,7 +304,7 @@ def run_clip(frames: np.ndarray, model, *, infer_type="center", seq_len=16, widt
     # rank 0 owns the host buffer of the whole clip; the other ranks only feed the gather
     sink = EventSink(device, len(frames) - 1, reuse=reuse_output) if rank == 0 else None
     gather = None
-    if world > 1:
+    if not isinstance(comm, vdist.LocalComm):               # (a forced world of one takes the collective path too)
         step_pairs = collections.deque(bp.n_pairs for bp in plans)
 
         def on_pieces(pieces, stream):

@@ -16,9 +16,10 @@ Differences from the reference, all deliberate:
   device and replayed, the Bernoulli event decided by ``u < frac(y)``), or caller-supplied ``u_int`` /
   ``u_dec`` / ``u_bern`` tensors (how parity with the oracle is tested).
 * The pure-slope reference folds bin 9 into bin 8 in the CALLER's tensor (:92-93); here ``y`` is not modified.
-* ``pooling_type`` other than 'none' raises NotImplementedError for the pure-slope sampler: the pooled values are
-  sums of non-integer f32 numbers whose rounding depends on the convolution backend's summation order, so there
-  is nothing to be bit-exact against (LDATI's pooled variant, which pools integer counts, is covered in LDATI.py).
+* ``pooling_type`` 'avg' / 'weighted' of the pure-slope sampler (pure_slope_sample.py:79-85): the pooled values are
+  sums of non-integer f32 numbers whose last bit depends on the convolution backend's summation order, so this one
+  option is held to "the reference's events with timestamps within 1 us" instead of bit-exactness (measured on the
+  goldens: identical; LDATI's pooled variant pools integer counts, which is exact, and is bit-exact in LDATI.py).
 """
 from __future__ import annotations
 
@@ -43,7 +44,8 @@ def _check_fps(fps) -> None:
 
 
 def sampler_device(y: torch.Tensor, mode: int, t0=0, fps=30, *, rng: str = "philox", seed: Optional[int] = None,
-                   frame_base: int = 0, u_int=None, u_dec=None, u_bern=None) -> DeviceEvents:
+                   frame_base: int = 0, u_int=None, u_dec=None, u_bern=None, pooling_type: str = "none",
+                   pooling_kernel_size: int = 3) -> DeviceEvents:
     """count -> emit on the device; the events stay there (``DeviceEvents`` with one segment per frame)."""
     if y.dim() != 5 or y.shape[1] != 2 or y.shape[2] != C:
         raise ValueError(f"expected y of shape [B,2,{C},H,W], got {tuple(y.shape)}")
@@ -59,6 +61,12 @@ def sampler_device(y: torch.Tensor, mode: int, t0=0, fps=30, *, rng: str = "phil
         opts = hip.SamplerOptions(mode=mode, rng_mode=hip.RNG_PHILOX, fps=float(fps), t0=float(t0), seed=0,
                                   frame_base=int(frame_base), replay_M=0, u_int=None, u_dec=None, u_bern=None)
         keep = []
+        if mode == hip.SAMPLER_PURE_SLOPE and pooling_type != "none":     # pure_slope_sample.py:79-85: y_pooled (slope only)
+            pooled = torch.empty_like(y)
+            hip.check(L.v2ce_sampler_pool(y.data_ptr(), B, H, W, hip.POOL_WEIGHTED if pooling_type == "weighted" else hip.POOL_AVG,
+                                          int(pooling_kernel_size), pooled.data_ptr(), st), "v2ce_sampler_pool")
+            opts.pooled = pooled.data_ptr()
+            keep.append(pooled)
         replay = u_bern is not None or rng == "torch"
         if replay:
             if u_bern is None:                      # the reference's own draws, on the device
@@ -137,7 +145,6 @@ def sample_voxel_pure_slope(y, t0=0, fps=30, pooling_type="none", pooling_kernel
     the un-relocated voxel values, bin 9 folded into bin 8, Bernoulli rounding of the fractional part."""
     assert pooling_type in ["avg", "weighted", "none"]                         # :68
     assert additional_events_strategy in ["none", "random", "slope"]           # :69 (asserted, never used there)
-    if pooling_type != "none":
-        raise NotImplementedError("pure-slope sampler with pooling: not bit-reproducible (see module docstring)")
     return sampler_device(y, hip.SAMPLER_PURE_SLOPE, t0, fps, rng=rng, seed=seed, frame_base=frame_base, u_int=u_int,
-                          u_dec=u_dec, u_bern=u_bern).to_recarrays()
+                          u_dec=u_dec, u_bern=u_bern, pooling_type=pooling_type,
+                          pooling_kernel_size=pooling_kernel_size).to_recarrays()

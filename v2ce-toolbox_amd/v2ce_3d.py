@@ -6,9 +6,8 @@ exactly (218 keys; ``scripts/v2ce_3d.py:13-24``, ``scripts/unet_2layer.py:203-31
 ``model.load_state_dict(torch.load('weights/v2ce_3d.pt'))``, ``.eval()``, ``.to('cuda')`` and
 ``model(x)`` work as in ``v2ce.py:30-43,81-82``.  The forward pass contains no torch compute ops:
 every convolution (with its folded BatchNorm, activation, residual add, nearest-upsample + concat
-input) is one ``v2ce_conv3d_fwd`` launch, every spectral-norm layer one ``v2ce_sn_power_iter`` +
-``v2ce_pack_weights[_f16x2]`` (include/v2ce_hip.h), the latter on a side stream overlapping the
-encoder.  ``precision`` selects the arithmetic of the residual-block convs: "f16x2" (default) =
+input) is one ``v2ce_conv3d_fwd`` launch, the 12 spectral-norm layers one ``v2ce_sn_update_batch`` (power
+iteration + split-half re-pack; include/v2ce_hip.h) in line in front of the head convolution.  ``precision`` selects the arithmetic of the residual-block convs: "f16x2" (default) =
 f32 operands split into two fp16 halves on the fp16 MFMA with device-side range tracking
 (f32-equivalent accuracy), "f32" = exact f32 MFMA.  Inference only (the
 reference runs it under ``torch.no_grad()`` in eval mode, ``v2ce.py:41,66``).
@@ -121,17 +120,28 @@ def _nearest_map(n_in: int, n_out: int) -> np.ndarray:
 class V2ce3d(nn.Module):
     """Drop-in for ``scripts/v2ce_3d.py:12``: ``V2ce3d()(x[B,L,2,H,W]) -> [B,L,20,H,W]``."""
 
-    def __init__(self, in_channels=2, out_channels=20, precision: str = "f16x2"):
+    def __init__(self, in_channels=2, out_channels=20, precision: str = "f16x2", guard: str = "call"):
         """precision of the 3x3x3 convolutions of the residual blocks (99 % of the FLOP):
         "f16x2" (default): every f32 operand is split into two fp16 halves (22 bits, power-of-two
             pre-scales tracked on the device) and each product is three fp16 MFMAs accumulated in f32;
             measured against an f64 evaluation of the network its error equals the exact-f32 path's
             (profiles/r01_d_precision_report.json: rms 9.8e-8 both, 10x inside the 1e-5 parity bar);
-        "f32": exact f32 MFMA arithmetic (v_mfma_f32_32x32x2_f32) everywhere."""
+        "f32": exact f32 MFMA arithmetic (v_mfma_f32_32x32x2_f32) everywhere.
+        guard (f16x2 only) -- who enforces the f32 contract of the reference's ``model(x)`` (v2ce_3d.py:26-30) when
+        a tensor's dynamic range exceeds what one scale per sequence covers (the range guard):
+        "call" (default): every forward reads its own guard bound back (4 bytes, one synchronisation -- the
+            reference's callers follow the call with ``.cpu()`` anyway) and, if it is above RANGE_GUARD_LIMIT,
+            rewinds the spectral-norm state and repeats THAT call on the exact-f32 kernels: a bare ``model(x)`` is
+            then either provably within 2.5e-6 of exact f32 arithmetic or exact f32 itself;
+        "deferred": forward never synchronises; the owner of a whole clip checks ``range_guard_value()`` once and
+            repeats the clip (glue.run_guarded: the CLI, pipeline.run_clip callers, bench.py)."""
         super().__init__()
         if precision not in ("f32", "f16x2"):
             raise ValueError(f"precision must be 'f32' or 'f16x2', got {precision!r}")
-        self.precision = precision
+        if guard not in ("call", "deferred"):
+            raise ValueError(f"guard must be 'call' or 'deferred', got {guard!r}")
+        self.precision, self.guard = precision, guard
+        self.guard_reruns = 0      # forwards repeated on the exact-f32 kernels by the per-call guard
         self.in_channels, self.out_channels = in_channels, out_channels
         self.UNet = _UNet3D(in_channels, out_channels)
         self._prep = None          # device-side derived constants (packed weights, folded BN)
@@ -149,6 +159,7 @@ class V2ce3d(nn.Module):
         r = super()._apply(fn, *a, **kw)
         self._prep = None
         self._maps = {}
+        self._sn_plist = self._sn_bufs = None
         return r
 
     def train(self, mode=True):
@@ -238,7 +249,7 @@ class V2ce3d(nn.Module):
         P["sigma"] = torch.empty(1, dtype=torch.float32, device=dev)
         P["sn_batch"] = None
         if self.precision == "f16x2":
-            # all 12 spectral-norm layers in one v2ce_sn_update_batch call (five launches instead of 84)
+            # all 12 spectral-norm layers in one v2ce_sn_update_batch call (six launches instead of 84)
             inners = [(getattr(blk, cn).module, P[f"{name}{i}"][cn + "_w"])
                       for name, blocks in (("res", self.UNet.resblocks), ("dec", self.UNet.decoders))
                       for i, blk in enumerate(blocks) if blk.sn for cn in ("conv1", "conv2")]
@@ -506,7 +517,24 @@ class V2ce3d(nn.Module):
         # every launch below goes to the current stream of x's device through the C ABI: make that
         # device current for the whole call (the ABI has no device argument, like a HIP stream call)
         with torch.cuda.device(x.device):
-            return self._forward(x, return_intermediates)
+            if self.precision != "f16x2" or self.guard != "call":
+                return self._forward(x, return_intermediates)
+            snap = self._sn_snapshot_fast()
+            out = self._forward(x, return_intermediates)
+            worst = float(self._prep["absmax"][:, :, 1].max().item())        # this call's bound (synchronises)
+            if worst <= self.RANGE_GUARD_LIMIT:
+                return out
+            import logging
+            logging.getLogger("V2CE").warning(
+                f"split-half range guard: bound {worst:.3e} > {self.RANGE_GUARD_LIMIT:.1e}; repeating this call on the "
+                "exact-f32 kernels")
+            del out
+            self._sn_restore_fast(snap)
+            self.guard_reruns += 1
+            # (switching precision rebuilds the derived constants on the way in and out: a one-off for a checkpoint
+            # that needs it on every call -- construct it with precision='f32' instead)
+            with self.exact_f32():
+                return self._forward(x, return_intermediates)
 
     def _forward(self, x, return_intermediates):
         if self._prep is None:
@@ -568,6 +596,25 @@ class V2ce3d(nn.Module):
         if reset:
             self._prep["guard"].zero_()
         return v
+
+    def _sn_params(self):
+        if getattr(self, "_sn_plist", None) is None:
+            self._sn_plist = [p for n, p in self.named_parameters() if n.endswith(("weight_u", "weight_v"))]
+        return self._sn_plist
+
+    def _sn_snapshot_fast(self):
+        """u / v of the 12 SN layers into persistent buffers with one multi-tensor copy (per-call guard)."""
+        ps = self._sn_params()
+        bufs = getattr(self, "_sn_bufs", None)
+        if bufs is None or bufs[0].device != ps[0].device:
+            bufs = self._sn_bufs = [torch.empty_like(p) for p in ps]
+        torch._foreach_copy_(bufs, [p.data for p in ps])
+        return bufs, self.calls
+
+    def _sn_restore_fast(self, snap):
+        bufs, calls = snap
+        torch._foreach_copy_([p.data for p in self._sn_params()], bufs)
+        self.calls = calls
 
     def sn_snapshot(self):
         """The state a forward call mutates (spectral-norm u / v of the 12 SN layers, call counter)."""
