@@ -69,14 +69,17 @@ def test_c3_2048_frames_batch32_single_and_eight_ranks():
     assert single_model.calls == 4                                   # 128 sequences / 32: four model calls
     ts = single["timestamp"]
     assert np.all(np.diff(ts) >= 0)                                  # frame-major, bins ascending, sorted segments
-    # every frame-pair i occupies [int(i/fps*1e6), int((i+1)/fps*1e6))  (v2ce.py:365 offset + LDATI's [0, 1/fps))
+    # frame-pair i occupies [int(i/fps*1e6), int((i+1)/fps*1e6)] (v2ce.py:365 offset + LDATI's f32 times in [0, 1/fps]: the
+    # last microsecond of a frame may round onto the next frame's offset, never beyond it)
     off = np.array([glue.frame_offset_us(i, 30) for i in range(n)], np.int64)
+    assert off[123] == int(123 * 1 / 30 * 1e6) and off[2046] == int(2046 * 1 / 30 * 1e6)
+    assert ts[0] >= 0 and ts[-1] <= off[n - 1] + 2
     per_pair = np.diff(np.searchsorted(ts, off, side="left"))
-    assert len(per_pair) == n - 1 and per_pair.min() > 1000 and per_pair.sum() == len(single)
+    assert len(per_pair) == n - 1 and per_pair.min() > 1000 and 0 <= len(single) - per_pair.sum() < 64
     for i in (123, 2046):
         seg = single[np.searchsorted(ts, off[i]):np.searchsorted(ts, off[i + 1])]
-        assert len(seg) == per_pair[i] and seg["timestamp"].min() >= off[i] == int(i * 1 / 30 * 1e6)
-        assert 0 <= seg["x"].min() and seg["x"].max() < W and seg["y"].max() < H
+        assert len(seg) == per_pair[i] > 1000 and seg["timestamp"].min() >= off[i]
+        assert 0 <= seg["x"].min() and seg["x"].max() < W and 0 <= seg["y"].min() and seg["y"].max() < H
     got, models = run_world(8, frames, **kw)
     assert all(m.calls == 4 for m in models)
     assert same_bytes(got, single)

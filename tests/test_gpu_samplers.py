@@ -103,8 +103,9 @@ def test_empty_and_errors():
     assert [len(r) for r in res] == [0, 0] and res[0].dtype.itemsize == 13
     with pytest.raises(AssertionError):
         SM.sample_voxel_baseline(y)
-    with pytest.raises(NotImplementedError):
-        SM.sample_voxel_pure_slope(y, pooling_type="avg")
+    assert [len(r) for r in SM.sample_voxel_pure_slope(y, pooling_type="avg")] == [0, 0]
+    with pytest.raises(hip.V2ceHipError):
+        SM.sample_voxel_pure_slope(y, pooling_type="avg", pooling_kernel_size=4)      # even sizes change H x W in the reference
     with pytest.raises(hip.V2ceHipError):
         SM.sample_voxel_baseline(y.cpu(), even=True)
     with pytest.raises(ValueError):

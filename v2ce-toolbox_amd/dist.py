@@ -298,11 +298,13 @@ class ThreadWorld:
 
     def run(self, fn: Callable[["ThreadComm"], object], device=None) -> list:
         results, errors = [None] * self.world, [None] * self.world
+        current = torch.cuda.current_device() if (device is not None and torch.device(device).type == "cuda") else 0
 
         def body(r):
             try:
                 if device is not None and torch.device(device).type == "cuda":
-                    torch.cuda.set_device(torch.device(device))
+                    d = torch.device(device)
+                    torch.cuda.set_device(d if d.index is not None else torch.device("cuda", current))
                 results[r] = fn(self.comm(r))
             except BaseException as e:                       # noqa: BLE001 -- re-raised on the caller's thread
                 errors[r] = e

@@ -362,7 +362,7 @@ class V2ce3d(nn.Module):
                          layout=hip.LAYOUT_C16 if c16 else hip.LAYOUT_PLANAR,
                          # [slot][B][2] table: one range slot per batch element (callers of the raw kernels that
                          # keep a [slot][2] table get one slot per tensor)
-                         absmax_batch_stride=2 if self._prep["absmax"].dim() == 3 else 0)
+                         absmax_batch_stride=2 if (getattr(self, "_prep", None) or {}).get("absmax", torch.empty(0)).dim() == 3 else 0)
         a0 = a1 = ay = None
         if track or split:         # range tracking for the split-half consumers (device side only)
             ay = y.absmax = self._prep["absmax"][self._slot]              # [B] x [max |y|, range-guard value]
