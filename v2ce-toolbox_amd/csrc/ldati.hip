@@ -33,6 +33,7 @@
 #include "common.h"
 
 #include <atomic>
+#include <mutex>
 #include <type_traits>
 
 #include <cstring>
@@ -63,6 +64,8 @@ struct LdatiParams {
     // scalars of LDATI.py:145-146 cast the way CPU torch casts python scalars
     double fps;        // python number used in the f64 single-event path
     float VS, VS2, INV, FPS;
+    float RFPS, R9;    // f32(1 / FPS), f32(1 / 9): reciprocals of the two constant divisors of the k == 0 time (k0_time)
+    int fast_slot;     // slot of g_fastdiv that holds the exhaustive check of k0_time's fast form for this FPS, or -1
     float offt[9];     // f32(arange(0,1/fps,1/fps/9)[c]) + f32(t0)
     long long kbase[9];  // key = timestamp - kbase[c], clamped to [0, NK)
     int NK, nbits;
@@ -235,6 +238,37 @@ __device__ __forceinline__ void slope_params(int n_l, int n_c, int n_r, int c, c
     bb = P.INV - (P.VS * k) / 2.0f;
 }
 
+// ---- the k == 0 time (u / fps) / 9 (LDATI.py:196) without the two IEEE division sequences ------------------------
+// Both divisors are constants of the call.  x / y = fma(fma(-q, y, x), r, q) with q = x * r, r = RN(1 / y), is the
+// correctly rounded quotient for all but rare (x, y); instead of proving which, the composition is checked against the
+// IEEE divisions for EVERY uniform the Philox path can produce (u = m * 2^-24, m < 2^24) by a 16 M-thread kernel, once
+// per device and FPS, enqueued in front of the first emit that needs it; the result lands in g_fastdiv[slot] and the
+// kernels take the fast form only when it says "identical for all inputs" (replayed uniforms are arbitrary floats: they
+// always take the divisions).  22 -> 6 VALU operations on a path every wave with a multi-event voxel executes.
+struct FastDiv { unsigned fps_bits; int ok; };
+__device__ FastDiv g_fastdiv[8];
+__device__ unsigned g_fastdiv_bad[8];
+
+__device__ __forceinline__ float k0_time_fast(float u, float FPS, float RFPS, float R9) {
+    float q = u * RFPS;
+    q = __builtin_fmaf(__builtin_fmaf(-q, FPS, u), RFPS, q);
+    float t = q * R9;
+    t = __builtin_fmaf(__builtin_fmaf(-t, 9.0f, q), R9, t);
+    return t;
+}
+
+__global__ __launch_bounds__(256) void ldati_fastdiv_check_kernel(float FPS, float RFPS, float R9, int slot) {
+    const unsigned m = blockIdx.x * 256u + threadIdx.x;                  // < 2^24
+    const float u = (float)m * (1.0f / 16777216.0f);
+    const float want = (u / FPS) / 9.0f;
+    const float got = k0_time_fast(u, FPS, RFPS, R9);
+    if (__float_as_uint(want) != __float_as_uint(got)) atomicAdd(&g_fastdiv_bad[slot], 1u);
+}
+__global__ void ldati_fastdiv_commit_kernel(float FPS, int slot) {
+    g_fastdiv[slot].fps_bits = __float_as_uint(FPS);
+    g_fastdiv[slot].ok = g_fastdiv_bad[slot] == 0u ? 1 : 0;
+}
+
 // multi-event timestamp, all f32 (LDATI.py:195-196,210-212)
 __device__ __forceinline__ long long multi_ts(float k, float bb, float u, float offt,
                                               const LdatiParams &P) {
@@ -253,12 +287,13 @@ __device__ __forceinline__ long long multi_ts(float k, float bb, float u, float 
 }
 
 // the same, f32 -> i32 (bit-identical to the i64 conversion while |t| < 2^31: P.ts32) and the key
-__device__ __forceinline__ unsigned multi_key(float k, float bb, float u, float offt, int kbase32, const LdatiParams &P) {
+__device__ __forceinline__ unsigned multi_key(float k, float bb, float u, float offt, int kbase32, const LdatiParams &P,
+                                              bool fast = false) {
     float t;
     if (P.strategy == V2CE_STRATEGY_RANDOM) {
         t = u;
     } else if (k == 0.0f) {
-        t = (u / P.FPS) / 9.0f;
+        t = fast ? k0_time_fast(u, P.FPS, P.RFPS, P.R9) : (u / P.FPS) / 9.0f;
     } else {
         const float s = bb * bb + (2.0f * k) * u;
         t = (-bb + __builtin_sqrtf(s)) / k;
@@ -370,6 +405,12 @@ __device__ __forceinline__ unsigned take_slot(bool atomic_order, bool has, unsig
     return take_slots(has, key, nbits, slot);
 }
 
+// px / W for px + 0.5 < 2^22 in three operations: (px + 0.5) / W lies at least 0.5 / W away from every integer, and the
+// two roundings (1 / W, the product) move it by less than (px + 0.5) / W * 2^-23 < 0.5 / W, so the truncation is exact
+__device__ __forceinline__ unsigned div_tiny(unsigned px, float rcpW) {
+    return (unsigned)(((float)px + 0.5f) * rcpW);
+}
+
 // px / W for px < 2^24 (exact in f32) without an integer division
 __device__ __forceinline__ unsigned div_small(unsigned px, unsigned W, float rcpW) {
     unsigned q = (unsigned)((float)px * rcpW);
@@ -388,14 +429,19 @@ __device__ __forceinline__ void store_packed_bytes(unsigned char *dst, long long
     dst[12] = (unsigned char)pp;
 }
 
-// inclusive scan over the 64 lanes of a wave
+// inclusive scan over the 64 lanes of a wave: DPP row shifts inside the rows of 16 lanes, then the two row
+// broadcasts of gfx9 (lane 15 of a row into the next row; lane 31 into rows 2-3) -- six VALU operations instead
+// of six dependent ds_bpermute round trips through the LDS crossbar (~100 cycles each)
 __device__ __forceinline__ unsigned wave_incl_scan(unsigned v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned t = __shfl_up(v, o);
-        if (lane >= o) v += t;
-    }
-    return v;
+    (void)lane;
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);   // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);   // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+    return (unsigned)x;
 }
 
 // exclusive scan of one value per thread over a workgroup of NW waves; `part` = NW+1 LDS words.
@@ -461,22 +507,35 @@ __global__ __launch_bounds__(kCountThreads) void ldati_count_tiles_kernel(
 #pragma unroll
     for (int i = 0; i < 9; ++i) cnt[i] = 0;
     int mx = 0;
+    constexpr int PPT = kTilePix / kCountThreads;
+    // four consecutive pixels per thread: one 16-byte load per plane, all ten in flight at once (any pixel order
+    // is right: only sums are formed)
+    float yq[PPT][10];
+    {
+        const int px = x0 + (int)threadIdx.x * PPT;
+        if ((HW & 3) == 0 && px + PPT <= HW) {
 #pragma unroll
-    for (int q = 0; q < kTilePix / kCountThreads; ++q) {
-        const int px = x0 + q * kCountThreads + threadIdx.x;      // any order: only sums are formed
-        if (px < HW) {
-            float yv[10];
-#pragma unroll
-            for (int i = 0; i < 10; ++i) yv[i] = plane0[(long long)i * HW + px];
-            int nn[9];
-            float td[9];
-            relocate_all(yv, bidir != 0, nn, td);
-#pragma unroll
-            for (int i = 0; i < 9; ++i) {
-                const int ni = nn[i];
-                cnt[i] += (strategy == V2CE_STRATEGY_NONE) ? (ni == 1) : (ni > 0 ? ni : 0);
-                mx = ni > mx ? ni : mx;
+            for (int i = 0; i < 10; ++i) {
+                const float4 v = *reinterpret_cast<const float4 *>(plane0 + (long long)i * HW + px);
+                yq[0][i] = v.x; yq[1][i] = v.y; yq[2][i] = v.z; yq[3][i] = v.w;
             }
+        } else {
+#pragma unroll
+            for (int q = 0; q < PPT; ++q)
+#pragma unroll
+                for (int i = 0; i < 10; ++i) yq[q][i] = (px + q < HW) ? plane0[(long long)i * HW + px + q] : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+        int nn[9];
+        float td[9];
+        relocate_all(yq[q], bidir != 0, nn, td);                     // (an all-zero pixel past the image counts nothing)
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int ni = nn[i];
+            cnt[i] += (strategy == V2CE_STRATEGY_NONE) ? (ni == 1) : (ni > 0 ? ni : 0);
+            mx = ni > mx ? ni : mx;
         }
     }
     __shared__ int red[kCountThreads / 64][10];
@@ -803,6 +862,10 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     constexpr int NW = NT / 64;
     const bool atomic_order = !P.ballot_ranks && __builtin_amdgcn_readfirstlane(g_lds_order_ok) != 0;
+    // the checked fast form of the k == 0 time: Philox uniforms only, and only if this FPS passed the exhaustive check
+    const bool fast_k0 = P.fast_slot >= 0 && P.rng_mode == V2CE_RNG_PHILOX &&
+                         __builtin_amdgcn_readfirstlane(g_fastdiv[P.fast_slot].ok) != 0 &&
+                         __builtin_amdgcn_readfirstlane((int)g_fastdiv[P.fast_slot].fps_bits) == (int)__float_as_uint(P.FPS);
 
     unsigned *S = reinterpret_cast<unsigned *>(tile_smem);
     unsigned *O = S + P.capA;
@@ -869,24 +932,40 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
             }
         }
         // ---- P1: classify ------------------------------------------------------------------
-        unsigned a_tot = 0, e_tot = 0;                  // per thread: singles | units << 12, multi events
+        // Multi-event voxels come in two classes: slope k == 0 (time = (u / fps) / 9: two constant divisions) and k != 0
+        // (a square root and a division).  Their 4-draw units go to two separate regions of the unit table (k == 0
+        // units first), so that a wave of the timestamp phase executes ONE of the two code paths, not both.
+        unsigned a_tot = 0, e_tot = 0;                  // per thread: singles | k==0 units << 12;  multi events | k!=0 units << 14
         unsigned a_q[PPT], e_q[PPT];
+        bool kz_q[PPT];
+        float kk_q[PPT], bb_q[PPT];
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
             const int n = valid[q] ? ncur[q] : 0;
             const bool single = n == 1;
             const bool multi = n >= 2 && P.strategy != V2CE_STRATEGY_NONE;
+            kk_q[q] = bb_q[q] = 0.0f;
+            if (multi) {
+                if (P.kbb) {                         // pooled counts (LDATI.py:177-190): from the pre-pass
+                    const float2 kq = P.kbb[((long long)(b * 2 + pidx) * 9 + c) * P.HW + (x0 + lpx0 + q)];
+                    kk_q[q] = kq.x; bb_q[q] = kq.y;
+                } else {
+                    slope_params(nprev[q], n, nnext[q], c, P, kk_q[q], bb_q[q]);
+                }
+            }
+            kz_q[q] = kk_q[q] == 0.0f;
+            const unsigned units = multi ? (unsigned)(n + 3) >> 2 : 0u;
             a_q[q] = a_tot;
             e_q[q] = e_tot;
-            a_tot += (single ? 1u : 0u) + (multi ? ((unsigned)(n + 3) >> 2) << 12 : 0u);
-            e_tot += multi ? (unsigned)n : 0u;
+            a_tot += (single ? 1u : 0u) + (kz_q[q] ? units << 12 : 0u);
+            e_tot += (multi ? (unsigned)n : 0u) + (kz_q[q] ? 0u : units << 14);
         }
         // ---- P2: workgroup scans in pixel order (thread-major, pixel-minor).  Their first barrier
         // also separates the previous bin's reads of O (P7) from this bin's unit tables.
         unsigned a_base, e_base, A_all, E_all;
         block_excl_scan2<NW>(a_tot, e_tot, part, a_base, e_base, A_all, E_all);
         STAMP(1);
-        const unsigned Ns = A_all & 0xFFFu, Um = A_all >> 12, Nm = E_all;
+        const unsigned Ns = A_all & 0xFFFu, U0 = A_all >> 12, Nm = E_all & 0x3FFFu, Um = U0 + (E_all >> 14);
         const unsigned N = Ns + Nm;
         uint2 *MU = SL + Ns;
         // the records are ranked in NC contiguous chunks of L records, one wave each (a sparse tile
@@ -899,19 +978,12 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
         for (int q = 0; q < PPT; ++q) {
             const int n = valid[q] ? ncur[q] : 0;
             const unsigned local = (unsigned)(lpx0 + q);
-            const unsigned ab = a_base + a_q[q];
+            const unsigned ab = a_base + a_q[q], eb = e_base + e_q[q];
             if (n == 1) {
                 SL[ab & 0xFFFu] = make_uint2(__float_as_uint(dcur[q]), local);
             } else if (n >= 2 && P.strategy != V2CE_STRATEGY_NONE) {
-                float k, bb;
-                if (P.kbb) {                         // pooled counts (LDATI.py:177-190): from the pre-pass
-                    const float2 kq = P.kbb[((long long)(b * 2 + pidx) * 9 + c) * P.HW + (x0 + lpx0 + q)];
-                    k = kq.x; bb = kq.y;
-                } else {
-                    slope_params(nprev[q], n, nnext[q], c, P, k, bb);
-                }
-                PT[local] = make_float2(k, bb);
-                const unsigned u0 = ab >> 12, ev0 = e_base + e_q[q];
+                PT[local] = make_float2(kk_q[q], bb_q[q]);
+                const unsigned u0 = kz_q[q] ? ab >> 12 : U0 + (eb >> 14), ev0 = eb & 0x3FFFu;
                 const unsigned units = (unsigned)(n + 3) >> 2;
                 for (unsigned jb = 0; jb < units; ++jb) {
                     const unsigned left = (unsigned)n - 4u * jb;
@@ -956,7 +1028,7 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 if ((unsigned)s < cnt) {
-                    const unsigned key = P.ts32 ? multi_key(kb.x, kb.y, u[s], P.offt[c], (int)P.kbase[c], P)
+                    const unsigned key = P.ts32 ? multi_key(kb.x, kb.y, u[s], P.offt[c], (int)P.kbase[c], P, fast_k0)
                                                 : (unsigned)key_of(multi_ts(kb.x, kb.y, u[s], P.offt[c], P), P.kbase[c], P.NK);
                     const unsigned pos = Ns + e.y + s;
                     S[pos] = (key << 12) | (1u << kLocalBits) | local;
@@ -1077,6 +1149,9 @@ __global__ __launch_bounds__(kSparseThreads) void ldati_tile_sparse_kernel(Ldati
     const int pidx = t < P.tpp ? 1 : 0;
     const int x0 = (t < P.tpp ? t : t - P.tpp) * kTilePix;
     const int tid = threadIdx.x;
+    const bool fast_k0 = P.fast_slot >= 0 && P.rng_mode == V2CE_RNG_PHILOX &&
+                         __builtin_amdgcn_readfirstlane(g_fastdiv[P.fast_slot].ok) != 0 &&
+                         __builtin_amdgcn_readfirstlane((int)g_fastdiv[P.fast_slot].fps_bits) == (int)__float_as_uint(P.FPS);
 
     unsigned *S = reinterpret_cast<unsigned *>(tile_smem);          // [kSparseCap] records (unordered, later final)
     unsigned *O = S + kSparseCap;                                   // [kSparseCap] records placed by cell
@@ -1213,7 +1288,7 @@ __global__ __launch_bounds__(kSparseThreads) void ldati_tile_sparse_kernel(Ldati
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
                     if ((unsigned)s < cnt) {
-                        const unsigned key = P.ts32 ? multi_key(mk[j], mb[j], u[s], offt, (int)kb64, P)
+                        const unsigned key = P.ts32 ? multi_key(mk[j], mb[j], u[s], offt, (int)kb64, P, fast_k0)
                                                     : (unsigned)key_of(multi_ts(mk[j], mb[j], u[s], offt, P), kb64, P.NK);
                         put(i0 + 4u * jb + s, c, key, 1u, local);
                     }
@@ -1317,36 +1392,49 @@ __global__ __launch_bounds__(512) void ldati_bucket_scan_kernel(LdatiParams P) {
     if (t < P.NB) pre[t] = ex;
     if (t == 0) pre[P.NB] = total;
     __syncthreads();
-    if (t == 0) {
-        // greedy groups: from `start`, the farthest end with <= cap2 records and <= span buckets (binary
-        // search on the prefix); a bucket beyond cap2 on its own goes to the big-bucket list
-        unsigned *grp = P.groups + (long long)seg * P.NB;
-        unsigned ng = 0;
-        int i = 0;
-        while (i < P.NB) {
-            const unsigned base = pre[i];
-            if (base == total) break;                                  // nothing but empty buckets left
-            if (pre[i + 1] == base) {                                  // skip a run of empty buckets
-                int lo = i + 1, hi = P.NB;                             // first j > i with pre[j] > base
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (pre[mid] > base) hi = mid; else lo = mid + 1;
-                }
-                i = lo - 1;
-                continue;
+    // greedy groups: from bucket i, the farthest end with <= cap2 records and <= span buckets; a bucket beyond cap2 on its
+    // own goes to the big-bucket list; runs of empty buckets are skipped.  The step from EVERY bucket is computed in
+    // parallel (binary searches on the prefix: one thread per bucket), then one thread follows the chain from bucket 0
+    // -- one LDS read per group instead of ~9 dependent ones (the serial version was 60 of this kernel's 75 us).
+    __shared__ unsigned step_to[kMaxNB + 1];           // next bucket | kind << 16  (kind 0 skip, 1 group, 2 big, 3 stop)
+    if (t < P.NB) {
+        const int i = t;
+        const unsigned base = pre[i];
+        unsigned st;
+        if (base == total) {
+            st = (3u << 16);                                           // nothing but empty buckets left
+        } else if (pre[i + 1] == base) {                               // a run of empty buckets: to the first non-empty one
+            int lo = i + 1, hi = P.NB;                                 // first j > i with pre[j] > base
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (pre[mid] > base) hi = mid; else lo = mid + 1;
             }
-            if (pre[i + 1] - base > (unsigned)P.cap2) {
-                P.big_list[atomicAdd(P.nbig, 1u)] = ((unsigned)seg << 16) | (unsigned)i;
-                ++i;
-                continue;
-            }
+            st = (unsigned)(lo - 1);
+        } else if (pre[i + 1] - base > (unsigned)P.cap2) {
+            st = (unsigned)(i + 1) | (2u << 16);
+        } else {
             int lo = i + 1, hi = i + P.span < P.NB ? i + P.span : P.NB;   // largest e in [lo, hi] with pre[e] - base <= cap2
             while (lo < hi) {
                 const int mid = (lo + hi + 1) >> 1;
                 if (pre[mid] - base <= (unsigned)P.cap2) lo = mid; else hi = mid - 1;
             }
-            grp[ng++] = (unsigned)i | ((unsigned)lo << 16);
-            i = lo;
+            st = (unsigned)lo | (1u << 16);
+        }
+        step_to[i] = st;
+    }
+    if (t == 0) step_to[P.NB] = 3u << 16;
+    __syncthreads();
+    if (t == 0) {
+        unsigned *grp = P.groups + (long long)seg * P.NB;
+        unsigned ng = 0;
+        int i = 0;
+        while (i < P.NB) {
+            const unsigned st = step_to[i];
+            const unsigned kind = st >> 16, nx = st & 0xFFFFu;
+            if (kind == 3u) break;
+            if (kind == 1u) grp[ng++] = (unsigned)i | (nx << 16);
+            else if (kind == 2u) P.big_list[atomicAdd(P.nbig, 1u)] = ((unsigned)seg << 16) | (unsigned)i;
+            i = (int)nx;
         }
         P.ngroups[seg] = ng;
         P.seg_flag[seg] = 0;
@@ -1363,7 +1451,8 @@ extern __shared__ __attribute__((aligned(16))) unsigned char sort_smem[];
 template <bool PACKED, int K>
 __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(LdatiParams P) {
     const int seg = blockIdx.y;
-    if (blockIdx.x >= P.ngroups[seg]) return;            // uniform per workgroup (flagged segments have no groups)
+    if (blockIdx.x >= P.ngroups[seg]) return;            // uniform per workgroup (flagged segments have no groups; empty
+                                                         // workgroups cost nothing measurable: a compact group list changed nothing)
     const unsigned grp = P.groups[(long long)seg * P.NB + blockIdx.x];
     const int bk0 = (int)(grp & 0xFFFFu), bk1 = (int)(grp >> 16);           // coarse buckets [bk0, bk1)
     const unsigned *bofs = P.bofs + (long long)seg * (P.NB + 1);
@@ -1478,14 +1567,18 @@ __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(Ldat
         }
     }
     STAMP(1);
-    // S2: widen to (fine | category | global pixel); per-wave histograms of (fine, category)
+    // S2: widen to (fine | category | global pixel); per-wave histograms of (fine, category).  A wave's range is whole
+    // 64-record batches plus at most one partial one: the full batches run without per-lane guards (a scalar branch per
+    // batch instead of an exec-mask sequence per record; the kernel is bound by instruction issue, not by memory)
+    const int nfull = __builtin_amdgcn_readfirstlane((int)((hi > lo ? hi - lo : 0u) >> 6));
+    const int ntail = __builtin_amdgcn_readfirstlane((int)((hi > lo ? hi - lo : 0u) & 63u));
+    unsigned *myhist = hist + wid * bins;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const unsigned i = lo + 64u * k + lane;
-        if (i < hi) {
+        if (k < nfull || (k == nfull && lane < ntail)) {     // first test: wave-uniform
             const unsigned r = rec[k];
             rec[k] = (((r >> 12) - key0) << (2 + P.PB)) | (tinfo[k] + (((r >> kLocalBits) & 1u) << P.PB) + (r & (kTilePix - 1)));
-            atomicAdd(&hist[wid * bins + (rec[k] >> P.PB)], 1u);
+            atomicAdd(&myhist[rec[k] >> P.PB], 1u);
         }
     }
     STAMP(2);
@@ -1513,15 +1606,28 @@ __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(Ldat
     __syncthreads();
     STAMP(4);
     // S4: stable ranks
+    if (atomic_order) {                                  // the rank IS the value the LDS atomic returns (g_lds_order_ok)
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        if (lo + 64u * k < hi) {                         // wave-uniform
-            const unsigned i = lo + 64u * k + lane;
-            const bool has = i < hi;
-            const unsigned r = rec[k];
-            const unsigned bin = r >> P.PB;
-            const unsigned pos = take_slot(atomic_order, has, bin, nb2, &hist[wid * bins + bin]);
-            if (has) Out[pos] = r;
+        for (int k = 0; k < K; ++k) {
+            if (k < nfull) {                             // wave-uniform
+                const unsigned r = rec[k];
+                Out[atomicAdd(&myhist[r >> P.PB], 1u)] = r;
+            } else if (k == nfull && lane < ntail) {
+                const unsigned r = rec[k];
+                Out[atomicAdd(&myhist[r >> P.PB], 1u)] = r;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (lo + 64u * k < hi) {                     // wave-uniform
+                const unsigned i = lo + 64u * k + lane;
+                const bool has = i < hi;
+                const unsigned r = rec[k];
+                const unsigned bin = r >> P.PB;
+                const unsigned pos = take_slots(has, bin, nb2, &myhist[bin]);
+                if (has) Out[pos] = r;
+            }
         }
     }
     STAMP(5);
@@ -1535,11 +1641,12 @@ __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(Ldat
     const unsigned W = (unsigned)P.W;
     const float rcpW = 1.0f / (float)W;
     const bool small = P.HW < (1 << 24);                 // pixel indices exact in f32
+    const bool tiny = P.HW < (1 << 22) - 1;              // ... and far enough from 2^22 for div_tiny
     if (!PACKED) {
         for (unsigned i = tid; i < N; i += kSortThreads) {
             const unsigned r = Out[i];
             const unsigned px = r & pmask, cat = (r >> P.PB) & 3u, fine = r >> (P.PB + 2);
-            const unsigned yy = small ? div_small(px, W, rcpW) : px / W;
+            const unsigned yy = tiny ? div_tiny(px, rcpW) : small ? div_small(px, W, rcpW) : px / W;
             P.ts[g0 + i] = tbase + fine;
             P.x[g0 + i] = (short)(px - yy * W);
             P.y[g0 + i] = (short)yy;
@@ -1554,16 +1661,18 @@ __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(Ldat
     const long long gN = g0 + N;
     const long long G0 = (g0 >> 2) & ~3ll, G1 = (gN + 3) >> 2;         // G0 % 4 == 0: 52*G0 % 16 == 0
     const long long B0 = 13 * g0, B1 = 13 * gN;                         // this bucket's bytes
+    const int i_base = (int)(4 * G0 - g0);                             // record index of the first slot (in [-15, 0])
     for (long long Ga = G0; Ga < G1; Ga += kSortThreads) {
         const long long G = Ga + tid;
         if (G < G1) {
             unsigned A[4], Bh[4], C[4], D[4];
+            const int i0 = i_base + 4 * (int)(G - G0);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const long long i = 4 * G + q - g0;
-                const unsigned r = (i >= 0 && i < (long long)N) ? Out[i] : 0u;
+                const int i = i0 + q;
+                const unsigned r = (i >= 0 && i < (int)N) ? Out[i] : 0u;
                 const unsigned px = r & pmask, cat = (r >> P.PB) & 3u, fine = r >> (P.PB + 2);
-                const unsigned yy = small ? div_small(px, W, rcpW) : px / W;
+                const unsigned yy = tiny ? div_tiny(px, rcpW) : small ? div_small(px, W, rcpW) : px / W;
                 const long long tq = tbase + fine;
                 A[q] = (unsigned)tq;
                 Bh[q] = (unsigned)((unsigned long long)tq >> 32);
@@ -1588,14 +1697,17 @@ __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(Ldat
         const unsigned nG = left < kSortThreads ? (unsigned)left : (unsigned)kSortThreads;
         const unsigned nPieces = (nG * 52u + 15u) >> 4;
         const long long img = 52 * Ga;                                   // global byte address of the image
-        for (unsigned q = tid; q < nPieces; q += kSortThreads) {
-            const long long lo_b = img + 16ll * q;
-            if (lo_b >= B0 && lo_b + 16 <= B1) {
-                *reinterpret_cast<uint4 *>(P.packed + lo_b) = reinterpret_cast<const uint4 *>(stage)[q];
+        // pieces [qa, qb) lie wholly inside this bucket's bytes (all but the first and the last of the bucket)
+        const int rel0 = (int)(B0 - img), rel1 = (int)(B1 - img);       // small: |rel0| < 256, rel1 <= 13 * cap2 + 256
+        const int qa = rel0 > 0 ? (rel0 + 15) >> 4 : 0, qb = rel1 >> 4;
+        unsigned char *dst = P.packed + img;
+        for (int q = tid; q < (int)nPieces; q += kSortThreads) {
+            if (q >= qa && q < qb) {
+                reinterpret_cast<uint4 *>(dst)[q] = reinterpret_cast<const uint4 *>(stage)[q];
             } else {
-                const unsigned char *sb = reinterpret_cast<const unsigned char *>(stage) + 16u * q;
+                const unsigned char *sb = reinterpret_cast<const unsigned char *>(stage) + 16 * q;
                 for (int k = 0; k < 16; ++k)
-                    if (lo_b + k >= B0 && lo_b + k < B1) P.packed[lo_b + k] = sb[k];
+                    if (16 * q + k >= rel0 && 16 * q + k < rel1) dst[16 * q + k] = sb[k];
             }
         }
         __syncthreads();
@@ -2080,6 +2192,31 @@ extern "C" int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps
     P.p = reinterpret_cast<signed char *>(p);
     P.packed = packed;
     P.sweep_ok = h.sweep_ok ? 1 : 0;
+    P.RFPS = (float)(1.0 / (double)h.FPS); P.R9 = (float)(1.0 / 9.0);
+    P.fast_slot = -1;
+    if (rng_mode == V2CE_RNG_PHILOX && o.strategy == V2CE_STRATEGY_SLOPE && !getenv("V2CE_LDATI_NO_FASTDIV")) {
+        // once per device and FPS: the exhaustive check of k0_time_fast against the IEEE divisions (see g_fastdiv)
+        static std::mutex mu;
+        static unsigned seen[64][8];
+        static int n_seen[64];
+        int dev = 0;
+        V2CE_HIP_CHECK(hipGetDevice(&dev));
+        unsigned bits;
+        memcpy(&bits, &h.FPS, 4);
+        std::lock_guard<std::mutex> g(mu);
+        if (dev >= 0 && dev < 64) {
+            int slot = -1;
+            for (int i = 0; i < n_seen[dev]; ++i)
+                if (seen[dev][i] == bits) slot = i;
+            if (slot < 0 && n_seen[dev] < 8) {
+                slot = n_seen[dev]++;
+                seen[dev][slot] = bits;
+                hipLaunchKernelGGL(ldati_fastdiv_check_kernel, dim3(65536), dim3(256), 0, as_stream(stream), h.FPS, P.RFPS, P.R9, slot);
+                hipLaunchKernelGGL(ldati_fastdiv_commit_kernel, dim3(1), dim3(1), 0, as_stream(stream), h.FPS, slot);
+            }
+            P.fast_slot = slot;
+        }
+    }
     { const char *e = getenv("V2CE_LDATI_NO_ATOMIC_ORDER"); P.ballot_ranks = (e && e[0] == '1') ? 1 : 0; }
     hipStream_t st = as_stream(stream);
     if (h.sweep_ok)
@@ -2166,6 +2303,10 @@ extern "C" int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps
         P.temp = reinterpret_cast<unsigned *>(P.status + 4);
         P.roff = reinterpret_cast<unsigned short *>(P.temp + (size_t)total_events);
         V2CE_HIP_CHECK(hipMemsetAsync(P.status, 0, 4 * sizeof(int), st));
+        // (Tried in round 3 and removed: walking the frames in groups so that the HBM-bound bucket sort of group g runs on a
+        // low-priority side stream under the VALU-bound tile pass of group g + 1.  24 stress frame-pairs: 1 group 1.74 ms,
+        // 2 groups 1.86, 4 groups 1.83, 8 groups 2.21 -- the tile pass needs whole CUs (1024 threads, ~100 KB of LDS), the sort
+        // workgroups that slip in between delay its rounds, and each group adds a partial last round.)
         if (P.sparse_cap) {
             V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ldati_tile_sparse_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSparseLds));
