@@ -272,11 +272,28 @@ int v2ce_conv3d_fwd_sc(const v2ce_conv3d_desc *desc, const float *x0, const floa
                        const void *sc_w, const float *sc_scale, const float *sc_shift, float *sc_y,
                        v2ce_stream_t stream);
 
+/* v2ce_conv3d_fwd with a 1x1x1 convolution FOLDED into its K loop: y = act(scale[co] * (conv3x3x3(x) + conv1x1x1'(tx))[co] +
+ * shift[co]) in ONE accumulator -- a whole residual block tail, scripts/submodules.py:249-264
+ * relu(bn2(conv2(t)) + bn_d(conv_d(x))), with the caller folding the two affine maps: tail weights Wd' = Wd * sd[co] / s2[co],
+ * scale = s2, shift = shift2 + shift_d.  No shortcut tensor is written or read, the shortcut's launch disappears.
+ * tail_desc describes the 1x1x1 conv (ksize 1, stride 1 or 2, its own virtual input tx0 (++ tx1) with index maps, layout
+ * C16; B, T, Cout, Hout, Wout equal to desc's); tail_w = v2ce_pack_weights_f16x2 of the [Cout][Cin_t][1] weights; the
+ * tail inputs carry their own range slots (tx0_absmax / tx1_absmax, same batch stride as desc's).  The accumulators are
+ * rescaled by an exact power of two between the two parts (the parts have different pre-scales); the range-guard value
+ * is the SUM of the two parts' bounds.  Requires precision F16X2, ksize 3, stride 1, Cout >= 64. */
+int v2ce_conv3d_fwd_tail(const v2ce_conv3d_desc *desc, const float *x0, const float *x1,
+                         const int32_t *hmap, const int32_t *wmap, const float *w_packed,
+                         const float *scale, const float *shift, float *y,
+                         const float *x0_absmax, const float *x1_absmax, float *y_absmax,
+                         const v2ce_conv3d_desc *tail_desc, const float *tx0, const float *tx1,
+                         const int32_t *thmap, const int32_t *twmap, const void *tail_w,
+                         const float *tx0_absmax, const float *tx1_absmax, v2ce_stream_t stream);
+
 /* Name of the kernel instantiation v2ce_conv3d_fwd would launch for desc ("conv3d_kernel<KS,S,
  * CO_FR,PO_FR,CK,EPT>", as it appears demangled in rocprofv3 traces); mapped != 0 means hmap/wmap
  * would be non-NULL.  Launches nothing.  Used by bench.py to attribute event timings. */
 int v2ce_conv3d_variant(const v2ce_conv3d_desc *desc, int mapped, char *name, size_t cap);
-/* Same for the fused entry points: fuse = 1 (v2ce_conv3d_fwd_pred), 2 (v2ce_conv3d_fwd_sc), 0 (plain); + 4 when the
+/* Same for the fused entry points: fuse = 1 (v2ce_conv3d_fwd_pred), 2 (v2ce_conv3d_fwd_sc), 3 (v2ce_conv3d_fwd_tail), 0 (plain); + 4 when the
  * launch has a residual (the kernels are instantiated per case: the last template argument). */
 int v2ce_conv3d_variant_fused(const v2ce_conv3d_desc *desc, int mapped, int fuse, char *name, size_t cap);
 

@@ -90,6 +90,15 @@ struct ConvParams {
     const _Float16 *sc_w;         // v2ce_pack_weights_f16x2 buffer of the [Cout][Cin][1] shortcut weights
     const float *sc_scale, *sc_shift;
     float *sc_y;                  // [B][T][Cout][Hout][Wout]
+    // folded 1x1x1 tail (v2ce_conv3d_fwd_tail, FUSE 3): tCG more 16-channel K chunks behind the 3x3x3 conv's own, one
+    // tap each, gathered at the OUTPUT positions (stride tS) from a second virtual input tx0 (++ tx1); weights = sc_w
+    const float *tx0, *tx1;
+    const int *thmap, *twmap;
+    int tC0, tH0, tW0p, tC1, tHin, tWin, tWinp, tS, tCG;
+    int tCHS;                     // pieces per plane of the LDS buffers of a tail launch (>= the halo plane, >= tTCH * tNPP)
+    int tNPP, tTCH, tSC0, tSC;    // a tail SUPER-chunk = up to tTCH channel groups of ONE source staged per barrier, group g at
+                                  // pieces [g * tNPP, + n_pos) (tNPP = n_pos rounded up to 64); tSC0 / tSC super-chunks of tx0 / in all
+    const float *tx0_absmax, *tx1_absmax;
 #ifdef V2CE_STAMP
     unsigned long long *stamps;   // diagnostic build only: [block][role][8] s_memtime stamps
 #endif
@@ -449,6 +458,37 @@ __device__ __forceinline__ void halo_offsets(const ConvParams &P, int tin0, int 
     }
 }
 
+// the same for the folded 1x1x1 tail: element r = output position r of the box (TT x TH x TW, row-major), read at
+// (t, h * tS, w * tS) of the tail's virtual input (tx0 through thmap / twmap, or tx1); channels-last-16 sources
+template <int EPT>
+__device__ __forceinline__ void tail_offsets(const ConvParams &P, int t0, int h0, int w0, bool src1, int tid,
+                                             unsigned (&goff)[EPT], unsigned &gsel) {
+    const int Cs = src1 ? P.tC1 : P.tC0;
+    const int Hs = src1 ? P.tHin : P.tH0, Ws = src1 ? P.tWinp : P.tW0p;
+    const bool mapped = !src1 && P.thmap != nullptr;
+    gsel = 0;                                              // 4 bits per element slot: its channel group inside the super-chunk
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int e = tid + 256 * i;
+        const int g = e / P.tNPP, r = e - g * P.tNPP;
+        unsigned off = kOOB;
+        if (g < P.tTCH && r < P.n_pos) {
+            const int tt = r / (P.TH * P.TW);
+            const int rem = r - tt * (P.TH * P.TW);
+            const int th = rem / P.TW;
+            const int tw = rem - th * P.TW;
+            const int t = t0 + tt, h = (h0 + th) * P.tS, w = (w0 + tw) * P.tS;
+            if (t < P.T && h < P.tHin && w < P.tWin) {
+                const int hs = mapped ? P.thmap[h] : h;
+                const int ws = mapped ? P.twmap[w] : w;
+                off = 4u * (unsigned)((t * Cs) * (Hs * Ws)) + 64u * (unsigned)(hs * Ws + ws) + (unsigned)g * (unsigned)(Hs * Ws * 64);
+            }
+        }
+        goff[i] = off;
+        gsel |= (unsigned)(g < 15 ? g : 15) << (4 * i);
+    }
+}
+
 template <int EPT, int WPT>
 struct DmaState {
     unsigned goff[EPT];
@@ -700,7 +740,9 @@ __global__ __launch_bounds__(256, MW) void conv3d_kernel(ConvParams P) {
 // issue and its branches never sit in the MFMA waves' instruction stream.
 // LDS: 2 x 64 B of pieces per halo element (up to 1280 elements: 512-position boxes).
 // ---------------------------------------------------------------------------------------------
-// FUSE: 0 = plain, 1 = fused 1x1x1 head (pred_epilogue), 2 = fused 1x1x1 shortcut (second accumulator set)
+// FUSE: 0 = plain, 1 = fused 1x1x1 head (pred_epilogue), 2 = fused 1x1x1 shortcut (second accumulator set),
+//       3 = folded 1x1x1 tail: a residual block's shortcut as P.tCG more K chunks of the SAME accumulators (conv2 of the
+//           block: relu(s2 (W2 * t + Wd' * x) + shift), Wd' = Wd sd / s2 folded on the host; no shortcut tensor at all)
 // RES: residual known at compile time (0 = none, 1 = present) or checked at run time (2), see conv_epilogue
 template <int KS, int S, int WCO, int CO_FR, int PO_FR, int NA, int FUSE = 0, int RES = 2>
 __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
@@ -708,7 +750,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
     // KS = 1: the "halo box" is the output box itself (positions gathered with stride S), one tap
     constexpr int K3 = KS * KS * KS, CK = 16, EPT = 5, PAD = KS / 2, GS = KS == 1 ? S : 1;
     constexpr int CO_TILE = WCO * CO_FR * 32;
-    const int chs = (P.plane + 63) & ~63;
+    const int chs = FUSE == 3 ? P.tCHS : (P.plane + 63) & ~63;
     f16x8 *pieces = reinterpret_cast<f16x8 *>(conv_smem);                      // [2][4][chs] x 16 B
 
     const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
@@ -755,6 +797,16 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
         return am;
     };
     auto scale_of = [&](int b) -> float { return P.x0_absmax ? pow2_prescale(amax_of(b)) : kActScale; };
+    constexpr bool TAIL = FUSE == 3;
+    static_assert(!TAIL || KS == 3, "the folded tail rides behind a 3x3x3 conv");
+    const int CGT = TAIL ? CG + P.tSC : CG;                  // barriers (chunks / tail super-chunks) per tile
+    auto tamax_of = [&](int b) -> float {                    // the same for the tail's input
+        if (!P.tx0_absmax) return 4094.0f;
+        float am = P.tx0_absmax[b * P.amax_bs];
+        if (P.tx1_absmax) am = fmaxf(am, P.tx1_absmax[b * P.amax_bs]);
+        return am;
+    };
+    auto tscale_of = [&](int b) -> float { return P.tx0_absmax ? pow2_prescale(tamax_of(b)) : kActScale; };
     // Range guard (y_absmax[1]): a bound on what the one-scale-per-tensor split can cost this launch's
     // outputs.  An operand whose scaled magnitude is below 2^-3 has an fp16-SUBNORMAL lo half: hi + lo
     // then misses it by up to 2^-25 (scaled), instead of by 2^-22 relative.  Worst case over a K-term
@@ -779,6 +831,15 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
             const float am = amax_of(b), xs = scale_of(b);
             float E = sm * (float)(P.Cin * K3) * 0x1p-25f * (tail[0] / xs + am / tail[1]);
             if (FUSE == 2) E = fmaxf(E, smd * (float)P.Cin * 0x1p-25f * (taild[0] / xs + am / taild[1]));
+            if (TAIL) {                                     // both parts land in the same output: the bounds add
+                const float *tl = reinterpret_cast<const float *>(P.sc_w + 2 * (long long)P.tCG * P.Cout * 16);
+                const float tam = tamax_of(b), txs = tscale_of(b);
+                E += sm * (float)(P.tCG * 16) * 0x1p-25f * (tl[0] / txs + tam / tl[1]);
+                // the accumulators are rescaled by (txs tl[1]) / (xs tail[1]) between the two parts: a power of two, exact
+                // unless it is so extreme that they leave the f32 range -- then report "unbounded"
+                const float rho = (txs * tl[1]) / (xs * tail[1]);
+                if (!(rho > 0x1p-40f && rho < 0x1p40f)) E = __builtin_inff();
+            }
             P.guard[b * P.amax_bs] = E;
         }
     }
@@ -798,14 +859,36 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
         // cursor (tile, chunk) therefore runs two chunks ahead of the conversion, across tiles.
         const int ptid = tid - 256;
         float x_scale = scale_of(T.b);                      // pre-scale of the tile being converted
+        float t_scale = TAIL ? tscale_of(T.b) : 1.0f;       // ... and of its tail chunks
         unsigned goff[EPT];
+        unsigned gsel = 0;                                   // tail: channel group of every element slot (tail_offsets)
         float R0[CK][EPT], R1[CK][EPT];
         __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x0), 0, 0, 0x00020000);
         int cur_src = -1, src_cstride4 = 0, src_cbase = 0;
-        auto load_chunk = [&](const TileId &L, int ci0, float (&R)[CK][EPT]) {
-            const int want_src = ci0 < P.C0 ? 0 : 1;
-            if (want_src != cur_src) {   // uniform; at most twice per tile
+        auto load_chunk = [&](const TileId &L, int cidx, float (&R)[CK][EPT]) {
+            const bool tail = TAIL && cidx >= CG;            // uniform
+            // tail super-chunk k = cidx - CG: tx0's groups first (tSC0 super-chunks of up to tTCH groups), then tx1's
+            const int tk = cidx - CG;
+            const int tg0 = tail ? (tk < P.tSC0 ? tk : tk - P.tSC0) * P.tTCH : 0;           // first group inside its source
+            const int tng = tail ? min(P.tTCH, (tk < P.tSC0 ? P.tC0 : P.tC1) / 16 - tg0) : 0;   // groups of this super-chunk
+            const int ci0 = tail ? tg0 * CK + (tk < P.tSC0 ? 0 : P.tC0) : cidx * CK;
+            const int want_src = tail ? (tk < P.tSC0 ? 2 : 3) : (ci0 < P.C0 ? 0 : 1);
+            if (want_src != cur_src) {   // uniform; at most four times per tile
                 cur_src = want_src;
+                if (tail) {
+                    tail_offsets<EPT>(P, L.t0, L.h0, L.w0, want_src == 3, ptid, goff, gsel);
+                    if (want_src == 2) {
+                        const long long seq = (long long)P.T * P.tC0 * (P.tH0 * P.tW0p);
+                        rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.tx0 + L.b * seq), 0, (int)(seq * 4), 0x00020000);
+                        src_cstride4 = P.tH0 * P.tW0p * 4;
+                        src_cbase = 0;
+                    } else {
+                        const long long seq = (long long)P.T * P.tC1 * (P.tHin * P.tWinp);
+                        rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.tx1 + L.b * seq), 0, (int)(seq * 4), 0x00020000);
+                        src_cstride4 = P.tHin * P.tWinp * 4;
+                        src_cbase = P.tC0;
+                    }
+                } else {
                 halo_offsets<EPT, true>(P, L.t0 - PAD, L.h0 * S - PAD, L.w0 * S - PAD, want_src == 1, ptid, goff, GS);
                 if (want_src == 0) {
                     const long long seq = (long long)P.T * P.C0 * (P.H0 * P.W0p);
@@ -818,17 +901,21 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
                     src_cstride4 = P.Hin * P.Winp * 4;
                     src_cbase = P.C0;
                 }
+                }
             }
+            const int lim = tail ? tng * P.tNPP : P.plane;            // element slots of this chunk
 #pragma unroll
             for (int i = 0; i < EPT; ++i) {
-                if ((wave - 4) * 64 + 256 * i < P.plane) {            // wave-uniform
+                if ((wave - 4) * 64 + 256 * i < lim) {                // wave-uniform
+                    // (tail: the slot's group must exist in this super-chunk -- the last one of a source may be short)
+                    const unsigned vo = (tail && (int)((gsel >> (4 * i)) & 15u) >= tng) ? kOOB : goff[i];
                     // the chunk is one 16-channel group: the element's 64 bytes in four 16-byte loads (one cache
                     // line per element; the planar layout needs 16 loads from 16 lines)
                     typedef float f32x4g __attribute__((ext_vector_type(4)));
 #pragma unroll
                     for (int k4 = 0; k4 < CK / 4; ++k4) {
                         const f32x4g v = __builtin_bit_cast(f32x4g, __builtin_amdgcn_raw_buffer_load_b128(
-                            rs_in, goff[i], ((ci0 - src_cbase) / 16) * (src_cstride4 * 16) + 16 * k4, 0));
+                            rs_in, vo, ((ci0 - src_cbase) / 16) * (src_cstride4 * 16) + 16 * k4, 0));
                         R[4 * k4][i] = v[0]; R[4 * k4 + 1][i] = v[1]; R[4 * k4 + 2][i] = v[2]; R[4 * k4 + 3][i] = v[3];
                     }
                 }
@@ -840,20 +927,24 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
         bool moreL = true;
         auto load_next = [&](float (&R)[CK][EPT]) {
             if (!moreL) return;
-            load_chunk(TL, cgL * CK, R);
-            if (++cgL == CG) {
+            load_chunk(TL, cgL, R);
+            if (++cgL == CGT) {
                 cgL = 0;
                 vbL += (int)gridDim.x;
                 moreL = next_tile(vbL, TL);
                 cur_src = -1;
             }
         };
+        int cgC = 0;                                         // conversion cursor: chunk inside the tile
         auto convert = [&](const float (&R)[CK][EPT]) {
             f16x8 *qb = pieces + (gc & 1) * 4 * chs;
+            const bool tail = TAIL && cgC >= CG;             // uniform
+            const float c_scale = tail ? t_scale : x_scale;
+            const int lim = tail ? P.tTCH * P.tNPP : P.plane;       // (slots of absent groups hold zeros: harmless)
 #pragma unroll
             for (int i = 0; i < EPT; ++i) {
                 const int r = ptid + 256 * i;
-                if ((wave - 4) * 64 + 256 * i < P.plane) {            // wave-uniform (lanes past the plane write padding)
+                if ((wave - 4) * 64 + 256 * i < lim) {                // wave-uniform (lanes past the box write padding)
 #pragma unroll
                     for (int hg = 0; hg < 2; ++hg) {
                         // hi = f16(x s), lo = f16(x s - hi): four mixed-precision FMAs per pair of values (x s is exact,
@@ -869,7 +960,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
                                 "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
                                 "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
                                 "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-                                : "=&v"(h), "=&v"(l) : "v"(xa), "v"(xb), "v"(x_scale));
+                                : "=&v"(h), "=&v"(l) : "v"(xa), "v"(xb), "v"(c_scale));
                             ph[c2] = h;
                             pl[c2] = l;
                         }
@@ -879,16 +970,18 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
                 }
             }
         };
-        // conversion cursor: counts the chunks of this workgroup's tiles
-        int cgC = 0;
+        // the conversion cursor counts the chunks of this workgroup's tiles
         bool moreC = true;
         auto advance = [&]() {
             ++gc;
-            if (++cgC == CG) {
+            if (++cgC == CGT) {
                 cgC = 0;
                 vb += (int)gridDim.x;
                 moreC = next_tile(vb, T);
-                if (moreC) x_scale = scale_of(T.b);
+                if (moreC) {
+                    x_scale = scale_of(T.b);
+                    if (TAIL) t_scale = tscale_of(T.b);
+                }
             }
         };
         STAMP(1, 0);
@@ -1067,6 +1160,68 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
                 }
             });
         }
+        float out_inv_scale = inv_scale;
+        if constexpr (TAIL) {
+            // ---- folded 1x1x1 tail: P.tCG more chunks into the same accumulators.  They arrive at another power-of-two
+            // scale (the tail input's and the tail weights' pre-scales): the accumulators are rescaled first (exact).
+            const long long tplane = (long long)P.tCG * P.Cout * 16;              // halves per plane of the tail weights
+            const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<_Float16 *>(P.sc_w), 0, (int)(4 * tplane), 0x00020000);
+            const float t_scale = tscale_of(T.b);
+            const float wt_scale = reinterpret_cast<const float *>(P.sc_w + 2 * tplane)[1];
+            const float rho = (t_scale * wt_scale) / (x_scale * w_scale);
+#pragma unroll
+            for (int q = 0; q < CO_FR; ++q)
+#pragma unroll
+                for (int f = 0; f < PO_FR; ++f)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[q][f][r] *= rho;
+            out_inv_scale = 1.0f / (t_scale * wt_scale);
+            int bpt[PO_FR];                                  // B fragments of a tail chunk: indexed by output position
+#pragma unroll
+            for (int f = 0; f < PO_FR; ++f) {
+                const int m = (wpo * PO_FR + f) * 32 + l32;
+                bpt[f] = half * chs + (m < P.n_pos ? m : 0);
+            }
+            f16x8 ath[2][CO_FR], atl[2][CO_FR];              // A fragments, double-buffered over the channel groups
+#pragma unroll
+            for (int q = 0; q < CO_FR; ++q) {
+                ath[0][q] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_t, wlane[q], 0, 0));
+                atl[0][q] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_t, wlane[q], (int)(2 * tplane), 0));
+            }
+            int cgt = 0;                                     // channel group of the tail (weights order: tx0's, then tx1's)
+            for (int k = 0; k < P.tSC; ++k, ++gc) {          // super-chunks: up to tTCH groups of one source per barrier
+                const f16x8 *qb = pieces + (gc & 1) * 4 * chs;
+                const int g0 = (k < P.tSC0 ? k : k - P.tSC0) * P.tTCH;
+                const int ng = min(P.tTCH, (k < P.tSC0 ? P.tC0 : P.tC1) / 16 - g0);
+                __syncthreads();                               // barrier gc: pieces[gc & 1] ready
+                for (int g = 0; g < ng; ++g, ++cgt) {
+                    if (cgt) {
+#pragma unroll
+                        for (int q = 0; q < CO_FR; ++q) { ath[0][q] = ath[1][q]; atl[0][q] = atl[1][q]; }
+                    }
+                    const int wn = (cgt + 1 < P.tCG ? cgt + 1 : cgt) * cg_stride;
+#pragma unroll
+                    for (int q = 0; q < CO_FR; ++q) {
+                        ath[1][q] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_t, wlane[q], wn, 0));
+                        atl[1][q] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_t, wlane[q], wn + (int)(2 * tplane), 0));
+                    }
+#pragma unroll
+                    for (int f = 0; f < PO_FR; ++f) {
+                        bh[f] = qb[bpt[f] + g * P.tNPP];
+                        bl[f] = qb[bpt[f] + g * P.tNPP + 2 * chs];
+                    }
+#pragma unroll
+                    for (int f = 0; f < PO_FR; ++f)
+#pragma unroll
+                        for (int q = 0; q < CO_FR; ++q) {
+                            acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ath[0][q], bh[f], acc[q][f], 0, 0, 0);
+                            acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ath[0][q], bl[f], acc[q][f], 0, 0, 0);
+                            acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(atl[0][q], bh[f], acc[q][f], 0, 0, 0);
+                        }
+                }
+            }
+        }
         if (gc == CG) STAMP(0, 3);
         int poff[PO_FR];                                    // output offsets (not kept live across the main loop)
 #pragma unroll
@@ -1101,7 +1256,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
             conv_epilogue<CO_FR, PO_FR, true, true, RES, true>(P, acc, poff, co0, half, T.b, inv_scale);
             pred_epilogue<PO_FR>(P, acc, wpo * PO_FR * 32, lane, T.b, T.t0, T.h0, T.w0);
         } else {
-            conv_epilogue<CO_FR, PO_FR, true, false, RES, true>(P, acc, poff, co0, half, T.b, inv_scale);   // Cout need not fill the last channel tile
+            conv_epilogue<CO_FR, PO_FR, true, false, RES, true>(P, acc, poff, co0, half, T.b, out_inv_scale);   // Cout need not fill the last channel tile
         }
 #ifdef V2CE_ABLATE_EPI
         if (P.ablate != 1)
@@ -1468,7 +1623,17 @@ int launch_f16x2_ws(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream)
     P.xcd_remap = 1;
     P.per_xcd = (P.n_spatial + 7) / 8;
     const long long blocks = (long long)8 * P.per_xcd * P.n_co_tiles;
-    const int chs = (P.plane + 63) & ~63;
+    int chs = (P.plane + 63) & ~63;
+    if (FUSE == 3) {
+        // tail super-chunks: as many channel groups per barrier as the producers' 5 x 256 element slots (= 160 KB of pieces) hold
+        P.tNPP = (P.n_pos + 63) & ~63;
+        const int tch = 1280 / P.tNPP;
+        P.tTCH = tch < 1 ? 1 : (tch > 15 ? 15 : tch);
+        P.tSC0 = (P.tC0 / 16 + P.tTCH - 1) / P.tTCH;
+        P.tSC = P.tSC0 + (P.tC1 / 16 + P.tTCH - 1) / P.tTCH;
+        chs = chs > P.tTCH * P.tNPP ? chs : P.tTCH * P.tNPP;
+        P.tCHS = chs;
+    }
     const size_t lds = (size_t)chs * (2 * 4 * 16);
     V2CE_REQUIRE(lds <= 160 * 1024, V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd(f16x2 ws): %zu B of LDS", lds);
     auto kern = conv3d_f16x2_ws_kernel<KS, S, WCO, CO_FR, PO_FR, NA, FUSE, RES>;
@@ -1593,7 +1758,10 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
                            float *y, const float *x0_absmax, const float *x1_absmax, float *y_absmax,
                            v2ce_stream_t stream, const void *pred_w = nullptr, const float *pred_b = nullptr,
                            int pred_cout = 0, float *pred_y = nullptr, const void *sc_w = nullptr,
-                           const float *sc_scale = nullptr, const float *sc_shift = nullptr, float *sc_y = nullptr) {
+                           const float *sc_scale = nullptr, const float *sc_shift = nullptr, float *sc_y = nullptr,
+                           const v2ce_conv3d_desc *tail = nullptr, const float *tx0 = nullptr, const float *tx1 = nullptr,
+                           const int32_t *thmap = nullptr, const int32_t *twmap = nullptr,
+                           const float *tx0_absmax = nullptr, const float *tx1_absmax = nullptr) {
     clear_error();
     V2CE_REQUIRE(desc && (g_name_out || (x0 && w_packed && scale && shift && (y || pred_w))), V2CE_ERR_BAD_ARG,
                  "v2ce_conv3d_fwd: null pointer");
@@ -1639,7 +1807,28 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
     if (pred_w && !y) P.y_absmax = nullptr;      // no y is materialised: only the guard value is reported
     P.pred_w = static_cast<const _Float16 *>(pred_w); P.pred_b = pred_b; P.pred_cout = pred_cout; P.pred_y = pred_y;
     P.sc_w = static_cast<const _Float16 *>(sc_w); P.sc_scale = sc_scale; P.sc_shift = sc_shift; P.sc_y = sc_y;
-    if (sc_w) {
+    if (tail) {
+        const v2ce_conv3d_desc &t = *tail;
+        V2CE_REQUIRE(d.precision == V2CE_PRECISION_F16X2 && d.ksize == 3 && d.stride_hw == 1 && d.Cout >= 64 && !pred_w && !residual &&
+                     sc_w && !sc_y, V2CE_ERR_UNSUPPORTED,
+                     "v2ce_conv3d_fwd_tail: the folded tail rides behind a split-half 3x3x3 stride-1 conv with >= 64 output channels, "
+                     "no residual and no fused head");
+        V2CE_REQUIRE(t.ksize == 1 && (t.stride_hw == 1 || t.stride_hw == 2) && t.layout == V2CE_LAYOUT_C16 && t.B == d.B && t.T == d.T &&
+                     t.Cout == d.Cout && t.Hout == d.Hout && t.Wout == d.Wout && t.C0 > 0 && t.C0 % 16 == 0 && t.C1 >= 0 &&
+                     t.C1 % 16 == 0 && t.Hout == (t.Hin - 1) / t.stride_hw + 1 && t.Wout == (t.Win - 1) / t.stride_hw + 1,
+                     V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd_tail: the tail must be a 1x1x1 conv (channels-last-16, channel counts multiples "
+                     "of 16) producing exactly the main conv's output shape");
+        V2CE_REQUIRE((g_name_out || tx0) && (t.C1 == 0 || tx1 || g_name_out) && (thmap == nullptr) == (twmap == nullptr) &&
+                     (thmap || (t.H0 == t.Hin && t.W0 == t.Win)), V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd_tail: tail inputs / index maps");
+        V2CE_REQUIRE((tx0_absmax != nullptr) == (x0_absmax != nullptr) && (t.C1 == 0 || !tx0_absmax || tx1_absmax), V2CE_ERR_BAD_ARG,
+                     "v2ce_conv3d_fwd_tail: range slots of the tail inputs");
+        P.tx0 = tx0; P.tx1 = tx1; P.thmap = thmap; P.twmap = twmap;
+        P.tC0 = t.C0; P.tH0 = t.H0; P.tW0p = t.W0_pitch > 0 ? t.W0_pitch : t.W0; P.tC1 = t.C1; P.tHin = t.Hin; P.tWin = t.Win;
+        P.tWinp = t.Win_pitch > 0 ? t.Win_pitch : t.Win; P.tS = t.stride_hw; P.tCG = (t.C0 + t.C1) / 16;
+        P.tx0_absmax = tx0_absmax; P.tx1_absmax = t.C1 > 0 ? tx1_absmax : nullptr;
+        V2CE_REQUIRE((long long)t.T * t.C0 * t.H0 * P.tW0p < (1ll << 29) && (long long)t.T * t.C1 * t.Hin * P.tWinp < (1ll << 29),
+                     V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd_tail: a single sequence exceeds the 2 GiB buffer-descriptor range");
+    } else if (sc_w) {
         V2CE_REQUIRE(d.precision == V2CE_PRECISION_F16X2 && d.ksize == 3 && (d.stride_hw == 2 || d.Cout <= 32) &&
                      !pred_w && sc_scale && sc_shift && sc_y, V2CE_ERR_UNSUPPORTED,
                      "v2ce_conv3d_fwd_sc: the fused shortcut needs a split-half 3x3x3 conv that is strided or has <= 32 "
@@ -1688,6 +1877,21 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
             if (small_co && P.pred_w) return V2CE_WS_RES(1, 3, 1, 1, 1, 4, 3, 1);
             if (small_co && P.sc_w) return launch_f16x2_ws<3, 1, 1, 1, 4, 3, 2, 0>(P, d, st);
             if (small_co) return V2CE_WS_RES(1, 3, 1, 1, 1, 4, 3, 0);
+            if (tail) {                                   // folded shortcut: no residual by construction
+                if (d.Cout >= 128) {
+                    auto cost = [&](int pos_tile) {
+                        const Tile t = choose_tile(d.T, d.Hout, d.Wout, 3, 1, pos_tile, 1280);
+                        const long long nsp = (long long)d.B * ((d.T + t.tt - 1) / t.tt) * ((d.Hout + t.th - 1) / t.th) *
+                                              ((d.Wout + t.tw - 1) / t.tw);
+                        const long long blocks = 8 * ((nsp + 7) / 8) * ((d.Cout + 127) / 128);
+                        return ((blocks + 255) / 256) * pos_tile;
+                    };
+                    const bool po3 = d.tile_t > 0 ? d.tile_t * d.tile_h * d.tile_w <= 192 : cost(192) < cost(256);
+                    if (po3) return launch_f16x2_ws<3, 1, 2, 2, 3, 3, 3, 0>(P, d, st);
+                    return launch_f16x2_ws<3, 1, 2, 2, 4, 3, 3, 0>(P, d, st);
+                }
+                return launch_f16x2_ws<3, 1, 1, 2, 4, 3, 3, 0>(P, d, st);
+            }
             if (d.Cout >= 128) {
                 // 256- or 192-position boxes (4 or 3 position fragments per wave): whichever needs fewer
                 // (workgroup rounds x box size).  17x22 planes: (16,2,8) boxes use 87 % of the MFMA lanes and
@@ -1843,6 +2047,21 @@ extern "C" int v2ce_conv3d_fwd_sc(const v2ce_conv3d_desc *desc, const float *x0,
                            x1_absmax, y_absmax, stream, nullptr, nullptr, 0, nullptr, sc_w, sc_scale, sc_shift, sc_y);
 }
 
+extern "C" int v2ce_conv3d_fwd_tail(const v2ce_conv3d_desc *desc, const float *x0, const float *x1,
+                                    const int32_t *hmap, const int32_t *wmap, const float *w_packed,
+                                    const float *scale, const float *shift, float *y,
+                                    const float *x0_absmax, const float *x1_absmax, float *y_absmax,
+                                    const v2ce_conv3d_desc *tail_desc, const float *tx0, const float *tx1,
+                                    const int32_t *thmap, const int32_t *twmap, const void *tail_w,
+                                    const float *tx0_absmax, const float *tx1_absmax, v2ce_stream_t stream) {
+    g_name_out = nullptr;
+    clear_error();
+    V2CE_REQUIRE(tail_desc && tail_w, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd_tail: null tail description / weights");
+    return conv3d_dispatch(desc, x0, x1, hmap, wmap, w_packed, scale, shift, nullptr, y, x0_absmax,
+                           x1_absmax, y_absmax, stream, nullptr, nullptr, 0, nullptr, tail_w, nullptr, nullptr, nullptr,
+                           tail_desc, tx0, tx1, thmap, twmap, tx0_absmax, tx1_absmax);
+}
+
 extern "C" size_t v2ce_pack_pred_weights_f16x2_bytes(void) { return 2048 * 2 + 16; }
 
 extern "C" int v2ce_pack_pred_weights_f16x2(const float *w, int cout, int cin, void *table, v2ce_stream_t stream) {
@@ -1865,12 +2084,19 @@ extern "C" int v2ce_conv3d_variant_fused(const v2ce_conv3d_desc *desc, int mappe
     static const int32_t dummy_map = 0;
     static const float dummy = 0.0f;
     const int32_t *m = mapped ? &dummy_map : nullptr;
+    v2ce_conv3d_desc td{};
+    if (fuse == 3 && desc) {                                 // a stand-in tail of the right output shape
+        td = *desc;
+        td.ksize = 1; td.stride_hw = 1; td.C0 = 16; td.C1 = 0; td.H0 = td.Hin = desc->Hout; td.W0 = td.Win = desc->Wout;
+        td.W0_pitch = td.Win_pitch = 0;
+    }
     const int rc = conv3d_dispatch(desc, nullptr, nullptr, m, m, nullptr, nullptr, nullptr, with_res ? &dummy : nullptr,
                                    nullptr, nullptr, nullptr, nullptr, nullptr,
                                    fuse == 1 ? &dummy : nullptr, fuse == 1 ? &dummy : nullptr, fuse == 1 ? 1 : 0,
                                    fuse == 1 ? const_cast<float *>(&dummy) : nullptr,
-                                   fuse == 2 ? &dummy : nullptr, fuse == 2 ? &dummy : nullptr,
-                                   fuse == 2 ? &dummy : nullptr, fuse == 2 ? const_cast<float *>(&dummy) : nullptr);
+                                   fuse >= 2 ? &dummy : nullptr, fuse == 2 ? &dummy : nullptr,
+                                   fuse == 2 ? &dummy : nullptr, fuse == 2 ? const_cast<float *>(&dummy) : nullptr,
+                                   fuse == 3 ? &td : nullptr);
     g_name_out = nullptr;
     return rc;
 }

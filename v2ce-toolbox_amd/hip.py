@@ -29,7 +29,7 @@ EXPORTS = [
     "v2ce_conv3d_variant", "v2ce_conv3d_variant_fused", "v2ce_pack_weights_f16x2", "v2ce_pack_weights_f16x2_bytes",
     "v2ce_pack_weights", "v2ce_sn_workspace_bytes", "v2ce_sn_power_iter", "v2ce_sn_batch_workspace_bytes", "v2ce_sn_update_batch",
     "v2ce_preprocess_pairs", "v2ce_preprocess_pairs_resize",
-    "v2ce_voxelize_events", "v2ce_conv3d_fwd_pred", "v2ce_conv3d_fwd_sc", "v2ce_pack_pred_weights_f16x2", "v2ce_pack_pred_weights_f16x2_bytes",
+    "v2ce_voxelize_events", "v2ce_conv3d_fwd_pred", "v2ce_conv3d_fwd_sc", "v2ce_conv3d_fwd_tail", "v2ce_pack_pred_weights_f16x2", "v2ce_pack_pred_weights_f16x2_bytes",
     "v2ce_sampler_count", "v2ce_sampler_workspace_bytes", "v2ce_sampler_emit", "v2ce_sampler_pool",
 ]
 
@@ -132,6 +132,8 @@ def lib() -> ctypes.CDLL:
     L.v2ce_conv3d_fwd_pred.restype = ctypes.c_int
     L.v2ce_conv3d_fwd_sc.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 16
     L.v2ce_conv3d_fwd_sc.restype = ctypes.c_int
+    L.v2ce_conv3d_fwd_tail.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 11 + [ctypes.POINTER(ConvDesc)] + [vp] * 8
+    L.v2ce_conv3d_fwd_tail.restype = ctypes.c_int
     L.v2ce_pack_pred_weights_f16x2.argtypes = [vp, i32, i32, vp, vp]
     L.v2ce_pack_pred_weights_f16x2.restype = ctypes.c_int
     L.v2ce_pack_pred_weights_f16x2_bytes.argtypes = []

@@ -234,6 +234,15 @@ class V2ce3d(nn.Module):
                 d["down_w"] = self._pack(blk.downsample[0].weight.contiguous(),
                                          split=self._fuse_shortcut(blk) or self._split(blk.cin, blk.cout, 1, blk.stride_hw))
                 d["down_bn"] = self._fold_bn(blk.downsample[1], blk.downsample[0].bias)
+                d["fold"] = None
+                if self._fold_shortcut(blk):
+                    # Wd' = Wd sd / s2 (one f32 rounding per weight on top of the 22-bit split: ~2^-22 relative on the shortcut's
+                    # contribution); a BatchNorm scale of (almost) zero in bn2 cannot be divided out: that block keeps its own launch
+                    s2, sh2 = d["bn2"]
+                    sd, shd = d["down_bn"]
+                    if float(s2.abs().min()) > 1e-20 and bool(torch.isfinite(sd / s2).all()):
+                        wf = (blk.downsample[0].weight * (sd / s2).view(-1, 1, 1, 1, 1)).contiguous()
+                        d["fold"] = (self._pack(wf, split=True), s2, (sh2 + shd).contiguous())
                 if blk.sn:
                     for cn in ("conv1", "conv2"):
                         m = getattr(blk, cn).module
@@ -286,6 +295,12 @@ class V2ce3d(nn.Module):
         disappears (enc0-3, dec3: ~0.9 ms per 64 frame-pairs)."""
         return self.precision == "f16x2" and (blk.stride_hw == 2 or blk.cout <= 32)
 
+    def _fold_shortcut(self, blk) -> bool:
+        """Fold the block's 1x1x1 shortcut into conv2's K loop (v2ce_conv3d_fwd_tail)?  Where it does not already ride on
+        conv1 (``_fuse_shortcut``) and conv2 has >= 64 output channels: res0-1, dec0-2.  V2CE_FOLD_SHORTCUT=0 disables."""
+        return self.precision == "f16x2" and not self._fuse_shortcut(blk) and blk.cout >= 64 and \
+            os.environ.get("V2CE_FOLD_SHORTCUT", "1") != "0"
+
     def _map(self, n_in, n_out, dev):
         key = (n_in, n_out, str(dev))
         if key not in self._maps:
@@ -324,7 +339,7 @@ class V2ce3d(nn.Module):
         return (w + 31) // 32 * 32
 
     def _conv(self, x0, x1, w_packed, scale, shift, cout, ksize, stride, act, residual=None,
-              up_to=None, split=False, track=False, pred=None, sc=None, dense_out=False):
+              up_to=None, split=False, track=False, pred=None, sc=None, dense_out=False, tail=None):
         """x0 [B,T,C0,H0,W0] (optionally nearest-upsampled to ``up_to``), x1 [B,T,C1,Hin,Win]."""
         # activations between the layers are [B,T,C,H,pitch] (planar) or [B,T,C/16,H,pitch,16] (`.c16`: what the
         # split-half kernels take and produce, include/v2ce_hip.h V2CE_LAYOUT_C16), logical width in `.lw` (see _pitch)
@@ -384,6 +399,28 @@ class V2ce3d(nn.Module):
                                                      tab.data_ptr(), pbias.data_ptr(), pcout, y.data_ptr(),
                                                      hip.stream_ptr(x0.device)),
                       "v2ce_conv3d_fwd_pred")
+        elif tail is not None:         # folded 1x1x1 tail: the block's shortcut inside this launch's K loop
+            tx0, tx1, t_up_to, t_stride, tw = tail
+            assert getattr(tx0, "c16", False) and (tx1 is None or getattr(tx1, "c16", False)) and residual is None
+            tC0, tH0, tW0p = tx0.shape[2] * 16, tx0.shape[3], tx0.shape[4]
+            tW0 = getattr(tx0, "lw", tW0p)
+            tHin, tWin = t_up_to if t_up_to is not None else (tH0, tW0)
+            thmap = twmap = None
+            if (tHin, tWin) != (tH0, tW0):
+                thmap, twmap = self._map(tH0, tHin, tx0.device), self._map(tW0, tWin, tx0.device)
+            td = hip.ConvDesc(B=B, T=T, C0=tC0, H0=tH0, W0=tW0, C1=0 if tx1 is None else tx1.shape[2] * 16, Hin=tHin, Win=tWin,
+                              Cout=cout, Hout=Hout, Wout=Wout, ksize=1, stride_hw=t_stride, act=hip.ACT_NONE,
+                              tile_t=0, tile_h=0, tile_w=0, precision=hip.PRECISION_F16X2, W0_pitch=tW0p,
+                              Win_pitch=tWin if tx1 is None else tx1.shape[4], Wout_pitch=Woutp, layout=hip.LAYOUT_C16,
+                              absmax_batch_stride=d.absmax_batch_stride)
+            ta0 = getattr(tx0, "absmax", None) if a0 is not None else None
+            ta1 = None if tx1 is None or ta0 is None else tx1.absmax
+            hip.check(hip.lib().v2ce_conv3d_fwd_tail(ctypes.byref(d), x0.data_ptr(), hip.ptr(x1), hip.ptr(hmap), hip.ptr(wmap),
+                                                     w_packed.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(),
+                                                     hip.ptr(a0), hip.ptr(a1), hip.ptr(ay), ctypes.byref(td), tx0.data_ptr(),
+                                                     hip.ptr(tx1), hip.ptr(thmap), hip.ptr(twmap), tw.data_ptr(),
+                                                     hip.ptr(ta0), hip.ptr(ta1), hip.stream_ptr(x0.device)),
+                      "v2ce_conv3d_fwd_tail")
         elif sc is not None:           # fused 1x1x1 shortcut: second output tensor
             sc_w, sc_scale, sc_shift = sc
             y_sc = torch.empty_like(y)
@@ -409,7 +446,10 @@ class V2ce3d(nn.Module):
                 flops += 2.0 * B * T * Hout * Wout * pred[2] * cout
             if sc is not None:
                 flops += 2.0 * B * T * Hout * Wout * cout * (C0 + C1)
-            prof.append((hip.conv_variant(d, hmap is not None, (1 if pred is not None else (2 if sc is not None else 0)) +
+            if tail is not None:
+                flops += 2.0 * B * T * Hout * Wout * cout * 16 * (tail[0].shape[2] + (0 if tail[1] is None else tail[1].shape[2]))
+            prof.append((hip.conv_variant(d, hmap is not None, (1 if pred is not None else (2 if sc is not None else
+                                                                                           (3 if tail is not None else 0))) +
                                           (4 if residual is not None else 0)),
                          flops, e0, e1))
         if sc is not None:
@@ -438,6 +478,12 @@ class V2ce3d(nn.Module):
         if self._fuse_shortcut(blk):
             t, res = self._conv(x0, x1, w1, *d["bn1"], blk.cout, 3, s, hip.ACT_RELU, up_to=up_to, split=True,
                                 sc=(d["down_w"], *d["down_bn"]))
+        elif d.get("fold") is not None and pred is None:
+            # the shortcut rides in conv2's K loop (v2ce_conv3d_fwd_tail): relu(s2 (W2 * t + Wd' * x) + shift2 + shift_d)
+            t = self._conv(x0, x1, w1, *d["bn1"], blk.cout, 3, s, hip.ACT_RELU, up_to=up_to, split=True)
+            fw, fscale, fshift = d["fold"]
+            return self._conv(t, None, d["conv2_w"], fscale, fshift, blk.cout, 3, 1, hip.ACT_RELU, split=True, track=track,
+                              tail=(x0, x1, up_to, s, fw))
         else:
             t = self._conv(x0, x1, w1, *d["bn1"], blk.cout, 3, s, hip.ACT_RELU, up_to=up_to,
                            split=self._split(blk.cin, blk.cout))
