@@ -116,6 +116,23 @@ def test_c2_batch4_default_vs_exact_f32():
     assert excess(out.cpu().numpy(), ref_out.numpy(), 2 * TOL) <= 2 * TOL
 
 
+def test_c2_batch4_rows_equal_single_sequence_runs(c1_case):
+    """C2 against the ORACLE (the B = 4 check above is HIP vs HIP): with one range slot per batch
+    element a sequence's voxels are bit-identical whatever shares its launch, so every row of the batch-of-four default
+    run (bench.py's step: fused head, fused / folded shortcuts, the batch-4 grids) must equal, bit for bit, the run of
+    that sequence alone -- and the run of one sequence alone is what test_c1_default_path_vs_oracle_full_depth holds
+    against oracle/unet.py at 1e-5 (row 0 here IS that sequence and is compared with the oracle again)."""
+    _, x0, want, _ = c1_case
+    xs = np.concatenate([x0] + [OG.preprocess(synth.synthetic_frames(17, H, W, seed=1000 + s))[None] for s in (1, 2, 3)])
+    x = torch.from_numpy(xs).cuda()
+    whole = fresh_model()(x)
+    assert whole.shape == (4, 16, 20, H, W)
+    for b in range(4):
+        alone = fresh_model()(x[b:b + 1].contiguous())
+        assert torch.equal(whole[b], alone[0]), b
+    assert excess(whole[:1].cpu().numpy(), want) <= TOL
+
+
 def test_c1_cli_full_size_byte_equal(tmp_path, c1_case):
     """BASELINE config 1 through the drop-in CLI at full size."""
     frames, x, want, _ = c1_case

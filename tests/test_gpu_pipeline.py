@@ -146,3 +146,26 @@ def test_bench_rccl_path_world_of_one():
     # the records of one step (13 bytes each; the spectral-norm state moves on from step to step, so not exactly the mean)
     assert line["gathered_bytes_per_step"] % 13 == 0
     assert abs(line["gathered_bytes_per_step"] / (13 * line["events_per_pair"] * 64) - 1) < 0.05
+
+
+def test_streamed_events_file_equals_in_memory_run(tmp_path):
+    """f1 (VERDICT r2 missing #3): the CLI's default output path -- pipeline.StreamingEventSink (pinned staging ring, D2H on
+    the copy stream, writer thread) into npz_stream.NpzStreamWriter while the clip runs -- leaves the file whose
+    np.load(...)['event_stream'] equals the in-memory run byte for byte; v2ce.py --stream_events false (one np.savez at
+    the end, like v2ce.py:371-372) gives the same content."""
+    from v2ce_toolbox_amd import v2ce as cli
+    frames = synth.synthetic_frames(70, 32, 48, seed=9)
+    want = cli.run(frames, load_model(), width=48, height=32, batch_size=2, fps=30, seed=3)
+    p = str(tmp_path / "e.npz")
+    n = cli.run(frames, load_model(), width=48, height=32, batch_size=2, fps=30, seed=3, out_path=p)
+    got = np.load(p)["event_stream"]
+    assert n == len(want) == len(got) > 1000 and got.dtype == want.dtype and got.tobytes() == want.tobytes()
+    outs = []
+    for flag in ("true", "false"):
+        out = tmp_path / flag
+        cmd = [sys.executable, os.path.join(ROOT, "v2ce.py"), "--synthetic", "40", "--height", "32", "--width", "48",
+               "--synthetic_weights", "0", "-o", str(out), "-b", "2", "--write_event_frame_video", "false", "--stream_events", flag]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out / "synthetic40-ceil_10-fps_30-events.npz")["event_stream"])
+    assert len(outs[0]) > 1000 and outs[0].tobytes() == outs[1].tobytes()

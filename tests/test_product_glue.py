@@ -151,3 +151,44 @@ def test_event_frame_writer_without_opencv(tmp_path, gold_dir):
     except ImportError:
         assert path.endswith(".npz")
         assert np.load(path)["event_frames"][..., ::-1].tobytes() == z["bgr_rgb"].tobytes()
+
+
+def test_streaming_npz_writer_and_sink(tmp_path):
+    """f1: npz_stream.NpzStreamWriter writes the file np.savez(path, event_stream=...) writes (v2ce.py:371-372) as far as
+    np.load is concerned, chunk by chunk; crc32_combine; the driver's streaming sink (CPU stand-in path) through v2ce.run."""
+    import zipfile
+    import zlib
+    from v2ce_toolbox_amd import synth
+    from v2ce_toolbox_amd import v2ce as cli
+    from v2ce_toolbox_amd.LDATI import EVENT_DTYPE
+    from v2ce_toolbox_amd.npz_stream import NpzStreamWriter, crc32_combine
+    a, b = os.urandom(999), os.urandom(123457)
+    assert crc32_combine(zlib.crc32(a), zlib.crc32(b), len(b)) == zlib.crc32(a + b)
+    rng = np.random.default_rng(0)
+    ev = np.zeros(50021, EVENT_DTYPE)
+    ev["timestamp"], ev["x"] = np.sort(rng.integers(0, 1 << 40, len(ev))), rng.integers(0, 346, len(ev))
+    ev["y"], ev["polarity"] = rng.integers(0, 260, len(ev)), rng.integers(0, 2, len(ev))
+    p = str(tmp_path / "s.npz")
+    with NpzStreamWriter(p, "event_stream", EVENT_DTYPE) as w:
+        raw = ev.view(np.uint8)
+        for i in range(0, len(raw), 13 * 4001):
+            w.write(raw[i:i + 13 * 4001])
+        with pytest.raises(ValueError):
+            w.write(raw[:5])
+    z = np.load(p)
+    assert z.files == ["event_stream"] and z["event_stream"].dtype == EVENT_DTYPE and z["event_stream"].tobytes() == ev.tobytes()
+    assert zipfile.ZipFile(p).testzip() is None
+    with NpzStreamWriter(p, "event_stream", EVENT_DTYPE):
+        pass
+    assert np.load(p)["event_stream"].shape == (0,)
+    # through the driver: the streamed file holds what the in-memory run returns
+    sys_path_tests = os.path.dirname(os.path.abspath(__file__))
+    import sys
+    sys.path.insert(0, sys_path_tests)
+    from test_dist_gloo import fake_stage2
+    frames = synth.synthetic_frames(53, 8, 20, seed=3)
+    kw = dict(infer_type="center", width=12, height=8, batch_size=2, device="cpu", stage2=fake_stage2(30))
+    want = cli.run(frames, FakeModel(), **kw)
+    n = cli.run(frames, FakeModel(), out_path=p, **kw)
+    got = np.load(p)["event_stream"]
+    assert n == len(want) == len(got) and got.tobytes() == want.tobytes()

@@ -165,6 +165,74 @@ class EventSink:
         return self.buf[:self.used].numpy().view(dtype)
 
 
+class StreamingEventSink:
+    """The ``EventSink`` interface in front of a file: packed records of successive batches -> a small ring of pinned
+    staging buffers (asynchronous D2H on a copy stream) -> ``writer.write`` on a writer thread, in push order
+    (``npz_stream.NpzStreamWriter``: the reference's ``np.savez(..., event_stream=...)`` file, v2ce.py:371-372, written
+    while the clip is still running).  The host holds at most `slots` batches; ``push`` blocks when the disk falls that
+    far behind.  ``result()`` drains, closes the writer and returns None (the events are in the file)."""
+
+    def __init__(self, device, writer, slots: int = 3):
+        import queue
+        import threading
+        self.device, self.writer = torch.device(device), writer
+        self.cuda = self.device.type == "cuda"
+        self.stream = torch.cuda.Stream(device=self.device) if self.cuda else None
+        self.free = queue.Queue()
+        for _ in range(slots):
+            self.free.put([None])                          # a slot = [pinned uint8 tensor or None]
+        self.work = queue.Queue()
+        self.error = None
+        self.thread = threading.Thread(target=self._drain, daemon=True)
+        self.thread.start()
+
+    def _drain(self):
+        while True:
+            item = self.work.get()
+            if item is None:
+                return
+            slot, n, done, _keep = item
+            try:
+                if self.error is None:
+                    if done is not None:
+                        done.synchronize()
+                    self.writer.write(slot[0][:n].numpy() if done is not None else slot[0])
+            except BaseException as e:                     # noqa: BLE001 -- re-raised by push / result on the caller's thread
+                self.error = e
+            finally:
+                if done is not None:
+                    self.free.put(slot)
+
+    def push(self, packed: torch.Tensor, n_pairs: int, keep=(), src_stream=None):
+        if self.error is not None:
+            raise self.error
+        n = int(packed.numel())
+        if not n:
+            return
+        if not packed.is_cuda:                             # CPU stand-ins: straight to the writer thread, no staging
+            self.work.put(([packed.numpy()], n, None, None))
+            return
+        slot = self.free.get()                             # blocks while every staging buffer waits for the disk
+        if slot[0] is None or slot[0].numel() < n:
+            slot[0] = torch.empty(int(n * 1.25) + (1 << 20), dtype=torch.uint8, pin_memory=True)
+        ready = torch.cuda.Event()
+        ready.record(src_stream if src_stream is not None else torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ready)
+            slot[0][:n].copy_(packed, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        self.work.put((slot, n, done, (packed, keep)))    # the device buffers stay referenced until the copy has landed
+
+    def result(self, dtype):
+        self.work.put(None)
+        self.thread.join()
+        if self.error is not None:
+            raise self.error
+        self.writer.close()
+        return None
+
+
 class FrameFeeder:
     """u8 frames of one batch: pageable numpy -> pinned staging (two slots) -> HBM on a copy stream."""
 
@@ -270,8 +338,11 @@ def shard_of_batch(bp: BatchPlan, seq_len: int, part: int, parts: int) -> BatchP
 def run_clip(frames: np.ndarray, model, *, infer_type="center", seq_len=16, width=346, height=260,
              batch_size=1, fps=30, seed=0, device="cuda", stage2=None, dtype=None,
              comm=None, trace: Optional[dict] = None,
-             reuse_output: bool = False, event_frames: Optional[list] = None) -> Optional[np.ndarray]:
+             reuse_output: bool = False, event_frames: Optional[list] = None, writer=None) -> Optional[np.ndarray]:
     """frames [N,H,W] uint8 -> event_stream (structured array) on rank 0, None elsewhere.
+
+    writer: an ``npz_stream.NpzStreamWriter`` (rank 0): the records go to the file batch by batch instead of into one
+    host array (``StreamingEventSink``); the function then returns None on every rank and closes the writer.
 
     comm: ``dist.TorchComm`` / ``dist.ThreadComm`` / ``dist.LocalComm`` (default: from torch.distributed).
     stage2: optional (begin, finish) pair replacing LDATI (CPU stand-ins in the tests):
@@ -302,7 +373,9 @@ def run_clip(frames: np.ndarray, model, *, infer_type="center", seq_len=16, widt
     mine = [shard_of_batch(bp, seq_len, seq_part, seq_parts) for bp in plans]
     feeder = FrameFeeder(frames, seq_len, device, height)
     # rank 0 owns the host buffer of the whole clip; the other ranks only feed the gather
-    sink = EventSink(device, len(frames) - 1, reuse=reuse_output) if rank == 0 else None
+    sink = None
+    if rank == 0:
+        sink = StreamingEventSink(device, writer) if writer is not None else EventSink(device, len(frames) - 1, reuse=reuse_output)
     gather = None
     if not isinstance(comm, vdist.LocalComm):               # (a forced world of one takes the collective path too)
         step_pairs = collections.deque(bp.n_pairs for bp in plans)

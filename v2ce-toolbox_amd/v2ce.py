@@ -79,6 +79,9 @@ def build_parser():
     p.add_argument("--device", type=str, default="cuda")
     p.add_argument("--seed", type=int, default=0, help="Philox seed of the LDATI draws")
     p.add_argument("--rng", type=str, default="philox", choices=["philox", "torch"])
+    p.add_argument("--stream_events", type=SBool, default=True, nargs="?", const=True,
+                   help="write the events file while the clip runs (batch by batch, same np.load content) instead of one "
+                        "np.savez of the whole clip at the end")
     p.add_argument("--precision", type=str, default="f16x2", choices=["f16x2", "f32"],
                    help="stage-1 conv arithmetic: split-half fp16 MFMA (f32-equivalent accuracy) or exact f32 MFMA")
     return p
@@ -201,8 +204,12 @@ def write_event_frame_video(efs: np.ndarray, ef_video_path, fps, ceil, upper_bou
 
 def run(frames: np.ndarray, model, infer_type="center", seq_len=16, width=346, height=260,
         batch_size=1, fps=30, stage2_batch_size=24, seed=0, rng="philox", device="cuda",
-        stage2=None, event_frames: Optional[list] = None, comm=None) -> Optional[np.ndarray]:
+        stage2=None, event_frames: Optional[list] = None, comm=None, out_path: Optional[str] = None):
     """frames [N,H,W] uint8 -> event_stream (numpy structured array, v2ce.py:368) on rank 0.
+
+    out_path (Philox draws only): write the reference's ``np.savez(out_path, event_stream=...)`` file WHILE the clip
+    runs (``npz_stream.NpzStreamWriter`` behind ``pipeline.StreamingEventSink``: the host never holds the clip, the disk
+    works under the GPU) and return the number of events on rank 0 instead of the array.
 
     Default (counter-based Philox draws): the per-batch pipeline of ``pipeline.run_clip`` (H2D,
     UNet + LDATI, D2H overlapped; under torch.distributed sharded over GPUs).  ``rng='torch'``
@@ -229,10 +236,15 @@ def run(frames: np.ndarray, model, infer_type="center", seq_len=16, width=346, h
         def clip():
             if event_frames is not None:
                 del event_frames[:]
-            return pipeline.run_clip(frames, model, infer_type=infer_type, seq_len=seq_len, width=width, height=height,
-                                     batch_size=batch_size, fps=fps, seed=seed, device=device, stage2=stage2,
-                                     dtype=EVENT_DTYPE, comm=comm,
-                                     event_frames=event_frames if world == 1 else None)
+            writer = None
+            if out_path is not None and comm.rank == 0:     # (a range-guard rerun of the clip starts the file again)
+                from .npz_stream import NpzStreamWriter
+                writer = NpzStreamWriter(out_path, "event_stream", EVENT_DTYPE)
+            out = pipeline.run_clip(frames, model, infer_type=infer_type, seq_len=seq_len, width=width, height=height,
+                                    batch_size=batch_size, fps=fps, seed=seed, device=device, stage2=stage2,
+                                    dtype=EVENT_DTYPE, comm=comm, writer=writer,
+                                    event_frames=event_frames if world == 1 else None)
+            return writer.count if writer is not None else out
     # the split-half convolutions report a dynamic-range bound; beyond its limit the clip is repeated on
     # the exact-f32 kernels (glue.run_guarded)
     return glue.run_guarded(model, clip, comm=comm)
@@ -285,9 +297,11 @@ def main(argv=None):
     efs = [] if (args.write_event_frame_video and world == 1) else None
     if args.write_event_frame_video and world > 1:
         logger.warning("the event-frame video (v2ce.py:241-280) is written by single-process runs only: skipped")
+    events_path = op.join(args.out_folder, f"{output_name}-events.npz")
+    streaming = args.stream_events and args.rng == "philox"
     event_stream = run(frames, model, args.infer_type, args.seq_len, args.width, args.height,
                        args.batch_size, args.fps, args.stage2_batch_size, args.seed, args.rng, device,
-                       event_frames=efs)
+                       event_frames=efs, out_path=events_path if streaming else None)
     if efs:
         ef = torch.cat([t for _, t in sorted(efs, key=lambda kv: kv[0])]).cpu().numpy()
         vis_color = "rgb" if args.vis_keep_polarity else "gray"
@@ -295,10 +309,12 @@ def main(argv=None):
         write_event_frame_video(ef, op.join(args.out_folder, f"{args.infer_type}-{output_name}-pred_ef_{vis_color}.mp4"),
                                 args.fps, args.ceil, args.upper_bound_percentile, args.vis_keep_polarity)
     if event_stream is not None:
-        logger.info(f"Generated event stream shape: , {event_stream.shape}")
-        path = op.join(args.out_folder, f"{output_name}-events.npz")
-        np.savez(path, event_stream=event_stream)
-        print(path)
+        if streaming:                                       # the file is already there (npz_stream.NpzStreamWriter)
+            logger.info(f"Generated event stream shape: , ({event_stream},)")
+        else:
+            logger.info(f"Generated event stream shape: , {event_stream.shape}")
+            np.savez(events_path, event_stream=event_stream)
+        print(events_path)
     if dist_on:
         torch.distributed.destroy_process_group()
 
