@@ -55,6 +55,8 @@ constexpr int kCapTile = 15360;       // events of one (tile, bin) the tile pass
 constexpr int kSparseCap = 8192;      // events of one tile over all nine bins the sparse tile kernel holds
 constexpr int kSparseThreads = 512;
 constexpr size_t kSparseLds = (size_t)(2 * kSparseCap + kSparseThreads * 5 + 34) * 4 + 9 * 8;
+constexpr int kSlopeM = 31;            // slope table (g_slope_tab): |count difference| <= kSlopeM, count <= kSlopeM; else computed
+constexpr int kSlopeTab = (2 * kSlopeM + 1) * (kSlopeM + 1);
 constexpr int kSortThreads = 256;
 constexpr int kSortWaves = kSortThreads / 64;
 
@@ -230,7 +232,15 @@ __device__ __forceinline__ long long single_ts(float debt, double fps, float off
 
 // slope parameters of one multi-event voxel, f32 (LDATI.py:188-190 with :25-45 folded in)
 __device__ __forceinline__ void slope_params(int n_l, int n_c, int n_r, int c, const LdatiParams &P,
-                                             float &k, float &bb) {
+                                             float &k, float &bb, const float2 *tab = nullptr) {
+    if (tab) {                                                 // the tabulated results of the expressions below
+        const int d = (c == 0 || c == 8) ? 0 : n_r - n_l;
+        if (d >= -kSlopeM && d <= kSlopeM && n_c >= 0 && n_c <= kSlopeM && n_l >= 0 && n_r >= 0 && n_l < (1 << 23) && n_r < (1 << 23)) {
+            const float2 kb = tab[(d + kSlopeM) * (kSlopeM + 1) + n_c];
+            k = kb.x; bb = kb.y;
+            return;
+        }
+    }
     // reflect padding makes the central difference vanish at the first and last bin
     const float sxy = (c == 0 || c == 8) ? 0.0f : ((float)n_r - (float)n_l);
     const float k0 = (3.0f * sxy) / 6.0f;
@@ -245,9 +255,13 @@ __device__ __forceinline__ void slope_params(int n_l, int n_c, int n_r, int c, c
 // per device and FPS, enqueued in front of the first emit that needs it; the result lands in g_fastdiv[slot] and the
 // kernels take the fast form only when it says "identical for all inputs" (replayed uniforms are arbitrary floats: they
 // always take the divisions).  22 -> 6 VALU operations on a path every wave with a multi-event voxel executes.
-struct FastDiv { unsigned fps_bits; int ok; };
+struct FastDiv { unsigned fps_bits; int ok; int tab_ready; };
 __device__ FastDiv g_fastdiv[8];
 __device__ unsigned g_fastdiv_bad[8];
+// The slope parameters {k, b} of a multi-event voxel (LDATI.py:188-190) depend on two small integers only -- the central
+// difference of the neighbouring counts and the voxel's own count -- and cost three IEEE divisions: tabulated once per
+// device and FPS by the very expressions of slope_params (so the entries ARE its results), looked up afterwards.
+__device__ float2 g_slope_tab[8][kSlopeTab];
 
 __device__ __forceinline__ float k0_time_fast(float u, float FPS, float RFPS, float R9) {
     float q = u * RFPS;
@@ -264,9 +278,19 @@ __global__ __launch_bounds__(256) void ldati_fastdiv_check_kernel(float FPS, flo
     const float got = k0_time_fast(u, FPS, RFPS, R9);
     if (__float_as_uint(want) != __float_as_uint(got)) atomicAdd(&g_fastdiv_bad[slot], 1u);
 }
+__global__ __launch_bounds__(256) void ldati_slope_tab_kernel(float VS, float VS2, float INV, int slot) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= kSlopeTab) return;
+    const int d = i / (kSlopeM + 1) - kSlopeM, n = i % (kSlopeM + 1);
+    const float sxy = (float)d;                                // = (float)n_r - (float)n_l: small integers, exact
+    const float k0 = (3.0f * sxy) / 6.0f;
+    const float k = (k0 / VS2) / ((float)n + 1e-8f);
+    g_slope_tab[slot][i] = make_float2(k, INV - (VS * k) / 2.0f);
+}
 __global__ void ldati_fastdiv_commit_kernel(float FPS, int slot) {
     g_fastdiv[slot].fps_bits = __float_as_uint(FPS);
     g_fastdiv[slot].ok = g_fastdiv_bad[slot] == 0u ? 1 : 0;
+    g_fastdiv[slot].tab_ready = 1;
 }
 
 // multi-event timestamp, all f32 (LDATI.py:195-196,210-212)
@@ -863,9 +887,10 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
     constexpr int NW = NT / 64;
     const bool atomic_order = !P.ballot_ranks && __builtin_amdgcn_readfirstlane(g_lds_order_ok) != 0;
     // the checked fast form of the k == 0 time: Philox uniforms only, and only if this FPS passed the exhaustive check
-    const bool fast_k0 = P.fast_slot >= 0 && P.rng_mode == V2CE_RNG_PHILOX &&
-                         __builtin_amdgcn_readfirstlane(g_fastdiv[P.fast_slot].ok) != 0 &&
-                         __builtin_amdgcn_readfirstlane((int)g_fastdiv[P.fast_slot].fps_bits) == (int)__float_as_uint(P.FPS);
+    const bool slot_ok = P.fast_slot >= 0 &&
+                         __builtin_amdgcn_readfirstlane((int)g_fastdiv[P.fast_slot >= 0 ? P.fast_slot : 0].fps_bits) == (int)__float_as_uint(P.FPS);
+    const bool fast_k0 = slot_ok && P.rng_mode == V2CE_RNG_PHILOX && __builtin_amdgcn_readfirstlane(g_fastdiv[P.fast_slot].ok) != 0;
+    const float2 *stab = (slot_ok && __builtin_amdgcn_readfirstlane(g_fastdiv[P.fast_slot].tab_ready) != 0) ? g_slope_tab[P.fast_slot] : nullptr;
 
     unsigned *S = reinterpret_cast<unsigned *>(tile_smem);
     unsigned *O = S + P.capA;
@@ -950,7 +975,7 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
                     const float2 kq = P.kbb[((long long)(b * 2 + pidx) * 9 + c) * P.HW + (x0 + lpx0 + q)];
                     kk_q[q] = kq.x; bb_q[q] = kq.y;
                 } else {
-                    slope_params(nprev[q], n, nnext[q], c, P, kk_q[q], bb_q[q]);
+                    slope_params(nprev[q], n, nnext[q], c, P, kk_q[q], bb_q[q], stab);
                 }
             }
             kz_q[q] = kk_q[q] == 0.0f;
@@ -1149,9 +1174,10 @@ __global__ __launch_bounds__(kSparseThreads) void ldati_tile_sparse_kernel(Ldati
     const int pidx = t < P.tpp ? 1 : 0;
     const int x0 = (t < P.tpp ? t : t - P.tpp) * kTilePix;
     const int tid = threadIdx.x;
-    const bool fast_k0 = P.fast_slot >= 0 && P.rng_mode == V2CE_RNG_PHILOX &&
-                         __builtin_amdgcn_readfirstlane(g_fastdiv[P.fast_slot].ok) != 0 &&
-                         __builtin_amdgcn_readfirstlane((int)g_fastdiv[P.fast_slot].fps_bits) == (int)__float_as_uint(P.FPS);
+    const bool slot_ok = P.fast_slot >= 0 &&
+                         __builtin_amdgcn_readfirstlane((int)g_fastdiv[P.fast_slot >= 0 ? P.fast_slot : 0].fps_bits) == (int)__float_as_uint(P.FPS);
+    const bool fast_k0 = slot_ok && P.rng_mode == V2CE_RNG_PHILOX && __builtin_amdgcn_readfirstlane(g_fastdiv[P.fast_slot].ok) != 0;
+    const float2 *stab = (slot_ok && __builtin_amdgcn_readfirstlane(g_fastdiv[P.fast_slot].tab_ready) != 0) ? g_slope_tab[P.fast_slot] : nullptr;
 
     unsigned *S = reinterpret_cast<unsigned *>(tile_smem);          // [kSparseCap] records (unordered, later final)
     unsigned *O = S + kSparseCap;                                   // [kSparseCap] records placed by cell
@@ -1217,7 +1243,7 @@ __global__ __launch_bounds__(kSparseThreads) void ldati_tile_sparse_kernel(Ldati
                     const float2 kq = P.kbb[((long long)(b * 2 + pidx) * 9 + c) * P.HW + (x0 + lpx0 + q)];
                     k = kq.x; bb = kq.y;
                 } else {
-                    slope_params(c > 0 ? nn[c - 1] : 0, n, c < 8 ? nn[c + 1] : 0, c, P, k, bb);
+                    slope_params(c > 0 ? nn[c - 1] : 0, n, c < 8 ? nn[c + 1] : 0, c, P, k, bb, stab);
                 }
                 const unsigned m = atomicAdd(&cur[1], 1u);
                 unsigned *e = MPtop - 3 * (m + 1);
@@ -2194,8 +2220,9 @@ extern "C" int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps
     P.sweep_ok = h.sweep_ok ? 1 : 0;
     P.RFPS = (float)(1.0 / (double)h.FPS); P.R9 = (float)(1.0 / 9.0);
     P.fast_slot = -1;
-    if (rng_mode == V2CE_RNG_PHILOX && o.strategy == V2CE_STRATEGY_SLOPE && !getenv("V2CE_LDATI_NO_FASTDIV")) {
-        // once per device and FPS: the exhaustive check of k0_time_fast against the IEEE divisions (see g_fastdiv)
+    if (o.strategy == V2CE_STRATEGY_SLOPE && !getenv("V2CE_LDATI_NO_FASTDIV")) {
+        // once per device and FPS: the exhaustive check of k0_time_fast against the IEEE divisions (see g_fastdiv) and the
+        // table of slope parameters (g_slope_tab)
         static std::mutex mu;
         static unsigned seen[64][8];
         static int n_seen[64];
@@ -2212,6 +2239,7 @@ extern "C" int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps
                 slot = n_seen[dev]++;
                 seen[dev][slot] = bits;
                 hipLaunchKernelGGL(ldati_fastdiv_check_kernel, dim3(65536), dim3(256), 0, as_stream(stream), h.FPS, P.RFPS, P.R9, slot);
+                hipLaunchKernelGGL(ldati_slope_tab_kernel, dim3((kSlopeTab + 255) / 256), dim3(256), 0, as_stream(stream), h.VS, h.VS2, h.INV, slot);
                 hipLaunchKernelGGL(ldati_fastdiv_commit_kernel, dim3(1), dim3(1), 0, as_stream(stream), h.FPS, slot);
             }
             P.fast_slot = slot;
