@@ -18,3 +18,11 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def gold_dir():
     return GOLD
+
+
+def pytest_collection_modifyitems(config, items):
+    """A hung test must fail, not sit on the GPU box until the runner's limit: 15 minutes per test (pytest-timeout)."""
+    if config.pluginmanager.hasplugin("timeout"):
+        for item in items:
+            if item.get_closest_marker("timeout") is None:
+                item.add_marker(pytest.mark.timeout(900))

@@ -137,3 +137,109 @@ def test_thread_world_equals_single_process(world, n_frames, infer_type, bs, wf)
     ref = FakeModel()
     _ = cli.run(frames, ref, infer_type=infer_type, width=12, height=8, batch_size=bs, device="cpu", stage2=fake_stage2(30))
     assert all(m.calls == ref.calls for m in models)        # every rank's model ends where the single run's does
+
+
+class FakeGuardModel:
+    """FakeModel + the range-guard interface of V2ce3d (glue.run_guarded): the 'split' arithmetic records the largest input it
+    saw as its guard bound; the 'exact' arithmetic adds 1000 to the output, so a rerun is visible in the result."""
+    RANGE_GUARD_LIMIT = 3.0
+
+    def __init__(self):
+        self.calls, self.precision, self.guard, self.worst, self.reruns = 0, "f16x2", "call", 0.0, 0
+
+    def advance_spectral_norm(self):
+        self.calls += 1
+
+    def parameters(self):
+        yield torch.zeros(1)
+
+    def __call__(self, x):
+        B, L, _, H, W = x.shape
+        base = x.mean(dim=2, keepdim=True) + 0.01 * self.calls
+        ch = torch.arange(20, dtype=torch.float32).view(1, 1, 20, 1, 1)
+        self.calls += 1
+        if self.precision == "f16x2":
+            self.worst = max(self.worst, float(x.abs().max()))
+            return (base * (1 + ch)).contiguous()
+        return (base * (1 + ch) + 1000.0).contiguous()
+
+    def range_guard_value(self, reset=True):
+        v = self.worst
+        if reset:
+            self.worst = 0.0
+        return v
+
+    def sn_snapshot(self):
+        return self.calls
+
+    def sn_restore(self, snap):
+        self.calls = snap
+
+    def exact_f32(self):
+        m = self
+
+        class Ctx:
+            def __enter__(self):
+                m.precision, m.reruns = "f32", m.reruns + 1
+
+            def __exit__(self, *exc):
+                m.precision = "f16x2"
+                return False
+        return Ctx()
+
+
+def _guard_frames():
+    from v2ce_toolbox_amd import synth
+    frames = (synth.synthetic_frames(70, 8, 20, seed=5) // 4).astype(np.uint8)      # dark: normalised values below 1.5
+    frames[60, 3, 7] = 255                                                          # one bright pixel in the LAST sequences only
+    return frames
+
+
+def _guard_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from v2ce_toolbox_amd import v2ce as cli
+        m = FakeGuardModel()
+        out = cli.run(_guard_frames(), m, infer_type="center", width=12, height=8, batch_size=4, device="cpu", stage2=fake_stage2(30))
+        q.put((rank, m.reruns, m.calls, None if out is None else out.tobytes()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_range_guard_decision_is_collective():
+    """glue.run_guarded under N ranks: the guard bound is reduced (max) over the ranks, so when ONE rank's
+    share trips it EVERY rank repeats the clip on the exact arithmetic (the clip contains collectives: a split decision would
+    hang) and rank 0 gets what the single-process run gets.  gloo world 2 and ThreadWorld 2; only the rank that holds the last
+    sequences sees the bright pixel."""
+    from v2ce_toolbox_amd import dist as vd
+    from v2ce_toolbox_amd import v2ce as cli
+    kw = dict(infer_type="center", width=12, height=8, batch_size=4, device="cpu", stage2=fake_stage2(30))
+    ref = FakeGuardModel()
+    single = cli.run(_guard_frames(), ref, **kw)
+    assert ref.reruns == 1 and single["y"].max() > 0
+    quiet = FakeGuardModel()
+    cli.run((_guard_frames() // 255).astype(np.uint8), quiet, **kw)
+    assert quiet.reruns == 0
+    # threads
+    models = [FakeGuardModel() for _ in range(2)]
+    outs = vd.ThreadWorld(2).run(lambda comm: cli.run(_guard_frames(), models[comm.rank], comm=comm, **kw))
+    assert [m.reruns for m in models] == [1, 1] and all(m.calls == ref.calls for m in models)
+    assert outs[1] is None and outs[0].tobytes() == single.tobytes()
+    # processes over gloo
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = [ctx.Process(target=_guard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [g[1] for g in got] == [1, 1] and [g[2] for g in got] == [ref.calls] * 2
+    assert got[0][3] == single.tobytes() and got[1][3] is None

@@ -167,3 +167,4 @@ def test_rccl_collectives_world_of_one():
     StreamedGather with ragged and empty payloads, TorchComm.max_float -- all on the nccl backend."""
     r = torchrun([os.path.join(ROOT, "tests", "rccl_world1_worker.py")], {})
     assert "rccl world-of-one ok" in r.stdout
+

@@ -277,6 +277,7 @@ class ThreadWorld:
 
     def __init__(self, world: int):
         self.world = world
+        self.failed = False
         self.barriers = {}                                  # one barrier per set of members (world, tile groups)
         self.slots = {}
         self.lock = threading.Lock()
@@ -285,10 +286,13 @@ class ThreadWorld:
         with self.lock:
             if members not in self.barriers:
                 self.barriers[members] = threading.Barrier(len(members))
+                if self.failed:                             # a rank has died: nobody may wait for it
+                    self.barriers[members].abort()
             return self.barriers[members]
 
     def abort(self) -> None:
         with self.lock:
+            self.failed = True
             bs = list(self.barriers.values())
         for b in bs:
             b.abort()
