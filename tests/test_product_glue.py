@@ -192,3 +192,26 @@ def test_streaming_npz_writer_and_sink(tmp_path):
     n = cli.run(frames, FakeModel(), out_path=p, **kw)
     got = np.load(p)["event_stream"]
     assert n == len(want) == len(got) and got.tobytes() == want.tobytes()
+
+
+def test_batch_shares_partition_the_clip():
+    """pipeline.plan_batches / shard_of_batch (v2ce.py:149-154,211-239 as a plan): for any clip length, batch size and number
+    of sequence shares the shares of a batch are disjoint, contiguous, in frame-pair order, and together keep exactly the
+    frame-pairs the reference keeps (N - 1, the overlapped last sequence contributing its last `mode` pairs)."""
+    from v2ce_toolbox_amd import pipeline
+    for n_frames in (17, 18, 33, 49, 50, 100, 277, 2048):
+        for bs in (1, 2, 4, 7, 32):
+            plans = pipeline.plan_batches(n_frames, 16, bs)
+            assert sum(p.n_pairs for p in plans) == n_frames - 1
+            assert [p.first_pair for p in plans] == [16 * bs * i for i in range(len(plans))]
+            for parts in (1, 2, 3, 4, 8):
+                nxt = 0
+                for bp in plans:
+                    shares = [pipeline.shard_of_batch(bp, 16, r, parts) for r in range(parts)]
+                    assert sum(len(s.seqs) for s in shares) == len(bp.seqs) and sum(s.n_pairs for s in shares) == bp.n_pairs
+                    assert sum(1 for s in shares if s.drop) == (1 if bp.drop else 0)
+                    for s in shares:
+                        if s.seqs:
+                            assert s.first_pair == nxt and s.starts == bp.starts[bp.seqs.index(s.seqs[0]):][:len(s.seqs)]
+                            nxt += s.n_pairs if not s.drop else len(s.seqs) * 16      # pair indices count the dropped ones too
+                    nxt = bp.first_pair + len(bp.seqs) * 16
