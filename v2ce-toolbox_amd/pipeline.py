@@ -9,7 +9,9 @@ through the model, voxel grids to host numpy and back, LDATI over the whole clip
                    emit phase of batch k-1 is enqueued BEHIND the model of batch k, so the one host
                    synchronisation LDATI needs (reading the segment table) never drains the GPU,
 * copy-out stream: packed 13-byte records of batch k-1 -> one growing pinned host buffer, which is
-                   returned as the structured array (no host-side concatenation).
+                   returned as the structured array (no host-side concatenation) -- or, with a ``writer``, a ring of
+                   pinned staging buffers behind which a thread writes the reference's ``.npz`` while the clip runs
+                   (``StreamingEventSink`` + ``npz_stream.NpzStreamWriter``; the CLI's default).
 
 The counter-based Philox draws make LDATI independent of the chunking, so a batch of sequences is
 also the LDATI chunk (``rng='torch'`` keeps the reference's --stage2_batch_size chunks over the whole
@@ -25,7 +27,7 @@ Multi-GPU (one process per GPU, ``torch.distributed``; ``dist.py``):
   (reference call index batch*tiles + g), then one all-to-all re-shards W-tiles -> frame-pairs so every rank
   runs full-width LDATI on its pairs; sequences are shared out over the groups;
 * the packed records stream to rank 0 batch by batch (``dist.StreamedGather`` on a communication stream; rank
-  order inside a step is frame-pair order), straight into the pinned host buffer of the clip.
+  order inside a step is frame-pair order), straight into rank 0's sink (host array or streamed file).
 """
 from __future__ import annotations
 
