@@ -327,3 +327,18 @@ def test_ballot_rank_fallback_forced(gold_dir, monkeypatch):
         ev = both(lambda: hip_events(vox, seed=99, frame_base=4))
         if regime == "sparse":
             soa_equal(ev, *O.emit_soa(vox, fps=30, seed=99, frame_base=4))
+
+
+def test_unphysical_voxels_are_refused():
+    """A voxel grid with counts in the millions (broken checkpoint, un-normalised input) would ask for billions of events -- the
+    reference dies allocating its dense [B,2,9,H,W,max_n] tensors (LDATI.py:171).  The build refuses before it allocates or
+    launches anything of that size (a quick V2ceHipError; nothing unbounded reaches the device or the page-locked pool)."""
+    import time
+    vox = synth.synthetic_voxels(2, 32, 48, seed=3, regime="stress")
+    vox[0, 0, 3, 5, 7] = 3.0e6
+    t0 = time.perf_counter()
+    with pytest.raises(hip.V2ceHipError, match="unphysical"):
+        hip_events(vox, seed=1)
+    assert time.perf_counter() - t0 < 5.0
+    vox[0, 0, 3, 5, 7] = 4000.0                                  # large but within the limits: runs, bit-exact
+    soa_equal(hip_events(vox, seed=1), *O.emit_soa(vox, fps=30, seed=1))

@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 from typing import List, Optional
 
 import numpy as np
@@ -230,6 +231,16 @@ def _ldati_finish(q: PendingLdati) -> DeviceEvents:
     elif seed is None:     # reproducible under torch.manual_seed, like the reference's draw
         seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
 
+    # An unphysical voxel grid (values in the thousands: a broken checkpoint, un-normalised input) asks for billions of events;
+    # the reference dies there allocating its dense [B,2,9,H,W,max_n] tensors (LDATI.py:171).  Refuse before anything of that
+    # size is allocated or launched (V2CE_MAX_EVENTS overrides the 2^31 default).
+    limit = int(os.environ.get("V2CE_MAX_EVENTS", 1 << 31))
+    # (the device-side counters are 32-bit per tile and per segment: a voxel count this large could wrap them, so it is
+    # checked first -- max_n comes from a per-voxel atomic max and cannot wrap)
+    if max_n > 4096 or 2 * H * W * max(max_n, 1) >= 1 << 32 or total > limit:
+        raise hip.V2ceHipError(f"LDATI: {total} events in one call of {B} frame-pairs, largest voxel count {max_n}: the voxel "
+                               f"values are unphysical (or the chunk is too large: limit {limit} events, V2CE_MAX_EVENTS; "
+                               "4096 events per voxel and time bin)")
     packed = soa = None
     ptrs = [None] * 5
     if q.layout == "packed":

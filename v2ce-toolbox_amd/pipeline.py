@@ -32,6 +32,7 @@ Multi-GPU (one process per GPU, ``torch.distributed``; ``dist.py``):
 from __future__ import annotations
 
 import collections
+import os
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Sequence
 
@@ -99,6 +100,8 @@ class EventSink:
     process and handed out again, so only the first clip pays for it -- the returned array then
     ALIASES that buffer and is overwritten by the next clip (copy it to keep it)."""
 
+    PIN_LIMIT_BYTES = int(os.environ.get("V2CE_PIN_LIMIT_GB", 48)) << 30
+
     def __init__(self, device, total_pairs: int, to_host: bool = True, reuse: bool = False):
         self.reuse = reuse
         self.device = torch.device(device)
@@ -122,7 +125,15 @@ class EventSink:
         if cached is not None and cached is not self.buf and cached.numel() >= need:
             new = cached
         else:
-            new = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
+            # page-locking is bounded: a clip whose events outgrow PIN_LIMIT_BYTES (the CLI streams to disk instead and
+            # never gets here) continues in pageable memory -- slower copies, but a data-dependent size must not lock
+            # hundreds of GB of host RAM
+            pin = cap <= self.PIN_LIMIT_BYTES
+            if not pin and not getattr(self, "_warned", False):
+                self._warned = True
+                import logging
+                logging.getLogger("V2CE").warning(f"event buffer of {cap / 2**30:.0f} GiB: beyond the page-locking limit, using pageable memory")
+            new = torch.empty(cap, dtype=torch.uint8, pin_memory=pin)
             if self.reuse:
                 _OUT_CACHE["buf"] = new
         if self.buf is not None and self.used:
