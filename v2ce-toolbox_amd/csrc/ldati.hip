@@ -468,53 +468,36 @@ __device__ __forceinline__ unsigned wave_incl_scan(unsigned v, int lane) {
     return (unsigned)x;
 }
 
-// exclusive scan of one value per thread over a workgroup of NW waves; `part` = NW+1 LDS words.
-// Returns the exclusive prefix; *total = sum over the workgroup.  Two barriers.
+// exclusive scan of one value per thread over a workgroup of NW <= 64 waves; `part` = NW LDS words.
+// Returns the exclusive prefix; *total = sum over the workgroup.  ONE barrier: every wave scans the NW wave totals itself
+// (a 64-lane DPP scan costs less than a second barrier and a serial loop on one thread).  The caller separates two scans
+// that share `part` by a barrier of its own (every call site has one: the totals are read right behind the barrier here).
 template <int NW>
 __device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned *part, unsigned *total) {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const unsigned incl = wave_incl_scan(v, lane);
     if (lane == 63) part[wid] = incl;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned run = 0;
-#pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            const unsigned t = part[i];
-            part[i] = run;
-            run += t;
-        }
-        part[NW] = run;
-    }
-    __syncthreads();
-    *total = part[NW];
-    return part[wid] + incl - v;
+    const unsigned pin = wave_incl_scan(lane < NW ? part[lane] : 0u, lane);
+    *total = (unsigned)__builtin_amdgcn_readlane((int)pin, NW - 1);
+    const unsigned base = wid ? (unsigned)__builtin_amdgcn_readlane((int)pin, wid - 1) : 0u;
+    return base + incl - v;
 }
 
-// the same for two values per thread with one pair of barriers; `part` = 2*(NW+1) LDS words
+// the same for two values per thread with one barrier; `part` = 2 * NW LDS words
 template <int NW>
 __device__ __forceinline__ void block_excl_scan2(unsigned a, unsigned e, unsigned *part, unsigned &a_ex,
                                                  unsigned &e_ex, unsigned &a_tot, unsigned &e_tot) {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const unsigned ia = wave_incl_scan(a, lane), ie = wave_incl_scan(e, lane);
-    if (lane == 63) { part[wid] = ia; part[NW + 1 + wid] = ie; }
+    if (lane == 63) { part[wid] = ia; part[NW + wid] = ie; }
     __syncthreads();
-    if (threadIdx.x < 2) {
-        unsigned *q = part + threadIdx.x * (NW + 1);
-        unsigned run = 0;
-#pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            const unsigned t = q[i];
-            q[i] = run;
-            run += t;
-        }
-        q[NW] = run;
-    }
-    __syncthreads();
-    a_tot = part[NW];
-    e_tot = part[2 * NW + 1];
-    a_ex = part[wid] + ia - a;
-    e_ex = part[NW + 1 + wid] + ie - e;
+    const unsigned pa = wave_incl_scan(lane < NW ? part[lane] : 0u, lane);
+    const unsigned pe = wave_incl_scan(lane < NW ? part[NW + lane] : 0u, lane);
+    a_tot = (unsigned)__builtin_amdgcn_readlane((int)pa, NW - 1);
+    e_tot = (unsigned)__builtin_amdgcn_readlane((int)pe, NW - 1);
+    a_ex = (wid ? (unsigned)__builtin_amdgcn_readlane((int)pa, wid - 1) : 0u) + ia - a;
+    e_ex = (wid ? (unsigned)__builtin_amdgcn_readlane((int)pe, wid - 1) : 0u) + ie - e;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -293,7 +293,11 @@ class V2ce3d(nn.Module):
         waves own one 32-channel fragment row (strided blocks, and the 32-channel last decoder): the
         second accumulator set fits, the shortcut's input is never read a second time and its launch
         disappears (enc0-3, dec3: ~0.9 ms per 64 frame-pairs)."""
-        return self.precision == "f16x2" and (blk.stride_hw == 2 or blk.cout <= 32)
+        if self.precision != "f16x2":
+            return False
+        if blk.stride_hw == 2 and os.environ.get("V2CE_FOLD_STRIDED", "0") == "1":
+            return False                                   # A/B: the strided blocks' shortcuts as conv2 tails (stride-2 gather)
+        return blk.stride_hw == 2 or blk.cout <= 32
 
     def _fold_shortcut(self, blk) -> bool:
         """Fold the block's 1x1x1 shortcut into conv2's K loop (v2ce_conv3d_fwd_tail)?  Where it does not already ride on
