@@ -593,7 +593,7 @@ def test_precision_report_vs_f64_truth():
 
 
 def test_batched_spectral_norm_equals_per_layer_calls():
-    """v2ce_sn_update_batch (all 12 layers in five launches) against 12 x (v2ce_sn_power_iter +
+    """v2ce_sn_update_batch (all 12 layers in six launches) against 12 x (v2ce_sn_power_iter +
     v2ce_pack_weights_f16x2): same u / v / packed weights / outputs, bit for bit, over three calls."""
     from v2ce_toolbox_amd.v2ce_3d import V2ce3d
     x = torch.from_numpy(OG.preprocess(synth.synthetic_frames(17, 32, 48, seed=6))[None]).cuda()
