@@ -1671,56 +1671,66 @@ __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(Ldat
     const long long G0 = (g0 >> 2) & ~3ll, G1 = (gN + 3) >> 2;         // G0 % 4 == 0: 52*G0 % 16 == 0
     const long long B0 = 13 * g0, B1 = 13 * gN;                         // this bucket's bytes
     const int i_base = (int)(4 * G0 - g0);                             // record index of the first slot (in [-15, 0])
-    for (long long Ga = G0; Ga < G1; Ga += kSortThreads) {
-        const long long G = Ga + tid;
-        if (G < G1) {
-            unsigned A[4], Bh[4], C[4], D[4];
-            const int i0 = i_base + 4 * (int)(G - G0);
+    const int nG_all = (int)(G1 - G0);                                 // groups of four records this bucket touches
+    // one copy of the loop per division form (the kernel is bound by instruction issue: a uniform three-way branch per
+    // record costs more than the division it selects)
+    auto emit_loop = [&](auto mode_c) {
+        constexpr int MODE = decltype(mode_c)::value;                  // 0: div_tiny, 1: div_small, 2: integer division
+        for (int ga = 0; ga < nG_all; ga += kSortThreads) {
+            const int g = ga + tid;
+            if (g < nG_all) {
+                unsigned A[4], Bh[4], C[4], D[4];
+                const int i0 = i_base + 4 * g;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int i = i0 + q;
-                const unsigned r = (i >= 0 && i < (int)N) ? Out[i] : 0u;
-                const unsigned px = r & pmask, cat = (r >> P.PB) & 3u, fine = r >> (P.PB + 2);
-                const unsigned yy = tiny ? div_tiny(px, rcpW) : small ? div_small(px, W, rcpW) : px / W;
-                const long long tq = tbase + fine;
-                A[q] = (unsigned)tq;
-                Bh[q] = (unsigned)((unsigned long long)tq >> 32);
-                C[q] = ((px - yy * W) & 0xFFFFu) | (yy << 16);
-                D[q] = cat >> 1;
+                for (int q = 0; q < 4; ++q) {
+                    // (slots outside the bucket repeat one of its end records: their bytes are never copied out)
+                    const int i = i0 + q, ic = i < 0 ? 0 : (i >= (int)N ? (int)N - 1 : i);
+                    const unsigned r = Out[ic];
+                    const unsigned px = r & pmask, cat = (r >> P.PB) & 3u, fine = r >> (P.PB + 2);
+                    const unsigned yy = MODE == 0 ? div_tiny(px, rcpW) : MODE == 1 ? div_small(px, W, rcpW) : px / W;
+                    const long long tq = tbase + fine;
+                    A[q] = (unsigned)tq;
+                    Bh[q] = (unsigned)((unsigned long long)tq >> 32);
+                    C[q] = ((px - yy * W) & 0xFFFFu) | (yy << 16);
+                    D[q] = cat >> 1;
+                }
+                unsigned *d = stage + tid * 13;
+                d[0] = A[0]; d[1] = Bh[0]; d[2] = C[0];
+                d[3] = D[0] | (A[1] << 8);
+                d[4] = (A[1] >> 24) | (Bh[1] << 8);
+                d[5] = (Bh[1] >> 24) | (C[1] << 8);
+                d[6] = (C[1] >> 24) | (D[1] << 8) | (A[2] << 16);
+                d[7] = (A[2] >> 16) | (Bh[2] << 16);
+                d[8] = (Bh[2] >> 16) | (C[2] << 16);
+                d[9] = (C[2] >> 16) | (D[2] << 16) | (A[3] << 24);
+                d[10] = (A[3] >> 8) | (Bh[3] << 24);
+                d[11] = (Bh[3] >> 8) | (C[3] << 24);
+                d[12] = (C[3] >> 8) | (D[3] << 24);
             }
-            unsigned *d = stage + tid * 13;
-            d[0] = A[0]; d[1] = Bh[0]; d[2] = C[0];
-            d[3] = D[0] | (A[1] << 8);
-            d[4] = (A[1] >> 24) | (Bh[1] << 8);
-            d[5] = (Bh[1] >> 24) | (C[1] << 8);
-            d[6] = (C[1] >> 24) | (D[1] << 8) | (A[2] << 16);
-            d[7] = (A[2] >> 16) | (Bh[2] << 16);
-            d[8] = (Bh[2] >> 16) | (C[2] << 16);
-            d[9] = (C[2] >> 16) | (D[2] << 16) | (A[3] << 24);
-            d[10] = (A[3] >> 8) | (Bh[3] << 24);
-            d[11] = (Bh[3] >> 8) | (C[3] << 24);
-            d[12] = (C[3] >> 8) | (D[3] << 24);
-        }
-        __syncthreads();
-        const long long left = G1 - Ga;
-        const unsigned nG = left < kSortThreads ? (unsigned)left : (unsigned)kSortThreads;
-        const unsigned nPieces = (nG * 52u + 15u) >> 4;
-        const long long img = 52 * Ga;                                   // global byte address of the image
-        // pieces [qa, qb) lie wholly inside this bucket's bytes (all but the first and the last of the bucket)
-        const int rel0 = (int)(B0 - img), rel1 = (int)(B1 - img);       // small: |rel0| < 256, rel1 <= 13 * cap2 + 256
-        const int qa = rel0 > 0 ? (rel0 + 15) >> 4 : 0, qb = rel1 >> 4;
-        unsigned char *dst = P.packed + img;
-        for (int q = tid; q < (int)nPieces; q += kSortThreads) {
-            if (q >= qa && q < qb) {
-                reinterpret_cast<uint4 *>(dst)[q] = reinterpret_cast<const uint4 *>(stage)[q];
-            } else {
-                const unsigned char *sb = reinterpret_cast<const unsigned char *>(stage) + 16 * q;
-                for (int k = 0; k < 16; ++k)
-                    if (16 * q + k >= rel0 && 16 * q + k < rel1) dst[16 * q + k] = sb[k];
+            __syncthreads();
+            const int left = nG_all - ga;
+            const int nG = left < kSortThreads ? left : kSortThreads;
+            const int nPieces = (nG * 52 + 15) >> 4;
+            const long long img = 52 * (G0 + ga);                          // global byte address of the image
+            // pieces [qa, qb) lie wholly inside this bucket's bytes (all but the first and the last of the bucket)
+            const int rel0 = (int)(B0 - img), rel1 = (int)(B1 - img);     // small: |rel0| < 256, rel1 <= 13 * cap2 + 256
+            const int qa = rel0 > 0 ? (rel0 + 15) >> 4 : 0, qb = rel1 >> 4;
+            unsigned char *dst = P.packed + img;
+            for (int q = tid; q < nPieces; q += kSortThreads) {
+                if (q >= qa && q < qb) {
+                    reinterpret_cast<uint4 *>(dst)[q] = reinterpret_cast<const uint4 *>(stage)[q];
+                } else {
+                    const unsigned char *sb = reinterpret_cast<const unsigned char *>(stage) + 16 * q;
+                    for (int k = 0; k < 16; ++k)
+                        if (16 * q + k >= rel0 && 16 * q + k < rel1) dst[16 * q + k] = sb[k];
+                }
             }
+            __syncthreads();
         }
-        __syncthreads();
-    }
+    };
+    if (tiny) emit_loop(std::integral_constant<int, 0>{});
+    else if (small) emit_loop(std::integral_constant<int, 1>{});
+    else emit_loop(std::integral_constant<int, 2>{});
     STAMP(7);
     STAMP_FLUSH(16, 8);
 }
