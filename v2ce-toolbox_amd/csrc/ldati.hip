@@ -1014,36 +1014,76 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
             if (!P.keys) atomicAdd(&hist[__umul24(w, (unsigned)P.NB) + (key >> P.shift)], 1u);
         }
         STAMP(3);
-        for (unsigned q = tid; q < Um; q += NT) {
-            const uint2 e = MU[q];
-            const unsigned local = e.x & (kTilePix - 1), jb = (e.x >> kLocalBits) & 0x1FFFFu, cnt = e.x >> 28;
-            const float2 kb = PT[local];
-            const unsigned px = (unsigned)x0 + local;
-            float u[4];
-            if (P.rng_mode == V2CE_RNG_REPLAY) {
-                const long long ub = (((long long)(b * 2 + pidx) * 9 + c) * P.HW + px) * P.replay_max_n;
+        // The common case -- Philox draws, 32-bit timestamps, the 'slope' strategy, the bucket machinery -- has its own copy of
+        // the loop without the per-event uniform tests (the pass is bound by instruction issue); COMMON 1 = with the checked
+        // fast k == 0 time, 2 = with the divisions.  The slope class is tested once per unit (waves are class-homogeneous).
+        auto multis = [&](auto common_c) {
+            constexpr int COMMON = decltype(common_c)::value;
+            const float offt_c = P.offt[c];
+            const int kbase_c = (int)P.kbase[c];
+            for (unsigned q = tid; q < Um; q += NT) {
+                const uint2 e = MU[q];
+                const unsigned local = e.x & (kTilePix - 1), jb = (e.x >> kLocalBits) & 0x1FFFFu, cnt = e.x >> 28;
+                const float2 kb = PT[local];
+                const unsigned px = (unsigned)x0 + local;
+                float u[4];
+                if (!COMMON && P.rng_mode == V2CE_RNG_REPLAY) {
+                    const long long ub = (((long long)(b * 2 + pidx) * 9 + c) * P.HW + px) * P.replay_max_n;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const int j = (int)(4u * jb) + s;
+                        u[s] = ((unsigned)s < cnt && j < P.replay_max_n) ? P.uniforms[ub + j] : 0.0f;
+                    }
+                } else {
+                    unsigned o[4];
+                    philox4(P.seed, px, jb, (unsigned)(pidx * 9 + c), frame, o);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) u[s] = u24(o[s]);
+                }
+                unsigned key[4];
+                if (COMMON) {
+                    float t[4];
+                    if (kb.x == 0.0f) {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                            t[s] = COMMON == 1 ? k0_time_fast(u[s], P.FPS, P.RFPS, P.R9) : (u[s] / P.FPS) / 9.0f;
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            const float sq = kb.y * kb.y + (2.0f * kb.x) * u[s];
+                            t[s] = (-kb.y + __builtin_sqrtf(sq)) / kb.x;
+                        }
+                    }
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {                   // multi_key's tail: (t + offt) * 1e6 -> key, clamped
+                        float tt = t[s] + offt_c;
+                        tt = tt * 1e6f;
+                        int k = (int)tt - kbase_c;
+                        k = k < 0 ? 0 : k;
+                        key[s] = (unsigned)(k >= P.NK ? P.NK - 1 : k);
+                    }
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        key[s] = P.ts32 ? multi_key(kb.x, kb.y, u[s], P.offt[c], (int)P.kbase[c], P, fast_k0)
+                                        : (unsigned)key_of(multi_ts(kb.x, kb.y, u[s], P.offt[c], P), P.kbase[c], P.NK);
+                }
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    const int j = (int)(4u * jb) + s;
-                    u[s] = ((unsigned)s < cnt && j < P.replay_max_n) ? P.uniforms[ub + j] : 0.0f;
-                }
-            } else {
-                unsigned o[4];
-                philox4(P.seed, px, jb, (unsigned)(pidx * 9 + c), frame, o);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) u[s] = u24(o[s]);
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                if ((unsigned)s < cnt) {
-                    const unsigned key = P.ts32 ? multi_key(kb.x, kb.y, u[s], P.offt[c], (int)P.kbase[c], P, fast_k0)
-                                                : (unsigned)key_of(multi_ts(kb.x, kb.y, u[s], P.offt[c], P), P.kbase[c], P.NK);
-                    const unsigned pos = Ns + e.y + s;
-                    S[pos] = (key << 12) | (1u << kLocalBits) | local;
-                    const unsigned w = (unsigned)(((float)pos + 0.5f) * invL);
-                    if (!P.keys) atomicAdd(&hist[__umul24(w, (unsigned)P.NB) + (key >> P.shift)], 1u);
+                    if ((unsigned)s < cnt) {
+                        const unsigned pos = Ns + e.y + s;
+                        S[pos] = (key[s] << 12) | (1u << kLocalBits) | local;
+                        const unsigned w = (unsigned)(((float)pos + 0.5f) * invL);
+                        if (COMMON || !P.keys) atomicAdd(&hist[__umul24(w, (unsigned)P.NB) + (key[s] >> P.shift)], 1u);
+                    }
                 }
             }
+        };
+        if (P.rng_mode == V2CE_RNG_PHILOX && P.ts32 && !P.keys && P.strategy == V2CE_STRATEGY_SLOPE) {
+            if (fast_k0) multis(std::integral_constant<int, 1>{});
+            else multis(std::integral_constant<int, 2>{});
+        } else {
+            multis(std::integral_constant<int, 0>{});
         }
         STAMP(4);
         __syncthreads();
