@@ -500,6 +500,19 @@ __device__ __forceinline__ void block_excl_scan2(unsigned a, unsigned e, unsigne
     e_ex = (wid ? (unsigned)__builtin_amdgcn_readlane((int)pe, wid - 1) : 0u) + ie - e;
 }
 
+// `want` consecutive slots of an LDS counter for every lane with ONE atomic per wave (all 64 lanes must be active):
+// a per-lane atomicAdd on one address is served lane by lane -- up to 64 LDS cycles per wave instruction.
+__device__ __forceinline__ unsigned wave_alloc(unsigned *counter, unsigned want, int lane) {
+    const unsigned incl = wave_incl_scan(want, lane);
+    const unsigned tot = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+    unsigned base = 0;
+    if (tot) {                                              // wave-uniform
+        if (lane == 63) base = atomicAdd(counter, tot);
+        base = (unsigned)__builtin_amdgcn_readlane((int)base, 63);
+    }
+    return base + incl - want;
+}
+
 // ---------------------------------------------------------------------------------------------
 // count: workgroup per (frame, tile); events per (tile, bin); max count per voxel
 // ---------------------------------------------------------------------------------------------
@@ -1246,7 +1259,8 @@ __global__ __launch_bounds__(kSparseThreads) void ldati_tile_sparse_kernel(Ldati
     if (tid < 9) { offt_s[tid] = P.offt[tid]; kbase_s[tid] = P.kbase[tid]; }
     __syncthreads();
 
-    // ---- 2a: classify; append to the lists
+    // ---- 2a: classify; append to the lists (slots from wave_alloc: one LDS atomic per wave, pixel and list)
+    const int lane_s = tid & 63;
 #pragma unroll
     for (int q = 0; q < PPT; ++q) {
         int nn[9];
@@ -1254,12 +1268,19 @@ __global__ __launch_bounds__(kSparseThreads) void ldati_tile_sparse_kernel(Ldati
         relocate_all(yv[q], P.bidir != 0, nn, td);
         const unsigned local = (unsigned)(lpx0 + q);
         const bool valid = x0 + lpx0 + q < P.HW;
+        unsigned ns = 0, nm = 0;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            const int n = valid ? nn[c] : 0;
+            ns += n == 1 ? 1u : 0u;
+            nm += (n >= 2 && P.strategy != V2CE_STRATEGY_NONE) ? 1u : 0u;
+        }
+        unsigned si = wave_alloc(&cur[0], ns, lane_s), mi0 = wave_alloc(&cur[1], nm, lane_s);
 #pragma unroll
         for (int c = 0; c < 9; ++c) {
             const int n = valid ? nn[c] : 0;
             if (n == 1) {
-                const unsigned i = atomicAdd(&cur[0], 1u);
-                SL[i] = make_uint2(__float_as_uint(td[c]), local | ((unsigned)c << kLocalBits));
+                SL[si++] = make_uint2(__float_as_uint(td[c]), local | ((unsigned)c << kLocalBits));
             } else if (n >= 2 && P.strategy != V2CE_STRATEGY_NONE) {
                 float k, bb;
                 if (P.kbb) {
@@ -1268,8 +1289,8 @@ __global__ __launch_bounds__(kSparseThreads) void ldati_tile_sparse_kernel(Ldati
                 } else {
                     slope_params(c > 0 ? nn[c - 1] : 0, n, c < 8 ? nn[c + 1] : 0, c, P, k, bb, stab);
                 }
-                const unsigned m = atomicAdd(&cur[1], 1u);
-                unsigned *e = MPtop - 3 * (m + 1);
+                unsigned *e = MPtop - 3 * (mi0 + 1);
+                ++mi0;
                 e[0] = local | ((unsigned)c << kLocalBits) | ((unsigned)n << 15);
                 e[1] = __float_as_uint(k);
                 e[2] = __float_as_uint(bb);
@@ -1307,15 +1328,18 @@ __global__ __launch_bounds__(kSparseThreads) void ldati_tile_sparse_kernel(Ldati
             const unsigned c = sl[j].y >> kLocalBits;
             const long long Tq = single_ts(__uint_as_float(sl[j].x), P.fps, offt_s[c]);
             const unsigned key = (unsigned)key_of(Tq, kbase_s[c], P.NK);
-            put(atomicAdd(&cur[2], 1u), c, key, 0u, sl[j].y & (kTilePix - 1));
+            put((unsigned)(tid + j * NT), c, key, 0u, sl[j].y & (kTilePix - 1));   // a single's record index = its list index
         }
     }
 #pragma unroll
     for (int j = 0; j < MPT; ++j) {
-        if ((unsigned)(tid + j * NT) < Nmp) {
+        if ((unsigned)(j * NT) >= Nmp) break;                // uniform: no multi-event pair left for anybody
+        const bool have = (unsigned)(tid + j * NT) < Nmp;
+        // the multi-event records follow the singles; cur[2] counts them (one atomic per wave)
+        const unsigned i0 = Ns + wave_alloc(&cur[2], have ? mi[j] >> 15 : 0u, lane_s);
+        if (have) {
             const unsigned local = mi[j] & (kTilePix - 1), c = (mi[j] >> kLocalBits) & 15u, n = mi[j] >> 15;
             const unsigned px = (unsigned)x0 + local;
-            const unsigned i0 = atomicAdd(&cur[2], n);
             const float offt = offt_s[c];
             const long long kb64 = kbase_s[c];
             for (unsigned jb = 0; 4u * jb < n; ++jb) {
@@ -1345,7 +1369,7 @@ __global__ __launch_bounds__(kSparseThreads) void ldati_tile_sparse_kernel(Ldati
         }
     }
     __syncthreads();
-    const unsigned N = cur[2];
+    const unsigned N = Ns + cur[2];
     if (N != ntot) {                                     // cannot happen: the count kernel saw the same voxels
         if (tid == 0) atomicExch(reinterpret_cast<unsigned *>(P.status), 3u);
         return;
