@@ -1143,13 +1143,25 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
         STAMP(6);
         // ---- P6: stable ranks: ballot match-any inside a 64-record batch, running base in LDS ----
         const unsigned lo = wid * L, hi = (lo + L < N) ? lo + L : N;
-        for (unsigned i0 = lo; i0 < hi; i0 += 64) {
-            const unsigned i = i0 + lane;
-            const bool has = i < hi;
-            const unsigned rec = has ? S[i] : 0u;
-            const unsigned bucket = rec >> (12 + P.shift);
-            const unsigned pos = take_slot(atomic_order, has, bucket, P.nb1, &hist[wid * P.NB + bucket]);
-            if (has) O[pos] = rec;
+        if (atomic_order) {                              // the rank IS what the LDS atomic returns (g_lds_order_ok)
+            unsigned *myhist = hist + wid * P.NB;
+            const unsigned sh = 12 + P.shift;
+            for (unsigned i0 = lo; i0 < hi; i0 += 64) {
+                const unsigned i = i0 + lane;
+                if (i < hi) {
+                    const unsigned rec = S[i];
+                    O[atomicAdd(&myhist[rec >> sh], 1u)] = rec;
+                }
+            }
+        } else {
+            for (unsigned i0 = lo; i0 < hi; i0 += 64) {
+                const unsigned i = i0 + lane;
+                const bool has = i < hi;
+                const unsigned rec = has ? S[i] : 0u;
+                const unsigned bucket = rec >> (12 + P.shift);
+                const unsigned pos = take_slots(has, bucket, P.nb1, &hist[wid * P.NB + bucket]);
+                if (has) O[pos] = rec;
+            }
         }
         STAMP(7);
         __syncthreads();
