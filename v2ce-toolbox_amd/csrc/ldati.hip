@@ -369,6 +369,28 @@ __device__ __forceinline__ unsigned take_slots(bool has, unsigned key, int nbits
     return pos;
 }
 
+// The same on a histogram that packs the counters of TWO waves into one word (16 bits each, `sh` = 0 or 16: the tile
+// pass): the word is shared with the neighbouring wave, so the group's slots are taken with one atomic add by its first
+// lane and handed to the peers through the LDS crossbar.
+__device__ __forceinline__ unsigned take_slots_packed(bool has, unsigned key, int nbits, unsigned *slot, unsigned sh) {
+    unsigned mlo = 0, mhi = 0;
+    const unsigned long long has_mask = __ballot(has);
+    for (int b = 0; b < nbits; ++b) {
+        const int sel = __builtin_amdgcn_sbfe((int)key, b, 1);
+        const unsigned long long m = __ballot(sel != 0);
+        mlo |= (unsigned)m ^ (unsigned)sel;
+        mhi |= (unsigned)(m >> 32) ^ (unsigned)sel;
+    }
+    const unsigned plo = (unsigned)has_mask & ~mlo, phi = (unsigned)(has_mask >> 32) & ~mhi;
+    const unsigned npeers = (unsigned)__popc(plo) + (unsigned)__popc(phi);
+    const unsigned rank = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+    const int leader = plo ? __builtin_ctz(plo) : 32 + __builtin_ctz(phi | 0x80000000u);
+    unsigned old = 0;
+    if (has && rank == 0) old = atomicAdd(slot, npeers << sh);
+    old = (unsigned)__shfl((int)old, leader);
+    return ((old >> sh) & 0xFFFFu) + rank;
+}
+
 // ---- ranks straight from LDS atomics ------------------------------------------------------------
 // On gfx950 one wave-instruction of ds_add_rtn_u32 serves the lanes that hit the same LDS word in
 // ascending lane order (tools/micro/lds_atomic_order.hip: 0 exceptions in 5.4e9 returned values),
@@ -863,7 +885,7 @@ __global__ __launch_bounds__(256) void ldati_emit_kernel(LdatiParams P) {
 // tile pass: workgroup per (frame, tile), NT threads, PPT consecutive pixels per thread, bin by bin
 // ---------------------------------------------------------------------------------------------
 // LDS map (dynamic): S [capA] u32 | O [capA + 2048] u32 (aliased by the unit tables while the
-// timestamps are computed) | PT [2048] {k, bb} | hist [NW][NB] u32 | misc
+// timestamps are computed) | PT [2048] {k, bb} | hist [NW/2][NB] u32 (two 16-bit chunk counters per word) | misc
 extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
 
 template <int NT, int PPT, bool BIDIR>
@@ -892,7 +914,7 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
     unsigned *O = S + P.capA;
     float2 *PT = reinterpret_cast<float2 *>(O + P.capA + 2048);
     unsigned *hist = reinterpret_cast<unsigned *>(PT + kTilePix);
-    unsigned *part = hist + NW * P.NB;                 // [NW + 1] x 2
+    unsigned *part = hist + (NW / 2) * P.NB;           // [NW] x 2 (hist: two 16-bit counters per word)
     // unit tables alias O: singles {debt bits, local} then multi units {info, event offset}
     uint2 *SL = reinterpret_cast<uint2 *>(O);
 
@@ -993,7 +1015,7 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
         // needs few: the histogram work below is proportional to NC)
         const unsigned NC = N > 256u * NW ? (unsigned)NW : (N + 255u) / 256u;
         const unsigned L = NC ? ((N + 64u * NC - 1u) / (64u * NC)) * 64u : 64u;
-        for (unsigned i = tid; i < NC * P.NB; i += NT) hist[i] = 0;
+        for (unsigned i = tid; i < ((NC + 1u) >> 1) * P.NB; i += NT) hist[i] = 0;   // (chunk pair, bucket): two 16-bit counters per word
         // ---- P3: unit tables ----------------------------------------------------------------
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
@@ -1024,7 +1046,7 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
             const unsigned key = (unsigned)key_of(Tq, P.kbase[c], P.NK);
             S[q] = (key << 12) | e.y;
             const unsigned w = (unsigned)(((float)q + 0.5f) * invL);
-            if (!P.keys) atomicAdd(&hist[__umul24(w, (unsigned)P.NB) + (key >> P.shift)], 1u);
+            if (!P.keys) atomicAdd(&hist[__umul24(w >> 1, (unsigned)P.NB) + (key >> P.shift)], 1u << ((w & 1u) * 16u));
         }
         STAMP(3);
         // The common case -- Philox draws, 32-bit timestamps, the 'slope' strategy, the bucket machinery -- has its own copy of
@@ -1087,7 +1109,7 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
                         const unsigned pos = Ns + e.y + s;
                         S[pos] = (key[s] << 12) | (1u << kLocalBits) | local;
                         const unsigned w = (unsigned)(((float)pos + 0.5f) * invL);
-                        if (COMMON || !P.keys) atomicAdd(&hist[__umul24(w, (unsigned)P.NB) + (key[s] >> P.shift)], 1u);
+                        if (COMMON || !P.keys) atomicAdd(&hist[__umul24(w >> 1, (unsigned)P.NB) + (key[s] >> P.shift)], 1u << ((w & 1u) * 16u));
                     }
                 }
             }
@@ -1115,24 +1137,28 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
         } else {
         // ---- P5: bucket-major, wave-minor exclusive scan; the tile's bucket counts and run offsets
         {
-            unsigned v[NW];
+            // (counts and offsets are below 2^16: a (tile, bin) holds at most kCapTile = 15360 records)
+            constexpr int NWP = NW / 2;                          // chunk pairs
+            const unsigned ncp = (NC + 1u) >> 1;
+            unsigned v[NWP];
             unsigned run = 0;
             if (tid < P.NB) {
 #pragma unroll
-                for (int w = 0; w < NW; ++w) v[w] = (unsigned)w < NC ? hist[w * P.NB + tid] : 0u;   // independent reads
+                for (int w = 0; w < NWP; ++w) v[w] = (unsigned)w < ncp ? hist[w * P.NB + tid] : 0u;   // independent reads
 #pragma unroll
-                for (int w = 0; w < NW; ++w) {
-                    const unsigned t0 = v[w];
-                    v[w] = run;
-                    run += t0;
+                for (int w = 0; w < NWP; ++w) {
+                    const unsigned lo = v[w] & 0xFFFFu, hi = v[w] >> 16;
+                    v[w] = run | ((run + lo) << 16);                // exclusive starts of the even and the odd chunk
+                    run += lo + hi;
                 }
             }
             unsigned tot;
             const unsigned boff = block_excl_scan<NW>(run, part, &tot);
             if (tid < P.NB) {
+                const unsigned b2 = boff | (boff << 16);
 #pragma unroll
-                for (int w = 0; w < NW; ++w)
-                    if ((unsigned)w < NC) hist[w * P.NB + tid] = v[w] + boff;
+                for (int w = 0; w < NWP; ++w)
+                    if ((unsigned)w < ncp) hist[w * P.NB + tid] = v[w] + b2;
             }
             // the tile's row of the run table: one contiguous, coalesced store
             unsigned short *row = P.roff + ((long long)(b * 9 + c) * P.T + t) * (P.NB + 1);
@@ -1144,13 +1170,13 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
         // ---- P6: stable ranks: ballot match-any inside a 64-record batch, running base in LDS ----
         const unsigned lo = wid * L, hi = (lo + L < N) ? lo + L : N;
         if (atomic_order) {                              // the rank IS what the LDS atomic returns (g_lds_order_ok)
-            unsigned *myhist = hist + wid * P.NB;
-            const unsigned sh = 12 + P.shift;
+            unsigned *myhist = hist + (wid >> 1) * P.NB;
+            const unsigned sh = 12 + P.shift, hs = (wid & 1) * 16;
             for (unsigned i0 = lo; i0 < hi; i0 += 64) {
                 const unsigned i = i0 + lane;
                 if (i < hi) {
                     const unsigned rec = S[i];
-                    O[atomicAdd(&myhist[rec >> sh], 1u)] = rec;
+                    O[(atomicAdd(&myhist[rec >> sh], 1u << hs) >> hs) & 0xFFFFu] = rec;
                 }
             }
         } else {
@@ -1159,7 +1185,7 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
                 const bool has = i < hi;
                 const unsigned rec = has ? S[i] : 0u;
                 const unsigned bucket = rec >> (12 + P.shift);
-                const unsigned pos = take_slots(has, bucket, P.nb1, &hist[wid * P.NB + bucket]);
+                const unsigned pos = take_slots_packed(has, bucket, P.nb1, &hist[(wid >> 1) * P.NB + bucket], (wid & 1) * 16);
                 if (has) O[pos] = rec;
             }
         }
@@ -2108,7 +2134,7 @@ Plan make_plan(const HostScalars &h, int B, int H, int W, int64_t total_events,
     p.n_tab = p.n_bkt * (size_t)p.T;
     p.tile_threads = tile_threads_choice(max_tile_events);
     p.lds_tile = (size_t)(2 * p.capA + 2048) * 4 + (size_t)kTilePix * 8 +
-                 (size_t)(p.tile_threads / 64) * p.NB * 4 + 2 * (p.tile_threads / 64 + 1) * 4;
+                 (size_t)(p.tile_threads / 128) * p.NB * 4 + 2 * (p.tile_threads / 64 + 1) * 4;
     const size_t bins = (size_t)4 * (size_t)(p.span << shift);          // <= 4 * max(kMaxSpanKeys, 2^shift)
     const size_t hist_bins = bins > 4 * (size_t)kMaxSpanKeys ? bins : 4 * (size_t)kMaxSpanKeys;
     const size_t tables = kSortWaves * hist_bins * 4 + (size_t)(2 * p.T) * 4 + (size_t)(2 * (p.cap2 / 32)) * 4 + (kSortWaves + 1) * 4;
