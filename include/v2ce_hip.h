@@ -124,8 +124,41 @@ int v2ce_ldati_status(const void *workspace, int B, int H, int W, double fps, do
  * Workspace layout (u32 units): bofs [n_bkt = B*9*(NB+1)] | groups [B*9*NB] | big_list [B*9*NB] | ngroups [B*9] |
  * seg_flag [B*9] | status [4] = {status, number of big buckets, -, -} | records [total] |
  * roff [n_tab = B*9*T*(NB+1)] as u16. */
+/* Fused count + sparse tile pass (round 4).  v2ce_ldati_count reads the voxel grid once to
+ * count and v2ce_ldati_emit reads it again to compute the timestamps.  On real UNet output every 2048-pixel tile is sparse
+ * (<= 8192 events over the nine bins): v2ce_ldati_count_fused does both in ONE pass -- it returns exactly what
+ * v2ce_ldati_count returns (seg_offsets, stats[0..3]; stats is int64[8] here, stats[4] = the largest tile's events over all
+ * nine bins) and leaves every sparse tile's bucket-grouped records in its own slot of `fused_ws` (needs the random-draw
+ * arguments of v2ce_ldati_emit for that).  v2ce_ldati_emit_fused is v2ce_ldati_emit with that workspace: when no tile
+ * exceeded its slot (largest_tile_events = stats[4] <= 8192) and the call's bucket geometry is the one the fused pass assumed
+ * (the geometry follows from the densest segment's events: expected_max_segment_events is the caller's guess, normally the
+ * previous batch's stats[2]; the same value goes to all three functions), only the bucket scan and the bucket sort remain; otherwise it ignores fused_ws and runs
+ * the two-pass path -- same bytes either way (tests/test_gpu_ldati.py::test_fused_count_equals_two_pass).
+ * v2ce_ldati_fused_ws_bytes = 0: no fused path for these options ('random', pooled slope) -- use v2ce_ldati_count. */
+size_t v2ce_ldati_fused_ws_bytes(int B, int H, int W, double fps, double t0, const v2ce_ldati_options *options,
+                                 int64_t expected_max_segment_events);
+int v2ce_ldati_count_fused(const float *vox, int B, int H, int W, double fps, double t0, const v2ce_ldati_options *options,
+                           int rng_mode, const float *uniforms, int replay_max_n, uint64_t seed, int64_t frame_base,
+                           int64_t expected_max_segment_events, void *tile_ws, size_t tile_ws_bytes, void *fused_ws, size_t fused_ws_bytes,
+                           int64_t *seg_offsets /* [B*9+1] */, int64_t *stats /* [8] */, v2ce_stream_t stream);
+int v2ce_ldati_emit_fused(const float *vox, int B, int H, int W, double fps, double t0, const v2ce_ldati_options *options,
+                          int rng_mode, const float *uniforms, int replay_max_n, uint64_t seed, int64_t frame_base,
+                          const int64_t *seg_offsets, const int64_t *frame_ts_add, int64_t *ts, int16_t *x, int16_t *y,
+                          int8_t *p, uint8_t *packed, int64_t total_events, int64_t max_segment_events,
+                          int64_t max_tile_events, const void *tile_ws, void *workspace, size_t workspace_bytes,
+                          const void *fused_ws, size_t fused_ws_bytes, int64_t largest_tile_events,
+                          int64_t expected_max_segment_events, v2ce_stream_t stream);
+
 int v2ce_ldati_plan_info(int B, int H, int W, double fps, double t0, const v2ce_ldati_options *options,
                          int64_t total_events, int64_t max_segment_events, int64_t max_tile_events, int64_t *info);
+
+/* Diagnostic (tests/test_gpu_ldati.py::test_exact_math_helpers), never called by the product: the dense tile kernel's
+ * Philox path evaluates LDATI.py:195's  (-b + sqrt(b^2 + 2 k u)) / k  with hand-scheduled correctly rounded sequences
+ * (csrc/ldati.hip: sqrt_rn_nr, div_rn_nr) and its Philox rounds on three-input xors.  This entry compares them with the
+ * compiler's IEEE square root / division for EVERY slope-table entry (|count difference| <= 31, count <= 31) and EVERY
+ * uniform m * 2^-24, and with the plain Philox rounds: mismatches[0] = differing times, mismatches[1] = differing
+ * Philox outputs (both must be 0).  Synchronous; ~0.1 s on MI355X. */
+int v2ce_ldati_selfcheck(double fps, int64_t *mismatches /* host [2] */);
 
 /* How the stable tie order inside the LDS counting sorts is obtained on the current device: 1 = straight from the
  * lane order in which one ds_add_rtn_u32 wave-instruction serves equal addresses (checked once per device by a probe

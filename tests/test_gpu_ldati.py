@@ -342,3 +342,136 @@ def test_unphysical_voxels_are_refused():
     assert time.perf_counter() - t0 < 5.0
     vox[0, 0, 3, 5, 7] = 4000.0                                  # large but within the limits: runs, bit-exact
     soa_equal(hip_events(vox, seed=1), *O.emit_soa(vox, fps=30, seed=1))
+
+
+def test_exact_math_helpers():
+    """The dense tile kernel's hand-scheduled square root / division (sqrt_rn_nr, div_rn_nr) and its bitop3 Philox rounds
+    against the compiler's IEEE operations and the plain rounds: every slope-table entry x every Philox uniform
+    (v2ce_ldati_selfcheck), at the CLI's fps and two others."""
+    import ctypes
+    for fps in (30.0, 25.0, 120.0):
+        bad = (ctypes.c_int64 * 2)()
+        hip.check(hip.lib().v2ce_ldati_selfcheck(fps, bad), "v2ce_ldati_selfcheck")
+        assert (bad[0], bad[1]) == (0, 0), f"fps {fps}: {bad[0]} time mismatches, {bad[1]} Philox mismatches"
+
+
+def test_dense_tile_kernel_equals_per_bin_kernel(gold_dir, monkeypatch):
+    """ldati_tile_dense_kernel (round 4: the common call's dense tiles) and ldati_tile_pass_kernel (every other option,
+    forced with V2CE_LDATI_OLD_TILE=1) are two implementations of one pass: same bytes on Philox stress frames (both
+    workgroup sizes: the second case needs the 16-wave form), on mixed frames, on a voxel outside the slope table, with
+    replayed uniforms (G4: the reference's own bytes), in 'none' mode and through the forced ballot ranks."""
+    def both(run):
+        monkeypatch.delenv("V2CE_LDATI_OLD_TILE", raising=False)
+        a = run()
+        monkeypatch.setenv("V2CE_LDATI_OLD_TILE", "1")
+        b = run()
+        monkeypatch.delenv("V2CE_LDATI_OLD_TILE")
+        assert a.packed().cpu().numpy().tobytes() == b.packed().cpu().numpy().tobytes()
+        assert np.array_equal(a.seg_counts, b.seg_counts)
+        return a
+
+    vox = synth.synthetic_voxels(2, 260, 346, seed=5, regime="stress")
+    ev = both(lambda: hip_events(vox, seed=31, frame_base=3))
+    seg, ts, x, y, p = O.emit_soa(vox[:1], fps=30, seed=31, frame_base=3)
+    n0 = int(seg.sum())
+    assert np.array_equal(ev.seg_counts[:1], seg) and np.array_equal(ev.ts.cpu().numpy()[:n0], ts)
+    assert np.array_equal(ev.x.cpu().numpy()[:n0], x) and np.array_equal(ev.p.cpu().numpy()[:n0], p)
+    dense = (10.0 * np.random.default_rng(3).random((1, 2, 10, 100, 160))).astype(np.float32)      # ~100 events per pixel
+    soa_equal(both(lambda: hip_events(dense, seed=8)), *O.emit_soa(dense, fps=30, seed=8))
+    rng = np.random.default_rng(21)
+    mix = np.zeros((2, 2, 10, 96, 160), np.float32)
+    mix[:, :, :, :40] = np.maximum(0.25 * rng.standard_normal((2, 2, 10, 40, 160)), 0)
+    mix[:, :, :, 40:] = 4.0 * rng.random((2, 2, 10, 56, 160))
+    mix[0, 0, 4, 50, 7] = 45.0                                    # count 45 > 31: outside the slope table (owner-lane path)
+    mix[1, 1, 2, 70, 9] = 60.0                                    # neighbours' difference > 31
+    for fps, t0 in ((30, 0), (60, 0.5)):
+        soa_equal(both(lambda: hip_events(mix, fps, t0, seed=77, frame_base=1)), *O.emit_soa(mix, fps=fps, t0=t0, seed=77, frame_base=1))
+    soa_equal(both(lambda: hip_events(mix, seed=5, strategy="none")), *O.emit_soa(mix, fps=30, seed=5, strategy="none"))
+    monkeypatch.setenv("V2CE_LDATI_NO_ATOMIC_ORDER", "1")
+    soa_equal(both(lambda: hip_events(mix, seed=78)), *O.emit_soa(mix, fps=30, seed=78))
+    monkeypatch.delenv("V2CE_LDATI_NO_ATOMIC_ORDER")
+    # replayed uniforms: G4, the reference's own bytes
+    meta = json.load(open(os.path.join(gold_dir, "ldati_g4.json")))
+    H, W = meta["H"], meta["W"]
+    vox4 = synth.synthetic_voxels(1, H, W, seed=meta["vox_seed"], regime=meta["vox_regime"])
+    mt = np.random.MT19937()
+    mt._legacy_seeding(meta["torch_seed"])
+    n = 2 * 9 * H * W * meta["max_n"]
+    u4 = ((mt.random_raw(n).astype(np.uint32) & 0xFFFFFF).astype(np.float32) * np.float32(2.0 ** -24)).reshape(1, 2, 9, H, W, meta["max_n"])
+    ev = both(lambda: hip_events(vox4, meta["fps"], meta["t0"], uniforms=u4))
+    assert hashlib.sha256(ev.to_recarrays()[0].tobytes()).hexdigest() == meta["sha256_packed_events"]
+
+
+def test_c5_stress_chunk_full_size(monkeypatch):
+    """BASELINE config 5 at the size bench.py times: 24 frame-pairs of 346x260 `6 U[0,1)` voxels, Philox (127.7 M events:
+    the fullest chunk histograms, 32-bit record offsets).  Counts of the first and the last frame vs the oracle, sortedness
+    inside every segment, the first and last frame's events vs the oracle, one frame byte-equal with the sweep path, and
+    the same chunk once through the forced ballot ranks."""
+    vox = synth.synthetic_voxels(24, 260, 346, seed=7, regime="stress")
+    y = torch.from_numpy(vox).cuda()
+    from v2ce_toolbox_amd.LDATI import ldati_device
+
+    def run():
+        ev = ldati_device(y, fps=30, seed=0x5EED, frame_base=11)
+        torch.cuda.synchronize()
+        ev.check()
+        return ev
+    ev = run()
+    assert ev.num_events > 120_000_000
+    seg_first, _ = O.count(vox[:1])
+    seg_last, _ = O.count(vox[-1:])
+    assert np.array_equal(ev.seg_counts[:1], seg_first) and np.array_equal(ev.seg_counts[-1:], seg_last)
+    ts = ev.ts
+    offs = np.concatenate([[0], np.cumsum(ev.seg_counts.reshape(-1))])
+    neg = (torch.nonzero(ts[1:] < ts[:-1]).flatten() + 1).cpu().numpy()
+    assert set(neg.tolist()) <= set(offs.tolist()), "timestamps must be sorted inside every segment"
+    x, yy, p = ev.x, ev.y, ev.p
+    assert int(x.min()) >= 0 and int(x.max()) <= 345 and int(yy.min()) >= 0 and int(yy.max()) <= 259
+    for f in (0, 23):
+        lo, hi = int(ev.frame_counts[:f].sum()), int(ev.frame_counts[:f + 1].sum())
+        seg, ots, ox, oy, op = O.emit_soa(vox[f:f + 1], fps=30, seed=0x5EED, frame_base=11 + f)
+        assert np.array_equal(ts[lo:hi].cpu().numpy(), ots) and np.array_equal(x[lo:hi].cpu().numpy(), ox)
+        assert np.array_equal(yy[lo:hi].cpu().numpy(), oy) and np.array_equal(p[lo:hi].cpu().numpy(), op)
+    sweep = hip_events(vox[5:6], seed=0x5EED, frame_base=16, path="sweep")
+    lo, hi = int(ev.frame_counts[:5].sum()), int(ev.frame_counts[:6].sum())
+    assert sweep.packed().cpu().numpy().tobytes() == ev.packed()[13 * lo:13 * hi].cpu().numpy().tobytes()
+    whole = ev.packed().cpu().numpy().tobytes()
+    del ev, ts, x, yy, p
+    monkeypatch.setenv("V2CE_LDATI_NO_ATOMIC_ORDER", "1")
+    assert run().packed().cpu().numpy().tobytes() == whole
+
+
+def test_fused_count_equals_two_pass(gold_dir, monkeypatch):
+    """v2ce_ldati_count_fused (one pass over the voxels: counts + the sparse tiles' records in per-tile slots) against the
+    two-pass path (V2CE_LDATI_NO_FUSED=1): same counts and same bytes on sparse full-size frames (the fused records are
+    used), on frames with dense tiles (emit falls back by itself), at a low fps whose geometry differs, with replayed
+    uniforms, 'none', bidirectional relocation and an event-free call."""
+    def both(run):
+        monkeypatch.delenv("V2CE_LDATI_NO_FUSED", raising=False)
+        first = run()                                    # (the first call of a shape has no geometry hint and may fall back)
+        a = run()
+        assert first.packed().cpu().numpy().tobytes() == a.packed().cpu().numpy().tobytes()
+        monkeypatch.setenv("V2CE_LDATI_NO_FUSED", "1")
+        b = run()
+        monkeypatch.delenv("V2CE_LDATI_NO_FUSED")
+        assert np.array_equal(a.seg_counts, b.seg_counts) and a.max_n == b.max_n
+        assert a.packed().cpu().numpy().tobytes() == b.packed().cpu().numpy().tobytes()
+        return a
+
+    vox = synth.synthetic_voxels(3, 260, 346, seed=12, regime="sparse")
+    soa_equal(both(lambda: hip_events(vox, seed=3, frame_base=9)), *O.emit_soa(vox, fps=30, seed=3, frame_base=9))
+    add = np.array([5, 33338, 66671], np.int64)
+    both(lambda: hip_events(vox, seed=3, frame_base=9, frame_ts_add=add, layout="soa"))
+    rng = np.random.default_rng(2)
+    mix = np.zeros((2, 2, 10, 96, 160), np.float32)
+    mix[:, :, :, :48] = np.maximum(0.3 * rng.standard_normal((2, 2, 10, 48, 160)), 0)
+    mix[1, :, :, 48:] = 3.0 * rng.random((2, 10, 48, 160))                  # dense tiles in the second frame only
+    soa_equal(both(lambda: hip_events(mix, seed=4)), *O.emit_soa(mix, fps=30, seed=4))
+    small = synth.synthetic_voxels(2, 40, 50, seed=10, regime="stress")
+    soa_equal(both(lambda: hip_events(small, 10, seed=77, frame_base=3)), *O.emit_soa(small, fps=10, seed=77, frame_base=3))
+    soa_equal(both(lambda: hip_events(vox[:1], seed=6, strategy="none")), *O.emit_soa(vox[:1], fps=30, seed=6, strategy="none"))
+    soa_equal(both(lambda: hip_events(vox[:1], seed=6, bidirectional=True)), *O.emit_soa(vox[:1], fps=30, seed=6, bidirectional=True))
+    z = np.load(os.path.join(gold_dir, "ldati_g3_ragged.npz"))
+    soa_equal(both(lambda: hip_events(z["vox"], float(z["fps"]), float(z["t0"]), uniforms=z["uniforms"])),
+              *O.emit_soa(z["vox"], fps=float(z["fps"]), t0=float(z["t0"]), uniforms=z["uniforms"]))
+    assert both(lambda: hip_events(np.zeros((2, 2, 10, 30, 40), np.float32), seed=1)).num_events == 0

@@ -135,6 +135,9 @@ class _PinnedPool:
 
 
 _PINNED = _PinnedPool()
+# densest-segment event count of the previous call with the same shape and options: the fused count pass assumes the
+# bucket geometry that follows from it (consecutive batches of a clip agree; a miss costs one two-pass call)
+_SEG_HINT = {}
 
 
 class PendingLdati:
@@ -187,12 +190,37 @@ def ldati_begin(y: torch.Tensor, t0=0, fps=30, *, rng: str = "philox", seed: Opt
         if path == "sweep" and not plain:
             raise hip.V2ceHipError("path='sweep' covers forward relocation without pooling ('slope' / 'none')")
         tile_ws = torch.empty(L.v2ce_ldati_tile_ws_bytes(B, H, W), dtype=torch.uint8, device=dev)
-        meta = torch.empty(B * 9 + 1 + 4, dtype=torch.int64, device=dev)       # seg_offsets | stats
+        meta = torch.empty(B * 9 + 1 + 8, dtype=torch.int64, device=dev)       # seg_offsets | stats
+        # the random draws are fixed here (not in finish): the fused count below already computes timestamps
+        mode, u_keep, replay_max_n = hip.RNG_PHILOX, None, 0
+        if uniforms is not None:
+            u_keep = hip.require_device_f32(uniforms.to(dev), "uniforms")
+            if u_keep.dim() != 6 or tuple(u_keep.shape[:5]) != (B, 2, 9, H, W):
+                raise ValueError(f"uniforms must be [B,2,9,H,W,>=max_n], got {tuple(u_keep.shape)}")
+            mode, replay_max_n = hip.RNG_REPLAY, int(u_keep.shape[5])
+        elif rng == "philox" and seed is None:     # reproducible under torch.manual_seed, like the reference's draw
+            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+        # One pass over the voxels instead of two (v2ce_ldati_count_fused): counts AND the sparse tiles' records; finish()
+        # falls back to the two-pass path by itself when a tile was dense.  rng='torch' draws its tensor after the counts.
+        fused_ws, seg_hint, hint_key = None, 0, None
+        if path == "bucket" and (rng == "philox" or uniforms is not None) and os.environ.get("V2CE_LDATI_NO_FUSED") is None:
+            hint_key = (dev.index, B, H, W, float(fps), float(t0), strategy, bool(bidirectional))
+            seg_hint = int(_SEG_HINT.get(hint_key, 0))
+            fb = L.v2ce_ldati_fused_ws_bytes(B, H, W, float(fps), float(t0), ctypes.byref(opts), seg_hint)
+            if fb:
+                fused_ws = torch.empty(fb, dtype=torch.uint8, device=dev)
         if profile is not None:    # HIP events on the launch stream around the count kernels
             c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             c0.record()
-        hip.check(L.v2ce_ldati_count(y.data_ptr(), B, H, W, ctypes.byref(opts), tile_ws.data_ptr(), tile_ws.numel(),
-                                     meta.data_ptr(), meta[B * 9 + 1:].data_ptr(), st), "v2ce_ldati_count")
+        if fused_ws is not None:
+            hip.check(L.v2ce_ldati_count_fused(y.data_ptr(), B, H, W, float(fps), float(t0), ctypes.byref(opts), mode, hip.ptr(u_keep),
+                                               replay_max_n, int(seed or 0) & (2 ** 64 - 1), int(frame_base), seg_hint, tile_ws.data_ptr(),
+                                               tile_ws.numel(), fused_ws.data_ptr(), fused_ws.numel(), meta.data_ptr(),
+                                               meta[B * 9 + 1:].data_ptr(), st), "v2ce_ldati_count_fused")
+        else:
+            meta[B * 9 + 5:].zero_()
+            hip.check(L.v2ce_ldati_count(y.data_ptr(), B, H, W, ctypes.byref(opts), tile_ws.data_ptr(), tile_ws.numel(),
+                                         meta.data_ptr(), meta[B * 9 + 1:].data_ptr(), st), "v2ce_ldati_count")
         if profile is not None:
             c1.record()
             profile.append(("count", c0, c1, 0))
@@ -200,9 +228,9 @@ def ldati_begin(y: torch.Tensor, t0=0, fps=30, *, rng: str = "philox", seed: Opt
         host.copy_(meta, non_blocking=True)
         ready = torch.cuda.Event()
         ready.record()
-    return PendingLdati(y=y, t0=t0, fps=fps, rng=rng, seed=seed, frame_base=frame_base, uniforms=uniforms,
+    return PendingLdati(y=y, t0=t0, fps=fps, rng=rng, seed=seed, frame_base=frame_base, uniforms=u_keep,
                         frame_ts_add=frame_ts_add, profile=profile, path=path, opts=opts, plain=plain, layout=layout,
-                        tile_ws=tile_ws, meta=meta, host=host, ready=ready)
+                        tile_ws=tile_ws, meta=meta, host=host, ready=ready, fused_ws=fused_ws, seg_hint=seg_hint, hint_key=hint_key)
 
 
 def _ldati_finish(q: PendingLdati) -> DeviceEvents:
@@ -215,21 +243,20 @@ def _ldati_finish(q: PendingLdati) -> DeviceEvents:
     host = q.host.numpy().copy()
     _PINNED.put(q.host)
     offs = host[:B * 9 + 1]
-    max_n, max_tile, max_seg, total = (int(v) for v in host[B * 9 + 1:])
+    max_n, max_tile, max_seg, total, tile_all = (int(v) for v in host[B * 9 + 1:B * 9 + 6])
     segc = np.diff(offs).reshape(B, 9)
+    if q.hint_key is not None:
+        _SEG_HINT[q.hint_key] = max_seg
 
     mode, u_ptr, replay_max_n = hip.RNG_PHILOX, None, 0
     keep, seed, uniforms = None, q.seed, q.uniforms
     if uniforms is not None:
-        uniforms = hip.require_device_f32(uniforms.to(dev), "uniforms")
-        if tuple(uniforms.shape[:5]) != (B, 2, 9, H, W) or uniforms.shape[5] < max_n:
+        if uniforms.shape[5] < max_n:
             raise ValueError(f"uniforms must be [B,2,9,H,W,>=max_n={max_n}], got {tuple(uniforms.shape)}")
         mode, u_ptr, replay_max_n, keep = hip.RNG_REPLAY, uniforms.data_ptr(), uniforms.shape[5], uniforms
     elif q.rng == "torch":
         keep = torch.rand([B, 2, 9, H, W, max_n], device=dev)      # LDATI.py:171
         mode, u_ptr, replay_max_n = hip.RNG_REPLAY, keep.data_ptr(), max_n
-    elif seed is None:     # reproducible under torch.manual_seed, like the reference's draw
-        seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
 
     # An unphysical voxel grid (values in the thousands: a broken checkpoint, un-normalised input) asks for billions of events;
     # the reference dies there allocating its dense [B,2,9,H,W,max_n] tensors (LDATI.py:171).  Refuse before anything of that
@@ -271,11 +298,14 @@ def _ldati_finish(q: PendingLdati) -> DeviceEvents:
         if q.profile is not None:    # HIP events on the launch stream around the emit kernels
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        hip.check(L.v2ce_ldati_emit(y.data_ptr(), B, H, W, float(fps), float(t0), ctypes.byref(q.opts), mode, u_ptr,
-                                    int(replay_max_n), int(seed or 0) & (2 ** 64 - 1), int(q.frame_base),
-                                    q.meta.data_ptr(), add_ptr, ptrs[0], ptrs[1], ptrs[2], ptrs[3], ptrs[4],
-                                    total, max_seg, max_tile, q.tile_ws.data_ptr(), hip.ptr(ws), int(ws_bytes), st),
-                  "v2ce_ldati_emit")
+        args = (y.data_ptr(), B, H, W, float(fps), float(t0), ctypes.byref(q.opts), mode, u_ptr,
+                int(replay_max_n), int(seed or 0) & (2 ** 64 - 1), int(q.frame_base),
+                q.meta.data_ptr(), add_ptr, ptrs[0], ptrs[1], ptrs[2], ptrs[3], ptrs[4],
+                total, max_seg, max_tile, q.tile_ws.data_ptr(), hip.ptr(ws), int(ws_bytes))
+        if q.fused_ws is not None and ws is not None:
+            hip.check(L.v2ce_ldati_emit_fused(*args, q.fused_ws.data_ptr(), q.fused_ws.numel(), tile_all, q.seg_hint, st), "v2ce_ldati_emit_fused")
+        else:
+            hip.check(L.v2ce_ldati_emit(*args, st), "v2ce_ldati_emit")
         if q.profile is not None:
             e1.record()
             # algorithmic bytes: 80 B per pixel read once + 13 B per event written once
@@ -286,7 +316,7 @@ def _ldati_finish(q: PendingLdati) -> DeviceEvents:
                                           max_tile, ctypes.byref(sp)), "v2ce_ldati_status")
             off = (sp.value - ws.data_ptr())
             ev._status = ws[off:off + 4].view(torch.int32)
-    ev._keepalive = (y, keep, frame_ts_add, q.meta, q.tile_ws, ws)
+    ev._keepalive = (y, keep, frame_ts_add, q.meta, q.tile_ws, ws, q.fused_ws)
     return ev
 
 

@@ -111,6 +111,12 @@ struct LdatiParams {
     int sweep_ok;
     int ballot_ranks;             // 1 = ignore g_lds_order_ok and rank with the ballot match-any (V2CE_LDATI_NO_ATOMIC_ORDER=1: the
                                   // fallback a device that fails the probe would take, forced so that tests can run it)
+    // fused count + sparse tile pass (v2ce_ldati_count_fused): every tile owns a slot of kSparseCap records
+    unsigned *tc_w;               // [B][T][9] tile counts, written by the fused kernel
+    unsigned long long *stats_w;  // [5] max voxel count | - | - | - | largest tile total (all nine bins)
+    unsigned *tile_abs_w;         // [B*9][T] record index of the (tile, bin) run inside `temp`
+    const unsigned *tile_abs;     // the same, read by the bucket sort (null: runs at seg_offsets + tile_off)
+    const int *fused_status;      // status word of the fused kernel, folded into `status` by the bucket scan
 };
 
 // ---- Philox4x32-10, counter (pixel, j>>2, p*9+c, frame), key = seed ---------------------------
@@ -1222,6 +1228,423 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// dense tile pass, round 4: the common call (forward relocation, 'slope' / 'none', no pooling, 32-bit times).
+//
+// What the SQ counters said about ldati_tile_pass_kernel on the stress chunk (profiles/r04_a_ldati_sq_counters.txt): its
+// waves are PARKED half of their cycles (six workgroup barriers and two workgroup scans per bin, one 1024-thread
+// workgroup per CU with nobody to run in the gaps), 182 VALU lane-slots per event at 78 % active lanes.  This kernel
+// keeps the algorithm (per bin: every timestamp once, stable counting sort by coarse bucket, one coalesced run) and
+// changes what that costs:
+//   * a wave OWNS 64 * PPT consecutive pixels: classification, the unit compaction (so that every lane of the
+//     timestamp code is busy) and the record positions come from 64-lane DPP scans, the unit tables are private to the
+//     wave, and the wave's own row of the histogram counts the records it will later rank -- no workgroup scan, no
+//     chunk arithmetic per record; the waves meet at four barriers per bin (wave totals, histogram complete, bucket
+//     offsets ready, run complete);
+//   * the slope parameters {k, b} of a multi-event voxel travel as an 11-bit index into g_slope_tab inside the unit
+//     entry (a voxel outside the table is generated by its owner lane in place), so no per-pixel table occupies LDS:
+//     records in, records out, NW histogram rows -- two 512-thread workgroups fit a CU and cover each other's barriers;
+//   * Philox rounds on v_bitop3_b32 (three-input xor), and for Philox draws the square root and the division of
+//     LDATI.py:195 as the compiler's own correctly rounded sequences minus their range scaling, with the refined
+//     reciprocal of the voxel's slope shared by its four draws (sqrt_rn_nr / div_rn_nr below: identical results inside
+//     the ranges the slope table spans; tests/test_gpu_ldati.py::test_exact_math_helpers checks them exhaustively).
+// Everything else (bidirectional, pooled slope, 'random', 64-bit times, a table that is not ready) stays on
+// ldati_tile_pass_kernel; both produce the same bytes (test_dense_tile_kernel_equals_per_bin_kernel).
+// LDS map (dynamic): S [capA] u32 | O [capA + 2 NW + 2] u32 (the unit tables alias the wave's slice) | hist [NW/2][NB] (two
+// 16-bit counters per word) | misc
+// ---------------------------------------------------------------------------------------------
+// correctly rounded sqrt for a == 0, a >= 2^-96, negative or NaN a: v_sqrt_f32 (1 ulp) and the two residual tests of the
+// compiler's expansion (which additionally rescales a < 2^-96: never the case for b^2 + 2 k u of a table entry)
+__device__ __forceinline__ float sqrt_rn_nr(float a) {
+    const float r = __builtin_amdgcn_sqrtf(a);
+    const float rdn = __uint_as_float(__float_as_uint(r) - 1u), rup = __uint_as_float(__float_as_uint(r) + 1u);
+    const float edn = __builtin_fmaf(-rdn, r, a), eup = __builtin_fmaf(-rup, r, a);
+    float o = (0.0f >= edn) ? rdn : r;
+    o = (0.0f < eup) ? rup : o;
+    return o;
+}
+// the refined reciprocal of the compiler's f32 division (v_rcp_f32 + one Newton step)
+__device__ __forceinline__ float rcp_refined(float k) {
+    const float r0 = __builtin_amdgcn_rcpf(k);
+    const float e = __builtin_fmaf(-k, r0, 1.0f);
+    return __builtin_fmaf(e, r0, r0);
+}
+// x / k, correctly rounded, by the compiler's sequence without v_div_scale / v_div_fixup: valid while neither rescales,
+// i.e. k and 1/k normal, x zero, NaN or >= 2^-103 in magnitude, x / k normal (LDATI: |k| in [1e2, 1e8], x = sqrt(.) - b)
+__device__ __forceinline__ float div_rn_nr(float x, float k, float r1) {
+    float q = x * r1;
+    float rem = __builtin_fmaf(-k, q, x);
+    q = __builtin_fmaf(rem, r1, q);
+    rem = __builtin_fmaf(-k, q, x);
+    return __builtin_fmaf(rem, r1, q);
+}
+// Philox4x32-10 as philox4(), the two three-input xors of a round as one v_bitop3_b32 each
+__device__ __forceinline__ void philox4_b3(unsigned long long seed, unsigned pixel, unsigned jb, unsigned pc, unsigned frame,
+                                           unsigned (&out)[4]) {
+    unsigned c0 = pixel, c1 = jb, c2 = pc, c3 = frame;
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = __builtin_amdgcn_bitop3_b32((unsigned)(p1 >> 32), c1, k0, 0x96);
+        const unsigned n2 = __builtin_amdgcn_bitop3_b32((unsigned)(p0 >> 32), c3, k1, 0x96);
+        c0 = n0; c1 = (unsigned)p1; c2 = n2; c3 = (unsigned)p0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// slope-table index of a multi-event voxel, or -1 when it lies outside the table (slope_params' own test)
+__device__ __forceinline__ int slope_index(int n_l, int n_c, int n_r, int c) {
+    const int d = (c == 0 || c == 8) ? 0 : n_r - n_l;
+    if (d >= -kSlopeM && d <= kSlopeM && n_c >= 0 && n_c <= kSlopeM && n_l >= 0 && n_r >= 0 && n_l < (1 << 23) && n_r < (1 << 23))
+        return (d + kSlopeM) * (kSlopeM + 1) + n_c;
+    return -1;
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 4) void ldati_tile_dense_kernel(LdatiParams P) {   // 4 waves per SIMD: two 512-thread workgroups per CU
+    constexpr int NT = 64 * NW, PPT = kTilePix / NT, WPX = 64 * PPT, NWP = NW / 2;
+    static_assert(PPT == 4 || PPT == 2, "a lane owns 2 or 4 consecutive pixels");
+    const int t = blockIdx.x, b = blockIdx.y;
+    if (P.sparse_cap) {                                 // the sparse tile kernel owns the lightly populated tiles
+        const unsigned *tcr = P.tc + ((long long)b * P.T + t) * 9;
+        unsigned ntot = 0;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) ntot += tcr[c];
+        if (ntot <= (unsigned)P.sparse_cap) return;
+    }
+    const int pidx = t < P.tpp ? 1 : 0;
+    const int x0 = (t < P.tpp ? t : t - P.tpp) * kTilePix;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool atomic_order = !P.ballot_ranks && __builtin_amdgcn_readfirstlane(g_lds_order_ok) != 0;
+    const bool slot_ok = P.fast_slot >= 0 &&
+                         __builtin_amdgcn_readfirstlane((int)g_fastdiv[P.fast_slot >= 0 ? P.fast_slot : 0].fps_bits) == (int)__float_as_uint(P.FPS);
+    const bool philox = P.rng_mode == V2CE_RNG_PHILOX;
+    const bool fast_k0 = slot_ok && philox && __builtin_amdgcn_readfirstlane(g_fastdiv[P.fast_slot].ok) != 0;
+    // (a table that another stream is still filling: every multi-event voxel takes the owner-lane path once)
+    const bool tab_ok = slot_ok && __builtin_amdgcn_readfirstlane(g_fastdiv[P.fast_slot].tab_ready) != 0;
+    const float2 *stab = g_slope_tab[P.fast_slot >= 0 ? P.fast_slot : 0];
+
+    unsigned *S = reinterpret_cast<unsigned *>(tile_smem);
+    unsigned *O = S + P.capA;
+    unsigned *hist = O + P.capA + 2 * NW + 2;           // [NW / 2][NB]: the 16-bit counters of waves 2j and 2j + 1 share a word
+    unsigned *part = hist + NWP * P.NB;                 // [NW] wave totals | [NW + 1] scan partials
+    unsigned *spart = part + NW;
+    unsigned *myhist = hist + (wid >> 1) * P.NB;
+    const unsigned hsh = (unsigned)(wid & 1) * 16u, hone = 1u << hsh;
+
+    const float *plane0 = P.vox + (long long)(b * 2 + pidx) * 10 * P.HW;
+    const unsigned frame = (unsigned)(P.frame_base + b);
+    const int lpx0 = wid * WPX + lane * PPT;           // the lane's PPT consecutive local pixels: lpx0 + q
+    const int gpx0 = x0 + lpx0;
+    const bool vec = (P.HW & 3) == 0;                  // every plane 16-byte aligned: one load per plane and lane
+    const float eps = 1e-6f;
+
+    // one plane's voxels of the lane's pixels (zero past the image)
+    auto load_plane = [&](int plane, float (&y)[PPT]) {
+        const float *src = plane0 + (long long)plane * P.HW + gpx0;
+        if (vec) {
+            if (PPT == 4) {
+                const float4 v = gpx0 < P.HW ? *reinterpret_cast<const float4 *>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+                y[0] = v.x; y[1] = v.y; y[PPT - 2] = v.z; y[PPT - 1] = v.w;
+            } else {
+                const float2 v = gpx0 < P.HW ? *reinterpret_cast<const float2 *>(src) : make_float2(0.f, 0.f);
+                y[0] = v.x; y[1] = v.y;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) y[q] = gpx0 + q < P.HW ? src[q] : 0.0f;
+        }
+    };
+
+    int nprev[PPT], ncur[PPT], nnext[PPT];
+    float dcur[PPT], dnext[PPT];
+    {
+        float y0[PPT], y1[PPT];
+        load_plane(0, y0);
+        load_plane(1, y1);
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            float r = y0[q] - 0.0f;
+            float cc = ceilf(r - eps);
+            dcur[q] = cc - r;
+            ncur[q] = (int)cc;
+            r = y1[q] - dcur[q];
+            cc = ceilf(r - eps);
+            dnext[q] = cc - r;
+            nnext[q] = (int)cc;
+            nprev[q] = 0;
+        }
+    }
+    if (wid & 1) {} else { for (int i = lane; i < P.NB; i += 64) myhist[i] = 0; }    // (the even wave of a pair clears the shared row)
+    __syncthreads();
+
+    STAMP_DECL;
+    for (int c = 0; c < 9; ++c) {
+        STAMP(0);
+        float ynn[PPT], y9[PPT];
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) ynn[q] = y9[q] = 0.0f;
+        if (c + 2 <= 8) load_plane(c + 2, ynn);
+        if (c + 2 == 8) load_plane(9, y9);
+        // ---- D1: classify; positions in pixel order (lane-major, slot-minor): a running sum per lane, ONE wave scan --
+        // cls: 0 nothing, 1 single, 2 multi with k == 0, 3 multi with k != 0 (both from the table), 4 multi outside the table;
+        // the slope-table index rides in bits 3..13
+        unsigned cls[PPT], aex[PPT], uex[PPT];
+        unsigned At = 0, Ut = 0;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const int n = ncur[q];                                          // (a pixel past the image holds zeros: no event)
+            const bool multi = n >= 2 && P.strategy != V2CE_STRATEGY_NONE;
+            const int si = multi ? slope_index(nprev[q], n, nnext[q], c) : -1;
+            const bool intab = tab_ok && si >= 0;
+            const bool kz = (c == 0 || c == 8) || nnext[q] == nprev[q];      // table entries: k == 0 exactly when the difference is
+            const unsigned cl = n == 1 ? 1u : !multi ? 0u : !intab ? 4u : kz ? 2u : 3u;
+            cls[q] = cl | (intab ? (unsigned)si << 3 : 0u);
+            const unsigned units = (unsigned)(n + 3) >> 2;
+            aex[q] = At;
+            uex[q] = Ut;
+            At += (cl ? (unsigned)n : 0u) | (cl == 1u ? 0x10000u : 0u);
+            Ut += (cl == 2u ? units : 0u) | (cl == 3u ? units << 16 : 0u);
+        }
+        const unsigned iA = wave_incl_scan(At, lane), iU = wave_incl_scan(Ut, lane);
+        const unsigned baseA = iA - At, baseU = iU - Ut;
+        const unsigned runA = (unsigned)__builtin_amdgcn_readlane((int)iA, 63), runU = (unsigned)__builtin_amdgcn_readlane((int)iU, 63);
+        const unsigned evW = runA & 0xFFFFu, sW = runA >> 16, u0W = runU & 0xFFFFu, u1W = runU >> 16;
+        if (lane == 0) part[wid] = evW;
+        __syncthreads();                                 // A: wave totals; O (the previous bin's run) is free again
+        STAMP(1);
+        unsigned sbase, N;
+        {
+            const unsigned pin = wave_incl_scan(lane < NW ? part[lane] : 0u, lane);
+            N = (unsigned)__builtin_amdgcn_readlane((int)pin, NW - 1);
+            sbase = wid ? (unsigned)__builtin_amdgcn_readlane((int)pin, wid - 1) : 0u;
+        }
+        unsigned *Sw = S + sbase;
+        const unsigned tb = (sbase + 2u * (unsigned)wid + 1u) & ~1u;     // the wave's table slice of O: 2 (u0W + u1W) + sW <= evW words
+        uint2 *UL = reinterpret_cast<uint2 *>(O + tb);
+        unsigned *SLs = O + tb + 2u * (u0W + u1W);
+        const float offt_c = P.offt[c];
+        const int kbase_c = (int)P.kbase[c];
+        const unsigned pc = (unsigned)(pidx * 9 + c);
+        // ---- D2: unit tables (and the rare voxel outside the slope table, generated in place by its owner) ---------
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const unsigned local = (unsigned)(lpx0 + q), pos = (baseA + aex[q]) & 0xFFFFu;
+            const int n = ncur[q];
+            const unsigned cl = cls[q] & 7u;
+            if (cl == 1u) {
+                SLs[(baseA + aex[q]) >> 16] = pos | (local << 14);
+                Sw[pos] = __float_as_uint(dcur[q]);              // the single's tendency waits in its record slot
+            } else if (cl == 2u || cl == 3u) {
+                const unsigned ue = baseU + uex[q];
+                const unsigned u0 = cl == 2u ? (ue & 0xFFFFu) : u0W + (ue >> 16);
+                const unsigned units = (unsigned)(n + 3) >> 2;
+                for (unsigned jb = 0; jb < units; ++jb) {
+                    const unsigned left = (unsigned)n - 4u * jb;
+                    UL[u0 + jb] = make_uint2(local | (jb << 11) | ((left < 4u ? left : 4u) << 29), (pos + 4u * jb) | ((cls[q] >> 3) << 14));
+                }
+            } else if (cl == 4u) {
+                float k, bb;
+                slope_params(nprev[q], n, nnext[q], c, P, k, bb);
+                const unsigned px = (unsigned)x0 + local;
+                for (int j = 0; j < n; ++j) {
+                    float u = 0.0f;
+                    if (philox) u = philox_uniform(P.seed, px, (unsigned)j, pc, frame);
+                    else if (j < P.replay_max_n) u = P.uniforms[(((long long)(b * 2 + pidx) * 9 + c) * P.HW + px) * P.replay_max_n + j];
+                    const unsigned key = multi_key(k, bb, u, offt_c, kbase_c, P, fast_k0);
+                    Sw[pos + (unsigned)j] = (key << 12) | (1u << kLocalBits) | local;
+                    atomicAdd(&myhist[key >> P.shift], hone);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        STAMP(2);
+        // ---- D3: timestamps, once, by the wave that owns the pixels ------------------------------------------------
+        for (unsigned i = lane; i < sW; i += 64) {
+            const unsigned e = SLs[i], pos = e & 0x3FFFu;
+            const long long Tq = single_ts(__uint_as_float(Sw[pos]), P.fps, offt_c);
+            const unsigned key = (unsigned)key_of(Tq, P.kbase[c], P.NK);
+            Sw[pos] = (key << 12) | (e >> 14);
+            atomicAdd(&myhist[key >> P.shift], hone);
+        }
+        STAMP(3);
+        auto unit_loop = [&](auto mode_c, unsigned first, unsigned count) {
+            // MODE 0: replayed uniforms (IEEE operations as the compiler expands them); 1 / 2: Philox, k == 0 units with /
+            // without the checked fast constant divisions; 3: Philox, k != 0 units (sqrt_rn_nr / div_rn_nr)
+            constexpr int MODE = decltype(mode_c)::value;
+            for (unsigned i = lane; i < count; i += 64) {
+                const uint2 e = UL[first + i];
+                const unsigned local = e.x & (kTilePix - 1), jb = (e.x >> kLocalBits) & 0x3FFFFu, cnt = e.x >> 29;
+                const unsigned pos = e.y & 0x3FFFu;
+                float2 kb = make_float2(0.0f, 0.0f);
+                if (MODE == 0 || MODE == 3) kb = stab[e.y >> 14];
+                const unsigned px = (unsigned)x0 + local;
+                float u[4];
+                unsigned key[4];
+                if (MODE == 0 && !philox) {
+                    const long long ub = (((long long)(b * 2 + pidx) * 9 + c) * P.HW + px) * P.replay_max_n;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const int j = (int)(4u * jb) + s;
+                        u[s] = ((unsigned)s < cnt && j < P.replay_max_n) ? P.uniforms[ub + j] : 0.0f;
+                    }
+                } else {
+                    unsigned o[4];
+                    philox4_b3(P.seed, px, jb, pc, frame, o);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) u[s] = u24(o[s]);
+                }
+                if (MODE == 0) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) key[s] = multi_key(kb.x, kb.y, u[s], offt_c, kbase_c, P, fast_k0);
+                } else {
+                    float tq[4];
+                    if (MODE == 3) {
+                        const float r1 = rcp_refined(kb.x), bb2 = kb.y * kb.y, k2 = 2.0f * kb.x;
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) tq[s] = div_rn_nr(-kb.y + sqrt_rn_nr(bb2 + k2 * u[s]), kb.x, r1);
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) tq[s] = MODE == 1 ? k0_time_fast(u[s], P.FPS, P.RFPS, P.R9) : (u[s] / P.FPS) / 9.0f;
+                    }
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        float tt = tq[s] + offt_c;
+                        tt = tt * 1e6f;
+                        int k = (int)tt - kbase_c;
+                        k = k < 0 ? 0 : k;
+                        key[s] = (unsigned)(k >= P.NK ? P.NK - 1 : k);
+                    }
+                }
+                const unsigned tag = (1u << kLocalBits) | local;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    if ((unsigned)s < cnt) {
+                        Sw[pos + s] = (key[s] << 12) | tag;
+                        atomicAdd(&myhist[key[s] >> P.shift], hone);
+                    }
+                }
+            }
+        };
+        if (!philox) {
+            unit_loop(std::integral_constant<int, 0>{}, 0u, u0W + u1W);
+        } else {
+            if (fast_k0) unit_loop(std::integral_constant<int, 1>{}, 0u, u0W);
+            else unit_loop(std::integral_constant<int, 2>{}, 0u, u0W);
+            unit_loop(std::integral_constant<int, 3>{}, u0W, u1W);
+        }
+        STAMP(4);
+        __syncthreads();                                 // B: every row of the histogram is complete
+        STAMP(5);
+        // ---- D4: bucket-major, wave-minor exclusive scan; the tile's row of the run table ------------------------
+        {
+            unsigned v[NWP];
+            unsigned run = 0;
+            if (tid < P.NB) {
+#pragma unroll
+                for (int w = 0; w < NWP; ++w) v[w] = hist[w * P.NB + tid];
+#pragma unroll
+                for (int w = 0; w < NWP; ++w) {
+                    const unsigned lo = v[w] & 0xFFFFu, hi = v[w] >> 16;
+                    v[w] = run | ((run + lo) << 16);                // exclusive starts of the even and the odd wave
+                    run += lo + hi;
+                }
+            }
+            unsigned tot;
+            const unsigned boff = block_excl_scan<NW>(run, spart, &tot);
+            if (tid < P.NB) {
+                const unsigned b2 = boff | (boff << 16);
+#pragma unroll
+                for (int w = 0; w < NWP; ++w) hist[w * P.NB + tid] = v[w] + b2;
+            }
+            unsigned short *row = P.roff + ((long long)(b * 9 + c) * P.T + t) * (P.NB + 1);
+            if (tid < P.NB) row[tid] = (unsigned short)boff;
+            if (tid == 0) row[P.NB] = (unsigned short)N;
+        }
+        __syncthreads();                                 // C: bucket offsets per wave
+        STAMP(6);
+        // ---- D5: stable ranks: the wave walks its records in pixel order -------------------------------------------
+        {
+            const unsigned sh = 12 + P.shift;
+            if (atomic_order) {                          // the rank IS what the LDS atomic returns (g_lds_order_ok)
+                for (unsigned i = lane; i < evW; i += 64) {
+                    const unsigned rec = Sw[i];
+                    O[(atomicAdd(&myhist[rec >> sh], hone) >> hsh) & 0xFFFFu] = rec;
+                }
+            } else {
+                for (unsigned i0 = 0; i0 < evW; i0 += 64) {
+                    const unsigned i = i0 + lane;
+                    const bool has = i < evW;
+                    const unsigned rec = has ? Sw[i] : 0u;
+                    const unsigned bucket = rec >> sh;
+                    const unsigned pos = take_slots_packed(has, bucket, P.nb1, &myhist[bucket], hsh);
+                    if (has) O[pos] = rec;
+                }
+            }
+        }
+        STAMP(7);
+        __syncthreads();                                 // D: the run is complete in O; every rank has read its histogram word
+        STAMP(8);
+        if (!(wid & 1)) for (int i = lane; i < P.NB; i += 64) myhist[i] = 0;    // for the next bin (first touched behind its barrier A)
+        {
+            unsigned *dst = P.temp + P.seg_offsets[b * 9 + c] + P.tile_off[((long long)b * P.T + t) * 9 + c];
+            for (unsigned i = tid; i < N; i += NT) dst[i] = O[i];
+        }
+        STAMP(9);
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            nprev[q] = ncur[q];
+            ncur[q] = nnext[q];
+            dcur[q] = dnext[q];
+            if (c + 2 <= 8) {
+                const float r = ynn[q] - dnext[q];
+                const float cc = ceilf(r - eps);
+                dnext[q] = cc - r;
+                int ni = (int)cc;
+                if (c + 2 == 8) ni += (int)(y9[q] - dnext[q]);   // LDATI.py:106
+                nnext[q] = ni;
+            }
+        }
+    }
+    STAMP(0);
+    STAMP_FLUSH(0, 10);
+}
+
+// Exhaustive check of the dense kernel's exact-math helpers (v2ce_ldati_selfcheck; a test, never on the product path):
+// for EVERY slope-table entry with k != 0 and EVERY uniform the Philox path can produce (m * 2^-24, m < 2^24) the time
+// (-b + sqrt(b^2 + 2 k u)) / k by sqrt_rn_nr / div_rn_nr against the compiler's IEEE square root and division; and
+// philox4_b3 against philox4 on the same counters.  bad[0] counts time mismatches, bad[1] Philox mismatches.
+__global__ __launch_bounds__(256) void ldati_selfcheck_kernel(float VS, float VS2, float INV, int d0, unsigned long long *bad) {
+    const unsigned m = blockIdx.x * 256u + threadIdx.x;                  // < 2^24
+    const float u = (float)m * (1.0f / 16777216.0f);
+    const int d = d0 + (int)blockIdx.y;
+    unsigned nb = 0, np = 0;
+    for (int n = 2; n <= kSlopeM; ++n) {
+        const float sxy = (float)d;
+        const float k0 = (3.0f * sxy) / 6.0f;
+        const float k = (k0 / VS2) / ((float)n + 1e-8f);
+        const float bb = INV - (VS * k) / 2.0f;
+        if (k == 0.0f) continue;
+        const float want = (-bb + __builtin_sqrtf(bb * bb + (2.0f * k) * u)) / k;
+        const float r1 = rcp_refined(k), bb2 = bb * bb, k2 = 2.0f * k;
+        const float got = div_rn_nr(-bb + sqrt_rn_nr(bb2 + k2 * u), k, r1);
+        const bool same = __float_as_uint(want) == __float_as_uint(got) || (want != want && got != got);
+        nb += same ? 0u : 1u;
+    }
+    {
+        unsigned a[4], c[4];
+        philox4(0x123456789ABCDEFull + (unsigned long long)d, m, m >> 7, (unsigned)(d & 15), m ^ 0x5bd1e995u, a);
+        philox4_b3(0x123456789ABCDEFull + (unsigned long long)d, m, m >> 7, (unsigned)(d & 15), m ^ 0x5bd1e995u, c);
+        np += (a[0] != c[0] || a[1] != c[1] || a[2] != c[2] || a[3] != c[3]) ? 1u : 0u;
+    }
+    if (nb) atomicAdd(&bad[0], (unsigned long long)nb);
+    if (np) atomicAdd(&bad[1], (unsigned long long)np);
+}
+
+// ---------------------------------------------------------------------------------------------
 // sparse tile pass: the same job as ldati_tile_pass_kernel for tiles with at most kSparseCap events
 // over ALL NINE bins (real UNet output: ~2000 per 2048-pixel tile; the per-bin kernel spends its
 // time in ~60 barriers and 18 workgroup scans for ~230 records per bin there).  One pass, 8 barriers:
@@ -1236,15 +1659,23 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
 //   6. nine coalesced runs + nine rows of the run table, exactly what the per-bin kernel writes.
 // LDS: list area / records S + O (32 KB) | packed histogram (10 KB) | scalars.
 // ---------------------------------------------------------------------------------------------
+// FUSED (round 4, v2ce_ldati_count_fused): the kernel also IS the count pass -- it forms the tile's counts from the voxels it
+// has just loaded (what ldati_count_tiles_kernel computes), so the voxel grid is read once per call instead of twice; the
+// record offsets a count pass would have provided are not needed because every tile writes into its own slot of kSparseCap
+// records (`temp` + slot; the (tile, bin) starts go to tile_abs for the bucket sort).  A tile beyond kSparseCap only reports
+// its counts; the host then takes the two-pass path for the call (v2ce_ldati_emit_fused).
+template <bool FUSED>
 __global__ __launch_bounds__(kSparseThreads) void ldati_tile_sparse_kernel(LdatiParams P) {
     constexpr int NT = kSparseThreads, NW = NT / 64, PPT = kTilePix / NT;
     constexpr int HWORDS = NT * 5;                       // 10 cells per thread >= 9 * kMaxNB + 1
     const int t = blockIdx.x, b = blockIdx.y;
-    const unsigned *tcr = P.tc + ((long long)b * P.T + t) * 9;
     unsigned ntot = 0;
+    if (!FUSED) {
+        const unsigned *tcr = P.tc + ((long long)b * P.T + t) * 9;
 #pragma unroll
-    for (int c = 0; c < 9; ++c) ntot += tcr[c];
-    if (ntot > (unsigned)P.sparse_cap) return;          // dense tile: ldati_tile_pass_kernel handles it
+        for (int c = 0; c < 9; ++c) ntot += tcr[c];
+        if (ntot > (unsigned)P.sparse_cap) return;          // dense tile: ldati_tile_pass_kernel handles it
+    }
     const int pidx = t < P.tpp ? 1 : 0;
     const int x0 = (t < P.tpp ? t : t - P.tpp) * kTilePix;
     const int tid = threadIdx.x;
@@ -1268,7 +1699,7 @@ __global__ __launch_bounds__(kSparseThreads) void ldati_tile_sparse_kernel(Ldati
     long long dst_off[9];                                           // where the tile's nine runs go
 #pragma unroll
     for (int c = 0; c < 9; ++c)
-        dst_off[c] = P.seg_offsets[b * 9 + c] + (long long)P.tile_off[((long long)b * P.T + t) * 9 + c];
+        dst_off[c] = FUSED ? 0ll : P.seg_offsets[b * 9 + c] + (long long)P.tile_off[((long long)b * P.T + t) * 9 + c];
 
     const float *plane0 = P.vox + (long long)(b * 2 + pidx) * 10 * P.HW;
     const unsigned frame = (unsigned)(P.frame_base + b);
@@ -1295,6 +1726,57 @@ __global__ __launch_bounds__(kSparseThreads) void ldati_tile_sparse_kernel(Ldati
     for (int i = tid; i < HWORDS; i += NT) hist[i] = 0;
     if (tid < 4) cur[tid] = 0;
     if (tid < 9) { offt_s[tid] = P.offt[tid]; kbase_s[tid] = P.kbase[tid]; }
+    if (FUSED) {
+        // the count pass (ldati_count_tiles_kernel): events per bin of this tile, largest voxel count
+        int cnt[9], mx = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) cnt[i] = 0;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            int nn[9];
+            float td[9];
+            relocate_all(yv[q], P.bidir != 0, nn, td);                   // (an all-zero pixel past the image counts nothing)
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                cnt[i] += (P.strategy == V2CE_STRATEGY_NONE) ? (nn[i] == 1) : (nn[i] > 0 ? nn[i] : 0);
+                mx = nn[i] > mx ? nn[i] : mx;
+            }
+        }
+        int *red = reinterpret_cast<int *>(S);                           // [NW][10], free until the lists are built
+        const int lane_c = tid & 63, wid_c = tid >> 6;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            int v = cnt[i];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if (lane_c == 0) red[wid_c * 10 + i] = v;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int m = __shfl_xor(mx, o);
+            mx = m > mx ? m : mx;
+        }
+        if (lane_c == 0) red[wid_c * 10 + 9] = mx;
+        __syncthreads();
+        unsigned sum9[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            unsigned v = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v += (unsigned)red[w * 10 + i];
+            sum9[i] = v;
+            ntot += v;
+        }
+        if (tid < 9) P.tc_w[((long long)b * P.T + t) * 9 + tid] = pick9(sum9, tid);
+        if (tid == 9) {
+            int m = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) m = red[w * 10 + 9] > m ? red[w * 10 + 9] : m;
+            if (m > 0) atomicMax(&P.stats_w[0], (unsigned long long)m);
+            if (ntot) atomicMax(&P.stats_w[4], (unsigned long long)ntot);
+        }
+        if (ntot > (unsigned)P.sparse_cap) return;       // uniform: the call falls back to the two-pass path
+    }
     __syncthreads();
 
     // ---- 2a: classify; append to the lists (slots from wave_alloc: one LDS atomic per wave, pixel and list)
@@ -1461,7 +1943,8 @@ __global__ __launch_bounds__(kSparseThreads) void ldati_tile_sparse_kernel(Ldati
     for (int c = 0; c < 9; ++c) {
         const unsigned bs = binstart[c], Nc = binstart[c + 1] - bs;
         const unsigned strip = ((unsigned)c * NKS) << 12;
-        unsigned *dst = P.temp + dst_off[c];
+        unsigned *dst = P.temp + (FUSED ? ((long long)b * P.T + t) * kSparseCap + bs : dst_off[c]);
+        if (FUSED && tid == 0) P.tile_abs_w[(long long)(b * 9 + c) * P.T + t] = (unsigned)(((long long)b * P.T + t) * kSparseCap + bs);
         for (unsigned i = tid; i < Nc; i += NT) dst[i] = S[bs + i] - strip;
         unsigned short *row = P.roff + ((long long)(b * 9 + c) * P.T + t) * (P.NB + 1);
         for (int k = tid; k < P.NB; k += NT) {
@@ -1549,6 +2032,7 @@ __global__ __launch_bounds__(512) void ldati_bucket_scan_kernel(LdatiParams P) {
         }
         P.ngroups[seg] = ng;
         P.seg_flag[seg] = 0;
+        if (seg == 0 && P.fused_status && *P.fused_status) atomicExch(reinterpret_cast<unsigned *>(P.status), (unsigned)*P.fused_status);
     }
 }
 
@@ -1604,7 +2088,7 @@ __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(Ldat
                 const unsigned short *row = P.roff + ((long long)seg * P.T + tt) * (P.NB + 1);
                 const unsigned r0 = row[bk0];
                 cv[q] = (unsigned)row[bk1] - r0;
-                ov[q] = r0 + P.tile_off[((long long)b * P.T + tt) * 9 + c];
+                ov[q] = r0 + (P.tile_abs ? P.tile_abs[(long long)seg * P.T + tt] : P.tile_off[((long long)b * P.T + tt) * 9 + c]);
             }
             sum += cv[q] | (cv[q] ? 0x10000u : 0u);
         }
@@ -1650,7 +2134,7 @@ __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(Ldat
     // its loads before the first use.
     const unsigned L = ((N + kSortThreads - 1) / kSortThreads) * 64;
     const unsigned lo = wid * L, hi = (lo + L < N) ? lo + L : N;
-    const unsigned *seg_temp = P.temp + P.seg_offsets[seg];
+    const unsigned *seg_temp = P.tile_abs ? P.temp : P.temp + P.seg_offsets[seg];
     unsigned rec[K];
     unsigned tinfo[K];
     {
@@ -1860,13 +2344,13 @@ __global__ __launch_bounds__(256) void ldati_big_bucket_kernel(LdatiParams P) {
         const long long g0 = P.seg_offsets[seg] + bofs[bucket];
         const unsigned key0 = (unsigned)bucket << P.shift;
         const long long tbase = P.kbase[c] + (long long)key0 + (P.frame_ts_add ? P.frame_ts_add[b] : 0);
-        const unsigned *seg_temp = P.temp + P.seg_offsets[seg];
+        const unsigned *seg_temp = P.tile_abs ? P.temp : P.temp + P.seg_offsets[seg];
         for (int i = tid; i < bins; i += 256) hist[i] = 0;
         __syncthreads();
         for (int tt = 0; tt < P.T; ++tt) {
             const unsigned short *row = P.roff + ((long long)seg * P.T + tt) * (P.NB + 1);
             const unsigned r0 = row[bucket], len = (unsigned)row[bucket + 1] - r0;
-            const unsigned *src = seg_temp + P.tile_off[((long long)b * P.T + tt) * 9 + c] + r0;
+            const unsigned *src = seg_temp + (P.tile_abs ? P.tile_abs[(long long)seg * P.T + tt] : P.tile_off[((long long)b * P.T + tt) * 9 + c]) + r0;
             const unsigned catb = tt < P.tpp ? 0u : 2u;
             for (unsigned j = tid; j < len; j += 256) {
                 const unsigned r = src[j];
@@ -1892,7 +2376,7 @@ __global__ __launch_bounds__(256) void ldati_big_bucket_kernel(LdatiParams P) {
             for (int tt = 0; tt < P.T; ++tt) {
                 const unsigned short *row = P.roff + ((long long)seg * P.T + tt) * (P.NB + 1);
                 const unsigned r0 = row[bucket], len = (unsigned)row[bucket + 1] - r0;
-                const unsigned *src = seg_temp + P.tile_off[((long long)b * P.T + tt) * 9 + c] + r0;
+                const unsigned *src = seg_temp + (P.tile_abs ? P.tile_abs[(long long)seg * P.T + tt] : P.tile_off[((long long)b * P.T + tt) * 9 + c]) + r0;
                 const unsigned catb = tt < P.tpp ? 0u : 2u;
                 const unsigned pxb = (unsigned)(tt < P.tpp ? tt : tt - P.tpp) * kTilePix;
                 for (unsigned j0 = 0; j0 < len; j0 += 64) {
@@ -2092,6 +2576,11 @@ int tile_threads_choice(int64_t max_tile_events) {
     return v ? v : (max_tile_events > 4096 ? 1024 : 512);
 }
 
+// dynamic LDS of ldati_tile_dense_kernel<NW>: S [capA] | O [capA + 2 NW + 2] | hist [NW/2][NB] | wave totals, scan partials
+size_t dense_tile_lds(int capA, int NB, int NW) {
+    return ((size_t)2 * capA + 2 * NW + 2 + (size_t)(NW / 2) * NB + 2 * NW + 2) * 4;
+}
+
 // geometry and capacities of the two-level path
 struct Plan {
     int tpp, T, shift, NB, nb1, PB, capA, cap2, tbits, tile_threads, span;
@@ -2118,6 +2607,13 @@ Plan make_plan(const HostScalars &h, int B, int H, int W, int64_t total_events,
     int shift = 4;
     while (shift > 0 && (double)max_segment_events * (double)(1 << shift) / (double)h.NK > p.cap2 / 20.0) --shift;
     while (shift < kMaxShift && ((h.NK + (1ll << shift) - 1) >> shift) > kMaxNB) ++shift;
+    // Dense segments (the rule above asks for the finest buckets) gain nothing from more than ~256 buckets: the sort groups
+    // merge consecutive buckets up to cap2 records anyway, while the tile pass pays per (wave, bucket) cell and the gather per
+    // run (V2CE_LDATI_NB_SOFT overrides the soft limit; kernel A/B runs)
+    {
+        static const int soft = [] { const char *e = getenv("V2CE_LDATI_NB_SOFT"); const int v = e ? atoi(e) : 0; return v >= 16 && v <= kMaxNB ? v : kMaxNB; }();   // (measured: 256 = tile pass -36 us, sort +31 us, bucket scan +10 us on the stress chunk: off)
+        while (shift < 4 && ((h.NK + (1ll << shift) - 1) >> shift) > soft) ++shift;
+    }
     p.shift = shift;
     p.NB = (int)((h.NK + (1ll << shift) - 1) >> shift);
     int nb1 = 0;
@@ -2155,6 +2651,16 @@ using namespace v2ce;
 
 namespace {
 struct Opts { int strategy, bidir, pooling, pool_k; };
+
+int probe_lds_order(hipStream_t s) {   // once per device: check that LDS atomics return ranks in lane order (see g_lds_order_ok)
+    static std::atomic<unsigned long long> probed{0};
+    int dev = 0;
+    V2CE_HIP_CHECK(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(probed.fetch_or(bit) & bit))
+        hipLaunchKernelGGL(ldati_lds_order_probe_kernel, dim3(64), dim3(256), 0, s, 200);
+    return V2CE_OK;
+}
 
 // NULL options = the CLI's call (v2ce.py:356): 'slope', no pooling, forward relocation
 int read_options(const v2ce_ldati_options *o, Opts &out, const char *who) {
@@ -2232,14 +2738,7 @@ extern "C" int v2ce_ldati_count(const float *vox, int B, int H, int W, const v2c
     const int tpp = (HW + kTilePix - 1) / kTilePix, T = 2 * tpp;
     unsigned *tc = static_cast<unsigned *>(tile_ws);
     unsigned *tile_off = tc + (size_t)B * T * 9;
-    {   // once per device: check that LDS atomics return ranks in lane order (see g_lds_order_ok)
-        static std::atomic<unsigned long long> probed{0};
-        int dev = 0;
-        V2CE_HIP_CHECK(hipGetDevice(&dev));
-        const unsigned long long bit = 1ull << (dev & 63);
-        if (!(probed.fetch_or(bit) & bit))
-            hipLaunchKernelGGL(ldati_lds_order_probe_kernel, dim3(64), dim3(256), 0, s, 200);
-    }
+    if (int rc = probe_lds_order(s)) return rc;
     V2CE_HIP_CHECK(hipMemsetAsync(stats, 0, 4 * sizeof(int64_t), s));
     // 'random' emits like 'slope' (every draw of a multi-event voxel); 'none' only the singles
     const int count_strategy = o.strategy == V2CE_STRATEGY_NONE ? V2CE_STRATEGY_NONE : V2CE_STRATEGY_SLOPE;
@@ -2270,13 +2769,150 @@ extern "C" size_t v2ce_ldati_workspace_bytes(int B, int H, int W, double fps, do
     return L.ok ? L.bytes : 0;
 }
 
-extern "C" int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps, double t0,
+namespace {
+// ---- fused count + sparse tile pass: geometry the kernel assumes BEFORE the counts exist, and its workspace ----------
+// The coarse-bucket geometry of a call follows from its densest segment (make_plan).  The fused kernel runs before that is
+// known, with the geometry of the caller's HINT (the previous call's max_segment_events: consecutive batches of a clip
+// agree); v2ce_ldati_emit_fused uses its records only if the plan made from the real counts has the same geometry and no
+// tile exceeded its slot.
+struct FusedLayout {
+    Plan p0;
+    size_t off_abs, off_rec, off_roff, bytes;
+    bool ok;
+};
+FusedLayout make_fused_layout(const HostScalars &h, const Opts &o, int B, int H, int W, int64_t seg_hint) {
+    FusedLayout F{};
+    F.p0 = make_plan(h, B, H, W, 0, seg_hint > 0 ? seg_hint : 0, 0);
+    const Plan &p = F.p0;
+    const size_t n_abs = (size_t)B * 9 * p.T, n_rec = (size_t)B * p.T * kSparseCap;
+    F.ok = h.ok && p.T <= kMaxTiles && p.NB <= kMaxNB && p.PB <= 22 && B * 9 <= 65535 && n_rec < (1ull << 32) &&
+           9ll * ((long long)p.NB << p.shift) < (1ll << 20) &&
+           (o.strategy == V2CE_STRATEGY_SLOPE || o.strategy == V2CE_STRATEGY_NONE) && o.pooling == V2CE_POOL_NONE &&
+           !getenv("V2CE_LDATI_NO_SPARSE") && !getenv("V2CE_LDATI_NO_FUSED");
+    F.off_abs = 16;
+    F.off_rec = (F.off_abs + n_abs * 4 + 15) / 16 * 16;
+    F.off_roff = (F.off_rec + n_rec * 4 + 15) / 16 * 16;
+    F.bytes = (F.off_roff + p.n_tab * 2 + 15) / 16 * 16;
+    return F;
+}
+
+int fill_params(LdatiParams &P, const HostScalars &h, const Opts &o, const float *vox, int B, int H, int W, double fps,
+                int rng_mode, const float *uniforms, int replay_max_n, uint64_t seed, int64_t frame_base, hipStream_t st) {
+    P.vox = vox; P.B = B; P.H = H; P.W = W; P.HW = H * W;
+    P.fps = fps; P.VS = h.VS; P.VS2 = h.VS2; P.INV = h.INV; P.FPS = h.FPS;
+    for (int c = 0; c < 9; ++c) { P.offt[c] = h.offt[c]; P.kbase[c] = h.kbase[c]; }
+    P.NK = (int)h.NK; P.nbits = h.nbits;
+    P.ts32 = (fabs((double)h.offt[8]) + 1.0 + 1.0 / fps) * 1e6 < 2.0e9 ? 1 : 0;
+    P.strategy = o.strategy; P.bidir = o.bidir;
+    P.rng_mode = rng_mode; P.uniforms = uniforms; P.replay_max_n = replay_max_n;
+    P.seed = seed; P.frame_base = frame_base;
+    P.sweep_ok = h.sweep_ok ? 1 : 0;
+    P.RFPS = (float)(1.0 / (double)h.FPS); P.R9 = (float)(1.0 / 9.0);
+    P.fast_slot = -1;
+    if (o.strategy == V2CE_STRATEGY_SLOPE && !getenv("V2CE_LDATI_NO_FASTDIV")) {
+        // once per device and FPS: the exhaustive check of k0_time_fast against the IEEE divisions (see g_fastdiv) and the
+        // table of slope parameters (g_slope_tab)
+        static std::mutex mu;
+        static unsigned seen[64][8];
+        static int n_seen[64];
+        int dev = 0;
+        V2CE_HIP_CHECK(hipGetDevice(&dev));
+        unsigned bits;
+        memcpy(&bits, &h.FPS, 4);
+        std::lock_guard<std::mutex> g(mu);
+        if (dev >= 0 && dev < 64) {
+            int slot = -1;
+            for (int i = 0; i < n_seen[dev]; ++i)
+                if (seen[dev][i] == bits) slot = i;
+            if (slot < 0 && n_seen[dev] < 8) {
+                slot = n_seen[dev]++;
+                seen[dev][slot] = bits;
+                hipLaunchKernelGGL(ldati_fastdiv_check_kernel, dim3(65536), dim3(256), 0, st, h.FPS, P.RFPS, P.R9, slot);
+                hipLaunchKernelGGL(ldati_slope_tab_kernel, dim3((kSlopeTab + 255) / 256), dim3(256), 0, st, h.VS, h.VS2, h.INV, slot);
+                hipLaunchKernelGGL(ldati_fastdiv_commit_kernel, dim3(1), dim3(1), 0, st, h.FPS, slot);
+            }
+            P.fast_slot = slot;
+        }
+    }
+    { const char *e = getenv("V2CE_LDATI_NO_ATOMIC_ORDER"); P.ballot_ranks = (e && e[0] == '1') ? 1 : 0; }
+    return V2CE_OK;
+}
+
+}  // namespace
+
+extern "C" size_t v2ce_ldati_fused_ws_bytes(int B, int H, int W, double fps, double t0, const v2ce_ldati_options *options,
+                                            int64_t expected_max_segment_events) {
+    if (!(fps > 0) || B <= 0 || H <= 0 || W <= 0 || (long long)H * W >= (1ll << 30)) return 0;
+    Opts o;
+    if (read_options(options, o, "v2ce_ldati_fused_ws_bytes")) return 0;
+    const HostScalars h = host_scalars(fps, t0, o.bidir, o.strategy == V2CE_STRATEGY_RANDOM);
+    const FusedLayout F = make_fused_layout(h, o, B, H, W, expected_max_segment_events);
+    return F.ok ? F.bytes : 0;
+}
+
+extern "C" int v2ce_ldati_count_fused(const float *vox, int B, int H, int W, double fps, double t0,
+                                      const v2ce_ldati_options *options, int rng_mode, const float *uniforms, int replay_max_n,
+                                      uint64_t seed, int64_t frame_base, int64_t expected_max_segment_events, void *tile_ws,
+                                      size_t tile_ws_bytes, void *fused_ws, size_t fused_ws_bytes, int64_t *seg_offsets, int64_t *stats,
+                                      v2ce_stream_t stream) {
+    clear_error();
+    V2CE_REQUIRE(vox && tile_ws && fused_ws && seg_offsets && stats, V2CE_ERR_BAD_ARG, "v2ce_ldati_count_fused: null pointer");
+    V2CE_REQUIRE(B > 0 && H > 0 && W > 0 && (long long)H * W < (1ll << 30), V2CE_ERR_BAD_ARG,
+                 "v2ce_ldati_count_fused: bad shape B=%d H=%d W=%d", B, H, W);
+    V2CE_REQUIRE(W <= 32767 && H <= 32767, V2CE_ERR_UNSUPPORTED, "v2ce_ldati_count_fused: x/y are int16 (LDATI.py:230-231)");
+    V2CE_REQUIRE(B <= 65535, V2CE_ERR_UNSUPPORTED, "v2ce_ldati_count_fused: B too large for one launch");
+    V2CE_REQUIRE(fps > 0, V2CE_ERR_BAD_ARG, "v2ce_ldati_count_fused: fps must be positive");
+    V2CE_REQUIRE(rng_mode == V2CE_RNG_REPLAY || rng_mode == V2CE_RNG_PHILOX, V2CE_ERR_BAD_ARG,
+                 "v2ce_ldati_count_fused: bad rng_mode %d", rng_mode);
+    V2CE_REQUIRE(rng_mode != V2CE_RNG_REPLAY || replay_max_n == 0 || uniforms != nullptr, V2CE_ERR_BAD_ARG,
+                 "v2ce_ldati_count_fused: REPLAY mode needs the uniform tensor");
+    Opts o;
+    if (int rc = read_options(options, o, "v2ce_ldati_count_fused")) return rc;
+    const HostScalars h = host_scalars(fps, t0, o.bidir, false);
+    const FusedLayout F = make_fused_layout(h, o, B, H, W, expected_max_segment_events);
+    V2CE_REQUIRE(F.ok, V2CE_ERR_UNSUPPORTED, "v2ce_ldati_count_fused: these arguments have no fused path (v2ce_ldati_fused_ws_bytes = 0)");
+    V2CE_REQUIRE(tile_ws_bytes >= v2ce_ldati_tile_ws_bytes(B, H, W), V2CE_ERR_WORKSPACE,
+                 "v2ce_ldati_count_fused: tile workspace %zu < %zu", tile_ws_bytes, v2ce_ldati_tile_ws_bytes(B, H, W));
+    V2CE_REQUIRE(fused_ws_bytes >= F.bytes, V2CE_ERR_WORKSPACE, "v2ce_ldati_count_fused: workspace %zu < %zu", fused_ws_bytes, F.bytes);
+    V2CE_REQUIRE((reinterpret_cast<uintptr_t>(fused_ws) & 15) == 0, V2CE_ERR_BAD_ARG, "v2ce_ldati_count_fused: workspace must be 16-byte aligned");
+    hipStream_t s = as_stream(stream);
+    const Plan &pl = F.p0;
+    unsigned *tc = static_cast<unsigned *>(tile_ws);
+    unsigned *tile_off = tc + (size_t)B * pl.T * 9;
+    if (int rc = probe_lds_order(s)) return rc;
+    V2CE_HIP_CHECK(hipMemsetAsync(stats, 0, 8 * sizeof(int64_t), s));
+    unsigned char *fb = static_cast<unsigned char *>(fused_ws);
+    V2CE_HIP_CHECK(hipMemsetAsync(fb, 0, 16, s));
+    LdatiParams P{};
+    if (int rc = fill_params(P, h, o, vox, B, H, W, fps, rng_mode, uniforms, replay_max_n, seed, frame_base, s)) return rc;
+    P.shift = pl.shift; P.NB = pl.NB; P.nb1 = pl.nb1; P.T = pl.T; P.tpp = pl.tpp; P.PB = pl.PB;
+    P.sparse_cap = kSparseCap;
+    P.status = reinterpret_cast<int *>(fb);
+    P.tc_w = tc;
+    P.stats_w = reinterpret_cast<unsigned long long *>(stats);
+    P.tile_abs_w = reinterpret_cast<unsigned *>(fb + F.off_abs);
+    P.temp = reinterpret_cast<unsigned *>(fb + F.off_rec);
+    P.roff = reinterpret_cast<unsigned short *>(fb + F.off_roff);
+    V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ldati_tile_sparse_kernel<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSparseLds));
+    hipLaunchKernelGGL(ldati_tile_sparse_kernel<true>, dim3(pl.T, B), dim3(kSparseThreads), kSparseLds, s, P);
+    hipLaunchKernelGGL(ldati_tile_scan_kernel, dim3((B * 9 + 3) / 4), dim3(256), 0, s, tc, B, pl.T, tile_off,
+                       reinterpret_cast<long long *>(seg_offsets), reinterpret_cast<unsigned long long *>(stats));
+    hipLaunchKernelGGL(ldati_seg_scan_kernel, dim3(1), dim3(256), 0, s, B * 9, reinterpret_cast<long long *>(seg_offsets),
+                       reinterpret_cast<unsigned long long *>(stats));
+    V2CE_HIP_CHECK(hipGetLastError());
+    return V2CE_OK;
+}
+
+namespace {
+int emit_impl(const float *vox, int B, int H, int W, double fps, double t0,
                                const v2ce_ldati_options *options, int rng_mode, const float *uniforms, int replay_max_n,
                                uint64_t seed, int64_t frame_base, const int64_t *seg_offsets,
                                const int64_t *frame_ts_add, int64_t *ts, int16_t *x, int16_t *y,
                                int8_t *p, uint8_t *packed, int64_t total_events,
                                int64_t max_segment_events, int64_t max_tile_events, const void *tile_ws,
-                               void *workspace, size_t workspace_bytes, v2ce_stream_t stream) {
+                               void *workspace, size_t workspace_bytes, v2ce_stream_t stream,
+                               const void *fused_ws, size_t fused_ws_bytes, int64_t fused_tile_max, int64_t fused_seg_hint) {
     clear_error();
     V2CE_REQUIRE(vox && seg_offsets, V2CE_ERR_BAD_ARG, "v2ce_ldati_emit: null pointer");
     V2CE_REQUIRE(B > 0 && H > 0 && W > 0 && (long long)H * W < (1ll << 30), V2CE_ERR_BAD_ARG,
@@ -2299,49 +2935,13 @@ extern "C" int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps
     V2CE_REQUIRE(h.ok, V2CE_ERR_UNSUPPORTED, "v2ce_ldati_emit: fps=%g t0=%g needs %lld keys per bin (max %d)",
                  fps, t0, h.NK, kMaxNB << kMaxShift);
     LdatiParams P{};
-    P.vox = vox; P.B = B; P.H = H; P.W = W; P.HW = H * W;
-    P.fps = fps; P.VS = h.VS; P.VS2 = h.VS2; P.INV = h.INV; P.FPS = h.FPS;
-    for (int c = 0; c < 9; ++c) { P.offt[c] = h.offt[c]; P.kbase[c] = h.kbase[c]; }
-    P.NK = (int)h.NK; P.nbits = h.nbits;
-    P.ts32 = (fabs((double)h.offt[8]) + 1.0 + 1.0 / fps) * 1e6 < 2.0e9 ? 1 : 0;
-    P.strategy = o.strategy; P.bidir = o.bidir;
-    P.rng_mode = rng_mode; P.uniforms = uniforms; P.replay_max_n = replay_max_n;
-    P.seed = seed; P.frame_base = frame_base;
+    hipStream_t st = as_stream(stream);
+    if (int rc = fill_params(P, h, o, vox, B, H, W, fps, rng_mode, uniforms, replay_max_n, seed, frame_base, st)) return rc;
     P.seg_offsets = reinterpret_cast<const long long *>(seg_offsets);
     P.frame_ts_add = reinterpret_cast<const long long *>(frame_ts_add);
     P.ts = reinterpret_cast<long long *>(ts); P.x = x; P.y = y;
     P.p = reinterpret_cast<signed char *>(p);
     P.packed = packed;
-    P.sweep_ok = h.sweep_ok ? 1 : 0;
-    P.RFPS = (float)(1.0 / (double)h.FPS); P.R9 = (float)(1.0 / 9.0);
-    P.fast_slot = -1;
-    if (o.strategy == V2CE_STRATEGY_SLOPE && !getenv("V2CE_LDATI_NO_FASTDIV")) {
-        // once per device and FPS: the exhaustive check of k0_time_fast against the IEEE divisions (see g_fastdiv) and the
-        // table of slope parameters (g_slope_tab)
-        static std::mutex mu;
-        static unsigned seen[64][8];
-        static int n_seen[64];
-        int dev = 0;
-        V2CE_HIP_CHECK(hipGetDevice(&dev));
-        unsigned bits;
-        memcpy(&bits, &h.FPS, 4);
-        std::lock_guard<std::mutex> g(mu);
-        if (dev >= 0 && dev < 64) {
-            int slot = -1;
-            for (int i = 0; i < n_seen[dev]; ++i)
-                if (seen[dev][i] == bits) slot = i;
-            if (slot < 0 && n_seen[dev] < 8) {
-                slot = n_seen[dev]++;
-                seen[dev][slot] = bits;
-                hipLaunchKernelGGL(ldati_fastdiv_check_kernel, dim3(65536), dim3(256), 0, as_stream(stream), h.FPS, P.RFPS, P.R9, slot);
-                hipLaunchKernelGGL(ldati_slope_tab_kernel, dim3((kSlopeTab + 255) / 256), dim3(256), 0, as_stream(stream), h.VS, h.VS2, h.INV, slot);
-                hipLaunchKernelGGL(ldati_fastdiv_commit_kernel, dim3(1), dim3(1), 0, as_stream(stream), h.FPS, slot);
-            }
-            P.fast_slot = slot;
-        }
-    }
-    { const char *e = getenv("V2CE_LDATI_NO_ATOMIC_ORDER"); P.ballot_ranks = (e && e[0] == '1') ? 1 : 0; }
-    hipStream_t st = as_stream(stream);
     if (h.sweep_ok)
         V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ldati_emit_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds_bytes));
@@ -2375,6 +2975,20 @@ extern "C" int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps
             P.kbb = kbb;
         }
         auto launch_tile_pass = [&]() -> int {
+            // the round-4 dense kernel serves the common call; everything else stays on the per-bin kernel
+            const size_t lds8 = dense_tile_lds(pl.capA, pl.NB, 8), lds16 = dense_tile_lds(pl.capA, pl.NB, 16);
+            const bool dense_ok = !L.generic && !o.bidir && !P.kbb && P.ts32 && !getenv("V2CE_LDATI_OLD_TILE") &&
+                                  (o.strategy == V2CE_STRATEGY_NONE || (o.strategy == V2CE_STRATEGY_SLOPE && P.fast_slot >= 0)) &&
+                                  lds16 <= 160 * 1024;
+            if (dense_ok) {
+                static const int force_nw = [] { const char *e = getenv("V2CE_LDATI_DENSE_NW"); return e ? atoi(e) : 0; }();   // kernel A/B runs
+                const bool w8 = force_nw == 16 ? false : (force_nw == 8 && lds8 <= 160 * 1024) ? true : lds8 <= 80 * 1024;       // two workgroups per CU
+                auto dk = w8 ? ldati_tile_dense_kernel<8> : ldati_tile_dense_kernel<16>;
+                const size_t lds = w8 ? lds8 : lds16;
+                V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(dk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(dk, dim3(pl.T, B), dim3(w8 ? 512 : 1024), lds, st, P);
+                return V2CE_OK;
+            }
             auto tile_kernel = o.bidir ? (pl.tile_threads == 512 ? ldati_tile_pass_kernel<512, 4, true> : ldati_tile_pass_kernel<1024, 2, true>)
                                        : (pl.tile_threads == 512 ? ldati_tile_pass_kernel<512, 4, false> : ldati_tile_pass_kernel<1024, 2, false>);
             V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(tile_kernel),
@@ -2426,16 +3040,33 @@ extern "C" int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps
         P.temp = reinterpret_cast<unsigned *>(P.status + 4);
         P.roff = reinterpret_cast<unsigned short *>(P.temp + (size_t)total_events);
         V2CE_HIP_CHECK(hipMemsetAsync(P.status, 0, 4 * sizeof(int), st));
+        // the fused count already ran the sparse tile pass: usable when its assumed geometry is the plan's and every tile fitted
+        bool fused = false;
+        if (fused_ws && P.sparse_cap && !P.kbb) {
+            const FusedLayout F = make_fused_layout(h, o, B, H, W, fused_seg_hint);
+            fused = F.ok && fused_ws_bytes >= F.bytes && fused_tile_max <= kSparseCap && F.p0.shift == pl.shift && F.p0.NB == pl.NB && F.p0.T == pl.T;
+            if (getenv("V2CE_LDATI_DEBUG"))
+                fprintf(stderr, "v2ce_ldati_emit_fused: fused=%d ok=%d bytes %zu/%zu tile_max=%lld shift %d/%d NB %d/%d T %d/%d\n", (int)fused, (int)F.ok,
+                        fused_ws_bytes, F.bytes, (long long)fused_tile_max, F.p0.shift, pl.shift, F.p0.NB, pl.NB, F.p0.T, pl.T);
+            if (fused) {
+                const unsigned char *fb = static_cast<const unsigned char *>(fused_ws);
+                P.fused_status = reinterpret_cast<const int *>(fb);
+                P.tile_abs = reinterpret_cast<const unsigned *>(fb + F.off_abs);
+                P.temp = const_cast<unsigned *>(reinterpret_cast<const unsigned *>(fb + F.off_rec));
+                P.roff = const_cast<unsigned short *>(reinterpret_cast<const unsigned short *>(fb + F.off_roff));
+            }
+        }
         // (Tried in round 3 and removed: walking the frames in groups so that the HBM-bound bucket sort of group g runs on a
         // low-priority side stream under the VALU-bound tile pass of group g + 1.  24 stress frame-pairs: 1 group 1.74 ms,
         // 2 groups 1.86, 4 groups 1.83, 8 groups 2.21 -- the tile pass needs whole CUs (1024 threads, ~100 KB of LDS), the sort
         // workgroups that slip in between delay its rounds, and each group adds a partial last round.)
-        if (P.sparse_cap) {
-            V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ldati_tile_sparse_kernel),
+        if (P.sparse_cap && !fused) {
+            V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ldati_tile_sparse_kernel<false>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSparseLds));
-            hipLaunchKernelGGL(ldati_tile_sparse_kernel, dim3(pl.T, B), dim3(kSparseThreads), kSparseLds, st, P);
+            hipLaunchKernelGGL(ldati_tile_sparse_kernel<false>, dim3(pl.T, B), dim3(kSparseThreads), kSparseLds, st, P);
         }
-        if (int rc = launch_tile_pass()) return rc;
+        if (!fused)
+            if (int rc = launch_tile_pass()) return rc;
         hipLaunchKernelGGL(ldati_bucket_scan_kernel, dim3(B * 9), dim3(512), 0, st, P);
         {
             auto sort_kernel = packed ? (pl.cap2 > kSortThreads * 8 ? ldati_bucket_sort_kernel<true, 24>
@@ -2459,6 +3090,33 @@ extern "C" int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps
     hipLaunchKernelGGL(ldati_emit_kernel, dim3(B * 9), dim3(256), h.lds_bytes, st, P);
     V2CE_HIP_CHECK(hipGetLastError());
     return V2CE_OK;
+}
+
+}  // namespace
+
+extern "C" int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps, double t0,
+                               const v2ce_ldati_options *options, int rng_mode, const float *uniforms, int replay_max_n,
+                               uint64_t seed, int64_t frame_base, const int64_t *seg_offsets,
+                               const int64_t *frame_ts_add, int64_t *ts, int16_t *x, int16_t *y,
+                               int8_t *p, uint8_t *packed, int64_t total_events,
+                               int64_t max_segment_events, int64_t max_tile_events, const void *tile_ws,
+                               void *workspace, size_t workspace_bytes, v2ce_stream_t stream) {
+    return emit_impl(vox, B, H, W, fps, t0, options, rng_mode, uniforms, replay_max_n, seed, frame_base, seg_offsets, frame_ts_add, ts, x,
+                     y, p, packed, total_events, max_segment_events, max_tile_events, tile_ws, workspace, workspace_bytes, stream,
+                     nullptr, 0, 0, 0);
+}
+
+extern "C" int v2ce_ldati_emit_fused(const float *vox, int B, int H, int W, double fps, double t0,
+                                     const v2ce_ldati_options *options, int rng_mode, const float *uniforms, int replay_max_n,
+                                     uint64_t seed, int64_t frame_base, const int64_t *seg_offsets,
+                                     const int64_t *frame_ts_add, int64_t *ts, int16_t *x, int16_t *y,
+                                     int8_t *p, uint8_t *packed, int64_t total_events,
+                                     int64_t max_segment_events, int64_t max_tile_events, const void *tile_ws,
+                                     void *workspace, size_t workspace_bytes, const void *fused_ws, size_t fused_ws_bytes,
+                                     int64_t largest_tile_events, int64_t expected_max_segment_events, v2ce_stream_t stream) {
+    return emit_impl(vox, B, H, W, fps, t0, options, rng_mode, uniforms, replay_max_n, seed, frame_base, seg_offsets, frame_ts_add, ts, x,
+                     y, p, packed, total_events, max_segment_events, max_tile_events, tile_ws, workspace, workspace_bytes, stream,
+                     fused_ws, fused_ws_bytes, largest_tile_events, expected_max_segment_events);
 }
 
 extern "C" int v2ce_ldati_plan_info(int B, int H, int W, double fps, double t0, const v2ce_ldati_options *options,
@@ -2502,6 +3160,23 @@ extern "C" int v2ce_ldati_rank_mode(int32_t *mode) {
     V2CE_HIP_CHECK(hipMemcpyFromSymbol(&ok, HIP_SYMBOL(g_lds_order_ok), sizeof(int)));
     const char *e = getenv("V2CE_LDATI_NO_ATOMIC_ORDER");
     *mode = (ok && !(e && e[0] == '1')) ? 1 : 0;
+    return V2CE_OK;
+}
+
+extern "C" int v2ce_ldati_selfcheck(double fps, int64_t *mismatches) {
+    clear_error();
+    V2CE_REQUIRE(mismatches && fps > 0, V2CE_ERR_BAD_ARG, "v2ce_ldati_selfcheck: bad argument");
+    const HostScalars h = host_scalars(fps, 0.0);
+    unsigned long long *bad = nullptr;
+    V2CE_HIP_CHECK(hipMalloc(&bad, 2 * sizeof(unsigned long long)));
+    V2CE_HIP_CHECK(hipMemset(bad, 0, 2 * sizeof(unsigned long long)));
+    hipLaunchKernelGGL(ldati_selfcheck_kernel, dim3(65536, 2 * kSlopeM + 1), dim3(256), 0, nullptr, h.VS, h.VS2, h.INV, -kSlopeM, bad);
+    unsigned long long host[2] = {0, 0};
+    const hipError_t e = hipMemcpy(host, bad, sizeof(host), hipMemcpyDeviceToHost);
+    (void)hipFree(bad);
+    V2CE_HIP_CHECK(e);
+    mismatches[0] = (int64_t)host[0];
+    mismatches[1] = (int64_t)host[1];
     return V2CE_OK;
 }
 

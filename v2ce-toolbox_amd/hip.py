@@ -24,7 +24,7 @@ PRECISION_F32, PRECISION_F16X2 = 0, 1
 
 EXPORTS = [
     "v2ce_version", "v2ce_last_error", "v2ce_ldati_count", "v2ce_ldati_rank_mode", "v2ce_ldati_tile_ws_bytes", "v2ce_ldati_status", "v2ce_ldati_plan_info",
-    "v2ce_ldati_lds_bytes", "v2ce_ldati_workspace_bytes", "v2ce_ldati_emit", "v2ce_events_pack", "v2ce_events_unpack",
+    "v2ce_ldati_selfcheck", "v2ce_ldati_fused_ws_bytes", "v2ce_ldati_count_fused", "v2ce_ldati_emit_fused", "v2ce_ldati_lds_bytes", "v2ce_ldati_workspace_bytes", "v2ce_ldati_emit", "v2ce_events_pack", "v2ce_events_unpack",
     "v2ce_conv3d_fwd",
     "v2ce_conv3d_variant", "v2ce_conv3d_variant_fused", "v2ce_pack_weights_f16x2", "v2ce_pack_weights_f16x2_bytes",
     "v2ce_pack_weights", "v2ce_sn_workspace_bytes", "v2ce_sn_power_iter", "v2ce_sn_batch_workspace_bytes", "v2ce_sn_update_batch",
@@ -102,12 +102,21 @@ def lib() -> ctypes.CDLL:
     L.v2ce_ldati_lds_bytes.restype = sz
     L.v2ce_ldati_emit.argtypes = [vp, i32, i32, i32, f64, f64, op, i32, vp, i32, u64, i64, vp, vp,
                                   vp, vp, vp, vp, vp, i64, i64, i64, vp, vp, sz, vp]
+    L.v2ce_ldati_fused_ws_bytes.argtypes = [i32, i32, i32, f64, f64, op, i64]
+    L.v2ce_ldati_fused_ws_bytes.restype = sz
+    L.v2ce_ldati_count_fused.argtypes = [vp, i32, i32, i32, f64, f64, op, i32, vp, i32, u64, i64, i64, vp, sz, vp, sz, vp, vp, vp]
+    L.v2ce_ldati_count_fused.restype = ctypes.c_int
+    L.v2ce_ldati_emit_fused.argtypes = [vp, i32, i32, i32, f64, f64, op, i32, vp, i32, u64, i64, vp, vp,
+                                        vp, vp, vp, vp, vp, i64, i64, i64, vp, vp, sz, vp, sz, i64, i64, vp]
+    L.v2ce_ldati_emit_fused.restype = ctypes.c_int
     L.v2ce_ldati_workspace_bytes.argtypes = [i32, i32, i32, f64, f64, op, i64, i64, i64, i32]
     L.v2ce_ldati_workspace_bytes.restype = sz
     L.v2ce_ldati_status.argtypes = [vp, i32, i32, i32, f64, f64, op, i64, i64, i64, ctypes.POINTER(vp)]
     L.v2ce_ldati_status.restype = ctypes.c_int
     L.v2ce_ldati_plan_info.argtypes = [i32, i32, i32, f64, f64, op, i64, i64, i64, vp]
     L.v2ce_ldati_plan_info.restype = ctypes.c_int
+    L.v2ce_ldati_selfcheck.argtypes = [f64, ctypes.POINTER(ctypes.c_int64)]
+    L.v2ce_ldati_selfcheck.restype = ctypes.c_int
     L.v2ce_ldati_rank_mode.argtypes = [ctypes.POINTER(ctypes.c_int32)]
     L.v2ce_ldati_rank_mode.restype = ctypes.c_int
     L.v2ce_events_pack.argtypes = [vp, vp, vp, vp, i64, vp, vp]
