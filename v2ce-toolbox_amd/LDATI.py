@@ -138,6 +138,7 @@ _PINNED = _PinnedPool()
 # densest-segment event count of the previous call with the same shape and options: the fused count pass assumes the
 # bucket geometry that follows from it (consecutive batches of a clip agree; a miss costs one two-pass call)
 _SEG_HINT = {}
+_SPARSE_TILE_CAP = 8192                  # kSparseCap of csrc/ldati.hip: events of one tile (all nine bins) the fused pass holds
 
 
 class PendingLdati:
@@ -205,8 +206,12 @@ def ldati_begin(y: torch.Tensor, t0=0, fps=30, *, rng: str = "philox", seed: Opt
         fused_ws, seg_hint, hint_key = None, 0, None
         if path == "bucket" and (rng == "philox" or uniforms is not None) and os.environ.get("V2CE_LDATI_NO_FUSED") is None:
             hint_key = (dev.index, B, H, W, float(fps), float(t0), strategy, bool(bidirectional))
-            seg_hint = int(_SEG_HINT.get(hint_key, 0))
-            fb = L.v2ce_ldati_fused_ws_bytes(B, H, W, float(fps), float(t0), ctypes.byref(opts), seg_hint)
+            seg_hint, tile_hint, calls = _SEG_HINT.get(hint_key, (0, 0, 0))
+            # a shape whose last call had a dense tile (the fused records were discarded) counts the plain way, and tries
+            # the fused pass again every 16th call
+            fb = 0
+            if tile_hint <= _SPARSE_TILE_CAP or calls % 16 == 0:
+                fb = L.v2ce_ldati_fused_ws_bytes(B, H, W, float(fps), float(t0), ctypes.byref(opts), seg_hint)
             if fb:
                 fused_ws = torch.empty(fb, dtype=torch.uint8, device=dev)
         if profile is not None:    # HIP events on the launch stream around the count kernels
@@ -246,7 +251,8 @@ def _ldati_finish(q: PendingLdati) -> DeviceEvents:
     max_n, max_tile, max_seg, total, tile_all = (int(v) for v in host[B * 9 + 1:B * 9 + 6])
     segc = np.diff(offs).reshape(B, 9)
     if q.hint_key is not None:
-        _SEG_HINT[q.hint_key] = max_seg
+        prev = _SEG_HINT.get(q.hint_key, (0, 0, 0))
+        _SEG_HINT[q.hint_key] = (max_seg, tile_all if q.fused_ws is not None else prev[1], prev[2] + 1)
 
     mode, u_ptr, replay_max_n = hip.RNG_PHILOX, None, 0
     keep, seed, uniforms = None, q.seed, q.uniforms

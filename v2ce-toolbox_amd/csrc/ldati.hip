@@ -117,6 +117,12 @@ struct LdatiParams {
     unsigned *tile_abs_w;         // [B*9][T] record index of the (tile, bin) run inside `temp`
     const unsigned *tile_abs;     // the same, read by the bucket sort (null: runs at seg_offsets + tile_off)
     const int *fused_status;      // status word of the fused kernel, folded into `status` by the bucket scan
+    // transposed tables for the bucket sort's setup (round 4): a sort group needs two columns of the run table and the
+    // run origins of ALL tiles -- rows of these arrays (contiguous loads) instead of one 938-byte-strided load per tile
+    int Tp;                       // T rounded up to a multiple of 8
+    unsigned short *roffT;        // [B*9][NB+1][Tp]: roff transposed, written by the bucket scan
+    unsigned *tile_src_w;         // [B*9][Tp] record index of the (tile, bin) run relative to the sort's base: tile_off transposed
+    const unsigned *tile_src;     // (classic: written by the tile scan; fused: the slot starts written by the fused kernel)
 };
 
 // ---- Philox4x32-10, counter (pixel, j>>2, p*9+c, frame), key = seed ---------------------------
@@ -619,6 +625,7 @@ __global__ __launch_bounds__(kCountThreads) void ldati_count_tiles_kernel(
 // lands in seg_offsets[seg]; the largest (tile, bin) and segment counts in stats[1], stats[2]).
 __global__ __launch_bounds__(256) void ldati_tile_scan_kernel(const unsigned *__restrict__ tc, int B,
                                                               int T, unsigned *__restrict__ tile_off,
+                                                              unsigned *__restrict__ tile_src, int Tp,
                                                               long long *seg_offsets,
                                                               unsigned long long *stats) {
     const int lane = threadIdx.x & 63, seg = blockIdx.x * 4 + (threadIdx.x >> 6), n = B * 9;
@@ -630,7 +637,10 @@ __global__ __launch_bounds__(256) void ldati_tile_scan_kernel(const unsigned *__
         const long long i = ((long long)b * T + tt) * 9 + c;
         const unsigned v = tt < T ? tc[i] : 0u;
         const unsigned incl = wave_incl_scan(v, lane);
-        if (tt < T) tile_off[i] = run + incl - v;
+        if (tt < T) {
+            tile_off[i] = run + incl - v;
+            tile_src[(long long)seg * Tp + tt] = run + incl - v;      // the same, [segment][tile] for the bucket sort's setup
+        }
         run += __shfl(incl, 63);
         mx = v > mx ? v : mx;
     }
@@ -1944,7 +1954,7 @@ __global__ __launch_bounds__(kSparseThreads) void ldati_tile_sparse_kernel(Ldati
         const unsigned bs = binstart[c], Nc = binstart[c + 1] - bs;
         const unsigned strip = ((unsigned)c * NKS) << 12;
         unsigned *dst = P.temp + (FUSED ? ((long long)b * P.T + t) * kSparseCap + bs : dst_off[c]);
-        if (FUSED && tid == 0) P.tile_abs_w[(long long)(b * 9 + c) * P.T + t] = (unsigned)(((long long)b * P.T + t) * kSparseCap + bs);
+        if (FUSED && tid == 0) P.tile_abs_w[(long long)(b * 9 + c) * P.Tp + t] = (unsigned)(((long long)b * P.T + t) * kSparseCap + bs);
         for (unsigned i = tid; i < Nc; i += NT) dst[i] = S[bs + i] - strip;
         unsigned short *row = P.roff + ((long long)(b * 9 + c) * P.T + t) * (P.NB + 1);
         for (int k = tid; k < P.NB; k += NT) {
@@ -1969,13 +1979,30 @@ __global__ __launch_bounds__(512) void ldati_bucket_scan_kernel(LdatiParams P) {
     const unsigned short *tab = P.roff + (long long)seg * P.T * (P.NB + 1);
     unsigned *bofs = P.bofs + (long long)seg * (P.NB + 1);
     // a bucket's total = sum over the tiles of (start of the next bucket - its start) = difference of the
-    // column sums: one load per tile and thread (NB + 1 <= 513 columns, 512 threads + one straggler)
-    for (int i = t; i <= P.NB; i += 512) {
-        unsigned s = 0;
+    // column sums.  The table passes through LDS in blocks of kTB tiles: rows in (coalesced), column sums from LDS, and
+    // the block leaves TRANSPOSED ([bucket][tile]) for the bucket sort, whose setup reads two columns of it per group.
+    constexpr int kTB = 32;
+    __shared__ unsigned short blk[kTB * (kMaxNB + 2)];
+    const int NC = P.NB + 1, NCp = NC | 1;                  // odd row pitch: the column reads below hit distinct banks
+    unsigned short *outT = P.roffT + (long long)seg * NC * P.Tp;
+    unsigned acc0 = 0, acc1 = 0;                            // columns t and t + 512
+    for (int t0 = 0; t0 < P.T; t0 += kTB) {
+        const int nt = P.T - t0 < kTB ? P.T - t0 : kTB;
+        for (int c0 = t; c0 < NC; c0 += 512) {              // (at most two columns per thread; the rows' loads are independent)
 #pragma unroll 8
-        for (int tt = 0; tt < P.T; ++tt) s += (unsigned)tab[(long long)tt * (P.NB + 1) + i];
-        pre[i] = s;
+            for (int r = 0; r < nt; ++r) blk[r * NCp + c0] = tab[(long long)(t0 + r) * NC + c0];
+        }
+        __syncthreads();
+        if (t < NC) for (int r = 0; r < nt; ++r) acc0 += (unsigned)blk[r * NCp + t];
+        if (t + 512 < NC) for (int r = 0; r < nt; ++r) acc1 += (unsigned)blk[r * NCp + t + 512];
+        for (int i = t; i < NC * kTB; i += 512) {
+            const int cidx = i / kTB, r = i - cidx * kTB;
+            if (r < nt) outT[(long long)cidx * P.Tp + t0 + r] = blk[r * NCp + cidx];
+        }
+        __syncthreads();
     }
+    if (t < NC) pre[t] = acc0;
+    if (t + 512 < NC) pre[t + 512] = acc1;
     __syncthreads();
     const unsigned tot_i = t < P.NB ? pre[t + 1] - pre[t] : 0u;
     unsigned total;
@@ -2085,10 +2112,10 @@ __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(Ldat
             const int tt = lane * TPL + q;
             cv[q] = 0u; ov[q] = 0u;
             if (tt < P.T) {
-                const unsigned short *row = P.roff + ((long long)seg * P.T + tt) * (P.NB + 1);
-                const unsigned r0 = row[bk0];
-                cv[q] = (unsigned)row[bk1] - r0;
-                ov[q] = r0 + (P.tile_abs ? P.tile_abs[(long long)seg * P.T + tt] : P.tile_off[((long long)b * P.T + tt) * 9 + c]);
+                const unsigned short *colT = P.roffT + (long long)seg * (P.NB + 1) * P.Tp + tt;
+                const unsigned r0 = colT[(long long)bk0 * P.Tp];
+                cv[q] = (unsigned)colT[(long long)bk1 * P.Tp] - r0;
+                ov[q] = r0 + P.tile_src[(long long)seg * P.Tp + tt];
             }
             sum += cv[q] | (cv[q] ? 0x10000u : 0u);
         }
@@ -2348,9 +2375,9 @@ __global__ __launch_bounds__(256) void ldati_big_bucket_kernel(LdatiParams P) {
         for (int i = tid; i < bins; i += 256) hist[i] = 0;
         __syncthreads();
         for (int tt = 0; tt < P.T; ++tt) {
-            const unsigned short *row = P.roff + ((long long)seg * P.T + tt) * (P.NB + 1);
-            const unsigned r0 = row[bucket], len = (unsigned)row[bucket + 1] - r0;
-            const unsigned *src = seg_temp + (P.tile_abs ? P.tile_abs[(long long)seg * P.T + tt] : P.tile_off[((long long)b * P.T + tt) * 9 + c]) + r0;
+            const unsigned short *colT = P.roffT + ((long long)seg * (P.NB + 1) + bucket) * P.Tp + tt;
+            const unsigned r0 = colT[0], len = (unsigned)colT[P.Tp] - r0;
+            const unsigned *src = seg_temp + P.tile_src[(long long)seg * P.Tp + tt] + r0;
             const unsigned catb = tt < P.tpp ? 0u : 2u;
             for (unsigned j = tid; j < len; j += 256) {
                 const unsigned r = src[j];
@@ -2374,9 +2401,9 @@ __global__ __launch_bounds__(256) void ldati_big_bucket_kernel(LdatiParams P) {
         __syncthreads();
         if (tid < 64) {
             for (int tt = 0; tt < P.T; ++tt) {
-                const unsigned short *row = P.roff + ((long long)seg * P.T + tt) * (P.NB + 1);
-                const unsigned r0 = row[bucket], len = (unsigned)row[bucket + 1] - r0;
-                const unsigned *src = seg_temp + (P.tile_abs ? P.tile_abs[(long long)seg * P.T + tt] : P.tile_off[((long long)b * P.T + tt) * 9 + c]) + r0;
+                const unsigned short *colT = P.roffT + ((long long)seg * (P.NB + 1) + bucket) * P.Tp + tt;
+                const unsigned r0 = colT[0], len = (unsigned)colT[P.Tp] - r0;
+                const unsigned *src = seg_temp + P.tile_src[(long long)seg * P.Tp + tt] + r0;
                 const unsigned catb = tt < P.tpp ? 0u : 2u;
                 const unsigned pxb = (unsigned)(tt < P.tpp ? tt : tt - P.tpp) * kTilePix;
                 for (unsigned j0 = 0; j0 < len; j0 += 64) {
@@ -2583,8 +2610,8 @@ size_t dense_tile_lds(int capA, int NB, int NW) {
 
 // geometry and capacities of the two-level path
 struct Plan {
-    int tpp, T, shift, NB, nb1, PB, capA, cap2, tbits, tile_threads, span;
-    size_t n_tab, n_bkt;                 // entries of roff; of bofs
+    int tpp, T, Tp, shift, NB, nb1, PB, capA, cap2, tbits, tile_threads, span;
+    size_t n_tab, n_tabT, n_bkt;         // entries of roff; of its transposed copy (rows padded to Tp); of bofs
     size_t lds_tile, lds_sort;
     size_t bytes;                        // workspace
     bool ok;
@@ -2596,6 +2623,7 @@ Plan make_plan(const HostScalars &h, int B, int H, int W, int64_t total_events,
     const long long HW = (long long)H * W;
     p.tpp = (int)((HW + kTilePix - 1) / kTilePix);
     p.T = 2 * p.tpp;
+    p.Tp = (p.T + 7) & ~7;
     int pb = 1;
     while ((1ll << pb) < HW) ++pb;
     p.PB = pb;
@@ -2628,6 +2656,7 @@ Plan make_plan(const HostScalars &h, int B, int H, int W, int64_t total_events,
            pb <= 22 && total_events < (1ll << 32) && B * 9 <= 65535;
     p.n_bkt = (size_t)B * 9 * (size_t)(p.NB + 1);
     p.n_tab = p.n_bkt * (size_t)p.T;
+    p.n_tabT = p.n_bkt * (size_t)p.Tp;
     p.tile_threads = tile_threads_choice(max_tile_events);
     p.lds_tile = (size_t)(2 * p.capA + 2048) * 4 + (size_t)kTilePix * 8 +
                  (size_t)(p.tile_threads / 128) * p.NB * 4 + 2 * (p.tile_threads / 64 + 1) * 4;
@@ -2637,9 +2666,9 @@ Plan make_plan(const HostScalars &h, int B, int H, int W, int64_t total_events,
     const size_t stage = (size_t)kSortThreads * 13 * 4;
     p.lds_sort = (size_t)p.cap2 * 4 + (tables > stage ? tables : stage);
     // bofs | groups [B*9*NB] | big_list [B*9*NB] | ngroups [B*9] | seg_flag [B*9] | status [4] (status, nbig) |
-    // records (u32) | roff (u16)
+    // records (u32) | roff (u16) | roffT (u16)
     p.bytes = (p.n_bkt + 2 * (size_t)B * 9 * p.NB + 2 * (size_t)B * 9 + 4 +
-               (size_t)(total_events > 0 ? total_events : 0)) * 4 + ((p.n_tab * 2 + 3) / 4) * 4;
+               (size_t)(total_events > 0 ? total_events : 0)) * 4 + ((p.n_tab * 2 + 3) / 4) * 4 + ((p.n_tabT * 2 + 3) / 4) * 4;
     if (p.lds_tile > 160 * 1024 || p.lds_sort > 160 * 1024) p.ok = false;
     return p;
 }
@@ -2716,7 +2745,8 @@ Layout make_layout(const HostScalars &h, const Opts &o, int B, int H, int W, int
 extern "C" size_t v2ce_ldati_tile_ws_bytes(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
     const long long tpp = ((long long)H * W + kTilePix - 1) / kTilePix;
-    return (size_t)2 * (size_t)B * (size_t)(2 * tpp) * 9 * 4;
+    const long long Tp = (2 * tpp + 7) & ~7ll;
+    return (size_t)2 * (size_t)B * (size_t)(2 * tpp) * 9 * 4 + (size_t)B * 9 * (size_t)Tp * 4;     // tile counts | tile offsets | the offsets [segment][tile]
 }
 
 extern "C" int v2ce_ldati_count(const float *vox, int B, int H, int W, const v2ce_ldati_options *options, void *tile_ws,
@@ -2744,7 +2774,7 @@ extern "C" int v2ce_ldati_count(const float *vox, int B, int H, int W, const v2c
     const int count_strategy = o.strategy == V2CE_STRATEGY_NONE ? V2CE_STRATEGY_NONE : V2CE_STRATEGY_SLOPE;
     hipLaunchKernelGGL(ldati_count_tiles_kernel, dim3(T, B), dim3(kCountThreads), 0, s, vox, HW, tpp, count_strategy, o.bidir, tc,
                        reinterpret_cast<unsigned long long *>(stats));
-    hipLaunchKernelGGL(ldati_tile_scan_kernel, dim3((B * 9 + 3) / 4), dim3(256), 0, s, tc, B, T, tile_off,
+    hipLaunchKernelGGL(ldati_tile_scan_kernel, dim3((B * 9 + 3) / 4), dim3(256), 0, s, tc, B, T, tile_off, tile_off + (size_t)B * T * 9, (T + 7) & ~7,
                        reinterpret_cast<long long *>(seg_offsets), reinterpret_cast<unsigned long long *>(stats));
     hipLaunchKernelGGL(ldati_seg_scan_kernel, dim3(1), dim3(256), 0, s, B * 9, reinterpret_cast<long long *>(seg_offsets),
                        reinterpret_cast<unsigned long long *>(stats));
@@ -2784,7 +2814,7 @@ FusedLayout make_fused_layout(const HostScalars &h, const Opts &o, int B, int H,
     FusedLayout F{};
     F.p0 = make_plan(h, B, H, W, 0, seg_hint > 0 ? seg_hint : 0, 0);
     const Plan &p = F.p0;
-    const size_t n_abs = (size_t)B * 9 * p.T, n_rec = (size_t)B * p.T * kSparseCap;
+    const size_t n_abs = (size_t)B * 9 * p.Tp, n_rec = (size_t)B * p.T * kSparseCap;
     F.ok = h.ok && p.T <= kMaxTiles && p.NB <= kMaxNB && p.PB <= 22 && B * 9 <= 65535 && n_rec < (1ull << 32) &&
            9ll * ((long long)p.NB << p.shift) < (1ll << 20) &&
            (o.strategy == V2CE_STRATEGY_SLOPE || o.strategy == V2CE_STRATEGY_NONE) && o.pooling == V2CE_POOL_NONE &&
@@ -2885,7 +2915,7 @@ extern "C" int v2ce_ldati_count_fused(const float *vox, int B, int H, int W, dou
     V2CE_HIP_CHECK(hipMemsetAsync(fb, 0, 16, s));
     LdatiParams P{};
     if (int rc = fill_params(P, h, o, vox, B, H, W, fps, rng_mode, uniforms, replay_max_n, seed, frame_base, s)) return rc;
-    P.shift = pl.shift; P.NB = pl.NB; P.nb1 = pl.nb1; P.T = pl.T; P.tpp = pl.tpp; P.PB = pl.PB;
+    P.shift = pl.shift; P.NB = pl.NB; P.nb1 = pl.nb1; P.T = pl.T; P.Tp = pl.Tp; P.tpp = pl.tpp; P.PB = pl.PB;
     P.sparse_cap = kSparseCap;
     P.status = reinterpret_cast<int *>(fb);
     P.tc_w = tc;
@@ -2896,7 +2926,7 @@ extern "C" int v2ce_ldati_count_fused(const float *vox, int B, int H, int W, dou
     V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ldati_tile_sparse_kernel<true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSparseLds));
     hipLaunchKernelGGL(ldati_tile_sparse_kernel<true>, dim3(pl.T, B), dim3(kSparseThreads), kSparseLds, s, P);
-    hipLaunchKernelGGL(ldati_tile_scan_kernel, dim3((B * 9 + 3) / 4), dim3(256), 0, s, tc, B, pl.T, tile_off,
+    hipLaunchKernelGGL(ldati_tile_scan_kernel, dim3((B * 9 + 3) / 4), dim3(256), 0, s, tc, B, pl.T, tile_off, tile_off + (size_t)B * pl.T * 9, pl.Tp,
                        reinterpret_cast<long long *>(seg_offsets), reinterpret_cast<unsigned long long *>(stats));
     hipLaunchKernelGGL(ldati_seg_scan_kernel, dim3(1), dim3(256), 0, s, B * 9, reinterpret_cast<long long *>(seg_offsets),
                        reinterpret_cast<unsigned long long *>(stats));
@@ -2958,9 +2988,10 @@ int emit_impl(const float *vox, int B, int H, int W, double fps, double t0,
                      workspace_bytes, L.bytes);
         unsigned char *wb = static_cast<unsigned char *>(workspace);
         unsigned *w = static_cast<unsigned *>(workspace);
-        P.shift = pl.shift; P.NB = pl.NB; P.nb1 = pl.nb1; P.T = pl.T; P.tpp = pl.tpp; P.PB = pl.PB;
+        P.shift = pl.shift; P.NB = pl.NB; P.nb1 = pl.nb1; P.T = pl.T; P.Tp = pl.Tp; P.tpp = pl.tpp; P.PB = pl.PB;
         P.capA = pl.capA; P.cap2 = pl.cap2; P.tbits = pl.tbits;
         P.tile_off = static_cast<const unsigned *>(tile_ws) + (size_t)B * pl.T * 9;
+        P.tile_src = P.tile_off + (size_t)B * pl.T * 9;
         P.tc = static_cast<const unsigned *>(tile_ws);
         // lightly populated tiles (all nine bins <= kSparseCap events) take the one-pass sparse kernel; it needs
         // the nine bins' keys side by side in 20 bits
@@ -3039,6 +3070,7 @@ int emit_impl(const float *vox, int B, int H, int W, double fps, double t0,
         P.nbig = reinterpret_cast<unsigned *>(P.status + 1);
         P.temp = reinterpret_cast<unsigned *>(P.status + 4);
         P.roff = reinterpret_cast<unsigned short *>(P.temp + (size_t)total_events);
+        P.roffT = P.roff + ((pl.n_tab + 1) & ~(size_t)1);
         V2CE_HIP_CHECK(hipMemsetAsync(P.status, 0, 4 * sizeof(int), st));
         // the fused count already ran the sparse tile pass: usable when its assumed geometry is the plan's and every tile fitted
         bool fused = false;
@@ -3052,6 +3084,7 @@ int emit_impl(const float *vox, int B, int H, int W, double fps, double t0,
                 const unsigned char *fb = static_cast<const unsigned char *>(fused_ws);
                 P.fused_status = reinterpret_cast<const int *>(fb);
                 P.tile_abs = reinterpret_cast<const unsigned *>(fb + F.off_abs);
+                P.tile_src = P.tile_abs;
                 P.temp = const_cast<unsigned *>(reinterpret_cast<const unsigned *>(fb + F.off_rec));
                 P.roff = const_cast<unsigned short *>(reinterpret_cast<const unsigned short *>(fb + F.off_roff));
             }
