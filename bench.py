@@ -175,32 +175,47 @@ def fresh_model(precision, device):
     return m.eval().to(device)
 
 
-def host_to_host(args, device, steps):
+def host_to_host(args, device, steps, comm=None, world=1):
     """SURVEY 8d's end-to-end INCLUDING the host hand-over, through the product driver
-    (pipeline.run_clip): u8 frames in host memory -> packed events in pinned host memory, for a clip of
-    steps x batch sequences.  H2D / compute / D2H overlap on three streams."""
+    (pipeline.run_clip): u8 frames in host memory -> packed events in host memory, for a clip of
+    steps x batch sequences per GPU.  H2D / compute / D2H overlap on three streams.  With more than one rank the
+    clip is world x as long and every reference batch (world x batch sequences) is shared out over the ranks, exactly
+    like the CLI under torchrun; the records reach host memory the way `V2CE_GATHER` says (default 'device': RCCL gather
+    to rank 0's HBM + rank 0's PCIe link into its pinned sink; 'host': every rank over its own link into one shared segment)."""
     from v2ce_toolbox_amd import pipeline
-    n_seq = steps * args.batch
+    n_seq = steps * args.batch * world
     base = synth.synthetic_frames(SEQ + 1, H, W, seed=1000)
     frames = np.concatenate([base[:SEQ]] * n_seq + [base[SEQ:SEQ + 1]])          # n_seq*16 + 1 frames
     model = fresh_model(args.precision, device)
-    kw = dict(infer_type="center", batch_size=args.batch, fps=30, seed=0x5EED, device=str(device), reuse_output=True)
+    kw = dict(infer_type="center", batch_size=args.batch * world, fps=30, seed=0x5EED, device=str(device), reuse_output=True)
+    if comm is not None:
+        kw["comm"] = comm
     # warm-up clip of the same length: device / pinned allocators, and the page-locked output buffer,
     # which a process keeps between clips (reuse_output; locking 1.9 GB costs ~140 ms once)
     pipeline.run_clip(frames, model, **kw)
     torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
     trace = {} if os.environ.get("V2CE_TRACE") else None
     t0 = time.perf_counter()
     ev = pipeline.run_clip(frames, model, trace=trace, **kw)
     torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
     dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t[0])
+        if ev is None:                                                          # only rank 0 holds the clip's events
+            return None
     if trace is not None:
         print("host_to_host trace (s):", {k: (round(v, 4) if not isinstance(v, list) else v) for k, v in trace.items()},
               "total", round(dt, 4), file=sys.stderr)
     pairs = n_seq * SEQ
     # the box's own device -> pinned-host copy rate for one step's records: on boxes where it is below
     # d2h_bytes_per_step / GPU step time, the copy-out stream (not the GPU) paces the pipeline
-    nbytes = int(len(ev) * 13 / steps)
+    nbytes = int(len(ev) * 13 / steps / world)                                  # one rank's records of one step
     src = torch.empty(nbytes, dtype=torch.uint8, device=device)
     dst = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
     best = float("inf")
@@ -210,7 +225,8 @@ def host_to_host(args, device, steps):
         dst.copy_(src, non_blocking=True)
         torch.cuda.synchronize()
         best = min(best, time.perf_counter() - c0)
-    return {"value": pairs / dt, "unit": "frame-pairs/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
+    return {"value": pairs / dt, "unit": "frame-pairs/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "n_gpus": world,
+            "gather": os.environ.get("V2CE_GATHER", "device") if world > 1 else None,
             "mevents_per_s": len(ev) / dt / 1e6, "h2d_bytes_per_step": int(args.batch * (SEQ + 1) * H * W),
             "d2h_bytes_per_step": nbytes, "d2h_copy_gb_per_s": nbytes / best / 1e9, "d2h_copy_ms_per_step": 1e3 * best,
             "what": "u8 frames in host memory -> event_stream array in pinned host memory through pipeline.run_clip "
@@ -291,7 +307,35 @@ def main():
     # rank 0 receives every rank's records of a step over RCCL on a communication stream (dist.StreamedGather, the
     # product driver's: pipeline.run_clip); the byte counts are read one step later, so no rank waits on its compute stream
     comm = vdist.default_comm(force=dist_on)
-    gather = comm.streamed_gather(None, dst=0) if dist_on else None
+    gather_mode = os.environ.get("V2CE_GATHER", "device")
+    d2h = {"bytes": 0, "s": 0.0}
+
+    def new_exchange():
+        """The exchange pipeline.run_clip builds for a clip: 'host' = every rank downloads its own records into its slice of
+        one shared host segment (only byte counts cross RCCL); 'device' = RCCL gather to rank 0's HBM, rank 0 downloads
+        everything into its pinned sink.  The bench's segment is a 4 GiB ring (a long run must not fill /dev/shm)."""
+        if not dist_on:
+            return None, None
+        from v2ce_toolbox_amd import pipeline
+        if gather_mode == "host":
+            path = None
+            if rank == 0:
+                path = pipeline._shared_segment_path()
+                open(path, "wb").close()
+            path = comm.broadcast_object(path, src=0)
+            ex = vdist.HostDirectGather(comm, device, path, 0, False)
+            ex.ring_bytes = 4 << 30
+            return ex, path
+        sink = pipeline.EventSink(device, 1, reuse=True) if rank == 0 else None
+
+        def on_pieces(pieces, stream):
+            for p in pieces:
+                sink.push(p, 0, src_stream=stream)
+            sink.used = 0                                       # (the bench keeps one step's worth: the sink is a staging area here)
+            return sink.last_done
+        return comm.streamed_gather(on_pieces if rank == 0 else None, dst=0), sink
+    gather, gather_aux = None, None
+    stale_segments = []
 
     def front(profile):
         """Stage 1 + LDATI count of one step; returns the pending LDATI call."""
@@ -332,6 +376,10 @@ def main():
             _, ev = back(p)
             if ev._status is not None:                          # LDATI's device status word, folded on the stream
                 status[0] = ev._status.clone() if status[0] is None else torch.maximum(status[0], ev._status)
+        nonlocal gather, gather_aux
+        t_x = time.perf_counter()
+        gather, gather_aux = new_exchange()
+        t_new = time.perf_counter() - t_x
         for _ in range(k):
             nxt = front(profile)
             if pending is not None:
@@ -339,8 +387,17 @@ def main():
             pending = nxt
         if pending is not None:
             done(pending)
+        t_loop = time.perf_counter() - t_x
         if gather is not None:
-            gather.drain()                                      # the last step's gather
+            gather.drain()                                      # the last step's exchange
+            if gather_mode == "host":
+                gather.finalize()                               # every rank's records are in the shared segment
+                if rank == 0:
+                    stale_segments.append(gather_aux)           # (unlinked behind the timed region: freeing the pages is not the product's job either -- rank 0 returns them as the array)
+            elif rank == 0 and gather_aux.stream is not None:
+                gather_aux.stream.synchronize()                 # rank 0's download of the last pieces
+            if os.environ.get("V2CE_TRACE"):
+                print(f"bench exchange: new {1e3 * t_new:.1f} ms, loop {1e3 * t_loop:.1f} ms, total {1e3 * (time.perf_counter() - t_x):.1f} ms", file=sys.stderr)
 
     run_steps(args.warmup, True)            # same code path as the timed steps (warms the HIP event pool too)
     ldati_prof.clear()
@@ -357,6 +414,9 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    for seg in stale_segments:
+        if os.path.exists(seg):
+            os.unlink(seg)
     if status[0] is not None and int(status[0].item()) != 0:
         sys.exit("bench.py: LDATI reported a segment it could not order (device status word)")
     events = float(n_events[0])
@@ -424,6 +484,9 @@ def main():
     except Exception:
         pass
 
+    h2h_multi = None
+    if world > 1 and args.workload == "e2e" and not args.no_host_to_host:
+        h2h_multi = host_to_host(args, device, 4, comm=comm, world=world)        # 4 reference batches of world x batch sequences (N = 8: BASELINE config 3's clip)
     if rank == 0:
         workloads = {"e2e": f"346x260 center, batch={b} sequences x 16 frame-pairs per GPU, "
                             "V2ce3d (synthetic weights seed 0) + LDATI (Philox), inputs resident in HBM",
@@ -455,6 +518,11 @@ def main():
         if dist_on:
             line["gathered_bytes_per_step"] = gather.bytes_last
             line["rccl_world"] = world
+            line["gather"] = {"mode": gather_mode,
+                              "what": ("every rank downloads its own records over its own PCIe link into its slice of one shared host "
+                                       "segment; RCCL carries one int64 byte count per rank and step (dist.HostDirectGather)") if gather_mode == "host"
+                              else "RCCL gather of the padded record buffers to rank 0's HBM, rank 0 downloads them (dist.StreamedGather)",
+                              "inside_timed_region": True}
         if world == 1 and args.workload == "e2e":
             if not args.no_host_to_host:
                 line["host_to_host"] = host_to_host(args, device, max(args.steps, 16))   # >= 16 batches (1025 frames): the drain of the last batch (0.5 ms LDATI + 152 MB D2H) is a fixed ~7 ms
@@ -474,6 +542,8 @@ def main():
                 torch.cuda.synchronize()
                 t32 = (time.perf_counter() - t32) / 3
                 line["exact_f32"] = {"value": pairs_per_rank / t32, "unit": "frame-pairs/s", "ms_per_step": 1e3 * t32, "steps": 3}
+        if h2h_multi is not None:
+            line["host_to_host"] = h2h_multi
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

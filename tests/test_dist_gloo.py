@@ -243,3 +243,138 @@ def test_range_guard_decision_is_collective():
         assert p.exitcode == 0
     assert [g[1] for g in got] == [1, 1] and [g[2] for g in got] == [ref.calls] * 2
     assert got[0][3] == single.tobytes() and got[1][3] is None
+
+
+# ------------------------------------------------------------------------------------------------
+# round 4: gather modes, failure protocol, bounded receive buffers
+# ------------------------------------------------------------------------------------------------
+def _spawn(target, world, args=(), timeout=180):
+    import socket
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + tuple(args)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=timeout) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return sorted(got)
+
+
+def _mode_worker(rank, world, port, q, mode, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), V2CE_GATHER=mode)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from test_product_glue import FakeModel
+        from v2ce_toolbox_amd import synth
+        from v2ce_toolbox_amd import v2ce as cli
+        frames = synth.synthetic_frames(85, 8, 20, seed=3)
+        kw = dict(infer_type="center", width=12, height=8, batch_size=2, device="cpu", stage2=fake_stage2(30))
+        out = cli.run(frames, FakeModel(), **kw)
+        path = os.path.join(out_dir, f"{mode}.npz")
+        n = cli.run(frames, FakeModel(), out_path=path, **kw)         # the streamed .npz: every rank writes its own slice
+        q.put((rank, None if out is None else bytes(out.tobytes()), n))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["host", "device"])
+def test_gather_modes_equal_single_process(mode, tmp_path):
+    """Both ways of bringing the ranks' records together -- 'host' (every rank writes its own slice of the shared host
+    segment / of the streamed .npz; only byte counts are exchanged) and 'device' (gather on rank 0, rank 0 downloads) --
+    give the single-process bytes, as an array and as a file."""
+    from v2ce_toolbox_amd import synth
+    from v2ce_toolbox_amd import v2ce as cli
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_product_glue import FakeModel
+    frames = synth.synthetic_frames(85, 8, 20, seed=3)
+    single = cli.run(frames, FakeModel(), infer_type="center", width=12, height=8, batch_size=2, device="cpu", stage2=fake_stage2(30))
+    got = _spawn(_mode_worker, 3, (mode, str(tmp_path)))
+    assert got[0][1] == single.tobytes() and got[1][1] is None and got[2][1] is None
+    assert got[0][2] == len(single)
+    z = np.load(tmp_path / f"{mode}.npz")["event_stream"]
+    assert z.tobytes() == single.tobytes() and not os.path.exists(tmp_path / f"{mode}.npz.part")
+
+
+def failing_stage2(fps, bad_rank, bad_pair):
+    begin, finish = fake_stage2(fps)
+
+    def begin2(vox, first_pair):
+        return (begin(vox, first_pair), first_pair, vox.shape[0])
+
+    def finish2(handle):
+        packed, first_pair, n = handle
+        if dist.get_rank() == bad_rank and first_pair <= bad_pair < first_pair + n:
+            raise ValueError("stage 2 failed on purpose")
+        return packed, None
+    return begin2, finish2
+
+
+def _failure_worker(rank, world, port, q, mode, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), V2CE_GATHER=mode)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=60))
+    try:
+        from test_product_glue import FakeModel
+        from v2ce_toolbox_amd import dist as vd
+        from v2ce_toolbox_amd import synth
+        from v2ce_toolbox_amd import v2ce as cli
+        frames = synth.synthetic_frames(101, 8, 20, seed=3)            # 7 sequences, batches of 2: rank 1 holds pairs 48..63 in batch 1
+        path = os.path.join(out_dir, "f.npz")
+        try:
+            cli.run(frames, FakeModel(), infer_type="center", width=12, height=8, batch_size=2, device="cpu",
+                    stage2=failing_stage2(30, 1, 50), out_path=path)
+            q.put((rank, "no error"))
+        except ValueError as e:
+            q.put((rank, "own:" + str(e)))
+        except vd.RankFailure as e:
+            q.put((rank, "peer:" + str(e.ranks)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["host", "device"])
+def test_rank_failure_stops_every_rank(mode, tmp_path):
+    """a stage-2 error on ONE rank in the middle of a clip.  The rank reports it with its next byte count
+    (-1), every rank stops at the same step -- the failed rank with its own error, the others with RankFailure naming it --,
+    nobody waits for a collective the failed rank never joins, and no file (complete or partial) is left behind."""
+    got = _spawn(_failure_worker, 2, (mode, str(tmp_path)), timeout=120)
+    assert got[0] == (0, "peer:[1]") and got[1] == (1, "own:stage 2 failed on purpose")
+    assert os.listdir(tmp_path) == []
+
+
+def _pool_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from v2ce_toolbox_amd import dist as vd
+        seen, caps = [], []
+        g = vd.StreamedGather(0, None, (lambda pieces, stream: seen.append([int(p.sum()) for p in pieces])) if rank == 0 else None)
+        sizes = [24 << 20, 30 << 20, 28 << 20, 30 << 20, 1 << 10, 29 << 20]       # "pano-sized" steps, scaled to the CPU box
+        for k, n in enumerate(sizes):
+            g.submit(torch.full((n + rank,), (k + rank) % 7, dtype=torch.uint8))
+            caps.append((g.pool.get("cap", 0), id(g.pool.get("recv"))))
+        g.drain()
+        ok = True
+        if rank == 0:
+            ok = seen == [[(k % 7) * sizes[k], ((k + 1) % 7) * (sizes[k] + 1)] for k in range(len(sizes))]
+        # one allocation for the first step, one growth for the 30 MiB step, then reuse: the receive buffers do not scale
+        # with the number of steps in flight
+        q.put((rank, ok, len({c for c in caps if c[0]})))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_device_gather_reuses_bounded_receive_buffers():
+    """the padded gather's send / receive buffers live in a pool sized from the largest step so far
+    (+25 %), not in fresh allocations per step: six steps of up to 30 MiB per rank allocate twice."""
+    got = _spawn(_pool_worker, 2)
+    assert all(ok for _, ok, _ in got) and all(n <= 2 for _, _, n in got), got

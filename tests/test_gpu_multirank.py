@@ -168,3 +168,27 @@ def test_rccl_collectives_world_of_one():
     r = torchrun([os.path.join(ROOT, "tests", "rccl_world1_worker.py")], {})
     assert "rccl world-of-one ok" in r.stdout
 
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: the real multi-process RCCL path (ADVICE r3)")
+@pytest.mark.parametrize("mode", ["host", "device"])
+def test_two_ranks_nccl_equal_single_process(tmp_path, mode):
+    """Two processes, two GPUs, RCCL: the CLI under torchrun against the single-process CLI, byte for byte, in both gather
+    modes (communication-stream ordering, buffer lifetimes and the concurrent use of the world and tile communicators are
+    only exercised here -- the ThreadWorld emulation shares one stream).  Skipped on the 1-GPU boxes of this pool."""
+    np.save(tmp_path / "f.npy", synth.synthetic_frames(150, 64, 160, seed=9))
+    outs = []
+    for nproc in (1, 2):
+        out = tmp_path / f"o{nproc}"
+        args = [os.path.join(ROOT, "v2ce.py"), "--npy_frames", str(tmp_path / "f.npy"), "--height", "64", "--width", "80",
+                "--synthetic_weights", "0", "-o", str(out), "-b", "4", "--seed", "3", "-t", "pano", "--write_event_frame_video", "false"]
+        env = dict(os.environ, V2CE_GATHER=mode)
+        env.pop("MASTER_PORT", None)
+        cmd = ([sys.executable] if nproc == 1 else
+               [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(free_port())]) + args
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+        files = [f for f in os.listdir(out) if f.endswith("-events.npz")]
+        outs.append(np.load(out / files[0])["event_stream"])
+    assert len(outs[0]) > 1000 and outs[0].tobytes() == outs[1].tobytes()

@@ -54,7 +54,7 @@ constexpr int kMaxSpanKeys = 128;     // timestamps a sort group spans at most (
 constexpr int kCapTile = 15360;       // events of one (tile, bin) the tile pass can hold in LDS
 constexpr int kSparseCap = 8192;      // events of one tile over all nine bins the sparse tile kernel holds
 constexpr int kSparseThreads = 512;
-constexpr size_t kSparseLds = (size_t)(2 * kSparseCap + kSparseThreads * 5 + 34) * 4 + 9 * 8;
+constexpr size_t kSparseLds = (size_t)(2 * kSparseCap + kSparseThreads * 5 + 34) * 4 + 9 * 8 + (kSparseThreads / 64) * 10 * 4;
 constexpr int kSlopeM = 31;            // slope table (g_slope_tab): |count difference| <= kSlopeM, count <= kSlopeM; else computed
 constexpr int kSlopeTab = (2 * kSlopeM + 1) * (kSlopeM + 1);
 constexpr int kSortThreads = 256;
@@ -117,12 +117,9 @@ struct LdatiParams {
     unsigned *tile_abs_w;         // [B*9][T] record index of the (tile, bin) run inside `temp`
     const unsigned *tile_abs;     // the same, read by the bucket sort (null: runs at seg_offsets + tile_off)
     const int *fused_status;      // status word of the fused kernel, folded into `status` by the bucket scan
-    // transposed tables for the bucket sort's setup (round 4): a sort group needs two columns of the run table and the
-    // run origins of ALL tiles -- rows of these arrays (contiguous loads) instead of one 938-byte-strided load per tile
     int Tp;                       // T rounded up to a multiple of 8
-    unsigned short *roffT;        // [B*9][NB+1][Tp]: roff transposed, written by the bucket scan
-    unsigned *tile_src_w;         // [B*9][Tp] record index of the (tile, bin) run relative to the sort's base: tile_off transposed
-    const unsigned *tile_src;     // (classic: written by the tile scan; fused: the slot starts written by the fused kernel)
+    const unsigned *tile_src;     // [B*9][Tp] record index of the (tile, bin) run relative to the sort's base, one contiguous row per
+                                  // segment (two-pass: tile_off transposed by the tile scan; fused: the slot starts)
 };
 
 // ---- Philox4x32-10, counter (pixel, j>>2, p*9+c, frame), key = seed ---------------------------
@@ -1705,6 +1702,7 @@ __global__ __launch_bounds__(kSparseThreads) void ldati_tile_sparse_kernel(Ldati
     unsigned *binstart = part + 10;                                 // [10]
     float *offt_s = reinterpret_cast<float *>(binstart + 10);       // [9]
     long long *kbase_s = reinterpret_cast<long long *>(offt_s + 10);   // [9], 8-byte aligned (kSparseLds)
+    unsigned *red = reinterpret_cast<unsigned *>(kbase_s + 9);         // [NW][10] the fused count's wave totals
     static_assert(NW + 1 <= 10 && ((2 * kSparseCap + HWORDS + 34) & 1) == 0, "sparse LDS map");
     long long dst_off[9];                                           // where the tile's nine runs go
 #pragma unroll
@@ -1736,61 +1734,16 @@ __global__ __launch_bounds__(kSparseThreads) void ldati_tile_sparse_kernel(Ldati
     for (int i = tid; i < HWORDS; i += NT) hist[i] = 0;
     if (tid < 4) cur[tid] = 0;
     if (tid < 9) { offt_s[tid] = P.offt[tid]; kbase_s[tid] = P.kbase[tid]; }
-    if (FUSED) {
-        // the count pass (ldati_count_tiles_kernel): events per bin of this tile, largest voxel count
-        int cnt[9], mx = 0;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) cnt[i] = 0;
-#pragma unroll
-        for (int q = 0; q < PPT; ++q) {
-            int nn[9];
-            float td[9];
-            relocate_all(yv[q], P.bidir != 0, nn, td);                   // (an all-zero pixel past the image counts nothing)
-#pragma unroll
-            for (int i = 0; i < 9; ++i) {
-                cnt[i] += (P.strategy == V2CE_STRATEGY_NONE) ? (nn[i] == 1) : (nn[i] > 0 ? nn[i] : 0);
-                mx = nn[i] > mx ? nn[i] : mx;
-            }
-        }
-        int *red = reinterpret_cast<int *>(S);                           // [NW][10], free until the lists are built
-        const int lane_c = tid & 63, wid_c = tid >> 6;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            int v = cnt[i];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-            if (lane_c == 0) red[wid_c * 10 + i] = v;
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const int m = __shfl_xor(mx, o);
-            mx = m > mx ? m : mx;
-        }
-        if (lane_c == 0) red[wid_c * 10 + 9] = mx;
-        __syncthreads();
-        unsigned sum9[9];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            unsigned v = 0;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) v += (unsigned)red[w * 10 + i];
-            sum9[i] = v;
-            ntot += v;
-        }
-        if (tid < 9) P.tc_w[((long long)b * P.T + t) * 9 + tid] = pick9(sum9, tid);
-        if (tid == 9) {
-            int m = 0;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) m = red[w * 10 + 9] > m ? red[w * 10 + 9] : m;
-            if (m > 0) atomicMax(&P.stats_w[0], (unsigned long long)m);
-            if (ntot) atomicMax(&P.stats_w[4], (unsigned long long)ntot);
-        }
-        if (ntot > (unsigned)P.sparse_cap) return;       // uniform: the call falls back to the two-pass path
-    }
     __syncthreads();
 
     // ---- 2a: classify; append to the lists (slots from wave_alloc: one LDS atomic per wave, pixel and list)
     const int lane_s = tid & 63;
+    // FUSED: the count pass rides along (what ldati_count_tiles_kernel computes: events per bin, largest voxel count).  The
+    // lists are written before the tile's total is known, so their indices are bounded: a tile whose lists would collide
+    // has more than kSparseCap events and is discarded below anyway.
+    int cnt9[9], vmax = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) cnt9[i] = 0;
 #pragma unroll
     for (int q = 0; q < PPT; ++q) {
         int nn[9];
@@ -1804,14 +1757,19 @@ __global__ __launch_bounds__(kSparseThreads) void ldati_tile_sparse_kernel(Ldati
             const int n = valid ? nn[c] : 0;
             ns += n == 1 ? 1u : 0u;
             nm += (n >= 2 && P.strategy != V2CE_STRATEGY_NONE) ? 1u : 0u;
+            if (FUSED) {
+                cnt9[c] += (P.strategy == V2CE_STRATEGY_NONE) ? (n == 1) : (n > 0 ? n : 0);
+                vmax = n > vmax ? n : vmax;
+            }
         }
         unsigned si = wave_alloc(&cur[0], ns, lane_s), mi0 = wave_alloc(&cur[1], nm, lane_s);
 #pragma unroll
         for (int c = 0; c < 9; ++c) {
             const int n = valid ? nn[c] : 0;
             if (n == 1) {
-                SL[si++] = make_uint2(__float_as_uint(td[c]), local | ((unsigned)c << kLocalBits));
-            } else if (n >= 2 && P.strategy != V2CE_STRATEGY_NONE) {
+                if (!FUSED || si < (unsigned)kSparseCap) SL[si] = make_uint2(__float_as_uint(td[c]), local | ((unsigned)c << kLocalBits));
+                ++si;
+            } else if (n >= 2 && P.strategy != V2CE_STRATEGY_NONE && (!FUSED || 3u * (mi0 + 1u) <= 2u * (unsigned)kSparseCap)) {
                 float k, bb;
                 if (P.kbb) {
                     const float2 kq = P.kbb[((long long)(b * 2 + pidx) * 9 + c) * P.HW + (x0 + lpx0 + q)];
@@ -1824,10 +1782,44 @@ __global__ __launch_bounds__(kSparseThreads) void ldati_tile_sparse_kernel(Ldati
                 e[0] = local | ((unsigned)c << kLocalBits) | ((unsigned)n << 15);
                 e[1] = __float_as_uint(k);
                 e[2] = __float_as_uint(bb);
+            } else if (FUSED && n >= 2 && P.strategy != V2CE_STRATEGY_NONE) {
+                ++mi0;                                       // (beyond the list: the tile is dense)
             }
         }
     }
+    if (FUSED) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const unsigned tot = wave_incl_scan((unsigned)cnt9[i], lane_s);
+            if (lane_s == 63) red[(tid >> 6) * 10 + i] = tot;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int m = __shfl_xor(vmax, o);
+            vmax = m > vmax ? m : vmax;
+        }
+        if (lane_s == 0) red[(tid >> 6) * 10 + 9] = (unsigned)vmax;
+    }
     __syncthreads();
+    if (FUSED) {
+        unsigned mine = 0;                                   // thread i < 9: events of bin i; thread 9: largest voxel count
+        if (tid < 10) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const unsigned v = red[w * 10 + tid];
+                mine = tid == 9 ? (v > mine ? v : mine) : mine + v;
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+#pragma unroll
+            for (int i = 0; i < 9; ++i) ntot += red[w * 10 + i];
+        if (tid < 9) P.tc_w[((long long)b * P.T + t) * 9 + tid] = mine;
+        // (plain reads first: after the first few tiles these maxima rarely grow, and same-address atomics serialise)
+        if (tid == 9 && mine > 0 && (unsigned long long)mine > P.stats_w[0]) atomicMax(&P.stats_w[0], (unsigned long long)mine);
+        if (tid == 10 && ntot > 0 && (unsigned long long)ntot > P.stats_w[4]) atomicMax(&P.stats_w[4], (unsigned long long)ntot);
+        if (ntot > (unsigned)P.sparse_cap) return;       // uniform: the call falls back to the two-pass path
+    }
     // ---- 2b: the lists move to registers (they share their LDS with the records)
     const unsigned Ns = cur[0], Nmp = cur[1];
     constexpr int SPT = kSparseCap / NT, MPT = kSparseCap / 2 / NT;    // most list entries per thread
@@ -1979,30 +1971,16 @@ __global__ __launch_bounds__(512) void ldati_bucket_scan_kernel(LdatiParams P) {
     const unsigned short *tab = P.roff + (long long)seg * P.T * (P.NB + 1);
     unsigned *bofs = P.bofs + (long long)seg * (P.NB + 1);
     // a bucket's total = sum over the tiles of (start of the next bucket - its start) = difference of the
-    // column sums.  The table passes through LDS in blocks of kTB tiles: rows in (coalesced), column sums from LDS, and
-    // the block leaves TRANSPOSED ([bucket][tile]) for the bucket sort, whose setup reads two columns of it per group.
-    constexpr int kTB = 32;
-    __shared__ unsigned short blk[kTB * (kMaxNB + 2)];
-    const int NC = P.NB + 1, NCp = NC | 1;                  // odd row pitch: the column reads below hit distinct banks
-    unsigned short *outT = P.roffT + (long long)seg * NC * P.Tp;
-    unsigned acc0 = 0, acc1 = 0;                            // columns t and t + 512
-    for (int t0 = 0; t0 < P.T; t0 += kTB) {
-        const int nt = P.T - t0 < kTB ? P.T - t0 : kTB;
-        for (int c0 = t; c0 < NC; c0 += 512) {              // (at most two columns per thread; the rows' loads are independent)
+    // column sums: one load per tile and thread (NB + 1 <= 513 columns, 512 threads + one straggler).
+    // (Round 4 tried handing the table to the sort TRANSPOSED -- [bucket][tile], through LDS here -- so that its setup reads
+    // two contiguous columns instead of one 938-byte-strided load per tile: sort 520 -> 483 us on the stress chunk, but this
+    // kernel 34 -> 48 us there and 20 -> 50 us in the e2e regime (576 segments, latency-bound): removed.)
+    for (int i = t; i <= P.NB; i += 512) {
+        unsigned s = 0;
 #pragma unroll 8
-            for (int r = 0; r < nt; ++r) blk[r * NCp + c0] = tab[(long long)(t0 + r) * NC + c0];
-        }
-        __syncthreads();
-        if (t < NC) for (int r = 0; r < nt; ++r) acc0 += (unsigned)blk[r * NCp + t];
-        if (t + 512 < NC) for (int r = 0; r < nt; ++r) acc1 += (unsigned)blk[r * NCp + t + 512];
-        for (int i = t; i < NC * kTB; i += 512) {
-            const int cidx = i / kTB, r = i - cidx * kTB;
-            if (r < nt) outT[(long long)cidx * P.Tp + t0 + r] = blk[r * NCp + cidx];
-        }
-        __syncthreads();
+        for (int tt = 0; tt < P.T; ++tt) s += (unsigned)tab[(long long)tt * (P.NB + 1) + i];
+        pre[i] = s;
     }
-    if (t < NC) pre[t] = acc0;
-    if (t + 512 < NC) pre[t + 512] = acc1;
     __syncthreads();
     const unsigned tot_i = t < P.NB ? pre[t + 1] - pre[t] : 0u;
     unsigned total;
@@ -2112,9 +2090,9 @@ __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(Ldat
             const int tt = lane * TPL + q;
             cv[q] = 0u; ov[q] = 0u;
             if (tt < P.T) {
-                const unsigned short *colT = P.roffT + (long long)seg * (P.NB + 1) * P.Tp + tt;
-                const unsigned r0 = colT[(long long)bk0 * P.Tp];
-                cv[q] = (unsigned)colT[(long long)bk1 * P.Tp] - r0;
+                const unsigned short *row = P.roff + ((long long)seg * P.T + tt) * (P.NB + 1);
+                const unsigned r0 = row[bk0];
+                cv[q] = (unsigned)row[bk1] - r0;
                 ov[q] = r0 + P.tile_src[(long long)seg * P.Tp + tt];
             }
             sum += cv[q] | (cv[q] ? 0x10000u : 0u);
@@ -2375,8 +2353,8 @@ __global__ __launch_bounds__(256) void ldati_big_bucket_kernel(LdatiParams P) {
         for (int i = tid; i < bins; i += 256) hist[i] = 0;
         __syncthreads();
         for (int tt = 0; tt < P.T; ++tt) {
-            const unsigned short *colT = P.roffT + ((long long)seg * (P.NB + 1) + bucket) * P.Tp + tt;
-            const unsigned r0 = colT[0], len = (unsigned)colT[P.Tp] - r0;
+            const unsigned short *row = P.roff + ((long long)seg * P.T + tt) * (P.NB + 1);
+            const unsigned r0 = row[bucket], len = (unsigned)row[bucket + 1] - r0;
             const unsigned *src = seg_temp + P.tile_src[(long long)seg * P.Tp + tt] + r0;
             const unsigned catb = tt < P.tpp ? 0u : 2u;
             for (unsigned j = tid; j < len; j += 256) {
@@ -2401,8 +2379,8 @@ __global__ __launch_bounds__(256) void ldati_big_bucket_kernel(LdatiParams P) {
         __syncthreads();
         if (tid < 64) {
             for (int tt = 0; tt < P.T; ++tt) {
-                const unsigned short *colT = P.roffT + ((long long)seg * (P.NB + 1) + bucket) * P.Tp + tt;
-                const unsigned r0 = colT[0], len = (unsigned)colT[P.Tp] - r0;
+                const unsigned short *row = P.roff + ((long long)seg * P.T + tt) * (P.NB + 1);
+                const unsigned r0 = row[bucket], len = (unsigned)row[bucket + 1] - r0;
                 const unsigned *src = seg_temp + P.tile_src[(long long)seg * P.Tp + tt] + r0;
                 const unsigned catb = tt < P.tpp ? 0u : 2u;
                 const unsigned pxb = (unsigned)(tt < P.tpp ? tt : tt - P.tpp) * kTilePix;
@@ -2611,7 +2589,7 @@ size_t dense_tile_lds(int capA, int NB, int NW) {
 // geometry and capacities of the two-level path
 struct Plan {
     int tpp, T, Tp, shift, NB, nb1, PB, capA, cap2, tbits, tile_threads, span;
-    size_t n_tab, n_tabT, n_bkt;         // entries of roff; of its transposed copy (rows padded to Tp); of bofs
+    size_t n_tab, n_bkt;                 // entries of roff; of bofs
     size_t lds_tile, lds_sort;
     size_t bytes;                        // workspace
     bool ok;
@@ -2656,7 +2634,6 @@ Plan make_plan(const HostScalars &h, int B, int H, int W, int64_t total_events,
            pb <= 22 && total_events < (1ll << 32) && B * 9 <= 65535;
     p.n_bkt = (size_t)B * 9 * (size_t)(p.NB + 1);
     p.n_tab = p.n_bkt * (size_t)p.T;
-    p.n_tabT = p.n_bkt * (size_t)p.Tp;
     p.tile_threads = tile_threads_choice(max_tile_events);
     p.lds_tile = (size_t)(2 * p.capA + 2048) * 4 + (size_t)kTilePix * 8 +
                  (size_t)(p.tile_threads / 128) * p.NB * 4 + 2 * (p.tile_threads / 64 + 1) * 4;
@@ -2666,9 +2643,9 @@ Plan make_plan(const HostScalars &h, int B, int H, int W, int64_t total_events,
     const size_t stage = (size_t)kSortThreads * 13 * 4;
     p.lds_sort = (size_t)p.cap2 * 4 + (tables > stage ? tables : stage);
     // bofs | groups [B*9*NB] | big_list [B*9*NB] | ngroups [B*9] | seg_flag [B*9] | status [4] (status, nbig) |
-    // records (u32) | roff (u16) | roffT (u16)
+    // records (u32) | roff (u16)
     p.bytes = (p.n_bkt + 2 * (size_t)B * 9 * p.NB + 2 * (size_t)B * 9 + 4 +
-               (size_t)(total_events > 0 ? total_events : 0)) * 4 + ((p.n_tab * 2 + 3) / 4) * 4 + ((p.n_tabT * 2 + 3) / 4) * 4;
+               (size_t)(total_events > 0 ? total_events : 0)) * 4 + ((p.n_tab * 2 + 3) / 4) * 4;
     if (p.lds_tile > 160 * 1024 || p.lds_sort > 160 * 1024) p.ok = false;
     return p;
 }
@@ -3070,7 +3047,6 @@ int emit_impl(const float *vox, int B, int H, int W, double fps, double t0,
         P.nbig = reinterpret_cast<unsigned *>(P.status + 1);
         P.temp = reinterpret_cast<unsigned *>(P.status + 4);
         P.roff = reinterpret_cast<unsigned short *>(P.temp + (size_t)total_events);
-        P.roffT = P.roff + ((pl.n_tab + 1) & ~(size_t)1);
         V2CE_HIP_CHECK(hipMemsetAsync(P.status, 0, 4 * sizeof(int), st));
         // the fused count already ran the sparse tile pass: usable when its assumed geometry is the plan's and every tile fitted
         bool fused = false;

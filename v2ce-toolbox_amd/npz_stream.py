@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import concurrent.futures
 import functools
+import os
 import struct
 import time
 import zlib
@@ -85,7 +86,10 @@ class NpzStreamWriter:
     def __init__(self, path: str, key: str, dtype):
         self.path, self.dtype = path, np.dtype(dtype)
         self.name = (key + ".npy").encode("ascii")
-        self.f = open(path, "wb")
+        # the file grows under a temporary name and takes its final name when it is complete: a clip that dies half-way
+        # (or is repeated by the range guard) never leaves a truncated archive under the final name
+        self.part_path = path + ".part"
+        self.f = open(self.part_path, "wb")
         t = time.localtime()
         self.dostime = (t.tm_hour << 11) | (t.tm_min << 5) | (t.tm_sec // 2)
         self.dosdate = ((t.tm_year - 1980) << 9) | (t.tm_mon << 5) | t.tm_mday
@@ -146,10 +150,36 @@ class NpzStreamWriter:
         f.write(self._local_header(crc, size))
         f.write(header)
         f.close()
+        os.replace(self.part_path, self.path)
+
+    @property
+    def records_start(self) -> int:
+        """File offset of the first record (behind the ZIP local header and the fixed .npy header)."""
+        return self.data_offset + _NPY_HEADER_BYTES
+
+    def set_external(self, nbytes: int, crc_data: int) -> None:
+        """The records were written into the file by others (``dist.HostDirectGather``: every rank writes its own
+        pieces at their offsets behind ``records_start``): take over their total size and CRC-32 before ``close()``."""
+        self.f.flush()
+        self.f.seek(self.records_start + nbytes)
+        self.nbytes, self.crc_data = int(nbytes), int(crc_data)
+
+    def abort(self) -> None:
+        """Drop the partial file (error path)."""
+        if not self.closed:
+            self.closed = True
+            try:
+                self.f.close()
+            finally:
+                if os.path.exists(self.part_path):
+                    os.unlink(self.part_path)
 
     def __enter__(self):
         return self
 
     def __exit__(self, *exc):
-        self.close()
+        if exc and exc[0] is not None:
+            self.abort()
+        else:
+            self.close()
         return False

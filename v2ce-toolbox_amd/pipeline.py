@@ -113,6 +113,7 @@ class EventSink:
         self.stream = torch.cuda.Stream(device=self.device) if self.cuda else None
         self.inflight = collections.deque()
         self.cpu_parts: List[torch.Tensor] = []
+        self.last_done = None                               # HIP event behind the last enqueued D2H copy
 
     def _reserve(self, nbytes: int):
         need = self.used + nbytes
@@ -159,6 +160,7 @@ class EventSink:
                 done = torch.cuda.Event()
                 done.record(self.stream)
             self.inflight.append((done, packed, keep))
+            self.last_done = done
         self.used += n
         while self.inflight and self.inflight[0][0].query():
             self.inflight.popleft()
@@ -196,6 +198,7 @@ class StreamingEventSink:
             self.free.put([None])                          # a slot = [pinned uint8 tensor or None]
         self.work = queue.Queue()
         self.error = None
+        self.last_done = None
         self.thread = threading.Thread(target=self._drain, daemon=True)
         self.thread.start()
 
@@ -235,15 +238,26 @@ class StreamingEventSink:
             slot[0][:n].copy_(packed, non_blocking=True)
             done = torch.cuda.Event()
             done.record(self.stream)
+        self.last_done = done
         self.work.put((slot, n, done, (packed, keep)))    # the device buffers stay referenced until the copy has landed
 
     def result(self, dtype):
         self.work.put(None)
         self.thread.join()
+        self.thread = None
         if self.error is not None:
             raise self.error
         self.writer.close()
         return None
+
+    def abort(self):
+        """Error path: stop the writer thread and drop the partial file."""
+        if self.thread is not None:
+            self.error = self.error or RuntimeError("aborted")
+            self.work.put(None)
+            self.thread.join()
+            self.thread = None
+        self.writer.abort()
 
 
 class FrameFeeder:
@@ -348,16 +362,33 @@ def shard_of_batch(bp: BatchPlan, seq_len: int, part: int, parts: int) -> BatchP
                      (hi - lo) * seq_len - drop)
 
 
+def _shared_segment_path() -> str:
+    """A fresh file name for the shared host segment of one clip (tmpfs: its pages are host memory)."""
+    import uuid
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else (os.environ.get("TMPDIR") or "/tmp")
+    return os.path.join(base, f"v2ce_events_{os.getpid()}_{uuid.uuid4().hex}.bin")
+
+
 def run_clip(frames: np.ndarray, model, *, infer_type="center", seq_len=16, width=346, height=260,
              batch_size=1, fps=30, seed=0, device="cuda", stage2=None, dtype=None,
              comm=None, trace: Optional[dict] = None,
-             reuse_output: bool = False, event_frames: Optional[list] = None, writer=None) -> Optional[np.ndarray]:
+             reuse_output: bool = False, event_frames: Optional[list] = None, writer=None,
+             gather: Optional[str] = None) -> Optional[np.ndarray]:
     """frames [N,H,W] uint8 -> event_stream (structured array) on rank 0, None elsewhere.
 
     writer: an ``npz_stream.NpzStreamWriter`` (rank 0): the records go to the file batch by batch instead of into one
     host array (``StreamingEventSink``); the function then returns None on every rank and closes the writer.
 
     comm: ``dist.TorchComm`` / ``dist.ThreadComm`` / ``dist.LocalComm`` (default: from torch.distributed).
+    gather (more than one rank; V2CE_GATHER overrides): 'device' (default) -- the records are gathered on rank 0's GPU over
+    RCCL / xGMI (``dist.StreamedGather``) and rank 0 downloads them into its pinned sink (one PCIe link: ~57 GB/s measured,
+    against 8 x 7.3 GB/s of records at N = 8 in the e2e regime: the link is the budget there); 'host' -- every rank
+    downloads its own records over its own PCIe link and writes them into its slice of the output (the streamed file, or a
+    shared tmpfs segment that rank 0 maps; only byte counts cross RCCL: ``dist.HostDirectGather``) -- no GPU gather and no
+    single link, but the kernel serialises the writers of one file (~6 GB/s per segment, tools/shm_write_probe.py), so it
+    only pays where the sink is a disk.
+    A rank that fails inside the clip makes EVERY rank raise at the same step (``dist.RankFailure``; the failed rank
+    re-raises its own error), and the LDATI status words are reduced over the ranks before rank 0 finalises its output.
     stage2: optional (begin, finish) pair replacing LDATI (CPU stand-ins in the tests):
     begin(vox, first_pair) -> handle; finish(handle) -> (packed uint8 tensor, keepalive).
     event_frames: a list that receives, per batch, (first pair, event_frame_sums(voxels)) on the device
@@ -369,6 +400,9 @@ def run_clip(frames: np.ndarray, model, *, infer_type="center", seq_len=16, widt
     rank, world = comm.rank, comm.world
     if infer_type not in ("center", "pano"):
         raise ValueError(f"Invalid infer_type {infer_type}")
+    gather = gather or os.environ.get("V2CE_GATHER", "device")
+    if gather not in ("host", "device"):
+        raise ValueError(f"gather must be 'host' or 'device', got {gather!r}")
     plans = plan_batches(len(frames), seq_len, batch_size)
     begin, finish = stage2 or default_stage2(fps, seed, len(frames) - 1, device)
     fw = resized_width(frames, height)
@@ -385,19 +419,37 @@ def run_clip(frames: np.ndarray, model, *, infer_type="center", seq_len=16, widt
         seq_part, seq_parts, tile_index, grp = rank, world, None, None
     mine = [shard_of_batch(bp, seq_len, seq_part, seq_parts) for bp in plans]
     feeder = FrameFeeder(frames, seq_len, device, height)
-    # rank 0 owns the host buffer of the whole clip; the other ranks only feed the gather
+    multi = not isinstance(comm, vdist.LocalComm)           # (a forced world of one takes the collective path too)
+    host_direct = multi and gather == "host"
+    # single rank, or device gather: rank 0 owns a sink that downloads everything
     sink = None
-    if rank == 0:
+    if rank == 0 and not host_direct:
         sink = StreamingEventSink(device, writer) if writer is not None else EventSink(device, len(frames) - 1, reuse=reuse_output)
-    gather = None
-    if not isinstance(comm, vdist.LocalComm):               # (a forced world of one takes the collective path too)
+    exchange, seg_path = None, None
+    if host_direct:
+        # the shared output: rank 0's streamed .npz (its records start behind the headers), or a host segment in tmpfs
+        if rank == 0:
+            if writer is not None:
+                writer.f.flush()
+                info = (writer.part_path, writer.records_start, True)
+            else:
+                seg_path = _shared_segment_path()
+                open(seg_path, "wb").close()
+                info = (seg_path, 0, False)
+        else:
+            info = None
+        path, data_start, need_crc = comm.broadcast_object(info, src=0)
+        exchange = vdist.HostDirectGather(comm, device, path, data_start, need_crc)
+    elif multi:
         step_pairs = collections.deque(bp.n_pairs for bp in plans)
 
         def on_pieces(pieces, stream):
             n = step_pairs.popleft()
             for k, p in enumerate(pieces):                  # rank order = frame-pair order inside a step
-                sink.push(p, n if k == 0 else 0, src_stream=stream)
-        gather = comm.streamed_gather(on_pieces if rank == 0 else None, dst=0)
+                # (CPU stand-ins keep the tensors they are handed: the receive buffers are reused, so they get copies)
+                sink.push(p if stream is not None else p.clone(), n if k == 0 else 0, src_stream=stream)
+            return sink.last_done if stream is not None else None    # the receive buffers are reused behind these copies
+        exchange = comm.streamed_gather(on_pieces if rank == 0 else None, dst=0)
     base_calls = int(getattr(model, "calls", 0))            # the reference keeps advancing one model
     import time as _time
 
@@ -408,15 +460,32 @@ def run_clip(frames: np.ndarray, model, *, infer_type="center", seq_len=16, widt
         return _time.perf_counter()
 
     status = {"acc": None, "msg": None}                     # device-side OR of the LDATI status words of the clip
+    failure = {"exc": None}                                 # this rank's first error (multi-rank: reported with the next byte count)
     pending = None                                          # (stage-2 handle, pairs)
+
+    def guarded(fn, *args):
+        """Multi-rank: an error is kept and travels to the peers with the next exchange (every rank then stops at the
+        same step); single rank: it propagates at once."""
+        if failure["exc"] is not None:
+            return None
+        if not multi:
+            return fn(*args)
+        try:
+            return fn(*args)
+        except vdist.RankFailure:
+            raise
+        except Exception as e:                              # noqa: BLE001 -- re-raised below, on every rank
+            failure["exc"] = e
+            return None
 
     def flush(p):
         handle, n_pairs = p
         t_f = _time.perf_counter()
-        if handle is None:                                  # this rank had no pairs in that batch
-            packed, keep = torch.empty(0, dtype=torch.uint8, device=device), None
-        else:
-            packed, keep = finish(handle)
+        packed, keep = torch.empty(0, dtype=torch.uint8, device=device), None
+        if handle is not None:                              # (else: this rank had no pairs in that batch)
+            got = guarded(finish, handle)
+            if got is not None:
+                packed, keep = got
         t_f = tick("flush.finish", t_f)
         st = getattr(keep, "_status", None)
         if st is not None:                                  # 4 bytes folded on the stream; the event object is not retained
@@ -424,8 +493,10 @@ def run_clip(frames: np.ndarray, model, *, infer_type="center", seq_len=16, widt
                 status["acc"] = torch.zeros_like(st)
             torch.maximum(status["acc"], st, out=status["acc"])
             status["msg"] = getattr(keep, "_status_message", None) or status["msg"]
-        if gather is not None:
-            gather.submit(packed)
+        if host_direct:
+            exchange.submit(packed, failed=failure["exc"] is not None, keep=keep)
+        elif multi:
+            exchange.submit(packed, failed=failure["exc"] is not None)
         else:
             sink.push(packed, n_pairs, keep)
         tick("flush.push", t_f)
@@ -435,53 +506,93 @@ def run_clip(frames: np.ndarray, model, *, infer_type="center", seq_len=16, widt
             i += 1
         return i
 
-    nxt_i = next_nonempty(0)
-    handle = feeder.submit(mine[nxt_i]) if nxt_i < len(mine) else None
-    with torch.no_grad():
-        for i, bp in enumerate(mine):
-            tt = _time.perf_counter()
-            vox, first_pair = None, bp.first_pair
-            if bp.seqs:
-                units = feeder.take(handle, bp)
-                tt = tick("take", tt)
-                nxt_i = next_nonempty(i + 1)
-                handle = feeder.submit(mine[nxt_i]) if nxt_i < len(mine) else None
-                tt = tick("submit", tt)
-                # call index of this batch in the reference's schedule (one spectral-norm iteration per call);
-                # ranks that sat a batch out catch up here
-                vdist.fast_forward(model, base_calls + bp.index * calls_per_batch + (tile_index or 0))
-                if not tile_parallel:
-                    if infer_type == "center":
-                        pred = glue.infer_center_image_unit(model, units, width)
-                    else:
-                        pred = glue.infer_pano_image_unit(model, units, width)
-                    vox = _voxels_of_batch(pred, bp, seq_len)
+    def batch_body(i, bp, state):
+        vox, first_pair = None, bp.first_pair
+        if bp.seqs:
+            units = feeder.take(state["handle"], bp)
+            nxt_i = next_nonempty(i + 1)
+            state["handle"] = feeder.submit(mine[nxt_i]) if nxt_i < len(mine) else None
+            # call index of this batch in the reference's schedule (one spectral-norm iteration per call);
+            # ranks that sat a batch out catch up here
+            vdist.fast_forward(model, base_calls + bp.index * calls_per_batch + (tile_index or 0))
+            if not tile_parallel:
+                if infer_type == "center":
+                    pred = glue.infer_center_image_unit(model, units, width)
                 else:
-                    lo, hi, keep_cols = tiles[tile_index]
-                    pred = model(units[..., lo:hi].float().contiguous())
-                    if keep_cols:
-                        pred = pred[..., -keep_cols:]
-                    part = _voxels_of_batch(pred, bp, seq_len)                          # [P,2,10,H,wt]
-                    vox, p_lo = comm.tiles_to_pairs(part, widths, tile_index, grp)       # [P_r,2,10,H,W_full]
-                    first_pair += p_lo
-            tt = tick("model", tt)
-            if event_frames is not None and vox is not None:
-                event_frames.append((first_pair, event_frame_sums(vox)))
-            nxt = (begin(vox, first_pair) if vox is not None and vox.shape[0] else None,
-                   0 if vox is None else int(vox.shape[0]))
-            tt = tick("begin", tt)
+                    pred = glue.infer_pano_image_unit(model, units, width)
+                vox = _voxels_of_batch(pred, bp, seq_len)
+            else:
+                lo, hi, keep_cols = tiles[tile_index]
+                pred = model(units[..., lo:hi].float().contiguous())
+                if keep_cols:
+                    pred = pred[..., -keep_cols:]
+                part = _voxels_of_batch(pred, bp, seq_len)                          # [P,2,10,H,wt]
+                vox, p_lo = comm.tiles_to_pairs(part, widths, tile_index, grp)       # [P_r,2,10,H,W_full]
+                first_pair += p_lo
+        if event_frames is not None and vox is not None:
+            event_frames.append((first_pair, event_frame_sums(vox)))
+        return (begin(vox, first_pair) if vox is not None and vox.shape[0] else None, 0 if vox is None else int(vox.shape[0]))
+
+    def cleanup_on_error():
+        if host_direct:
+            exchange.close()
+            if seg_path is not None and os.path.exists(seg_path):
+                os.unlink(seg_path)
+        if writer is not None and rank == 0:
+            if isinstance(sink, StreamingEventSink):
+                sink.abort()
+            else:
+                writer.abort()
+
+    try:
+        nxt_i = next_nonempty(0)
+        state = {"handle": feeder.submit(mine[nxt_i]) if nxt_i < len(mine) else None}
+        with torch.no_grad():
+            for i, bp in enumerate(mine):
+                tt = _time.perf_counter()
+                nxt = guarded(batch_body, i, bp, state) or (None, 0)
+                tt = tick("model+begin", tt)
+                if pending is not None:
+                    flush(pending)
+                tt = tick("flush", tt)
+                pending = nxt
             if pending is not None:
                 flush(pending)
-            tt = tick("flush", tt)
-            pending = nxt
-        if pending is not None:
-            flush(pending)
-        # every rank leaves the model where the single-process run leaves it
-        vdist.fast_forward(model, base_calls + len(plans) * calls_per_batch)
-    if gather is not None:
-        gather.drain()
-    if status["acc"] is not None and int(status["acc"].item()) != 0:
-        from . import hip
-        raise hip.V2ceHipError(status["msg"] or "LDATI: a (frame, bin) segment could not be ordered on the device "
-                               "(more equal-time events than the LDS sort holds at an fps beyond the sweep kernel's histogram)")
-    return sink.result(dtype) if rank == 0 else None
+            # every rank leaves the model where the single-process run leaves it
+            if failure["exc"] is None:
+                vdist.fast_forward(model, base_calls + len(plans) * calls_per_batch)
+        if exchange is not None:
+            exchange.drain()
+        # the LDATI status words of all ranks, before anything is finalised (a rank with a bad segment must not leave rank 0
+        # closing a valid-looking file)
+        st_local = float(int(status["acc"].item())) if status["acc"] is not None else 0.0
+        st_all = comm.max_float(st_local, device=device) if multi else st_local
+        if st_all != 0.0:
+            from . import hip
+            raise hip.V2ceHipError(status["msg"] or "LDATI: a (frame, bin) segment could not be ordered on the device "
+                                   "(more equal-time events than the LDS sort holds at an fps beyond the sweep kernel's histogram)"
+                                   + ("" if st_local else " [reported by another rank]"))
+        if host_direct:
+            total = exchange.finalize()                     # collective; rank 0: (bytes, crc)
+            if rank != 0:
+                return None
+            nbytes, crc = total
+            if writer is not None:
+                writer.set_external(nbytes, crc)
+                writer.close()
+                return None
+            if nbytes == 0:
+                os.unlink(seg_path)
+                return np.empty(0, dtype)
+            mm = np.memmap(seg_path, dtype=np.uint8, mode="r+", shape=(nbytes,))
+            os.unlink(seg_path)                             # the mapping keeps the pages; the name goes now
+            return mm.view(dtype)
+        return sink.result(dtype) if rank == 0 else None
+    except vdist.RankFailure as rf:
+        cleanup_on_error()
+        if failure["exc"] is not None:                      # this rank is (one of) the failed ones: its own error
+            raise failure["exc"] from rf
+        raise
+    except BaseException:
+        cleanup_on_error()
+        raise
