@@ -483,6 +483,23 @@ def main():
         roofline["traffic_source"] = os.path.basename(files[-1]) + " (PMC FETCH_SIZE x2 + WRITE_SIZE, avg per launch)"
     except Exception:
         pass
+    # counter-derived shares from the latest committed SQ summaries (tools/profile_counters.sh -> tools/counters_summary.py):
+    # the dominant conv kernel's MFMA-busy share of the SIMD cycles; LDATI's VALU-issue roofline fraction
+    try:
+        import glob
+        if model is not None:
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_e2e_mfma_busy.json")))
+            mb = json.load(open(files[-1]))[roofline["kernel"].replace(" ", "")]
+            roofline["mfma_busy"] = mb["mfma_busy"]
+            roofline["mfma_busy_source"] = os.path.basename(files[-1]) + " (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8), avg per launch)"
+        else:
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{args.workload}_sq_counters.json")))
+            sq = json.load(open(files[-1]))
+            roofline["valu_frac"] = sq["valu_frac"]
+            roofline["valu_lane_slots_per_event"] = sq["valu_lane_slots_per_event"]
+            roofline["valu_source"] = os.path.basename(files[-1]) + " (SQ_INSTS_VALU x 64 / (1024 SIMDs x 16 lanes/clk x GRBM_GUI_ACTIVE / 8))"
+    except Exception:
+        pass
 
     h2h_multi = None
     if world > 1 and args.workload == "e2e" and not args.no_host_to_host:

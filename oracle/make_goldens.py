@@ -45,7 +45,7 @@ import torch
 warnings.filterwarnings("ignore")
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-GOLD = os.path.join(ROOT, "tests", "golden")
+GOLD = os.environ.get("V2CE_GOLDEN_DIR") or os.path.join(ROOT, "tests", "golden")   # (V2CE_GOLDEN_DIR: the recipe test writes elsewhere)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, "/root/reference")
 
@@ -585,10 +585,8 @@ def gen_voxelize():
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     which = sys.argv[1:] or ["unet", "ldati", "options", "large", "kat", "glue", "voxelize", "event_frames", "samplers"]
-    if "event_frames" in which:
-        gen_event_frames()
-    if "voxelize" in which:
-        gen_voxelize()
+    # dependency order: the voxeliser golden (G8) is made from the events of the LDATI goldens (G3), so "ldati" comes first --
+    # the default order works from an EMPTY tests/golden/ (tests/test_oracle_goldens_recipe.py runs it into a temp directory)
     if "unet" in which:
         gen_unet()
     if "ldati" in which:
@@ -601,6 +599,10 @@ if __name__ == "__main__":
         gen_kat()
     if "glue" in which:
         gen_glue()
+    if "voxelize" in which:
+        gen_voxelize()
+    if "event_frames" in which:
+        gen_event_frames()
     if "samplers" in which:
         gen_sample_methods()
         gen_sample_methods_pooled()

@@ -1,0 +1,33 @@
+"""oracle/make_goldens.py is the recipe that pins the oracle to outputs of the reference itself.  Where the reference is
+present (this container; never the GPU box) two small fixture sets are regenerated into a temporary directory, starting
+from an EMPTY one and in the recipe's default order for them, and compared byte for byte with the committed fixtures
+(the default order used to run the voxeliser set before the LDATI set whose events it reads)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "scripts")), reason="the reference tree is not on this machine")
+def test_recipe_regenerates_committed_fixtures_from_an_empty_directory(tmp_path):
+    env = dict(os.environ, V2CE_GOLDEN_DIR=str(tmp_path), PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "make_goldens.py"), "voxelize", "ldati", "kat"],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    made = sorted(os.listdir(tmp_path))
+    assert "voxelize_g8.npz" in made and "ldati_kat.json" in made and sum(f.startswith("ldati_g3_") for f in made) >= 7
+    gold = os.path.join(ROOT, "tests", "golden")
+    for f in made:
+        a, b = open(os.path.join(tmp_path, f), "rb").read(), open(os.path.join(gold, f), "rb").read()
+        if a != b and f.endswith(".npz"):                       # (same arrays; zip timestamps may differ)
+            za, zb = np.load(os.path.join(tmp_path, f), allow_pickle=True), np.load(os.path.join(gold, f), allow_pickle=True)
+            assert sorted(za.files) == sorted(zb.files)
+            for k in za.files:
+                assert np.asarray(za[k]).tobytes() == np.asarray(zb[k]).tobytes(), (f, k)
+        else:
+            assert a == b, f

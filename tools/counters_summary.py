@@ -76,6 +76,22 @@ def ldati_table(out, wl, events_per_launch):
         if c.get("SQ_LDS_IDX_ACTIVE"):
             lines.append("      LDS bank conflicts: %.1f %% of the LDS-array cycles" % (100 * c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"]))
     lines.append(f"  all LDATI kernels: {tot_valu:.1f} VALU lane-slots per event")
+    # VALU-issue roofline of the whole call: executed VALU wave-instructions x 64 lanes against 1024 SIMDs x 16 lanes per clock
+    # over the kernels' own busy clocks (GRBM_GUI_ACTIVE / 8 XCDs)
+    js = {"events_per_call": events_per_launch, "valu_lane_slots_per_event": tot_valu, "kernels": {}}
+    gui_tot, inst_tot = 0.0, 0.0
+    for k, c in per.items():
+        if not k.startswith("ldati") or any(x in k for x in ("probe", "check", "slope_tab", "commit")):
+            continue
+        iv, gui = avg(c.get("SQ_INSTS_VALU", [])), avg(c.get("GRBM_GUI_ACTIVE", []))
+        js["kernels"][k] = {"avg_us": avg(dur.get(k, [0])), "insts_valu": iv, "gui_active": gui,
+                            "valu_frac": (iv * 64.0) / (16.0 * 1024.0 * gui / 8.0) if gui else None,
+                            "active_lane_share": (avg(c.get("SQ_THREAD_CYCLES_VALU", [])) / 4.0 / iv / 16.0) if iv else None}
+        gui_tot += gui
+        inst_tot += iv
+    js["valu_frac"] = (inst_tot * 64.0) / (16.0 * 1024.0 * gui_tot / 8.0) if gui_tot else None
+    lines.append(f"  VALU-issue roofline of the call (VALU wave-instructions x 64 / (1024 SIMDs x 16 lanes/clk x busy clocks)): {js['valu_frac']}")
+    json.dump(js, open(os.path.join(out, f"{wl}_sq_counters.json"), "w"), indent=1)
     return lines
 
 

@@ -222,8 +222,7 @@ def ldati_begin(y: torch.Tensor, t0=0, fps=30, *, rng: str = "philox", seed: Opt
                                                replay_max_n, int(seed or 0) & (2 ** 64 - 1), int(frame_base), seg_hint, tile_ws.data_ptr(),
                                                tile_ws.numel(), fused_ws.data_ptr(), fused_ws.numel(), meta.data_ptr(),
                                                meta[B * 9 + 1:].data_ptr(), st), "v2ce_ldati_count_fused")
-        else:
-            meta[B * 9 + 5:].zero_()
+        else:                                          # (stats[4..7] stay unwritten: only the fused path reads stats[4])
             hip.check(L.v2ce_ldati_count(y.data_ptr(), B, H, W, ctypes.byref(opts), tile_ws.data_ptr(), tile_ws.numel(),
                                          meta.data_ptr(), meta[B * 9 + 1:].data_ptr(), st), "v2ce_ldati_count")
         if profile is not None:

@@ -1256,8 +1256,7 @@ __global__ __launch_bounds__(NT) void ldati_tile_pass_kernel(LdatiParams P) {
 //     the ranges the slope table spans; tests/test_gpu_ldati.py::test_exact_math_helpers checks them exhaustively).
 // Everything else (bidirectional, pooled slope, 'random', 64-bit times, a table that is not ready) stays on
 // ldati_tile_pass_kernel; both produce the same bytes (test_dense_tile_kernel_equals_per_bin_kernel).
-// LDS map (dynamic): S [capA] u32 | O [capA + 2 NW + 2] u32 (the unit tables alias the wave's slice) | hist [NW/2][NB] (two
-// 16-bit counters per word) | misc
+// LDS map (dynamic): S [capA] u32 | O [capA + 2] u32 (the workgroup's work lists alias it) | hist [NW][NB] | misc
 // ---------------------------------------------------------------------------------------------
 // correctly rounded sqrt for a == 0, a >= 2^-96, negative or NaN a: v_sqrt_f32 (1 ulp) and the two residual tests of the
 // compiler's expansion (which additionally rescales a < 2^-96: never the case for b^2 + 2 k u of a table entry)
@@ -1312,7 +1311,7 @@ __device__ __forceinline__ int slope_index(int n_l, int n_c, int n_r, int c) {
 
 template <int NW>
 __global__ __launch_bounds__(64 * NW, 4) void ldati_tile_dense_kernel(LdatiParams P) {   // 4 waves per SIMD: two 512-thread workgroups per CU
-    constexpr int NT = 64 * NW, PPT = kTilePix / NT, WPX = 64 * PPT, NWP = NW / 2;
+    constexpr int NT = 64 * NW, PPT = kTilePix / NT, WPX = 64 * PPT;
     static_assert(PPT == 4 || PPT == 2, "a lane owns 2 or 4 consecutive pixels");
     const int t = blockIdx.x, b = blockIdx.y;
     if (P.sparse_cap) {                                 // the sparse tile kernel owns the lightly populated tiles
@@ -1336,11 +1335,11 @@ __global__ __launch_bounds__(64 * NW, 4) void ldati_tile_dense_kernel(LdatiParam
 
     unsigned *S = reinterpret_cast<unsigned *>(tile_smem);
     unsigned *O = S + P.capA;
-    unsigned *hist = O + P.capA + 2 * NW + 2;           // [NW / 2][NB]: the 16-bit counters of waves 2j and 2j + 1 share a word
-    unsigned *part = hist + NWP * P.NB;                 // [NW] wave totals | [NW + 1] scan partials
-    unsigned *spart = part + NW;
-    unsigned *myhist = hist + (wid >> 1) * P.NB;
-    const unsigned hsh = (unsigned)(wid & 1) * 16u, hone = 1u << hsh;
+    unsigned *hist = O + P.capA + 2;                    // [NW][NB]: row r counts the records at positions [r L, (r + 1) L)
+    unsigned *part = hist + NW * P.NB;                  // [3][NW] wave totals (events | singles, k == 0 units << 16 | k != 0 units)
+    unsigned *spart = part + 3 * NW;                    // [NW + 1] scan partials
+    unsigned *bctr = spart + NW + 1;                    // the next batch of the timestamp phase
+    unsigned *myhist = hist + wid * P.NB;
 
     const float *plane0 = P.vox + (long long)(b * 2 + pidx) * 10 * P.HW;
     const unsigned frame = (unsigned)(P.frame_base + b);
@@ -1385,7 +1384,8 @@ __global__ __launch_bounds__(64 * NW, 4) void ldati_tile_dense_kernel(LdatiParam
             nprev[q] = 0;
         }
     }
-    if (wid & 1) {} else { for (int i = lane; i < P.NB; i += 64) myhist[i] = 0; }    // (the even wave of a pair clears the shared row)
+    for (int i = lane; i < P.NB; i += 64) myhist[i] = 0;
+    if (tid == 0) *bctr = 0;
     __syncthreads();
 
     STAMP_DECL;
@@ -1420,38 +1420,50 @@ __global__ __launch_bounds__(64 * NW, 4) void ldati_tile_dense_kernel(LdatiParam
         const unsigned baseA = iA - At, baseU = iU - Ut;
         const unsigned runA = (unsigned)__builtin_amdgcn_readlane((int)iA, 63), runU = (unsigned)__builtin_amdgcn_readlane((int)iU, 63);
         const unsigned evW = runA & 0xFFFFu, sW = runA >> 16, u0W = runU & 0xFFFFu, u1W = runU >> 16;
-        if (lane == 0) part[wid] = evW;
+        if (lane == 0) { part[wid] = evW; part[NW + wid] = sW | (u0W << 16); part[2 * NW + wid] = u1W; }
         __syncthreads();                                 // A: wave totals; O (the previous bin's run) is free again
         STAMP(1);
-        unsigned sbase, N;
+        // Work lists of the WORKGROUP in O (2 (U1 + U0) + Ns <= N words): k != 0 units | k == 0 units | singles, each in
+        // pixel order; the timestamp phase below hands them out in batches of 64 to whichever wave is free, so a lane is
+        // idle only in the last batch of a class (per-wave lists left 38 % of the VALU lanes idle: r04_j counters)
+        unsigned sbase, N, sS, sU0, sU1, Ns, U0, U1;
         {
-            const unsigned pin = wave_incl_scan(lane < NW ? part[lane] : 0u, lane);
-            N = (unsigned)__builtin_amdgcn_readlane((int)pin, NW - 1);
-            sbase = wid ? (unsigned)__builtin_amdgcn_readlane((int)pin, wid - 1) : 0u;
+            const unsigned v0 = lane < NW ? part[lane] : 0u, v1 = lane < NW ? part[NW + lane] : 0u, v2 = lane < NW ? part[2 * NW + lane] : 0u;
+            const unsigned p0 = wave_incl_scan(v0, lane), p1 = wave_incl_scan(v1 & 0xFFFFu, lane);
+            const unsigned p2 = wave_incl_scan(v1 >> 16, lane), p3 = wave_incl_scan(v2, lane);
+            N = (unsigned)__builtin_amdgcn_readlane((int)p0, NW - 1);
+            Ns = (unsigned)__builtin_amdgcn_readlane((int)p1, NW - 1);
+            U0 = (unsigned)__builtin_amdgcn_readlane((int)p2, NW - 1);
+            U1 = (unsigned)__builtin_amdgcn_readlane((int)p3, NW - 1);
+            sbase = wid ? (unsigned)__builtin_amdgcn_readlane((int)p0, wid - 1) : 0u;
+            sS = wid ? (unsigned)__builtin_amdgcn_readlane((int)p1, wid - 1) : 0u;
+            sU0 = wid ? (unsigned)__builtin_amdgcn_readlane((int)p2, wid - 1) : 0u;
+            sU1 = wid ? (unsigned)__builtin_amdgcn_readlane((int)p3, wid - 1) : 0u;
         }
-        unsigned *Sw = S + sbase;
-        const unsigned tb = (sbase + 2u * (unsigned)wid + 1u) & ~1u;     // the wave's table slice of O: 2 (u0W + u1W) + sW <= evW words
-        uint2 *UL = reinterpret_cast<uint2 *>(O + tb);
-        unsigned *SLs = O + tb + 2u * (u0W + u1W);
+        uint2 *UL1 = reinterpret_cast<uint2 *>(O), *UL0 = UL1 + U1;
+        unsigned *SLs = O + 2u * (U1 + U0);
+        // ranks are taken in NW chunks of L = 2^lgL consecutive positions (one wave each); a record counts in its chunk's row
+        int lgL = 6;
+        while (((unsigned)NW << lgL) < N) ++lgL;
         const float offt_c = P.offt[c];
         const int kbase_c = (int)P.kbase[c];
         const unsigned pc = (unsigned)(pidx * 9 + c);
         // ---- D2: unit tables (and the rare voxel outside the slope table, generated in place by its owner) ---------
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
-            const unsigned local = (unsigned)(lpx0 + q), pos = (baseA + aex[q]) & 0xFFFFu;
+            const unsigned local = (unsigned)(lpx0 + q), pos = sbase + ((baseA + aex[q]) & 0xFFFFu);     // position in S
             const int n = ncur[q];
             const unsigned cl = cls[q] & 7u;
             if (cl == 1u) {
-                SLs[(baseA + aex[q]) >> 16] = pos | (local << 14);
-                Sw[pos] = __float_as_uint(dcur[q]);              // the single's tendency waits in its record slot
+                SLs[sS + ((baseA + aex[q]) >> 16)] = pos | (local << 14);
+                S[pos] = __float_as_uint(dcur[q]);               // the single's tendency waits in its record slot
             } else if (cl == 2u || cl == 3u) {
                 const unsigned ue = baseU + uex[q];
-                const unsigned u0 = cl == 2u ? (ue & 0xFFFFu) : u0W + (ue >> 16);
+                uint2 *dstu = cl == 2u ? UL0 + sU0 + (ue & 0xFFFFu) : UL1 + sU1 + (ue >> 16);
                 const unsigned units = (unsigned)(n + 3) >> 2;
                 for (unsigned jb = 0; jb < units; ++jb) {
                     const unsigned left = (unsigned)n - 4u * jb;
-                    UL[u0 + jb] = make_uint2(local | (jb << 11) | ((left < 4u ? left : 4u) << 29), (pos + 4u * jb) | ((cls[q] >> 3) << 14));
+                    dstu[jb] = make_uint2(local | (jb << 11) | ((left < 4u ? left : 4u) << 29), (pos + 4u * jb) | ((cls[q] >> 3) << 14));
                 }
             } else if (cl == 4u) {
                 float k, bb;
@@ -1462,30 +1474,35 @@ __global__ __launch_bounds__(64 * NW, 4) void ldati_tile_dense_kernel(LdatiParam
                     if (philox) u = philox_uniform(P.seed, px, (unsigned)j, pc, frame);
                     else if (j < P.replay_max_n) u = P.uniforms[(((long long)(b * 2 + pidx) * 9 + c) * P.HW + px) * P.replay_max_n + j];
                     const unsigned key = multi_key(k, bb, u, offt_c, kbase_c, P, fast_k0);
-                    Sw[pos + (unsigned)j] = (key << 12) | (1u << kLocalBits) | local;
-                    atomicAdd(&myhist[key >> P.shift], hone);
+                    const unsigned sp = pos + (unsigned)j;
+                    S[sp] = (key << 12) | (1u << kLocalBits) | local;
+                    atomicAdd(&hist[(sp >> lgL) * (unsigned)P.NB + (key >> P.shift)], 1u);
                 }
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();                                 // A2: the work lists are complete
         STAMP(2);
-        // ---- D3: timestamps, once, by the wave that owns the pixels ------------------------------------------------
-        for (unsigned i = lane; i < sW; i += 64) {
-            const unsigned e = SLs[i], pos = e & 0x3FFFu;
-            const long long Tq = single_ts(__uint_as_float(Sw[pos]), P.fps, offt_c);
-            const unsigned key = (unsigned)key_of(Tq, P.kbase[c], P.NK);
-            Sw[pos] = (key << 12) | (e >> 14);
-            atomicAdd(&myhist[key >> P.shift], hone);
-        }
-        STAMP(3);
-        auto unit_loop = [&](auto mode_c, unsigned first, unsigned count) {
+        // ---- D3: timestamps, once; batches of 64 list entries, handed out through an LDS counter --------------------
+        auto put = [&](unsigned sp, unsigned rec, unsigned key) {
+            S[sp] = rec;
+            atomicAdd(&hist[(sp >> lgL) * (unsigned)P.NB + (key >> P.shift)], 1u);
+        };
+        auto single_batch = [&](unsigned i) {
+            if (i < Ns) {
+                const unsigned e = SLs[i], sp = e & 0x3FFFu;
+                const long long Tq = single_ts(__uint_as_float(S[sp]), P.fps, offt_c);
+                const unsigned key = (unsigned)key_of(Tq, P.kbase[c], P.NK);
+                put(sp, (key << 12) | (e >> 14), key);
+            }
+        };
+        auto unit_batch = [&](auto mode_c, const uint2 *list, unsigned i, unsigned count) {
             // MODE 0: replayed uniforms (IEEE operations as the compiler expands them); 1 / 2: Philox, k == 0 units with /
             // without the checked fast constant divisions; 3: Philox, k != 0 units (sqrt_rn_nr / div_rn_nr)
             constexpr int MODE = decltype(mode_c)::value;
-            for (unsigned i = lane; i < count; i += 64) {
-                const uint2 e = UL[first + i];
+            if (i < count) {
+                const uint2 e = list[i];
                 const unsigned local = e.x & (kTilePix - 1), jb = (e.x >> kLocalBits) & 0x3FFFFu, cnt = e.x >> 29;
-                const unsigned pos = e.y & 0x3FFFu;
+                const unsigned sp = e.y & 0x3FFFu;
                 float2 kb = make_float2(0.0f, 0.0f);
                 if (MODE == 0 || MODE == 3) kb = stab[e.y >> 14];
                 const unsigned px = (unsigned)x0 + local;
@@ -1521,51 +1538,59 @@ __global__ __launch_bounds__(64 * NW, 4) void ldati_tile_dense_kernel(LdatiParam
                     for (int s = 0; s < 4; ++s) {
                         float tt = tq[s] + offt_c;
                         tt = tt * 1e6f;
-                        int k = (int)tt - kbase_c;
-                        k = k < 0 ? 0 : k;
-                        key[s] = (unsigned)(k >= P.NK ? P.NK - 1 : k);
+                        int kk = (int)tt - kbase_c;
+                        kk = kk < 0 ? 0 : kk;
+                        key[s] = (unsigned)(kk >= P.NK ? P.NK - 1 : kk);
                     }
                 }
                 const unsigned tag = (1u << kLocalBits) | local;
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    if ((unsigned)s < cnt) {
-                        Sw[pos + s] = (key[s] << 12) | tag;
-                        atomicAdd(&myhist[key[s] >> P.shift], hone);
-                    }
-                }
+                for (int s = 0; s < 4; ++s)
+                    if ((unsigned)s < cnt) put(sp + s, (key[s] << 12) | tag, key[s]);
             }
         };
-        if (!philox) {
-            unit_loop(std::integral_constant<int, 0>{}, 0u, u0W + u1W);
-        } else {
-            if (fast_k0) unit_loop(std::integral_constant<int, 1>{}, 0u, u0W);
-            else unit_loop(std::integral_constant<int, 2>{}, 0u, u0W);
-            unit_loop(std::integral_constant<int, 3>{}, u0W, u1W);
+        {
+            const unsigned nK = (U1 + 63u) >> 6, nZ = (U0 + 63u) >> 6, nS = (Ns + 63u) >> 6, nb = nK + nZ + nS;
+            for (;;) {
+                unsigned bid = 0;
+                if (lane == 0) bid = atomicAdd(bctr, 1u);
+                bid = (unsigned)__builtin_amdgcn_readfirstlane((int)bid);
+                if (bid >= nb) break;
+                if (bid < nK) {                          // the long batches first
+                    if (philox) unit_batch(std::integral_constant<int, 3>{}, UL1, bid * 64u + lane, U1);
+                    else unit_batch(std::integral_constant<int, 0>{}, UL1, bid * 64u + lane, U1);
+                } else if (bid < nK + nZ) {
+                    const unsigned i = (bid - nK) * 64u + lane;
+                    if (!philox) unit_batch(std::integral_constant<int, 0>{}, UL0, i, U0);
+                    else if (fast_k0) unit_batch(std::integral_constant<int, 1>{}, UL0, i, U0);
+                    else unit_batch(std::integral_constant<int, 2>{}, UL0, i, U0);
+                } else {
+                    single_batch((bid - nK - nZ) * 64u + lane);
+                }
+            }
         }
         STAMP(4);
         __syncthreads();                                 // B: every row of the histogram is complete
         STAMP(5);
         // ---- D4: bucket-major, wave-minor exclusive scan; the tile's row of the run table ------------------------
         {
-            unsigned v[NWP];
+            unsigned v[NW];
             unsigned run = 0;
             if (tid < P.NB) {
 #pragma unroll
-                for (int w = 0; w < NWP; ++w) v[w] = hist[w * P.NB + tid];
+                for (int w = 0; w < NW; ++w) v[w] = hist[w * P.NB + tid];
 #pragma unroll
-                for (int w = 0; w < NWP; ++w) {
-                    const unsigned lo = v[w] & 0xFFFFu, hi = v[w] >> 16;
-                    v[w] = run | ((run + lo) << 16);                // exclusive starts of the even and the odd wave
-                    run += lo + hi;
+                for (int w = 0; w < NW; ++w) {
+                    const unsigned x = v[w];
+                    v[w] = run;
+                    run += x;
                 }
             }
             unsigned tot;
             const unsigned boff = block_excl_scan<NW>(run, spart, &tot);
             if (tid < P.NB) {
-                const unsigned b2 = boff | (boff << 16);
 #pragma unroll
-                for (int w = 0; w < NWP; ++w) hist[w * P.NB + tid] = v[w] + b2;
+                for (int w = 0; w < NW; ++w) hist[w * P.NB + tid] = v[w] + boff;
             }
             unsigned short *row = P.roff + ((long long)(b * 9 + c) * P.T + t) * (P.NB + 1);
             if (tid < P.NB) row[tid] = (unsigned short)boff;
@@ -1576,26 +1601,28 @@ __global__ __launch_bounds__(64 * NW, 4) void ldati_tile_dense_kernel(LdatiParam
         // ---- D5: stable ranks: the wave walks its records in pixel order -------------------------------------------
         {
             const unsigned sh = 12 + P.shift;
+            const unsigned lo = (unsigned)wid << lgL, hi = min(N, lo + (1u << lgL));
             if (atomic_order) {                          // the rank IS what the LDS atomic returns (g_lds_order_ok)
-                for (unsigned i = lane; i < evW; i += 64) {
-                    const unsigned rec = Sw[i];
-                    O[(atomicAdd(&myhist[rec >> sh], hone) >> hsh) & 0xFFFFu] = rec;
+                for (unsigned i = lo + lane; i < hi; i += 64) {
+                    const unsigned rec = S[i];
+                    O[atomicAdd(&myhist[rec >> sh], 1u)] = rec;
                 }
             } else {
-                for (unsigned i0 = 0; i0 < evW; i0 += 64) {
+                for (unsigned i0 = lo; i0 < hi; i0 += 64) {
                     const unsigned i = i0 + lane;
-                    const bool has = i < evW;
-                    const unsigned rec = has ? Sw[i] : 0u;
+                    const bool has = i < hi;
+                    const unsigned rec = has ? S[i] : 0u;
                     const unsigned bucket = rec >> sh;
-                    const unsigned pos = take_slots_packed(has, bucket, P.nb1, &myhist[bucket], hsh);
+                    const unsigned pos = take_slots(has, bucket, P.nb1, &myhist[bucket]);
                     if (has) O[pos] = rec;
                 }
             }
         }
         STAMP(7);
-        __syncthreads();                                 // D: the run is complete in O; every rank has read its histogram word
+        __syncthreads();                                 // D: the run is complete in O
         STAMP(8);
-        if (!(wid & 1)) for (int i = lane; i < P.NB; i += 64) myhist[i] = 0;    // for the next bin (first touched behind its barrier A)
+        for (int i = lane; i < P.NB; i += 64) myhist[i] = 0;    // for the next bin (first touched behind its barrier A)
+        if (tid == 0) *bctr = 0;
         {
             unsigned *dst = P.temp + P.seg_offsets[b * 9 + c] + P.tile_off[((long long)b * P.T + t) * 9 + c];
             for (unsigned i = tid; i < N; i += NT) dst[i] = O[i];
@@ -2581,9 +2608,9 @@ int tile_threads_choice(int64_t max_tile_events) {
     return v ? v : (max_tile_events > 4096 ? 1024 : 512);
 }
 
-// dynamic LDS of ldati_tile_dense_kernel<NW>: S [capA] | O [capA + 2 NW + 2] | hist [NW/2][NB] | wave totals, scan partials
+// dynamic LDS of ldati_tile_dense_kernel<NW>: S [capA] | O [capA + 2] | hist [NW][NB] | wave totals, scan partials, batch counter
 size_t dense_tile_lds(int capA, int NB, int NW) {
-    return ((size_t)2 * capA + 2 * NW + 2 + (size_t)(NW / 2) * NB + 2 * NW + 2) * 4;
+    return ((size_t)2 * capA + 2 + (size_t)NW * NB + 3 * NW + NW + 1 + 1 + 2) * 4;
 }
 
 // geometry and capacities of the two-level path
