@@ -15,7 +15,7 @@ LIGHT="--no-cpu-baseline --no-exact-f32 --no-host-to-host"
 for wl in e2e ldati_stress; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$wl -- python3 bench.py --workload $wl --steps 3 --warmup 1 $LIGHT > $OUT/kt_$wl.log 2>&1
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_${wl}_$c -- python3 bench.py --workload $wl --steps 1 --warmup 1 $LIGHT > $OUT/pmc_${wl}_$c.log 2>&1
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_${wl}_$c -- python3 bench.py --workload $wl --steps 2 --warmup 3 $LIGHT > $OUT/pmc_${wl}_$c.log 2>&1
   done
 done
 ls -R $OUT | head -50

@@ -118,6 +118,9 @@ struct LdatiParams {
     const unsigned *tile_abs;     // the same, read by the bucket sort (null: runs at seg_offsets + tile_off)
     const int *fused_status;      // status word of the fused kernel, folded into `status` by the bucket scan
     int Tp;                       // T rounded up to a multiple of 8
+    unsigned *gruns;              // [B*9][NB][Tp] per sort group and tile: run start inside the tile's (tile, bin) run | records << 16,
+                                  // written by the bucket scan (which has the run table in L2 anyway) so that a sort workgroup's
+                                  // setup is ONE contiguous row instead of two 938-byte-strided loads per tile
     const unsigned *tile_src;     // [B*9][Tp] record index of the (tile, bin) run relative to the sort's base, one contiguous row per
                                   // segment (two-pass: tile_off transposed by the tile scan; fused: the slot starts)
 };
@@ -2004,7 +2007,7 @@ __global__ __launch_bounds__(512) void ldati_bucket_scan_kernel(LdatiParams P) {
     // kernel 34 -> 48 us there and 20 -> 50 us in the e2e regime (576 segments, latency-bound): removed.)
     for (int i = t; i <= P.NB; i += 512) {
         unsigned s = 0;
-#pragma unroll 8
+#pragma unroll 22                                           // (latency-bound: a quarter of the 88 tiles' loads in flight at a time)
         for (int tt = 0; tt < P.T; ++tt) s += (unsigned)tab[(long long)tt * (P.NB + 1) + i];
         pre[i] = s;
     }
@@ -2050,6 +2053,8 @@ __global__ __launch_bounds__(512) void ldati_bucket_scan_kernel(LdatiParams P) {
     }
     if (t == 0) step_to[P.NB] = 3u << 16;
     __syncthreads();
+    __shared__ unsigned sgrp[kMaxNB];
+    __shared__ unsigned sng;
     if (t == 0) {
         unsigned *grp = P.groups + (long long)seg * P.NB;
         unsigned ng = 0;
@@ -2058,13 +2063,43 @@ __global__ __launch_bounds__(512) void ldati_bucket_scan_kernel(LdatiParams P) {
             const unsigned st = step_to[i];
             const unsigned kind = st >> 16, nx = st & 0xFFFFu;
             if (kind == 3u) break;
-            if (kind == 1u) grp[ng++] = (unsigned)i | (nx << 16);
+            if (kind == 1u) { sgrp[ng] = (unsigned)i | (nx << 16); grp[ng++] = (unsigned)i | (nx << 16); }
             else if (kind == 2u) P.big_list[atomicAdd(P.nbig, 1u)] = ((unsigned)seg << 16) | (unsigned)i;
             i = (int)nx;
         }
         P.ngroups[seg] = ng;
+        sng = ng;
         P.seg_flag[seg] = 0;
         if (seg == 0 && P.fused_status && *P.fused_status) atomicExch(reinterpret_cast<unsigned *>(P.status), (unsigned)*P.fused_status);
+    }
+    __syncthreads();
+    // every sort group's run in every tile (the table was read a moment ago: these loads hit L2), one contiguous row per group
+    {
+        const unsigned ng = sng;
+        unsigned *out = P.gruns + (long long)seg * P.NB * P.Tp;
+        // thread = (tile, group lane): no division, the groups' loads independent of each other
+        int lgT = 3;
+        while ((1 << lgT) < P.T) ++lgT;
+        if (lgT <= 9) {
+            const unsigned tt = (unsigned)t & ((1u << lgT) - 1u), gstep = 512u >> lgT;
+            if (tt < (unsigned)P.T) {
+                const unsigned short *row = tab + (long long)tt * (P.NB + 1);
+#pragma unroll 4
+                for (unsigned g = (unsigned)t >> lgT; g < ng; g += gstep) {
+                    const unsigned gr = sgrp[g];
+                    const unsigned r0 = row[gr & 0xFFFFu];
+                    out[(long long)g * P.Tp + tt] = r0 | (((unsigned)row[gr >> 16] - r0) << 16);
+                }
+            }
+        } else {
+            for (unsigned idx = t; idx < ng * (unsigned)P.T; idx += 512) {
+                const unsigned g = idx / (unsigned)P.T, tt = idx - g * (unsigned)P.T;
+                const unsigned gr = sgrp[g];
+                const unsigned short *row = tab + (long long)tt * (P.NB + 1);
+                const unsigned r0 = row[gr & 0xFFFFu];
+                out[(long long)g * P.Tp + tt] = r0 | (((unsigned)row[gr >> 16] - r0) << 16);
+            }
+        }
     }
 }
 
@@ -2117,10 +2152,9 @@ __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(Ldat
             const int tt = lane * TPL + q;
             cv[q] = 0u; ov[q] = 0u;
             if (tt < P.T) {
-                const unsigned short *row = P.roff + ((long long)seg * P.T + tt) * (P.NB + 1);
-                const unsigned r0 = row[bk0];
-                cv[q] = (unsigned)row[bk1] - r0;
-                ov[q] = r0 + P.tile_src[(long long)seg * P.Tp + tt];
+                const unsigned gr = P.gruns[((long long)seg * P.NB + blockIdx.x) * P.Tp + tt];
+                cv[q] = gr >> 16;
+                ov[q] = (gr & 0xFFFFu) + P.tile_src[(long long)seg * P.Tp + tt];
             }
             sum += cv[q] | (cv[q] ? 0x10000u : 0u);
         }
@@ -2670,9 +2704,9 @@ Plan make_plan(const HostScalars &h, int B, int H, int W, int64_t total_events,
     const size_t stage = (size_t)kSortThreads * 13 * 4;
     p.lds_sort = (size_t)p.cap2 * 4 + (tables > stage ? tables : stage);
     // bofs | groups [B*9*NB] | big_list [B*9*NB] | ngroups [B*9] | seg_flag [B*9] | status [4] (status, nbig) |
-    // records (u32) | roff (u16)
+    // records (u32) | roff (u16) | gruns (u32 [B*9][NB][Tp])
     p.bytes = (p.n_bkt + 2 * (size_t)B * 9 * p.NB + 2 * (size_t)B * 9 + 4 +
-               (size_t)(total_events > 0 ? total_events : 0)) * 4 + ((p.n_tab * 2 + 3) / 4) * 4;
+               (size_t)(total_events > 0 ? total_events : 0)) * 4 + ((p.n_tab * 2 + 3) / 4) * 4 + (size_t)B * 9 * p.NB * p.Tp * 4;
     if (p.lds_tile > 160 * 1024 || p.lds_sort > 160 * 1024) p.ok = false;
     return p;
 }
@@ -3074,6 +3108,7 @@ int emit_impl(const float *vox, int B, int H, int W, double fps, double t0,
         P.nbig = reinterpret_cast<unsigned *>(P.status + 1);
         P.temp = reinterpret_cast<unsigned *>(P.status + 4);
         P.roff = reinterpret_cast<unsigned short *>(P.temp + (size_t)total_events);
+        P.gruns = reinterpret_cast<unsigned *>(P.roff + ((pl.n_tab + 1) & ~(size_t)1));
         V2CE_HIP_CHECK(hipMemsetAsync(P.status, 0, 4 * sizeof(int), st));
         // the fused count already ran the sparse tile pass: usable when its assumed geometry is the plan's and every tile fitted
         bool fused = false;
