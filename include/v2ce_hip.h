@@ -157,8 +157,10 @@ int v2ce_ldati_plan_info(int B, int H, int W, double fps, double t0, const v2ce_
  * (csrc/ldati.hip: sqrt_rn_nr, div_rn_nr) and its Philox rounds on three-input xors.  This entry compares them with the
  * compiler's IEEE square root / division for EVERY slope-table entry (|count difference| <= 31, count <= 31) and EVERY
  * uniform m * 2^-24, and with the plain Philox rounds: mismatches[0] = differing times, mismatches[1] = differing
- * Philox outputs (both must be 0).  Synchronous; ~0.1 s on MI355X. */
-int v2ce_ldati_selfcheck(double fps, int64_t *mismatches /* host [2] */);
+ * Philox outputs; mismatches[2] = tendencies (every f32 in [0, 1) and (-2^-18, 0)) for which the single-event time's two
+ * constant f64 divisions differ between their fused-multiply-add form (single_time_fast) and the IEEE divisions -- the
+ * check the library itself runs once per device and fps before it uses that form.  All three must be 0.  Synchronous; ~0.1 s. */
+int v2ce_ldati_selfcheck(double fps, int64_t *mismatches /* host [3] */);
 
 /* How the stable tie order inside the LDS counting sorts is obtained on the current device: 1 = straight from the
  * lane order in which one ds_add_rtn_u32 wave-instruction serves equal addresses (checked once per device by a probe

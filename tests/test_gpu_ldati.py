@@ -350,9 +350,9 @@ def test_exact_math_helpers():
     (v2ce_ldati_selfcheck), at the CLI's fps and two others."""
     import ctypes
     for fps in (30.0, 25.0, 120.0):
-        bad = (ctypes.c_int64 * 2)()
+        bad = (ctypes.c_int64 * 3)()
         hip.check(hip.lib().v2ce_ldati_selfcheck(fps, bad), "v2ce_ldati_selfcheck")
-        assert (bad[0], bad[1]) == (0, 0), f"fps {fps}: {bad[0]} time mismatches, {bad[1]} Philox mismatches"
+        assert (bad[0], bad[1], bad[2]) == (0, 0, 0), f"fps {fps}: {bad[0]} time mismatches, {bad[1]} Philox mismatches, {bad[2]} f64 single-time mismatches"
 
 
 def test_dense_tile_kernel_equals_per_bin_kernel(gold_dir, monkeypatch):

@@ -67,6 +67,7 @@ struct LdatiParams {
     double fps;        // python number used in the f64 single-event path
     float VS, VS2, INV, FPS;
     float RFPS, R9;    // f32(1 / FPS), f32(1 / 9): reciprocals of the two constant divisors of the k == 0 time (k0_time)
+    double RFPS64, R9_64;   // RN(1 / fps), RN(1 / 9) in f64: the single-event time's two constant divisors (single_key_fast)
     int fast_slot;     // slot of g_fastdiv that holds the exhaustive check of k0_time's fast form for this FPS, or -1
     float offt[9];     // f32(arange(0,1/fps,1/fps/9)[c]) + f32(t0)
     long long kbase[9];  // key = timestamp - kbase[c], clamped to [0, NK)
@@ -267,9 +268,10 @@ __device__ __forceinline__ void slope_params(int n_l, int n_c, int n_r, int c, c
 // per device and FPS, enqueued in front of the first emit that needs it; the result lands in g_fastdiv[slot] and the
 // kernels take the fast form only when it says "identical for all inputs" (replayed uniforms are arbitrary floats: they
 // always take the divisions).  22 -> 6 VALU operations on a path every wave with a multi-event voxel executes.
-struct FastDiv { unsigned fps_bits; int ok; int tab_ready; };
+struct FastDiv { unsigned fps_bits; int ok; int tab_ready; int ok64; };
 __device__ FastDiv g_fastdiv[8];
 __device__ unsigned g_fastdiv_bad[8];
+__device__ unsigned g_fast64_bad[8];
 // The slope parameters {k, b} of a multi-event voxel (LDATI.py:188-190) depend on two small integers only -- the central
 // difference of the neighbouring counts and the voxel's own count -- and cost three IEEE divisions: tabulated once per
 // device and FPS by the very expressions of slope_params (so the entries ARE its results), looked up afterwards.
@@ -281,6 +283,36 @@ __device__ __forceinline__ float k0_time_fast(float u, float FPS, float RFPS, fl
     float t = q * R9;
     t = __builtin_fmaf(__builtin_fmaf(-t, 9.0f, q), R9, t);
     return t;
+}
+
+// ---- the single-event time (LDATI.py:156-165) without its two f64 division sequences ---------------------------------
+// t = (double)debt / fps / 9 with two constant divisors: q = x r, q = fma(fma(-q, y, x), r, q) with r = RN(1 / y) in f64, twice.
+// As for k0_time_fast the composition is CHECKED, not proven: a kernel compares it with the IEEE divisions for every f32 the
+// tendency of a forward-relocated voxel can take -- all floats in [0, 1) and all negative ones down to -2^-18 (the
+// recurrence leaves debt in (-1e-6 - ulp, 1)) -- once per device and fps (~2e9 values, a few ms); the kernels use it only when
+// the verdict is "identical everywhere" AND the lane's value lies inside the checked range (anything else -- the
+// bidirectional branch's tendencies reach 2 -- takes the divisions).  ~70 -> ~12 f64 operations per single event, which is
+// most events of real UNet output.
+__device__ __forceinline__ double single_time_fast(float debt, double fps, double rfps, double r9) {
+    const double x = (double)debt;
+    double q = x * rfps;
+    q = __builtin_fma(__builtin_fma(-q, fps, x), rfps, q);
+    double t = q * r9;
+    t = __builtin_fma(__builtin_fma(-t, 9.0, q), r9, t);
+    return t;
+}
+constexpr unsigned kFast64Neg = 0x36800000u;                 // bits of 2^-18: negative tendencies checked down to -2^-18
+__device__ __forceinline__ bool single_fast_range(float debt) { return debt < 1.0f && debt > -0x1p-18f; }
+
+__global__ __launch_bounds__(256) void ldati_fast64_check_kernel(double fps, double rfps, double r9, int slot) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x;
+    const unsigned npos = 0x3F800000u;                                    // floats in [0, 1)
+    if (i >= (unsigned long long)npos + kFast64Neg) return;
+    const unsigned bits = i < npos ? (unsigned)i : 0x80000000u + (unsigned)(i - npos);
+    const float d = __uint_as_float(bits);
+    const double want = (double)d / fps / 9.0;
+    const double got = single_time_fast(d, fps, rfps, r9);
+    if (!(want == got)) atomicAdd(&g_fast64_bad[slot], 1u);      // (numeric: -0 against +0 for debt = -0 is the same time)
 }
 
 __global__ __launch_bounds__(256) void ldati_fastdiv_check_kernel(float FPS, float RFPS, float R9, int slot) {
@@ -302,6 +334,7 @@ __global__ __launch_bounds__(256) void ldati_slope_tab_kernel(float VS, float VS
 __global__ void ldati_fastdiv_commit_kernel(float FPS, int slot) {
     g_fastdiv[slot].fps_bits = __float_as_uint(FPS);
     g_fastdiv[slot].ok = g_fastdiv_bad[slot] == 0u ? 1 : 0;
+    g_fastdiv[slot].ok64 = g_fast64_bad[slot] == 0u ? 1 : 0;
     g_fastdiv[slot].tab_ready = 1;
 }
 
@@ -348,6 +381,22 @@ __device__ __forceinline__ int key_of(long long T, long long kbase, int NK) {
     k = k >= NK ? NK - 1 : k;
     return (int)k;
 }
+
+// the key of a single event: fast form when the wave's tendencies all lie inside the checked range (`fast`: the device
+// verdict, 32-bit times), else the divisions.  Must be called by whole waves (the range test is a wave vote).
+__device__ __forceinline__ unsigned single_key(bool has, float debt, float offt, long long kbase, bool fast, const LdatiParams &P) {
+    const bool in = !has || single_fast_range(debt);
+    if (fast && __ballot(!in) == 0ull) {
+        double t = single_time_fast(debt, P.fps, P.RFPS64, P.R9_64);
+        t += (double)offt;
+        t *= 1e6;
+        int k = (int)t - (int)kbase;                      // (int)t == (long long)t while |t| < 2^31 (P.ts32)
+        k = k < 0 ? 0 : k;
+        return (unsigned)(k >= P.NK ? P.NK - 1 : k);
+    }
+    return (unsigned)key_of(single_ts(debt, P.fps, offt), kbase, P.NK);
+}
+
 
 // ballot match-any: lanes of `has_mask` with equal `key` form a peer group.  Returns the rank of
 // this lane inside its group (peers on lower lanes) and the group size.  ~5 VALU per key bit.
@@ -1334,6 +1383,7 @@ __global__ __launch_bounds__(64 * NW, 4) void ldati_tile_dense_kernel(LdatiParam
     const bool fast_k0 = slot_ok && philox && __builtin_amdgcn_readfirstlane(g_fastdiv[P.fast_slot].ok) != 0;
     // (a table that another stream is still filling: every multi-event voxel takes the owner-lane path once)
     const bool tab_ok = slot_ok && __builtin_amdgcn_readfirstlane(g_fastdiv[P.fast_slot].tab_ready) != 0;
+    const bool fast_s = slot_ok && P.ts32 && __builtin_amdgcn_readfirstlane(g_fastdiv[P.fast_slot].ok64) != 0;   // single_key's fast form
     const float2 *stab = g_slope_tab[P.fast_slot >= 0 ? P.fast_slot : 0];
 
     unsigned *S = reinterpret_cast<unsigned *>(tile_smem);
@@ -1490,13 +1540,11 @@ __global__ __launch_bounds__(64 * NW, 4) void ldati_tile_dense_kernel(LdatiParam
             S[sp] = rec;
             atomicAdd(&hist[(sp >> lgL) * (unsigned)P.NB + (key >> P.shift)], 1u);
         };
-        auto single_batch = [&](unsigned i) {
-            if (i < Ns) {
-                const unsigned e = SLs[i], sp = e & 0x3FFFu;
-                const long long Tq = single_ts(__uint_as_float(S[sp]), P.fps, offt_c);
-                const unsigned key = (unsigned)key_of(Tq, P.kbase[c], P.NK);
-                put(sp, (key << 12) | (e >> 14), key);
-            }
+        auto single_batch = [&](unsigned i) {                // (called by whole waves: single_key votes)
+            const bool has = i < Ns;
+            const unsigned e = has ? SLs[i] : 0u, sp = e & 0x3FFFu;
+            const unsigned key = single_key(has, has ? __uint_as_float(S[sp]) : 0.0f, offt_c, P.kbase[c], fast_s, P);
+            if (has) put(sp, (key << 12) | (e >> 14), key);
         };
         auto unit_batch = [&](auto mode_c, const uint2 *list, unsigned i, unsigned count) {
             // MODE 0: replayed uniforms (IEEE operations as the compiler expands them); 1 / 2: Philox, k == 0 units with /
@@ -1874,14 +1922,14 @@ __global__ __launch_bounds__(kSparseThreads) void ldati_tile_sparse_kernel(Ldati
         atomicAdd(&hist[g >> 1], 1u << ((g & 1u) * 16u));
         S[idx] = (ck << 12) | (multi << kLocalBits) | local;
     };
+    const bool fast_s = slot_ok && P.ts32 && __builtin_amdgcn_readfirstlane(g_fastdiv[P.fast_slot].ok64) != 0;      // single_key's fast form
 #pragma unroll
     for (int j = 0; j < SPT; ++j) {
-        if ((unsigned)(tid + j * NT) < Ns) {
-            const unsigned c = sl[j].y >> kLocalBits;
-            const long long Tq = single_ts(__uint_as_float(sl[j].x), P.fps, offt_s[c]);
-            const unsigned key = (unsigned)key_of(Tq, kbase_s[c], P.NK);
-            put((unsigned)(tid + j * NT), c, key, 0u, sl[j].y & (kTilePix - 1));   // a single's record index = its list index
-        }
+        if ((unsigned)(j * NT) >= Ns) break;                 // uniform: no single left for anybody
+        const bool has = (unsigned)(tid + j * NT) < Ns;
+        const unsigned c = has ? sl[j].y >> kLocalBits : 0u;
+        const unsigned key = single_key(has, __uint_as_float(sl[j].x), offt_s[c], kbase_s[c], fast_s, P);
+        if (has) put((unsigned)(tid + j * NT), c, key, 0u, sl[j].y & (kTilePix - 1));   // a single's record index = its list index
     }
 #pragma unroll
     for (int j = 0; j < MPT; ++j) {
@@ -2876,6 +2924,7 @@ int fill_params(LdatiParams &P, const HostScalars &h, const Opts &o, const float
     P.seed = seed; P.frame_base = frame_base;
     P.sweep_ok = h.sweep_ok ? 1 : 0;
     P.RFPS = (float)(1.0 / (double)h.FPS); P.R9 = (float)(1.0 / 9.0);
+    P.RFPS64 = 1.0 / fps; P.R9_64 = 1.0 / 9.0;
     P.fast_slot = -1;
     if (o.strategy == V2CE_STRATEGY_SLOPE && !getenv("V2CE_LDATI_NO_FASTDIV")) {
         // once per device and FPS: the exhaustive check of k0_time_fast against the IEEE divisions (see g_fastdiv) and the
@@ -2892,10 +2941,12 @@ int fill_params(LdatiParams &P, const HostScalars &h, const Opts &o, const float
             int slot = -1;
             for (int i = 0; i < n_seen[dev]; ++i)
                 if (seen[dev][i] == bits) slot = i;
-            if (slot < 0 && n_seen[dev] < 8) {
+            if (slot < 0 && n_seen[dev] < 7) {                   // (slot 7: v2ce_ldati_selfcheck's scratch)
                 slot = n_seen[dev]++;
                 seen[dev][slot] = bits;
                 hipLaunchKernelGGL(ldati_fastdiv_check_kernel, dim3(65536), dim3(256), 0, st, h.FPS, P.RFPS, P.R9, slot);
+                hipLaunchKernelGGL(ldati_fast64_check_kernel, dim3((0x3F800000u + kFast64Neg + 255u) / 256u), dim3(256), 0, st, fps, P.RFPS64,
+                                   P.R9_64, slot);
                 hipLaunchKernelGGL(ldati_slope_tab_kernel, dim3((kSlopeTab + 255) / 256), dim3(256), 0, st, h.VS, h.VS2, h.INV, slot);
                 hipLaunchKernelGGL(ldati_fastdiv_commit_kernel, dim3(1), dim3(1), 0, st, h.FPS, slot);
             }
@@ -3248,6 +3299,13 @@ extern "C" int v2ce_ldati_selfcheck(double fps, int64_t *mismatches) {
     V2CE_HIP_CHECK(e);
     mismatches[0] = (int64_t)host[0];
     mismatches[1] = (int64_t)host[1];
+    // the single-event time's fast form (single_time_fast): the product's own one-time check, run here in a spare slot
+    const unsigned zero = 0;
+    V2CE_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_fast64_bad), &zero, sizeof(unsigned), 7 * sizeof(unsigned)));
+    hipLaunchKernelGGL(ldati_fast64_check_kernel, dim3((0x3F800000u + kFast64Neg + 255u) / 256u), dim3(256), 0, nullptr, fps, 1.0 / fps, 1.0 / 9.0, 7);
+    unsigned bad64 = 0;
+    V2CE_HIP_CHECK(hipMemcpyFromSymbol(&bad64, HIP_SYMBOL(g_fast64_bad), sizeof(unsigned), 7 * sizeof(unsigned)));
+    mismatches[2] = (int64_t)bad64;
     return V2CE_OK;
 }
 
