@@ -66,16 +66,17 @@ def ldati_table(out, wl, events_per_launch):
                          "(LDS-issue %.1f %%), parked %.1f %%" % tuple(100 * c.get(x, 0.0) / wc for x in (
                              "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM",
                              "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_WAIT_ANY")))
+        once = any(x in k for x in ("probe", "check", "slope_tab", "commit"))     # one-time device checks: not part of a call
         if c.get("SQ_INSTS_VALU") and events_per_launch:
             lane = 64.0 * c["SQ_INSTS_VALU"] / events_per_launch
-            tot_valu += lane
+            tot_valu += 0.0 if once else lane
             extra = ""
             if c.get("SQ_THREAD_CYCLES_VALU"):
                 extra = ", active lanes per VALU instruction %.1f of 64" % (c["SQ_THREAD_CYCLES_VALU"] / 4.0 / c["SQ_INSTS_VALU"])
             lines.append(f"      VALU wave-instructions x 64 / event = {lane:.1f} lane-slots per event{extra}")
         if c.get("SQ_LDS_IDX_ACTIVE"):
             lines.append("      LDS bank conflicts: %.1f %% of the LDS-array cycles" % (100 * c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"]))
-    lines.append(f"  all LDATI kernels: {tot_valu:.1f} VALU lane-slots per event")
+    lines.append(f"  all LDATI kernels of a call (one-time device checks excluded; kernels that ran on the first call only -- a fused pass whose hint missed, its two-pass repeat -- are averaged over their own launches): {tot_valu:.1f} VALU lane-slots per event")
     # VALU-issue roofline of the whole call: executed VALU wave-instructions x 64 lanes against 1024 SIMDs x 16 lanes per clock
     # over the kernels' own busy clocks (GRBM_GUI_ACTIVE / 8 XCDs)
     js = {"events_per_call": events_per_launch, "valu_lane_slots_per_event": tot_valu, "kernels": {}}

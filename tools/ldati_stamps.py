@@ -36,7 +36,10 @@ for _ in range(3):
 torch.cuda.synchronize()
 L.v2ce_debug_stamps(buf)
 v = np.array(buf[:], dtype=np.float64)
-names_t = ["loop head/advance", "P1+scan", "hist zero+P3 tables+barrier", "P4 singles", "P4 multis", "barrier", "P5 scan", "P6 rank", "barrier", "P7 copy"]
+# ldati_tile_dense_kernel (round 4); V2CE_LDATI_OLD_TILE=1 stamps ldati_tile_pass_kernel with the same ten slots
+# (loop head, P1 + scan, hist zero + P3 tables + barrier, P4 singles, P4 multis, barrier, P5 scan, P6 rank, barrier, P7 copy)
+names_t = ["loop head / advance / loads", "D1 classify + scan + barrier A", "D2 work lists + barrier A2", "(unused)", "D3 timestamp batches",
+           "barrier B", "D4 bucket scan + run table", "D5 rank", "barrier D", "copy-out"]
 names_s = ["S0 setup", "S1 gather", "S2 widen+hist", "barrier", "S3 scan", "S4 rank", "barrier", "S5 emit"]
 for title, base, names in (("tile pass (wave 0 of every workgroup)", 0, names_t), ("bucket sort", 16, names_s)):
     tot = v[base:base + len(names)].sum()
