@@ -475,3 +475,47 @@ def test_fused_count_equals_two_pass(gold_dir, monkeypatch):
     soa_equal(both(lambda: hip_events(z["vox"], float(z["fps"]), float(z["t0"]), uniforms=z["uniforms"])),
               *O.emit_soa(z["vox"], fps=float(z["fps"]), t0=float(z["t0"]), uniforms=z["uniforms"]))
     assert both(lambda: hip_events(np.zeros((2, 2, 10, 30, 40), np.float32), seed=1)).num_events == 0
+
+
+def test_c_abi_fused_call_sequence():
+    """The call sequence INTEGRATION.md gives a maintainer of the reference, through ctypes alone (no LDATI.py): hint 0 ->
+    v2ce_ldati_fused_ws_bytes -> v2ce_ldati_count_fused -> read stats -> v2ce_ldati_workspace_bytes -> v2ce_ldati_emit_fused;
+    once with the default hint (the geometry may miss: the emit falls back by itself) and once with the real densest-segment
+    count as the hint.  Both give the oracle's events; argument errors come back as codes, never as exceptions."""
+    import ctypes
+    L = hip.lib()
+    vox = synth.synthetic_voxels(2, 96, 160, seed=31, regime="sparse")
+    y = torch.from_numpy(vox).cuda()
+    B, _, _, H, W = y.shape
+    want = O.emit_soa(vox, fps=30, seed=99, frame_base=5)
+    st = hip.stream_ptr(y.device)
+    o = hip.LdatiOptions(hip.STRATEGY_SLOPE, 0, hip.POOL_NONE, 3)
+    hint = 0
+    for attempt in range(2):
+        fb = L.v2ce_ldati_fused_ws_bytes(B, H, W, 30.0, 0.0, ctypes.byref(o), hint)
+        assert fb > 0
+        tws = torch.empty(L.v2ce_ldati_tile_ws_bytes(B, H, W), dtype=torch.uint8, device="cuda")
+        fws = torch.empty(fb, dtype=torch.uint8, device="cuda")
+        meta = torch.empty(B * 9 + 1 + 8, dtype=torch.int64, device="cuda")
+        hip.check(L.v2ce_ldati_count_fused(y.data_ptr(), B, H, W, 30.0, 0.0, ctypes.byref(o), hip.RNG_PHILOX, None, 0, 99, 5, hint,
+                                           tws.data_ptr(), tws.numel(), fws.data_ptr(), fws.numel(), meta.data_ptr(),
+                                           meta[B * 9 + 1:].data_ptr(), st), "count_fused")
+        host = meta.cpu().numpy()
+        max_n, max_tile, max_seg, total, tile_all = (int(v) for v in host[B * 9 + 1:B * 9 + 6])
+        assert total == int(want[0].sum()) and np.array_equal(np.diff(host[:B * 9 + 1]).reshape(B, 9), want[0]) and tile_all <= 8192
+        nb = L.v2ce_ldati_workspace_bytes(B, H, W, 30.0, 0.0, ctypes.byref(o), total, max_seg, max_tile, 1)
+        ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        out = torch.empty(total * 13 + 64, dtype=torch.uint8, device="cuda")
+        hip.check(L.v2ce_ldati_emit_fused(y.data_ptr(), B, H, W, 30.0, 0.0, ctypes.byref(o), hip.RNG_PHILOX, None, 0, 99, 5,
+                                          meta.data_ptr(), None, None, None, None, None, out.data_ptr(), total, max_seg, max_tile,
+                                          tws.data_ptr(), ws.data_ptr(), nb, fws.data_ptr(), fws.numel(), tile_all, hint, st), "emit_fused")
+        rec = out[:total * 13].cpu().numpy().view(O.EVENT_DTYPE)
+        assert np.array_equal(rec["timestamp"], want[1]) and np.array_equal(rec["x"], want[2])
+        assert np.array_equal(rec["y"], want[3]) and np.array_equal(rec["polarity"], want[4])
+        hint = max_seg
+    # errors are return codes with a message
+    assert L.v2ce_ldati_count_fused(y.data_ptr(), B, H, W, 30.0, 0.0, ctypes.byref(o), hip.RNG_PHILOX, None, 0, 99, 5, 0, tws.data_ptr(),
+                                    tws.numel(), fws.data_ptr(), 16, meta.data_ptr(), meta[B * 9 + 1:].data_ptr(), st) != 0
+    assert b"workspace" in L.v2ce_last_error()
+    rnd = hip.LdatiOptions(hip.STRATEGY_RANDOM, 0, hip.POOL_NONE, 3)
+    assert L.v2ce_ldati_fused_ws_bytes(B, H, W, 30.0, 0.0, ctypes.byref(rnd), 0) == 0        # 'random' has no fused path
