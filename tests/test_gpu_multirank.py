@@ -146,20 +146,20 @@ def test_cli_under_torchrun_world_of_one_nccl(tmp_path, infer_type, wf):
     pinned sink), the all_reduce behind run_guarded -- same file as the plain single-process CLI."""
     outs = []
     np.save(tmp_path / "f.npy", synth.synthetic_frames(70, 32, wf, seed=9))
-    for forced in (False, True):
-        out = tmp_path / ("d" if forced else "s")
+    for forced in (False, "device", "host"):               # both gather modes of the distributed path (RCCL world of one)
+        out = tmp_path / (forced or "s")
         args = [os.path.join(ROOT, "v2ce.py"), "--npy_frames", str(tmp_path / "f.npy"), "--height", "32", "--width", "48",
                 "--synthetic_weights", "0", "-o", str(out), "-b", "2", "--seed", "3", "-t", infer_type,
                 "--write_event_frame_video", "false"]
         if forced:
-            torchrun(args, {"V2CE_FORCE_DIST": "1"})
+            torchrun(args, {"V2CE_FORCE_DIST": "1", "V2CE_GATHER": forced})
         else:
             r = subprocess.run([sys.executable] + args, capture_output=True, text=True, timeout=900, cwd=ROOT)
             assert r.returncode == 0, r.stderr[-2000:]
         files = [f for f in os.listdir(out) if f.endswith("-events.npz")]
         assert len(files) == 1
         outs.append(np.load(out / files[0])["event_stream"])
-    assert len(outs[0]) > 1000 and outs[0].tobytes() == outs[1].tobytes()
+    assert len(outs[0]) > 1000 and outs[0].tobytes() == outs[1].tobytes() == outs[2].tobytes()
 
 
 def test_rccl_collectives_world_of_one():
