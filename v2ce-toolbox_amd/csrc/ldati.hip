@@ -2376,8 +2376,12 @@ __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(Ldat
     // record costs more than the division it selects)
     auto emit_loop = [&](auto mode_c) {
         constexpr int MODE = decltype(mode_c)::value;                  // 0: div_tiny, 1: div_small, 2: integer division
+        // Every WAVE assembles and copies out its own 64 groups (3328 bytes = 208 16-byte pieces, 16-byte aligned in global
+        // memory like the workgroup's image): no workgroup barrier inside the loop (round 4; the loop used to pay two per
+        // 1024 records and was 45 % of the kernel's time)
         for (int ga = 0; ga < nG_all; ga += kSortThreads) {
-            const int g = ga + tid;
+            const int gw0 = ga + 64 * wid;
+            const int g = gw0 + lane;
             if (g < nG_all) {
                 unsigned A[4], Bh[4], C[4], D[4];
                 const int i0 = i_base + 4 * g;
@@ -2407,25 +2411,29 @@ __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(Ldat
                 d[11] = (Bh[3] >> 8) | (C[3] << 24);
                 d[12] = (C[3] >> 8) | (D[3] << 24);
             }
-            __syncthreads();
-            const int left = nG_all - ga;
-            const int nG = left < kSortThreads ? left : kSortThreads;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();                               // (one wave's LDS operations complete in order)
+            const int left = nG_all - gw0;
+            const int nG = left < 64 ? (left > 0 ? left : 0) : 64;
             const int nPieces = (nG * 52 + 15) >> 4;
-            const long long img = 52 * (G0 + ga);                          // global byte address of the image
+            const long long img = 52 * (G0 + gw0);                         // global byte address of the wave's image
             // pieces [qa, qb) lie wholly inside this bucket's bytes (all but the first and the last of the bucket)
-            const int rel0 = (int)(B0 - img), rel1 = (int)(B1 - img);     // small: |rel0| < 256, rel1 <= 13 * cap2 + 256
+            const long long r0l = B0 - img, r1l = B1 - img;
+            const int rel0 = (int)(r0l < -(1 << 20) ? -(1 << 20) : r0l), rel1 = (int)r1l;     // rel1 <= 13 * cap2 + 256
             const int qa = rel0 > 0 ? (rel0 + 15) >> 4 : 0, qb = rel1 >> 4;
             unsigned char *dst = P.packed + img;
-            for (int q = tid; q < nPieces; q += kSortThreads) {
+            const unsigned *stage_w = stage + wid * (64 * 13);
+            for (int q = lane; q < nPieces; q += 64) {
                 if (q >= qa && q < qb) {
-                    reinterpret_cast<uint4 *>(dst)[q] = reinterpret_cast<const uint4 *>(stage)[q];
+                    reinterpret_cast<uint4 *>(dst)[q] = reinterpret_cast<const uint4 *>(stage_w)[q];
                 } else {
-                    const unsigned char *sb = reinterpret_cast<const unsigned char *>(stage) + 16 * q;
+                    const unsigned char *sb = reinterpret_cast<const unsigned char *>(stage_w) + 16 * q;
                     for (int k = 0; k < 16; ++k)
                         if (16 * q + k >= rel0 && 16 * q + k < rel1) dst[16 * q + k] = sb[k];
                 }
             }
-            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     };
     if (tiny) emit_loop(std::integral_constant<int, 0>{});
