@@ -378,3 +378,31 @@ def test_device_gather_reuses_bounded_receive_buffers():
     (+25 %), not in fresh allocations per step: six steps of up to 30 MiB per rank allocate twice."""
     got = _spawn(_pool_worker, 2)
     assert all(ok for _, ok, _ in got) and all(n <= 2 for _, _, n in got), got
+
+
+def test_single_rank_failure_leaves_no_partial_file(tmp_path):
+    """a clip that dies half-way through a streamed .npz must not leave a truncated archive (nor its
+    .part) behind, and the writer thread must be gone -- single process, error raised by stage 2 in the third batch."""
+    import threading
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_product_glue import FakeModel
+    from v2ce_toolbox_amd import synth
+    from v2ce_toolbox_amd import v2ce as cli
+    begin, finish = fake_stage2(30)
+    calls = {"n": 0}
+
+    def finish_bad(handle):
+        calls["n"] += 1
+        if calls["n"] == 3:
+            raise ValueError("stage 2 failed on purpose")
+        return finish(handle)
+    frames = synth.synthetic_frames(101, 8, 20, seed=3)
+    before = threading.active_count()
+    with pytest.raises(ValueError, match="on purpose"):
+        cli.run(frames, FakeModel(), infer_type="center", width=12, height=8, batch_size=2, device="cpu",
+                stage2=(begin, finish_bad), out_path=str(tmp_path / "f.npz"))
+    assert os.listdir(tmp_path) == [] and threading.active_count() <= before
+    # and the same call without the fault writes the file under its final name only
+    n = cli.run(frames, FakeModel(), infer_type="center", width=12, height=8, batch_size=2, device="cpu",
+                stage2=(begin, finish), out_path=str(tmp_path / "f.npz"))
+    assert os.listdir(tmp_path) == ["f.npz"] and len(np.load(tmp_path / "f.npz")["event_stream"]) == n
