@@ -63,7 +63,8 @@ const char *v2ce_last_error(void);
  * vox [B,2,10,H,W] f32.  seg_offsets [B*9+1] i64: exclusive prefix of the segment counts (last =
  * total events).  stats [4] i64 = {max count of any voxel (LDATI.py:169 max_n), most events of one
  * (2048-pixel tile, bin), largest segment, total events}.  tile_ws (>= v2ce_ldati_tile_ws_bytes):
- * per-tile counts and offsets, consumed by v2ce_ldati_emit's two-level path. */
+ * per-tile counts and offsets (and the offsets once more as one contiguous row per segment, for the bucket sort's
+ * setup), consumed by v2ce_ldati_emit's two-level path. */
 /* The keyword options of sample_voxel_statistical (LDATI.py:126).  NULL = the CLI's call (v2ce.py:356):
  * additional_events_strategy='slope', pooling_type='none', bidirectional=False. */
 typedef struct {

@@ -37,7 +37,8 @@ def test_argument_validation_without_gpu():
     assert L.v2ce_ldati_workspace_bytes(1, 260, 346, 30.0, 0.0, None, 10 ** 7, 10 ** 6, 20000, 1) == 0   # tile-bin beyond LDS
     rnd = hip.LdatiOptions(strategy=hip.STRATEGY_RANDOM, bidirectional=0, pooling_type=0, pooling_kernel_size=3)
     assert L.v2ce_ldati_workspace_bytes(1, 260, 346, 30.0, 0.0, ctypes.byref(rnd), 100000, 20000, 500, 1) > 16 * 100000
-    assert L.v2ce_ldati_tile_ws_bytes(24, 260, 346) == 2 * 24 * 88 * 9 * 4
+    # tile counts [B][T][9] + tile offsets [B][T][9] + the offsets again as one row of T (padded to 8) per segment (round 4)
+    assert L.v2ce_ldati_tile_ws_bytes(24, 260, 346) == 2 * 24 * 88 * 9 * 4 + 24 * 9 * 88 * 4
     assert L.v2ce_sn_workspace_bytes(512, 13824) >= 4 * (512 + 13824)
     d = hip.ConvDesc(B=1, T=16, C0=64, H0=130, W0=173, C1=0, Hin=130, Win=173, Cout=64, Hout=130,
                      Wout=173, ksize=5, stride_hw=1, act=1, tile_t=0, tile_h=0, tile_w=0, precision=0)
