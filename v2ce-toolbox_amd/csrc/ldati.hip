@@ -1388,7 +1388,7 @@ __global__ __launch_bounds__(64 * NW, 4) void ldati_tile_dense_kernel(LdatiParam
 
     unsigned *S = reinterpret_cast<unsigned *>(tile_smem);
     unsigned *O = S + P.capA;
-    unsigned *hist = O + P.capA + 2;                    // [NW][NB]: row r counts the records at positions [r L, (r + 1) L)
+    unsigned *hist = O + P.capA + 8;                    // [NW][NB]: row r counts the records at positions [r L, (r + 1) L)
     unsigned *part = hist + NW * P.NB;                  // [3][NW] wave totals (events | singles, k == 0 units << 16 | k != 0 units)
     unsigned *spart = part + 3 * NW;                    // [NW + 1] scan partials
     unsigned *bctr = spart + NW + 1;                    // the next batch of the timestamp phase
@@ -1454,20 +1454,23 @@ __global__ __launch_bounds__(64 * NW, 4) void ldati_tile_dense_kernel(LdatiParam
         // the slope-table index rides in bits 3..13
         unsigned cls[PPT], aex[PPT], uex[PPT];
         unsigned At = 0, Ut = 0;
+        const bool multi_on = P.strategy != V2CE_STRATEGY_NONE, edge = c == 0 || c == 8;
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
             const int n = ncur[q];                                          // (a pixel past the image holds zeros: no event)
-            const bool multi = n >= 2 && P.strategy != V2CE_STRATEGY_NONE;
-            const int si = multi ? slope_index(nprev[q], n, nnext[q], c) : -1;
-            const bool intab = tab_ok && si >= 0;
-            const bool kz = (c == 0 || c == 8) || nnext[q] == nprev[q];      // table entries: k == 0 exactly when the difference is
-            const unsigned cl = n == 1 ? 1u : !multi ? 0u : !intab ? 4u : kz ? 2u : 3u;
-            cls[q] = cl | (intab ? (unsigned)si << 3 : 0u);
+            const bool multi = n >= 2 && multi_on;
+            // slope-table entry (slope_index's test in three unsigned compares): |difference| <= 31, count <= 31, neighbours in [0, 2^23)
+            const int dd = edge ? 0 : nnext[q] - nprev[q];
+            const bool intab = tab_ok && (unsigned)(dd + kSlopeM) <= 2u * kSlopeM && (unsigned)n <= (unsigned)kSlopeM &&
+                               (unsigned)(nprev[q] | nnext[q]) < (1u << 23);
+            const unsigned si = (unsigned)((dd + kSlopeM) * (kSlopeM + 1) + n);
+            const unsigned cl = n == 1 ? 1u : !multi ? 0u : !intab ? 4u : dd == 0 ? 2u : 3u;      // table entries: k == 0 exactly when the difference is
+            cls[q] = cl | ((si & 0x7FFu) << 3);
             const unsigned units = (unsigned)(n + 3) >> 2;
             aex[q] = At;
             uex[q] = Ut;
-            At += (cl ? (unsigned)n : 0u) | (cl == 1u ? 0x10000u : 0u);
-            Ut += (cl == 2u ? units : 0u) | (cl == 3u ? units << 16 : 0u);
+            At += (cl ? (unsigned)n : 0u) + (cl == 1u ? 0x10000u : 0u);
+            Ut += cl == 2u ? units : cl == 3u ? units << 16 : 0u;
         }
         const unsigned iA = wave_incl_scan(At, lane), iU = wave_incl_scan(Ut, lane);
         const unsigned baseA = iA - At, baseU = iU - Ut;
@@ -1493,6 +1496,10 @@ __global__ __launch_bounds__(64 * NW, 4) void ldati_tile_dense_kernel(LdatiParam
             sU0 = wid ? (unsigned)__builtin_amdgcn_readlane((int)p2, wid - 1) : 0u;
             sU1 = wid ? (unsigned)__builtin_amdgcn_readlane((int)p3, wid - 1) : 0u;
         }
+        // where the tile's run of this bin goes; its records are ranked into O at the same phase modulo four records, so that the
+        // copy-out moves whole 16-byte pieces
+        const long long dst0 = P.seg_offsets[b * 9 + c] + (long long)P.tile_off[((long long)b * P.T + t) * 9 + c];
+        const unsigned dshift = (unsigned)dst0 & 3u;
         uint2 *UL1 = reinterpret_cast<uint2 *>(O), *UL0 = UL1 + U1;
         unsigned *SLs = O + 2u * (U1 + U0);
         // ranks are taken in NW chunks of L = 2^lgL consecutive positions (one wave each); a record counts in its chunk's row
@@ -1513,10 +1520,15 @@ __global__ __launch_bounds__(64 * NW, 4) void ldati_tile_dense_kernel(LdatiParam
             } else if (cl == 2u || cl == 3u) {
                 const unsigned ue = baseU + uex[q];
                 uint2 *dstu = cl == 2u ? UL0 + sU0 + (ue & 0xFFFFu) : UL1 + sU1 + (ue >> 16);
-                const unsigned units = (unsigned)(n + 3) >> 2;
-                for (unsigned jb = 0; jb < units; ++jb) {
-                    const unsigned left = (unsigned)n - 4u * jb;
-                    dstu[jb] = make_uint2(local | (jb << 11) | ((left < 4u ? left : 4u) << 29), (pos + 4u * jb) | ((cls[q] >> 3) << 14));
+                const unsigned units = (unsigned)(n + 3) >> 2, hi = (cls[q] >> 3) << 14;
+                dstu[0] = make_uint2(local | (((unsigned)n < 4u ? (unsigned)n : 4u) << 29), pos | hi);      // (most voxels: one or two units)
+                if (units > 1u) {
+                    const unsigned l1 = (unsigned)n - 4u;
+                    dstu[1] = make_uint2(local | (1u << 11) | ((l1 < 4u ? l1 : 4u) << 29), (pos + 4u) | hi);
+                    for (unsigned jb = 2; jb < units; ++jb) {
+                        const unsigned left = (unsigned)n - 4u * jb;
+                        dstu[jb] = make_uint2(local | (jb << 11) | ((left < 4u ? left : 4u) << 29), (pos + 4u * jb) | hi);
+                    }
                 }
             } else if (cl == 4u) {
                 float k, bb;
@@ -1625,11 +1637,16 @@ __global__ __launch_bounds__(64 * NW, 4) void ldati_tile_dense_kernel(LdatiParam
         STAMP(5);
         // ---- D4: bucket-major, wave-minor exclusive scan; the tile's row of the run table ------------------------
         {
+            // thread 2 b + h takes rows [h NW/2, (h + 1) NW/2) of bucket b when the workgroup has 2 NB threads (the workgroup
+            // scan then runs over (bucket, half) in exactly the order the offsets need), else one thread takes the bucket
+            const bool two = 2 * P.NB <= NT;                  // uniform
+            constexpr int RH = NW / 2;
+            const int bkt = two ? tid >> 1 : tid, r0 = two ? (tid & 1) * RH : 0, nr = two ? RH : NW;
             unsigned v[NW];
             unsigned run = 0;
-            if (tid < P.NB) {
+            if (bkt < P.NB) {
 #pragma unroll
-                for (int w = 0; w < NW; ++w) v[w] = hist[w * P.NB + tid];
+                for (int w = 0; w < NW; ++w) v[w] = w < nr ? hist[(r0 + w) * P.NB + bkt] : 0u;
 #pragma unroll
                 for (int w = 0; w < NW; ++w) {
                     const unsigned x = v[w];
@@ -1639,12 +1656,13 @@ __global__ __launch_bounds__(64 * NW, 4) void ldati_tile_dense_kernel(LdatiParam
             }
             unsigned tot;
             const unsigned boff = block_excl_scan<NW>(run, spart, &tot);
-            if (tid < P.NB) {
+            if (bkt < P.NB) {
 #pragma unroll
-                for (int w = 0; w < NW; ++w) hist[w * P.NB + tid] = v[w] + boff;
+                for (int w = 0; w < NW; ++w)
+                    if (w < nr) hist[(r0 + w) * P.NB + bkt] = v[w] + boff + dshift;
             }
             unsigned short *row = P.roff + ((long long)(b * 9 + c) * P.T + t) * (P.NB + 1);
-            if (tid < P.NB) row[tid] = (unsigned short)boff;
+            if (bkt < P.NB && r0 == 0) row[bkt] = (unsigned short)boff;
             if (tid == 0) row[P.NB] = (unsigned short)N;
         }
         __syncthreads();                                 // C: bucket offsets per wave
@@ -1675,8 +1693,20 @@ __global__ __launch_bounds__(64 * NW, 4) void ldati_tile_dense_kernel(LdatiParam
         for (int i = lane; i < P.NB; i += 64) myhist[i] = 0;    // for the next bin (first touched behind its barrier A)
         if (tid == 0) *bctr = 0;
         {
-            unsigned *dst = P.temp + P.seg_offsets[b * 9 + c] + P.tile_off[((long long)b * P.T + t) * 9 + c];
-            for (unsigned i = tid; i < N; i += NT) dst[i] = O[i];
+            // O[dshift + i] -> dst[i]: 16-byte pieces where the piece lies inside the run, single records at its two ends
+            unsigned *dstq = P.temp + (dst0 - (long long)dshift);             // 16-byte aligned (temp is; dst0 - dshift is a multiple of 4 records)
+            const unsigned nq = (dshift + N + 3u) >> 2;
+            for (unsigned q = tid; q < nq; q += NT) {
+                const uint4 v = reinterpret_cast<const uint4 *>(O)[q];
+                if (4u * q >= dshift && 4u * q + 4u <= dshift + N) {
+                    reinterpret_cast<uint4 *>(dstq)[q] = v;
+                } else {
+                    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (4u * q + j >= dshift && 4u * q + j < dshift + N) dstq[4u * q + j] = w[j];
+                }
+            }
         }
         STAMP(9);
 #pragma unroll
@@ -2700,7 +2730,7 @@ int tile_threads_choice(int64_t max_tile_events) {
 
 // dynamic LDS of ldati_tile_dense_kernel<NW>: S [capA] | O [capA + 2] | hist [NW][NB] | wave totals, scan partials, batch counter
 size_t dense_tile_lds(int capA, int NB, int NW) {
-    return ((size_t)2 * capA + 2 + (size_t)NW * NB + 3 * NW + NW + 1 + 1 + 2) * 4;
+    return ((size_t)2 * capA + 8 + (size_t)NW * NB + 3 * NW + NW + 1 + 1 + 2) * 4;
 }
 
 // geometry and capacities of the two-level path
