@@ -1,19 +1,21 @@
 #!/bin/bash
-# LDATI A/B on the GPU box: bench.py --workload ldati_stress / ldati_sparse under a few settings; one line each.
-# usage: tools/ldati_ab.sh "VAR=VAL ..." ["VAR=VAL ..."] ...   (each argument = one environment to try; "" = defaults)
-mkdir -p gpurun_out
-for envs in "$@"; do
-  for wl in ldati_stress ldati_sparse; do
-    out=$(env $envs python bench.py --workload $wl --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1)
-    python - "$envs" "$wl" "$out" <<'PY'
-import json, sys
-envs, wl, out = sys.argv[1:4]
-try:
-    d = json.loads(out)
-    print(f"[{envs or 'default'}] {wl}: {d['ms_per_step']:.3f} ms/step wall, ldati {d['ldati']['avg_ms']:.3f} ms (count {d['ldati']['count_ms']:.3f}), "
-          f"frac {d['roofline']['frac']:.3f}, {d['mevents_per_s']:.0f} Mev/s")
-except Exception as e:
-    print(f"[{envs}] {wl}: FAILED {e}: {out[-300:]}")
+# A/B of the LDATI kernels on the GPU box: LDATI tests, then rocprofv3 kernel stats of the stress and e2e benches.
+#   bash tools/ldati_ab.sh <tag> [pytest-args]
+TAG=${1:-ab}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+python -m pytest tests/test_gpu_ldati.py -x -q ${2:-} 2>&1 | tail -4
+export TMPDIR=/tmp
+for wl in ldati_stress e2e; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$wl -- python3 bench.py --workload $wl --steps 20 --warmup 5 --no-cpu-baseline --no-exact-f32 --no-host-to-host > $OUT/$wl.log 2>&1
+  grep "^{" $OUT/$wl.log | python3 -c "import sys,json; j=json.loads(sys.stdin.readline()); print(j['config']['workload'][:30], 'ms/step', round(j['ms_per_step'],4), 'frac', j['roofline'].get('frac'))"
+  f=$(ls $OUT/$wl/*/*kernel_stats.csv | head -1)
+  python3 - "$f" <<'PY'
+import csv, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    n = r['Name']
+    if 'ldati' in n and 'check' not in n and 'probe' not in n and 'slope_tab' not in n:
+        n = n.replace('void ', '').replace('v2ce::(anonymous namespace)::', '').split('(')[0]
+        print(f"   {n:44s} {r['Calls']:>4s} {float(r['AverageNs']) / 1e3:9.1f} us")
 PY
-  done
 done

@@ -1392,6 +1392,8 @@ __global__ __launch_bounds__(64 * NW, 4) void ldati_tile_dense_kernel(LdatiParam
     unsigned *part = hist + NW * P.NB;                  // [3][NW] wave totals (events | singles, k == 0 units << 16 | k != 0 units)
     unsigned *spart = part + 3 * NW;                    // [NW + 1] scan partials
     unsigned *bctr = spart + NW + 1;                    // the next batch of the timestamp phase
+    unsigned *dsto = bctr + 2;                          // [9][2]: where the tile's run of bin c starts in records[] (loaded once: a
+                                                        // global load per bin would stall all sixteen waves for its whole latency)
     unsigned *myhist = hist + wid * P.NB;
 
     const float *plane0 = P.vox + (long long)(b * 2 + pidx) * 10 * P.HW;
@@ -1439,6 +1441,11 @@ __global__ __launch_bounds__(64 * NW, 4) void ldati_tile_dense_kernel(LdatiParam
     }
     for (int i = lane; i < P.NB; i += 64) myhist[i] = 0;
     if (tid == 0) *bctr = 0;
+    if (tid < 9) {
+        const long long d = P.seg_offsets[b * 9 + tid] + (long long)P.tile_off[((long long)b * P.T + t) * 9 + tid];
+        dsto[2 * tid] = (unsigned)d;
+        dsto[2 * tid + 1] = (unsigned)((unsigned long long)d >> 32);
+    }
     __syncthreads();
 
     STAMP_DECL;
@@ -1498,8 +1505,7 @@ __global__ __launch_bounds__(64 * NW, 4) void ldati_tile_dense_kernel(LdatiParam
         }
         // where the tile's run of this bin goes; its records are ranked into O at the same phase modulo four records, so that the
         // copy-out moves whole 16-byte pieces
-        const long long dst0 = P.seg_offsets[b * 9 + c] + (long long)P.tile_off[((long long)b * P.T + t) * 9 + c];
-        const unsigned dshift = (unsigned)dst0 & 3u;
+        const unsigned dshift = dsto[2 * c] & 3u;
         uint2 *UL1 = reinterpret_cast<uint2 *>(O), *UL0 = UL1 + U1;
         unsigned *SLs = O + 2u * (U1 + U0);
         // ranks are taken in NW chunks of L = 2^lgL consecutive positions (one wave each); a record counts in its chunk's row
@@ -1614,11 +1620,12 @@ __global__ __launch_bounds__(64 * NW, 4) void ldati_tile_dense_kernel(LdatiParam
         };
         {
             const unsigned nK = (U1 + 63u) >> 6, nZ = (U0 + 63u) >> 6, nS = (Ns + 63u) >> 6, nb = nK + nZ + nS;
+            unsigned nxt = 0;
+            if (lane == 0) nxt = atomicAdd(bctr, 1u);
             for (;;) {
-                unsigned bid = 0;
-                if (lane == 0) bid = atomicAdd(bctr, 1u);
-                bid = (unsigned)__builtin_amdgcn_readfirstlane((int)bid);
+                const unsigned bid = (unsigned)__builtin_amdgcn_readfirstlane((int)nxt);
                 if (bid >= nb) break;
+                if (lane == 0) nxt = atomicAdd(bctr, 1u);        // (in flight while this batch runs)
                 if (bid < nK) {                          // the long batches first
                     if (philox) unit_batch(std::integral_constant<int, 3>{}, UL1, bid * 64u + lane, U1);
                     else unit_batch(std::integral_constant<int, 0>{}, UL1, bid * 64u + lane, U1);
@@ -1672,7 +1679,19 @@ __global__ __launch_bounds__(64 * NW, 4) void ldati_tile_dense_kernel(LdatiParam
             const unsigned sh = 12 + P.shift;
             const unsigned lo = (unsigned)wid << lgL, hi = min(N, lo + (1u << lgL));
             if (atomic_order) {                          // the rank IS what the LDS atomic returns (g_lds_order_ok)
-                for (unsigned i = lo + lane; i < hi; i += 64) {
+                // (four read -> atomic -> write chains in flight; a wave's LDS atomics execute in program order, so the ranks
+                // are still taken in position order)
+                unsigned i = lo + lane, i0 = lo;
+                for (; i0 + 256u <= hi; i0 += 256u, i += 256u) {      // (a wave-uniform bound: every lane takes the same trips)
+                    unsigned rec[4], at[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) rec[j] = S[i + 64u * j];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) at[j] = atomicAdd(&myhist[rec[j] >> sh], 1u);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) O[at[j]] = rec[j];
+                }
+                for (; i < hi; i += 64u) {
                     const unsigned rec = S[i];
                     O[atomicAdd(&myhist[rec >> sh], 1u)] = rec;
                 }
@@ -1694,6 +1713,7 @@ __global__ __launch_bounds__(64 * NW, 4) void ldati_tile_dense_kernel(LdatiParam
         if (tid == 0) *bctr = 0;
         {
             // O[dshift + i] -> dst[i]: 16-byte pieces where the piece lies inside the run, single records at its two ends
+            const long long dst0 = (long long)(((unsigned long long)dsto[2 * c + 1] << 32) | dsto[2 * c]);
             unsigned *dstq = P.temp + (dst0 - (long long)dshift);             // 16-byte aligned (temp is; dst0 - dshift is a multiple of 4 records)
             const unsigned nq = (dshift + N + 3u) >> 2;
             for (unsigned q = tid; q < nq; q += NT) {
@@ -2206,7 +2226,7 @@ __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(Ldat
     const bool atomic_order = !P.ballot_ranks && __builtin_amdgcn_readfirstlane(g_lds_order_ok) != 0;
 
     unsigned *Out = reinterpret_cast<unsigned *>(sort_smem);
-    unsigned *hist = Out + kSortThreads * K;             // [kSortWaves][bins]
+    unsigned *hist = Out + kSortThreads * K + 20;        // [kSortWaves][bins]  (Out: 20 more words, the slot phase of the emit loop)
     unsigned *ne_src = hist + kSortWaves * P.hist_bins;  // [T] per non-empty tile: source index - flat index
     unsigned *ne_info = ne_src + P.T;                    // [T] (polarity category << PB) | first pixel of the tile
     unsigned *bits = ne_info + P.T;                      // [K*8] bit i = a tile's run starts at flat index i
@@ -2323,6 +2343,11 @@ __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(Ldat
     STAMP(2);
     __syncthreads();
     STAMP(3);
+    // The packed emit loop (S5) walks SLOTS: four records per lane starting at a global record index that is a multiple of
+    // 16; record i of the group is ranked into Out[i + oshift], its slot, so that a lane's four records are one aligned
+    // 16-byte LDS read (they used to be four reads at a four-word lane stride: 8-way bank conflicts, and an index clamp each)
+    const long long g0 = P.seg_offsets[seg] + bofs[bk0];                  // first global record
+    const unsigned oshift = PACKED ? (unsigned)(g0 - (((g0 >> 2) & ~3ll) << 2)) : 0u;      // in [0, 15]
     // S3: bin-major, wave-minor exclusive scan
     {
         const int per = (bins + kSortThreads - 1) / kSortThreads;
@@ -2332,7 +2357,7 @@ __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(Ldat
 #pragma unroll
             for (int w = 0; w < kSortWaves; ++w) s += hist[w * bins + q];
         unsigned tot;
-        unsigned run = block_excl_scan<kSortWaves>(s, part, &tot);
+        unsigned run = block_excl_scan<kSortWaves>(s, part, &tot) + oshift;
         for (int q = b0; q < b1; ++q) {
 #pragma unroll
             for (int w = 0; w < kSortWaves; ++w) {
@@ -2373,7 +2398,6 @@ __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(Ldat
     __syncthreads();
     STAMP(6);
     // S5: decode and write the final records
-    const long long g0 = P.seg_offsets[seg] + bofs[bk0];                  // first global record
     const long long tbase = P.kbase[c] + (long long)key0 +
                             (P.frame_ts_add ? P.frame_ts_add[b] : 0);
     const unsigned pmask = (1u << P.PB) - 1u;
@@ -2400,7 +2424,6 @@ __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(Ldat
     const long long gN = g0 + N;
     const long long G0 = (g0 >> 2) & ~3ll, G1 = (gN + 3) >> 2;         // G0 % 4 == 0: 52*G0 % 16 == 0
     const long long B0 = 13 * g0, B1 = 13 * gN;                         // this bucket's bytes
-    const int i_base = (int)(4 * G0 - g0);                             // record index of the first slot (in [-15, 0])
     const int nG_all = (int)(G1 - G0);                                 // groups of four records this bucket touches
     // one copy of the loop per division form (the kernel is bound by instruction issue: a uniform three-way branch per
     // record costs more than the division it selects)
@@ -2414,12 +2437,12 @@ __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(Ldat
             const int g = gw0 + lane;
             if (g < nG_all) {
                 unsigned A[4], Bh[4], C[4], D[4];
-                const int i0 = i_base + 4 * g;
+                // (slots outside the bucket hold whatever the LDS held: their bytes are never copied out)
+                const uint4 r4 = reinterpret_cast<const uint4 *>(Out)[g];
+                const unsigned rr[4] = {r4.x, r4.y, r4.z, r4.w};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    // (slots outside the bucket repeat one of its end records: their bytes are never copied out)
-                    const int i = i0 + q, ic = i < 0 ? 0 : (i >= (int)N ? (int)N - 1 : i);
-                    const unsigned r = Out[ic];
+                    const unsigned r = rr[q];
                     const unsigned px = r & pmask, cat = (r >> P.PB) & 3u, fine = r >> (P.PB + 2);
                     const unsigned yy = MODE == 0 ? div_tiny(px, rcpW) : MODE == 1 ? div_small(px, W, rcpW) : px / W;
                     const long long tq = tbase + fine;
@@ -2730,7 +2753,7 @@ int tile_threads_choice(int64_t max_tile_events) {
 
 // dynamic LDS of ldati_tile_dense_kernel<NW>: S [capA] | O [capA + 2] | hist [NW][NB] | wave totals, scan partials, batch counter
 size_t dense_tile_lds(int capA, int NB, int NW) {
-    return ((size_t)2 * capA + 8 + (size_t)NW * NB + 3 * NW + NW + 1 + 1 + 2) * 4;
+    return ((size_t)2 * capA + 8 + (size_t)NW * NB + 3 * NW + NW + 1 + 2 + 18 + 2) * 4;
 }
 
 // geometry and capacities of the two-level path
@@ -2788,7 +2811,7 @@ Plan make_plan(const HostScalars &h, int B, int H, int W, int64_t total_events,
     const size_t hist_bins = bins > 4 * (size_t)kMaxSpanKeys ? bins : 4 * (size_t)kMaxSpanKeys;
     const size_t tables = kSortWaves * hist_bins * 4 + (size_t)(2 * p.T) * 4 + (size_t)(2 * (p.cap2 / 32)) * 4 + (kSortWaves + 1) * 4;
     const size_t stage = (size_t)kSortThreads * 13 * 4;
-    p.lds_sort = (size_t)p.cap2 * 4 + (tables > stage ? tables : stage);
+    p.lds_sort = (size_t)(p.cap2 + 20) * 4 + (tables > stage ? tables : stage);
     // bofs | groups [B*9*NB] | big_list [B*9*NB] | ngroups [B*9] | seg_flag [B*9] | status [4] (status, nbig) |
     // records (u32) | roff (u16) | gruns (u32 [B*9][NB][Tp])
     p.bytes = (p.n_bkt + 2 * (size_t)B * 9 * p.NB + 2 * (size_t)B * 9 + 4 +
