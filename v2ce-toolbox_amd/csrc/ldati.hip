@@ -50,6 +50,7 @@ constexpr int kCountThreads = 512;
 constexpr int kMaxTiles = 512;        // tiles per frame (both polarities) the bucket sort indexes
 constexpr int kMaxNB = 512;           // coarse buckets per segment
 constexpr int kMaxShift = 8;          // log2 of the widest coarse bucket
+constexpr long long kSortSmallSegment = 50000;   // densest segment up to which the sort runs 128-thread workgroups
 constexpr int kMaxSpanKeys = 128;     // timestamps a sort group spans at most (its histogram has 4x as many bins)
 constexpr int kCapTile = 15360;       // events of one (tile, bin) the tile pass can hold in LDS
 constexpr int kSparseCap = 8192;      // events of one tile over all nine bins the sparse tile kernel holds
@@ -57,8 +58,7 @@ constexpr int kSparseThreads = 512;
 constexpr size_t kSparseLds = (size_t)(2 * kSparseCap + kSparseThreads * 5 + 34) * 4 + 9 * 8 + (kSparseThreads / 64) * 10 * 4;
 constexpr int kSlopeM = 31;            // slope table (g_slope_tab): |count difference| <= kSlopeM, count <= kSlopeM; else computed
 constexpr int kSlopeTab = (2 * kSlopeM + 1) * (kSlopeM + 1);
-constexpr int kSortThreads = 256;
-constexpr int kSortWaves = kSortThreads / 64;
+// sort workgroups: 256 threads (dense segments) or 128 (make_plan)
 
 struct LdatiParams {
     const float *vox;
@@ -2208,8 +2208,9 @@ __global__ __launch_bounds__(512) void ldati_bucket_scan_kernel(LdatiParams P) {
 // ---------------------------------------------------------------------------------------------
 extern __shared__ __attribute__((aligned(16))) unsigned char sort_smem[];
 
-template <bool PACKED, int K>
+template <bool PACKED, int K, int kSortThreads>
 __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(LdatiParams P) {
+    constexpr int kSortWaves = kSortThreads / 64;
     const int seg = blockIdx.y;
     if (blockIdx.x >= P.ngroups[seg]) return;            // uniform per workgroup (flagged segments have no groups; empty
                                                          // workgroups cost nothing measurable: a compact group list changed nothing)
@@ -2230,10 +2231,10 @@ __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(Ldat
     unsigned *ne_src = hist + kSortWaves * P.hist_bins;  // [T] per non-empty tile: source index - flat index
     unsigned *ne_info = ne_src + P.T;                    // [T] (polarity category << PB) | first pixel of the tile
     unsigned *bits = ne_info + P.T;                      // [K*8] bit i = a tile's run starts at flat index i
-    unsigned *wpre = bits + K * 8;                       // [K*8] run starts below each 32-index word
-    unsigned *part = wpre + K * 8;                       // [kSortWaves + 1]
+    constexpr int kWords = kSortThreads * K / 32;        // words of the run-start bit table
+    unsigned *wpre = bits + kWords;                      // [kWords] run starts below each 32-index word
+    unsigned *part = wpre + kWords;                      // [kSortWaves + 1]
     unsigned *stage = hist;                              // [256 * 13], 16-byte aligned; aliases the tables (dead in S5)
-    constexpr int kWords = K * 8;                        // 256*K / 32
 
     STAMP_DECL;
     // S0 (wave 0; the other waves clear the histograms meanwhile): this bucket's run in every tile,
@@ -2287,9 +2288,11 @@ __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(Ldat
         }
         };
         if (P.T <= 128) setup(std::integral_constant<int, 2>{}); else setup(std::integral_constant<int, kMaxTiles / 64>{});
-    } else {
+    } else if (kSortWaves > 1) {
         for (int i = tid - 64; i < kSortWaves * bins; i += kSortThreads - 64) hist[i] = 0;
     }
+    if (kSortWaves == 1)
+        for (int i = tid; i < bins; i += 64) hist[i] = 0;
     __syncthreads();
     STAMP(0);
     // S1: gather.  The bucket's records are the tiles' runs in tile order (negative tiles first,
@@ -2758,7 +2761,7 @@ size_t dense_tile_lds(int capA, int NB, int NW) {
 
 // geometry and capacities of the two-level path
 struct Plan {
-    int tpp, T, Tp, shift, NB, nb1, PB, capA, cap2, tbits, tile_threads, span;
+    int tpp, T, Tp, shift, NB, nb1, PB, capA, cap2, tbits, tile_threads, span, sort_threads;
     size_t n_tab, n_bkt;                 // entries of roff; of bofs
     size_t lds_tile, lds_sort;
     size_t bytes;                        // workspace
@@ -2779,6 +2782,14 @@ Plan make_plan(const HostScalars &h, int B, int H, int W, int64_t total_events,
     // put more than cap2/20 records into an AVERAGE bucket (on real UNet output the fullest bucket of a
     // segment holds ~20x the average: timestamps crowd at the end of a bin), never finer than kMaxNB
     // buckets allow.  The sort groups (bucket scan kernel) merge consecutive buckets up to cap2 records.
+    // sort workgroups of 128 threads (3072 records) for segments of real UNet output, 256 (6144) for dense ones: measured on the
+    // e2e step 146 -> 99 us, on the stress chunk 432 -> 490 us (V2CE_LDATI_SORT_THREADS overrides; kernel A/B runs)
+    {
+        static const int forced = [] { const char *e = getenv("V2CE_LDATI_SORT_THREADS"); const int v = e ? atoi(e) : 0; return v == 64 || v == 128 || v == 256 ? v : 0; }();
+        p.sort_threads = forced ? forced : (max_segment_events > kSortSmallSegment ? 256 : 128);
+    }
+    const int kSortThreads = max_segment_events > 2048 ? p.sort_threads : 256, kSortWaves = kSortThreads / 64;
+    p.sort_threads = kSortThreads;
     p.cap2 = max_segment_events > 2048 ? kSortThreads * 24 : kSortThreads * 8;
     int shift = 4;
     while (shift > 0 && (double)max_segment_events * (double)(1 << shift) / (double)h.NK > p.cap2 / 20.0) --shift;
@@ -3252,13 +3263,15 @@ int emit_impl(const float *vox, int B, int H, int W, double fps, double t0,
             if (int rc = launch_tile_pass()) return rc;
         hipLaunchKernelGGL(ldati_bucket_scan_kernel, dim3(B * 9), dim3(512), 0, st, P);
         {
-            auto sort_kernel = packed ? (pl.cap2 > kSortThreads * 8 ? ldati_bucket_sort_kernel<true, 24>
-                                                                     : ldati_bucket_sort_kernel<true, 8>)
-                                      : (pl.cap2 > kSortThreads * 8 ? ldati_bucket_sort_kernel<false, 24>
-                                                                     : ldati_bucket_sort_kernel<false, 8>);
+            const bool k24 = pl.cap2 > pl.sort_threads * 8;
+            const int sth = pl.sort_threads;
+            auto sort_kernel = packed ? (k24 ? (sth == 64 ? ldati_bucket_sort_kernel<true, 24, 64> : sth == 128 ? ldati_bucket_sort_kernel<true, 24, 128> : ldati_bucket_sort_kernel<true, 24, 256>)
+                                             : ldati_bucket_sort_kernel<true, 8, 256>)
+                                      : (k24 ? (sth == 64 ? ldati_bucket_sort_kernel<false, 24, 64> : sth == 128 ? ldati_bucket_sort_kernel<false, 24, 128> : ldati_bucket_sort_kernel<false, 24, 256>)
+                                             : ldati_bucket_sort_kernel<false, 8, 256>);
             V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(sort_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_sort));
-            hipLaunchKernelGGL(sort_kernel, dim3(pl.NB, B * 9), dim3(kSortThreads), pl.lds_sort, st, P);
+            hipLaunchKernelGGL(sort_kernel, dim3(pl.NB, B * 9), dim3(pl.sort_threads), pl.lds_sort, st, P);
         }
         if (packed) hipLaunchKernelGGL(ldati_big_bucket_kernel<true>, dim3(256), dim3(256), 0, st, P);
         else hipLaunchKernelGGL(ldati_big_bucket_kernel<false>, dim3(256), dim3(256), 0, st, P);
