@@ -50,7 +50,6 @@ constexpr int kCountThreads = 512;
 constexpr int kMaxTiles = 512;        // tiles per frame (both polarities) the bucket sort indexes
 constexpr int kMaxNB = 512;           // coarse buckets per segment
 constexpr int kMaxShift = 8;          // log2 of the widest coarse bucket
-constexpr long long kSortSmallSegment = 50000;   // densest segment up to which the sort runs 128-thread workgroups
 constexpr int kMaxSpanKeys = 128;     // timestamps a sort group spans at most (its histogram has 4x as many bins)
 constexpr int kCapTile = 15360;       // events of one (tile, bin) the tile pass can hold in LDS
 constexpr int kSparseCap = 8192;      // events of one tile over all nine bins the sparse tile kernel holds
@@ -1340,6 +1339,9 @@ __device__ __forceinline__ void philox4_b3(unsigned long long seed, unsigned pix
                                            unsigned (&out)[4]) {
     unsigned c0 = pixel, c1 = jb, c2 = pc, c3 = frame;
     unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+    // (the key schedule is recomputed here, two scalar adds per round: hoisted out of the caller's loops its twenty values
+    // live in SGPRs the kernel does not have -- they were spilled to VGPR lanes and read back with v_readlane every round)
+    asm volatile("" : "+s"(k0), "+s"(k1));
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
@@ -1361,8 +1363,11 @@ __device__ __forceinline__ int slope_index(int n_l, int n_c, int n_r, int c) {
     return -1;
 }
 
-template <int NW>
-__global__ __launch_bounds__(64 * NW, 4) void ldati_tile_dense_kernel(LdatiParams P) {   // 4 waves per SIMD: two 512-thread workgroups per CU
+// FAST: every run-time switch of the common call is known to be on (Philox draws, the checked fast divisions, the slope table,
+// LDS-atomic ranks, 16-byte aligned planes, 'slope'): the switches cost SGPRs the kernel does not have (they were spilled to VGPR
+// lanes and read back with v_readlane), and their untaken sides cost code
+template <int NW, bool FAST>
+__device__ __forceinline__ void dense_tile_body(const LdatiParams &P) {
     constexpr int NT = 64 * NW, PPT = kTilePix / NT, WPX = 64 * PPT;
     static_assert(PPT == 4 || PPT == 2, "a lane owns 2 or 4 consecutive pixels");
     const int t = blockIdx.x, b = blockIdx.y;
@@ -1376,14 +1381,14 @@ __global__ __launch_bounds__(64 * NW, 4) void ldati_tile_dense_kernel(LdatiParam
     const int pidx = t < P.tpp ? 1 : 0;
     const int x0 = (t < P.tpp ? t : t - P.tpp) * kTilePix;
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool atomic_order = !P.ballot_ranks && __builtin_amdgcn_readfirstlane(g_lds_order_ok) != 0;
-    const bool slot_ok = P.fast_slot >= 0 &&
-                         __builtin_amdgcn_readfirstlane((int)g_fastdiv[P.fast_slot >= 0 ? P.fast_slot : 0].fps_bits) == (int)__float_as_uint(P.FPS);
-    const bool philox = P.rng_mode == V2CE_RNG_PHILOX;
-    const bool fast_k0 = slot_ok && philox && __builtin_amdgcn_readfirstlane(g_fastdiv[P.fast_slot].ok) != 0;
+    const bool atomic_order = FAST || (!P.ballot_ranks && __builtin_amdgcn_readfirstlane(g_lds_order_ok) != 0);
+    const bool slot_ok = FAST || (P.fast_slot >= 0 &&
+                         __builtin_amdgcn_readfirstlane((int)g_fastdiv[P.fast_slot >= 0 ? P.fast_slot : 0].fps_bits) == (int)__float_as_uint(P.FPS));
+    const bool philox = FAST || P.rng_mode == V2CE_RNG_PHILOX;
+    const bool fast_k0 = FAST || (slot_ok && philox && __builtin_amdgcn_readfirstlane(g_fastdiv[P.fast_slot].ok) != 0);
     // (a table that another stream is still filling: every multi-event voxel takes the owner-lane path once)
-    const bool tab_ok = slot_ok && __builtin_amdgcn_readfirstlane(g_fastdiv[P.fast_slot].tab_ready) != 0;
-    const bool fast_s = slot_ok && P.ts32 && __builtin_amdgcn_readfirstlane(g_fastdiv[P.fast_slot].ok64) != 0;   // single_key's fast form
+    const bool tab_ok = FAST || (slot_ok && __builtin_amdgcn_readfirstlane(g_fastdiv[P.fast_slot].tab_ready) != 0);
+    const bool fast_s = FAST || (slot_ok && P.ts32 && __builtin_amdgcn_readfirstlane(g_fastdiv[P.fast_slot].ok64) != 0);   // single_key's fast form
     const float2 *stab = g_slope_tab[P.fast_slot >= 0 ? P.fast_slot : 0];
 
     unsigned *S = reinterpret_cast<unsigned *>(tile_smem);
@@ -1400,7 +1405,7 @@ __global__ __launch_bounds__(64 * NW, 4) void ldati_tile_dense_kernel(LdatiParam
     const unsigned frame = (unsigned)(P.frame_base + b);
     const int lpx0 = wid * WPX + lane * PPT;           // the lane's PPT consecutive local pixels: lpx0 + q
     const int gpx0 = x0 + lpx0;
-    const bool vec = (P.HW & 3) == 0;                  // every plane 16-byte aligned: one load per plane and lane
+    const bool vec = FAST || (P.HW & 3) == 0;          // every plane 16-byte aligned: one load per plane and lane
     const float eps = 1e-6f;
 
     // one plane's voxels of the lane's pixels (zero past the image)
@@ -1461,7 +1466,7 @@ __global__ __launch_bounds__(64 * NW, 4) void ldati_tile_dense_kernel(LdatiParam
         // the slope-table index rides in bits 3..13
         unsigned cls[PPT], aex[PPT], uex[PPT];
         unsigned At = 0, Ut = 0;
-        const bool multi_on = P.strategy != V2CE_STRATEGY_NONE, edge = c == 0 || c == 8;
+        const bool multi_on = FAST || P.strategy != V2CE_STRATEGY_NONE, edge = c == 0 || c == 8;
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
             const int n = ncur[q];                                          // (a pixel past the image holds zeros: no event)
@@ -1746,6 +1751,20 @@ __global__ __launch_bounds__(64 * NW, 4) void ldati_tile_dense_kernel(LdatiParam
     }
     STAMP(0);
     STAMP_FLUSH(0, 10);
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 4) void ldati_tile_dense_kernel(LdatiParams P) {   // 4 waves per SIMD: two 512-thread workgroups per CU
+    bool fast = P.fast_slot >= 0 && P.rng_mode == V2CE_RNG_PHILOX && !P.ballot_ranks && P.ts32 && (P.HW & 3) == 0 &&
+                P.strategy != V2CE_STRATEGY_NONE;
+    if (fast) {
+        const FastDiv &f = g_fastdiv[P.fast_slot];
+        fast = __builtin_amdgcn_readfirstlane((int)f.fps_bits) == (int)__float_as_uint(P.FPS) && __builtin_amdgcn_readfirstlane(f.ok) != 0 &&
+               __builtin_amdgcn_readfirstlane(f.tab_ready) != 0 && __builtin_amdgcn_readfirstlane(f.ok64) != 0 &&
+               __builtin_amdgcn_readfirstlane(g_lds_order_ok) != 0;
+    }
+    if (fast) dense_tile_body<NW, true>(P);
+    else dense_tile_body<NW, false>(P);
 }
 
 // Exhaustive check of the dense kernel's exact-math helpers (v2ce_ldati_selfcheck; a test, never on the product path):
@@ -2783,10 +2802,13 @@ Plan make_plan(const HostScalars &h, int B, int H, int W, int64_t total_events,
     // segment holds ~20x the average: timestamps crowd at the end of a bin), never finer than kMaxNB
     // buckets allow.  The sort groups (bucket scan kernel) merge consecutive buckets up to cap2 records.
     // sort workgroups of 128 threads (3072 records) for segments of real UNet output, 256 (6144) for dense ones: measured on the
-    // e2e step 146 -> 99 us, on the stress chunk 432 -> 490 us (V2CE_LDATI_SORT_THREADS overrides; kernel A/B runs)
+    // e2e step (densest segment 85 K events) 151 -> 98 us, sparse bench 93 -> 73 us, on the stress chunk 432 -> 490 us, pano sort
+    // -66 us but bucket scan +80 us (V2CE_LDATI_SORT_THREADS overrides; kernel A/B runs)
     {
         static const int forced = [] { const char *e = getenv("V2CE_LDATI_SORT_THREADS"); const int v = e ? atoi(e) : 0; return v == 64 || v == 128 || v == 256 ? v : 0; }();
-        p.sort_threads = forced ? forced : (max_segment_events > kSortSmallSegment ? 256 : 128);
+        // (the densest segment spread evenly over its keys: a group of kMaxSpanKeys keys then holds at most 1.5 x 3072 records --
+        // groups of such segments are closed by their key span, not by their record count)
+        p.sort_threads = forced ? forced : (max_segment_events * kMaxSpanKeys > 4608 * h.NK ? 256 : 128);
     }
     const int kSortThreads = max_segment_events > 2048 ? p.sort_threads : 256, kSortWaves = kSortThreads / 64;
     p.sort_threads = kSortThreads;
@@ -3239,8 +3261,8 @@ int emit_impl(const float *vox, int B, int H, int W, double fps, double t0,
             const FusedLayout F = make_fused_layout(h, o, B, H, W, fused_seg_hint);
             fused = F.ok && fused_ws_bytes >= F.bytes && fused_tile_max <= kSparseCap && F.p0.shift == pl.shift && F.p0.NB == pl.NB && F.p0.T == pl.T;
             if (getenv("V2CE_LDATI_DEBUG"))
-                fprintf(stderr, "v2ce_ldati_emit_fused: fused=%d ok=%d bytes %zu/%zu tile_max=%lld shift %d/%d NB %d/%d T %d/%d\n", (int)fused, (int)F.ok,
-                        fused_ws_bytes, F.bytes, (long long)fused_tile_max, F.p0.shift, pl.shift, F.p0.NB, pl.NB, F.p0.T, pl.T);
+                fprintf(stderr, "v2ce_ldati_emit_fused: fused=%d ok=%d bytes %zu/%zu tile_max=%lld shift %d/%d NB %d/%d T %d/%d max_segment %lld sort threads %d cap2 %d\n", (int)fused, (int)F.ok,
+                        fused_ws_bytes, F.bytes, (long long)fused_tile_max, F.p0.shift, pl.shift, F.p0.NB, pl.NB, F.p0.T, pl.T, (long long)max_segment_events, pl.sort_threads, pl.cap2);
             if (fused) {
                 const unsigned char *fb = static_cast<const unsigned char *>(fused_ws);
                 P.fused_status = reinterpret_cast<const int *>(fb);
