@@ -644,10 +644,8 @@ __global__ __launch_bounds__(kCountThreads) void ldati_count_tiles_kernel(
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
-        int v = cnt[i];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        if (lane == 0) red[wid][i] = v;
+        const unsigned v = wave_incl_scan((unsigned)cnt[i], lane);       // (DPP: no LDS crossbar traffic)
+        if (lane == 63) red[wid][i] = (int)v;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -665,7 +663,8 @@ __global__ __launch_bounds__(kCountThreads) void ldati_count_tiles_kernel(
         int m = 0;
 #pragma unroll
         for (int w = 0; w < kCountThreads / 64; ++w) m = red[w][9] > m ? red[w][9] : m;
-        if (m > 0) atomicMax(&stats[0], (unsigned long long)m);
+        // (a plain read first: after the first few tiles the maximum rarely grows, and 2 000 same-address atomics serialise)
+        if (m > 0 && (unsigned long long)m > *reinterpret_cast<volatile unsigned long long *>(&stats[0])) atomicMax(&stats[0], (unsigned long long)m);
     }
 }
 
