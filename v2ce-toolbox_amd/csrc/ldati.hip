@@ -1393,7 +1393,7 @@ __device__ __forceinline__ void dense_tile_body(const LdatiParams &P) {
     unsigned *S = reinterpret_cast<unsigned *>(tile_smem);
     unsigned *O = S + P.capA;
     unsigned *hist = O + P.capA + 8;                    // [NW][NB]: row r counts the records at positions [r L, (r + 1) L)
-    unsigned *part = hist + NW * P.NB;                  // [3][NW] wave totals (events | singles, k == 0 units << 16 | k != 0 units)
+    unsigned *part = hist + NW * P.NB;                  // [3][NW] wave totals: events | singles << 16, k == 0 units | k != 0 units << 16 (third row unused)
     unsigned *spart = part + 3 * NW;                    // [NW + 1] scan partials
     unsigned *bctr = spart + NW + 1;                    // the next batch of the timestamp phase
     unsigned *dsto = bctr + 2;                          // [9][2]: where the tile's run of bin c starts in records[] (loaded once: a
@@ -1486,8 +1486,7 @@ __device__ __forceinline__ void dense_tile_body(const LdatiParams &P) {
         const unsigned iA = wave_incl_scan(At, lane), iU = wave_incl_scan(Ut, lane);
         const unsigned baseA = iA - At, baseU = iU - Ut;
         const unsigned runA = (unsigned)__builtin_amdgcn_readlane((int)iA, 63), runU = (unsigned)__builtin_amdgcn_readlane((int)iU, 63);
-        const unsigned evW = runA & 0xFFFFu, sW = runA >> 16, u0W = runU & 0xFFFFu, u1W = runU >> 16;
-        if (lane == 0) { part[wid] = evW; part[NW + wid] = sW | (u0W << 16); part[2 * NW + wid] = u1W; }
+        if (lane == 0) { part[wid] = runA; part[NW + wid] = runU; }      // (events | singles << 16), (k == 0 units | k != 0 units << 16)
         __syncthreads();                                 // A: wave totals; O (the previous bin's run) is free again
         STAMP(1);
         // Work lists of the WORKGROUP in O (2 (U1 + U0) + Ns <= N words): k != 0 units | k == 0 units | singles, each in
@@ -1495,17 +1494,14 @@ __device__ __forceinline__ void dense_tile_body(const LdatiParams &P) {
         // idle only in the last batch of a class (per-wave lists left 38 % of the VALU lanes idle: r04_j counters)
         unsigned sbase, N, sS, sU0, sU1, Ns, U0, U1;
         {
-            const unsigned v0 = lane < NW ? part[lane] : 0u, v1 = lane < NW ? part[NW + lane] : 0u, v2 = lane < NW ? part[2 * NW + lane] : 0u;
-            const unsigned p0 = wave_incl_scan(v0, lane), p1 = wave_incl_scan(v1 & 0xFFFFu, lane);
-            const unsigned p2 = wave_incl_scan(v1 >> 16, lane), p3 = wave_incl_scan(v2, lane);
-            N = (unsigned)__builtin_amdgcn_readlane((int)p0, NW - 1);
-            Ns = (unsigned)__builtin_amdgcn_readlane((int)p1, NW - 1);
-            U0 = (unsigned)__builtin_amdgcn_readlane((int)p2, NW - 1);
-            U1 = (unsigned)__builtin_amdgcn_readlane((int)p3, NW - 1);
-            sbase = wid ? (unsigned)__builtin_amdgcn_readlane((int)p0, wid - 1) : 0u;
-            sS = wid ? (unsigned)__builtin_amdgcn_readlane((int)p1, wid - 1) : 0u;
-            sU0 = wid ? (unsigned)__builtin_amdgcn_readlane((int)p2, wid - 1) : 0u;
-            sU1 = wid ? (unsigned)__builtin_amdgcn_readlane((int)p3, wid - 1) : 0u;
+            // two packed scans (every total is below 2^16: a (tile, bin) holds at most kCapTile records)
+            const unsigned v0 = lane < NW ? part[lane] : 0u, v1 = lane < NW ? part[NW + lane] : 0u;
+            const unsigned p0 = wave_incl_scan(v0, lane), p1 = wave_incl_scan(v1, lane);
+            const unsigned tA = (unsigned)__builtin_amdgcn_readlane((int)p0, NW - 1), tU = (unsigned)__builtin_amdgcn_readlane((int)p1, NW - 1);
+            const unsigned bA = wid ? (unsigned)__builtin_amdgcn_readlane((int)p0, wid - 1) : 0u;
+            const unsigned bU = wid ? (unsigned)__builtin_amdgcn_readlane((int)p1, wid - 1) : 0u;
+            N = tA & 0xFFFFu; Ns = tA >> 16; U0 = tU & 0xFFFFu; U1 = tU >> 16;
+            sbase = bA & 0xFFFFu; sS = bA >> 16; sU0 = bU & 0xFFFFu; sU1 = bU >> 16;
         }
         // where the tile's run of this bin goes; its records are ranked into O at the same phase modulo four records, so that the
         // copy-out moves whole 16-byte pieces
@@ -1551,7 +1547,7 @@ __device__ __forceinline__ void dense_tile_body(const LdatiParams &P) {
                     const unsigned key = multi_key(k, bb, u, offt_c, kbase_c, P, fast_k0);
                     const unsigned sp = pos + (unsigned)j;
                     S[sp] = (key << 12) | (1u << kLocalBits) | local;
-                    atomicAdd(&hist[(sp >> lgL) * (unsigned)P.NB + (key >> P.shift)], 1u);
+                    atomicAdd(&hist[__umul24(sp >> lgL, (unsigned)P.NB) + (key >> P.shift)], 1u);
                 }
             }
         }
@@ -1560,7 +1556,7 @@ __device__ __forceinline__ void dense_tile_body(const LdatiParams &P) {
         // ---- D3: timestamps, once; batches of 64 list entries, handed out through an LDS counter --------------------
         auto put = [&](unsigned sp, unsigned rec, unsigned key) {
             S[sp] = rec;
-            atomicAdd(&hist[(sp >> lgL) * (unsigned)P.NB + (key >> P.shift)], 1u);
+            atomicAdd(&hist[__umul24(sp >> lgL, (unsigned)P.NB) + (key >> P.shift)], 1u);
         };
         auto single_batch = [&](unsigned i) {                // (called by whole waves: single_key votes)
             const bool has = i < Ns;
@@ -1657,7 +1653,7 @@ __device__ __forceinline__ void dense_tile_body(const LdatiParams &P) {
             unsigned run = 0;
             if (bkt < P.NB) {
 #pragma unroll
-                for (int w = 0; w < NW; ++w) v[w] = w < nr ? hist[(r0 + w) * P.NB + bkt] : 0u;
+                for (int w = 0; w < NW; ++w) v[w] = w < nr ? hist[__umul24((unsigned)(r0 + w), (unsigned)P.NB) + bkt] : 0u;
 #pragma unroll
                 for (int w = 0; w < NW; ++w) {
                     const unsigned x = v[w];
@@ -1670,7 +1666,7 @@ __device__ __forceinline__ void dense_tile_body(const LdatiParams &P) {
             if (bkt < P.NB) {
 #pragma unroll
                 for (int w = 0; w < NW; ++w)
-                    if (w < nr) hist[(r0 + w) * P.NB + bkt] = v[w] + boff + dshift;
+                    if (w < nr) hist[__umul24((unsigned)(r0 + w), (unsigned)P.NB) + bkt] = v[w] + boff + dshift;
             }
             unsigned short *row = P.roff + ((long long)(b * 9 + c) * P.T + t) * (P.NB + 1);
             if (bkt < P.NB && r0 == 0) row[bkt] = (unsigned short)boff;
@@ -1985,7 +1981,7 @@ __global__ __launch_bounds__(kSparseThreads) void ldati_tile_sparse_kernel(Ldati
     __syncthreads();
     // ---- 3: timestamps -> records, cell histogram
     auto put = [&](unsigned idx, unsigned c, unsigned key, unsigned multi, unsigned local) {
-        const unsigned ck = c * NKS + key;
+        const unsigned ck = __umul24(c, NKS) + key;       // (c < 9, NKS < 2^16: the 24-bit multiply issues at full rate)
         const unsigned g = ck >> P.shift;
         atomicAdd(&hist[g >> 1], 1u << ((g & 1u) * 16u));
         S[idx] = (ck << 12) | (multi << kLocalBits) | local;
@@ -2469,7 +2465,8 @@ __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(Ldat
                     const long long tq = tbase + fine;
                     A[q] = (unsigned)tq;
                     Bh[q] = (unsigned)((unsigned long long)tq >> 32);
-                    C[q] = ((px - yy * W) & 0xFFFFu) | (yy << 16);
+                    // (v_mul_lo_u32 issues at a quarter of the rate of v_mul_u32_u24; px < 2^24 in the two float-division modes)
+                    C[q] = ((px - (MODE == 2 ? yy * W : __umul24(yy, W))) & 0xFFFFu) | (yy << 16);
                     D[q] = cat >> 1;
                 }
                 unsigned *d = stage + tid * 13;
