@@ -283,6 +283,36 @@ def rank_mode():
     return m.value
 
 
+def test_sort_workgroup_sizes_equal(gold_dir, monkeypatch):
+    """The bucket sort runs workgroups of 128 threads (3072 records) on segments of real UNet output and of 256 (6144) on
+    dense ones (make_plan's rule); V2CE_LDATI_SORT_THREADS forces 64 / 128 / 256: each size, on a sparse, a mid-density and a
+    stress frame at full size and on the G4 stress frame, gives the bytes of the default rule, and G4 keeps the reference's SHA."""
+    def all_sizes(run):
+        monkeypatch.delenv("V2CE_LDATI_SORT_THREADS", raising=False)
+        ref = run().packed().cpu().numpy().tobytes()
+        for th in ("64", "128", "256"):
+            monkeypatch.setenv("V2CE_LDATI_SORT_THREADS", th)
+            assert run().packed().cpu().numpy().tobytes() == ref, th
+        monkeypatch.delenv("V2CE_LDATI_SORT_THREADS")
+        return ref
+
+    for regime, scale in (("sparse", 1.0), ("frac", 1.0), ("stress", 1.0 / 3.0), ("stress", 1.0)):
+        vox = (synth.synthetic_voxels(2, 260, 346, seed=91, regime=regime) * np.float32(scale)).astype(np.float32)
+        all_sizes(lambda: hip_events(vox, seed=13))
+    meta = json.load(open(os.path.join(gold_dir, "ldati_g4.json")))
+    H, W = meta["H"], meta["W"]
+    vox4 = synth.synthetic_voxels(1, H, W, seed=meta["vox_seed"], regime=meta["vox_regime"])
+    mt = np.random.MT19937()
+    mt._legacy_seeding(meta["torch_seed"])
+    n = 2 * 9 * H * W * meta["max_n"]
+    u4 = ((mt.random_raw(n).astype(np.uint32) & 0xFFFFFF).astype(np.float32) * np.float32(2.0 ** -24)).reshape(1, 2, 9, H, W, meta["max_n"])
+    for th in ("128", "256"):
+        monkeypatch.setenv("V2CE_LDATI_SORT_THREADS", th)
+        ev = hip_events(vox4, meta["fps"], meta["t0"], uniforms=u4)
+        assert hashlib.sha256(ev.to_recarrays()[0].tobytes()).hexdigest() == meta["sha256_packed_events"]
+    monkeypatch.delenv("V2CE_LDATI_SORT_THREADS")
+
+
 def test_ballot_rank_fallback_forced(gold_dir, monkeypatch):
     """The ballot match-any ranks -- what the tile pass, the bucket sort and the big-bucket kernel fall back to on a
     device whose LDS atomics fail the lane-order probe -- forced with V2CE_LDATI_NO_ATOMIC_ORDER=1 (the probe passes on

@@ -2801,7 +2801,8 @@ Plan make_plan(const HostScalars &h, int B, int H, int W, int64_t total_events,
     // e2e step (densest segment 85 K events) 151 -> 98 us, sparse bench 93 -> 73 us, on the stress chunk 432 -> 490 us, pano sort
     // -66 us but bucket scan +80 us (V2CE_LDATI_SORT_THREADS overrides; kernel A/B runs)
     {
-        static const int forced = [] { const char *e = getenv("V2CE_LDATI_SORT_THREADS"); const int v = e ? atoi(e) : 0; return v == 64 || v == 128 || v == 256 ? v : 0; }();
+        const char *e = getenv("V2CE_LDATI_SORT_THREADS");            // (read per plan: tests switch it inside one process)
+        const int ev = e ? atoi(e) : 0, forced = ev == 64 || ev == 128 || ev == 256 ? ev : 0;
         // (the densest segment spread evenly over its keys: a group of kMaxSpanKeys keys then holds at most 1.5 x 3072 records --
         // groups of such segments are closed by their key span, not by their record count)
         p.sort_threads = forced ? forced : (max_segment_events * kMaxSpanKeys > 4608 * h.NK ? 256 : 128);
