@@ -41,6 +41,10 @@ v = np.array(buf[:], dtype=np.float64)
 names_t = ["loop head / advance / loads", "D1 classify + scan + barrier A", "D2 work lists + barrier A2", "(unused)", "D3 timestamp batches",
            "barrier B", "D4 bucket scan + run table", "D5 rank", "barrier D", "copy-out"]
 names_s = ["S0 setup", "S1 gather", "S2 widen+hist", "barrier", "S3 scan", "S4 rank", "barrier", "S5 emit"]
+names_sp = ["1 loads + LDS clear + barrier", "2a relocate + classify + list append", "fused count: scans + barrier + reduce", "2b lists to registers + barrier",
+            "3 singles", "3 multi-event pairs + barrier", "4 cell scan + barrier", "placement + barrier", "5 in-cell order + barrier", "6 runs + run table"]
+if regime in ("e2e", "sparse"):
+    names_t = names_sp                     # every tile takes ldati_tile_sparse_kernel<true> there (same ten slots)
 for title, base, names in (("tile pass (wave 0 of every workgroup)", 0, names_t), ("bucket sort", 16, names_s)):
     tot = v[base:base + len(names)].sum()
     print(title)

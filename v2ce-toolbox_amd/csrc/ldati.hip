@@ -1856,6 +1856,7 @@ __global__ __launch_bounds__(kSparseThreads) void ldati_tile_sparse_kernel(Ldati
     const int lpx0 = tid * PPT;
     const unsigned NKS = (unsigned)P.NB << P.shift;                 // key stride between bins (>= NK)
 
+    STAMP_DECL;
     // ---- 1: loads (all in flight at once), then the LDS tables are cleared under them
     float yv[PPT][10];
     {
@@ -1878,6 +1879,7 @@ __global__ __launch_bounds__(kSparseThreads) void ldati_tile_sparse_kernel(Ldati
     if (tid < 9) { offt_s[tid] = P.offt[tid]; kbase_s[tid] = P.kbase[tid]; }
     __syncthreads();
 
+    STAMP(0);
     // ---- 2a: classify; append to the lists (slots from wave_alloc: one LDS atomic per wave, pixel and list)
     const int lane_s = tid & 63;
     // FUSED: the count pass rides along (what ldati_count_tiles_kernel computes: events per bin, largest voxel count).  The
@@ -1929,39 +1931,53 @@ __global__ __launch_bounds__(kSparseThreads) void ldati_tile_sparse_kernel(Ldati
             }
         }
     }
+    STAMP(1);
     if (FUSED) {
+        // the tile's total and its largest voxel count: one wave scan and one wave maximum.  The per-bin counts of a tile that
+        // fits come out of the cell scan for free (binstart, step 6); only a tile beyond kSparseCap -- which this kernel cannot
+        // place -- reduces its nine per-bin sums here (what ldati_count_tiles_kernel reports)
+        unsigned tl = 0;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            const unsigned tot = wave_incl_scan((unsigned)cnt9[i], lane_s);
-            if (lane_s == 63) red[(tid >> 6) * 10 + i] = tot;
-        }
+        for (int i = 0; i < 9; ++i) tl += (unsigned)cnt9[i];
+        const unsigned wt = wave_incl_scan(tl, lane_s);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const int m = __shfl_xor(vmax, o);
             vmax = m > vmax ? m : vmax;
         }
+        if (lane_s == 63) red[(tid >> 6) * 10 + 8] = wt;
         if (lane_s == 0) red[(tid >> 6) * 10 + 9] = (unsigned)vmax;
     }
     __syncthreads();
     if (FUSED) {
-        unsigned mine = 0;                                   // thread i < 9: events of bin i; thread 9: largest voxel count
-        if (tid < 10) {
+        unsigned mx = 0;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                const unsigned v = red[w * 10 + tid];
-                mine = tid == 9 ? (v > mine ? v : mine) : mine + v;
-            }
+        for (int w = 0; w < NW; ++w) {
+            ntot += red[w * 10 + 8];
+            const unsigned v = red[w * 10 + 9];
+            mx = v > mx ? v : mx;
         }
-#pragma unroll
-        for (int w = 0; w < NW; ++w)
-#pragma unroll
-            for (int i = 0; i < 9; ++i) ntot += red[w * 10 + i];
-        if (tid < 9) P.tc_w[((long long)b * P.T + t) * 9 + tid] = mine;
         // (plain reads first: after the first few tiles these maxima rarely grow, and same-address atomics serialise)
-        if (tid == 9 && mine > 0 && (unsigned long long)mine > P.stats_w[0]) atomicMax(&P.stats_w[0], (unsigned long long)mine);
+        if (tid == 9 && mx > 0 && (unsigned long long)mx > P.stats_w[0]) atomicMax(&P.stats_w[0], (unsigned long long)mx);
         if (tid == 10 && ntot > 0 && (unsigned long long)ntot > P.stats_w[4]) atomicMax(&P.stats_w[4], (unsigned long long)ntot);
-        if (ntot > (unsigned)P.sparse_cap) return;       // uniform: the call falls back to the two-pass path
+        if (ntot > (unsigned)P.sparse_cap) {             // uniform: the call falls back to the two-pass path
+            __syncthreads();                             // (red is rewritten)
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const unsigned tot = wave_incl_scan((unsigned)cnt9[i], lane_s);
+                if (lane_s == 63) red[(tid >> 6) * 10 + i] = tot;
+            }
+            __syncthreads();
+            if (tid < 9) {
+                unsigned mine = 0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) mine += red[w * 10 + tid];
+                P.tc_w[((long long)b * P.T + t) * 9 + tid] = mine;
+            }
+            return;
+        }
     }
+    STAMP(2);
     // ---- 2b: the lists move to registers (they share their LDS with the records)
     const unsigned Ns = cur[0], Nmp = cur[1];
     constexpr int SPT = kSparseCap / NT, MPT = kSparseCap / 2 / NT;    // most list entries per thread
@@ -1979,6 +1995,7 @@ __global__ __launch_bounds__(kSparseThreads) void ldati_tile_sparse_kernel(Ldati
         mb[j] = m < Nmp ? __uint_as_float(e[2]) : 0.0f;
     }
     __syncthreads();
+    STAMP(3);
     // ---- 3: timestamps -> records, cell histogram
     auto put = [&](unsigned idx, unsigned c, unsigned key, unsigned multi, unsigned local) {
         const unsigned ck = __umul24(c, NKS) + key;       // (c < 9, NKS < 2^16: the 24-bit multiply issues at full rate)
@@ -1995,6 +2012,7 @@ __global__ __launch_bounds__(kSparseThreads) void ldati_tile_sparse_kernel(Ldati
         const unsigned key = single_key(has, __uint_as_float(sl[j].x), offt_s[c], kbase_s[c], fast_s, P);
         if (has) put((unsigned)(tid + j * NT), c, key, 0u, sl[j].y & (kTilePix - 1));   // a single's record index = its list index
     }
+    STAMP(4);
 #pragma unroll
     for (int j = 0; j < MPT; ++j) {
         if ((unsigned)(j * NT) >= Nmp) break;                // uniform: no multi-event pair left for anybody
@@ -2033,6 +2051,7 @@ __global__ __launch_bounds__(kSparseThreads) void ldati_tile_sparse_kernel(Ldati
         }
     }
     __syncthreads();
+    STAMP(5);
     const unsigned N = Ns + cur[2];
     if (N != ntot) {                                     // cannot happen: the count kernel saw the same voxels
         if (tid == 0) atomicExch(reinterpret_cast<unsigned *>(P.status), 3u);
@@ -2056,6 +2075,7 @@ __global__ __launch_bounds__(kSparseThreads) void ldati_tile_sparse_kernel(Ldati
         for (int j = 0; j < 5; ++j) hist[tid * 5 + j] = (cnt[2 * j] + ex) | ((cnt[2 * j + 1] + ex) << 16);
     }
     __syncthreads();
+    STAMP(6);
     auto cell = [&](unsigned g) { return (hist[g >> 1] >> ((g & 1u) * 16u)) & 0xFFFFu; };
     // placement: the cell's word advances from its start to its end
     for (unsigned i = tid; i < N; i += NT) {
@@ -2065,38 +2085,85 @@ __global__ __launch_bounds__(kSparseThreads) void ldati_tile_sparse_kernel(Ldati
         O[(old >> ((g & 1u) * 16u)) & 0xFFFFu] = rec;
     }
     __syncthreads();
+    STAMP(7);
     if (tid < 10) binstart[tid] = tid == 9 ? N : (tid ? cell((unsigned)tid * (unsigned)P.NB - 1u) : 0u);
-    // ---- 5: order inside the cells: by local pixel (ties: by arrival, any fixed order is right)
-    for (unsigned i = tid; i < N; i += NT) {
-        const unsigned rec = O[i];
-        const unsigned g = rec >> (12 + P.shift);
-        const unsigned lo = g ? cell(g - 1) : 0u, hi = cell(g);
-        unsigned r = lo;
-        if (hi - lo > 1u) {
-            const unsigned me = rec & (kTilePix - 1);
-            for (unsigned j = lo; j < hi; ++j) {
-                const unsigned o = O[j] & (kTilePix - 1);
-                r += (o < me || (o == me && j < i)) ? 1u : 0u;
+    // ---- 5: order inside the cells: by local pixel (ties: by arrival, any fixed order is right); four records per thread at a
+    // time, so that their dependent LDS reads (record, the cell's two bounds, the cell's members) overlap
+    for (unsigned i0 = tid; i0 < N; i0 += 4 * NT) {
+        unsigned rec[4], lo[4], hi[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rec[j] = i0 + j * NT < N ? O[i0 + j * NT] : 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned g = rec[j] >> (12 + P.shift);
+            lo[j] = g ? cell(g - 1) : 0u;
+            hi[j] = cell(g);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned i = i0 + j * NT;
+            if (i < N) {
+                unsigned r = lo[j];
+                if (hi[j] - lo[j] > 1u) {
+                    const unsigned me = rec[j] & (kTilePix - 1);
+                    for (unsigned q = lo[j]; q < hi[j]; ++q) {
+                        const unsigned o = O[q] & (kTilePix - 1);
+                        r += (o < me || (o == me && q < i)) ? 1u : 0u;
+                    }
+                }
+                S[r] = rec[j];
             }
         }
-        S[r] = rec;
     }
     __syncthreads();
+    STAMP(8);
     // ---- 6: nine runs of records, nine rows of the run table
+    unsigned bst[10];
 #pragma unroll
-    for (int c = 0; c < 9; ++c) {
-        const unsigned bs = binstart[c], Nc = binstart[c + 1] - bs;
-        const unsigned strip = ((unsigned)c * NKS) << 12;
-        unsigned *dst = P.temp + (FUSED ? ((long long)b * P.T + t) * kSparseCap + bs : dst_off[c]);
-        if (FUSED && tid == 0) P.tile_abs_w[(long long)(b * 9 + c) * P.Tp + t] = (unsigned)(((long long)b * P.T + t) * kSparseCap + bs);
-        for (unsigned i = tid; i < Nc; i += NT) dst[i] = S[bs + i] - strip;
-        unsigned short *row = P.roff + ((long long)(b * 9 + c) * P.T + t) * (P.NB + 1);
-        for (int k = tid; k < P.NB; k += NT) {
-            const unsigned g = (unsigned)c * (unsigned)P.NB + (unsigned)k;
-            row[k] = (unsigned short)((g ? cell(g - 1) : 0u) - bs);
+    for (int c = 0; c < 10; ++c) bst[c] = binstart[c];
+    if (FUSED) {
+        // the nine runs are contiguous in the tile's slot: one loop, the bin of a record from its position
+        const long long slot = ((long long)b * P.T + t) * kSparseCap;
+        if (tid < 9) {
+            P.tile_abs_w[(long long)(b * 9 + tid) * P.Tp + t] = (unsigned)(slot + bst[tid]);
+            P.tc_w[((long long)b * P.T + t) * 9 + tid] = bst[tid + 1] - bst[tid];       // the count pass's output
         }
-        if (tid == 0) row[P.NB] = (unsigned short)Nc;
+        unsigned *dst = P.temp + slot;
+        for (unsigned i = tid; i < N; i += NT) {
+            unsigned c = 0;
+#pragma unroll
+            for (int j = 1; j < 9; ++j) c += i >= bst[j] ? 1u : 0u;
+            dst[i] = S[i] - (__umul24(c, NKS) << 12);
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            const unsigned bs = bst[c], Nc = bst[c + 1] - bs;
+            const unsigned strip = ((unsigned)c * NKS) << 12;
+            unsigned *dst = P.temp + dst_off[c];
+            for (unsigned i = tid; i < Nc; i += NT) dst[i] = S[bs + i] - strip;
+        }
     }
+    {
+        unsigned short *row0 = P.roff + ((long long)(b * 9) * P.T + t) * (P.NB + 1);
+        const long long rstep = (long long)P.T * (P.NB + 1);
+        for (int k0 = 0; k0 < P.NB; k0 += NT) {          // (one trip: NB <= kSparseThreads unless the key range is huge)
+            const int kk = k0 + tid;
+            if (kk < P.NB) {
+                unsigned cv[9];
+#pragma unroll
+                for (int c = 0; c < 9; ++c) {
+                    const unsigned g = (unsigned)c * (unsigned)P.NB + (unsigned)kk;
+                    cv[c] = g ? cell(g - 1) : 0u;
+                }
+#pragma unroll
+                for (int c = 0; c < 9; ++c) row0[c * rstep + kk] = (unsigned short)(cv[c] - bst[c]);
+            }
+        }
+        if (tid < 9) row0[tid * rstep + P.NB] = (unsigned short)(bst[tid + 1] - bst[tid]);
+    }
+    STAMP(9);
+    STAMP_FLUSH(0, 10);
 }
 
 // per segment: bucket totals over the tiles, their exclusive prefix, and the SORT GROUPS: maximal
