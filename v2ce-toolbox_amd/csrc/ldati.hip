@@ -1625,7 +1625,10 @@ __device__ __forceinline__ void dense_tile_body(const LdatiParams &P) {
             for (;;) {
                 const unsigned bid = (unsigned)__builtin_amdgcn_readfirstlane((int)nxt);
                 if (bid >= nb) break;
-                if (lane == 0) nxt = atomicAdd(bctr, 1u);        // (in flight while this batch runs)
+                // far from the end the next batch is reserved now (its LDS round trip runs under this batch); near the end a
+                // wave takes its next batch only when it is free, so that nobody sits on a batch an idle wave could run
+                const bool early = bid + 2u * NW < nb;
+                if (early && lane == 0) nxt = atomicAdd(bctr, 1u);
                 if (bid < nK) {                          // the long batches first
                     if (philox) unit_batch(std::integral_constant<int, 3>{}, UL1, bid * 64u + lane, U1);
                     else unit_batch(std::integral_constant<int, 0>{}, UL1, bid * 64u + lane, U1);
@@ -1637,6 +1640,7 @@ __device__ __forceinline__ void dense_tile_body(const LdatiParams &P) {
                 } else {
                     single_batch((bid - nK - nZ) * 64u + lane);
                 }
+                if (!early && lane == 0) nxt = atomicAdd(bctr, 1u);
             }
         }
         STAMP(4);
