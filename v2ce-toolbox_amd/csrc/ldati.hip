@@ -2537,7 +2537,12 @@ __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(Ldat
                     A[q] = (unsigned)tq;
                     Bh[q] = (unsigned)((unsigned long long)tq >> 32);
                     // (v_mul_lo_u32 issues at a quarter of the rate of v_mul_u32_u24; px < 2^24 in the two float-division modes)
-                    C[q] = ((px - (MODE == 2 ? yy * W : __umul24(yy, W))) & 0xFFFFu) | (yy << 16);
+                    // yy * W: only its low 16 bits are used, so the compiler drops __umul24's masks and falls back to the
+                    // quarter-rate v_mul_lo_u32 -- hence the instruction by name (px < 2^24 in the two float-division modes)
+                    unsigned yw;
+                    if (MODE == 2) yw = yy * W;
+                    else asm("v_mul_u32_u24 %0, %1, %2" : "=v"(yw) : "v"(yy), "v"(W));
+                    C[q] = ((px - yw) & 0xFFFFu) | (yy << 16);
                     D[q] = cat >> 1;
                 }
                 unsigned *d = stage + tid * 13;
