@@ -2331,16 +2331,25 @@ __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(Ldat
         for (int i = lane; i < kWords; i += 64) bits[i] = 0;
         unsigned cv[TPL], ov[TPL];
         unsigned sum = 0;
+        {
+            // branch-free (tiles past the last one read the last one's entries and are masked): all 2 TPL loads are issued
+            // back to back and waited for once -- behind a per-tile `if` each pair was waited for before the next was issued
+            const unsigned *gr_row = P.gruns + ((long long)seg * P.NB + blockIdx.x) * P.Tp;
+            const unsigned *ts_row = P.tile_src + (long long)seg * P.Tp;
+            unsigned gr[TPL], ts[TPL];
 #pragma unroll
-        for (int q = 0; q < TPL; ++q) {
-            const int tt = lane * TPL + q;
-            cv[q] = 0u; ov[q] = 0u;
-            if (tt < P.T) {
-                const unsigned gr = P.gruns[((long long)seg * P.NB + blockIdx.x) * P.Tp + tt];
-                cv[q] = gr >> 16;
-                ov[q] = (gr & 0xFFFFu) + P.tile_src[(long long)seg * P.Tp + tt];
+            for (int q = 0; q < TPL; ++q) {
+                const int tt = min(lane * TPL + q, P.T - 1);
+                gr[q] = gr_row[tt];
+                ts[q] = ts_row[tt];
             }
-            sum += cv[q] | (cv[q] ? 0x10000u : 0u);
+#pragma unroll
+            for (int q = 0; q < TPL; ++q) {
+                const bool in = lane * TPL + q < P.T;
+                cv[q] = in ? gr[q] >> 16 : 0u;
+                ov[q] = (gr[q] & 0xFFFFu) + ts[q];
+                sum += cv[q] | (cv[q] ? 0x10000u : 0u);
+            }
         }
         unsigned ex = wave_incl_scan(sum, lane) - sum;
 #pragma unroll
