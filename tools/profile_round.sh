@@ -8,7 +8,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 python3 bench.py --steps 8 --warmup 2 > $OUT/bench_e2e.json 2> $OUT/bench_e2e.err
 for wl in ldati_stress ldati_sparse; do
-  python3 bench.py --workload $wl --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err
+  python3 bench.py --workload $wl --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err
 done
 python3 bench.py --workload pano --steps 4 --warmup 1 --no-cpu-baseline > $OUT/bench_pano.json 2> $OUT/bench_pano.err
 LIGHT="--no-cpu-baseline --no-exact-f32 --no-host-to-host"
