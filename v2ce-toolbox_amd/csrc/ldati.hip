@@ -51,6 +51,7 @@ constexpr int kMaxTiles = 512;        // tiles per frame (both polarities) the b
 constexpr int kMaxNB = 512;           // coarse buckets per segment
 constexpr int kMaxShift = 8;          // log2 of the widest coarse bucket
 constexpr int kMaxSpanKeys = 128;     // timestamps a sort group spans at most (its histogram has 4x as many bins)
+constexpr int kSmallGroupSpanKeys = 256;   // ... in the small-group regime (make_plan; measured 128 / 256 / 512: e2e sort 94 / 89 / 116 us)
 constexpr int kCapTile = 15360;       // events of one (tile, bin) the tile pass can hold in LDS
 constexpr int kSparseCap = 8192;      // events of one tile over all nine bins the sparse tile kernel holds
 constexpr int kSparseThreads = 512;
@@ -2910,7 +2911,16 @@ Plan make_plan(const HostScalars &h, int B, int H, int W, int64_t total_events,
     int nb1 = 0;
     while ((1 << nb1) < p.NB) ++nb1;
     p.nb1 = nb1;
-    p.span = (kMaxSpanKeys >> shift) > 0 ? (kMaxSpanKeys >> shift) : 1;
+    // key span of a sort group: 128 keys for dense segments; for the small-group regime (128-thread workgroups) the groups are
+    // closed by their span, not by their records, so a wider span means fewer, fuller groups (V2CE_LDATI_SPAN_KEYS: A/B runs)
+    int span_keys = kMaxSpanKeys;
+    {
+        const char *e = getenv("V2CE_LDATI_SPAN_KEYS");
+        const int ev = e ? atoi(e) : 0;
+        if (ev == 128 || ev == 256 || ev == 512) span_keys = ev;
+        else if (p.sort_threads == 128 && max_segment_events > 2048) span_keys = kSmallGroupSpanKeys;
+    }
+    p.span = (span_keys >> shift) > 0 ? (span_keys >> shift) : 1;
     p.tbits = 0;
     while ((1 << p.tbits) < p.T) ++p.tbits;
     p.capA = (int)((max_tile_events + 255) / 256 * 256);
