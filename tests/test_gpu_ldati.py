@@ -408,6 +408,9 @@ def test_dense_tile_kernel_equals_per_bin_kernel(gold_dir, monkeypatch):
     assert np.array_equal(ev.x.cpu().numpy()[:n0], x) and np.array_equal(ev.p.cpu().numpy()[:n0], p)
     dense = (10.0 * np.random.default_rng(3).random((1, 2, 10, 100, 160))).astype(np.float32)      # ~100 events per pixel
     soa_equal(both(lambda: hip_events(dense, seed=8)), *O.emit_soa(dense, fps=30, seed=8))
+    # planes that are not 16-byte aligned (H W % 4 != 0): the dense kernel's general body with scalar plane loads
+    odd = (8.0 * np.random.default_rng(4).random((1, 2, 10, 99, 161))).astype(np.float32)
+    soa_equal(both(lambda: hip_events(odd, seed=9, frame_base=2)), *O.emit_soa(odd, fps=30, seed=9, frame_base=2))
     rng = np.random.default_rng(21)
     mix = np.zeros((2, 2, 10, 96, 160), np.float32)
     mix[:, :, :, :40] = np.maximum(0.25 * rng.standard_normal((2, 2, 10, 40, 160)), 0)
