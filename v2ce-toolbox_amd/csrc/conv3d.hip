@@ -904,8 +904,14 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
                 }
             }
             const int lim = tail ? tng * P.tNPP : P.plane;            // element slots of this chunk
+#ifdef V2CE_ABLATE_UP
+            const int ne_abl = (!tail && want_src == 0 && P.hmap) ? V2CE_ABLATE_UP : EPT;     // timing ablation: an upsampled source gathered once per SOURCE element
+#endif
 #pragma unroll
             for (int i = 0; i < EPT; ++i) {
+#ifdef V2CE_ABLATE_UP
+                if (i >= ne_abl) continue;
+#endif
                 if ((wave - 4) * 64 + 256 * i < lim) {                // wave-uniform
                     // (tail: the slot's group must exist in this super-chunk -- the last one of a source may be short)
                     const unsigned vo = (tail && (int)((gsel >> (4 * i)) & 15u) >= tng) ? kOOB : goff[i];
@@ -941,8 +947,14 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
             const bool tail = TAIL && cgC >= CG;             // uniform
             const float c_scale = tail ? t_scale : x_scale;
             const int lim = tail ? P.tTCH * P.tNPP : P.plane;       // (slots of absent groups hold zeros: harmless)
+#ifdef V2CE_ABLATE_UP
+            const int ne_abl = (!tail && cgC * CK < P.C0 && P.hmap) ? V2CE_ABLATE_UP : EPT;
+#endif
 #pragma unroll
             for (int i = 0; i < EPT; ++i) {
+#ifdef V2CE_ABLATE_UP
+                if (i >= ne_abl) continue;
+#endif
                 const int r = ptid + 256 * i;
                 if ((wave - 4) * 64 + 256 * i < lim) {                // wave-uniform (lanes past the box write padding)
 #pragma unroll
