@@ -1334,7 +1334,8 @@ __device__ __forceinline__ float div_rn_nr(float x, float k, float r1) {
     rem = __builtin_fmaf(-k, q, x);
     return __builtin_fmaf(rem, r1, q);
 }
-// Philox4x32-10 as philox4(), the two three-input xors of a round as one v_bitop3_b32 each
+// Philox4x32-10 as philox4(), the two three-input xors of a round as one v_bitop3_b32 each.  `seed` must be wave-uniform (it
+// is the call's seed everywhere): the key schedule lives in scalar registers
 __device__ __forceinline__ void philox4_b3(unsigned long long seed, unsigned pixel, unsigned jb, unsigned pc, unsigned frame,
                                            unsigned (&out)[4]) {
     unsigned c0 = pixel, c1 = jb, c2 = pc, c3 = frame;
