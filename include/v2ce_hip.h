@@ -135,12 +135,18 @@ int v2ce_ldati_status(const void *workspace, int B, int H, int W, double fps, do
  * (the geometry follows from the densest segment's events: expected_max_segment_events is the caller's guess, normally the
  * previous batch's stats[2]; the same value goes to all three functions), only the bucket scan and the bucket sort remain; otherwise it ignores fused_ws and runs
  * the two-pass path -- same bytes either way (tests/test_gpu_ldati.py::test_fused_count_equals_two_pass).
- * v2ce_ldati_fused_ws_bytes = 0: no fused path for these options ('random', pooled slope) -- use v2ce_ldati_count. */
+ * v2ce_ldati_fused_ws_bytes = 0: no fused path for these options ('random', pooled slope) -- use v2ce_ldati_count.
+ * Dense regime (expected_max_tile_bin_events > 0: the caller's guess of the densest (tile, bin) run, normally the previous
+ * batch's stats[1] plus a margin; 0 selects the sparse form above): the dense tile kernel is the count pass and the tile pass
+ * at once, every (tile, bin) run in its own slot of that many records (rounded up to 256); v2ce_ldati_emit_fused uses the
+ * slots when max_tile_events = stats[1] fits them and the geometry matches, and repeats the tile pass on the two-pass path
+ * otherwise -- same bytes either way.  The same two expectations go to all three functions of a call. */
 size_t v2ce_ldati_fused_ws_bytes(int B, int H, int W, double fps, double t0, const v2ce_ldati_options *options,
-                                 int64_t expected_max_segment_events);
+                                 int64_t expected_max_segment_events, int64_t expected_max_tile_bin_events);
 int v2ce_ldati_count_fused(const float *vox, int B, int H, int W, double fps, double t0, const v2ce_ldati_options *options,
                            int rng_mode, const float *uniforms, int replay_max_n, uint64_t seed, int64_t frame_base,
-                           int64_t expected_max_segment_events, void *tile_ws, size_t tile_ws_bytes, void *fused_ws, size_t fused_ws_bytes,
+                           int64_t expected_max_segment_events, int64_t expected_max_tile_bin_events, void *tile_ws, size_t tile_ws_bytes,
+                           void *fused_ws, size_t fused_ws_bytes,
                            int64_t *seg_offsets /* [B*9+1] */, int64_t *stats /* [8] */, v2ce_stream_t stream);
 int v2ce_ldati_emit_fused(const float *vox, int B, int H, int W, double fps, double t0, const v2ce_ldati_options *options,
                           int rng_mode, const float *uniforms, int replay_max_n, uint64_t seed, int64_t frame_base,
@@ -148,7 +154,7 @@ int v2ce_ldati_emit_fused(const float *vox, int B, int H, int W, double fps, dou
                           int8_t *p, uint8_t *packed, int64_t total_events, int64_t max_segment_events,
                           int64_t max_tile_events, const void *tile_ws, void *workspace, size_t workspace_bytes,
                           const void *fused_ws, size_t fused_ws_bytes, int64_t largest_tile_events,
-                          int64_t expected_max_segment_events, v2ce_stream_t stream);
+                          int64_t expected_max_segment_events, int64_t expected_max_tile_bin_events, v2ce_stream_t stream);
 
 int v2ce_ldati_plan_info(int B, int H, int W, double fps, double t0, const v2ce_ldati_options *options,
                          int64_t total_events, int64_t max_segment_events, int64_t max_tile_events, int64_t *info);

@@ -510,6 +510,57 @@ def test_fused_count_equals_two_pass(gold_dir, monkeypatch):
     assert both(lambda: hip_events(np.zeros((2, 2, 10, 30, 40), np.float32), seed=1)).num_events == 0
 
 
+def test_c_abi_fused_dense_call_sequence(monkeypatch, capfd):
+    """The dense form of the fused count (expected_max_tile_bin_events > 0: ldati_tile_dense_kernel is the count pass and the tile
+    pass at once, a slot per (tile, bin)) through ctypes alone: a first call without expectations (the sparse form; its tiles
+    are dense, the emit takes the two-pass path), then with the first call's statistics as expectations (the slots are used:
+    checked in the library's debug line), then with an expectation that is too small (the emit repeats the tile pass).  All
+    three give the oracle's events; the statistics of the dense form equal the count pass's."""
+    import ctypes
+    L = hip.lib()
+    rng = np.random.default_rng(5)
+    vox = (5.0 * rng.random((2, 2, 10, 96, 160))).astype(np.float32)
+    vox[1, :, :, :40] = np.maximum(0.3 * rng.standard_normal((2, 10, 40, 160)), 0)        # sparse tiles too: the dense kernel takes them all
+    y = torch.from_numpy(vox).cuda()
+    B, _, _, H, W = y.shape
+    want = O.emit_soa(vox, fps=30, seed=42, frame_base=2)
+    st = hip.stream_ptr(y.device)
+    o = hip.LdatiOptions(hip.STRATEGY_SLOPE, 0, hip.POOL_NONE, 3)
+    monkeypatch.setenv("V2CE_LDATI_DEBUG", "1")
+    hint, bin_hint, ref_stats = 0, 0, None
+    for attempt, expect_fused in ((0, False), (1, True), (2, False)):
+        if attempt == 2:
+            bin_hint = max(256, ref_stats[1] // 2)
+        fb = L.v2ce_ldati_fused_ws_bytes(B, H, W, 30.0, 0.0, ctypes.byref(o), hint, bin_hint)
+        assert fb > 0
+        tws = torch.empty(L.v2ce_ldati_tile_ws_bytes(B, H, W), dtype=torch.uint8, device="cuda")
+        fws = torch.empty(fb, dtype=torch.uint8, device="cuda")
+        meta = torch.empty(B * 9 + 1 + 8, dtype=torch.int64, device="cuda")
+        hip.check(L.v2ce_ldati_count_fused(y.data_ptr(), B, H, W, 30.0, 0.0, ctypes.byref(o), hip.RNG_PHILOX, None, 0, 42, 2, hint, bin_hint,
+                                           tws.data_ptr(), tws.numel(), fws.data_ptr(), fws.numel(), meta.data_ptr(),
+                                           meta[B * 9 + 1:].data_ptr(), st), "count_fused")
+        host = meta.cpu().numpy()
+        max_n, max_tile, max_seg, total, tile_all = (int(v) for v in host[B * 9 + 1:B * 9 + 6])
+        assert total == int(want[0].sum()) and np.array_equal(np.diff(host[:B * 9 + 1]).reshape(B, 9), want[0]) and tile_all > 8192
+        if ref_stats is None:
+            ref_stats = (max_n, max_tile, max_seg, total, tile_all)
+        assert (max_n, max_tile, max_seg, total, tile_all) == ref_stats          # the dense kernel counts what the count pass counts
+        nb = L.v2ce_ldati_workspace_bytes(B, H, W, 30.0, 0.0, ctypes.byref(o), total, max_seg, max_tile, 1)
+        ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        out = torch.empty(total * 13 + 64, dtype=torch.uint8, device="cuda")
+        capfd.readouterr()
+        hip.check(L.v2ce_ldati_emit_fused(y.data_ptr(), B, H, W, 30.0, 0.0, ctypes.byref(o), hip.RNG_PHILOX, None, 0, 42, 2,
+                                          meta.data_ptr(), None, None, None, None, None, out.data_ptr(), total, max_seg, max_tile,
+                                          tws.data_ptr(), ws.data_ptr(), nb, fws.data_ptr(), fws.numel(), tile_all, hint, bin_hint, st), "emit_fused")
+        torch.cuda.synchronize()
+        err = capfd.readouterr().err
+        assert ("fused=1" in err) == expect_fused, err
+        rec = out[:total * 13].cpu().numpy().view(O.EVENT_DTYPE)
+        assert np.array_equal(rec["timestamp"], want[1]) and np.array_equal(rec["x"], want[2])
+        assert np.array_equal(rec["y"], want[3]) and np.array_equal(rec["polarity"], want[4])
+        hint, bin_hint = max_seg, max_tile + 64
+
+
 def test_c_abi_fused_call_sequence():
     """The call sequence INTEGRATION.md gives a maintainer of the reference, through ctypes alone (no LDATI.py): hint 0 ->
     v2ce_ldati_fused_ws_bytes -> v2ce_ldati_count_fused -> read stats -> v2ce_ldati_workspace_bytes -> v2ce_ldati_emit_fused;
@@ -525,12 +576,12 @@ def test_c_abi_fused_call_sequence():
     o = hip.LdatiOptions(hip.STRATEGY_SLOPE, 0, hip.POOL_NONE, 3)
     hint = 0
     for attempt in range(2):
-        fb = L.v2ce_ldati_fused_ws_bytes(B, H, W, 30.0, 0.0, ctypes.byref(o), hint)
+        fb = L.v2ce_ldati_fused_ws_bytes(B, H, W, 30.0, 0.0, ctypes.byref(o), hint, 0)
         assert fb > 0
         tws = torch.empty(L.v2ce_ldati_tile_ws_bytes(B, H, W), dtype=torch.uint8, device="cuda")
         fws = torch.empty(fb, dtype=torch.uint8, device="cuda")
         meta = torch.empty(B * 9 + 1 + 8, dtype=torch.int64, device="cuda")
-        hip.check(L.v2ce_ldati_count_fused(y.data_ptr(), B, H, W, 30.0, 0.0, ctypes.byref(o), hip.RNG_PHILOX, None, 0, 99, 5, hint,
+        hip.check(L.v2ce_ldati_count_fused(y.data_ptr(), B, H, W, 30.0, 0.0, ctypes.byref(o), hip.RNG_PHILOX, None, 0, 99, 5, hint, 0,
                                            tws.data_ptr(), tws.numel(), fws.data_ptr(), fws.numel(), meta.data_ptr(),
                                            meta[B * 9 + 1:].data_ptr(), st), "count_fused")
         host = meta.cpu().numpy()
@@ -541,14 +592,15 @@ def test_c_abi_fused_call_sequence():
         out = torch.empty(total * 13 + 64, dtype=torch.uint8, device="cuda")
         hip.check(L.v2ce_ldati_emit_fused(y.data_ptr(), B, H, W, 30.0, 0.0, ctypes.byref(o), hip.RNG_PHILOX, None, 0, 99, 5,
                                           meta.data_ptr(), None, None, None, None, None, out.data_ptr(), total, max_seg, max_tile,
-                                          tws.data_ptr(), ws.data_ptr(), nb, fws.data_ptr(), fws.numel(), tile_all, hint, st), "emit_fused")
+                                          tws.data_ptr(), ws.data_ptr(), nb, fws.data_ptr(), fws.numel(), tile_all, hint, 0, st), "emit_fused")
         rec = out[:total * 13].cpu().numpy().view(O.EVENT_DTYPE)
         assert np.array_equal(rec["timestamp"], want[1]) and np.array_equal(rec["x"], want[2])
         assert np.array_equal(rec["y"], want[3]) and np.array_equal(rec["polarity"], want[4])
         hint = max_seg
     # errors are return codes with a message
-    assert L.v2ce_ldati_count_fused(y.data_ptr(), B, H, W, 30.0, 0.0, ctypes.byref(o), hip.RNG_PHILOX, None, 0, 99, 5, 0, tws.data_ptr(),
+    assert L.v2ce_ldati_count_fused(y.data_ptr(), B, H, W, 30.0, 0.0, ctypes.byref(o), hip.RNG_PHILOX, None, 0, 99, 5, 0, 0, tws.data_ptr(),
                                     tws.numel(), fws.data_ptr(), 16, meta.data_ptr(), meta[B * 9 + 1:].data_ptr(), st) != 0
     assert b"workspace" in L.v2ce_last_error()
     rnd = hip.LdatiOptions(hip.STRATEGY_RANDOM, 0, hip.POOL_NONE, 3)
-    assert L.v2ce_ldati_fused_ws_bytes(B, H, W, 30.0, 0.0, ctypes.byref(rnd), 0) == 0        # 'random' has no fused path
+    assert L.v2ce_ldati_fused_ws_bytes(B, H, W, 30.0, 0.0, ctypes.byref(rnd), 0, 0) == 0        # 'random' has no fused path
+    assert L.v2ce_ldati_fused_ws_bytes(B, H, W, 30.0, 0.0, ctypes.byref(rnd), 0, 5000) == 0

@@ -203,15 +203,22 @@ def ldati_begin(y: torch.Tensor, t0=0, fps=30, *, rng: str = "philox", seed: Opt
             seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
         # One pass over the voxels instead of two (v2ce_ldati_count_fused): counts AND the sparse tiles' records; finish()
         # falls back to the two-pass path by itself when a tile was dense.  rng='torch' draws its tensor after the counts.
-        fused_ws, seg_hint, hint_key = None, 0, None
+        fused_ws, seg_hint, bin_hint, hint_key = None, 0, 0, None
         if path == "bucket" and (rng == "philox" or uniforms is not None) and os.environ.get("V2CE_LDATI_NO_FUSED") is None:
             hint_key = (dev.index, B, H, W, float(fps), float(t0), strategy, bool(bidirectional))
-            seg_hint, tile_hint, calls = _SEG_HINT.get(hint_key, (0, 0, 0))
-            # a shape whose last call had a dense tile (the fused records were discarded) counts the plain way, and tries
-            # the fused pass again every 16th call
+            seg_hint, tile_hint, calls, bin_last = _SEG_HINT.get(hint_key, (0, 0, 0, 0))
+            # Sparse tiles last time (or no history): the sparse kernel's fused form, a slot per tile.  A dense tile last time:
+            # the dense kernel's fused form, a slot per (tile, bin) sized from last time's densest one plus a margin (a miss
+            # costs the pass and its two-pass repeat; the bytes are the same) -- and the sparse form again every 16th call, so
+            # that a stream that turns sparse is picked up.
             fb = 0
             if tile_hint <= _SPARSE_TILE_CAP or calls % 16 == 0:
-                fb = L.v2ce_ldati_fused_ws_bytes(B, H, W, float(fps), float(t0), ctypes.byref(opts), seg_hint)
+                fb = L.v2ce_ldati_fused_ws_bytes(B, H, W, float(fps), float(t0), ctypes.byref(opts), seg_hint, 0)
+            elif bin_last > 0:
+                bin_hint = int(bin_last * 1.06) + 128
+                fb = L.v2ce_ldati_fused_ws_bytes(B, H, W, float(fps), float(t0), ctypes.byref(opts), seg_hint, bin_hint)
+                if not fb:
+                    bin_hint = 0                          # (no dense form for these options: the plain count)
             if fb:
                 fused_ws = torch.empty(fb, dtype=torch.uint8, device=dev)
         if profile is not None:    # HIP events on the launch stream around the count kernels
@@ -219,8 +226,8 @@ def ldati_begin(y: torch.Tensor, t0=0, fps=30, *, rng: str = "philox", seed: Opt
             c0.record()
         if fused_ws is not None:
             hip.check(L.v2ce_ldati_count_fused(y.data_ptr(), B, H, W, float(fps), float(t0), ctypes.byref(opts), mode, hip.ptr(u_keep),
-                                               replay_max_n, int(seed or 0) & (2 ** 64 - 1), int(frame_base), seg_hint, tile_ws.data_ptr(),
-                                               tile_ws.numel(), fused_ws.data_ptr(), fused_ws.numel(), meta.data_ptr(),
+                                               replay_max_n, int(seed or 0) & (2 ** 64 - 1), int(frame_base), seg_hint, bin_hint,
+                                               tile_ws.data_ptr(), tile_ws.numel(), fused_ws.data_ptr(), fused_ws.numel(), meta.data_ptr(),
                                                meta[B * 9 + 1:].data_ptr(), st), "v2ce_ldati_count_fused")
         else:                                          # (stats[4..7] stay unwritten: only the fused path reads stats[4])
             hip.check(L.v2ce_ldati_count(y.data_ptr(), B, H, W, ctypes.byref(opts), tile_ws.data_ptr(), tile_ws.numel(),
@@ -234,7 +241,7 @@ def ldati_begin(y: torch.Tensor, t0=0, fps=30, *, rng: str = "philox", seed: Opt
         ready.record()
     return PendingLdati(y=y, t0=t0, fps=fps, rng=rng, seed=seed, frame_base=frame_base, uniforms=u_keep,
                         frame_ts_add=frame_ts_add, profile=profile, path=path, opts=opts, plain=plain, layout=layout,
-                        tile_ws=tile_ws, meta=meta, host=host, ready=ready, fused_ws=fused_ws, seg_hint=seg_hint, hint_key=hint_key)
+                        tile_ws=tile_ws, meta=meta, host=host, ready=ready, fused_ws=fused_ws, seg_hint=seg_hint, bin_hint=bin_hint, hint_key=hint_key)
 
 
 def _ldati_finish(q: PendingLdati) -> DeviceEvents:
@@ -250,8 +257,8 @@ def _ldati_finish(q: PendingLdati) -> DeviceEvents:
     max_n, max_tile, max_seg, total, tile_all = (int(v) for v in host[B * 9 + 1:B * 9 + 6])
     segc = np.diff(offs).reshape(B, 9)
     if q.hint_key is not None:
-        prev = _SEG_HINT.get(q.hint_key, (0, 0, 0))
-        _SEG_HINT[q.hint_key] = (max_seg, tile_all if q.fused_ws is not None else prev[1], prev[2] + 1)
+        prev = _SEG_HINT.get(q.hint_key, (0, 0, 0, 0))
+        _SEG_HINT[q.hint_key] = (max_seg, tile_all if q.fused_ws is not None else prev[1], prev[2] + 1, max_tile)
 
     mode, u_ptr, replay_max_n = hip.RNG_PHILOX, None, 0
     keep, seed, uniforms = None, q.seed, q.uniforms
@@ -308,7 +315,7 @@ def _ldati_finish(q: PendingLdati) -> DeviceEvents:
                 q.meta.data_ptr(), add_ptr, ptrs[0], ptrs[1], ptrs[2], ptrs[3], ptrs[4],
                 total, max_seg, max_tile, q.tile_ws.data_ptr(), hip.ptr(ws), int(ws_bytes))
         if q.fused_ws is not None and ws is not None:
-            hip.check(L.v2ce_ldati_emit_fused(*args, q.fused_ws.data_ptr(), q.fused_ws.numel(), tile_all, q.seg_hint, st), "v2ce_ldati_emit_fused")
+            hip.check(L.v2ce_ldati_emit_fused(*args, q.fused_ws.data_ptr(), q.fused_ws.numel(), tile_all, q.seg_hint, q.bin_hint, st), "v2ce_ldati_emit_fused")
         else:
             hip.check(L.v2ce_ldati_emit(*args, st), "v2ce_ldati_emit")
         if q.profile is not None:

@@ -118,6 +118,8 @@ struct LdatiParams {
     unsigned *tile_abs_w;         // [B*9][T] record index of the (tile, bin) run inside `temp`
     const unsigned *tile_abs;     // the same, read by the bucket sort (null: runs at seg_offsets + tile_off)
     const int *fused_status;      // status word of the fused kernel, folded into `status` by the bucket scan
+    int slot_cap;                 // > 0: ldati_tile_dense_kernel is ALSO the count pass (v2ce_ldati_count_fused in the dense regime): every
+                                  // (tile, bin) run goes to its own slot of slot_cap (= capA) records, counts to tc_w, maxima to stats_w
     int Tp;                       // T rounded up to a multiple of 8
     unsigned *gruns;              // [B*9][NB][Tp] per sort group and tile: run start inside the tile's (tile, bin) run | records << 16,
                                   // written by the bucket scan (which has the run table in L2 anyway) so that a sort workgroup's
@@ -1400,6 +1402,7 @@ __device__ __forceinline__ void dense_tile_body(const LdatiParams &P) {
     unsigned *bctr = spart + NW + 1;                    // the next batch of the timestamp phase
     unsigned *dsto = bctr + 2;                          // [9][2]: where the tile's run of bin c starts in records[] (loaded once: a
                                                         // global load per bin would stall all sixteen waves for its whole latency)
+    unsigned *nbin = dsto + 18;                         // [9] slot mode: the bins' record counts
     unsigned *myhist = hist + wid * P.NB;
 
     const float *plane0 = P.vox + (long long)(b * 2 + pidx) * 10 * P.HW;
@@ -1448,10 +1451,14 @@ __device__ __forceinline__ void dense_tile_body(const LdatiParams &P) {
     for (int i = lane; i < P.NB; i += 64) myhist[i] = 0;
     if (tid == 0) *bctr = 0;
     if (tid < 9) {
-        const long long d = P.seg_offsets[b * 9 + tid] + (long long)P.tile_off[((long long)b * P.T + t) * 9 + tid];
+        // slot mode (the kernel is the count pass too: no offsets exist yet): the (tile, bin) run goes to its own slot
+        const long long d = P.slot_cap ? (((long long)b * P.T + t) * 9 + tid) * (long long)P.slot_cap
+                                       : P.seg_offsets[b * 9 + tid] + (long long)P.tile_off[((long long)b * P.T + t) * 9 + tid];
         dsto[2 * tid] = (unsigned)d;
         dsto[2 * tid + 1] = (unsigned)((unsigned long long)d >> 32);
+        if (P.slot_cap) P.tile_abs_w[(long long)(b * 9 + tid) * P.Tp + t] = (unsigned)d;
     }
+    int vmax_l = 0;                                     // slot mode: the lane's largest voxel count (the bins' counts wait in nbin)
     __syncthreads();
 
     STAMP_DECL;
@@ -1504,6 +1511,30 @@ __device__ __forceinline__ void dense_tile_body(const LdatiParams &P) {
             const unsigned bU = wid ? (unsigned)__builtin_amdgcn_readlane((int)p1, wid - 1) : 0u;
             N = tA & 0xFFFFu; Ns = tA >> 16; U0 = tU & 0xFFFFu; U1 = tU >> 16;
             sbase = bA & 0xFFFFu; sS = bA >> 16; sU0 = bU & 0xFFFFu; sU1 = bU >> 16;
+        }
+        if (P.slot_cap) {
+            // the count pass's outputs; a run beyond the slot (and the LDS) is only counted -- the host sees the largest
+            // (tile, bin) count in the statistics and repeats the call on the two-pass path
+            if (tid == 0) nbin[c] = N;                   // (written out at the end: no pointer or sum lives across the bins)
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) vmax_l = ncur[q] > vmax_l ? ncur[q] : vmax_l;
+            if (N > (unsigned)P.capA) {                  // uniform
+#pragma unroll
+                for (int q = 0; q < PPT; ++q) {
+                    nprev[q] = ncur[q];
+                    ncur[q] = nnext[q];
+                    dcur[q] = dnext[q];
+                    if (c + 2 <= 8) {
+                        const float r = ynn[q] - dnext[q];
+                        const float cc = ceilf(r - eps);
+                        dnext[q] = cc - r;
+                        int ni = (int)cc;
+                        if (c + 2 == 8) ni += (int)(y9[q] - dnext[q]);   // LDATI.py:106
+                        nnext[q] = ni;
+                    }
+                }
+                continue;
+            }
         }
         // where the tile's run of this bin goes; its records are ranked into O at the same phase modulo four records, so that the
         // copy-out moves whole 16-byte pieces
@@ -1748,6 +1779,25 @@ __device__ __forceinline__ void dense_tile_body(const LdatiParams &P) {
                 if (c + 2 == 8) ni += (int)(y9[q] - dnext[q]);   // LDATI.py:106
                 nnext[q] = ni;
             }
+        }
+    }
+    if (P.slot_cap) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int m = __shfl_xor(vmax_l, o);
+            vmax_l = m > vmax_l ? m : vmax_l;
+        }
+        // (plain reads first: after the first few tiles these maxima rarely grow, and same-address atomics serialise)
+        if (lane == 0 && vmax_l > 0 && (unsigned long long)vmax_l > *reinterpret_cast<volatile unsigned long long *>(&P.stats_w[0]))
+            atomicMax(&P.stats_w[0], (unsigned long long)vmax_l);
+        __syncthreads();
+        if (tid < 9) P.tc_w[((long long)b * P.T + t) * 9 + tid] = nbin[tid];
+        if (tid == 0) {
+            unsigned tile_total = 0;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) tile_total += nbin[c];
+            if (tile_total > 0 && (unsigned long long)tile_total > *reinterpret_cast<volatile unsigned long long *>(&P.stats_w[4]))
+                atomicMax(&P.stats_w[4], (unsigned long long)tile_total);
         }
     }
     STAMP(0);
@@ -2858,7 +2908,7 @@ int tile_threads_choice(int64_t max_tile_events) {
 
 // dynamic LDS of ldati_tile_dense_kernel<NW>: S [capA] | O [capA + 2] | hist [NW][NB] | wave totals, scan partials, batch counter
 size_t dense_tile_lds(int capA, int NB, int NW) {
-    return ((size_t)2 * capA + 8 + (size_t)NW * NB + 3 * NW + NW + 1 + 2 + 18 + 2) * 4;
+    return ((size_t)2 * capA + 8 + (size_t)NW * NB + 3 * NW + NW + 1 + 2 + 18 + 10 + 2) * 4;
 }
 
 // geometry and capacities of the two-level path
@@ -3081,17 +3131,22 @@ namespace {
 struct FusedLayout {
     Plan p0;
     size_t off_abs, off_rec, off_roff, bytes;
+    int slot_cap;                        // dense mode: records per (tile, bin) slot (= the tile pass's LDS capacity); 0 = sparse mode
     bool ok;
 };
-FusedLayout make_fused_layout(const HostScalars &h, const Opts &o, int B, int H, int W, int64_t seg_hint) {
+// tile_bin_hint = 0: the sparse kernel's fused form (a slot of kSparseCap records per tile);  > 0: the dense kernel's (a slot per
+// (tile, bin), sized from the caller's expectation of the densest one)
+FusedLayout make_fused_layout(const HostScalars &h, const Opts &o, int B, int H, int W, int64_t seg_hint, int64_t tile_bin_hint = 0) {
     FusedLayout F{};
-    F.p0 = make_plan(h, B, H, W, 0, seg_hint > 0 ? seg_hint : 0, 0);
+    F.p0 = make_plan(h, B, H, W, 0, seg_hint > 0 ? seg_hint : 0, tile_bin_hint > 0 ? tile_bin_hint : 0);
     const Plan &p = F.p0;
-    const size_t n_abs = (size_t)B * 9 * p.Tp, n_rec = (size_t)B * p.T * kSparseCap;
+    F.slot_cap = tile_bin_hint > 0 ? p.capA : 0;
+    const size_t n_abs = (size_t)B * 9 * p.Tp, n_rec = F.slot_cap ? (size_t)B * p.T * 9 * (size_t)F.slot_cap : (size_t)B * p.T * kSparseCap;
     F.ok = h.ok && p.T <= kMaxTiles && p.NB <= kMaxNB && p.PB <= 22 && B * 9 <= 65535 && n_rec < (1ull << 32) &&
-           9ll * ((long long)p.NB << p.shift) < (1ll << 20) &&
+           (F.slot_cap ? (p.capA <= kCapTile && !o.bidir && dense_tile_lds(p.capA, p.NB, 16) <= 160 * 1024 && !getenv("V2CE_LDATI_OLD_TILE"))
+                       : 9ll * ((long long)p.NB << p.shift) < (1ll << 20) && !getenv("V2CE_LDATI_NO_SPARSE")) &&
            (o.strategy == V2CE_STRATEGY_SLOPE || o.strategy == V2CE_STRATEGY_NONE) && o.pooling == V2CE_POOL_NONE &&
-           !getenv("V2CE_LDATI_NO_SPARSE") && !getenv("V2CE_LDATI_NO_FUSED");
+           !getenv("V2CE_LDATI_NO_FUSED");
     F.off_abs = 16;
     F.off_rec = (F.off_abs + n_abs * 4 + 15) / 16 * 16;
     F.off_roff = (F.off_rec + n_rec * 4 + 15) / 16 * 16;
@@ -3146,19 +3201,39 @@ int fill_params(LdatiParams &P, const HostScalars &h, const Opts &o, const float
 
 }  // namespace
 
+namespace {
+// the round-4 dense tile kernel serves the common call (forward relocation, 'slope' with the device tables of this fps or 'none',
+// no pooling, 32-bit times); everything else stays on the per-bin kernel
+bool dense_kernel_serves(const LdatiParams &P, const Opts &o) {
+    return !o.bidir && !P.kbb && P.ts32 && !getenv("V2CE_LDATI_OLD_TILE") &&
+           (o.strategy == V2CE_STRATEGY_NONE || (o.strategy == V2CE_STRATEGY_SLOPE && P.fast_slot >= 0));
+}
+int launch_dense_kernel(const LdatiParams &P, const Plan &pl, int B, hipStream_t st) {
+    const size_t lds8 = dense_tile_lds(pl.capA, pl.NB, 8), lds16 = dense_tile_lds(pl.capA, pl.NB, 16);
+    static const int force_nw = [] { const char *e = getenv("V2CE_LDATI_DENSE_NW"); return e ? atoi(e) : 0; }();   // kernel A/B runs
+    const bool w8 = force_nw == 16 ? false : (force_nw == 8 && lds8 <= 160 * 1024) ? true : lds8 <= 80 * 1024;       // two workgroups per CU
+    auto dk = w8 ? ldati_tile_dense_kernel<8> : ldati_tile_dense_kernel<16>;
+    const size_t lds = w8 ? lds8 : lds16;
+    V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(dk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(dk, dim3(pl.T, B), dim3(w8 ? 512 : 1024), lds, st, P);
+    return V2CE_OK;
+}
+}  // namespace
+
 extern "C" size_t v2ce_ldati_fused_ws_bytes(int B, int H, int W, double fps, double t0, const v2ce_ldati_options *options,
-                                            int64_t expected_max_segment_events) {
+                                            int64_t expected_max_segment_events, int64_t expected_max_tile_bin_events) {
     if (!(fps > 0) || B <= 0 || H <= 0 || W <= 0 || (long long)H * W >= (1ll << 30)) return 0;
     Opts o;
     if (read_options(options, o, "v2ce_ldati_fused_ws_bytes")) return 0;
     const HostScalars h = host_scalars(fps, t0, o.bidir, o.strategy == V2CE_STRATEGY_RANDOM);
-    const FusedLayout F = make_fused_layout(h, o, B, H, W, expected_max_segment_events);
+    const FusedLayout F = make_fused_layout(h, o, B, H, W, expected_max_segment_events, expected_max_tile_bin_events);
     return F.ok ? F.bytes : 0;
 }
 
 extern "C" int v2ce_ldati_count_fused(const float *vox, int B, int H, int W, double fps, double t0,
                                       const v2ce_ldati_options *options, int rng_mode, const float *uniforms, int replay_max_n,
-                                      uint64_t seed, int64_t frame_base, int64_t expected_max_segment_events, void *tile_ws,
+                                      uint64_t seed, int64_t frame_base, int64_t expected_max_segment_events,
+                                      int64_t expected_max_tile_bin_events, void *tile_ws,
                                       size_t tile_ws_bytes, void *fused_ws, size_t fused_ws_bytes, int64_t *seg_offsets, int64_t *stats,
                                       v2ce_stream_t stream) {
     clear_error();
@@ -3175,7 +3250,7 @@ extern "C" int v2ce_ldati_count_fused(const float *vox, int B, int H, int W, dou
     Opts o;
     if (int rc = read_options(options, o, "v2ce_ldati_count_fused")) return rc;
     const HostScalars h = host_scalars(fps, t0, o.bidir, false);
-    const FusedLayout F = make_fused_layout(h, o, B, H, W, expected_max_segment_events);
+    const FusedLayout F = make_fused_layout(h, o, B, H, W, expected_max_segment_events, expected_max_tile_bin_events);
     V2CE_REQUIRE(F.ok, V2CE_ERR_UNSUPPORTED, "v2ce_ldati_count_fused: these arguments have no fused path (v2ce_ldati_fused_ws_bytes = 0)");
     V2CE_REQUIRE(tile_ws_bytes >= v2ce_ldati_tile_ws_bytes(B, H, W), V2CE_ERR_WORKSPACE,
                  "v2ce_ldati_count_fused: tile workspace %zu < %zu", tile_ws_bytes, v2ce_ldati_tile_ws_bytes(B, H, W));
@@ -3199,9 +3274,22 @@ extern "C" int v2ce_ldati_count_fused(const float *vox, int B, int H, int W, dou
     P.tile_abs_w = reinterpret_cast<unsigned *>(fb + F.off_abs);
     P.temp = reinterpret_cast<unsigned *>(fb + F.off_rec);
     P.roff = reinterpret_cast<unsigned short *>(fb + F.off_roff);
+    if (F.slot_cap && dense_kernel_serves(P, o)) {
+        // dense regime: ldati_tile_dense_kernel is the count pass and the tile pass at once (slot mode)
+        P.sparse_cap = 0;
+        P.slot_cap = F.slot_cap;
+        P.capA = pl.capA;
+        launch_dense_kernel(P, pl, B, s);
+    } else if (F.slot_cap) {
+        // (a call the dense kernel does not serve -- more than seven fps values on this device, 64-bit times: the plain count
+        // pass, so that the emit phase finds valid counts and takes the two-pass path)
+        hipLaunchKernelGGL(ldati_count_tiles_kernel, dim3(pl.T, B), dim3(kCountThreads), 0, s, vox, H * W, pl.tpp, o.strategy, o.bidir, tc,
+                           reinterpret_cast<unsigned long long *>(stats));
+    } else {
     V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ldati_tile_sparse_kernel<true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSparseLds));
     hipLaunchKernelGGL(ldati_tile_sparse_kernel<true>, dim3(pl.T, B), dim3(kSparseThreads), kSparseLds, s, P);
+    }
     hipLaunchKernelGGL(ldati_tile_scan_kernel, dim3((B * 9 + 3) / 4), dim3(256), 0, s, tc, B, pl.T, tile_off, tile_off + (size_t)B * pl.T * 9, pl.Tp,
                        reinterpret_cast<long long *>(seg_offsets), reinterpret_cast<unsigned long long *>(stats));
     hipLaunchKernelGGL(ldati_seg_scan_kernel, dim3(1), dim3(256), 0, s, B * 9, reinterpret_cast<long long *>(seg_offsets),
@@ -3218,7 +3306,8 @@ int emit_impl(const float *vox, int B, int H, int W, double fps, double t0,
                                int8_t *p, uint8_t *packed, int64_t total_events,
                                int64_t max_segment_events, int64_t max_tile_events, const void *tile_ws,
                                void *workspace, size_t workspace_bytes, v2ce_stream_t stream,
-                               const void *fused_ws, size_t fused_ws_bytes, int64_t fused_tile_max, int64_t fused_seg_hint) {
+                               const void *fused_ws, size_t fused_ws_bytes, int64_t fused_tile_max, int64_t fused_seg_hint,
+                               int64_t fused_tile_bin_hint) {
     clear_error();
     V2CE_REQUIRE(vox && seg_offsets, V2CE_ERR_BAD_ARG, "v2ce_ldati_emit: null pointer");
     V2CE_REQUIRE(B > 0 && H > 0 && W > 0 && (long long)H * W < (1ll << 30), V2CE_ERR_BAD_ARG,
@@ -3282,20 +3371,7 @@ int emit_impl(const float *vox, int B, int H, int W, double fps, double t0,
             P.kbb = kbb;
         }
         auto launch_tile_pass = [&]() -> int {
-            // the round-4 dense kernel serves the common call; everything else stays on the per-bin kernel
-            const size_t lds8 = dense_tile_lds(pl.capA, pl.NB, 8), lds16 = dense_tile_lds(pl.capA, pl.NB, 16);
-            const bool dense_ok = !L.generic && !o.bidir && !P.kbb && P.ts32 && !getenv("V2CE_LDATI_OLD_TILE") &&
-                                  (o.strategy == V2CE_STRATEGY_NONE || (o.strategy == V2CE_STRATEGY_SLOPE && P.fast_slot >= 0)) &&
-                                  lds16 <= 160 * 1024;
-            if (dense_ok) {
-                static const int force_nw = [] { const char *e = getenv("V2CE_LDATI_DENSE_NW"); return e ? atoi(e) : 0; }();   // kernel A/B runs
-                const bool w8 = force_nw == 16 ? false : (force_nw == 8 && lds8 <= 160 * 1024) ? true : lds8 <= 80 * 1024;       // two workgroups per CU
-                auto dk = w8 ? ldati_tile_dense_kernel<8> : ldati_tile_dense_kernel<16>;
-                const size_t lds = w8 ? lds8 : lds16;
-                V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(dk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(dk, dim3(pl.T, B), dim3(w8 ? 512 : 1024), lds, st, P);
-                return V2CE_OK;
-            }
+            if (!L.generic && dense_kernel_serves(P, o) && dense_tile_lds(pl.capA, pl.NB, 16) <= 160 * 1024) return launch_dense_kernel(P, pl, B, st);
             auto tile_kernel = o.bidir ? (pl.tile_threads == 512 ? ldati_tile_pass_kernel<512, 4, true> : ldati_tile_pass_kernel<1024, 2, true>)
                                        : (pl.tile_threads == 512 ? ldati_tile_pass_kernel<512, 4, false> : ldati_tile_pass_kernel<1024, 2, false>);
             V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(tile_kernel),
@@ -3350,12 +3426,15 @@ int emit_impl(const float *vox, int B, int H, int W, double fps, double t0,
         V2CE_HIP_CHECK(hipMemsetAsync(P.status, 0, 4 * sizeof(int), st));
         // the fused count already ran the sparse tile pass: usable when its assumed geometry is the plan's and every tile fitted
         bool fused = false;
-        if (fused_ws && P.sparse_cap && !P.kbb) {
-            const FusedLayout F = make_fused_layout(h, o, B, H, W, fused_seg_hint);
-            fused = F.ok && fused_ws_bytes >= F.bytes && fused_tile_max <= kSparseCap && F.p0.shift == pl.shift && F.p0.NB == pl.NB && F.p0.T == pl.T;
+        if (fused_ws && !P.kbb && (fused_tile_bin_hint > 0 || P.sparse_cap)) {
+            const FusedLayout F = make_fused_layout(h, o, B, H, W, fused_seg_hint, fused_tile_bin_hint);
+            // sparse form: every tile fitted its slot; dense form: the dense kernel ran (count_fused's own test) and every (tile, bin) run fitted
+            fused = F.ok && fused_ws_bytes >= F.bytes && F.p0.shift == pl.shift && F.p0.NB == pl.NB && F.p0.T == pl.T &&
+                    (F.slot_cap ? dense_kernel_serves(P, o) && max_tile_events <= F.slot_cap : fused_tile_max <= kSparseCap);
             if (getenv("V2CE_LDATI_DEBUG"))
                 fprintf(stderr, "v2ce_ldati_emit_fused: fused=%d ok=%d bytes %zu/%zu tile_max=%lld shift %d/%d NB %d/%d T %d/%d max_segment %lld sort threads %d cap2 %d\n", (int)fused, (int)F.ok,
                         fused_ws_bytes, F.bytes, (long long)fused_tile_max, F.p0.shift, pl.shift, F.p0.NB, pl.NB, F.p0.T, pl.T, (long long)max_segment_events, pl.sort_threads, pl.cap2);
+            if (getenv("V2CE_LDATI_DEBUG") && F.slot_cap) fprintf(stderr, "   dense slots of %d records, largest (tile, bin) %lld\n", F.slot_cap, (long long)max_tile_events);
             if (fused) {
                 const unsigned char *fb = static_cast<const unsigned char *>(fused_ws);
                 P.fused_status = reinterpret_cast<const int *>(fb);
@@ -3414,7 +3493,7 @@ extern "C" int v2ce_ldati_emit(const float *vox, int B, int H, int W, double fps
                                void *workspace, size_t workspace_bytes, v2ce_stream_t stream) {
     return emit_impl(vox, B, H, W, fps, t0, options, rng_mode, uniforms, replay_max_n, seed, frame_base, seg_offsets, frame_ts_add, ts, x,
                      y, p, packed, total_events, max_segment_events, max_tile_events, tile_ws, workspace, workspace_bytes, stream,
-                     nullptr, 0, 0, 0);
+                     nullptr, 0, 0, 0, 0);
 }
 
 extern "C" int v2ce_ldati_emit_fused(const float *vox, int B, int H, int W, double fps, double t0,
@@ -3424,10 +3503,11 @@ extern "C" int v2ce_ldati_emit_fused(const float *vox, int B, int H, int W, doub
                                      int8_t *p, uint8_t *packed, int64_t total_events,
                                      int64_t max_segment_events, int64_t max_tile_events, const void *tile_ws,
                                      void *workspace, size_t workspace_bytes, const void *fused_ws, size_t fused_ws_bytes,
-                                     int64_t largest_tile_events, int64_t expected_max_segment_events, v2ce_stream_t stream) {
+                                     int64_t largest_tile_events, int64_t expected_max_segment_events,
+                                     int64_t expected_max_tile_bin_events, v2ce_stream_t stream) {
     return emit_impl(vox, B, H, W, fps, t0, options, rng_mode, uniforms, replay_max_n, seed, frame_base, seg_offsets, frame_ts_add, ts, x,
                      y, p, packed, total_events, max_segment_events, max_tile_events, tile_ws, workspace, workspace_bytes, stream,
-                     fused_ws, fused_ws_bytes, largest_tile_events, expected_max_segment_events);
+                     fused_ws, fused_ws_bytes, largest_tile_events, expected_max_segment_events, expected_max_tile_bin_events);
 }
 
 extern "C" int v2ce_ldati_plan_info(int B, int H, int W, double fps, double t0, const v2ce_ldati_options *options,

@@ -102,12 +102,12 @@ def lib() -> ctypes.CDLL:
     L.v2ce_ldati_lds_bytes.restype = sz
     L.v2ce_ldati_emit.argtypes = [vp, i32, i32, i32, f64, f64, op, i32, vp, i32, u64, i64, vp, vp,
                                   vp, vp, vp, vp, vp, i64, i64, i64, vp, vp, sz, vp]
-    L.v2ce_ldati_fused_ws_bytes.argtypes = [i32, i32, i32, f64, f64, op, i64]
+    L.v2ce_ldati_fused_ws_bytes.argtypes = [i32, i32, i32, f64, f64, op, i64, i64]
     L.v2ce_ldati_fused_ws_bytes.restype = sz
-    L.v2ce_ldati_count_fused.argtypes = [vp, i32, i32, i32, f64, f64, op, i32, vp, i32, u64, i64, i64, vp, sz, vp, sz, vp, vp, vp]
+    L.v2ce_ldati_count_fused.argtypes = [vp, i32, i32, i32, f64, f64, op, i32, vp, i32, u64, i64, i64, i64, vp, sz, vp, sz, vp, vp, vp]
     L.v2ce_ldati_count_fused.restype = ctypes.c_int
     L.v2ce_ldati_emit_fused.argtypes = [vp, i32, i32, i32, f64, f64, op, i32, vp, i32, u64, i64, vp, vp,
-                                        vp, vp, vp, vp, vp, i64, i64, i64, vp, vp, sz, vp, sz, i64, i64, vp]
+                                        vp, vp, vp, vp, vp, i64, i64, i64, vp, vp, sz, vp, sz, i64, i64, i64, vp]
     L.v2ce_ldati_emit_fused.restype = ctypes.c_int
     L.v2ce_ldati_workspace_bytes.argtypes = [i32, i32, i32, f64, f64, op, i64, i64, i64, i32]
     L.v2ce_ldati_workspace_bytes.restype = sz
