@@ -3143,7 +3143,8 @@ FusedLayout make_fused_layout(const HostScalars &h, const Opts &o, int B, int H,
     F.slot_cap = tile_bin_hint > 0 ? p.capA : 0;
     const size_t n_abs = (size_t)B * 9 * p.Tp, n_rec = F.slot_cap ? (size_t)B * p.T * 9 * (size_t)F.slot_cap : (size_t)B * p.T * kSparseCap;
     F.ok = h.ok && p.T <= kMaxTiles && p.NB <= kMaxNB && p.PB <= 22 && B * 9 <= 65535 && n_rec < (1ull << 32) &&
-           (F.slot_cap ? (p.capA <= kCapTile && !o.bidir && dense_tile_lds(p.capA, p.NB, 16) <= 160 * 1024 && !getenv("V2CE_LDATI_OLD_TILE"))
+           (F.slot_cap ? (p.capA <= kCapTile && !o.bidir && dense_tile_lds(p.capA, p.NB, 16) <= 160 * 1024 && !getenv("V2CE_LDATI_OLD_TILE") &&
+                          n_rec <= (1ull << 30))                 // (at most 4 GiB of slots: beyond that the count pass is the cheaper price)
                        : 9ll * ((long long)p.NB << p.shift) < (1ll << 20) && !getenv("V2CE_LDATI_NO_SPARSE")) &&
            (o.strategy == V2CE_STRATEGY_SLOPE || o.strategy == V2CE_STRATEGY_NONE) && o.pooling == V2CE_POOL_NONE &&
            !getenv("V2CE_LDATI_NO_FUSED");
