@@ -140,7 +140,8 @@ int v2ce_ldati_status(const void *workspace, int B, int H, int W, double fps, do
  * batch's stats[1] plus a margin; 0 selects the sparse form above): the dense tile kernel is the count pass and the tile pass
  * at once, every (tile, bin) run in its own slot of that many records (rounded up to 256); v2ce_ldati_emit_fused uses the
  * slots when max_tile_events = stats[1] fits them and the geometry matches, and repeats the tile pass on the two-pass path
- * otherwise -- same bytes either way.  The same two expectations go to all three functions of a call. */
+ * otherwise -- same bytes either way.  The same two expectations go to all three functions of a call.  No dense form
+ * (v2ce_ldati_fused_ws_bytes = 0) for bidirectional relocation, 'random', pooled slope, or when the slots would exceed 4 GiB. */
 size_t v2ce_ldati_fused_ws_bytes(int B, int H, int W, double fps, double t0, const v2ce_ldati_options *options,
                                  int64_t expected_max_segment_events, int64_t expected_max_tile_bin_events);
 int v2ce_ldati_count_fused(const float *vox, int B, int H, int W, double fps, double t0, const v2ce_ldati_options *options,
