@@ -561,6 +561,22 @@ def test_c_abi_fused_dense_call_sequence(monkeypatch, capfd):
         hint, bin_hint = max_seg, max_tile + 64
 
 
+def test_fused_dense_form_falls_back_for_calls_the_dense_kernel_does_not_serve():
+    """Dense voxels at t0 = 3000 s need 64-bit times: the dense tile kernel does not serve such a call.  With the expectations of
+    a dense stream ldati_begin still asks for the dense form of the fused count; the library then runs the plain count pass
+    inside it and the emit takes the two-pass path (per-bin kernel).  Three consecutive calls (no history / dense expectation /
+    whatever the second left behind) all give the oracle's events; the same at fps 10 with bidirectional relocation (no
+    dense form at all: v2ce_ldati_fused_ws_bytes = 0)."""
+    rng = np.random.default_rng(17)
+    vox = (5.0 * rng.random((2, 2, 10, 64, 160))).astype(np.float32)
+    want = O.emit_soa(vox, fps=30, t0=3000.0, seed=21, frame_base=1)
+    for _ in range(3):
+        soa_equal(hip_events(vox, 30, 3000.0, seed=21, frame_base=1), *want)
+    want = O.emit_soa(vox, fps=10, seed=22, bidirectional=True)
+    for _ in range(3):
+        soa_equal(hip_events(vox, 10, 0, seed=22, bidirectional=True), *want)
+
+
 def test_c_abi_fused_call_sequence():
     """The call sequence INTEGRATION.md gives a maintainer of the reference, through ctypes alone (no LDATI.py): hint 0 ->
     v2ce_ldati_fused_ws_bytes -> v2ce_ldati_count_fused -> read stats -> v2ce_ldati_workspace_bytes -> v2ce_ldati_emit_fused;
