@@ -430,12 +430,14 @@ def main():
 
     # ---- per-kernel HIP-event timings collected inside the timed region
     per = {}
-    for name, flops, e0, e1 in conv_prof:
-        d = per.setdefault(name, [0.0, 0.0, 0])
+    for name, flops, e0, e1, executed in conv_prof:
+        d = per.setdefault(name, [0.0, 0.0, 0, 0.0])
         d[0] += e0.elapsed_time(e1) * 1e-3
-        d[1] += flops
+        d[1] += flops                   # algorithmic: the reference convolution's multiply-adds
         d[2] += 1
-    kernels = {k: {"launches": v[2], "avg_ms": 1e3 * v[0] / v[2], "tflops": v[1] / v[0] / 1e12}
+        d[3] += executed                # what the launch multiplies (less for the phase-folded decoder kernels)
+    kernels = {k: {"launches": v[2], "avg_ms": 1e3 * v[0] / v[2], "tflops": v[1] / v[0] / 1e12,
+                   **({"executed_tflops": v[3] / v[0] / 1e12} if v[3] != v[1] else {})}
                for k, v in sorted(per.items(), key=lambda kv: -kv[1][0])}
     # LDATI = count kernels + emit kernels (the host read of the segment table between them is not GPU time)
     em = [(e0.elapsed_time(e1) * 1e-3, nb) for tag, e0, e1, nb in ldati_prof if tag == "emit"]
@@ -450,18 +452,22 @@ def main():
     if model is not None:
         name = max(per, key=lambda k: per[k][0])
         v = per[name]
-        split = "f16x2" in name
+        split = "f16x2" in name or "up_kernel" in name
         peak = PEAK_SPLIT_TFLOPS if split else PEAK_F32_MATRIX_TFLOPS
-        ws3 = [q[1] / q[0] / 1e12 / PEAK_SPLIT_TFLOPS for k, q in per.items() if "ws_kernel<3," in k]
+        ws3 = [q[3] / q[0] / 1e12 / PEAK_SPLIT_TFLOPS for k, q in per.items() if "ws_kernel<3," in k or "up_kernel<" in k]
         roofline = {"bound": "mfma", "kernel": name, "achieved": v[1] / v[0] / 1e12,
                     "peak": peak, "unit": "TFLOP/s",
                     "frac": v[1] / v[0] / 1e12 / peak, "traffic": None,
                     "avg_launch_ms": 1e3 * v[0] / v[2], "flop_per_launch": v[1] / v[2],
+                    "executed_flop_per_launch": v[3] / v[2], "executed_frac": v[3] / v[0] / 1e12 / peak,
                     "peak_note": ("algorithmic (f32-equivalent) FLOP; the kernel executes 3 fp16 MFMAs per product, so "
                                   f"peak = dense fp16 MFMA peak {PEAK_F16_MATRIX_TFLOPS:.0f} / 3") if split else
                                  "dense f32 MFMA peak",
                     "all_conv_tflops": sum(q[1] for q in per.values()) / sum(q[0] for q in per.values()) / 1e12,
-                    "min_3x3x3_split_variant_frac": min(ws3) if ws3 else None}
+                    "min_3x3x3_split_variant_frac": min(ws3) if ws3 else None,
+                    "frac_note": "achieved / frac count the ALGORITHMIC flop of the reference's convolution (SURVEY 8d: 135.58 GFLOP per "
+                                 "frame-pair); executed_* count what the launch really multiplies (the decoder conv1 kernels fold the "
+                                 "2x-upsampled channels' 27 taps into 12: DESIGN 4.1e); min_3x3x3_split_variant_frac is on executed flop"}
     else:
         roofline = {"bound": "hbm", "kernel": "v2ce_ldati_count + v2ce_ldati_emit (count_tiles, tile_scan, tile_pass, bucket_scan, bucket_sort)",
                     "achieved": ldati["achieved_GBps"],
@@ -532,6 +538,10 @@ def main():
             if model is not None else None,
             "roofline": roofline, "ldati": ldati, "kernels": kernels,
         }
+        if model is not None and per:
+            n_fw = total_pairs / world        # frame-pairs this rank's profiled launches covered
+            line["executed_flop_per_pair"] = sum(q[3] for q in per.values()) / n_fw
+            line["algorithmic_flop_per_pair"] = sum(q[1] for q in per.values()) / n_fw
         if model is not None and args.precision == "f16x2":
             # the split-half range guard over the timed steps: worst per-launch bound vs its limit
             line["range_guard"] = {"worst_bound": model.range_guard_value(), "limit": model.RANGE_GUARD_LIMIT}

@@ -332,6 +332,28 @@ int v2ce_conv3d_fwd_tail(const v2ce_conv3d_desc *desc, const float *x0, const fl
                          const int32_t *thmap, const int32_t *twmap, const void *tail_w,
                          const float *tx0_absmax, const float *tx1_absmax, v2ce_stream_t stream);
 
+/* conv1 of a decoder block (scripts/unet_2layer.py:358-365, scripts/submodules.py:249-264): the 3x3x3 conv whose input is the
+ * virtual concat  nearest-upsample-2x(x0) ++ x1, with the upsampled channels PHASE-FOLDED.  ATen's nearest map for an exact
+ * 2x size ratio (H0 = ceil(Hin / 2), W0 = ceil(Win / 2): every decoder size of the network) is src = dst >> 1, so an output
+ * position of parity (ph, pw) sees only 2 x 2 distinct source pixels through its 3 x 3 (H, W) taps: 12 taps with pre-summed
+ * weights instead of 27 on the C0 channels (5/9 of their multiplies never happen; 16.5 % of the whole network's).  Odd output
+ * sizes (the last, even, row / column has the convolution's zero padding as its +1 neighbour) are exact through correction
+ * lists in the tiles that hold that row / column (csrc/conv3d_up.hip).  Same result as v2ce_conv3d_fwd[_sc] on the same
+ * tensors up to the summation order of the pre-summed weights (f32 sums of <= 4 quotients w / sigma).
+ * desc: ksize 3, stride 1, precision F16X2, layout C16, H0 = ceil(Hin / 2), W0 = ceil(Win / 2), C0 % 16 == C1 % 16 == 0, C1 > 0,
+ * Cout % 32 == 0; no index maps (the map is implied).  w_up = buffer of v2ce_pack_weights_f16x2_up: a v2ce_pack_weights_f16x2
+ * buffer of the [Cout][C0 + C1][27] weights (valid as w_packed of v2ce_conv3d_fwd too) followed by the folded region of the
+ * first C0 input channels (108 tap slots of [C0 / 16][Cout][16] per fp16 plane), one common power-of-two pre-scale.
+ * sc_w .. sc_y: optional fused 1x1x1 shortcut exactly as v2ce_conv3d_fwd_sc (Cout <= 32); all NULL otherwise. */
+size_t v2ce_pack_weights_f16x2_up_bytes(int Cout, int C0, int C1);
+int v2ce_pack_weights_f16x2_up(const float *w, int Cout, int C0, int C1, const float *sigma, void *w_up, v2ce_stream_t stream);
+int v2ce_conv3d_fwd_up2(const v2ce_conv3d_desc *desc, const float *x0, const float *x1, const void *w_up,
+                        const float *scale, const float *shift, float *y, const float *x0_absmax,
+                        const float *x1_absmax, float *y_absmax, const void *sc_w, const float *sc_scale,
+                        const float *sc_shift, float *sc_y, v2ce_stream_t stream);
+/* Name of the kernel instantiation v2ce_conv3d_fwd_up2 would launch ("conv3d_up_kernel<WCO,CO_FR,PO_FR,FUSE>"). */
+int v2ce_conv3d_up2_variant(const v2ce_conv3d_desc *desc, int with_shortcut, char *name, size_t cap);
+
 /* Name of the kernel instantiation v2ce_conv3d_fwd would launch for desc ("conv3d_kernel<KS,S,
  * CO_FR,PO_FR,CK,EPT>", as it appears demangled in rocprofv3 traces); mapped != 0 means hmap/wmap
  * would be non-NULL.  Launches nothing.  Used by bench.py to attribute event timings. */
@@ -412,7 +434,9 @@ typedef struct {
     const float *w_bar;   /* [rows][cols] */
     float *u, *v;         /* [rows], [cols]: updated in place */
     void *packed;         /* out */
-    int32_t rows, cols, k3, reserved;
+    int32_t rows, cols, k3;
+    int32_t up_c0;        /* 0, or: `packed` is a v2ce_pack_weights_f16x2_up buffer (decoder conv1, v2ce_conv3d_fwd_up2) whose first
+                           * up_c0 input channels -- the nearest-upsampled source -- are also packed phase-folded */
 } v2ce_sn_layer;
 size_t v2ce_sn_batch_workspace_bytes(const v2ce_sn_layer *layers, int n);
 int v2ce_sn_update_batch(const v2ce_sn_layer *layers, int n, void *workspace, size_t workspace_bytes,

@@ -48,4 +48,11 @@ __host__ __device__ __forceinline__ float pow2_prescale(float amax) {
 }
 
 
+// internals shared between translation units (conv3d.hip, conv3d_up.hip, sn.hip)
+int v2ce_pack_weights_f16x2_absmax_only(const float *w, int Cout, int Cin, int k3, const float *sigma, void *w_f16x2, v2ce_stream_t stream);
+int v2ce_pack_weights_f16x2_pack_only(const float *w, int Cout, int Cin, int k3, const float *sigma, void *w_f16x2, v2ce_stream_t stream);
+// the folded region of a v2ce_pack_weights_f16x2_up buffer (conv3d_up.hip): max |folded sums| into tail[0]; the pack itself
+int v2ce_up_fold_absmax(const float *w, int Cout, int Cin, int C0, const float *sigma, void *w_up, hipStream_t st);
+int v2ce_up_fold_pack(const float *w, int Cout, int Cin, int C0, const float *sigma, void *w_up, hipStream_t st);
+
 }  // namespace v2ce

@@ -1,0 +1,842 @@
+// conv3d_up.hip -- conv1 of the UNet's decoder blocks on gfx950: a 3x3x3 convolution whose input is the
+// VIRTUAL concatenation  nearest-upsample-2x(x0) ++ x1  (/root/reference/scripts/unet_2layer.py:358-365,
+// /root/reference/scripts/submodules.py:249-264), with the upsampled part PHASE-FOLDED.
+//
+// ATen's nearest map for every decoder size of this network is src = dst >> 1 (H0 = ceil(Hin / 2)), so an
+// output position of parity (ph, pw) sees, through the 3x3 (H, W) taps on an upsampled channel, only 2x2
+// distinct source pixels:
+//     even row h = 2i:   w[-1] x[i-1] + (w[0] + w[+1]) x[i]          ("E": 2 taps)
+//     odd  row h = 2i+1: (w[-1] + w[0]) x[i] + w[+1] x[i+1]          ("O": 2 taps)
+// and the same along W: 12 taps with pre-summed weights instead of 27 on the C0 channels -- 5/9 of their
+// multiplies (16.5 % of the whole network's) never happen, and the low-resolution halo box staged per chunk
+// is a third of the mapped one.  The skip channels (x1) keep their 27 taps.
+// One exception: when Hout (Wout) is odd, the LAST row (column) is an even one whose +1 neighbour is the
+// convolution's zero padding, not x[i] again: the folded tap (w[0] + w[+1]) x[i] carries a phantom w[+1] x[i].
+// Tiles that contain that row (column) run, behind the folded list of an even phase, a CORRECTION list of the same
+// shape -- 12 taps with the weights -w[+1] (folded along the other axis) on the taps that read x[i], zero elsewhere --
+// in which only the lanes of the last row (column) read the halo box; every other lane reads a zeroed region of
+// LDS.  (Corner tiles: one list per axis and a third, +w[+1][+1], for the corner lane: inclusion-exclusion.)
+//
+// Same workgroup as conv3d_f16x2_ws_kernel (conv3d.hip): 8 waves, producers 4-7 gather + split a 16-channel
+// chunk of the halo into fp16 hi / lo pieces one chunk ahead, consumers 0-3 run three fp16 MFMAs per k-step
+// with A fragments (weights) from L2 through a three-slot ring, one barrier per chunk, persistent over tiles.
+// What differs:
+//   * every 32-position MFMA fragment is PHASE-HOMOGENEOUS (its positions share (ph, pw)), all fragments of
+//     a wave's phase share the A fragment of a tap: a tile is a (TT, TH, TW) box of full-resolution outputs
+//     (TH, TW even) whose four phase sub-boxes (TT, TH/2, TW/2) each fill NFG fragments;
+//   * a chunk's taps are a LIST of consecutive tap slots of one weight region -- a folded list of 12 per phase
+//     (+ correction lists in edge tiles) on the upsampled chunks, the 27 plain taps on the skip chunks -- all
+//     multiples of three, so the ring's three slots stay static across lists, chunks and tiles;
+//   * the skip channels' halo is staged with its columns DE-INTERLEAVED (even columns, then odd ones), so the
+//     stride-2 positions of a phase read consecutive 16-byte pieces.
+#include "conv3d_dev.h"
+
+#include <cstdlib>
+
+namespace v2ce {
+namespace {
+
+// Tap slots of the folded region, 12 per list in (dt, a, b) order [plane][slot][cg][co][16]:
+//   slot 12 p            phase p = 2 ph + pw: fold_h(ph) x fold_w(pw), fold(0) = E, fold(1) = O
+//   slot 48 + 12 pw      H correction of phase (0, pw): -w[.][+1][fold_w(pw)] at a = 1
+//   slot 72 + 12 ph      W correction of phase (ph, 0): -w[.][fold_h(ph)][+1] at b = 1
+//   slot 96              corner correction of phase (0, 0): +w[.][+1][+1] at (a, b) = (1, 1)
+constexpr int kUpSlots = 108;
+constexpr int kUpListTaps = 12;
+
+// source taps of folded tap t (0, 1) of an axis: bit k set = w[k - 1] takes part.  odd = 0: E = w[-1] | w[0] + w[+1];
+// odd = 1: O = w[-1] + w[0] | w[+1]
+__host__ __device__ inline int up_axis_mask(int odd, int t) { return odd ? (t == 0 ? 3 : 4) : (t == 0 ? 1 : 6); }
+// weight of slot list `li` (0 .. 8), tap (a, b), as masks over (dh, dw) and a sign; 0 masks = a zero weight
+__host__ __device__ inline void up_list_masks(int li, int a, int b, int &mh, int &mw, int &sign) {
+    sign = 1;
+    if (li < 4) { mh = up_axis_mask(li >> 1, a); mw = up_axis_mask(li & 1, b); return; }
+    sign = -1;
+    if (li < 6) { mh = a == 1 ? 4 : 0; mw = up_axis_mask(li - 4, b); return; }          // H correction: the +1 row
+    if (li < 8) { mh = up_axis_mask(li - 6, a); mw = b == 1 ? 4 : 0; return; }          // W correction: the +1 column
+    sign = 1; mh = a == 1 ? 4 : 0; mw = b == 1 ? 4 : 0;                                  // corner
+}
+
+struct UpParams {
+    ConvParams C;
+    int SH, SW, n_sub;            // phase sub-box (TH / 2, TW / 2), its positions TT * SH * SW
+    int HH0, HW0, plane0;         // low-resolution halo box (TT + 2) x (SH + 2) x (SW + 2)
+    int zero0;                    // first piece of the zeroed region of an upsampled chunk's planes (edge tiles; >= plane0)
+    int chs;                      // pieces per plane of the LDS buffers (>= the skip halo, >= zero0 + plane0)
+    int HWh;                      // HWd / 2: first odd column of the de-interleaved skip halo
+    int CG0;                      // C0 / 16
+    int odd_h, odd_w;
+    int fold_off;                 // bytes from wq to the folded region's hi plane
+    int fold_plane;               // bytes between its hi and lo planes
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+
+// halo offsets of the two sources (channels-last-16: byte offset of the element's 64-byte group in channel group 0
+// of its time step; kOOB = zero padding)
+//   low:  element r of the (HT, HH0, HW0) box = x0 at (t0 - 1 + ht, i0 - 1 + hr, j0 - 1 + hc)
+//   skip: element r of the (HT, HH, HWd) box, columns de-interleaved: x = r % HWd < HWh ? column 2x : column 2 (x - HWh) + 1
+template <int EPT>
+__device__ __forceinline__ void up_offsets(const UpParams &U, bool skip, int t0, int h0, int w0, int tid, unsigned (&goff)[EPT]) {
+    const ConvParams &P = U.C;
+    const int hh_n = skip ? P.HH : U.HH0, hw_n = skip ? P.HWd : U.HW0, plane = skip ? P.plane : U.plane0;
+    const int Cs = skip ? P.C1 : P.C0, Hs = skip ? P.Hin : P.H0, Ws = skip ? P.Win : P.W0, Wp = skip ? P.Winp : P.W0p;
+    const int hb = skip ? h0 - 1 : (h0 >> 1) - 1, wb = skip ? w0 - 1 : (w0 >> 1) - 1;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int r = tid + 256 * i;
+        unsigned off = kOOB;
+        if (r < plane) {
+            const int ht = r / (hh_n * hw_n);
+            const int rem = r - ht * (hh_n * hw_n);
+            const int hr = rem / hw_n;
+            int hc = rem - hr * hw_n;
+            if (skip) hc = hc < U.HWh ? 2 * hc : 2 * (hc - U.HWh) + 1;
+            const int t = t0 - 1 + ht, h = hb + hr, w = wb + hc;
+            if (t >= 0 && t < P.T && h >= 0 && h < Hs && w >= 0 && w < Ws)
+                off = 4u * (unsigned)((t * Cs) * (Hs * Wp)) + 64u * (unsigned)(h * Wp + w);
+        }
+        goff[i] = off;
+    }
+}
+
+#endif  // __HIP_DEVICE_COMPILE__
+
+// WCO: consumer waves across the channel tile (1: every wave one phase; 2: two position-waves of two phases each)
+// FUSE: 0 = plain, 2 = fused 1x1x1 shortcut (second accumulator set at the centre tap; CO_FR == 1)
+template <int WCO, int CO_FR, int PO_FR, int FUSE>
+__global__ __launch_bounds__(512, 1) void conv3d_up_kernel(UpParams U) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const ConvParams &P = U.C;
+    constexpr int CK = 16, EPT = 5, K3 = 27;
+    constexpr int NG = WCO;                       // phase groups per consumer wave
+    constexpr int NFG = PO_FR / NG;               // fragments per phase
+    static_assert(WCO == 1 || WCO == 2, "one or two phases per wave");
+    static_assert(PO_FR % NG == 0, "fragments split evenly over the phases of a wave");
+    constexpr int CO_TILE = WCO * CO_FR * 32;
+    const int chs = U.chs;
+    f16x8 *pieces = reinterpret_cast<f16x8 *>(conv_smem);                      // [2][4][chs] x 16 B
+
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int CG = P.Cin / CK, CG0 = U.CG0;
+    const long long wplane = (long long)K3 * CG * P.Cout * 16;               // halves per plane of the plain region
+    const int tap_stride = CG * P.Cout * 32, tap_stride0 = CG0 * P.Cout * 32, cg_stride = P.Cout * 32;
+
+
+    struct TileId { int b, co_t, t0, h0, w0; };
+    auto decode = [&](int vb, TileId &T) -> bool {
+        const int xcd = vb & 7, q = vb >> 3;
+        T.co_t = q % P.n_co_tiles;
+        const int sp = q / P.n_co_tiles;
+        int bid = xcd * P.per_xcd + sp;
+        if (sp >= P.per_xcd || bid >= P.n_spatial) return false;
+        const int iw = bid % P.nW;            bid /= P.nW;
+        const int ih = bid % P.nH;            bid /= P.nH;
+        const int it = bid % P.nT;            bid /= P.nT;
+        T.b = bid;
+        T.t0 = it * P.TT; T.h0 = ih * P.TH; T.w0 = iw * P.TW;
+        return true;
+    };
+    auto next_tile = [&](int &vb, TileId &T) -> bool {
+        for (; vb < P.total_blocks; vb += (int)gridDim.x)
+            if (decode(vb, T)) return true;
+        return false;
+    };
+
+    const float w_scale = reinterpret_cast<const float *>(P.wq + 2 * wplane)[1];
+    auto amax_of = [&](int b) -> float {
+        if (!P.x0_absmax) return 4094.0f;
+        float am = P.x0_absmax[b * P.amax_bs];
+        if (P.x1_absmax) am = fmaxf(am, P.x1_absmax[b * P.amax_bs]);
+        return am;
+    };
+    auto scale_of = [&](int b) -> float { return P.x0_absmax ? pow2_prescale(amax_of(b)) : kActScale; };
+    // range guard: as conv3d_f16x2_ws_kernel (tail[0] covers the folded weights too; K = Cin * 27 bounds the folded sums)
+    if (P.guard && blockIdx.x == 0 && wave == 0) {
+        auto smax = [&](const float *scale) {
+            float sm = 0.0f;
+            for (int co = lane; co < P.Cout; co += 64) sm = fmaxf(sm, fabsf(scale[co]));
+#pragma unroll
+            for (int o = 32; o; o >>= 1) sm = fmaxf(sm, __shfl_xor(sm, o));
+            return sm;
+        };
+        const float sm = smax(P.scale), smd = FUSE == 2 ? smax(P.sc_scale) : 0.0f;
+        const float *tail = reinterpret_cast<const float *>(P.wq + 2 * wplane);
+        const float *taild = reinterpret_cast<const float *>(P.sc_w + 2 * (long long)CG * P.Cout * 16);
+        const int nb = P.amax_bs ? P.B : 1;
+        for (int b = lane; b < nb; b += 64) {
+            const float am = amax_of(b), xs = scale_of(b);
+            float E = sm * (float)(P.Cin * K3) * 0x1p-25f * (tail[0] / xs + am / tail[1]);
+            if (FUSE == 2) E = fmaxf(E, smd * (float)P.Cin * 0x1p-25f * (taild[0] / xs + am / taild[1]));
+            P.guard[b * P.amax_bs] = E;
+        }
+    }
+
+    int vb = blockIdx.x;
+    TileId T;
+    if (!next_tile(vb, T)) return;
+    int gc = 0;
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ producers (see conv3d_f16x2_ws_kernel)
+        const int ptid = tid - 256;
+        float x_scale = scale_of(T.b);
+        unsigned goff[EPT];
+        float R0[CK][EPT], R1[CK][EPT];
+        __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x0), 0, 0, 0x00020000);
+        int cur_src = -1, src_cstride4 = 0;
+        auto load_chunk = [&](const TileId &L, int cidx, float (&R)[CK][EPT]) {
+            const int want_src = cidx < CG0 ? 0 : 1;
+            if (want_src != cur_src) {   // uniform; twice per tile
+                cur_src = want_src;
+                up_offsets<EPT>(U, want_src == 1, L.t0, L.h0, L.w0, ptid, goff);
+                if (want_src == 0) {
+                    const long long seq = (long long)P.T * P.C0 * (P.H0 * P.W0p);
+                    rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x0 + L.b * seq), 0, (int)(seq * 4), 0x00020000);
+                    src_cstride4 = P.H0 * P.W0p * 4;
+                } else {
+                    const long long seq = (long long)P.T * P.C1 * (P.Hin * P.Winp);
+                    rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x1 + L.b * seq), 0, (int)(seq * 4), 0x00020000);
+                    src_cstride4 = P.Hin * P.Winp * 4;
+                }
+            }
+            const int lim = want_src ? P.plane : U.plane0;
+            const int grp = want_src ? cidx - CG0 : cidx;
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) {
+                if ((wave - 4) * 64 + 256 * i < lim) {                // wave-uniform
+                    typedef float f32x4g __attribute__((ext_vector_type(4)));
+#pragma unroll
+                    for (int k4 = 0; k4 < CK / 4; ++k4) {
+                        const f32x4g v = __builtin_bit_cast(f32x4g, __builtin_amdgcn_raw_buffer_load_b128(
+                            rs_in, goff[i], grp * (src_cstride4 * 16) + 16 * k4, 0));
+                        R[4 * k4][i] = v[0]; R[4 * k4 + 1][i] = v[1]; R[4 * k4 + 2][i] = v[2]; R[4 * k4 + 3][i] = v[3];
+                    }
+                }
+            }
+        };
+        int vbL = vb, cgL = 0;
+        TileId TL = T;
+        bool moreL = true;
+        auto load_next = [&](float (&R)[CK][EPT]) {
+            if (!moreL) return;
+            load_chunk(TL, cgL, R);
+            if (++cgL == CG) {
+                cgL = 0;
+                vbL += (int)gridDim.x;
+                moreL = next_tile(vbL, TL);
+                cur_src = -1;
+            }
+        };
+        int cgC = 0;
+        auto convert = [&](const float (&R)[CK][EPT]) {
+            f16x8 *qb = pieces + (gc & 1) * 4 * chs;
+            const int lim = cgC < CG0 ? U.plane0 : P.plane;
+            // edge tiles: the region the correction lists' other lanes read (the skip chunks overwrite it every time)
+            if (cgC < CG0 && ((U.odd_h && T.h0 + P.TH >= P.Hout) || (U.odd_w && T.w0 + P.TW >= P.Wout))) {     // uniform
+                const f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int r = ptid; r < U.plane0; r += 256) {
+#pragma unroll
+                    for (int pl = 0; pl < 4; ++pl) qb[pl * chs + U.zero0 + r] = z;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) {
+                const int r = ptid + 256 * i;
+                if ((wave - 4) * 64 + 256 * i < lim) {                // wave-uniform (lanes past the box write padding)
+#pragma unroll
+                    for (int hg = 0; hg < 2; ++hg) {
+                        typedef unsigned u32x4c __attribute__((ext_vector_type(4)));
+                        u32x4c ph, pl;
+#pragma unroll
+                        for (int c2 = 0; c2 < 4; ++c2) {
+                            const float xa = R[8 * hg + 2 * c2][i], xb = R[8 * hg + 2 * c2 + 1][i];
+                            unsigned h, l;
+                            asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
+                                "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
+                                "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
+                                "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                                : "=&v"(h), "=&v"(l) : "v"(xa), "v"(xb), "v"(x_scale));
+                            ph[c2] = h;
+                            pl[c2] = l;
+                        }
+                        qb[hg * chs + r] = __builtin_bit_cast(f16x8, ph);
+                        qb[(2 + hg) * chs + r] = __builtin_bit_cast(f16x8, pl);
+                    }
+                }
+            }
+        };
+        bool moreC = true;
+        auto advance = [&]() {
+            ++gc;
+            if (++cgC == CG) {
+                cgC = 0;
+                vb += (int)gridDim.x;
+                moreC = next_tile(vb, T);
+                if (moreC) x_scale = scale_of(T.b);
+            }
+        };
+        load_next(R0);
+        load_next(R1);
+        while (moreC) {
+            convert(R0);
+            load_next(R0);
+            __syncthreads();                                          // barrier gc: pieces[gc & 1] ready
+            advance();
+            if (!moreC) break;
+            convert(R1);
+            load_next(R1);
+            __syncthreads();
+            advance();
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers
+    __builtin_amdgcn_s_setprio(2);
+    const int wco = wave % WCO, wpo = wave / WCO;
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<_Float16 *>(P.wq), 0, U.fold_off + 2 * U.fold_plane, 0x00020000);
+    const int lo_off = (int)(2 * wplane);                  // plain region: bytes from the hi plane to the lo plane
+    constexpr bool SC = FUSE == 2;
+    static_assert(!SC || CO_FR == 1, "the fused shortcut needs a second accumulator set: 32-channel wave tiles");
+    const long long wplane_d = (long long)CG * P.Cout * 16;
+    const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<_Float16 *>(SC ? P.sc_w : P.wq), 0, (int)(4 * wplane_d), 0x00020000);
+
+    f16x8 ah[3][CO_FR], al[3][CO_FR], bh[PO_FR], bl[PO_FR];
+    int wlane[CO_FR];
+#define V2CE_LOAD_A(slot_, soff_, lod_)                                                        \
+    {                                                                                          \
+        const int so_ = (soff_), sl_ = so_ + (lod_);                                           \
+        _Pragma("unroll") for (int q = 0; q < CO_FR; ++q) {                                    \
+            ah[slot_][q] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_a, wlane[q], so_, 0)); \
+            al[slot_][q] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_a, wlane[q], sl_, 0)); \
+        }                                                                                      \
+    }
+    // a tap list = consecutive tap slots of one weight region: tap t at abase + t * tstride (hi), + lod (lo)
+    struct ListRef { int abase, tstride, lod; };
+    auto phase_of = [&](int g) -> int { return wpo * NG + g; };              // phase of group g of this wave
+    auto list0 = [&](int li, int cg) -> ListRef { return ListRef{U.fold_off + li * kUpListTaps * tap_stride0 + cg * cg_stride, tap_stride0, U.fold_plane}; };
+    auto list1 = [&](int cg) -> ListRef { return ListRef{cg * cg_stride, tap_stride, lo_off}; };
+
+    int ring_key = -1;
+    bool more = true;
+    while (more) {
+        const int co0 = T.co_t * CO_TILE + wco * CO_FR * 32;
+        const float x_scale = scale_of(T.b);
+        const float inv_scale = 1.0f / (x_scale * w_scale);
+        const bool tile_h = U.odd_h && T.h0 + P.TH >= P.Hout;       // the tile holds the last (even) row
+        const bool tile_w = U.odd_w && T.w0 + P.TW >= P.Wout;
+        // piece index of this lane's position f at tap (0,0,0): in the low-resolution box while the upsampled chunks run,
+        // in the skip box behind them (recomputed at the switch: one array live instead of two).  kind > 0: the bases of a
+        // correction list -- lanes outside the output's last row (1) / last column (2) / corner (3) point into the zeroed region
+        int bb[PO_FR];
+        auto set_bases = [&](bool skip, int kind) {
+#pragma unroll
+            for (int f = 0; f < PO_FR; ++f) {
+                const int g = f / NFG, p = phase_of(g), ph = p >> 1, pw = p & 1;
+                const int s = (f - g * NFG) * 32 + l32;
+                bb[f] = half * chs;
+                bool on = kind == 0;
+                if (s < U.n_sub) {
+                    const int tt = s / (U.SH * U.SW);
+                    const int rem = s - tt * (U.SH * U.SW);
+                    const int i = rem / U.SW;
+                    const int j = rem - i * U.SW;
+                    if (skip) bb[f] += (tt * P.HH + 2 * i + ph) * P.HWd + j;
+                    else {
+                        const bool row = T.h0 + 2 * i + ph == P.Hout - 1, col = T.w0 + 2 * j + pw == P.Wout - 1;
+                        on = on || (kind == 1 && row) || (kind == 2 && col) || (kind == 3 && row && col);
+                        bb[f] += on ? (tt * U.HH0 + i + ph) * U.HW0 + j + pw : U.zero0;
+                    }
+                } else if (!on) bb[f] += U.zero0;
+            }
+        };
+        set_bases(false, 0);
+        if (T.co_t != ring_key) {                             // uniform: (re)load the ring for this channel tile
+#pragma unroll
+            for (int q = 0; q < CO_FR; ++q) {
+                int co = co0 + q * 32 + l32;
+                co = co < P.Cout ? co : P.Cout - 1;
+                wlane[q] = (co * 16 + 8 * half) * 2;
+            }
+            const ListRef L = list0(phase_of(0), 0);
+            V2CE_LOAD_A(0, L.abase, L.lod)
+            V2CE_LOAD_A(1, L.abase + L.tstride, L.lod)
+        }
+
+        f32x16 acc[CO_FR][PO_FR];
+#pragma unroll
+        for (int q = 0; q < CO_FR; ++q)
+#pragma unroll
+            for (int f = 0; f < PO_FR; ++f)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[q][f][r] = 0.0f;
+        f32x16 accd[SC ? CO_FR : 1][SC ? PO_FR : 1];
+        if constexpr (SC) {
+#pragma unroll
+            for (int q = 0; q < CO_FR; ++q)
+#pragma unroll
+                for (int f = 0; f < PO_FR; ++f)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) accd[q][f][r] = 0.0f;
+        }
+        f16x8 ahd[CO_FR], ald[CO_FR];                        // this chunk's shortcut weights
+
+        // ---- one tap list over fragments [F0, F0 + NF), fully unrolled.  Slots 0 / 1 of the ring hold its taps 0 / 1 on
+        // entry and the next list's on exit.
+        //   SKIP:   the skip chunks' 27 taps; the piece offset of (dh, dw) depends on the fragment's column parity pw
+        //           (columns are de-interleaved in LDS)
+        //   !SKIP:  12 folded taps (dt, a, b) of the low-resolution box (a correction list runs on bases that send the lanes
+        //           it does not apply to into the zeroed region)
+        //   rc:     (fused shortcut; -1 = none) the tap in [4, 8) that reads x[i][j] itself
+        auto run_list = [&](auto F0c, auto NFc, auto SKIPc, int rc, const ListRef cur, const ListRef nxt, const f16x8 *qb) {
+            constexpr int F0 = decltype(F0c)::value, NF = decltype(NFc)::value;
+            constexpr bool SKIP = decltype(SKIPc)::value;
+            constexpr int NT = SKIP ? K3 : kUpListTaps;
+            auto addr = [&](int f, int tap) -> int {
+                if constexpr (SKIP) {
+                    const int pw = phase_of(f / NFG) & 1;                      // uniform
+                    const int dt = tap / 9, dh = (tap / 3) % 3, dw = tap % 3;
+                    return bb[f] + (dt * P.HH + dh) * P.HWd + ((pw + dw) & 1) * U.HWh + ((pw + dw) >> 1);
+                } else {
+                    const int dt = tap >> 2, a = (tap >> 1) & 1, b = tap & 1;
+                    return bb[f] + (dt * U.HH0 + a) * U.HW0 + b;
+                }
+            };
+#pragma unroll
+            for (int f = F0; f < F0 + NF; ++f) {
+                const int a = addr(f, 0);
+                bh[f] = qb[a];
+                bl[f] = qb[a + 2 * chs];
+            }
+            step_loop<0, NT>([&](auto tc) {
+                constexpr int tap = decltype(tc)::value;
+                constexpr int pt = tap + 2;                   // the tap whose A fragments are fetched now
+                if constexpr (pt < NT) {
+                    V2CE_LOAD_A(pt % 3, cur.abase + pt * cur.tstride, cur.lod)
+                } else {
+                    V2CE_LOAD_A(pt % 3, nxt.abase + (pt - NT) * nxt.tstride, nxt.lod)
+                }
+                bool centre = false;
+                if constexpr (SC && SKIP) centre = tap == 13;
+                if constexpr (SC && !SKIP && tap / 4 == 1) centre = tap == rc;          // uniform
+#pragma unroll
+                for (int f = F0; f < F0 + NF; ++f) {
+#pragma unroll
+                    for (int q = 0; q < CO_FR; ++q) {
+                        acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tap % 3][q], bh[f], acc[q][f], 0, 0, 0);
+                        acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tap % 3][q], bl[f], acc[q][f], 0, 0, 0);
+                        acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tap % 3][q], bh[f], acc[q][f], 0, 0, 0);
+                    }
+                    if constexpr (SC) {
+                        if (centre) {
+#pragma unroll
+                            for (int q = 0; q < CO_FR; ++q) {
+                                accd[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahd[q], bh[f], accd[q][f], 0, 0, 0);
+                                accd[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahd[q], bl[f], accd[q][f], 0, 0, 0);
+                                accd[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ald[q], bh[f], accd[q][f], 0, 0, 0);
+                            }
+                        }
+                    }
+                    if constexpr (tap + 1 < NT) {            // refill in place for the next tap
+                        const int a = addr(f, tap + 1);
+                        bh[f] = qb[a];
+                        bl[f] = qb[a + 2 * chs];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+        };
+        using std::integral_constant;
+        typedef integral_constant<bool, true> Yes;
+        typedef integral_constant<bool, false> No;
+
+        auto chunk_head = [&](int cg) -> const f16x8 * {
+            if constexpr (SC) {
+                const int wc = cg * cg_stride;
+#pragma unroll
+                for (int q = 0; q < CO_FR; ++q) {
+                    ahd[q] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_d, wlane[q], wc, 0));
+                    ald[q] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_d, wlane[q], wc + (int)(2 * wplane_d), 0));
+                }
+            }
+            __syncthreads();                                   // barrier gc: pieces[gc & 1] ready
+            // (opaque per chunk: otherwise the per-tap piece addresses -- bb[f] + tap offset, invariant over the chunks -- are
+            // all hoisted out of the chunk loop and spilled, a scratch reload per tap and fragment)
+#pragma unroll
+            for (int f = 0; f < PO_FR; ++f) asm volatile("" : "+v"(bb[f]));
+            return pieces + (gc & 1) * 4 * chs;
+        };
+        // ---- upsampled chunks: per phase group its folded list, then (edge tiles, even phases) the correction lists
+        for (int cg = 0; cg < CG0; ++cg, ++gc) {
+            const f16x8 *qb = chunk_head(cg);
+            // after this chunk's last list: the next upsampled chunk's first list, or the first skip chunk's
+            const ListRef after = cg + 1 < CG0 ? list0(phase_of(0), cg + 1) : list1(CG0);
+            step_loop<0, NG>([&](auto gcst) {
+                constexpr int g = decltype(gcst)::value;
+                const int p = phase_of(g), ph = p >> 1, pw = p & 1;
+                const bool ch = tile_h && ph == 0, cw = tile_w && pw == 0;         // uniform
+                const int npass = 1 + (ch ? 1 : 0) + (cw ? 1 : 0) + (ch && cw ? 1 : 0);
+                ListRef grp_after = after;
+                if constexpr (g + 1 < NG) grp_after = list0(phase_of(g + 1), cg);
+                auto pass_list = [&](int k, int &kind) -> ListRef {      // k-th pass of this group
+                    if (k == 0) { kind = 0; return list0(p, cg); }
+                    if (ch && k == 1) { kind = 1; return list0(4 + pw, cg); }
+                    if (cw && k == (ch ? 2 : 1)) { kind = 2; return list0(6 + ph, cg); }
+                    kind = 3;
+                    return list0(8, cg);
+                };
+                const int rc = SC ? 4 + (1 - ph) * 2 + (1 - pw) : -1;
+                for (int k = 0; k < npass; ++k) {
+                    int kind, nkind;
+                    const ListRef cur = pass_list(k, kind);
+                    const ListRef nxt = k + 1 < npass ? pass_list(k + 1, nkind) : grp_after;
+                    if (k > 0) set_bases(false, kind);                   // (edge tiles only)
+                    run_list(integral_constant<int, g * NFG>{}, integral_constant<int, NFG>{}, No{}, k == 0 ? rc : -1, cur, nxt, qb);
+                }
+                if (npass > 1) set_bases(false, 0);
+            });
+        }
+        // ---- skip chunks
+        set_bases(true, 0);
+        for (int cg = CG0; cg < CG; ++cg, ++gc) {
+            const f16x8 *qb = chunk_head(cg);
+            // the last chunk prefetches the first list of the next tile with the same channel tile
+            const ListRef nxt = cg + 1 < CG ? list1(cg + 1) : list0(phase_of(0), 0);
+            run_list(integral_constant<int, 0>{}, integral_constant<int, PO_FR>{}, Yes{}, -1, list1(cg), nxt, qb);
+        }
+        ring_key = T.co_t;
+
+        int poff[PO_FR];
+#pragma unroll
+        for (int f = 0; f < PO_FR; ++f) {
+            const int g = f / NFG, p = phase_of(g), ph = p >> 1, pw = p & 1;
+            const int s = (f - g * NFG) * 32 + l32;
+            poff[f] = -1;
+            if (s < U.n_sub) {
+                const int tt = s / (U.SH * U.SW);
+                const int rem = s - tt * (U.SH * U.SW);
+                const int i = rem / U.SW;
+                const int j = rem - i * U.SW;
+                const int t = T.t0 + tt, h = T.h0 + 2 * i + ph, w = T.w0 + 2 * j + pw;
+                if (t < P.T && h < P.Hout && w < P.Wout)
+                    poff[f] = 4 * ((t * P.Cout) * (P.Hout * P.Woutp)) + 64 * (h * P.Woutp + w);
+            }
+        }
+        conv_epilogue<CO_FR, PO_FR, true, false, 0, true>(P, acc, poff, co0, half, T.b, inv_scale);
+        if constexpr (SC) {
+            ConvParams Q = P;
+            Q.scale = P.sc_scale; Q.shift = P.sc_shift; Q.res = nullptr; Q.y = P.sc_y; Q.act = V2CE_ACT_NONE;
+            Q.y_absmax = nullptr;
+            const float wd_scale = reinterpret_cast<const float *>(P.sc_w + 2 * wplane_d)[1];
+            conv_epilogue<CO_FR, PO_FR, true, false, 0, true>(Q, accd, poff, co0, half, T.b, 1.0f / (x_scale * wd_scale));
+        }
+        vb += (int)gridDim.x;
+        more = next_tile(vb, T);
+    }
+#undef V2CE_LOAD_A
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+// ---------------------------------------------------------------------------------------------
+// weights: the folded region behind a v2ce_pack_weights_f16x2 buffer
+// ---------------------------------------------------------------------------------------------
+// max over every tap of every list of the folded region of |sum of (w / sigma)| for the C0 channels -> atomic max into tail[0]
+// (the correction lists hold single weights or two-term sums: covered by the plain maximum and the folded lists')
+__global__ __launch_bounds__(256) void up_fold_absmax_kernel(const float *__restrict__ w, int Cout, int Cin, int C0,
+                                                             const float *sigma, float *tail) {
+    // one thread per (co, ci < C0, dt): its nine (dh, dw) weights
+    const long long n = (long long)Cout * C0 * 3;
+    float m = 0.0f;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+        const int dt = (int)(e % 3);
+        const long long r = e / 3;
+        const int ci = (int)(r % C0), co = (int)(r / C0);
+        const float *p = w + ((long long)co * Cin + ci) * 27 + dt * 9;
+        float v[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            v[k] = p[k];
+            if (sigma) v[k] = v[k] / sigma[0];
+        }
+#pragma unroll
+        for (int li = 0; li < 9; ++li)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    int mh, mw, sign;
+                    up_list_masks(li, a, b, mh, mw, sign);
+                    float s = 0.0f;
+#pragma unroll
+                    for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+                        for (int dw = 0; dw < 3; ++dw)
+                            if ((mh >> dh & 1) && (mw >> dw & 1)) s += v[dh * 3 + dw];
+                    m = fmaxf(m, fabsf(s));
+                }
+    }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned *>(tail), __float_as_uint(m));
+}
+
+// fold[plane][slot][cg][co][16] (108 slots) = fp16 hi / lo of  +-s * sum over the slot's source taps of w[co][cg*16+j][.] / sigma,
+// s = pow2_prescale(tail[0]).  A workgroup takes 32 output channels x one 16-channel group: stages their 27 taps (scaled
+// quotients, f32) in LDS -- 32 contiguous runs of W in -- and writes, per slot and plane, 1 KiB contiguous.
+__global__ __launch_bounds__(256) void up_fold_pack_kernel(const float *__restrict__ w, int Cout, int Cin, int C0,
+                                                           const float *sigma, const float *tail, _Float16 *__restrict__ fold) {
+    __shared__ float st[32 * 16 * 27];
+    const int CG0 = C0 / 16, run = 16 * 27;
+    const int cg = blockIdx.x % CG0, co0 = (blockIdx.x / CG0) * 32;
+    const float w_scale = pow2_prescale(tail[0]);
+    const float sg = sigma ? sigma[0] : 1.0f;
+    for (int e = threadIdx.x; e < 32 * run; e += 256) {
+        const int col = e / run, rem = e - col * run;                 // rem = j * 27 + tap
+        float v = w[((long long)(co0 + col) * Cin + cg * 16) * 27 + rem];
+        if (sigma) v = v / sg;
+        st[e] = v * w_scale;
+    }
+    __syncthreads();
+    const long long plane = (long long)kUpSlots * CG0 * Cout * 16;     // halves
+    const int col = threadIdx.x >> 3, j2 = (threadIdx.x & 7) * 2;      // this thread: channel col, inputs j2, j2 + 1
+    const float *s0 = st + (col * 16 + j2) * 27, *s1 = s0 + 27;
+    for (int li = 0; li < 9; ++li) {
+        for (int tau = 0; tau < kUpListTaps; ++tau) {
+            const int dt = tau >> 2, a = (tau >> 1) & 1, b = tau & 1;
+            int mh, mw, sign;
+            up_list_masks(li, a, b, mh, mw, sign);
+            float x0 = 0.0f, x1 = 0.0f;
+#pragma unroll
+            for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+                for (int dw = 0; dw < 3; ++dw)
+                    if ((mh >> dh & 1) && (mw >> dw & 1)) {
+                        x0 += s0[dt * 9 + dh * 3 + dw];
+                        x1 += s1[dt * 9 + dh * 3 + dw];
+                    }
+            if (sign < 0) { x0 = -x0; x1 = -x1; }
+            typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+            const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+            const f16x2v hi{h0, h1}, lo{(_Float16)(x0 - (float)h0), (_Float16)(x1 - (float)h1)};
+            const long long o = (((long long)(li * kUpListTaps + tau) * CG0 + cg) * Cout + co0 + col) * 16 + j2;
+            *reinterpret_cast<f16x2v *>(fold + o) = hi;
+            *reinterpret_cast<f16x2v *>(fold + plane + o) = lo;
+        }
+    }
+}
+
+struct Box { int tt, sh, sw; };
+
+// phase sub-box (tt, sh, sw): tt * sh * sw <= n_sub_max positions per phase, skip halo (tt+2)(2sh+2)(2sw+2) <= 1280;
+// fewest workgroup rounds over the CUs, then fewest tiles, then the smaller halo volume, then wide rows
+Box choose_up_box(int B, int T, int Ho, int Wo, int n_sub_max, int n_co_tiles, int n_cu) {
+    Box best{1, 1, 1};
+    long long best_rounds = -1, best_blocks = 0, best_halo = 0;
+    for (int tt = 1; tt <= 16 && tt <= (T > 1 ? 2 * T - 1 : 1); tt *= 2)
+        for (int sh = 1; sh <= 64 && 2 * (sh - 1) < Ho; ++sh)
+            for (int sw = 1; sw <= 64 && 2 * (sw - 1) < Wo; ++sw) {
+                if (tt * sh * sw > n_sub_max) break;
+                const long long halo1 = (long long)(tt + 2) * (2 * sh + 2) * (2 * sw + 2);
+                if (halo1 > 1280) break;
+                const long long nsp = (long long)B * ((T + tt - 1) / tt) * ((Ho + 2 * sh - 1) / (2 * sh)) * ((Wo + 2 * sw - 1) / (2 * sw));
+                const long long blocks = 8 * ((nsp + 7) / 8) * n_co_tiles;
+                const long long rounds = (blocks + n_cu - 1) / n_cu;
+                const long long halo = halo1 + 2 * (long long)(tt + 2) * (sh + 2) * (sw + 2);
+                const bool better = best_rounds < 0 || rounds < best_rounds ||
+                                    (rounds == best_rounds && (blocks < best_blocks ||
+                                     (blocks == best_blocks && (halo < best_halo || (halo == best_halo && sw > best.sw)))));
+                if (better) { best = {tt, sh, sw}; best_rounds = rounds; best_blocks = blocks; best_halo = halo; }
+            }
+    return best;
+}
+
+thread_local char *g_up_name_out = nullptr;
+thread_local size_t g_up_name_cap = 0;
+
+template <int WCO, int CO_FR, int PO_FR, int FUSE>
+int launch_up(UpParams U, const v2ce_conv3d_desc &d, hipStream_t stream) {
+    ConvParams &P = U.C;
+    constexpr int CO_TILE = WCO * CO_FR * 32, NFG = PO_FR / WCO;
+    if (g_up_name_out) {
+        snprintf(g_up_name_out, g_up_name_cap, "conv3d_up_kernel<%d,%d,%d,%d>", WCO, CO_FR, PO_FR, FUSE);
+        return V2CE_OK;
+    }
+    static const int n_cu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            n = 256;
+        return n < 8 ? 8 : (n / 8) * 8;
+    }();
+    P.n_co_tiles = (d.Cout + CO_TILE - 1) / CO_TILE;
+    Box bx{0, 0, 0};
+    if (d.tile_t > 0 && d.tile_h > 0 && d.tile_w > 0) bx = Box{d.tile_t, d.tile_h / 2, d.tile_w / 2};
+    else {
+        char key[64];
+        snprintf(key, sizeof key, "V2CE_UPBOX_%dx%d_%d", d.Hout, d.Wout, NFG * 32);
+        if (const char *e = getenv(key)) {
+            int a, b, c;
+            if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3) bx = Box{a, b / 2, c / 2};
+        }
+        if (bx.tt <= 0) bx = choose_up_box(d.B, d.T, d.Hout, d.Wout, NFG * 32, P.n_co_tiles, n_cu);
+    }
+    V2CE_REQUIRE(bx.tt > 0 && bx.sh > 0 && bx.sw > 0 && bx.tt * bx.sh * bx.sw <= NFG * 32, V2CE_ERR_UNSUPPORTED,
+                 "v2ce_conv3d_fwd_up2: box %dx%dx%d does not fit %d positions per phase (TH, TW must be even)", bx.tt, 2 * bx.sh,
+                 2 * bx.sw, NFG * 32);
+    P.TT = bx.tt; P.TH = 2 * bx.sh; P.TW = 2 * bx.sw;
+    U.SH = bx.sh; U.SW = bx.sw; U.n_sub = bx.tt * bx.sh * bx.sw;
+    P.n_pos = 4 * U.n_sub;
+    P.HT = P.TT + 2; P.HH = P.TH + 2; P.HWd = P.TW + 2;
+    P.plane = P.HT * P.HH * P.HWd;
+    U.HH0 = U.SH + 2; U.HW0 = U.SW + 2; U.plane0 = P.HT * U.HH0 * U.HW0;
+    U.HWh = P.HWd / 2;
+    V2CE_REQUIRE(P.plane <= 1280, V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd_up2: the box's halo does not fit (%d > 1280 elements)", P.plane);
+    P.nT = (d.T + P.TT - 1) / P.TT; P.nH = (d.Hout + P.TH - 1) / P.TH; P.nW = (d.Wout + P.TW - 1) / P.TW;
+    P.n_spatial = d.B * P.nT * P.nH * P.nW;
+    P.xcd_remap = 1;
+    P.per_xcd = (P.n_spatial + 7) / 8;
+    const long long blocks = (long long)8 * P.per_xcd * P.n_co_tiles;
+    V2CE_REQUIRE(blocks < (1ll << 31), V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd_up2: grid too large");
+    U.zero0 = (U.plane0 + 63) & ~63;
+    int chs = (P.plane + 63) & ~63;
+    if (chs < U.zero0 + U.plane0) chs = (U.zero0 + U.plane0 + 63) & ~63;      // (tiny boxes only)
+    U.chs = chs;
+    const size_t lds = (size_t)chs * 128;
+    V2CE_REQUIRE(lds <= 160 * 1024, V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd_up2: %zu B of LDS", lds);
+    auto kern = conv3d_up_kernel<WCO, CO_FR, PO_FR, FUSE>;
+    V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    P.total_blocks = (int)blocks;
+    const unsigned grid = (unsigned)(blocks > n_cu ? n_cu : blocks);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, U);
+    V2CE_HIP_CHECK(hipGetLastError());
+    return V2CE_OK;
+}
+
+}  // namespace
+}  // namespace v2ce
+
+using namespace v2ce;
+
+static size_t up_fold_off(int Cout, int Cin) { return (size_t)Cout * Cin * 27 * 4 + 16; }   // plain planes + {max, scale, 0, 0}
+
+extern "C" size_t v2ce_pack_weights_f16x2_up_bytes(int Cout, int C0, int C1) {
+    if (Cout <= 0 || C0 <= 0 || C1 < 0) return 0;
+    return up_fold_off(Cout, C0 + C1) + (size_t)kUpSlots * C0 * Cout * 4;
+}
+
+// enqueue the two fold passes behind a tail[0] that already holds max |w / sigma| (see v2ce_pack_weights_f16x2_up and
+// v2ce_sn_update_batch, which call them around their own plain packs)
+int v2ce::v2ce_up_fold_absmax(const float *w, int Cout, int Cin, int C0, const float *sigma, void *w_up, hipStream_t st) {
+    float *tail = reinterpret_cast<float *>(static_cast<char *>(w_up) + (size_t)Cout * Cin * 27 * 4);
+    const long long n = (long long)Cout * C0 * 3;
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(up_fold_absmax_kernel, dim3(nb < 2048 ? nb : 2048), dim3(256), 0, st, w, Cout, Cin, C0, sigma, tail);
+    return V2CE_OK;
+}
+int v2ce::v2ce_up_fold_pack(const float *w, int Cout, int Cin, int C0, const float *sigma, void *w_up, hipStream_t st) {
+    const float *tail = reinterpret_cast<const float *>(static_cast<char *>(w_up) + (size_t)Cout * Cin * 27 * 4);
+    _Float16 *fold = reinterpret_cast<_Float16 *>(static_cast<char *>(w_up) + up_fold_off(Cout, Cin));
+    hipLaunchKernelGGL(up_fold_pack_kernel, dim3((unsigned)((Cout / 32) * (C0 / 16))), dim3(256), 0, st, w, Cout, Cin, C0, sigma, tail, fold);
+    return V2CE_OK;
+}
+
+extern "C" int v2ce_pack_weights_f16x2_up(const float *w, int Cout, int C0, int C1, const float *sigma, void *w_up,
+                                          v2ce_stream_t stream) {
+    clear_error();
+    V2CE_REQUIRE(w && w_up && Cout > 0 && Cout % 32 == 0 && C0 > 0 && C0 % 16 == 0 && C1 > 0 && C1 % 16 == 0, V2CE_ERR_BAD_ARG,
+                 "v2ce_pack_weights_f16x2_up: needs Cout %% 32 == 0 and C0, C1 positive multiples of 16");
+    const int Cin = C0 + C1;
+    hipStream_t st = as_stream(stream);
+    char *base = static_cast<char *>(w_up);
+    float *tail = reinterpret_cast<float *>(base + (size_t)Cout * Cin * 27 * 4);
+    V2CE_HIP_CHECK(hipMemsetAsync(tail, 0, 4 * sizeof(float), st));
+    // max |w / sigma| over the plain weights, then over the folded sums; then the two packs with the common scale
+    int rc = v2ce_pack_weights_f16x2_absmax_only(w, Cout, Cin, 27, sigma, w_up, stream);
+    if (rc != V2CE_OK) return rc;
+    v2ce_up_fold_absmax(w, Cout, Cin, C0, sigma, w_up, st);
+    rc = v2ce_pack_weights_f16x2_pack_only(w, Cout, Cin, 27, sigma, w_up, stream);
+    if (rc != V2CE_OK) return rc;
+    v2ce_up_fold_pack(w, Cout, Cin, C0, sigma, w_up, st);
+    V2CE_HIP_CHECK(hipGetLastError());
+    return V2CE_OK;
+}
+
+static int up_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const float *x1, const void *w_up,
+                       const float *scale, const float *shift, float *y, const float *x0_absmax,
+                       const float *x1_absmax, float *y_absmax, const void *sc_w, const float *sc_scale,
+                       const float *sc_shift, float *sc_y, v2ce_stream_t stream) {
+    clear_error();
+    V2CE_REQUIRE(desc && (g_up_name_out || (x0 && x1 && w_up && scale && shift && y)), V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd_up2: null pointer");
+    const v2ce_conv3d_desc &d = *desc;
+    V2CE_REQUIRE(d.B > 0 && d.T > 0 && d.C0 > 0 && d.C1 > 0 && d.Hin > 0 && d.Win > 0 && d.Cout > 0, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd_up2: bad shape");
+    V2CE_REQUIRE(d.ksize == 3 && d.stride_hw == 1 && d.precision == V2CE_PRECISION_F16X2 && d.layout == V2CE_LAYOUT_C16, V2CE_ERR_UNSUPPORTED,
+                 "v2ce_conv3d_fwd_up2: a split-half 3x3x3 stride-1 conv on channels-last-16 activations");
+    V2CE_REQUIRE(d.H0 == (d.Hin + 1) / 2 && d.W0 == (d.Win + 1) / 2 && d.Hout == d.Hin && d.Wout == d.Win, V2CE_ERR_BAD_ARG,
+                 "v2ce_conv3d_fwd_up2: x0 must be the 2x nearest-upsample source (H0 = ceil(Hin / 2), W0 = ceil(Win / 2)), got %dx%d for %dx%d",
+                 d.H0, d.W0, d.Hin, d.Win);
+    V2CE_REQUIRE(d.C0 % 16 == 0 && d.C1 % 16 == 0 && d.Cout % 32 == 0, V2CE_ERR_UNSUPPORTED,
+                 "v2ce_conv3d_fwd_up2: channel counts must be multiples of 16 (inputs) / 32 (outputs)");
+    V2CE_REQUIRE(d.act >= 0 && d.act <= 2, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd_up2: act %d", d.act);
+    const int W0p = d.W0_pitch > 0 ? d.W0_pitch : d.W0, Winp = d.Win_pitch > 0 ? d.Win_pitch : d.Win;
+    const int Woutp = d.Wout_pitch > 0 ? d.Wout_pitch : d.Wout;
+    V2CE_REQUIRE(W0p >= d.W0 && Winp >= d.Win && Woutp >= d.Wout, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd_up2: a row pitch is smaller than its width");
+    V2CE_REQUIRE((long long)d.T * d.C0 * d.H0 * W0p < (1ll << 29) && (long long)d.T * d.C1 * d.Hin * Winp < (1ll << 29) &&
+                 (long long)d.T * d.Cout * d.Hout * Woutp < (1ll << 29), V2CE_ERR_UNSUPPORTED,
+                 "v2ce_conv3d_fwd_up2: a single sequence exceeds the 2 GiB buffer-descriptor range");
+    V2CE_REQUIRE(x0_absmax || !x1_absmax, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd_up2: x1_absmax without x0_absmax");
+    V2CE_REQUIRE(!x0_absmax || x1_absmax, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd_up2: x0_absmax without x1_absmax");
+    V2CE_REQUIRE(!sc_w || (d.Cout <= 32 && sc_scale && sc_shift && (sc_y || g_up_name_out)), V2CE_ERR_UNSUPPORTED,
+                 "v2ce_conv3d_fwd_up2: the fused shortcut needs <= 32 output channels and its scale / shift / output");
+    const size_t total = v2ce_pack_weights_f16x2_up_bytes(d.Cout, d.C0, d.C1);
+    V2CE_REQUIRE(total < (1ull << 31), V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd_up2: the weight buffer exceeds the 2 GiB buffer-descriptor range");
+
+    UpParams U{};
+    ConvParams &P = U.C;
+    P.x0 = x0; P.x1 = x1; P.scale = scale; P.shift = shift; P.y = y;
+    P.B = d.B; P.T = d.T; P.C0 = d.C0; P.H0 = d.H0; P.W0 = d.W0; P.C1 = d.C1; P.Hin = d.Hin; P.Win = d.Win;
+    P.Cin = d.C0 + d.C1; P.Cout = d.Cout; P.Hout = d.Hout; P.Wout = d.Wout;
+    P.W0p = W0p; P.Winp = Winp; P.Woutp = Woutp;
+    P.c16 = 1;
+    P.act = d.act;
+    P.wq = static_cast<const _Float16 *>(w_up);
+    P.x0_absmax = x0_absmax; P.x1_absmax = x1_absmax; P.y_absmax = y_absmax;
+    P.guard = y_absmax ? y_absmax + 1 : nullptr;
+    P.amax_bs = d.absmax_batch_stride;
+    V2CE_REQUIRE(P.amax_bs == 0 || P.amax_bs >= 2, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd_up2: absmax_batch_stride must be 0 or >= 2");
+    P.sc_w = static_cast<const _Float16 *>(sc_w); P.sc_scale = sc_scale; P.sc_shift = sc_shift; P.sc_y = sc_y;
+    U.CG0 = d.C0 / 16;
+    U.odd_h = d.Hout & 1; U.odd_w = d.Wout & 1;
+    U.fold_off = (int)up_fold_off(d.Cout, P.Cin);
+    U.fold_plane = (int)((size_t)kUpSlots * d.C0 * d.Cout * 2);
+    hipStream_t st = as_stream(stream);
+    if (sc_w) return launch_up<1, 1, 4, 2>(U, d, st);
+    if (d.Cout <= 32) return launch_up<1, 1, 4, 0>(U, d, st);
+    static const int wide = [] { const char *e = getenv("V2CE_UP_WIDE"); return e ? atoi(e) : 1; }();
+    if (d.Cout >= 128 && wide) return launch_up<2, 2, 4, 0>(U, d, st);
+    return launch_up<1, 2, 4, 0>(U, d, st);
+}
+
+extern "C" int v2ce_conv3d_fwd_up2(const v2ce_conv3d_desc *desc, const float *x0, const float *x1, const void *w_up,
+                                   const float *scale, const float *shift, float *y, const float *x0_absmax,
+                                   const float *x1_absmax, float *y_absmax, const void *sc_w, const float *sc_scale,
+                                   const float *sc_shift, float *sc_y, v2ce_stream_t stream) {
+    g_up_name_out = nullptr;
+    return up_dispatch(desc, x0, x1, w_up, scale, shift, y, x0_absmax, x1_absmax, y_absmax, sc_w, sc_scale, sc_shift, sc_y, stream);
+}
+
+extern "C" int v2ce_conv3d_up2_variant(const v2ce_conv3d_desc *desc, int with_shortcut, char *name, size_t cap) {
+    V2CE_REQUIRE(name && cap > 0, V2CE_ERR_BAD_ARG, "v2ce_conv3d_up2_variant: no buffer");
+    name[0] = '\0';
+    g_up_name_out = name;
+    g_up_name_cap = cap;
+    static const float dummy = 0.0f;
+    const int rc = up_dispatch(desc, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                               with_shortcut ? &dummy : nullptr, with_shortcut ? &dummy : nullptr, with_shortcut ? &dummy : nullptr,
+                               nullptr, nullptr);
+    g_up_name_out = nullptr;
+    return rc;
+}

@@ -112,6 +112,7 @@ struct SnLayer {
     double *part;               // [kRowChunks][cols]
     float *t, *s, *rowmax, *sigma;
     int rows, cols, k3, cin;
+    int up_c0;                  // > 0: `packed` is a v2ce_pack_weights_f16x2_up buffer whose first up_c0 input channels are also folded
 };
 struct SnBatch {
     SnLayer L[kMaxBatch];
@@ -226,6 +227,7 @@ __global__ __launch_bounds__(1024) void sn_batch_finalize_kernel(SnBatch B) {
         const float am = fabsf(m / sg);                        // = max |w / sigma| of weights_absmax_kernel
         tail[0] = am;
         tail[1] = pow2_prescale(am);
+        if (P.up_c0) { tail[2] = 0.0f; tail[3] = 0.0f; }      // (an up buffer's tail is 16 bytes; the fold passes may still raise tail[0])
     }
 }
 
@@ -244,8 +246,10 @@ __global__ __launch_bounds__(256) void sn_batch_pack_kernel(SnBatch B) {
     const int blk = blockIdx.x - B.el_blk[l];            // (co block, cg)
     const int cg = blk % CG, co0 = (blk / CG) * 32;
     const long long n = (long long)P.rows * P.cols;
-    const float *tail = reinterpret_cast<const float *>(P.packed + 2 * n);
-    const float w_scale = tail[1], sigma = P.sigma[0];
+    float *tail = reinterpret_cast<float *>(P.packed + 2 * n);
+    // (tail[0] may have been raised behind the finalize kernel by the folded sums of an up layer: the scale is derived here)
+    const float w_scale = pow2_prescale(tail[0]), sigma = P.sigma[0];
+    if (blk == 0 && threadIdx.x == 0) tail[1] = w_scale;
     // (a tap's 512 halves are padded by one dword: consecutive lanes hold consecutive taps, 1 KiB apart = one LDS bank)
     _Float16 *hi = pk_smem, *lo = pk_smem + k3 * 514;
     constexpr int U = 6;                                 // loads in flight per thread (two workgroups per CU: latency-bound otherwise)
@@ -342,6 +346,9 @@ extern "C" int v2ce_sn_update_batch(const v2ce_sn_layer *layers, int n, void *wo
         SnLayer &o = B.L[l];
         o.w = in.w_bar; o.u = in.u; o.v = in.v; o.packed = static_cast<_Float16 *>(in.packed);
         o.rows = in.rows; o.cols = in.cols; o.k3 = in.k3; o.cin = in.cols / in.k3;
+        o.up_c0 = in.up_c0;
+        V2CE_REQUIRE(in.up_c0 == 0 || (in.k3 == 27 && in.up_c0 > 0 && in.up_c0 % 16 == 0 && in.up_c0 < o.cin), V2CE_ERR_BAD_ARG,
+                     "v2ce_sn_update_batch: layer %d: up_c0 must be a multiple of 16 below Cin of a 3x3x3 layer", l);
         o.part = reinterpret_cast<double *>(ws);
         o.t = reinterpret_cast<float *>(o.part + (size_t)kRowChunks * in.cols);
         o.s = o.t + in.cols;
@@ -360,6 +367,9 @@ extern "C" int v2ce_sn_update_batch(const v2ce_sn_layer *layers, int n, void *wo
     hipLaunchKernelGGL(sn_batch_normalize_kernel, dim3(n), dim3(1024), 0, st, B);
     hipLaunchKernelGGL(sn_batch_w_v_kernel, dim3(B.row_blk[n]), dim3(256), 0, st, B);
     hipLaunchKernelGGL(sn_batch_finalize_kernel, dim3(n), dim3(1024), 0, st, B);
+    // decoder conv1 layers (v2ce_conv3d_fwd_up2): the folded sums of W / sigma join the maximum the common pre-scale is derived from
+    for (int l = 0; l < n; ++l)
+        if (B.L[l].up_c0) v2ce_up_fold_absmax(B.L[l].w, B.L[l].rows, B.L[l].cin, B.L[l].up_c0, B.L[l].sigma, B.L[l].packed, st);
     int k3max = 1;
     bool all27 = true;
     for (int l = 0; l < n; ++l) {
@@ -368,6 +378,8 @@ extern "C" int v2ce_sn_update_batch(const v2ce_sn_layer *layers, int n, void *wo
     }
     if (all27) hipLaunchKernelGGL(sn_batch_pack_kernel<27>, dim3(B.el_blk[n]), dim3(256), (size_t)27 * 2056, st, B);
     else hipLaunchKernelGGL(sn_batch_pack_kernel<0>, dim3(B.el_blk[n]), dim3(256), (size_t)k3max * 2056, st, B);
+    for (int l = 0; l < n; ++l)
+        if (B.L[l].up_c0) v2ce_up_fold_pack(B.L[l].w, B.L[l].rows, B.L[l].cin, B.L[l].up_c0, B.L[l].sigma, B.L[l].packed, st);
     V2CE_HIP_CHECK(hipGetLastError());
     return V2CE_OK;
 }

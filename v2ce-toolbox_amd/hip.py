@@ -31,6 +31,7 @@ EXPORTS = [
     "v2ce_preprocess_pairs", "v2ce_preprocess_pairs_resize",
     "v2ce_voxelize_events", "v2ce_conv3d_fwd_pred", "v2ce_conv3d_fwd_sc", "v2ce_conv3d_fwd_tail", "v2ce_pack_pred_weights_f16x2", "v2ce_pack_pred_weights_f16x2_bytes",
     "v2ce_sampler_count", "v2ce_sampler_workspace_bytes", "v2ce_sampler_emit", "v2ce_sampler_pool",
+    "v2ce_conv3d_fwd_up2", "v2ce_pack_weights_f16x2_up", "v2ce_pack_weights_f16x2_up_bytes", "v2ce_conv3d_up2_variant",
 ]
 
 
@@ -48,7 +49,7 @@ class ConvDesc(ctypes.Structure):
 class SnLayer(ctypes.Structure):
     """``v2ce_sn_layer`` (include/v2ce_hip.h): one spectral-norm layer of v2ce_sn_update_batch."""
     _fields_ = [("w_bar", ctypes.c_void_p), ("u", ctypes.c_void_p), ("v", ctypes.c_void_p), ("packed", ctypes.c_void_p),
-                ("rows", ctypes.c_int32), ("cols", ctypes.c_int32), ("k3", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("rows", ctypes.c_int32), ("cols", ctypes.c_int32), ("k3", ctypes.c_int32), ("up_c0", ctypes.c_int32)]
 
 
 class LdatiOptions(ctypes.Structure):
@@ -143,6 +144,14 @@ def lib() -> ctypes.CDLL:
     L.v2ce_conv3d_fwd_sc.restype = ctypes.c_int
     L.v2ce_conv3d_fwd_tail.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 11 + [ctypes.POINTER(ConvDesc)] + [vp] * 8
     L.v2ce_conv3d_fwd_tail.restype = ctypes.c_int
+    L.v2ce_conv3d_fwd_up2.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 14
+    L.v2ce_conv3d_fwd_up2.restype = ctypes.c_int
+    L.v2ce_pack_weights_f16x2_up.argtypes = [vp, i32, i32, i32, vp, vp, vp]
+    L.v2ce_pack_weights_f16x2_up.restype = ctypes.c_int
+    L.v2ce_pack_weights_f16x2_up_bytes.argtypes = [i32, i32, i32]
+    L.v2ce_pack_weights_f16x2_up_bytes.restype = sz
+    L.v2ce_conv3d_up2_variant.argtypes = [ctypes.POINTER(ConvDesc), i32, ctypes.c_char_p, sz]
+    L.v2ce_conv3d_up2_variant.restype = ctypes.c_int
     L.v2ce_pack_pred_weights_f16x2.argtypes = [vp, i32, i32, vp, vp]
     L.v2ce_pack_pred_weights_f16x2.restype = ctypes.c_int
     L.v2ce_pack_pred_weights_f16x2_bytes.argtypes = []
@@ -190,6 +199,12 @@ def require_device_f32(t: torch.Tensor, name: str) -> torch.Tensor:
     if t.dtype != torch.float32:
         raise V2ceHipError(f"{name} must be float32 (got {t.dtype})")
     return t.contiguous()
+
+
+def conv_up2_variant(desc: ConvDesc, with_shortcut: bool) -> str:
+    buf = ctypes.create_string_buffer(96)
+    check(lib().v2ce_conv3d_up2_variant(ctypes.byref(desc), int(with_shortcut), buf, 96), "v2ce_conv3d_up2_variant")
+    return buf.value.decode()
 
 
 def conv_variant(desc: ConvDesc, mapped: bool, fuse: int = 0) -> str:

@@ -110,6 +110,12 @@ class _UNet3D(nn.Module):
         self.pred = _ConvLayer3D(BASE, cout, 1)
 
 
+def _nearest_is_half(n_in: int, n_out: int) -> bool:
+    """ATen's nearest source index equals dst >> 1 for this size pair (true for every n_in = ceil(n_out / 2) that was
+    checked, but it is a property of a float computation: tested, not assumed)."""
+    return bool(np.array_equal(_nearest_map(n_in, n_out), np.arange(n_out) >> 1))
+
+
 def _nearest_map(n_in: int, n_out: int) -> np.ndarray:
     """ATen nearest: src = min(floorf(dst * (float)in/out), in-1) (unet_2layer.py:360)."""
     scale = np.float32(n_in) / np.float32(n_out)
@@ -179,6 +185,12 @@ class V2ce3d(nn.Module):
     def _pack(self, w, sigma=None, out=None, split=False):
         cout, cin = w.shape[0], w.shape[1]
         k3 = w.shape[2] * w.shape[3] * w.shape[4]
+        if split and out is not None and getattr(out, "up_c0", 0):
+            # decoder conv1: plain planes + the phase-folded region of the upsampled channels (v2ce_conv3d_fwd_up2)
+            hip.check(hip.lib().v2ce_pack_weights_f16x2_up(w.data_ptr(), cout, out.up_c0, cin - out.up_c0, hip.ptr(sigma),
+                                                           out.data_ptr(), hip.stream_ptr(w.device)),
+                      "v2ce_pack_weights_f16x2_up")
+            return out
         if split:      # fp16 hi/lo planes for the split-half conv path
             if out is None:
                 out = self._split_buffer(cout, cin, k3, w.device)
@@ -194,8 +206,14 @@ class V2ce3d(nn.Module):
         return out
 
     @staticmethod
-    def _split_buffer(cout, cin, k3, dev):
-        """fp16 hi/lo planes + the {max |w|, pre-scale} tail of v2ce_pack_weights_f16x2."""
+    def _split_buffer(cout, cin, k3, dev, up_c0=0):
+        """fp16 hi/lo planes + the {max |w|, pre-scale} tail of v2ce_pack_weights_f16x2; up_c0 > 0: followed by the
+        phase-folded region of the first up_c0 input channels (v2ce_pack_weights_f16x2_up)."""
+        if up_c0:
+            buf = torch.empty(hip.lib().v2ce_pack_weights_f16x2_up_bytes(cout, up_c0, cin - up_c0) // 2, dtype=torch.float16,
+                              device=dev)
+            buf.up_c0 = up_c0
+            return buf
         return torch.empty(hip.lib().v2ce_pack_weights_f16x2_bytes(cout, cin, k3) // 2, dtype=torch.float16,
                            device=dev)
 
@@ -247,7 +265,9 @@ class V2ce3d(nn.Module):
                     for cn in ("conv1", "conv2"):
                         m = getattr(blk, cn).module
                         rows, cols = m.weight_bar.shape[0], m.weight_bar[0].numel()
-                        d[cn + "_w"] = (self._split_buffer(rows, m.weight_bar.shape[1], 27, dev)
+                        # a decoder's conv1 reads upsample(x) ++ skip: its first 2/3 input channels are packed phase-folded too
+                        up_c0 = blk.cin * 2 // 3 if (name == "dec" and cn == "conv1" and self._upfold()) else 0
+                        d[cn + "_w"] = (self._split_buffer(rows, m.weight_bar.shape[1], 27, dev, up_c0=up_c0)
                                         if splits[cn] else torch.empty(rows * cols, dtype=torch.float32, device=dev))
                         sn_ws = max(sn_ws, hip.lib().v2ce_sn_workspace_bytes(rows, cols))
                 else:
@@ -266,6 +286,7 @@ class V2ce3d(nn.Module):
             for e, (m, out) in zip(arr, inners):
                 e.w_bar, e.u, e.v, e.packed = m.weight_bar.data_ptr(), m.weight_u.data_ptr(), m.weight_v.data_ptr(), out.data_ptr()
                 e.rows, e.cols, e.k3 = m.weight_bar.shape[0], m.weight_bar[0].numel(), 27
+                e.up_c0 = getattr(out, "up_c0", 0)
             nb = hip.lib().v2ce_sn_batch_workspace_bytes(arr, len(inners))
             if nb:
                 P["sn_batch"] = (arr, len(inners), torch.empty(nb, dtype=torch.uint8, device=dev))
@@ -287,6 +308,11 @@ class V2ce3d(nn.Module):
         if self.precision != "f16x2":
             return False
         return ksize == 3 or stride == 2 or cout >= 64
+
+    def _upfold(self) -> bool:
+        """Phase-folded upsampled channels in the decoders' conv1 (v2ce_conv3d_fwd_up2; V2CE_UPFOLD=0: the mapped gather
+        with all 27 taps, for A/B runs)."""
+        return self.precision == "f16x2" and os.environ.get("V2CE_UPFOLD", "1") != "0"
 
     def _fuse_shortcut(self, blk) -> bool:
         """Ride the block's 1x1x1 shortcut on conv1's launch (v2ce_conv3d_fwd_sc)?  Possible where conv1's
@@ -362,6 +388,11 @@ class V2ce3d(nn.Module):
         hmap = wmap = None
         if (Hin, Win) != (H0, W0):
             hmap, wmap = self._map(H0, Hin, x0.device), self._map(W0, Win, x0.device)
+        # exact 2x nearest upsample (ATen's map is then dst >> 1: _nearest_is_half) into a conv whose weights carry the
+        # phase-folded region: the decoder kernel (12 instead of 27 taps on the upsampled channels)
+        up2 = (split and hmap is not None and x1 is not None and getattr(w_packed, "up_c0", 0) == x0.shape[2] * 16 and ksize == 3
+               and stride == 1 and pred is None and tail is None and residual is None
+               and H0 == (Hin + 1) // 2 and W0 == (Win + 1) // 2 and _nearest_is_half(H0, Hin) and _nearest_is_half(W0, Win))
         C1 = 0 if x1 is None else x1.shape[2] * (16 if getattr(x1, "c16", False) else 1)
         Winp = Win if x1 is None else x1.shape[4]
         assert x1 is None or getattr(x1, "lw", Winp) == Win
@@ -393,7 +424,18 @@ class V2ce3d(nn.Module):
         if prof is not None:       # HIP events on the launch stream (torch's current stream)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        if pred is not None:           # fused 1x1x1 head: only its output is materialised
+        if up2:
+            y_sc = None
+            if sc is not None:
+                y_sc = torch.empty_like(y)
+                y_sc.lw, y_sc.c16 = Wout, c16
+            sc_w, sc_scale, sc_shift = sc if sc is not None else (None, None, None)
+            hip.check(hip.lib().v2ce_conv3d_fwd_up2(ctypes.byref(d), x0.data_ptr(), x1.data_ptr(), w_packed.data_ptr(),
+                                                    scale.data_ptr(), shift.data_ptr(), y.data_ptr(),
+                                                    hip.ptr(a0), hip.ptr(a1), hip.ptr(ay), hip.ptr(sc_w), hip.ptr(sc_scale),
+                                                    hip.ptr(sc_shift), hip.ptr(y_sc), hip.stream_ptr(x0.device)),
+                      "v2ce_conv3d_fwd_up2")
+        elif pred is not None:           # fused 1x1x1 head: only its output is materialised
             tab, pbias, pcout = pred
             y = torch.empty((B, T, pcout, Hout, Wout), dtype=torch.float32, device=x0.device)
             hip.check(hip.lib().v2ce_conv3d_fwd_pred(ctypes.byref(d), x0.data_ptr(), hip.ptr(x1),
@@ -452,10 +494,12 @@ class V2ce3d(nn.Module):
                 flops += 2.0 * B * T * Hout * Wout * cout * (C0 + C1)
             if tail is not None:
                 flops += 2.0 * B * T * Hout * Wout * cout * 16 * (tail[0].shape[2] + (0 if tail[1] is None else tail[1].shape[2]))
-            prof.append((hip.conv_variant(d, hmap is not None, (1 if pred is not None else (2 if sc is not None else
-                                                                                           (3 if tail is not None else 0))) +
-                                          (4 if residual is not None else 0)),
-                         flops, e0, e1))
+            name = hip.conv_up2_variant(d, sc is not None) if up2 else \
+                hip.conv_variant(d, hmap is not None, (1 if pred is not None else (2 if sc is not None else (3 if tail is not None else 0))) +
+                                 (4 if residual is not None else 0))
+            # (flops = the ALGORITHMIC count of the reference's convolution; a phase-folded launch executes fewer: `executed`)
+            executed = flops - (2.0 * B * T * Hout * Wout * cout * C0 * 15 if up2 else 0.0)
+            prof.append((name, flops, e0, e1, executed))
         if sc is not None:
             return y, y_sc
         return y
