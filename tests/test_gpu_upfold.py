@@ -108,9 +108,9 @@ def test_conv3d_up2_vs_f64(case):
 
 
 def test_up_buffer_is_a_plain_buffer_too():
-    """The plain planes of a v2ce_pack_weights_f16x2_up buffer drive the generic kernel (mapped gather, 27 taps); both
-    kernels agree far inside the tolerance (they differ by the summation order of the pre-summed weights, and the common
-    pre-scale may cost the plain weights a bit of their 22)."""
+    """The plain planes of a v2ce_pack_weights_f16x2_up buffer drive the generic kernel (mapped gather, 27 taps); the two
+    kernels agree inside the parity bar (they differ by the order of their f32 accumulations -- 2592 products per output
+    here -- and by the pre-summed weights)."""
     from v2ce_toolbox_amd import hip
     from v2ce_toolbox_amd.v2ce_3d import V2ce3d
     B, T, C0, C1, Cout, H, W = 1, 4, 64, 32, 64, 13, 18
@@ -131,7 +131,7 @@ def test_up_buffer_is_a_plain_buffer_too():
     torch.cuda.synchronize()
     assert "conv3d_up_kernel" in m.profile[0][0] and "ws_kernel" in m.profile[1][0], [p[0] for p in m.profile]
     a, b = V2ce3d.to_planar(y_up).cpu().numpy(), V2ce3d.to_planar(y_gen).cpu().numpy()
-    assert_close(a, b, "folded vs mapped", 2e-6)
+    assert_close(a, b, "folded vs mapped")
     want = ref_conv(x0, w, sc1, sh1, 3, 1, 1, x1=x1, up_to=(H, W))
     assert_close(np.transpose(b, (0, 2, 1, 3, 4)), want, "mapped kernel on the up buffer")
 

@@ -31,7 +31,12 @@
 //     stride-2 positions of a phase read consecutive 16-byte pieces.
 #include "conv3d_dev.h"
 
+#include <algorithm>
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
 
 namespace v2ce {
 namespace {
@@ -60,9 +65,15 @@ __host__ __device__ inline void up_list_masks(int li, int a, int b, int &mh, int
 struct UpParams {
     ConvParams C;
     int SH, SW, n_sub;            // phase sub-box (TH / 2, TW / 2), its positions TT * SH * SW
-    int HH0, HW0, plane0;         // low-resolution halo box (TT + 2) x (SH + 2) x (SW + 2)
+    int HH0, HW0, plane0;         // low-resolution halo box (TT + 2) x (SH + 2) x (SW + 2); plane0 = HT * Q0 pieces in LDS
+    int P0, Q0, P1, Q1;           // LDS pitches (pieces) between rows / time steps of the low-resolution box and of the skip box
+                                  // (>= the dense ones: chosen with the lane order so that the 16-lane groups of a ds_read_b128 hit
+                                  // sixteen different 16-byte slots of the 256-byte bank row)
+    int lbit[5];                  // lane order: bit b of a lane's rank in its ds_read_b128 group pair becomes bit lbit[b] of its position
     int zero0;                    // first piece of the zeroed region of an upsampled chunk's planes (edge tiles; >= plane0)
     int chs;                      // pieces per plane of the LDS buffers (>= the skip halo, >= zero0 + plane0)
+    int stage_off;                // bytes from the start of LDS to the consumers' epilogue staging (4 x 4 KB)
+    int dbg;                      // timing experiments (V2CE_UP_DBG; WRONG results): 1 = stores dropped by the range check, 2 = no epilogue
     int HWh;                      // HWd / 2: first odd column of the de-interleaved skip halo
     int CG0;                      // C0 / 16
     int odd_h, odd_w;
@@ -79,7 +90,9 @@ struct UpParams {
 template <int EPT>
 __device__ __forceinline__ void up_offsets(const UpParams &U, bool skip, int t0, int h0, int w0, int tid, unsigned (&goff)[EPT]) {
     const ConvParams &P = U.C;
-    const int hh_n = skip ? P.HH : U.HH0, hw_n = skip ? P.HWd : U.HW0, plane = skip ? P.plane : U.plane0;
+    // slot r of the PITCHED box: time step r / Q, row (r % Q) / P, column r % P; slots in the padding read as zero
+    const int hh_n = skip ? P.HH : U.HH0, hw_n = skip ? P.HWd : U.HW0, pr = skip ? U.P1 : U.P0, qr = skip ? U.Q1 : U.Q0;
+    const int plane = skip ? P.plane : U.plane0;
     const int Cs = skip ? P.C1 : P.C0, Hs = skip ? P.Hin : P.H0, Ws = skip ? P.Win : P.W0, Wp = skip ? P.Winp : P.W0p;
     const int hb = skip ? h0 - 1 : (h0 >> 1) - 1, wb = skip ? w0 - 1 : (w0 >> 1) - 1;
 #pragma unroll
@@ -87,27 +100,132 @@ __device__ __forceinline__ void up_offsets(const UpParams &U, bool skip, int t0,
         const int r = tid + 256 * i;
         unsigned off = kOOB;
         if (r < plane) {
-            const int ht = r / (hh_n * hw_n);
-            const int rem = r - ht * (hh_n * hw_n);
-            const int hr = rem / hw_n;
-            int hc = rem - hr * hw_n;
-            if (skip) hc = hc < U.HWh ? 2 * hc : 2 * (hc - U.HWh) + 1;
-            const int t = t0 - 1 + ht, h = hb + hr, w = wb + hc;
-            if (t >= 0 && t < P.T && h >= 0 && h < Hs && w >= 0 && w < Ws)
-                off = 4u * (unsigned)((t * Cs) * (Hs * Wp)) + 64u * (unsigned)(h * Wp + w);
+            const int ht = r / qr;
+            const int rem = r - ht * qr;
+            const int hr = rem / pr;
+            int hc = rem - hr * pr;
+            if (hr < hh_n && hc < hw_n) {
+                if (skip) hc = hc < U.HWh ? 2 * hc : 2 * (hc - U.HWh) + 1;
+                const int t = t0 - 1 + ht, h = hb + hr, w = wb + hc;
+                if (t >= 0 && t < P.T && h >= 0 && h < Hs && w >= 0 && w < Ws)
+                    off = 4u * (unsigned)((t * Cs) * (Hs * Wp)) + 64u * (unsigned)(h * Wp + w);
+            }
         }
         goff[i] = off;
     }
 }
 
+// rank of lane l32 inside its pair of ds_read_b128 lane groups ({0-3, 12-15, 20-27} = ranks 0-15, {4-11, 16-19, 28-31} = 16-31;
+// MI355X_MICROARCH.md, LDS), permuted bitwise into the lane's position inside its fragment
+__device__ __forceinline__ int up_lane_position(const UpParams &U, int l32) {
+    int rank;
+    if (l32 < 4) rank = l32;
+    else if (l32 < 12) rank = 16 + (l32 - 4);
+    else if (l32 < 16) rank = 4 + (l32 - 12);
+    else if (l32 < 20) rank = 24 + (l32 - 16);
+    else if (l32 < 28) rank = 8 + (l32 - 20);
+    else rank = 28 + (l32 - 28);
+    int pos = 0;
+#pragma unroll
+    for (int b = 0; b < 5; ++b) pos |= ((rank >> b) & 1) << U.lbit[b];
+    return pos;
+}
+
+#endif  // __HIP_DEVICE_COMPILE__
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// Epilogue of the phase-folded kernel: y = act(acc * scale + shift), max |y| tracking -- conv_epilogue's arithmetic (RES 0) --
+// with the stores re-shaped through a wave-private 4 KB of LDS.  A fragment's 32 positions share a phase: consecutive lanes
+// are positions TWO columns apart, so conv_epilogue's direct stores (lane = position, 32 bytes of its 64-byte channel group
+// per instruction) would touch 32 half-empty 128-byte lines per instruction -- measured: 35 k cycles for the two epilogues of
+// a dec3.conv1 tile against 16 k on the contiguous layout.  Here every lane writes its four channel quads position-major into
+// LDS ([group][position][quarter] x 16 B) and reads them back as lane = (position, quarter): a store instruction then carries
+// the WHOLE 64-byte groups of 16 positions (16 lines per instruction, four instructions per fragment and 16-channel group pair).
+// stage: this wave's 256 x 16 B.  Positions outside the tensor / the box: poff < 0.
+template <int CO_FR, int PO_FR>
+__device__ __forceinline__ void up_epilogue(const ConvParams &P, f32x16 (&acc)[CO_FR][PO_FR], const int (&poff)[PO_FR], int co0,
+                                            int lane, int b, float inv_scale, float *stage_f, float *y, const float *scale_p,
+                                            const float *shift_p, int act, float *y_absmax) {
+    typedef float f32x4q __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x4q __attribute__((ext_vector_type(4)));
+    f32x4q *stage = reinterpret_cast<f32x4q *>(stage_f);
+    const int l32 = lane & 31, half = lane >> 5;
+    const long long seq = (long long)P.T * P.Cout * (P.Hout * P.Woutp);
+    const int gstride = P.Hout * P.Woutp * 64;              // bytes between 16-channel groups
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(y + b * seq, 0, (int)(seq * 4), 0x00020000);
+    const float slope = act_slope(act);
+    const int cbase = co0 + 4 * half;
+    // the position this lane STORES for fragment f, half k: lane (16 k + lane / 4) of the fragment (lanes 0-31 and 32-63 hold the same poff)
+    unsigned vo[PO_FR][2], vmask[PO_FR];
+#pragma unroll
+    for (int f = 0; f < PO_FR; ++f) {
+        vmask[f] = poff[f] >= 0 ? 0x7fffffffu : 0u;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int pn = __builtin_amdgcn_ds_bpermute((16 * k + (lane >> 2)) * 4, poff[f]);
+            vo[f][k] = pn >= 0 ? (unsigned)(pn + 16 * (lane & 3)) : kOOB;
+        }
+    }
+    unsigned ymax = 0u;
+#pragma unroll
+    for (int q = 0; q < CO_FR; ++q) {
+        const bool cok = co0 + q * 32 < P.Cout;              // uniform (Cout need not fill the last channel tile)
+        float sc[16], sh[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int co = cbase + q * 32 + (r & 3) + 8 * (r >> 2);
+            co = co < P.Cout ? co : P.Cout - 1;
+            sc[r] = scale_p[co] * inv_scale;
+            sh[r] = shift_p[co];
+        }
+#pragma unroll
+        for (int f = 0; f < PO_FR; ++f) {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                f32x4q out;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int r = 4 * r4 + k;
+                    float v = acc[q][f][r] * sc[r] + sh[r];
+                    v = apply_act(v, slope);
+                    out[k] = v;
+                    const unsigned av = __builtin_bit_cast(unsigned, v) & (cok ? vmask[f] : 0u);
+                    ymax = av > ymax ? av : ymax;
+                }
+                // channel quad r4 of this lane = group r4 / 2, quarter (r4 & 1) * 2 + half
+                stage[((r4 >> 1) * 32 + l32) * 4 + (r4 & 1) * 2 + half] = out;
+            }
+#pragma unroll
+            for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    f32x4q v = stage[(gq * 32 + 16 * k) * 4 + lane];
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4q, v), rs_y, cok ? vo[f][k] : kOOB,
+                                                           (co0 / 16 + 2 * q + gq) * gstride, 0);
+                    asm volatile("s_nop 1" : "+v"(v));       // store-data hazard of 16-byte stores, see conv_epilogue
+                }
+        }
+    }
+    if (y_absmax) absmax_commit(__builtin_bit_cast(float, ymax), y_absmax + b * P.amax_bs);
+}
 #endif  // __HIP_DEVICE_COMPILE__
 
 // WCO: consumer waves across the channel tile (1: every wave one phase; 2: two position-waves of two phases each)
 // FUSE: 0 = plain, 2 = fused 1x1x1 shortcut (second accumulator set at the centre tap; CO_FR == 1)
+#ifdef V2CE_STAMP
+// diagnostic build: per workgroup and role (consumer wave 0, producer wave 4) the cycles of the whole kernel [0], inside the
+// chunk barriers [1], (consumer) inside the epilogues [2] and the tile setup [3]
+#define TICK() __builtin_amdgcn_s_memtime()
+#define ACC_T(var_, t0_) var_ += TICK() - (t0_)
+#else
+#define TICK() 0ull
+#define ACC_T(var_, t0_) do {} while (0)
+#endif
 template <int WCO, int CO_FR, int PO_FR, int FUSE>
 __global__ __launch_bounds__(512, 1) void conv3d_up_kernel(UpParams U) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const ConvParams &P = U.C;
+    [[maybe_unused]] unsigned long long t_all = TICK(), t_bar = 0, t_epi = 0, t_set = 0;
     constexpr int CK = 16, EPT = 5, K3 = 27;
     constexpr int NG = WCO;                       // phase groups per consumer wave
     constexpr int NFG = PO_FR / NG;               // fragments per phase
@@ -282,14 +400,24 @@ __global__ __launch_bounds__(512, 1) void conv3d_up_kernel(UpParams U) {
         while (moreC) {
             convert(R0);
             load_next(R0);
+            { [[maybe_unused]] const unsigned long long tb = TICK();
             __syncthreads();                                          // barrier gc: pieces[gc & 1] ready
+            ACC_T(t_bar, tb); }
             advance();
             if (!moreC) break;
             convert(R1);
             load_next(R1);
+            { [[maybe_unused]] const unsigned long long tb = TICK();
             __syncthreads();
+            ACC_T(t_bar, tb); }
             advance();
         }
+#ifdef V2CE_STAMP
+        if (lane == 0 && wave == 4) {
+            P.stamps[((long long)blockIdx.x * 2 + 1) * 8 + 0] = TICK() - t_all;
+            P.stamps[((long long)blockIdx.x * 2 + 1) * 8 + 1] = t_bar;
+        }
+#endif
         return;
     }
 
@@ -305,7 +433,14 @@ __global__ __launch_bounds__(512, 1) void conv3d_up_kernel(UpParams U) {
     const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<_Float16 *>(SC ? P.sc_w : P.wq), 0, (int)(4 * wplane_d), 0x00020000);
 
-    f16x8 ah[3][CO_FR], al[3][CO_FR], bh[PO_FR], bl[PO_FR];
+    // B fragments: refilled in place behind the MFMAs that read them (two fragment rows per wave: six MFMAs of the other
+    // fragments cover the LDS round trip), or -- one fragment row per wave, three MFMAs per fragment and tap -- two sets
+    // alternating by tap, the next tap's reads issued a whole tap ahead
+#ifndef V2CE_UP_NB_SC
+#define V2CE_UP_NB_SC 1
+#endif
+    constexpr int NB = CO_FR == 1 ? (FUSE == 2 ? V2CE_UP_NB_SC : 2) : 1;
+    f16x8 ah[3][CO_FR], al[3][CO_FR], bh[NB][PO_FR], bl[NB][PO_FR];
     int wlane[CO_FR];
 #define V2CE_LOAD_A(slot_, soff_, lod_)                                                        \
     {                                                                                          \
@@ -321,9 +456,11 @@ __global__ __launch_bounds__(512, 1) void conv3d_up_kernel(UpParams U) {
     auto list0 = [&](int li, int cg) -> ListRef { return ListRef{U.fold_off + li * kUpListTaps * tap_stride0 + cg * cg_stride, tap_stride0, U.fold_plane}; };
     auto list1 = [&](int cg) -> ListRef { return ListRef{cg * cg_stride, tap_stride, lo_off}; };
 
+    const int lpos = up_lane_position(U, l32);           // this lane's position inside each of its fragments
     int ring_key = -1;
     bool more = true;
     while (more) {
+        [[maybe_unused]] const unsigned long long ts = TICK();
         const int co0 = T.co_t * CO_TILE + wco * CO_FR * 32;
         const float x_scale = scale_of(T.b);
         const float inv_scale = 1.0f / (x_scale * w_scale);
@@ -337,7 +474,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_up_kernel(UpParams U) {
 #pragma unroll
             for (int f = 0; f < PO_FR; ++f) {
                 const int g = f / NFG, p = phase_of(g), ph = p >> 1, pw = p & 1;
-                const int s = (f - g * NFG) * 32 + l32;
+                const int s = (f - g * NFG) * 32 + lpos;
                 bb[f] = half * chs;
                 bool on = kind == 0;
                 if (s < U.n_sub) {
@@ -345,11 +482,11 @@ __global__ __launch_bounds__(512, 1) void conv3d_up_kernel(UpParams U) {
                     const int rem = s - tt * (U.SH * U.SW);
                     const int i = rem / U.SW;
                     const int j = rem - i * U.SW;
-                    if (skip) bb[f] += (tt * P.HH + 2 * i + ph) * P.HWd + j;
+                    if (skip) bb[f] += tt * U.Q1 + (2 * i + ph) * U.P1 + j;
                     else {
                         const bool row = T.h0 + 2 * i + ph == P.Hout - 1, col = T.w0 + 2 * j + pw == P.Wout - 1;
                         on = on || (kind == 1 && row) || (kind == 2 && col) || (kind == 3 && row && col);
-                        bb[f] += on ? (tt * U.HH0 + i + ph) * U.HW0 + j + pw : U.zero0;
+                        bb[f] += on ? tt * U.Q0 + (i + ph) * U.P0 + j + pw : U.zero0;
                     }
                 } else if (!on) bb[f] += U.zero0;
             }
@@ -367,6 +504,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_up_kernel(UpParams U) {
             V2CE_LOAD_A(1, L.abase + L.tstride, L.lod)
         }
 
+        ACC_T(t_set, ts);
         f32x16 acc[CO_FR][PO_FR];
 #pragma unroll
         for (int q = 0; q < CO_FR; ++q)
@@ -392,7 +530,10 @@ __global__ __launch_bounds__(512, 1) void conv3d_up_kernel(UpParams U) {
         //   !SKIP:  12 folded taps (dt, a, b) of the low-resolution box (a correction list runs on bases that send the lanes
         //           it does not apply to into the zeroed region)
         //   rc:     (fused shortcut; -1 = none) the tap in [4, 8) that reads x[i][j] itself
-        auto run_list = [&](auto F0c, auto NFc, auto SKIPc, int rc, const ListRef cur, const ListRef nxt, const f16x8 *qb) {
+        //   have:   the first tap's B fragments are already in flight (the previous group's list issued them: `pre`)
+        //   pre:    also issue the first-tap reads of the NEXT group's fragments (same chunk, bases valid): its list then starts
+        //           without the LDS round trip in front of its first MFMA
+        auto run_list = [&](auto F0c, auto NFc, auto SKIPc, int rc, const ListRef cur, const ListRef nxt, const f16x8 *qb, bool have, bool pre) {
             constexpr int F0 = decltype(F0c)::value, NF = decltype(NFc)::value;
             constexpr bool SKIP = decltype(SKIPc)::value;
             constexpr int NT = SKIP ? K3 : kUpListTaps;
@@ -400,25 +541,46 @@ __global__ __launch_bounds__(512, 1) void conv3d_up_kernel(UpParams U) {
                 if constexpr (SKIP) {
                     const int pw = phase_of(f / NFG) & 1;                      // uniform
                     const int dt = tap / 9, dh = (tap / 3) % 3, dw = tap % 3;
-                    return bb[f] + (dt * P.HH + dh) * P.HWd + ((pw + dw) & 1) * U.HWh + ((pw + dw) >> 1);
+                    return bb[f] + dt * U.Q1 + dh * U.P1 + ((pw + dw) & 1) * U.HWh + ((pw + dw) >> 1);
                 } else {
                     const int dt = tap >> 2, a = (tap >> 1) & 1, b = tap & 1;
-                    return bb[f] + (dt * U.HH0 + a) * U.HW0 + b;
+                    return bb[f] + dt * U.Q0 + a * U.P0 + b;
                 }
             };
+            if (!have) {
 #pragma unroll
-            for (int f = F0; f < F0 + NF; ++f) {
-                const int a = addr(f, 0);
-                bh[f] = qb[a];
-                bl[f] = qb[a + 2 * chs];
+                for (int f = F0; f < F0 + NF; ++f) {
+                    const int a = addr(f, 0);
+                    bh[0][f] = qb[a];
+                    bl[0][f] = qb[a + 2 * chs];
+                }
+            }
+            if constexpr (!SKIP && F0 + NF < PO_FR) {
+                if (pre) {
+#pragma unroll
+                    for (int f = F0 + NF; f < F0 + 2 * NF; ++f) {
+                        const int a = addr(f, 0);
+                        bh[0][f] = qb[a];
+                        bl[0][f] = qb[a + 2 * chs];
+                    }
+                }
             }
             step_loop<0, NT>([&](auto tc) {
                 constexpr int tap = decltype(tc)::value;
                 constexpr int pt = tap + 2;                   // the tap whose A fragments are fetched now
+                constexpr int cs = NB == 2 ? tap % 2 : 0, ns = NB == 2 ? (tap + 1) % 2 : 0;      // B sets of this / the next tap
                 if constexpr (pt < NT) {
                     V2CE_LOAD_A(pt % 3, cur.abase + pt * cur.tstride, cur.lod)
                 } else {
                     V2CE_LOAD_A(pt % 3, nxt.abase + (pt - NT) * nxt.tstride, nxt.lod)
+                }
+                if constexpr (NB == 2 && tap + 1 < NT) {       // the next tap's B fragments, a whole tap ahead
+#pragma unroll
+                    for (int f = F0; f < F0 + NF; ++f) {
+                        const int a = addr(f, tap + 1);
+                        bh[ns][f] = qb[a];
+                        bl[ns][f] = qb[a + 2 * chs];
+                    }
                 }
                 bool centre = false;
                 if constexpr (SC && SKIP) centre = tap == 13;
@@ -427,24 +589,24 @@ __global__ __launch_bounds__(512, 1) void conv3d_up_kernel(UpParams U) {
                 for (int f = F0; f < F0 + NF; ++f) {
 #pragma unroll
                     for (int q = 0; q < CO_FR; ++q) {
-                        acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tap % 3][q], bh[f], acc[q][f], 0, 0, 0);
-                        acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tap % 3][q], bl[f], acc[q][f], 0, 0, 0);
-                        acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tap % 3][q], bh[f], acc[q][f], 0, 0, 0);
+                        acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tap % 3][q], bh[cs][f], acc[q][f], 0, 0, 0);
+                        acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tap % 3][q], bl[cs][f], acc[q][f], 0, 0, 0);
+                        acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tap % 3][q], bh[cs][f], acc[q][f], 0, 0, 0);
                     }
                     if constexpr (SC) {
                         if (centre) {
 #pragma unroll
                             for (int q = 0; q < CO_FR; ++q) {
-                                accd[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahd[q], bh[f], accd[q][f], 0, 0, 0);
-                                accd[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahd[q], bl[f], accd[q][f], 0, 0, 0);
-                                accd[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ald[q], bh[f], accd[q][f], 0, 0, 0);
+                                accd[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahd[q], bh[cs][f], accd[q][f], 0, 0, 0);
+                                accd[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahd[q], bl[cs][f], accd[q][f], 0, 0, 0);
+                                accd[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ald[q], bh[cs][f], accd[q][f], 0, 0, 0);
                             }
                         }
                     }
-                    if constexpr (tap + 1 < NT) {            // refill in place for the next tap
+                    if constexpr (NB == 1 && tap + 1 < NT) {   // refill in place for the next tap
                         const int a = addr(f, tap + 1);
-                        bh[f] = qb[a];
-                        bl[f] = qb[a + 2 * chs];
+                        bh[0][f] = qb[a];
+                        bl[0][f] = qb[a + 2 * chs];
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -463,7 +625,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_up_kernel(UpParams U) {
                     ald[q] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_d, wlane[q], wc + (int)(2 * wplane_d), 0));
                 }
             }
+            { [[maybe_unused]] const unsigned long long tb = TICK();
             __syncthreads();                                   // barrier gc: pieces[gc & 1] ready
+            ACC_T(t_bar, tb); }
             // (opaque per chunk: otherwise the per-tap piece addresses -- bb[f] + tap offset, invariant over the chunks -- are
             // all hoisted out of the chunk loop and spilled, a scratch reload per tap and fragment)
 #pragma unroll
@@ -490,12 +654,15 @@ __global__ __launch_bounds__(512, 1) void conv3d_up_kernel(UpParams U) {
                     return list0(8, cg);
                 };
                 const int rc = SC ? 4 + (1 - ph) * 2 + (1 - pw) : -1;
+                // (group 0 without correction passes hands group 1 its first B fragments: see run_list)
+                const bool chain0 = NG == 2 && !(tile_h && (phase_of(0) >> 1) == 0) && !tile_w;
                 for (int k = 0; k < npass; ++k) {
                     int kind, nkind;
                     const ListRef cur = pass_list(k, kind);
                     const ListRef nxt = k + 1 < npass ? pass_list(k + 1, nkind) : grp_after;
                     if (k > 0) set_bases(false, kind);                   // (edge tiles only)
-                    run_list(integral_constant<int, g * NFG>{}, integral_constant<int, NFG>{}, No{}, k == 0 ? rc : -1, cur, nxt, qb);
+                    run_list(integral_constant<int, g * NFG>{}, integral_constant<int, NFG>{}, No{}, k == 0 ? rc : -1, cur, nxt, qb,
+                             g == 1 && k == 0 && chain0, g == 0 && chain0);
                 }
                 if (npass > 1) set_bases(false, 0);
             });
@@ -506,7 +673,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_up_kernel(UpParams U) {
             const f16x8 *qb = chunk_head(cg);
             // the last chunk prefetches the first list of the next tile with the same channel tile
             const ListRef nxt = cg + 1 < CG ? list1(cg + 1) : list0(phase_of(0), 0);
-            run_list(integral_constant<int, 0>{}, integral_constant<int, PO_FR>{}, Yes{}, -1, list1(cg), nxt, qb);
+            run_list(integral_constant<int, 0>{}, integral_constant<int, PO_FR>{}, Yes{}, -1, list1(cg), nxt, qb, false, false);
         }
         ring_key = T.co_t;
 
@@ -514,7 +681,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_up_kernel(UpParams U) {
 #pragma unroll
         for (int f = 0; f < PO_FR; ++f) {
             const int g = f / NFG, p = phase_of(g), ph = p >> 1, pw = p & 1;
-            const int s = (f - g * NFG) * 32 + l32;
+            const int s = (f - g * NFG) * 32 + lpos;
             poff[f] = -1;
             if (s < U.n_sub) {
                 const int tt = s / (U.SH * U.SW);
@@ -526,17 +693,42 @@ __global__ __launch_bounds__(512, 1) void conv3d_up_kernel(UpParams U) {
                     poff[f] = 4 * ((t * P.Cout) * (P.Hout * P.Woutp)) + 64 * (h * P.Woutp + w);
             }
         }
-        conv_epilogue<CO_FR, PO_FR, true, false, 0, true>(P, acc, poff, co0, half, T.b, inv_scale);
-        if constexpr (SC) {
-            ConvParams Q = P;
-            Q.scale = P.sc_scale; Q.shift = P.sc_shift; Q.res = nullptr; Q.y = P.sc_y; Q.act = V2CE_ACT_NONE;
-            Q.y_absmax = nullptr;
-            const float wd_scale = reinterpret_cast<const float *>(P.sc_w + 2 * wplane_d)[1];
-            conv_epilogue<CO_FR, PO_FR, true, false, 0, true>(Q, accd, poff, co0, half, T.b, 1.0f / (x_scale * wd_scale));
+        [[maybe_unused]] const unsigned long long te = TICK();
+        float *stage = reinterpret_cast<float *>(conv_smem + U.stage_off) + wave * 1024;       // this wave's 4 KB
+        if (U.dbg == 1) {
+#pragma unroll
+            for (int f = 0; f < PO_FR; ++f) poff[f] = -1;
         }
+        if (U.dbg != 2) {
+        up_epilogue<CO_FR, PO_FR>(P, acc, poff, co0, lane, T.b, inv_scale, stage, P.y, P.scale, P.shift, P.act, P.y_absmax);
+        if constexpr (SC) {                                     // shortcut: bn_d(conv_d x), no activation, no range slot
+            const float wd_scale = reinterpret_cast<const float *>(P.sc_w + 2 * wplane_d)[1];
+            up_epilogue<CO_FR, PO_FR>(P, accd, poff, co0, lane, T.b, 1.0f / (x_scale * wd_scale), stage, P.sc_y, P.sc_scale, P.sc_shift,
+                                      V2CE_ACT_NONE, nullptr);
+        }
+        } else {
+            float sink = 0.0f;
+#pragma unroll
+            for (int q = 0; q < CO_FR; ++q)
+#pragma unroll
+                for (int f = 0; f < PO_FR; ++f) {
+                    sink += acc[q][f][0];
+                    if constexpr (SC) sink += accd[q][f][0];
+                }
+            if (sink == 12345.678f) P.y[0] = sink;
+        }
+        ACC_T(t_epi, te);
         vb += (int)gridDim.x;
         more = next_tile(vb, T);
     }
+#ifdef V2CE_STAMP
+    if (lane == 0 && wave == 0) {
+        P.stamps[((long long)blockIdx.x * 2 + 0) * 8 + 0] = TICK() - t_all;
+        P.stamps[((long long)blockIdx.x * 2 + 0) * 8 + 1] = t_bar;
+        P.stamps[((long long)blockIdx.x * 2 + 0) * 8 + 2] = t_epi;
+        P.stamps[((long long)blockIdx.x * 2 + 0) * 8 + 3] = t_set;
+    }
+#endif
 #undef V2CE_LOAD_A
 #endif  // __HIP_DEVICE_COMPILE__
 }
@@ -629,29 +821,122 @@ __global__ __launch_bounds__(256) void up_fold_pack_kernel(const float *__restri
     }
 }
 
-struct Box { int tt, sh, sw; };
+// ---------------------------------------------------------------------------------------------
+// host side: box, LDS pitches and lane order
+// ---------------------------------------------------------------------------------------------
+struct UpCfg {
+    int tt, sh, sw;               // phase sub-box
+    int P0, Q0, P1, Q1;           // LDS pitches (rows / time steps) of the low-resolution and of the skip box
+    int lbit[5];                  // lane order (up_lane_position)
+    double conf0, conf1;          // LDS cycles per 16-lane group of a B-fragment read (1 = conflict-free), upsampled / skip chunks
+};
 
-// phase sub-box (tt, sh, sw): tt * sh * sw <= n_sub_max positions per phase, skip halo (tt+2)(2sh+2)(2sw+2) <= 1280;
-// fewest workgroup rounds over the CUs, then fewest tiles, then the smaller halo volume, then wide rows
-Box choose_up_box(int B, int T, int Ho, int Wo, int n_sub_max, int n_co_tiles, int n_cu) {
-    Box best{1, 1, 1};
-    long long best_rounds = -1, best_blocks = 0, best_halo = 0;
+// LDS cycles per 16-lane group of the consumers' ds_read_b128 (each group is served in max-multiplicity-per-slot cycles: a 16-byte
+// piece covers one of the sixteen slots of the 256-byte bank row), averaged over the groups of the nfg fragments of a phase
+double up_conflicts(const int (&lbit)[5], int sh, int sw, int n_sub, int nfg, int pr, int qr, int rowmul) {
+    static const int grp[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                   {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
+    double sum = 0.0;
+    for (int k = 0; k < nfg; ++k)
+        for (int g = 0; g < 2; ++g) {
+            int cnt[16] = {0}, worst = 1;
+            int seen[16][16];
+            for (int idx = 0; idx < 16; ++idx) {
+                const int rank = g * 16 + idx;
+                int pos = 0;
+                for (int b = 0; b < 5; ++b) pos |= ((rank >> b) & 1) << lbit[b];
+                const int s = k * 32 + pos;
+                int a = 0;                                     // lanes past the sub-box read piece 0
+                if (s < n_sub) {
+                    const int tt = s / (sh * sw), rem = s - tt * (sh * sw), i = rem / sw, j = rem - i * sw;
+                    a = tt * qr + rowmul * i * pr + j;
+                }
+                const int slot = a & 15;
+                bool dup = false;                              // identical addresses broadcast
+                for (int c = 0; c < cnt[slot]; ++c) dup = dup || seen[slot][c] == a;
+                if (!dup) seen[slot][cnt[slot]++] = a;
+                worst = cnt[slot] > worst ? cnt[slot] : worst;
+            }
+            (void)grp;
+            sum += worst;
+        }
+    return sum / (2.0 * nfg);
+}
+
+// For a sub-box: the pitches and lane order with the fewest LDS cycles per read, the two chunk kinds searched independently per
+// lane order (w0 / w1 = reads of a tile on upsampled / skip chunks); false when nothing fits the LDS budget (chs <= 1152 pieces)
+bool up_pitches(UpCfg &c, int nfg, bool edges, double w0, double w1) {
+    const int HT = c.tt + 2, HH0 = c.sh + 2, HW0 = c.sw + 2, HH = 2 * c.sh + 2, HWd = 2 * c.sw + 2, n_sub = c.tt * c.sh * c.sw;
+    int perm[5] = {0, 1, 2, 3, 4};
+    double best = -1.0;
+    do {
+        double b0 = -1.0, b1 = -1.0;
+        int p0 = 0, q0 = 0, p1 = 0, q1 = 0;
+        for (int P = HW0; P <= HW0 + 8; ++P)
+            for (int pad = 0; pad < 16; ++pad) {
+                const int Q = HH0 * P + pad, plane0 = HT * Q, z0 = (plane0 + 63) & ~63;
+                if ((edges ? z0 + plane0 : plane0) > 1152) continue;
+                const double cf = up_conflicts(perm, c.sh, c.sw, n_sub, nfg, P, Q, 1) + 1e-4 * plane0;
+                if (b0 < 0 || cf < b0) { b0 = cf; p0 = P; q0 = Q; }
+            }
+        for (int P = HWd; P <= HWd + 8; ++P)
+            for (int pad = 0; pad < 16; ++pad) {
+                const int Q = HH * P + pad;
+                if (HT * Q > 1152) continue;
+                const double cf = up_conflicts(perm, c.sh, c.sw, n_sub, nfg, P, Q, 2) + 1e-4 * HT * Q;
+                if (b1 < 0 || cf < b1) { b1 = cf; p1 = P; q1 = Q; }
+            }
+        if (b0 < 0 || b1 < 0) return false;
+        const double tot = w0 * b0 + w1 * b1;
+        if (best < 0 || tot < best) {
+            best = tot;
+            c.P0 = p0; c.Q0 = q0; c.P1 = p1; c.Q1 = q1;
+            for (int b = 0; b < 5; ++b) c.lbit[b] = perm[b];
+            c.conf0 = b0; c.conf1 = b1;
+        }
+    } while (std::next_permutation(perm, perm + 5));
+    return true;
+}
+
+// phase sub-box (tt, sh, sw): tt * sh * sw <= n_sub_max positions per phase.  Fewest workgroup rounds over the CUs; among the
+// boxes within 3 % of the fewest tiles the one whose B-fragment reads cost the fewest LDS cycles, then the smaller halo, then
+// wide rows.  fixed: a caller-given box (only the pitches are searched)
+bool choose_up_cfg(UpCfg &out, int B, int T, int Ho, int Wo, int n_sub_max, int nfg, int n_co_tiles, int n_cu, bool edges, double w0,
+                   double w1, const UpCfg *fixed) {
+    struct Cand { UpCfg c; long long rounds, blocks, halo; };
+    std::vector<Cand> cands;
     for (int tt = 1; tt <= 16 && tt <= (T > 1 ? 2 * T - 1 : 1); tt *= 2)
         for (int sh = 1; sh <= 64 && 2 * (sh - 1) < Ho; ++sh)
             for (int sw = 1; sw <= 64 && 2 * (sw - 1) < Wo; ++sw) {
+                if (fixed && (tt != fixed->tt || sh != fixed->sh || sw != fixed->sw)) continue;
                 if (tt * sh * sw > n_sub_max) break;
                 const long long halo1 = (long long)(tt + 2) * (2 * sh + 2) * (2 * sw + 2);
-                if (halo1 > 1280) break;
+                if (halo1 > 1152) break;                     // (128 B of pieces per element + 16 KB of epilogue staging in 160 KB)
                 const long long nsp = (long long)B * ((T + tt - 1) / tt) * ((Ho + 2 * sh - 1) / (2 * sh)) * ((Wo + 2 * sw - 1) / (2 * sw));
-                const long long blocks = 8 * ((nsp + 7) / 8) * n_co_tiles;
-                const long long rounds = (blocks + n_cu - 1) / n_cu;
-                const long long halo = halo1 + 2 * (long long)(tt + 2) * (sh + 2) * (sw + 2);
-                const bool better = best_rounds < 0 || rounds < best_rounds ||
-                                    (rounds == best_rounds && (blocks < best_blocks ||
-                                     (blocks == best_blocks && (halo < best_halo || (halo == best_halo && sw > best.sw)))));
-                if (better) { best = {tt, sh, sw}; best_rounds = rounds; best_blocks = blocks; best_halo = halo; }
+                Cand k{};
+                k.c.tt = tt; k.c.sh = sh; k.c.sw = sw;
+                k.blocks = 8 * ((nsp + 7) / 8) * n_co_tiles;
+                k.rounds = (k.blocks + n_cu - 1) / n_cu;
+                k.halo = halo1 + 2 * (long long)(tt + 2) * (sh + 2) * (sw + 2);
+                cands.push_back(k);
             }
-    return best;
+    if (cands.empty()) return false;
+    long long min_rounds = cands[0].rounds, min_blocks = -1;
+    for (const Cand &k : cands) min_rounds = k.rounds < min_rounds ? k.rounds : min_rounds;
+    for (const Cand &k : cands)
+        if (k.rounds == min_rounds && (min_blocks < 0 || k.blocks < min_blocks)) min_blocks = k.blocks;
+    bool have = false;
+    double best_cost = 0.0;
+    long long best_halo = 0;
+    for (Cand &k : cands) {
+        if (k.rounds != min_rounds || k.blocks * 100 > min_blocks * 103) continue;
+        if (!up_pitches(k.c, nfg, edges, w0, w1)) continue;
+        const double cost = (double)k.blocks * (w0 * k.c.conf0 + w1 * k.c.conf1);
+        if (!have || cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && (k.halo < best_halo || (k.halo == best_halo && k.c.sw > out.sw)))) {
+            have = true; best_cost = cost; best_halo = k.halo; out = k.c;
+        }
+    }
+    return have;
 }
 
 thread_local char *g_up_name_out = nullptr;
@@ -673,28 +958,48 @@ int launch_up(UpParams U, const v2ce_conv3d_desc &d, hipStream_t stream) {
         return n < 8 ? 8 : (n / 8) * 8;
     }();
     P.n_co_tiles = (d.Cout + CO_TILE - 1) / CO_TILE;
-    Box bx{0, 0, 0};
-    if (d.tile_t > 0 && d.tile_h > 0 && d.tile_w > 0) bx = Box{d.tile_t, d.tile_h / 2, d.tile_w / 2};
-    else {
-        char key[64];
-        snprintf(key, sizeof key, "V2CE_UPBOX_%dx%d_%d", d.Hout, d.Wout, NFG * 32);
-        if (const char *e = getenv(key)) {
-            int a, b, c;
-            if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3) bx = Box{a, b / 2, c / 2};
+    // box, pitches and lane order: searched once per launch geometry
+    UpCfg cfg{};
+    {
+        static std::mutex mu;
+        static std::map<std::tuple<int, int, int, int, int, int, int, int, int, int>, UpCfg> cache;
+        std::lock_guard<std::mutex> g(mu);
+        const auto key = std::make_tuple(d.B, d.T, d.Hout, d.Wout, d.C0, d.C1, d.Cout, NFG + 16 * WCO, d.tile_t, d.tile_h * 4096 + d.tile_w);
+        auto it = cache.find(key);
+        if (it == cache.end()) {
+            UpCfg fixed{};
+            bool have_fixed = false;
+            if (d.tile_t > 0 && d.tile_h > 0 && d.tile_w > 0) { fixed.tt = d.tile_t; fixed.sh = d.tile_h / 2; fixed.sw = d.tile_w / 2; have_fixed = true; }
+            else {
+                char name[64];
+                snprintf(name, sizeof name, "V2CE_UPBOX_%dx%d_%d", d.Hout, d.Wout, NFG * 32);
+                if (const char *e = getenv(name)) {
+                    int a, b, c;
+                    if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3) { fixed.tt = a; fixed.sh = b / 2; fixed.sw = c / 2; have_fixed = true; }
+                }
+            }
+            const bool ok = choose_up_cfg(cfg, d.B, d.T, d.Hout, d.Wout, NFG * 32, NFG, P.n_co_tiles, n_cu, U.odd_h || U.odd_w,
+                                          12.0 * (d.C0 / 16), 27.0 * (d.C1 / 16), have_fixed ? &fixed : nullptr);
+            V2CE_REQUIRE(ok, V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd_up2: no box fits (%d positions per phase; TH, TW must be even; halo <= 1152 elements)", NFG * 32);
+            it = cache.emplace(key, cfg).first;
+            if (getenv("V2CE_UP_VERBOSE"))
+                fprintf(stderr, "[up cfg %dx%d C0=%d C1=%d Cout=%d] box %dx%dx%d pitches low %d/%d skip %d/%d lane bits %d%d%d%d%d LDS cycles per read %.2f / %.2f\n", d.Hout,
+                        d.Wout, d.C0, d.C1, d.Cout, cfg.tt, 2 * cfg.sh, 2 * cfg.sw, cfg.P0, cfg.Q0, cfg.P1, cfg.Q1, cfg.lbit[0], cfg.lbit[1], cfg.lbit[2],
+                        cfg.lbit[3], cfg.lbit[4], cfg.conf0, cfg.conf1);
         }
-        if (bx.tt <= 0) bx = choose_up_box(d.B, d.T, d.Hout, d.Wout, NFG * 32, P.n_co_tiles, n_cu);
+        cfg = it->second;
     }
-    V2CE_REQUIRE(bx.tt > 0 && bx.sh > 0 && bx.sw > 0 && bx.tt * bx.sh * bx.sw <= NFG * 32, V2CE_ERR_UNSUPPORTED,
-                 "v2ce_conv3d_fwd_up2: box %dx%dx%d does not fit %d positions per phase (TH, TW must be even)", bx.tt, 2 * bx.sh,
-                 2 * bx.sw, NFG * 32);
-    P.TT = bx.tt; P.TH = 2 * bx.sh; P.TW = 2 * bx.sw;
-    U.SH = bx.sh; U.SW = bx.sw; U.n_sub = bx.tt * bx.sh * bx.sw;
+    P.TT = cfg.tt; P.TH = 2 * cfg.sh; P.TW = 2 * cfg.sw;
+    U.SH = cfg.sh; U.SW = cfg.sw; U.n_sub = cfg.tt * cfg.sh * cfg.sw;
     P.n_pos = 4 * U.n_sub;
     P.HT = P.TT + 2; P.HH = P.TH + 2; P.HWd = P.TW + 2;
-    P.plane = P.HT * P.HH * P.HWd;
-    U.HH0 = U.SH + 2; U.HW0 = U.SW + 2; U.plane0 = P.HT * U.HH0 * U.HW0;
+    U.HH0 = U.SH + 2; U.HW0 = U.SW + 2;
     U.HWh = P.HWd / 2;
-    V2CE_REQUIRE(P.plane <= 1280, V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd_up2: the box's halo does not fit (%d > 1280 elements)", P.plane);
+    U.P0 = cfg.P0; U.Q0 = cfg.Q0; U.P1 = cfg.P1; U.Q1 = cfg.Q1;
+    for (int b = 0; b < 5; ++b) U.lbit[b] = cfg.lbit[b];
+    P.plane = P.HT * U.Q1;                                 // pitched slots of a skip chunk
+    U.plane0 = P.HT * U.Q0;
+    V2CE_REQUIRE(P.plane <= 1152, V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd_up2: the box's halo does not fit (%d > 1152 elements)", P.plane);
     P.nT = (d.T + P.TT - 1) / P.TT; P.nH = (d.Hout + P.TH - 1) / P.TH; P.nW = (d.Wout + P.TW - 1) / P.TW;
     P.n_spatial = d.B * P.nT * P.nH * P.nW;
     P.xcd_remap = 1;
@@ -705,14 +1010,40 @@ int launch_up(UpParams U, const v2ce_conv3d_desc &d, hipStream_t stream) {
     int chs = (P.plane + 63) & ~63;
     if (chs < U.zero0 + U.plane0) chs = (U.zero0 + U.plane0 + 63) & ~63;      // (tiny boxes only)
     U.chs = chs;
-    const size_t lds = (size_t)chs * 128;
+    U.stage_off = chs * 128;
+    const size_t lds = (size_t)chs * 128 + 4 * 4096;
     V2CE_REQUIRE(lds <= 160 * 1024, V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd_up2: %zu B of LDS", lds);
     auto kern = conv3d_up_kernel<WCO, CO_FR, PO_FR, FUSE>;
     V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     P.total_blocks = (int)blocks;
     const unsigned grid = (unsigned)(blocks > n_cu ? n_cu : blocks);
+#ifdef V2CE_STAMP
+    V2CE_HIP_CHECK(hipMalloc(&P.stamps, (size_t)grid * 16 * sizeof(unsigned long long)));
+    V2CE_HIP_CHECK(hipMemset(P.stamps, 0, (size_t)grid * 16 * sizeof(unsigned long long)));
+#endif
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, U);
     V2CE_HIP_CHECK(hipGetLastError());
+#ifdef V2CE_STAMP
+    {
+        std::vector<unsigned long long> h((size_t)grid * 16);
+        V2CE_HIP_CHECK(hipDeviceSynchronize());
+        V2CE_HIP_CHECK(hipMemcpy(h.data(), P.stamps, h.size() * 8, hipMemcpyDeviceToHost));
+        V2CE_HIP_CHECK(hipFree(P.stamps));
+        auto med = [&](int role, int a) {
+            std::vector<unsigned long long> v;
+            for (unsigned k = 0; k < grid; ++k) v.push_back(h[(k * 2 + role) * 8 + a]);
+            std::sort(v.begin(), v.end());
+            return (long long)v[v.size() / 2];
+        };
+        const double tiles = (double)blocks / grid;
+        fprintf(stderr, "[stamp up<%d,%d,%d,%d> CG0=%d CG=%d box=%dx%dx%d plane0=%d plane1=%d blocks=%lld = %.2f tiles per workgroup] "
+                "consumer wave 0 (cycles, median over workgroups): kernel %lld, in chunk barriers %lld (%.1f %%), epilogues %lld (%.1f %%), tile setup %lld (%.1f %%) | "
+                "producer wave 4: kernel %lld, in chunk barriers %lld (%.1f %%)\n",
+                WCO, CO_FR, PO_FR, FUSE, U.CG0, P.Cin / 16, P.TT, P.TH, P.TW, U.plane0, P.plane, blocks, tiles,
+                med(0, 0), med(0, 1), 100.0 * med(0, 1) / med(0, 0), med(0, 2), 100.0 * med(0, 2) / med(0, 0), med(0, 3), 100.0 * med(0, 3) / med(0, 0),
+                med(1, 0), med(1, 1), 100.0 * med(1, 1) / med(1, 0));
+    }
+#endif
     return V2CE_OK;
 }
 
@@ -812,6 +1143,7 @@ static int up_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const floa
     U.odd_h = d.Hout & 1; U.odd_w = d.Wout & 1;
     U.fold_off = (int)up_fold_off(d.Cout, P.Cin);
     U.fold_plane = (int)((size_t)kUpSlots * d.C0 * d.Cout * 2);
+    { const char *e = getenv("V2CE_UP_DBG"); U.dbg = e ? atoi(e) : 0; }
     hipStream_t st = as_stream(stream);
     if (sc_w) return launch_up<1, 1, 4, 2>(U, d, st);
     if (d.Cout <= 32) return launch_up<1, 1, 4, 0>(U, d, st);
