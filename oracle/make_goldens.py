@@ -438,8 +438,16 @@ def gen_kat():
 
 
 # --------------------------------------------------------------------------------------------- G7
+_REF_V2CE = None
+
+
 def import_reference_v2ce():
-    """Import /root/reference/v2ce.py with its missing third-party imports stubbed."""
+    """Import /root/reference/v2ce.py with its missing third-party imports stubbed.  Imported ONCE: a second
+    call used to install a fresh cv2 stub in sys.modules while the cached reference module kept the first one, so
+    gen_event_frames() patched a stub the reference never saw (the default invocation died there)."""
+    global _REF_V2CE
+    if _REF_V2CE is not None:
+        return _REF_V2CE
     cv2 = types.ModuleType("cv2")
 
     def resize(img, size):
@@ -477,6 +485,7 @@ def import_reference_v2ce():
     import v2ce as ref_v2ce
     ref_v2ce.logger = logging.getLogger("V2CE")
     torch.Tensor.cuda = lambda self, *a, **k: self
+    _REF_V2CE = ref_v2ce
     return ref_v2ce
 
 
