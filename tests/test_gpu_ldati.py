@@ -561,6 +561,46 @@ def test_c_abi_fused_dense_call_sequence(monkeypatch, capfd):
         hint, bin_hint = max_seg, max_tile + 64
 
 
+def test_dense_slot_mode_counts_a_tile_bin_beyond_16_bits():
+    """in slot mode the dense tile kernel is the count pass; its packed 16 + 16-bit wave totals wrapped for a
+    (tile, bin) of >= 65536 events (mean >= 32 per pixel and bin: unphysical, but reachable right behind a dense call that armed
+    the dense hint), the wrapped count passed the slot test and the emit accepted garbage.  A dense call, then a grid of ~40
+    events per voxel of the same shape: counts, statistics and events equal the two-pass path's / the oracle's."""
+    import ctypes
+    from v2ce_toolbox_amd import LDATI as LD
+    L = hip.lib()
+    rng = np.random.default_rng(11)
+    H, W = 64, 128                                              # 4 tiles of 2048 pixels per polarity plane
+    dense = (5.0 * rng.random((1, 2, 10, H, W))).astype(np.float32)
+    huge = (36.0 + 8.0 * rng.random((1, 2, 10, H, W))).astype(np.float32)        # ~40 events per voxel: ~82 k per (tile, bin)
+    LD._SEG_HINT.clear()
+    for vox in (dense, dense, huge):                            # (the second call runs the dense fused form; the third inherits its hint)
+        y = torch.from_numpy(vox).cuda()
+        ev = LD.ldati_device(y, fps=30, seed=9)
+        want = O.emit_soa(vox, fps=30, seed=9)
+        assert np.array_equal(ev.seg_counts, want[0])
+        assert np.array_equal(ev.ts.cpu().numpy(), want[1]) and np.array_equal(ev.x.cpu().numpy(), want[2])
+        assert np.array_equal(ev.y.cpu().numpy(), want[3]) and np.array_equal(ev.p.cpu().numpy(), want[4])
+    # and at the ABI: the dense fused count with a slot hint reports the true (unwrapped) statistics of the huge grid
+    y = torch.from_numpy(huge).cuda()
+    o = hip.LdatiOptions(hip.STRATEGY_SLOPE, 0, hip.POOL_NONE, 3)
+    st = hip.stream_ptr(y.device)
+    tws = torch.empty(L.v2ce_ldati_tile_ws_bytes(1, H, W), dtype=torch.uint8, device="cuda")
+    meta = torch.empty(9 + 1 + 8, dtype=torch.int64, device="cuda")
+    hip.check(L.v2ce_ldati_count(y.data_ptr(), 1, H, W, ctypes.byref(o), tws.data_ptr(), tws.numel(), meta.data_ptr(), meta[10:].data_ptr(), st), "count")
+    ref = meta.cpu().numpy().copy()
+    seg_hint, bin_hint = int(ref[12]), 12000
+    fb = L.v2ce_ldati_fused_ws_bytes(1, H, W, 30.0, 0.0, ctypes.byref(o), seg_hint, bin_hint)
+    assert fb > 0
+    fws = torch.empty(fb, dtype=torch.uint8, device="cuda")
+    meta2 = torch.zeros(9 + 1 + 8, dtype=torch.int64, device="cuda")
+    hip.check(L.v2ce_ldati_count_fused(y.data_ptr(), 1, H, W, 30.0, 0.0, ctypes.byref(o), hip.RNG_PHILOX, None, 0, 9, 0, seg_hint, bin_hint,
+                                       tws.data_ptr(), tws.numel(), fws.data_ptr(), fws.numel(), meta2.data_ptr(), meta2[10:].data_ptr(), st), "count_fused")
+    got = meta2.cpu().numpy()
+    assert np.array_equal(got[:10], ref[:10]), (got[:10], ref[:10])                       # segment offsets
+    assert np.array_equal(got[10:14], ref[10:14]) and got[11] > 65535, (got[10:15], ref[10:14])   # max_n, max (tile, bin), max segment, total
+
+
 def test_fused_dense_form_falls_back_for_calls_the_dense_kernel_does_not_serve():
     """Dense voxels at t0 = 3000 s need 64-bit times: the dense tile kernel does not serve such a call.  With the expectations of
     a dense stream ldati_begin still asks for the dense form of the fused count; the library then runs the plain count pass

@@ -1410,7 +1410,7 @@ __device__ __forceinline__ void dense_tile_body(const LdatiParams &P) {
     unsigned *S = reinterpret_cast<unsigned *>(tile_smem);
     unsigned *O = S + P.capA;
     unsigned *hist = O + P.capA + 8;                    // [NW][NB]: row r counts the records at positions [r L, (r + 1) L)
-    unsigned *part = hist + NW * P.NB;                  // [3][NW] wave totals: events | singles << 16, k == 0 units | k != 0 units << 16 (third row unused)
+    unsigned *part = hist + NW * P.NB;                  // [3][NW] wave totals: events | singles << 16, k == 0 units | k != 0 units << 16, slot mode: events unpacked
     unsigned *spart = part + 3 * NW;                    // [NW + 1] scan partials
     unsigned *bctr = spart + NW + 1;                    // the next batch of the timestamp phase
     unsigned *dsto = bctr + 2;                          // [9][2]: where the tile's run of bin c starts in records[] (loaded once: a
@@ -1487,6 +1487,10 @@ __device__ __forceinline__ void dense_tile_body(const LdatiParams &P) {
         // the slope-table index rides in bits 3..13
         unsigned cls[PPT], aex[PPT], uex[PPT];
         unsigned At = 0, Ut = 0;
+        // slot mode: the lane's events once more, UNPACKED.  The packed totals wrap at 2^16; the two-pass path bounds a (tile, bin)
+        // by capA before this kernel runs, but as the count pass it must count ANY grid right (an unphysical one behind a dense call
+        // that armed the dense hint: a wrapped total would pass the `N > capA` test below and index S past the slot)
+        unsigned Ae = 0;
         const bool multi_on = FAST || P.strategy != V2CE_STRATEGY_NONE, edge = c == 0 || c == 8;
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
@@ -1504,11 +1508,16 @@ __device__ __forceinline__ void dense_tile_body(const LdatiParams &P) {
             uex[q] = Ut;
             At += (cl ? (unsigned)n : 0u) + (cl == 1u ? 0x10000u : 0u);
             Ut += cl == 2u ? units : cl == 3u ? units << 16 : 0u;
+            Ae += cl ? ((unsigned)n < (1u << 20) ? (unsigned)n : 1u << 20) : 0u;     // (saturating per voxel: the sum of a tile stays below 2^32)
         }
         const unsigned iA = wave_incl_scan(At, lane), iU = wave_incl_scan(Ut, lane);
         const unsigned baseA = iA - At, baseU = iU - Ut;
         const unsigned runA = (unsigned)__builtin_amdgcn_readlane((int)iA, 63), runU = (unsigned)__builtin_amdgcn_readlane((int)iU, 63);
         if (lane == 0) { part[wid] = runA; part[NW + wid] = runU; }      // (events | singles << 16), (k == 0 units | k != 0 units << 16)
+        if (P.slot_cap) {                                                   // uniform
+            const unsigned runE = (unsigned)__builtin_amdgcn_readlane((int)wave_incl_scan(Ae, lane), 63);
+            if (lane == 0) part[2 * NW + wid] = runE;
+        }
         __syncthreads();                                 // A: wave totals; O (the previous bin's run) is free again
         STAMP(1);
         // Work lists of the WORKGROUP in O (2 (U1 + U0) + Ns <= N words): k != 0 units | k == 0 units | singles, each in
@@ -1527,11 +1536,13 @@ __device__ __forceinline__ void dense_tile_body(const LdatiParams &P) {
         }
         if (P.slot_cap) {
             // the count pass's outputs; a run beyond the slot (and the LDS) is only counted -- the host sees the largest
-            // (tile, bin) count in the statistics and repeats the call on the two-pass path
-            if (tid == 0) nbin[c] = N;                   // (written out at the end: no pointer or sum lives across the bins)
+            // (tile, bin) count in the statistics and repeats the call on the two-pass path.  The count is the UNPACKED sum:
+            // the packed N above is only meaningful once this one says the run fits (capA < 2^16)
+            const unsigned N32 = (unsigned)__builtin_amdgcn_readlane((int)wave_incl_scan(lane < NW ? part[2 * NW + lane] : 0u, lane), NW - 1);
+            if (tid == 0) nbin[c] = N32;                 // (written out at the end: no pointer or sum lives across the bins)
 #pragma unroll
             for (int q = 0; q < PPT; ++q) vmax_l = ncur[q] > vmax_l ? ncur[q] : vmax_l;
-            if (N > (unsigned)P.capA) {                  // uniform
+            if (N32 > (unsigned)P.capA) {                // uniform
 #pragma unroll
                 for (int q = 0; q < PPT; ++q) {
                     nprev[q] = ncur[q];
