@@ -406,3 +406,105 @@ def test_single_rank_failure_leaves_no_partial_file(tmp_path):
     n = cli.run(frames, FakeModel(), infer_type="center", width=12, height=8, batch_size=2, device="cpu",
                 stage2=(begin, finish), out_path=str(tmp_path / "f.npz"))
     assert os.listdir(tmp_path) == ["f.npz"] and len(np.load(tmp_path / "f.npz")["event_stream"]) == n
+
+
+# ------------------------------------------------------------------------------------------------
+# round 5: failures that used to leave the peers inside a collective
+# ------------------------------------------------------------------------------------------------
+def _pano_failure_worker(rank, world, port, q, bad_rank, bad_call):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=60))
+    try:
+        from test_product_glue import FakeModel
+        from v2ce_toolbox_amd import dist as vd
+        from v2ce_toolbox_amd import synth
+        from v2ce_toolbox_amd import v2ce as cli
+
+        class FailingModel(FakeModel):
+            def __call__(self, x):
+                self.n_real = getattr(self, "n_real", 0) + 1
+                if rank == bad_rank and self.n_real == bad_call:
+                    raise ValueError("model failed on purpose")
+                return super().__call__(x)
+        frames = synth.synthetic_frames(101, 8, 40, seed=3)           # 4 tiles on 4 ranks: one tile per rank, 4 batches of 2 sequences
+        try:
+            cli.run(frames, FailingModel(), infer_type="pano", width=12, height=8, batch_size=2, device="cpu", stage2=fake_stage2(30))
+            q.put((rank, "no error"))
+        except ValueError as e:
+            q.put((rank, "own:" + str(e)))
+        except vd.RankFailure as e:
+            q.put((rank, "peer:" + str(e.ranks)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bad_rank,bad_call", [(2, 2), (0, 1), (3, 4)])
+def test_pano_tile_rank_failure_stops_every_rank(bad_rank, bad_call):
+    """A tile rank whose MODEL call raises, i.e. between the start of a batch and the group's all_to_all: it keeps taking
+    part in the tile exchanges (zeros of the right shape), reports the failure with its next byte count, and every rank
+    stops at the same step -- nobody is left inside an unmatched collective (the old protocol hung here until the watchdog)."""
+    got = _spawn(_pano_failure_worker, 4, (bad_rank, bad_call), timeout=150)
+    for r, msg in got:
+        assert msg == ("own:model failed on purpose" if r == bad_rank else f"peer:[{bad_rank}]"), got
+
+
+def _io_failure_worker(rank, world, port, q, mode, out_dir, what):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), V2CE_GATHER=mode)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=60))
+    try:
+        import errno
+        from test_product_glue import FakeModel
+        from v2ce_toolbox_amd import dist as vd
+        from v2ce_toolbox_amd import pipeline, synth
+        from v2ce_toolbox_amd import v2ce as cli
+        calls = {"n": 0}
+        if what == "pwrite" and rank == 1:                     # rank 1's writer thread: the segment is full at its second piece
+            real = os.pwrite
+
+            def full(fd, data, off):
+                calls["n"] += 1
+                if calls["n"] >= 2:
+                    raise OSError(errno.ENOSPC, "No space left on device (on purpose)")
+                return real(fd, data, off)
+            vd.os.pwrite = full
+        if what == "sink" and rank == 0:                       # rank 0's sink (device gather): fails at the third batch
+            real_push = pipeline.EventSink.push
+
+            def push(self, packed, n_pairs, keep=(), src_stream=None):
+                calls["n"] += 1
+                if calls["n"] >= 5:
+                    raise OSError(errno.EIO, "sink failed on purpose")
+                return real_push(self, packed, n_pairs, keep, src_stream=src_stream)
+            pipeline.EventSink.push = push
+        if what == "open" and rank == 1:                       # rank 1 cannot open the shared segment
+            real_open = os.open
+
+            def no_open(path, flags, *a):
+                if "v2ce" in str(path) or str(path).endswith(".part"):
+                    raise OSError(errno.EACCES, "cannot open the shared segment (on purpose)")
+                return real_open(path, flags, *a)
+            vd.os.open = no_open
+        frames = synth.synthetic_frames(101, 8, 20, seed=3)
+        try:
+            cli.run(frames, FakeModel(), infer_type="center", width=12, height=8, batch_size=2, device="cpu", stage2=fake_stage2(30))
+            q.put((rank, "no error"))
+        except OSError as e:
+            q.put((rank, "own:" + str(e.strerror)))
+        except vd.RankFailure as e:
+            q.put((rank, "peer:" + str(e.ranks)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,what,bad", [("host", "pwrite", 1), ("host", "open", 1), ("device", "sink", 0)])
+def test_local_io_failure_stops_every_rank(mode, what, bad, tmp_path):
+    """A rank-local I/O error -- the writer thread of gather='host' (ENOSPC), opening the shared segment, rank 0's sink under
+    gather='device' -- is reported through the failure flag of the next exchange: the failing rank raises its own OSError,
+    every other rank RankFailure naming it, at the same step; none is left waiting in a collective."""
+    got = _spawn(_io_failure_worker, 2, (mode, str(tmp_path), what), timeout=150)
+    for r, msg in got:
+        assert msg.startswith("own:") if r == bad else msg == f"peer:[{bad}]", got

@@ -101,15 +101,16 @@ class SizeExchange:
     host memory (a pageable source would make the copy -- and with it the host -- wait for the stream) and the
     result comes back into pinned memory: ``result()`` waits for that copy alone, typically one step later."""
 
-    def __init__(self, value: int, device, group=None, after_stream=None):
+    def __init__(self, value: int, device, group=None, after_stream=None, wait: bool = True):
         self.world = dist.get_world_size(group)
         self.device = torch.device(device)
         self.cuda = self.device.type == "cuda"
         if self.cuda:
             self.stream = comm_stream(self.device)
-            ready = torch.cuda.Event()
-            ready.record(after_stream if after_stream is not None else torch.cuda.current_stream(self.device))
-            self.stream.wait_event(ready)
+            if wait:                                          # (the value is host-known: callers that move no device data behind
+                ready = torch.cuda.Event()                    # this exchange pass wait=False, so that a failure flag still travels
+                ready.record(after_stream if after_stream is not None else torch.cuda.current_stream(self.device))
+                self.stream.wait_event(ready)                 # when the compute stream is stuck, ADVICE r4)
             self.src, self.host = _pinned_pair(self.world)   # recycled by hand: a fresh pin_memory() is a hipHostMalloc,
             self.src[0] = int(value)                          # which synchronises the device in the middle of the pipeline
             with torch.cuda.stream(self.stream):
@@ -153,9 +154,14 @@ class EventGather:
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.cuda = packed.is_cuda
         self.pool = pool if pool is not None else {}
-        self.sizes = SizeExchange(-1 if failed else packed.numel(), packed.device, group)
+        # the byte counts do not wait for the compute stream (they are host-known, and a failure flag must always get through);
+        # the copy of `packed` in finish() does
+        self.sizes = SizeExchange(-1 if failed else packed.numel(), packed.device, group, wait=False)
         self.stream = self.sizes.stream
+        self.ready = None
         if self.cuda:
+            self.ready = torch.cuda.Event()
+            self.ready.record(torch.cuda.current_stream(packed.device))
             packed.record_stream(self.stream)
 
     def finish(self):
@@ -164,6 +170,8 @@ class EventGather:
         longest = max(max(sizes), 1)
         ctx = torch.cuda.stream(self.stream) if self.cuda else _NullCtx()
         with ctx:
+            if self.ready is not None:
+                self.stream.wait_event(self.ready)             # `packed` is complete on its producer's stream
             reads_done = self.pool.pop("reads_done", None)     # the consumer of the previous step's pieces (reused buffers)
             if reads_done is not None and self.cuda:
                 self.stream.wait_event(reads_done)
@@ -214,25 +222,50 @@ class StreamedGather:
         self.inflight = collections.deque()
         self.bytes_last = 0
         self.pool = {}
+        self.error = None                                      # an error of THIS rank's consumer (rank dst's sink: full disk, ...)
+        self.device = None
 
     def submit(self, packed: torch.Tensor, failed: bool = False) -> None:
-        self.inflight.append(EventGather(packed, self.dst, self.group, failed=failed, pool=self.pool))
+        # a local consumer error is reported like a stage-2 failure: with the next byte count, so that every rank stops at
+        # the same step instead of waiting for a rank that has left
+        self.device = packed.device
+        self.inflight.append(EventGather(packed, self.dst, self.group, failed=failed or self.error is not None, pool=self.pool))
         while len(self.inflight) > self.depth:
             self._finish_one()
 
     def _finish_one(self) -> None:
         g = self.inflight.popleft()
-        pieces = g.finish()
+        try:
+            pieces = g.finish()
+        except RankFailure as rf:
+            if self.error is not None:                         # this rank is (one of) the failed ones: its own error
+                raise self.error from rf
+            raise
         if pieces is not None:
             self.bytes_last = int(sum(p.numel() for p in pieces))
-            if self.on_pieces is not None:
-                ev = self.on_pieces(pieces, g.stream)          # a HIP event behind the consumer's reads of the pieces, or None
+            if self.on_pieces is not None and self.error is None:
+                try:
+                    ev = self.on_pieces(pieces, g.stream)      # a HIP event behind the consumer's reads of the pieces, or None
+                except RankFailure:
+                    raise
+                except Exception as e:                         # noqa: BLE001 -- re-raised at the next collective point, on every rank
+                    self.error, ev = e, None
                 if ev is not None:
                     self.pool["reads_done"] = ev
 
     def drain(self) -> None:
         while self.inflight:
             self._finish_one()
+        if self.device is not None:
+            # the last step's consumer may have failed too: one more flag exchange, so that no rank walks on into the clip's
+            # closing collectives while rank dst raises
+            flags = SizeExchange(-1 if self.error is not None else 0, self.device, self.group, wait=False).result()
+            try:
+                check_sizes(flags)
+            except RankFailure as rf:
+                if self.error is not None:
+                    raise self.error from rf
+                raise
 
     def finalize(self):
         return None
@@ -242,8 +275,9 @@ _SLOT_CACHE, _SLOT_LOCK = [], threading.Lock()
 
 
 class HostDirectGather:
-    """The per-step exchange of the drivers when the records are wanted in HOST memory (``gather='host'``, the default
-    of pipeline.run_clip and bench.py): no record crosses a GPU-GPU link or rank 0's PCIe link.  Per step the ranks
+    """The per-step exchange of the drivers when the records are wanted in HOST memory (``gather='host'``; the default of
+    pipeline.run_clip and bench.py is 'device'): no record crosses a GPU-GPU link or rank 0's PCIe link.  Every rank must be
+    able to open `path` (one host: pipeline.run_clip checks that before it chooses this mode).  Per step the ranks
     exchange only their byte counts (``SizeExchange``: one all_gather of one int64 over RCCL); every rank then knows the
     byte offset of its piece in the clip's record stream -- records of step k precede step k+1's, rank r's precede rank
     r+1's inside a step: frame-pair order -- downloads its piece over ITS OWN PCIe link into a pinned staging buffer and
@@ -257,7 +291,22 @@ class HostDirectGather:
         import threading
         self.comm, self.device = comm, torch.device(device)
         self.cuda = self.device.type == "cuda"
-        self.fd = os.open(path, os.O_RDWR)
+        # construction is collective: a rank that cannot open the shared file must not leave its peers in the first exchange
+        self.fd, open_err = None, None
+        try:
+            self.fd = os.open(path, os.O_RDWR)
+        except OSError as e:
+            open_err = e
+        errs = comm.all_gather_object(None if open_err is None else repr(open_err))
+        bad = [r for r, e in enumerate(errs) if e is not None]
+        if bad:
+            if self.fd is not None:
+                os.close(self.fd)
+                self.fd = None
+            self.thread = None
+            if open_err is not None:
+                raise open_err
+            raise RankFailure(bad)
         self.data_start, self.need_crc, self.depth = int(data_start), need_crc, depth
         self.base = 0                                          # bytes of all ranks' completed steps
         self.ring_bytes = 0                                    # > 0 (bench.py only): offsets wrap, the segment stays bounded
@@ -305,10 +354,11 @@ class HostDirectGather:
                     self.free.put(slot)
 
     def submit(self, packed: torch.Tensor, failed: bool = False, keep=()) -> None:
-        if self.error is not None:
-            raise self.error
+        # an error of this rank's writer thread (ENOSPC on /dev/shm, a full disk under the .npz.part) is reported like a
+        # stage-2 failure: -1 with the next byte count, every rank stops at that step (raising it here, on this
+        # rank alone, left the peers in the next collective until the watchdog fired)
         n = int(packed.numel())
-        ex = self.comm.all_gather_int(-1 if failed else n, packed.device)
+        ex = self.comm.all_gather_int(-1 if (failed or self.error is not None) else n, packed.device)
         slot, done, host = None, None, None
         if n and packed.is_cuda:
             slot = self.free.get()                             # blocks while every staging buffer waits for the file
@@ -332,9 +382,11 @@ class HostDirectGather:
         try:
             sizes = ex.result()
             check_sizes(sizes)
-        except BaseException:
+        except BaseException as e:
             if slot is not None:
                 self.free.put(slot)
+            if isinstance(e, RankFailure) and self.error is not None:
+                raise self.error from e                        # this rank's own writer error
             raise
         off = self.base + sum(sizes[:self.comm.rank])
         self.base += sum(sizes)
@@ -360,10 +412,15 @@ class HostDirectGather:
 
     def finalize(self):
         self.drain()
-        self.close()
+        self.close()                                           # (joins the writer: every write of this rank is done or has failed)
+        # also the barrier behind every rank's last write; a late writer error travels with it, so that all ranks raise
+        got = self.comm.all_gather_object((self.pieces, None if self.error is None else repr(self.error)))
+        bad = [r for r, (_, e) in enumerate(got) if e is not None]
         if self.error is not None:
             raise self.error
-        lists = self.comm.all_gather_object(self.pieces)       # also the barrier behind every rank's last write
+        if bad:
+            raise RankFailure(bad)
+        lists = [p for p, _ in got]
         if self.comm.rank != 0:
             return None
         total, crc = 0, 0

@@ -369,6 +369,17 @@ def _shared_segment_path() -> str:
     return os.path.join(base, f"v2ce_events_{os.getpid()}_{uuid.uuid4().hex}.bin")
 
 
+def _host_identity() -> str:
+    """Something all ranks of one machine share and ranks of different machines do not (gather='host' precondition)."""
+    import socket
+    boot = ""
+    try:
+        boot = open("/proc/sys/kernel/random/boot_id").read().strip()
+    except OSError:
+        pass
+    return socket.gethostname() + ":" + boot
+
+
 def run_clip(frames: np.ndarray, model, *, infer_type="center", seq_len=16, width=346, height=260,
              batch_size=1, fps=30, seed=0, device="cuda", stage2=None, dtype=None,
              comm=None, trace: Optional[dict] = None,
@@ -421,6 +432,13 @@ def run_clip(frames: np.ndarray, model, *, infer_type="center", seq_len=16, widt
     feeder = FrameFeeder(frames, seq_len, device, height)
     multi = not isinstance(comm, vdist.LocalComm)           # (a forced world of one takes the collective path too)
     host_direct = multi and gather == "host"
+    if host_direct:
+        # 'host' needs every rank on rank 0's machine (one tmpfs / one local file system): checked, not assumed
+        ids = comm.all_gather_object(_host_identity())
+        if len(set(ids)) > 1:
+            import logging
+            logging.getLogger("V2CE").warning("gather='host' needs all ranks on one host (%d distinct hosts): using 'device'", len(set(ids)))
+            host_direct, gather = False, "device"
     # single rank, or device gather: rank 0 owns a sink that downloads everything
     sink = None
     if rank == 0 and not host_direct:
@@ -506,31 +524,45 @@ def run_clip(frames: np.ndarray, model, *, infer_type="center", seq_len=16, widt
             i += 1
         return i
 
+    def model_part(i, bp, state):
+        """Everything of a batch in front of the tile exchange: this rank's voxels ([P,2,10,H,W], or its W-tile of them)."""
+        units = feeder.take(state["handle"], bp)
+        nxt_i = next_nonempty(i + 1)
+        state["handle"] = feeder.submit(mine[nxt_i]) if nxt_i < len(mine) else None
+        # call index of this batch in the reference's schedule (one spectral-norm iteration per call);
+        # ranks that sat a batch out catch up here
+        vdist.fast_forward(model, base_calls + bp.index * calls_per_batch + (tile_index or 0))
+        if not tile_parallel:
+            if infer_type == "center":
+                pred = glue.infer_center_image_unit(model, units, width)
+            else:
+                pred = glue.infer_pano_image_unit(model, units, width)
+            return _voxels_of_batch(pred, bp, seq_len)
+        lo, hi, keep_cols = tiles[tile_index]
+        pred = model(units[..., lo:hi].float().contiguous())
+        if keep_cols:
+            pred = pred[..., -keep_cols:]
+        return _voxels_of_batch(pred, bp, seq_len)                                  # [P,2,10,H,wt]
+
     def batch_body(i, bp, state):
         vox, first_pair = None, bp.first_pair
         if bp.seqs:
-            units = feeder.take(state["handle"], bp)
-            nxt_i = next_nonempty(i + 1)
-            state["handle"] = feeder.submit(mine[nxt_i]) if nxt_i < len(mine) else None
-            # call index of this batch in the reference's schedule (one spectral-norm iteration per call);
-            # ranks that sat a batch out catch up here
-            vdist.fast_forward(model, base_calls + bp.index * calls_per_batch + (tile_index or 0))
             if not tile_parallel:
-                if infer_type == "center":
-                    pred = glue.infer_center_image_unit(model, units, width)
-                else:
-                    pred = glue.infer_pano_image_unit(model, units, width)
-                vox = _voxels_of_batch(pred, bp, seq_len)
+                vox = model_part(i, bp, state)
             else:
-                lo, hi, keep_cols = tiles[tile_index]
-                pred = model(units[..., lo:hi].float().contiguous())
-                if keep_cols:
-                    pred = pred[..., -keep_cols:]
-                part = _voxels_of_batch(pred, bp, seq_len)                          # [P,2,10,H,wt]
+                # The tile exchange is a collective of the group: a rank that has failed (now or in an earlier batch) still
+                # takes part, with zeros of the right shape, so that its peers are never left inside an unmatched all_to_all
+                # (ADVICE r4); its failure travels with the next byte count like any other
+                part = guarded(model_part, i, bp, state)
+                if part is None:
+                    part = torch.zeros((bp.n_pairs, 2, 10, height, widths[tile_index]), dtype=torch.float32, device=device)
                 vox, p_lo = comm.tiles_to_pairs(part, widths, tile_index, grp)       # [P_r,2,10,H,W_full]
                 first_pair += p_lo
         if event_frames is not None and vox is not None:
             event_frames.append((first_pair, event_frame_sums(vox)))
+        if tile_parallel:
+            handle = guarded(begin, vox, first_pair) if vox is not None and vox.shape[0] else None
+            return (handle, 0 if vox is None else int(vox.shape[0]))
         return (begin(vox, first_pair) if vox is not None and vox.shape[0] else None, 0 if vox is None else int(vox.shape[0]))
 
     def cleanup_on_error():
@@ -550,7 +582,8 @@ def run_clip(frames: np.ndarray, model, *, infer_type="center", seq_len=16, widt
         with torch.no_grad():
             for i, bp in enumerate(mine):
                 tt = _time.perf_counter()
-                nxt = guarded(batch_body, i, bp, state) or (None, 0)
+                # (tile-parallel: the body guards its own parts and never skips the group's collective)
+                nxt = (batch_body(i, bp, state) if tile_parallel else guarded(batch_body, i, bp, state)) or (None, 0)
                 tt = tick("model+begin", tt)
                 if pending is not None:
                     flush(pending)
