@@ -36,7 +36,15 @@ def layer_plan():
     return plan
 
 
+_TAILS = {"family": "normal"}      # set by make_state_dict for the duration of a call
+
+
 def _normal(rng, shape, std):
+    if _TAILS["family"] == "student":
+        # Student-t with 4 degrees of freedom, rescaled to the requested standard deviation (variance of t_4 = 2): the
+        # largest of a million weights sits ~30 sigma out instead of ~5 -- the tail a trained checkpoint may have
+        t = rng.standard_t(4, shape).astype(np.float32) / np.float32(2.0 ** 0.5)
+        return torch.from_numpy(t * np.float32(std))
     return torch.from_numpy((rng.standard_normal(shape, dtype=np.float32) * np.float32(std)))
 
 
@@ -48,6 +56,17 @@ def _bn(rng, sd, prefix, c, gamma):
         (0.05 * rng.standard_normal(c)).astype(np.float32))
     sd[prefix + ".running_var"] = torch.from_numpy(
         (1.0 + 0.2 * rng.random(c)).astype(np.float32))
+    if _TAILS["family"] == "student":
+        # a tenth of the channels with running_var log-uniform in [1e-3, 1] and gamma moved with sqrt(var) x U[0.5, 2): the
+        # folded scale gamma / sqrt(var + eps) spreads over a factor of four instead of 1.2, the statistics over three decades
+        pick = rng.random(c) < 0.1
+        var = np.exp(rng.uniform(np.log(1e-3), 0.0, c))
+        spread = rng.uniform(0.5, 2.0, c)
+        rv = sd[prefix + ".running_var"].numpy().copy()
+        w = sd[prefix + ".weight"].numpy().copy()
+        w[pick] = (w[pick] * np.sqrt(var[pick] / rv[pick]) * spread[pick]).astype(np.float32)
+        rv[pick] = var[pick].astype(np.float32)
+        sd[prefix + ".running_var"], sd[prefix + ".weight"] = torch.from_numpy(rv), torch.from_numpy(w)
     sd[prefix + ".num_batches_tracked"] = torch.tensor(1000, dtype=torch.int64)
 
 
@@ -56,13 +75,48 @@ def _unit(rng, n):
     return torch.from_numpy((v / np.linalg.norm(v)).astype(np.float32))
 
 
-def make_state_dict(seed: int = 0, out_gain: float = 1.0) -> "OrderedDict[str, torch.Tensor]":
+def make_state_dict(seed: int = 0, out_gain: float = 1.0, tails: str = "normal") -> "OrderedDict[str, torch.Tensor]":
     """Synthetic ``V2ce3d`` weights (reference key layout).
 
     Scales are chosen so that activations neither die nor explode through the 22 conv layers and
     the final ReLU output has a DVS-like distribution (mostly < 1, a tail above 1) so LDATI is
     exercised in all three regimes (no event / single event / multiple events per voxel).
+    tails: "normal" (Gaussian weights, BatchNorm variances in [1, 1.2]) or "student" (Student-t_4 weights and a tenth of
+    the BatchNorm channels with variances down to 1e-3: a heavier-tailed stand-in for a trained checkpoint).
     """
+    if tails not in ("normal", "student"):
+        raise ValueError(tails)
+    _TAILS["family"] = tails
+    try:
+        return _make_state_dict(seed, out_gain)
+    finally:
+        _TAILS["family"] = "normal"
+
+
+def converge_spectral_norm(sd, iterations: int = 50, separate: float = 0.0):
+    """u / v of every spectral-norm layer after `iterations` power iterations (spectral_norm.py:19-31) -- where a trained
+    checkpoint's are (the generator's are random unit vectors): in place, f64 arithmetic, returns sd.
+    separate > 0: first add separate * sigma_1 * u_1 v_1^T to every weight_bar.  The leading singular values of an i.i.d.
+    Gaussian matrix are nearly degenerate (the power iteration needs ~1e4 steps there); a trained layer has a dominant
+    direction, and with a gap of 1 + separate fifty iterations reach the fixed point to rounding."""
+    for k in [k for k in sd if k.endswith(".weight_bar")]:
+        w = sd[k].double().reshape(sd[k].shape[0], -1)
+        if separate > 0:
+            U_, S_, Vh_ = torch.linalg.svd(w, full_matrices=False)
+            w = w + separate * S_[0] * torch.outer(U_[:, 0], Vh_[0])
+            sd[k] = w.float().reshape(sd[k].shape).contiguous()
+            w = sd[k].double().reshape(sd[k].shape[0], -1)
+        u, v = sd[k[:-4] + "_u"].double(), sd[k[:-4] + "_v"].double()
+        for _ in range(iterations):
+            v = w.t() @ u
+            v = v / (v.norm() + 1e-12)
+            u = w @ v
+            u = u / (u.norm() + 1e-12)
+        sd[k[:-4] + "_u"], sd[k[:-4] + "_v"] = u.float(), v.float()
+    return sd
+
+
+def _make_state_dict(seed, out_gain):
     rng = np.random.Generator(np.random.Philox(seed))
     sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
     sd["UNet.head.conv3d.weight"] = _normal(rng, (BASE, IN_CH, 3, 3, 3), (2.0 / (IN_CH * 27)) ** 0.5)
