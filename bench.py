@@ -477,10 +477,21 @@ def main():
     # HBM-side traffic of the same kernel(s) from the latest committed PMC summary of this workload
     # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, tools/pmc_summary.py): bytes per
     # launch, or null when no summary for this workload is committed
+    from v2ce_toolbox_amd import hip as _hip
+    my_hash = _hip.source_hash()
+
+    def fresh(path):
+        """A committed counter summary counts only when it was collected from THIS tree's kernel sources (VERDICT r4 #5)."""
+        data = json.load(open(path))
+        prov = data.pop("_provenance", None) or {}
+        if prov.get("source_hash") != my_hash:
+            raise LookupError(f"{os.path.basename(path)} was collected from other kernel sources ({prov.get('source_hash')} != {my_hash})")
+        return data, prov
+    stale = []
     try:
         import glob
         files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{args.workload}_pmc_traffic.json")))
-        pmc = json.load(open(files[-1]))
+        pmc, prov = fresh(files[-1])
         if model is not None:
             key = roofline["kernel"].replace(" ", "")
             roofline["traffic"] = pmc[key]["traffic_bytes"]
@@ -489,7 +500,9 @@ def main():
             ld = {k: v for k, v in pmc.items() if k.startswith("ldati_") and not any(x in k for x in ("check", "probe", "slope_tab", "commit"))}
             nmax = max(v["launches"] for v in ld.values())
             roofline["traffic"] = sum(v["traffic_bytes"] for v in ld.values() if 2 * v["launches"] > nmax)
-        roofline["traffic_source"] = os.path.basename(files[-1]) + " (PMC FETCH_SIZE x2 + WRITE_SIZE, avg per launch)"
+        roofline["traffic_source"] = os.path.basename(files[-1]) + f" (PMC FETCH_SIZE x2 + WRITE_SIZE, avg per launch; {prov['lib_version']}, sources {prov['source_hash']})"
+    except LookupError as e:
+        stale.append(str(e))
     except Exception:
         pass
     # counter-derived shares from the latest committed SQ summaries (tools/profile_counters.sh -> tools/counters_summary.py):
@@ -498,17 +511,22 @@ def main():
         import glob
         if model is not None:
             files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_e2e_mfma_busy.json")))
-            mb = json.load(open(files[-1]))[roofline["kernel"].replace(" ", "")]
+            data, prov = fresh(files[-1])
+            mb = data[roofline["kernel"].replace(" ", "")]
             roofline["mfma_busy"] = mb["mfma_busy"]
-            roofline["mfma_busy_source"] = os.path.basename(files[-1]) + " (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8), avg per launch)"
+            roofline["mfma_busy_source"] = os.path.basename(files[-1]) + f" (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8), avg per launch; {prov['lib_version']}, sources {prov['source_hash']})"
         else:
             files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{args.workload}_sq_counters.json")))
-            sq = json.load(open(files[-1]))
+            sq, prov = fresh(files[-1])
             roofline["valu_frac"] = sq["valu_frac"]
             roofline["valu_lane_slots_per_event"] = sq["valu_lane_slots_per_event"]
-            roofline["valu_source"] = os.path.basename(files[-1]) + " (SQ_INSTS_VALU x 64 / (1024 SIMDs x 16 lanes/clk x GRBM_GUI_ACTIVE / 8))"
+            roofline["valu_source"] = os.path.basename(files[-1]) + f" (SQ_INSTS_VALU x 64 / (1024 SIMDs x 16 lanes/clk x GRBM_GUI_ACTIVE / 8); {prov['lib_version']}, sources {prov['source_hash']})"
+    except LookupError as e:
+        stale.append(str(e))
     except Exception:
         pass
+    if stale:
+        roofline["counter_fields_dropped"] = stale      # (no counter-derived number of another build rides on this line)
 
     h2h_multi = None
     if world > 1 and args.workload == "e2e" and not args.no_host_to_host:
@@ -528,6 +546,9 @@ def main():
             "value": total_pairs / dt, "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
+            "value_is": "device-resident: inputs in HBM when the timed region starts, records left in HBM (the measurement contract of "
+                        "this build: a PCIe-inclusive rate is never `value`); SURVEY 8d's own figure -- u8 frames in host memory -> "
+                        "records in pinned host memory -- is `host_to_host.value` on the same line",
             "dtype": DTYPE_NOTE[args.precision], "data": "synthetic",
             "config": {"workload": workloads[args.workload], "frame_pairs_per_step_per_gpu": pairs_per_rank, "fps": fps,
                        "parallelism": (f"tile-per-GPU groups of 4 x {world // pano_tiles} over batches" if tile_parallel

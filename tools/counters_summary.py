@@ -17,6 +17,17 @@ import os
 import re
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def _prov():
+    """{lib_version, source_hash} of the tree the counters were collected from (bench.py ignores a summary of other sources)."""
+    try:
+        from v2ce_toolbox_amd import hip
+        return hip.provenance()
+    except Exception as e:                      # noqa: BLE001 -- a summary without provenance is simply never used by bench.py
+        return {"error": repr(e)}
+
 
 def kname(s):
     return re.sub(r"\(.*", "", s.replace("void ", "").replace("v2ce::(anonymous namespace)::", "")).replace(" ", "")
@@ -97,6 +108,7 @@ def ldati_table(out, wl, events_per_launch):
         inst_tot += iv
     js["valu_frac"] = (inst_tot * 64.0) / (16.0 * 1024.0 * gui_tot / 8.0) if gui_tot else None
     lines.append(f"  VALU-issue roofline of the call (VALU wave-instructions x 64 / (1024 SIMDs x 16 lanes/clk x busy clocks)): {js['valu_frac']}")
+    js["_provenance"] = _prov()
     json.dump(js, open(os.path.join(out, f"{wl}_sq_counters.json"), "w"), indent=1)
     return lines
 
@@ -146,6 +158,7 @@ def main():
     lines, js = mfma_table(out)
     if lines:
         open(os.path.join(out, "e2e_mfma_busy.txt"), "w").write("\n".join(lines) + "\n")
+        js["_provenance"] = _prov()
         json.dump(js, open(os.path.join(out, "e2e_mfma_busy.json"), "w"), indent=1)
         print("\n".join(lines))
 

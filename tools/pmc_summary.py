@@ -14,8 +14,11 @@ import collections
 import csv
 import glob
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def load(d):
@@ -38,7 +41,11 @@ def main():
         w = sum(wr.get(k, [0.0])) / max(1, len(wr.get(k, [])))
         out[k] = {"launches": n, "fetch_raw_bytes": f, "fetch_corrected_bytes": 2 * f, "write_bytes": w,
                   "traffic_bytes": 2 * f + w}
+    from v2ce_toolbox_amd import hip
+    out["_provenance"] = hip.provenance()          # (bench.py ignores a summary whose source hash is not its own tree's)
     json.dump(out, open(sys.argv[3], "w"), indent=1)
+    prov = out.pop("_provenance")
+    print("provenance:", prov)
     for k, v in sorted(out.items(), key=lambda kv: -kv[1]["traffic_bytes"] * kv[1]["launches"]):
         print(f"{k:45s} n={v['launches']:3d} fetch_x2={v['fetch_corrected_bytes']/1e6:9.1f} MB write={v['write_bytes']/1e6:9.1f} MB")
 

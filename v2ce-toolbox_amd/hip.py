@@ -179,6 +179,26 @@ def lib() -> ctypes.CDLL:
     return L
 
 
+def source_hash() -> str:
+    """16 hex digits over the kernel sources and the C ABI header of THIS tree (csrc/*.hip, csrc/*.h, include/*.h): the
+    provenance stamp of the counter summaries under profiles/ -- bench.py drops a counter-derived field whose summary was
+    collected from other sources (the GPU box has no .git to ask for a commit hash)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")) +
+                   glob.glob(os.path.join(os.path.dirname(_HERE), "include", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def provenance() -> dict:
+    """What a profile summary records about the build it measured."""
+    return {"lib_version": lib().v2ce_version().decode(), "source_hash": source_hash()}
+
+
 def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = lib().v2ce_last_error().decode()
