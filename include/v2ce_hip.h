@@ -332,6 +332,19 @@ int v2ce_conv3d_fwd_tail(const v2ce_conv3d_desc *desc, const float *x0, const fl
                          const int32_t *thmap, const int32_t *twmap, const void *tail_w,
                          const float *tx0_absmax, const float *tx1_absmax, v2ce_stream_t stream);
 
+/* The UNet's first layer (scripts/unet_2layer.py:341: ConvLayer3D(2, 32, 3, padding 1) + LeakyReLU; scripts/submodules.py:96,
+ * 115-124) in split-half arithmetic: K = 54 as four 16-wide k-steps of three fp16 MFMAs, the output -- 16x the input -- as
+ * 1 KB contiguous stores of the channels-last-16 layout.  desc: C0 = 2, C1 = 0, Cout = 32, ksize 3, stride 1, layout C16 (the
+ * layout of y; x is the planar network input [B][T][2][H][W0_pitch]).  w_table = v2ce_pack_head_weights_f16x2 of the
+ * [32][2][27] f32 weights; bias [32].  x_absmax: per batch element (desc.absmax_batch_stride) max |x| -- v2ce_absmax_batch
+ * computes it -- or NULL (|x| < 4094 required); y_absmax as for v2ce_conv3d_fwd (max |y|, range-guard value). */
+size_t v2ce_pack_head_weights_f16x2_bytes(void);
+int v2ce_pack_head_weights_f16x2(const float *w, void *table, v2ce_stream_t stream);
+int v2ce_conv3d_head_f16x2(const v2ce_conv3d_desc *desc, const float *x, const void *w_table, const float *bias, float *y,
+                           const float *x_absmax, float *y_absmax, v2ce_stream_t stream);
+/* slots[b * stride] = max |x[b][0 .. n)| for b < B (slots zeroed by the caller): the range slot of a network INPUT. */
+int v2ce_absmax_batch(const float *x, int B, long long n, float *slots, int stride, v2ce_stream_t stream);
+
 /* conv1 of a decoder block (scripts/unet_2layer.py:358-365, scripts/submodules.py:249-264): the 3x3x3 conv whose input is the
  * virtual concat  nearest-upsample-2x(x0) ++ x1, with the upsampled channels PHASE-FOLDED.  ATen's nearest map for an exact
  * 2x size ratio (H0 = ceil(Hin / 2), W0 = ceil(Win / 2): every decoder size of the network) is src = dst >> 1, so an output

@@ -178,3 +178,35 @@ def test_up2_rejects_what_it_cannot_do():
     assert L.v2ce_conv3d_up2_variant(ctypes.byref(d), 0, buf, 96) == -2
     d.layout, d.C1 = hip.LAYOUT_C16, 0
     assert L.v2ce_conv3d_up2_variant(ctypes.byref(d), 0, buf, 96) == -1
+
+
+# ------------------------------------------------------------------------------------------------
+# the head convolution in split-half arithmetic (csrc/conv3d_head.hip)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", [(1, 4, 20, 28), (2, 5, 37, 71), (1, 3, 9, 33), (2, 16, 8, 130), (1, 1, 1, 1)])
+def test_head_split_half_vs_f64(case):
+    """v2ce_conv3d_head_f16x2 (Conv3d(2, 32, 3, padding 1) + bias + LeakyReLU, unet_2layer.py:341 / submodules.py:115-124)
+    against the f64 convolution: ragged in T, H and W (boxes of 4 x 4 x 64), inputs spanning the range of normalised frames
+    (-0.93 .. 5.1), per-sequence range slots; max |y| and the range-guard value are reported."""
+    from v2ce_toolbox_amd import hip
+    from v2ce_toolbox_amd.v2ce_3d import V2ce3d
+    B, T, H, W = case
+    g = torch.Generator().manual_seed(7 + H + W)
+    x = torch.rand(B, 2, T, H, W, generator=g) * 6.0 - 0.93
+    x[0] *= 0.01                                                  # sequence 0 lives 100x lower: its own pre-scale
+    w = torch.randn(32, 2, 3, 3, 3, generator=g) * (2.0 / 54) ** 0.5
+    bias = 0.3 * torch.randn(32, generator=g)
+    m = _model()
+    m._prep = {"absmax": torch.zeros((8, B, 2), device="cuda")}
+    tab = torch.empty(hip.lib().v2ce_pack_head_weights_f16x2_bytes() // 2, dtype=torch.float16, device="cuda")
+    hip.check(hip.lib().v2ce_pack_head_weights_f16x2(w.cuda().contiguous().data_ptr(), tab.data_ptr(), hip.stream_ptr("cuda")), "pack")
+    y = V2ce3d._head_split(m, to_btchw(x).cuda(), tab, bias.cuda())
+    torch.cuda.synchronize()
+    want = F.leaky_relu(F.conv3d(x.double(), w.double(), bias.double(), 1, 1), 0.01).numpy()
+    got = V2ce3d.to_planar(y).permute(0, 2, 1, 3, 4).cpu().numpy()
+    assert_close(got, want, f"head {case}")
+    slots = m._prep["absmax"].cpu().numpy()
+    for b in range(B):
+        assert abs(slots[0, b, 0] - float(x[b].abs().max())) <= 1e-6 * float(x[b].abs().max())       # max |x| of the sequence
+        assert abs(slots[1, b, 0] - np.abs(want[b]).max()) <= 2e-5 * max(1.0, np.abs(want[b]).max())  # max |y|
+        assert 0 < slots[1, b, 1] < 2.5e-6                                                           # its guard value

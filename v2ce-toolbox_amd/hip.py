@@ -32,6 +32,7 @@ EXPORTS = [
     "v2ce_voxelize_events", "v2ce_conv3d_fwd_pred", "v2ce_conv3d_fwd_sc", "v2ce_conv3d_fwd_tail", "v2ce_pack_pred_weights_f16x2", "v2ce_pack_pred_weights_f16x2_bytes",
     "v2ce_sampler_count", "v2ce_sampler_workspace_bytes", "v2ce_sampler_emit", "v2ce_sampler_pool",
     "v2ce_conv3d_fwd_up2", "v2ce_pack_weights_f16x2_up", "v2ce_pack_weights_f16x2_up_bytes", "v2ce_conv3d_up2_variant",
+    "v2ce_conv3d_head_f16x2", "v2ce_pack_head_weights_f16x2", "v2ce_pack_head_weights_f16x2_bytes", "v2ce_absmax_batch",
 ]
 
 
@@ -152,6 +153,14 @@ def lib() -> ctypes.CDLL:
     L.v2ce_pack_weights_f16x2_up_bytes.restype = sz
     L.v2ce_conv3d_up2_variant.argtypes = [ctypes.POINTER(ConvDesc), i32, ctypes.c_char_p, sz]
     L.v2ce_conv3d_up2_variant.restype = ctypes.c_int
+    L.v2ce_conv3d_head_f16x2.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 7
+    L.v2ce_conv3d_head_f16x2.restype = ctypes.c_int
+    L.v2ce_pack_head_weights_f16x2.argtypes = [vp, vp, vp]
+    L.v2ce_pack_head_weights_f16x2.restype = ctypes.c_int
+    L.v2ce_pack_head_weights_f16x2_bytes.argtypes = []
+    L.v2ce_pack_head_weights_f16x2_bytes.restype = sz
+    L.v2ce_absmax_batch.argtypes = [vp, i32, ctypes.c_longlong, vp, i32, vp]
+    L.v2ce_absmax_batch.restype = ctypes.c_int
     L.v2ce_pack_pred_weights_f16x2.argtypes = [vp, i32, i32, vp, vp]
     L.v2ce_pack_pred_weights_f16x2.restype = ctypes.c_int
     L.v2ce_pack_pred_weights_f16x2_bytes.argtypes = []

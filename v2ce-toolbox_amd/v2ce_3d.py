@@ -229,6 +229,13 @@ class V2ce3d(nn.Module):
         ones = lambda c: torch.ones(c, dtype=torch.float32, device=dev)
         h = self.UNet.head.conv3d
         P["head"] = (self._pack(h.weight.contiguous()), ones(h.weight.shape[0]), h.bias.float().contiguous())
+        P["head_split"] = None
+        if self.precision == "f16x2" and tuple(h.weight.shape) == (32, 2, 3, 3, 3) and os.environ.get("V2CE_HEAD_SPLIT", "1") != "0":
+            # the head in split-half arithmetic like every other layer (v2ce_conv3d_head_f16x2: a stream of 1 KB stores)
+            tab = torch.empty(hip.lib().v2ce_pack_head_weights_f16x2_bytes() // 2, dtype=torch.float16, device=dev)
+            hip.check(hip.lib().v2ce_pack_head_weights_f16x2(h.weight.contiguous().data_ptr(), tab.data_ptr(), hip.stream_ptr(dev)),
+                      "v2ce_pack_head_weights_f16x2")
+            P["head_split"] = (tab, h.bias.float().contiguous())
         pr = self.UNet.pred.conv3d
         P["pred"] = (self._pack(pr.weight.contiguous()), ones(pr.weight.shape[0]), pr.bias.float().contiguous())
         P["pred_fused"] = None
@@ -504,6 +511,38 @@ class V2ce3d(nn.Module):
             return y, y_sc
         return y
 
+    def _head_split(self, x, table, bias):
+        """The head convolution on the split-half kernel: max |x| per sequence into a range slot (v2ce_absmax_batch), then
+        v2ce_conv3d_head_f16x2 -- planar network input in, channels-last-16 activations out."""
+        B, T, _, H, W = x.shape
+        Wp = self._pitch(W)
+        y = torch.empty((B, T, 2, H, Wp, 16), dtype=torch.float32, device=x.device)
+        y.lw, y.c16 = W, True
+        per_b = self._prep["absmax"].dim() == 3
+        ax = self._prep["absmax"][self._slot]
+        ay = y.absmax = self._prep["absmax"][self._slot + 1]
+        self._slot += 2
+        st = hip.stream_ptr(x.device)
+        n = T * 2 * H * W
+        if per_b:
+            hip.check(hip.lib().v2ce_absmax_batch(x.data_ptr(), B, n, ax.data_ptr(), 2, st), "v2ce_absmax_batch")
+        else:
+            hip.check(hip.lib().v2ce_absmax_batch(x.data_ptr(), 1, B * n, ax.data_ptr(), 2, st), "v2ce_absmax_batch")
+        d = hip.ConvDesc(B=B, T=T, C0=2, H0=H, W0=W, C1=0, Hin=H, Win=W, Cout=32, Hout=H, Wout=W, ksize=3, stride_hw=1,
+                         act=hip.ACT_LEAKY, tile_t=0, tile_h=0, tile_w=0, precision=hip.PRECISION_F16X2, W0_pitch=W, Win_pitch=W,
+                         Wout_pitch=Wp, layout=hip.LAYOUT_C16, absmax_batch_stride=2 if per_b else 0)
+        prof = getattr(self, "profile", None)
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        hip.check(hip.lib().v2ce_conv3d_head_f16x2(ctypes.byref(d), x.data_ptr(), table.data_ptr(), bias.data_ptr(), y.data_ptr(),
+                                                   ax.data_ptr(), ay.data_ptr(), st), "v2ce_conv3d_head_f16x2")
+        if prof is not None:
+            e1.record()
+            flops = 2.0 * B * T * H * W * 32 * 54
+            prof.append(("conv3d_head_f16x2_kernel", flops, e0, e1, flops))
+        return y
+
     def _sn_weight(self, inner: _SNConvInner, out):
         """spectral_norm.py:19-31: one power iteration (u, v updated in place), W_bar/sigma packed."""
         P = self._prep
@@ -642,8 +681,11 @@ class V2ce3d(nn.Module):
                 P["absmax"].zero_()
         self._launch_sn()
         inter = OrderedDict()
-        h = self._conv(x, None, *P["head"], BASE, 3, 1, hip.ACT_LEAKY,           # unet_2layer.py:341
-                       track=self.precision == "f16x2")
+        if P["head_split"] is not None:
+            h = self._head_split(x, *P["head_split"])                               # unet_2layer.py:341
+        else:
+            h = self._conv(x, None, *P["head"], BASE, 3, 1, hip.ACT_LEAKY,           # unet_2layer.py:341
+                           track=self.precision == "f16x2")
         inter["head"] = self.to_planar(h) if return_intermediates else None
         # The spectral-norm stream overlaps the head convolution only (both are many small workgroups; the head
         # is bound by its output stream, the power iterations by reading W).  The persistent residual-block
