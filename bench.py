@@ -226,7 +226,7 @@ def host_to_host(args, device, steps, comm=None, world=1):
         torch.cuda.synchronize()
         best = min(best, time.perf_counter() - c0)
     return {"value": pairs / dt, "unit": "frame-pairs/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "n_gpus": world,
-            "gather": os.environ.get("V2CE_GATHER", "device") if world > 1 else None,
+            "gather": vdist.default_gather_mode(world) if world > 1 else None,
             "mevents_per_s": len(ev) / dt / 1e6, "h2d_bytes_per_step": int(args.batch * (SEQ + 1) * H * W),
             "d2h_bytes_per_step": nbytes, "d2h_copy_gb_per_s": nbytes / best / 1e9, "d2h_copy_ms_per_step": 1e3 * best,
             "what": "u8 frames in host memory -> event_stream array in pinned host memory through pipeline.run_clip "
@@ -307,7 +307,7 @@ def main():
     # rank 0 receives every rank's records of a step over RCCL on a communication stream (dist.StreamedGather, the
     # product driver's: pipeline.run_clip); the byte counts are read one step later, so no rank waits on its compute stream
     comm = vdist.default_comm(force=dist_on)
-    gather_mode = os.environ.get("V2CE_GATHER", "device")
+    gather_mode = vdist.default_gather_mode(world)        # the product's default: 'device' below eight ranks, 'host' from eight on
     d2h = {"bytes": 0, "s": 0.0}
 
     def new_exchange():

@@ -274,6 +274,17 @@ class StreamedGather:
 _SLOT_CACHE, _SLOT_LOCK = [], threading.Lock()
 
 
+def default_gather_mode(world: int) -> str:
+    """How the ranks' records reach host memory unless the caller says otherwise (V2CE_GATHER overrides): 'device' -- RCCL
+    gather to rank 0's HBM, rank 0 downloads everything over its one PCIe link (~57 GB/s measured) -- up to seven ranks;
+    'host' -- every rank writes its own records into the registered shared segment over its own link -- from eight ranks on,
+    where the e2e regime's 8 x 7.3 GB/s of records no longer fit rank 0's link."""
+    env = os.environ.get("V2CE_GATHER")
+    if env:
+        return env
+    return "host" if world >= 8 else "device"
+
+
 class RegisteredSegment:
     """The first `nbytes` of a host file (tmpfs) mapped and page-locked for the GPU (hipHostRegister): ``tensor`` is a uint8 view
     a copy-out stream can write with ``copy_(..., non_blocking=True)``.  Page-locking costs ~70 us per MB: a process that runs

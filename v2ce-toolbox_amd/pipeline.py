@@ -409,13 +409,14 @@ def run_clip(frames: np.ndarray, model, *, infer_type="center", seq_len=16, widt
     host array (``StreamingEventSink``); the function then returns None on every rank and closes the writer.
 
     comm: ``dist.TorchComm`` / ``dist.ThreadComm`` / ``dist.LocalComm`` (default: from torch.distributed).
-    gather (more than one rank; V2CE_GATHER overrides): 'device' (default) -- the records are gathered on rank 0's GPU over
-    RCCL / xGMI (``dist.StreamedGather``) and rank 0 downloads them into its pinned sink (one PCIe link: ~57 GB/s measured,
-    against 8 x 7.3 GB/s of records at N = 8 in the e2e regime: the link is the budget there); 'host' -- every rank
-    downloads its own records over its own PCIe link and writes them into its slice of the output (the streamed file, or a
-    shared tmpfs segment that rank 0 maps; only byte counts cross RCCL: ``dist.HostDirectGather``) -- no GPU gather and no
-    single link, but the kernel serialises the writers of one file (~6 GB/s per segment, tools/shm_write_probe.py), so it
-    only pays where the sink is a disk.
+    gather (more than one rank; V2CE_GATHER overrides; default ``dist.default_gather_mode``: 'device' below eight ranks, 'host'
+    from eight on): 'device' -- the records are gathered on rank 0's GPU over RCCL / xGMI (``dist.StreamedGather``) and rank 0
+    downloads them into its pinned sink (one PCIe link: ~57 GB/s measured, against 8 x 7.3 GB/s of records at N = 8 in the e2e
+    regime: the link is the budget there); 'host' -- every rank brings its own records to host memory over its own
+    PCIe link, into its slice of the output (``dist.HostDirectGather``; only byte counts cross RCCL): a shared tmpfs segment
+    whose first V2CE_HOST_SEGMENT_MB every rank page-locks and fills by GPU DMA (round 5: faster than the device gather even
+    on one GPU), the rest -- and the streamed .npz, whose CRC needs the CPU anyway -- through pinned staging and pwrite
+    (~6 GB/s per inode, tools/shm_write_probe.py).
     A rank that fails inside the clip makes EVERY rank raise at the same step (``dist.RankFailure``; the failed rank
     re-raises its own error), and the LDATI status words are reduced over the ranks before rank 0 finalises its output.
     stage2: optional (begin, finish) pair replacing LDATI (CPU stand-ins in the tests):
@@ -429,7 +430,7 @@ def run_clip(frames: np.ndarray, model, *, infer_type="center", seq_len=16, widt
     rank, world = comm.rank, comm.world
     if infer_type not in ("center", "pano"):
         raise ValueError(f"Invalid infer_type {infer_type}")
-    gather = gather or os.environ.get("V2CE_GATHER", "device")
+    gather = gather or vdist.default_gather_mode(world)
     if gather not in ("host", "device"):
         raise ValueError(f"gather must be 'host' or 'device', got {gather!r}")
     plans = plan_batches(len(frames), seq_len, batch_size)
