@@ -1147,8 +1147,47 @@ static int up_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const floa
     hipStream_t st = as_stream(stream);
     if (sc_w) return launch_up<1, 1, 4, 2>(U, d, st);
     if (d.Cout <= 32) return launch_up<1, 1, 4, 0>(U, d, st);
-    static const int wide = [] { const char *e = getenv("V2CE_UP_WIDE"); return e ? atoi(e) : 1; }();
-    if (d.Cout >= 128 && wide) return launch_up<2, 2, 4, 0>(U, d, st);
+    // >= 64 output channels: 128 channels x 256 positions (two phases per wave), 64 x 512 (one phase per wave) or 64 x 256 (the same at
+    // half the positions) -- whichever walks the CUs in the fewest tile-equivalents (whole rounds of the persistent grid x tile size).
+    // dec0 (33 x 44 planes, 256 channels): 800 tiles of 128 x 256 are FOUR rounds on 256 CUs where 3.1 would do; 1 600 half tiles
+    // are seven half rounds.  V2CE_UP_TILE = 0 (choose) | 1 | 2 | 3 forces one of the three.
+    static const int force = [] { const char *e = getenv("V2CE_UP_TILE"); return e ? atoi(e) : 0; }();
+    static const int n_cu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+        return n < 8 ? 8 : (n / 8) * 8;
+    }();
+    auto cost = [&](int co_tile, int n_sub_max, int nfg, double size) -> double {      // rounds x tile size, for the best box of that shape
+        UpCfg c{};
+        const int n_co = (d.Cout + co_tile - 1) / co_tile;
+        if (!choose_up_cfg(c, d.B, d.T, d.Hout, d.Wout, n_sub_max, nfg, n_co, n_cu, U.odd_h || U.odd_w, 12.0 * (d.C0 / 16), 27.0 * (d.C1 / 16), nullptr))
+            return 1e30;
+        const long long nsp = (long long)d.B * ((d.T + c.tt - 1) / c.tt) * ((d.Hout + 2 * c.sh - 1) / (2 * c.sh)) * ((d.Wout + 2 * c.sw - 1) / (2 * c.sw));
+        const long long blocks = 8 * ((nsp + 7) / 8) * n_co;
+        return (double)((blocks + n_cu - 1) / n_cu) * size;
+    };
+    int pick = force;
+    if (!pick) {
+        {
+            static std::mutex mu;
+            static std::map<std::tuple<int, int, int, int, int, int, int>, int> cache;
+            std::lock_guard<std::mutex> g(mu);
+            const auto key = std::make_tuple(d.B, d.T, d.Hout, d.Wout, d.C0, d.C1, d.Cout);
+            auto it = cache.find(key);
+            if (it == cache.end()) {
+                const double c1 = d.Cout >= 128 ? cost(128, 64, 2, 1.0) : 1e30, c2 = cost(64, 128, 4, 1.0), c3 = cost(64, 64, 2, 0.5);
+                // (the half tile pays twice the weight stream per MFMA: it must save at least 8 % to be taken)
+                int p = d.Cout >= 128 ? 1 : 2;
+                double best = p == 1 ? c1 : c2;
+                if (c2 < best - 1e-9) { p = 2; best = c2; }
+                if (c3 < 0.92 * best) p = 3;
+                it = cache.emplace(key, p).first;
+            }
+            pick = it->second;
+        }
+    }
+    if (pick == 1 && d.Cout >= 128) return launch_up<2, 2, 4, 0>(U, d, st);
+    if (pick == 3) return launch_up<1, 2, 2, 0>(U, d, st);
     return launch_up<1, 2, 4, 0>(U, d, st);
 }
 
