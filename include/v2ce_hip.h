@@ -367,6 +367,21 @@ int v2ce_conv3d_fwd_up2(const v2ce_conv3d_desc *desc, const float *x0, const flo
 /* Name of the kernel instantiation v2ce_conv3d_fwd_up2 would launch ("conv3d_up_kernel<WCO,CO_FR,PO_FR,FUSE>"). */
 int v2ce_conv3d_up2_variant(const v2ce_conv3d_desc *desc, int with_shortcut, char *name, size_t cap);
 
+/* A 3x3x3, stride-1, one-source convolution of a residual block (scripts/submodules.py:249-264: conv2 of every block, conv1 of the
+ * two middle blocks) with the Winograd transform F(2,3) along T: per pair of time steps four transformed 3x3 (H, W) convolutions
+ * instead of six direct tap rows -- 2/3 of the multiplies of v2ce_conv3d_fwd.  Transforms, products (split-half fp16 MFMA) and sums
+ * in f32: the result differs from v2ce_conv3d_fwd's by rounding (1e-6 relative), inside the 1e-5 parity bar of the network
+ * (csrc/conv3d_wt.hip; tools/winograd_t_sim.py).  desc: ksize 3, stride 1, precision F16X2, layout C16, C1 = 0 (x = x0 of C0
+ * channels, H0 = Hin = Hout, W0 = Win = Wout), C0 % 16 == 0, Cout % 64 == 0.  w_wt = buffer of v2ce_pack_weights_f16x2_wt
+ * (the transformed weights of W / sigma: 36 tap slots of [C0 / 16][Cout][16] per fp16 plane, then { max |G|, pre-scale, 0, 0 }).
+ * residual (may be NULL): added before the activation, layout of y.  x_absmax / y_absmax as for v2ce_conv3d_fwd. */
+size_t v2ce_pack_weights_f16x2_wt_bytes(int Cout, int Cin);
+int v2ce_pack_weights_f16x2_wt(const float *w, int Cout, int Cin, const float *sigma, void *w_wt, v2ce_stream_t stream);
+int v2ce_conv3d_fwd_wt(const v2ce_conv3d_desc *desc, const float *x, const void *w_wt, const float *scale, const float *shift,
+                       const float *residual, float *y, const float *x_absmax, float *y_absmax, v2ce_stream_t stream);
+/* Name of the kernel instantiation v2ce_conv3d_fwd_wt would launch ("conv3d_wt_kernel<CO_FR,PO_FR,RES>"). */
+int v2ce_conv3d_wt_variant(const v2ce_conv3d_desc *desc, int with_residual, char *name, size_t cap);
+
 /* Name of the kernel instantiation v2ce_conv3d_fwd would launch for desc ("conv3d_kernel<KS,S,
  * CO_FR,PO_FR,CK,EPT>", as it appears demangled in rocprofv3 traces); mapped != 0 means hmap/wmap
  * would be non-NULL.  Launches nothing.  Used by bench.py to attribute event timings. */

@@ -1,0 +1,125 @@
+"""GPU parity of the Winograd-T convolution (csrc/conv3d_wt.hip, v2ce_conv3d_fwd_wt): a 3x3x3 stride-1 conv + BN (+ residual)
++ ReLU of a residual block -- reference /root/reference/scripts/submodules.py:249-264 (conv2 of every block, conv1 of the two
+middle blocks) -- against the same convolution evaluated in f64, and against the direct split-half kernel on the same buffers.
+Tolerance (north_star): 1e-5 abs + 1e-5 rel."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def assert_close(a, b, what="", tol=TOL):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = np.abs(a - b) - tol * np.abs(b)
+    i = np.unravel_index(np.argmax(err), err.shape)
+    assert err[i] <= tol, f"{what}: max excess at {i}: got {a[i]!r} want {b[i]!r} (|d|={abs(a[i]-b[i]):.3e})"
+
+
+def to_btchw(x_ncdhw):
+    return x_ncdhw.permute(0, 2, 1, 3, 4).contiguous()
+
+
+def ref_conv(x, w, scale, shift, act, residual=None):
+    y = F.conv3d(x.double(), w.double(), None, 1, 1)
+    y = y * scale.double().view(1, -1, 1, 1, 1) + shift.double().view(1, -1, 1, 1, 1)
+    if residual is not None:
+        y = y + residual.double()
+    if act == 1:
+        y = torch.relu(y)
+    return y.numpy()
+
+
+def _model():
+    from v2ce_toolbox_amd.v2ce_3d import V2ce3d
+    m = V2ce3d.__new__(V2ce3d)
+    torch.nn.Module.__init__(m)
+    m._maps, m.precision, m._slot = {}, "f16x2", 0
+    m._prep = {"absmax": torch.zeros((8, 2), device="cuda")}
+    return m
+
+
+def _weights(m, w, wt, sigma=None):
+    from v2ce_toolbox_amd.v2ce_3d import V2ce3d
+    buf = V2ce3d._split_buffer(w.shape[0], w.shape[1], 27, "cuda", wt=wt)
+    return V2ce3d._pack(m, w.cuda().contiguous(), sigma, buf, split=True)
+
+
+CASES = [
+    # B, T, Cin, Cout, H, W, residual
+    (1, 4, 64, 64, 12, 20, False),
+    (2, 16, 64, 64, 33, 44, True),        # enc0 / dec2 family, whole pairs
+    (1, 5, 32, 64, 9, 7, True),           # odd T: the last pair's second step does not exist
+    (1, 1, 16, 64, 5, 5, False),          # a single time step
+    (1, 16, 128, 128, 17, 22, True),      # two channel tiles
+    (2, 16, 256, 256, 9, 11, True),       # res family: four channel tiles, K = 6912
+    (1, 6, 64, 64, 1, 40, False),         # one row
+    (1, 2, 48, 192, 40, 3, True),         # three columns, three channel tiles
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv3d_wt_vs_f64(case):
+    from v2ce_toolbox_amd import hip
+    from v2ce_toolbox_amd.v2ce_3d import V2ce3d
+    B, T, Cin, Cout, H, W, with_res = case
+    g = torch.Generator().manual_seed(Cin + 3 * H + W)
+    amp = 0.25 if Cin * 27 > 6000 else 1.0
+    x = amp * torch.randn(B, Cin, T, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) * (2.0 / (Cin * 27)) ** 0.5
+    sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    res = amp * torch.randn(B, Cout, T, H, W, generator=g) if with_res else None
+    m = _model()
+    xd = to_btchw(x).cuda()
+    xd.absmax = xd.abs().max().reshape(1)
+    wq = _weights(m, w, True)
+    rd = V2ce3d.to_c16(to_btchw(res).cuda()) if with_res else None
+    m.profile = []
+    y = V2ce3d._conv(m, V2ce3d.to_c16(xd), None, wq, sc.cuda(), sh.cuda(), Cout, 3, 1, hip.ACT_RELU, residual=rd, split=True,
+                     dense_out=True, track=True)
+    torch.cuda.synchronize()
+    assert "conv3d_wt_kernel" in m.profile[0][0], m.profile[0][0]
+    want = ref_conv(x, w, sc, sh, 1, res)
+    got = V2ce3d.to_planar(y).permute(0, 2, 1, 3, 4).cpu().numpy()
+    assert_close(got, want, f"wt {case}")
+    # range tracking: max |y| of the launch, and a finite guard bound
+    am = y.absmax.cpu().numpy().reshape(-1)
+    assert abs(am[0] - np.abs(got).max()) <= 1e-6 * max(1.0, am[0]) and np.isfinite(am[1]) and am[1] > 0
+
+
+def test_wt_equals_direct_kernel_inside_the_bar():
+    """The same tensors through the direct split-half kernel (27 taps) and the Winograd-T one (36 transformed taps per pair):
+    different summation orders and one more f32 rounding per transformed operand, inside the parity bar; spectral-norm
+    sigma is divided out before the transform."""
+    from v2ce_toolbox_amd import hip
+    from v2ce_toolbox_amd.v2ce_3d import V2ce3d
+    B, T, Cin, Cout, H, W = 2, 8, 64, 128, 21, 30
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, Cin, T, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) * 0.05
+    sigma = torch.tensor([1.7], device="cuda")
+    sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    m = _model()
+    xd = to_btchw(x).cuda()
+    xd.absmax = xd.abs().max().reshape(1)
+    xc = V2ce3d.to_c16(xd)
+    ya = V2ce3d._conv(m, xc, None, _weights(m, w, True, sigma), sc.cuda(), sh.cuda(), Cout, 3, 1, hip.ACT_RELU, split=True, dense_out=True)
+    yb = V2ce3d._conv(m, xc, None, _weights(m, w, False, sigma), sc.cuda(), sh.cuda(), Cout, 3, 1, hip.ACT_RELU, split=True, dense_out=True)
+    torch.cuda.synchronize()
+    assert_close(ya.cpu().numpy(), yb.cpu().numpy(), "winograd-T vs direct")
+    assert_close(V2ce3d.to_planar(ya).permute(0, 2, 1, 3, 4).cpu().numpy(), ref_conv(x, w / 1.7, sc, sh, 1), "winograd-T vs f64")
+
+
+def test_wt_rejects_what_it_cannot_do():
+    from v2ce_toolbox_amd import hip
+    import ctypes
+    d = hip.ConvDesc(B=1, T=2, C0=16, H0=4, W0=4, C1=0, Hin=4, Win=4, Cout=32, Hout=4, Wout=4, ksize=3, stride_hw=1, act=1,
+                     tile_t=0, tile_h=0, tile_w=0, precision=hip.PRECISION_F16X2, W0_pitch=4, Win_pitch=4, Wout_pitch=4,
+                     layout=hip.LAYOUT_C16, absmax_batch_stride=0)
+    t = torch.zeros(4096, device="cuda")
+    rc = hip.lib().v2ce_conv3d_fwd_wt(ctypes.byref(d), t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), None, t.data_ptr(),
+                                      None, None, None)
+    assert rc != 0 and b"Cout" in hip.lib().v2ce_last_error()

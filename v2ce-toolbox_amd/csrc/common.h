@@ -55,4 +55,9 @@ int v2ce_pack_weights_f16x2_pack_only(const float *w, int Cout, int Cin, int k3,
 int v2ce_up_fold_absmax(const float *w, int Cout, int Cin, int C0, const float *sigma, void *w_up, hipStream_t st);
 int v2ce_up_fold_pack(const float *w, int Cout, int Cin, int C0, const float *sigma, void *w_up, hipStream_t st);
 
+// the Winograd planes (conv3d_wt.hip) of up to 16 layers in one launch per pass: pass 0 raises tail[0] (zeroed by the caller) to
+// max |G|, pass 1 derives the pre-scale from it and writes the planes; sigma[l]: device scalar or null
+int v2ce_wt_pack_batch(const float *const *w, const float *const *sigma, void *const *packed, const int *rows, const int *cin, int n, int pass,
+                       hipStream_t st);
+
 }  // namespace v2ce

@@ -1,0 +1,627 @@
+// conv3d_wt.hip -- 3x3x3, stride-1 convolution of a residual block (submodules.py:249-264: conv2 of every block, conv1 of the
+// two middle blocks) with the Winograd transform F(2,3) along T, on the split-half fp16 MFMA arithmetic of conv3d.hip.  gfx950.
+//
+// Two outputs y(2p), y(2p+1) of the same pixel need, over the three time taps g0 g1 g2 and the four inputs d0..d3 = x(2p-1 .. 2p+2),
+// six products per (dh, dw, ci) in the direct form and FOUR in the transformed one:
+//     m0 = (d0 - d2) g0          m1 = (d1 + d2) (g0 + g1 + g2)/2       m2 = (d2 - d1) (g0 - g1 + g2)/2       m3 = (d1 - d3) g2
+//     y(2p) = m0 + m1 + m2       y(2p+1) = m1 - m2 - m3
+// i.e. four independent 3x3 (H, W) convolutions -- "transform slots" j = 0..3 -- over transformed inputs D_j with transformed
+// weights G_j, summed over (dh, dw, ci) BEFORE the output transform.  The executed MFMA work of the layer drops by 1.5x (36 instead
+// of 54 k-steps per output pair and channel chunk); the chip is power-limited on fp16 MFMA, so the executed flop is
+// the lever that is left.  Numerics: transforms, products (22-bit split operands) and sums in f32 -- the network-level deviation from
+// the direct f32 form is 1-2e-6 like the direct form's own distance from f64 (tools/winograd_t_sim.py), the parity bar is 1e-5.
+//
+// Mapping on the wave-specialised kernel (waves 0-3 consume, 4-7 produce, one barrier per 16-channel chunk):
+//   * consumer wave j owns transform slot j for the WHOLE tile: CO_FR x PO_FR accumulator tiles (32 channels x 32 pair-positions
+//     (p, h, w)), A fragments of (slot, tap, chunk) reused across the PO_FR position fragments exactly like the direct kernel's;
+//   * a producer lane owns one (p, hh, hw) element of the halo box: four 64-byte loads (the four time steps), the input transform
+//     on sixteen channels, the hi/lo split, and sixteen 16-byte pieces (4 slots x hi/lo x channel halves) into LDS -- at most 256
+//     elements per box, two chunks in flight in registers;
+//   * output transform across the four waves at the end of a tile, through the LDS buffer the tile's last chunk has just freed:
+//     per channel fragment every wave leaves its 16 KB of accumulators in ITS OWN slot region (the only region it was still reading),
+//     barrier, wave f sums the four slots of position fragment f into y(2p), y(2p+1) and runs conv_epilogue on them (scale, shift,
+//     residual, activation, range tracking -- the same code as the direct kernel).  The producers take part in the 2 * CO_FR extra
+//     barriers before they refill that buffer.
+#include "conv3d_dev.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <tuple>
+
+namespace v2ce {
+namespace {
+
+constexpr int kWtSlot = 256;             // element slots per transform slot in a quarter plane (>= elements of a halo box)
+constexpr int kWtChs = 4 * kWtSlot;      // pieces per quarter plane (hi ch 0-7 | hi ch 8-15 | lo 0-7 | lo 8-15)
+constexpr int kWtTaps = 36;              // 4 transform slots x 9 (dh, dw) taps
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// workgroup barrier that waits only for this wave's LDS traffic (__syncthreads also drains the vector-memory counter: the
+// epilogue's stores of the previous round would be waited for at every rendezvous)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
+
+template <int CO_FR, int PO_FR, int RES>
+__global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(PO_FR == 4, "the output transform hands position fragment f to consumer wave f");
+    constexpr int CK = 16, NA = 3, CO_TILE = CO_FR * 32, chs = kWtChs;
+    constexpr int NX = 2 * CO_FR;                                    // extra barriers per tile (output transform)
+    f16x8 *pieces = reinterpret_cast<f16x8 *>(conv_smem);            // [2][4][chs] x 16 B
+
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int CG = P.Cin / CK;
+    const long long wplane = (long long)kWtTaps * CG * P.Cout * 16;  // halves per plane
+
+    struct TileId { int b, co_t, t0, h0, w0; };
+    auto decode = [&](int vb, TileId &T) -> bool {                   // (the direct kernel's walk: conv3d.hip)
+        const int xcd = vb & 7, q = vb >> 3;
+        T.co_t = q % P.n_co_tiles;
+        const int sp = q / P.n_co_tiles;
+        int bid = xcd * P.per_xcd + sp;
+        if (sp >= P.per_xcd || bid >= P.n_spatial) return false;
+        const int iw = bid % P.nW;            bid /= P.nW;
+        const int ih = bid % P.nH;            bid /= P.nH;
+        const int it = bid % P.nT;            bid /= P.nT;
+        T.b = bid;
+        T.t0 = it * P.TT; T.h0 = ih * P.TH; T.w0 = iw * P.TW;
+        return true;
+    };
+    auto next_tile = [&](int &vb, TileId &T) -> bool {
+        for (; vb < P.total_blocks; vb += (int)gridDim.x)
+            if (decode(vb, T)) return true;
+        return false;
+    };
+
+    const float *tail = reinterpret_cast<const float *>(P.wq + 2 * wplane);
+    const float w_scale = tail[1];
+    auto amax_of = [&](int b) -> float { return P.x0_absmax ? P.x0_absmax[b * P.amax_bs] : 4094.0f; };
+    // the transformed inputs reach 2 max |x|: one binade less than the direct kernel's pre-scale
+    auto scale_of = [&](int b) -> float { return P.x0_absmax ? pow2_prescale(2.0f * amax_of(b)) : 0.5f * kActScale; };
+    // range guard (conv3d_f16x2_ws_kernel): K = 9 Cin terms per slot, three slots per output, operands 2 max |x| and max |G|
+    if (P.guard && blockIdx.x == 0 && wave == 0) {
+        float sm = 0.0f;
+        for (int co = lane; co < P.Cout; co += 64) sm = fmaxf(sm, fabsf(P.scale[co]));
+#pragma unroll
+        for (int o = 32; o; o >>= 1) sm = fmaxf(sm, __shfl_xor(sm, o));
+        const int nb = P.amax_bs ? P.B : 1;
+        for (int b = lane; b < nb; b += 64) {
+            const float am = 2.0f * amax_of(b), xs = scale_of(b);
+            P.guard[b * P.amax_bs] = sm * (float)(P.Cin * 27) * 0x1p-25f * (tail[0] / xs + am / tail[1]);
+        }
+    }
+
+    int vb = blockIdx.x;
+    TileId T;
+    if (!next_tile(vb, T)) return;
+    int gc = 0;                                                       // chunks handled so far: pieces buffer gc & 1
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ producers
+        const int ptid = tid - 256;                                   // = the element (p, hh, hw) of the halo box this lane owns
+        const bool wave_on = (wave - 4) * 64 < P.plane;               // wave-uniform
+        float x_scale = scale_of(T.b);
+        unsigned goff[4];                                             // the element's four time steps 2p-1 .. 2p+2 (kOOB: zero padding)
+        float R0[4][CK], R1[4][CK];
+        __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x0), 0, 0, 0x00020000);
+        const long long seq = (long long)P.T * P.Cin * (P.Hin * P.Winp);
+        const int cg_bytes = P.Hin * P.Winp * 64;                     // bytes between 16-channel groups of a time step
+        auto load_chunk = [&](const TileId &L, int cidx, float (&R)[4][CK]) {
+            if (cidx == 0) {                                          // uniform: a new tile
+#pragma unroll
+                for (int i = 0; i < 4; ++i) goff[i] = kOOB;
+                if (ptid < P.plane) {
+                    const int pp = ptid / (P.HH * P.HWd);
+                    const int rem = ptid - pp * (P.HH * P.HWd);
+                    const int hh = rem / P.HWd;
+                    const int hw = rem - hh * P.HWd;
+                    const int h = L.h0 - 1 + hh, w = L.w0 - 1 + hw;
+                    if (h >= 0 && h < P.Hin && w >= 0 && w < P.Win) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int t = L.t0 + 2 * pp - 1 + i;
+                            if (t >= 0 && t < P.T) goff[i] = 4u * (unsigned)((t * P.Cin) * (P.Hin * P.Winp)) + 64u * (unsigned)(h * P.Winp + w);
+                        }
+                    }
+                }
+                rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x0 + L.b * seq), 0, (int)(seq * 4), 0x00020000);
+            }
+            if (wave_on) {
+                typedef float f32x4g __attribute__((ext_vector_type(4)));
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int k4 = 0; k4 < CK / 4; ++k4) {
+                        const f32x4g v = __builtin_bit_cast(f32x4g, __builtin_amdgcn_raw_buffer_load_b128(rs_in, goff[i], cidx * cg_bytes + 16 * k4, 0));
+                        R[i][4 * k4] = v[0]; R[i][4 * k4 + 1] = v[1]; R[i][4 * k4 + 2] = v[2]; R[i][4 * k4 + 3] = v[3];
+                    }
+            }
+        };
+        int vbL = vb, cgL = 0;                                        // load cursor: two chunks ahead of the conversion, across tiles
+        TileId TL = T;
+        bool moreL = true;
+        auto load_next = [&](float (&R)[4][CK]) {
+            if (!moreL) return;
+            load_chunk(TL, cgL, R);
+            if (++cgL == CG) {
+                cgL = 0;
+                vbL += (int)gridDim.x;
+                moreL = next_tile(vbL, TL);
+            }
+        };
+        int cgC = 0;                                                  // conversion cursor: chunk inside the tile
+        auto convert = [&](const float (&R)[4][CK]) {
+            f16x8 *qb = pieces + (gc & 1) * 4 * chs;
+            if (!wave_on) return;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int hg = 0; hg < 2; ++hg) {
+                    typedef unsigned u32x4c __attribute__((ext_vector_type(4)));
+                    u32x4c ph, pl;
+#pragma unroll
+                    for (int c2 = 0; c2 < 4; ++c2) {
+                        const int ca = 8 * hg + 2 * c2, cb = ca + 1;
+                        // input transform B^T d (f32): d0 - d2 | d1 + d2 | d2 - d1 | d1 - d3
+                        const float xa = j == 0 ? R[0][ca] - R[2][ca] : j == 1 ? R[1][ca] + R[2][ca] : j == 2 ? R[2][ca] - R[1][ca] : R[1][ca] - R[3][ca];
+                        const float xb = j == 0 ? R[0][cb] - R[2][cb] : j == 1 ? R[1][cb] + R[2][cb] : j == 2 ? R[2][cb] - R[1][cb] : R[1][cb] - R[3][cb];
+                        unsigned h, l;                                // hi = f16(x s), lo = f16(x s - hi)  (conv3d.hip, producers)
+                        asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
+                            "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
+                            "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
+                            "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                            : "=&v"(h), "=&v"(l) : "v"(xa), "v"(xb), "v"(x_scale));
+                        ph[c2] = h;
+                        pl[c2] = l;
+                    }
+                    qb[hg * chs + j * kWtSlot + ptid] = __builtin_bit_cast(f16x8, ph);
+                    qb[(2 + hg) * chs + j * kWtSlot + ptid] = __builtin_bit_cast(f16x8, pl);
+                }
+            }
+        };
+        bool moreC = true;
+        auto advance = [&]() {
+            ++gc;
+            if (++cgC == CG) {
+                cgC = 0;
+                vb += (int)gridDim.x;
+                moreC = next_tile(vb, T);
+                if (moreC) x_scale = scale_of(T.b);
+            }
+        };
+        auto tile_rendezvous = [&]() {                                // the consumers' output transform of the tile before this one
+#pragma unroll
+            for (int k = 0; k < NX; ++k) lds_barrier();
+        };
+        load_next(R0);
+        load_next(R1);
+        while (moreC) {
+            convert(R0);
+            load_next(R0);
+            if (cgC == 0 && gc != 0) tile_rendezvous();
+            __syncthreads();                                          // barrier gc: pieces[gc & 1] ready
+            advance();
+            if (!moreC) break;
+            convert(R1);
+            load_next(R1);
+            if (cgC == 0 && gc != 0) tile_rendezvous();
+            __syncthreads();
+            advance();
+        }
+        tile_rendezvous();                                            // the last tile's
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers: wave = transform slot
+    __builtin_amdgcn_s_setprio(2);
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(P.wq), 0, (int)(4 * wplane), 0x00020000);
+    const int lo_off = (int)(2 * wplane);                             // bytes from the hi plane to the lo plane
+    const int tap_stride = CG * P.Cout * 32;                          // bytes between taps
+    const int cg_stride = P.Cout * 32;                                // bytes between 16-channel groups
+    const int slot_off = wave * 9 * tap_stride;                       // this slot's nine taps
+    f16x8 ah[NA][CO_FR], al[NA][CO_FR], bh[PO_FR], bl[PO_FR];
+    int wlane[CO_FR];
+#define V2CE_LOAD_A(slot_, soff_)                                                              \
+    {                                                                                          \
+        const int so_ = (soff_);                                                               \
+        _Pragma("unroll") for (int q = 0; q < CO_FR; ++q) {                                    \
+            ah[slot_][q] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_a, wlane[q], so_, 0));          \
+            al[slot_][q] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_a, wlane[q], so_ + lo_off, 0)); \
+        }                                                                                      \
+    }
+    int ring_co_t = -1;
+    bool more = true;
+    while (more) {
+        const int co0 = T.co_t * CO_TILE;
+        const float x_scale = scale_of(T.b);
+        const float inv_scale = 1.0f / (x_scale * w_scale);           // a power of two: exact
+        int bhb[PO_FR];
+#pragma unroll
+        for (int f = 0; f < PO_FR; ++f) {
+            const int m = f * 32 + l32;                               // pair-position (p, h, w) of the box
+            bhb[f] = half * chs + wave * kWtSlot;
+            if (m < P.n_pos) {
+                const int pp = m / (P.TH * P.TW);
+                const int rem = m - pp * (P.TH * P.TW);
+                const int th = rem / P.TW;
+                const int tw = rem - th * P.TW;
+                bhb[f] += (pp * P.HH + th) * P.HWd + tw;
+            }
+        }
+        if (T.co_t != ring_co_t) {                                    // uniform: (re)load the ring for this channel tile
+            ring_co_t = T.co_t;
+#pragma unroll
+            for (int q = 0; q < CO_FR; ++q) {
+                int co = co0 + q * 32 + l32;
+                co = co < P.Cout ? co : P.Cout - 1;
+                wlane[q] = (co * 16 + 8 * half) * 2;
+            }
+            step_loop<0, NA - 1>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                V2CE_LOAD_A(t, slot_off + t * tap_stride)             // chunk 0, taps 0 .. NA-2
+            });
+        }
+        f32x16 acc[CO_FR][PO_FR];
+#pragma unroll
+        for (int q = 0; q < CO_FR; ++q)
+#pragma unroll
+            for (int f = 0; f < PO_FR; ++f)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[q][f][r] = 0.0f;
+
+        for (int cg = 0; cg < CG; ++cg, ++gc) {
+            const f16x8 *qb = pieces + (gc & 1) * 4 * chs;
+            const int wc = slot_off + cg * cg_stride;
+            const int wn = cg + 1 < CG ? wc + cg_stride : slot_off;   // last chunk: chunk 0 again (the next tile's start)
+            __syncthreads();                                          // barrier gc: pieces[gc & 1] ready
+#pragma unroll
+            for (int f = 0; f < PO_FR; ++f) {
+                bh[f] = qb[bhb[f]];
+                bl[f] = qb[bhb[f] + 2 * chs];
+            }
+            step_loop<0, 9>([&](auto tc) {
+                constexpr int tap = decltype(tc)::value;
+                constexpr int nt = tap + 1;
+                constexpr int dh = nt / 3, dw = nt % 3;
+                constexpr int pt = tap + NA - 1;                      // the tap whose A fragments are fetched now
+                if constexpr (pt < 9) {
+                    V2CE_LOAD_A(pt % NA, wc + pt * tap_stride)
+                } else {
+                    V2CE_LOAD_A(pt % NA, wn + (pt - 9) * tap_stride)
+                }
+                const int toff = dh * P.HWd + dw;                     // next tap's offset in the slot's plane
+#pragma unroll
+                for (int f = 0; f < PO_FR; ++f) {
+#pragma unroll
+                    for (int q = 0; q < CO_FR; ++q) {
+                        acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tap % NA][q], bh[f], acc[q][f], 0, 0, 0);
+                        acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tap % NA][q], bl[f], acc[q][f], 0, 0, 0);
+                        acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tap % NA][q], bh[f], acc[q][f], 0, 0, 0);
+                    }
+                    if constexpr (nt < 9) {                           // refill in place for the next tap
+                        bh[f] = qb[bhb[f] + toff];
+                        bl[f] = qb[bhb[f] + toff + 2 * chs];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+        }
+
+        // ---- output transform + epilogue.  This wave stores position fragment f = wave: outputs t = 2p, 2p + 1.
+        int poff[2];
+        {
+            const int m = wave * 32 + l32;
+            poff[0] = poff[1] = -1;
+            if (m < P.n_pos) {
+                const int pp = m / (P.TH * P.TW);
+                const int rem = m - pp * (P.TH * P.TW);
+                const int th = rem / P.TW;
+                const int tw = rem - th * P.TW;
+                const int t = T.t0 + 2 * pp, h = T.h0 + th, w = T.w0 + tw;
+                if (h < P.Hout && w < P.Wout) {
+                    if (t < P.T) poff[0] = 4 * ((t * P.Cout) * (P.Hout * P.Woutp)) + 64 * (h * P.Woutp + w);
+                    if (t + 1 < P.T) poff[1] = 4 * (((t + 1) * P.Cout) * (P.Hout * P.Woutp)) + 64 * (h * P.Woutp + w);
+                }
+            }
+        }
+        typedef float f32x4t __attribute__((ext_vector_type(4)));
+        f32x4t *xch = reinterpret_cast<f32x4t *>(pieces + ((gc - 1) & 1) * 4 * chs);   // the buffer of the tile's last chunk
+#pragma unroll
+        for (int q = 0; q < CO_FR; ++q) {
+            // (round q > 0: the previous round's reads are behind its second barrier)
+#pragma unroll
+            for (int f = 0; f < PO_FR; ++f)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    f32x4t v;
+                    v[0] = acc[q][f][4 * r4]; v[1] = acc[q][f][4 * r4 + 1]; v[2] = acc[q][f][4 * r4 + 2]; v[3] = acc[q][f][4 * r4 + 3];
+                    xch[f * chs + wave * kWtSlot + r4 * 64 + lane] = v;
+                }
+            lds_barrier();
+            f32x16 yy[1][2];
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const f32x4t m0 = xch[wave * chs + 0 * kWtSlot + r4 * 64 + lane], m1 = xch[wave * chs + 1 * kWtSlot + r4 * 64 + lane];
+                const f32x4t m2 = xch[wave * chs + 2 * kWtSlot + r4 * 64 + lane], m3 = xch[wave * chs + 3 * kWtSlot + r4 * 64 + lane];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    yy[0][0][4 * r4 + k] = (m0[k] + m1[k]) + m2[k];
+                    yy[0][1][4 * r4 + k] = (m1[k] - m2[k]) - m3[k];
+                }
+            }
+            lds_barrier();                                            // reads done: the next round / the producers may write
+            conv_epilogue<1, 2, true, false, RES, true>(P, yy, poff, co0 + 32 * q, half, T.b, inv_scale);
+        }
+        vb += (int)gridDim.x;
+        more = next_tile(vb, T);
+    }
+#undef V2CE_LOAD_A
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+// ---------------------------------------------------------------------------------------------
+// weights: G_j of W / sigma as fp16 hi / lo planes [2][slot * 9 + dh * 3 + dw][Cin / 16][Cout][16], tail { max |G|, pre-scale, 0, 0 }.
+// A workgroup takes 32 output channels x one 16-channel group (32 runs of 432 contiguous floats of W), like sn_batch_pack_kernel.
+// PASS 0: max |G| into tail[0] (atomic max on the bit pattern; the caller zeroes it); PASS 1: the planes.
+// ---------------------------------------------------------------------------------------------
+constexpr int kWtMaxBatch = 16;
+struct WtLayer {
+    const float *w, *sigma;       // [Cout][Cin][27]; sigma: device scalar or null (1)
+    _Float16 *packed;
+    int rows, cin;
+};
+struct WtBatch {
+    WtLayer L[kWtMaxBatch];
+    int n;
+    int blk[kWtMaxBatch + 1];     // prefix of (rows / 32) * (cin / 16)
+};
+constexpr size_t kWtPackLds = (size_t)32 * 432 * 4 + (size_t)2 * kWtTaps * 514 * 2;
+
+template <int PASS>
+__global__ __launch_bounds__(256) void wt_pack_kernel(WtBatch B) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wt_smem[];
+    float *wf = reinterpret_cast<float *>(wt_smem);                   // [32][16][27] = W / sigma
+    _Float16 *hi = reinterpret_cast<_Float16 *>(wt_smem + 32 * 432 * 4), *lo = hi + kWtTaps * 514;
+    int l = 0;
+    while (l + 1 < B.n && (int)blockIdx.x >= B.blk[l + 1]) ++l;
+    const WtLayer &P = B.L[l];
+    const int CG = P.cin / 16;
+    const int blk = blockIdx.x - B.blk[l];
+    const int cg = blk % CG, co0 = (blk / CG) * 32;
+    const long long n = (long long)P.rows * P.cin * kWtTaps;
+    float *tail = reinterpret_cast<float *>(P.packed + 2 * n);
+    const float sigma = P.sigma ? P.sigma[0] : 1.0f;
+    for (int e = threadIdx.x; e < 32 * 432; e += 256) {
+        const int col = e / 432, rem = e - col * 432;
+        wf[e] = P.w[((long long)(co0 + col) * P.cin + cg * 16) * 27 + rem] / sigma;
+    }
+    __syncthreads();
+    const float w_scale = PASS ? pow2_prescale(tail[0]) : 1.0f;
+    if (PASS && blk == 0 && threadIdx.x == 0) tail[1] = w_scale;
+    float m = 0.0f;
+    for (int it = threadIdx.x; it < 32 * 16 * 9; it += 256) {
+        const int col = it / 144, rem = it - col * 144, j = rem / 9, t9 = rem - j * 9;
+        const float *g = wf + col * 432 + j * 27 + t9;
+        const float g0 = g[0], g1 = g[9], g2 = g[18];
+        float G[4];
+        G[0] = g0;
+        G[1] = ((g0 + g1) + g2) * 0.5f;
+        G[2] = ((g0 - g1) + g2) * 0.5f;
+        G[3] = g2;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (PASS) {
+                const float v = G[s] * w_scale;
+                const _Float16 h = (_Float16)v;
+                hi[(s * 9 + t9) * 514 + col * 16 + j] = h;
+                lo[(s * 9 + t9) * 514 + col * 16 + j] = (_Float16)(v - (float)h);
+            } else {
+                m = fmaxf(m, fabsf(G[s]));
+            }
+        }
+    }
+    if (!PASS) {
+#pragma unroll
+        for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if ((threadIdx.x & 63) == 0 && __float_as_uint(m) > __atomic_load_n(reinterpret_cast<unsigned *>(tail), __ATOMIC_RELAXED))
+            atomicMax(reinterpret_cast<unsigned *>(tail), __float_as_uint(m));
+        return;
+    }
+    __syncthreads();
+    const unsigned *hi32 = reinterpret_cast<const unsigned *>(hi), *lo32 = reinterpret_cast<const unsigned *>(lo);
+    for (int tap = 0; tap < kWtTaps; ++tap) {
+        const long long o = (((long long)tap * CG + cg) * P.rows + co0) * 16;       // halves
+        reinterpret_cast<unsigned *>(P.packed + o)[threadIdx.x] = hi32[tap * 257 + threadIdx.x];
+        reinterpret_cast<unsigned *>(P.packed + n + o)[threadIdx.x] = lo32[tap * 257 + threadIdx.x];
+    }
+}
+
+int wt_pack_launch(const WtBatch &B, int pass, hipStream_t st) {
+    static const int once = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wt_pack_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWtPackLds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(wt_pack_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWtPackLds);
+        return 0;
+    }();
+    (void)once;
+    if (B.blk[B.n] == 0) return V2CE_OK;
+    if (pass == 0) hipLaunchKernelGGL(wt_pack_kernel<0>, dim3(B.blk[B.n]), dim3(256), kWtPackLds, st, B);
+    else hipLaunchKernelGGL(wt_pack_kernel<1>, dim3(B.blk[B.n]), dim3(256), kWtPackLds, st, B);
+    V2CE_HIP_CHECK(hipGetLastError());
+    return V2CE_OK;
+}
+
+thread_local char *g_wt_name_out = nullptr;
+thread_local size_t g_wt_name_cap = 0;
+
+struct WtBox { int pp, th, tw; };
+
+// The box (pairs x rows x columns) of a tile: at most PO_FR * 32 pair-positions, at most 256 halo elements (one per producer
+// lane); fewest rounds of the persistent grid first, then the least halo per output.  V2CE_WT_BOX=pp,th,tw forces one.
+WtBox choose_wt_box(int B, int T, int H, int W, int n_co, int n_cu, int pos_tile) {
+    if (const char *e = getenv("V2CE_WT_BOX")) {
+        WtBox b{};
+        if (sscanf(e, "%d,%d,%d", &b.pp, &b.th, &b.tw) == 3 && b.pp > 0 && b.th > 0 && b.tw > 0 && b.pp * b.th * b.tw <= pos_tile &&
+            b.pp * (b.th + 2) * (b.tw + 2) <= kWtSlot)
+            return b;
+    }
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, int, int, int, int>, WtBox> cache;
+    std::lock_guard<std::mutex> g(mu);
+    const auto key = std::make_tuple(B, T, H, W, n_co, pos_tile);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    const int pairs = (T + 1) / 2;
+    WtBox best{0, 0, 0};
+    double best_cost = 1e30;
+    for (int pp = 1; pp <= pairs && pp <= 16; ++pp)
+        for (int th = 1; th <= H && th <= 64; ++th)
+            for (int tw = 1; tw <= W && tw <= 128; ++tw) {
+                if (pp * th * tw > pos_tile || pp * (th + 2) * (tw + 2) > kWtSlot) continue;
+                const long long nsp = (long long)B * ((pairs + pp - 1) / pp) * ((H + th - 1) / th) * ((W + tw - 1) / tw);
+                const long long blocks = 8 * ((nsp + 7) / 8) * n_co;
+                const double rounds = (double)((blocks + n_cu - 1) / n_cu);
+                // a tile costs its MFMA work (fixed) plus what its producers gather: 4 loads per halo element
+                const double halo = (double)pp * (th + 2) * (tw + 2) / kWtSlot;
+                const double cost = rounds * (1.0 + 0.15 * halo) + 1e-3 * (double)blocks / n_cu;
+                if (cost < best_cost) { best_cost = cost; best = WtBox{pp, th, tw}; }
+            }
+    cache.emplace(key, best);
+    return best;
+}
+
+template <int CO_FR, int PO_FR, int RES>
+int launch_wt(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream) {
+    constexpr int CO_TILE = CO_FR * 32, POS_TILE = PO_FR * 32;
+    if (g_wt_name_out) {
+        snprintf(g_wt_name_out, g_wt_name_cap, "conv3d_wt_kernel<%d,%d,%d>", CO_FR, PO_FR, RES);
+        return V2CE_OK;
+    }
+    static const int n_cu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+        return n < 8 ? 8 : (n / 8) * 8;
+    }();
+    P.n_co_tiles = (d.Cout + CO_TILE - 1) / CO_TILE;
+    WtBox bx{d.tile_t / 2, d.tile_h, d.tile_w};
+    if (bx.pp <= 0 || bx.th <= 0 || bx.tw <= 0) bx = choose_wt_box(d.B, d.T, d.Hout, d.Wout, P.n_co_tiles, n_cu, POS_TILE);
+    V2CE_REQUIRE(bx.pp > 0 && bx.pp * bx.th * bx.tw <= POS_TILE && bx.pp * (bx.th + 2) * (bx.tw + 2) <= kWtSlot, V2CE_ERR_UNSUPPORTED,
+                 "v2ce_conv3d_fwd_wt: no box fits");
+    P.TT = 2 * bx.pp; P.TH = bx.th; P.TW = bx.tw;
+    P.n_pos = bx.pp * bx.th * bx.tw;                       // pair-positions
+    P.HT = bx.pp; P.HH = bx.th + 2; P.HWd = bx.tw + 2;
+    P.plane = P.HT * P.HH * P.HWd;                         // halo elements (p, hh, hw)
+    P.nT = (d.T + P.TT - 1) / P.TT; P.nH = (d.Hout + bx.th - 1) / bx.th; P.nW = (d.Wout + bx.tw - 1) / bx.tw;
+    P.n_spatial = d.B * P.nT * P.nH * P.nW;
+    P.xcd_remap = 1;
+    P.per_xcd = (P.n_spatial + 7) / 8;
+    const long long blocks = (long long)8 * P.per_xcd * P.n_co_tiles;
+    P.total_blocks = (int)blocks;
+    const size_t lds = (size_t)kWtChs * (2 * 4 * 16);      // 128 KB
+    auto kern = conv3d_wt_kernel<CO_FR, PO_FR, RES>;
+    static const int once = [&] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        return 0;
+    }();
+    (void)once;
+    if (getenv("V2CE_WT_VERBOSE"))
+        fprintf(stderr, "[wt<%d,%d,%d> %dx%dx%dx%d C %d -> %d] box %d pairs x %d x %d (%d halo elements), %lld tiles\n", CO_FR, PO_FR, RES, d.B, d.T,
+                d.Hout, d.Wout, P.Cin, P.Cout, bx.pp, bx.th, bx.tw, P.plane, blocks);
+    const unsigned grid = (unsigned)(blocks > n_cu ? n_cu : blocks);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, P);
+    V2CE_HIP_CHECK(hipGetLastError());
+    return V2CE_OK;
+}
+
+int wt_dispatch(const v2ce_conv3d_desc *desc, const float *x, const void *w_wt, const float *scale, const float *shift,
+                const float *residual, float *y, const float *x_absmax, float *y_absmax, v2ce_stream_t stream) {
+    clear_error();
+    V2CE_REQUIRE(desc && (g_wt_name_out || (x && w_wt && scale && shift && y)), V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd_wt: null pointer");
+    const v2ce_conv3d_desc &d = *desc;
+    V2CE_REQUIRE(d.B > 0 && d.T > 0 && d.C0 > 0 && d.C1 == 0 && d.Hin > 0 && d.Win > 0 && d.Cout > 0, V2CE_ERR_BAD_ARG,
+                 "v2ce_conv3d_fwd_wt: bad shape (one source: C1 must be 0)");
+    V2CE_REQUIRE(d.ksize == 3 && d.stride_hw == 1 && d.precision == V2CE_PRECISION_F16X2 && d.layout == V2CE_LAYOUT_C16, V2CE_ERR_UNSUPPORTED,
+                 "v2ce_conv3d_fwd_wt: a split-half 3x3x3 stride-1 conv on channels-last-16 activations");
+    V2CE_REQUIRE(d.H0 == d.Hin && d.W0 == d.Win && d.Hout == d.Hin && d.Wout == d.Win, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd_wt: input and output planes must have one size");
+    V2CE_REQUIRE(d.C0 % 16 == 0 && d.Cout % 64 == 0, V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd_wt: Cin must be a multiple of 16, Cout of 64");
+    V2CE_REQUIRE(d.act >= 0 && d.act <= 2, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd_wt: act %d", d.act);
+    const int Winp = d.W0_pitch > 0 ? d.W0_pitch : d.W0, Woutp = d.Wout_pitch > 0 ? d.Wout_pitch : d.Wout;
+    V2CE_REQUIRE(Winp >= d.Win && Woutp >= d.Wout, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd_wt: a row pitch is smaller than its width");
+    V2CE_REQUIRE((long long)d.T * d.C0 * d.Hin * Winp < (1ll << 29) && (long long)d.T * d.Cout * d.Hout * Woutp < (1ll << 29), V2CE_ERR_UNSUPPORTED,
+                 "v2ce_conv3d_fwd_wt: a single sequence exceeds the 2 GiB buffer-descriptor range");
+    V2CE_REQUIRE(v2ce_pack_weights_f16x2_wt_bytes(d.Cout, d.C0) < (1ull << 31), V2CE_ERR_UNSUPPORTED,
+                 "v2ce_conv3d_fwd_wt: the weight buffer exceeds the 2 GiB buffer-descriptor range");
+    ConvParams P{};
+    P.x0 = x; P.scale = scale; P.shift = shift; P.res = residual; P.y = y;
+    P.B = d.B; P.T = d.T; P.C0 = d.C0; P.H0 = d.H0; P.W0 = d.W0; P.Hin = d.Hin; P.Win = d.Win;
+    P.Cin = d.C0; P.Cout = d.Cout; P.Hout = d.Hout; P.Wout = d.Wout;
+    P.W0p = Winp; P.Winp = Winp; P.Woutp = Woutp;
+    P.c16 = 1;
+    P.act = d.act;
+    P.wq = static_cast<const _Float16 *>(w_wt);
+    P.x0_absmax = x_absmax; P.y_absmax = y_absmax;
+    P.guard = y_absmax ? y_absmax + 1 : nullptr;
+    P.amax_bs = d.absmax_batch_stride;
+    V2CE_REQUIRE(P.amax_bs == 0 || P.amax_bs >= 2, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd_wt: absmax_batch_stride must be 0 or >= 2");
+    hipStream_t st = as_stream(stream);
+    if (residual || (g_wt_name_out && scale)) return launch_wt<2, 4, 1>(P, d, st);
+    return launch_wt<2, 4, 0>(P, d, st);
+}
+
+}  // namespace
+
+// internals for sn.hip: the Winograd planes of spectral-norm layers, all layers of a batch in one launch per pass
+int v2ce_wt_pack_batch(const float *const *w, const float *const *sigma, void *const *packed, const int *rows, const int *cin, int n, int pass,
+                       hipStream_t st) {
+    V2CE_REQUIRE(n >= 0 && n <= kWtMaxBatch, V2CE_ERR_BAD_ARG, "v2ce_wt_pack_batch: 0..%d layers", kWtMaxBatch);
+    WtBatch B{};
+    B.n = n;
+    for (int l = 0; l < n; ++l) {
+        V2CE_REQUIRE(rows[l] % 32 == 0 && cin[l] % 16 == 0, V2CE_ERR_UNSUPPORTED, "v2ce_wt_pack_batch: Cout %% 32, Cin %% 16");
+        B.L[l] = WtLayer{w[l], sigma[l], static_cast<_Float16 *>(packed[l]), rows[l], cin[l]};
+        B.blk[l + 1] = B.blk[l] + (rows[l] / 32) * (cin[l] / 16);
+    }
+    if (n == 0) return V2CE_OK;
+    return wt_pack_launch(B, pass, st);
+}
+
+}  // namespace v2ce
+
+using namespace v2ce;
+
+extern "C" size_t v2ce_pack_weights_f16x2_wt_bytes(int Cout, int Cin) {
+    if (Cout <= 0 || Cin <= 0) return 0;
+    return (size_t)2 * kWtTaps * Cout * Cin * sizeof(_Float16) + 16;
+}
+
+extern "C" int v2ce_pack_weights_f16x2_wt(const float *w, int Cout, int Cin, const float *sigma, void *w_wt, v2ce_stream_t stream) {
+    clear_error();
+    V2CE_REQUIRE(w && w_wt && Cout > 0 && Cin > 0, V2CE_ERR_BAD_ARG, "v2ce_pack_weights_f16x2_wt: bad argument");
+    V2CE_REQUIRE(Cout % 32 == 0 && Cin % 16 == 0, V2CE_ERR_UNSUPPORTED, "v2ce_pack_weights_f16x2_wt: Cout must be a multiple of 32, Cin of 16");
+    hipStream_t st = as_stream(stream);
+    unsigned char *tail = static_cast<unsigned char *>(w_wt) + (size_t)2 * kWtTaps * Cout * Cin * sizeof(_Float16);
+    V2CE_HIP_CHECK(hipMemsetAsync(tail, 0, 16, st));
+    void *pk = w_wt;
+    int rc = v2ce_wt_pack_batch(&w, &sigma, &pk, &Cout, &Cin, 1, 0, st);
+    if (rc != V2CE_OK) return rc;
+    return v2ce_wt_pack_batch(&w, &sigma, &pk, &Cout, &Cin, 1, 1, st);
+}
+
+extern "C" int v2ce_conv3d_fwd_wt(const v2ce_conv3d_desc *desc, const float *x, const void *w_wt, const float *scale, const float *shift,
+                                  const float *residual, float *y, const float *x_absmax, float *y_absmax, v2ce_stream_t stream) {
+    g_wt_name_out = nullptr;
+    return wt_dispatch(desc, x, w_wt, scale, shift, residual, y, x_absmax, y_absmax, stream);
+}
+
+extern "C" int v2ce_conv3d_wt_variant(const v2ce_conv3d_desc *desc, int with_residual, char *name, size_t cap) {
+    V2CE_REQUIRE(name && cap > 0, V2CE_ERR_BAD_ARG, "v2ce_conv3d_wt_variant: no buffer");
+    name[0] = '\0';
+    g_wt_name_out = name;
+    g_wt_name_cap = cap;
+    static const float dummy = 0.0f;
+    const int rc = wt_dispatch(desc, nullptr, nullptr, with_residual ? &dummy : nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    g_wt_name_out = nullptr;
+    return rc;
+}

@@ -191,6 +191,12 @@ class V2ce3d(nn.Module):
                                                            out.data_ptr(), hip.stream_ptr(w.device)),
                       "v2ce_pack_weights_f16x2_up")
             return out
+        if split and out is not None and getattr(out, "wt", False):
+            # Winograd F(2,3) along T: the transformed weights of W / sigma (v2ce_conv3d_fwd_wt)
+            hip.check(hip.lib().v2ce_pack_weights_f16x2_wt(w.data_ptr(), cout, cin, hip.ptr(sigma), out.data_ptr(),
+                                                           hip.stream_ptr(w.device)),
+                      "v2ce_pack_weights_f16x2_wt")
+            return out
         if split:      # fp16 hi/lo planes for the split-half conv path
             if out is None:
                 out = self._split_buffer(cout, cin, k3, w.device)
@@ -206,9 +212,14 @@ class V2ce3d(nn.Module):
         return out
 
     @staticmethod
-    def _split_buffer(cout, cin, k3, dev, up_c0=0):
+    def _split_buffer(cout, cin, k3, dev, up_c0=0, wt=False):
         """fp16 hi/lo planes + the {max |w|, pre-scale} tail of v2ce_pack_weights_f16x2; up_c0 > 0: followed by the
-        phase-folded region of the first up_c0 input channels (v2ce_pack_weights_f16x2_up)."""
+        phase-folded region of the first up_c0 input channels (v2ce_pack_weights_f16x2_up); wt: the Winograd-T planes of
+        v2ce_pack_weights_f16x2_wt instead (36 tap slots)."""
+        if wt:
+            buf = torch.empty(hip.lib().v2ce_pack_weights_f16x2_wt_bytes(cout, cin) // 2, dtype=torch.float16, device=dev)
+            buf.wt = True
+            return buf
         if up_c0:
             buf = torch.empty(hip.lib().v2ce_pack_weights_f16x2_up_bytes(cout, up_c0, cin - up_c0) // 2, dtype=torch.float16,
                               device=dev)
@@ -400,6 +411,11 @@ class V2ce3d(nn.Module):
         up2 = (split and hmap is not None and x1 is not None and getattr(w_packed, "up_c0", 0) == x0.shape[2] * 16 and ksize == 3
                and stride == 1 and pred is None and tail is None and residual is None
                and H0 == (Hin + 1) // 2 and W0 == (Win + 1) // 2 and _nearest_is_half(H0, Hin) and _nearest_is_half(W0, Win))
+        # Winograd F(2,3) along T (v2ce_conv3d_fwd_wt): a one-source stride-1 3x3x3 conv whose weights were packed transformed
+        wt = split and getattr(w_packed, "wt", False)
+        if wt:
+            assert ksize == 3 and stride == 1 and x1 is None and hmap is None and pred is None and tail is None and sc is None, \
+                "Winograd-T weights drive only the plain one-source 3x3x3 stride-1 launch"
         C1 = 0 if x1 is None else x1.shape[2] * (16 if getattr(x1, "c16", False) else 1)
         Winp = Win if x1 is None else x1.shape[4]
         assert x1 is None or getattr(x1, "lw", Winp) == Win
@@ -431,7 +447,12 @@ class V2ce3d(nn.Module):
         if prof is not None:       # HIP events on the launch stream (torch's current stream)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        if up2:
+        if wt:
+            hip.check(hip.lib().v2ce_conv3d_fwd_wt(ctypes.byref(d), x0.data_ptr(), w_packed.data_ptr(), scale.data_ptr(),
+                                                   shift.data_ptr(), hip.ptr(residual), y.data_ptr(), hip.ptr(a0), hip.ptr(ay),
+                                                   hip.stream_ptr(x0.device)),
+                      "v2ce_conv3d_fwd_wt")
+        elif up2:
             y_sc = None
             if sc is not None:
                 y_sc = torch.empty_like(y)
@@ -501,11 +522,13 @@ class V2ce3d(nn.Module):
                 flops += 2.0 * B * T * Hout * Wout * cout * (C0 + C1)
             if tail is not None:
                 flops += 2.0 * B * T * Hout * Wout * cout * 16 * (tail[0].shape[2] + (0 if tail[1] is None else tail[1].shape[2]))
-            name = hip.conv_up2_variant(d, sc is not None) if up2 else \
+            name = hip.conv_wt_variant(d, residual is not None) if wt else hip.conv_up2_variant(d, sc is not None) if up2 else \
                 hip.conv_variant(d, hmap is not None, (1 if pred is not None else (2 if sc is not None else (3 if tail is not None else 0))) +
                                  (4 if residual is not None else 0))
             # (flops = the ALGORITHMIC count of the reference's convolution; a phase-folded launch executes fewer: `executed`)
             executed = flops - (2.0 * B * T * Hout * Wout * cout * C0 * 15 if up2 else 0.0)
+            if wt:          # four transformed 3x3 convolutions per pair of time steps instead of six tap rows
+                executed = 2.0 * B * ((T + 1) // 2) * Hout * Wout * cout * C0 * 36
             prof.append((name, flops, e0, e1, executed))
         if sc is not None:
             return y, y_sc
