@@ -465,6 +465,9 @@ typedef struct {
     int32_t rows, cols, k3;
     int32_t up_c0;        /* 0, or: `packed` is a v2ce_pack_weights_f16x2_up buffer (decoder conv1, v2ce_conv3d_fwd_up2) whose first
                            * up_c0 input channels -- the nearest-upsampled source -- are also packed phase-folded */
+    int32_t wt;           /* 1: `packed` is a v2ce_pack_weights_f16x2_wt buffer instead (Winograd-T planes of w_bar / sigma, k3 = 27,
+                           * up_c0 = 0); 0: the plain planes */
+    int32_t reserved;     /* 0 */
 } v2ce_sn_layer;
 size_t v2ce_sn_batch_workspace_bytes(const v2ce_sn_layer *layers, int n);
 int v2ce_sn_update_batch(const v2ce_sn_layer *layers, int n, void *workspace, size_t workspace_bytes,

@@ -27,6 +27,10 @@ struct ConvParams {
     int nT, nH, nW;       // boxes per dimension
     int HT, HH, HWd;      // halo box
     int plane;            // HT*HH*HWd  (LDS stride between channels)
+    int flat;             // > 0 (conv3d_wt.hip): a tile's positions are a RANGE of `flat` consecutive positions of the row-major
+                          // Hout x Wout plane (per time block) instead of a TH x TW rectangle -- planes like 17 x 22 split into three
+                          // ranges of 125 where rectangles of <= 128 positions need four; nH = 1, nW = ranges per plane, TW = Wout,
+                          // the halo box = the range's rows (+-1) x (Wout + 2)
     int n_co_tiles;
     int n_pos;            // TT*TH*TW
     int n_spatial;        // B*nT*nH*nW

@@ -29,6 +29,7 @@
 #include <map>
 #include <mutex>
 #include <tuple>
+#include <vector>
 
 namespace v2ce {
 namespace {
@@ -43,9 +44,18 @@ constexpr int kWtTaps = 36;              // 4 transform slots x 9 (dh, dw) taps
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #endif
 
+#ifdef V2CE_STAMP
+#define TICK() __builtin_amdgcn_s_memtime()
+#define ACC_T(var_, t0_) var_ += TICK() - (t0_)
+#else
+#define TICK() 0ull
+#define ACC_T(var_, t0_) do {} while (0)
+#endif
+
 template <int CO_FR, int PO_FR, int RES>
 __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    [[maybe_unused]] unsigned long long t_all = TICK(), t_bar = 0, t_epi = 0, t_xbar = 0, t_cvt = 0;
     static_assert(PO_FR == 4, "the output transform hands position fragment f to consumer wave f");
     constexpr int CK = 16, NA = 3, CO_TILE = CO_FR * 32, chs = kWtChs;
     constexpr int NX = 2 * CO_FR;                                    // extra barriers per tile (output transform)
@@ -56,19 +66,38 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
     const int CG = P.Cin / CK;
     const long long wplane = (long long)kWtTaps * CG * P.Cout * 16;  // halves per plane
 
-    struct TileId { int b, co_t, t0, h0, w0; };
+    struct TileId { int b, co_t, t0, h0, w0, s0; };
     auto decode = [&](int vb, TileId &T) -> bool {                   // (the direct kernel's walk: conv3d.hip)
         const int xcd = vb & 7, q = vb >> 3;
-        T.co_t = q % P.n_co_tiles;
-        const int sp = q / P.n_co_tiles;
+        // xcd_remap 1: all channel tiles of a box back to back (the XCD's L2 keeps the box's input); 2: the XCD's boxes back to
+        // back per channel tile (its L2 keeps that tile's weights: deep layers, whose weights are larger than their activations)
+        T.co_t = P.xcd_remap == 2 ? q / P.per_xcd : q % P.n_co_tiles;
+        const int sp = P.xcd_remap == 2 ? q - T.co_t * P.per_xcd : q / P.n_co_tiles;
         int bid = xcd * P.per_xcd + sp;
         if (sp >= P.per_xcd || bid >= P.n_spatial) return false;
         const int iw = bid % P.nW;            bid /= P.nW;
         const int ih = bid % P.nH;            bid /= P.nH;
         const int it = bid % P.nT;            bid /= P.nT;
         T.b = bid;
-        T.t0 = it * P.TT; T.h0 = ih * P.TH; T.w0 = iw * P.TW;
+        T.t0 = it * P.TT; T.h0 = ih * P.TH; T.w0 = iw * P.TW; T.s0 = 0;
+        if (P.flat) { T.s0 = iw * P.flat; T.h0 = T.s0 / P.Wout; T.w0 = 0; }     // a range of the plane: its first row, all columns
         return true;
+    };
+    // pair-position m of a tile -> (pair, row, column) relative to the tile's origin (t0, h0, w0); false: not an output
+    auto pos_of = [&](int m, const TileId &T, int &pp, int &th, int &tw) -> bool {
+        if (P.flat) {
+            pp = m / P.flat;
+            const int s = T.s0 + (m - pp * P.flat);
+            const int h = s / P.Wout;
+            th = h - T.h0;
+            tw = s - h * P.Wout;
+            return m < P.n_pos && s < P.Hout * P.Wout;
+        }
+        pp = m / (P.TH * P.TW);
+        const int rem = m - pp * (P.TH * P.TW);
+        th = rem / P.TW;
+        tw = rem - th * P.TW;
+        return m < P.n_pos;
     };
     auto next_tile = [&](int &vb, TileId &T) -> bool {
         for (; vb < P.total_blocks; vb += (int)gridDim.x)
@@ -156,6 +185,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
         auto convert = [&](const float (&R)[4][CK]) {
             f16x8 *qb = pieces + (gc & 1) * 4 * chs;
             if (!wave_on) return;
+            [[maybe_unused]] const unsigned long long tcv = TICK();
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -181,6 +211,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
                     qb[(2 + hg) * chs + j * kWtSlot + ptid] = __builtin_bit_cast(f16x8, pl);
                 }
             }
+            ACC_T(t_cvt, tcv);
         };
         bool moreC = true;
         auto advance = [&]() {
@@ -193,8 +224,10 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
             }
         };
         auto tile_rendezvous = [&]() {                                // the consumers' output transform of the tile before this one
+            [[maybe_unused]] const unsigned long long tb = TICK();
 #pragma unroll
             for (int k = 0; k < NX; ++k) lds_barrier();
+            ACC_T(t_xbar, tb);
         };
         load_next(R0);
         load_next(R1);
@@ -202,16 +235,26 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
             convert(R0);
             load_next(R0);
             if (cgC == 0 && gc != 0) tile_rendezvous();
+            { [[maybe_unused]] const unsigned long long tb = TICK();
             __syncthreads();                                          // barrier gc: pieces[gc & 1] ready
+            ACC_T(t_bar, tb); }
             advance();
             if (!moreC) break;
             convert(R1);
             load_next(R1);
             if (cgC == 0 && gc != 0) tile_rendezvous();
+            { [[maybe_unused]] const unsigned long long tb = TICK();
             __syncthreads();
+            ACC_T(t_bar, tb); }
             advance();
         }
         tile_rendezvous();                                            // the last tile's
+#ifdef V2CE_STAMP
+        if (lane == 0 && wave == 4) {
+            unsigned long long *o = P.stamps + ((long long)blockIdx.x * 2 + 1) * 8;
+            o[0] = TICK() - t_all; o[1] = t_bar; o[2] = t_xbar; o[3] = t_cvt;
+        }
+#endif
         return;
     }
 
@@ -243,13 +286,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
         for (int f = 0; f < PO_FR; ++f) {
             const int m = f * 32 + l32;                               // pair-position (p, h, w) of the box
             bhb[f] = half * chs + wave * kWtSlot;
-            if (m < P.n_pos) {
-                const int pp = m / (P.TH * P.TW);
-                const int rem = m - pp * (P.TH * P.TW);
-                const int th = rem / P.TW;
-                const int tw = rem - th * P.TW;
-                bhb[f] += (pp * P.HH + th) * P.HWd + tw;
-            }
+            int pp, th, tw;
+            if (pos_of(m, T, pp, th, tw)) bhb[f] += (pp * P.HH + th) * P.HWd + tw;
         }
         if (T.co_t != ring_co_t) {                                    // uniform: (re)load the ring for this channel tile
             ring_co_t = T.co_t;
@@ -276,7 +314,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
             const f16x8 *qb = pieces + (gc & 1) * 4 * chs;
             const int wc = slot_off + cg * cg_stride;
             const int wn = cg + 1 < CG ? wc + cg_stride : slot_off;   // last chunk: chunk 0 again (the next tile's start)
+            { [[maybe_unused]] const unsigned long long tb = TICK();
             __syncthreads();                                          // barrier gc: pieces[gc & 1] ready
+            ACC_T(t_bar, tb); }
 #pragma unroll
             for (int f = 0; f < PO_FR; ++f) {
                 bh[f] = qb[bhb[f]];
@@ -311,15 +351,13 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
         }
 
         // ---- output transform + epilogue.  This wave stores position fragment f = wave: outputs t = 2p, 2p + 1.
+        [[maybe_unused]] const unsigned long long te = TICK();
         int poff[2];
         {
             const int m = wave * 32 + l32;
             poff[0] = poff[1] = -1;
-            if (m < P.n_pos) {
-                const int pp = m / (P.TH * P.TW);
-                const int rem = m - pp * (P.TH * P.TW);
-                const int th = rem / P.TW;
-                const int tw = rem - th * P.TW;
+            int pp, th, tw;
+            if (pos_of(m, T, pp, th, tw)) {
                 const int t = T.t0 + 2 * pp, h = T.h0 + th, w = T.w0 + tw;
                 if (h < P.Hout && w < P.Wout) {
                     if (t < P.T) poff[0] = 4 * ((t * P.Cout) * (P.Hout * P.Woutp)) + 64 * (h * P.Woutp + w);
@@ -328,9 +366,37 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
             }
         }
         typedef float f32x4t __attribute__((ext_vector_type(4)));
+        typedef unsigned u32x4t __attribute__((ext_vector_type(4)));
         f32x4t *xch = reinterpret_cast<f32x4t *>(pieces + ((gc - 1) & 1) * 4 * chs);   // the buffer of the tile's last chunk
+        // The epilogue proper is conv_epilogue's arithmetic (conv3d_dev.h: y = act(acc * scale * inv_scale + shift + residual), max |y|,
+        // 16-byte stores of the four channels a lane holds per r >> 2) with its loads -- residual, scale, shift -- issued BEFORE the
+        // accumulators go through LDS, so that their latency is covered by the exchange instead of following it.
+        const long long yseq = (long long)P.T * P.Cout * (P.Hout * P.Woutp);
+        const int gstride = P.Hout * P.Woutp * 64;                    // bytes between 16-channel groups of a time step
+        const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(P.y + T.b * yseq, 0, (int)(yseq * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(RES ? P.res + T.b * yseq : P.scale), 0,
+                                                                              RES ? (int)(yseq * 4) : 0, 0x00020000);
+        unsigned vo[2], vmask[2];
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            vo[o] = poff[o] >= 0 ? (unsigned)(poff[o] + 16 * half) : kOOB;
+            vmask[o] = poff[o] >= 0 ? 0x7fffffffu : 0u;
+        }
+        const float slope = act_slope(P.act);
+        unsigned ymax = 0u;
 #pragma unroll
         for (int q = 0; q < CO_FR; ++q) {
+            // channels co0 + 32 q + 8 r4 + 4 half + {0..3}: group (co0 / 16 + 2 q + (r4 >> 1)), bytes 32 (r4 & 1) + 16 half inside it
+            auto soff = [&](int r4) -> int { return (co0 / 16 + 2 * q + (r4 >> 1)) * gstride + 32 * (r4 & 1); };
+            f32x4t rv[2][4], scq[4], shq[4];
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+#pragma unroll
+                for (int o = 0; o < 2; ++o) {
+                    if constexpr (RES) rv[o][r4] = __builtin_bit_cast(f32x4t, __builtin_amdgcn_raw_buffer_load_b128(rs_r, vo[o], soff(r4), 0));
+                    else rv[o][r4] = f32x4t{0.0f, 0.0f, 0.0f, 0.0f};
+                }
+            }
             // (round q > 0: the previous round's reads are behind its second barrier)
 #pragma unroll
             for (int f = 0; f < PO_FR; ++f)
@@ -340,24 +406,59 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
                     v[0] = acc[q][f][4 * r4]; v[1] = acc[q][f][4 * r4 + 1]; v[2] = acc[q][f][4 * r4 + 2]; v[3] = acc[q][f][4 * r4 + 3];
                     xch[f * chs + wave * kWtSlot + r4 * 64 + lane] = v;
                 }
+            { [[maybe_unused]] const unsigned long long tb = TICK();
             lds_barrier();
-            f32x16 yy[1][2];
+            ACC_T(t_xbar, tb); }
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const f32x4t m0 = xch[wave * chs + 0 * kWtSlot + r4 * 64 + lane], m1 = xch[wave * chs + 1 * kWtSlot + r4 * 64 + lane];
-                const f32x4t m2 = xch[wave * chs + 2 * kWtSlot + r4 * 64 + lane], m3 = xch[wave * chs + 3 * kWtSlot + r4 * 64 + lane];
+            for (int r4 = 0; r4 < 4; ++r4) {                          // (cache hits after the first tiles; behind the barrier for the registers' sake)
+                scq[r4] = *reinterpret_cast<const f32x4t *>(P.scale + co0 + 32 * q + 8 * r4 + 4 * half);
+                shq[r4] = *reinterpret_cast<const f32x4t *>(P.shift + co0 + 32 * q + 8 * r4 + 4 * half);
+            }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    yy[0][0][4 * r4 + k] = (m0[k] + m1[k]) + m2[k];
-                    yy[0][1][4 * r4 + k] = (m1[k] - m2[k]) - m3[k];
+            for (int hp = 0; hp < 2; ++hp) {                          // two r4 per pass: 32 registers of transformed sums at a time
+                f32x4t mm[2][4];
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) mm[rr][jj] = xch[wave * chs + jj * kWtSlot + (2 * hp + rr) * 64 + lane];
+                if (hp == 1) {
+                    [[maybe_unused]] const unsigned long long tb = TICK();
+                    lds_barrier();                                    // reads done: the next round / the producers may write
+                    ACC_T(t_xbar, tb);
+                }
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    const int r4 = 2 * hp + rr;
+#pragma unroll
+                    for (int o = 0; o < 2; ++o) {
+                        f32x4t out;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float y = o == 0 ? (mm[rr][0][k] + mm[rr][1][k]) + mm[rr][2][k] : (mm[rr][1][k] - mm[rr][2][k]) - mm[rr][3][k];
+                            float v = y * (scq[r4][k] * inv_scale) + shq[r4][k];
+                            v += rv[o][r4][k];
+                            v = apply_act(v, slope);
+                            out[k] = v;
+                            const unsigned av = __builtin_bit_cast(unsigned, v) & vmask[o];
+                            ymax = av > ymax ? av : ymax;
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4t, out), rs_y, vo[o], soff(r4), 0);
+                        asm volatile("s_nop 1" : "+v"(out));          // (16-byte store data hazard: conv_epilogue)
+                    }
                 }
             }
-            lds_barrier();                                            // reads done: the next round / the producers may write
-            conv_epilogue<1, 2, true, false, RES, true>(P, yy, poff, co0 + 32 * q, half, T.b, inv_scale);
         }
+        if (P.y_absmax) absmax_commit(__builtin_bit_cast(float, ymax), P.y_absmax + T.b * P.amax_bs);
+        ACC_T(t_epi, te);
         vb += (int)gridDim.x;
         more = next_tile(vb, T);
     }
+#ifdef V2CE_STAMP
+    if (lane == 0 && wave == 0) {
+        unsigned long long *o = P.stamps + ((long long)blockIdx.x * 2 + 0) * 8;
+        o[0] = TICK() - t_all; o[1] = t_bar; o[2] = t_xbar; o[3] = t_epi; o[4] = (unsigned long long)gc;
+    }
+#endif
 #undef V2CE_LOAD_A
 #endif  // __HIP_DEVICE_COMPILE__
 }
@@ -456,13 +557,13 @@ int wt_pack_launch(const WtBatch &B, int pass, hipStream_t st) {
 thread_local char *g_wt_name_out = nullptr;
 thread_local size_t g_wt_name_cap = 0;
 
-struct WtBox { int pp, th, tw; };
+struct WtBox { int pp, th, tw, flat; };     // flat > 0: ranges of `flat` positions of the plane instead of th x tw rectangles
 
 // The box (pairs x rows x columns) of a tile: at most PO_FR * 32 pair-positions, at most 256 halo elements (one per producer
 // lane); fewest rounds of the persistent grid first, then the least halo per output.  V2CE_WT_BOX=pp,th,tw forces one.
 WtBox choose_wt_box(int B, int T, int H, int W, int n_co, int n_cu, int pos_tile) {
     if (const char *e = getenv("V2CE_WT_BOX")) {
-        WtBox b{};
+        WtBox b{0, 0, 0, 0};
         if (sscanf(e, "%d,%d,%d", &b.pp, &b.th, &b.tw) == 3 && b.pp > 0 && b.th > 0 && b.tw > 0 && b.pp * b.th * b.tw <= pos_tile &&
             b.pp * (b.th + 2) * (b.tw + 2) <= kWtSlot)
             return b;
@@ -474,8 +575,23 @@ WtBox choose_wt_box(int B, int T, int H, int W, int n_co, int n_cu, int pos_tile
     auto it = cache.find(key);
     if (it != cache.end()) return it->second;
     const int pairs = (T + 1) / 2;
-    WtBox best{0, 0, 0};
+    WtBox best{0, 0, 0, 0};
     double best_cost = 1e30;
+    static const int flat_mode = [] { const char *e = getenv("V2CE_WT_FLAT"); return e ? atoi(e) : 1; }();
+    // ranges of the row-major plane (narrow planes): n positions span at most (W - 1 + n - 1) / W + 1 rows of W + 2 halo columns
+    for (int pp = 1; flat_mode && pp <= pairs && pp <= 16; ++pp) {
+        const int n_max = pos_tile / pp;
+        if (n_max < 1) break;
+        const int nR = (H * W + n_max - 1) / n_max, n = (H * W + nR - 1) / nR;
+        const int rows = std::min(H, (W - 1 + n - 1) / W + 1);
+        if (pp * (rows + 2) * (W + 2) > kWtSlot) continue;
+        const long long nsp = (long long)B * ((pairs + pp - 1) / pp) * nR;
+        const long long blocks = 8 * ((nsp + 7) / 8) * n_co;
+        const double rounds = (double)((blocks + n_cu - 1) / n_cu);
+        const double halo = (double)pp * (rows + 2) * (W + 2) / kWtSlot;
+        const double cost = rounds * (1.0 + 0.15 * halo) + 1e-3 * (double)blocks / n_cu;
+        if (cost < best_cost) { best_cost = cost; best = WtBox{pp, rows, W, n}; }
+    }
     for (int pp = 1; pp <= pairs && pp <= 16; ++pp)
         for (int th = 1; th <= H && th <= 64; ++th)
             for (int tw = 1; tw <= W && tw <= 128; ++tw) {
@@ -486,7 +602,7 @@ WtBox choose_wt_box(int B, int T, int H, int W, int n_co, int n_cu, int pos_tile
                 // a tile costs its MFMA work (fixed) plus what its producers gather: 4 loads per halo element
                 const double halo = (double)pp * (th + 2) * (tw + 2) / kWtSlot;
                 const double cost = rounds * (1.0 + 0.15 * halo) + 1e-3 * (double)blocks / n_cu;
-                if (cost < best_cost) { best_cost = cost; best = WtBox{pp, th, tw}; }
+                if (cost < best_cost - 1e-9) { best_cost = cost; best = WtBox{pp, th, tw, 0}; }
             }
     cache.emplace(key, best);
     return best;
@@ -505,18 +621,25 @@ int launch_wt(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream) {
         return n < 8 ? 8 : (n / 8) * 8;
     }();
     P.n_co_tiles = (d.Cout + CO_TILE - 1) / CO_TILE;
-    WtBox bx{d.tile_t / 2, d.tile_h, d.tile_w};
+    WtBox bx{d.tile_t / 2, d.tile_h, d.tile_w, 0};
     if (bx.pp <= 0 || bx.th <= 0 || bx.tw <= 0) bx = choose_wt_box(d.B, d.T, d.Hout, d.Wout, P.n_co_tiles, n_cu, POS_TILE);
-    V2CE_REQUIRE(bx.pp > 0 && bx.pp * bx.th * bx.tw <= POS_TILE && bx.pp * (bx.th + 2) * (bx.tw + 2) <= kWtSlot, V2CE_ERR_UNSUPPORTED,
-                 "v2ce_conv3d_fwd_wt: no box fits");
+    V2CE_REQUIRE(bx.pp > 0 && bx.th > 0 && bx.tw > 0, V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd_wt: no box fits");
     P.TT = 2 * bx.pp; P.TH = bx.th; P.TW = bx.tw;
-    P.n_pos = bx.pp * bx.th * bx.tw;                       // pair-positions
+    P.flat = bx.flat;
+    P.n_pos = bx.flat ? bx.pp * bx.flat : bx.pp * bx.th * bx.tw;      // pair-positions
     P.HT = bx.pp; P.HH = bx.th + 2; P.HWd = bx.tw + 2;
     P.plane = P.HT * P.HH * P.HWd;                         // halo elements (p, hh, hw)
     P.nT = (d.T + P.TT - 1) / P.TT; P.nH = (d.Hout + bx.th - 1) / bx.th; P.nW = (d.Wout + bx.tw - 1) / bx.tw;
+    if (bx.flat) { P.nH = 1; P.nW = (d.Hout * d.Wout + bx.flat - 1) / bx.flat; }
+    V2CE_REQUIRE(P.n_pos <= POS_TILE && P.plane <= kWtSlot, V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd_wt: tile does not fit");
     P.n_spatial = d.B * P.nT * P.nH * P.nW;
-    P.xcd_remap = 1;
     P.per_xcd = (P.n_spatial + 7) / 8;
+    {
+        // weights of a channel tile vs the input of the XCD's boxes: walk the larger one once
+        static const int force = [] { const char *e = getenv("V2CE_WT_ORDER"); return e ? atoi(e) : 0; }();
+        const double w_bytes = (double)CO_TILE * P.Cin * kWtTaps * 4, x_bytes = (double)P.per_xcd * P.n_pos * 2 * P.Cin * 4;
+        P.xcd_remap = force ? force : (P.n_co_tiles > 1 && w_bytes * P.n_co_tiles > x_bytes ? 2 : 1);
+    }
     const long long blocks = (long long)8 * P.per_xcd * P.n_co_tiles;
     P.total_blocks = (int)blocks;
     const size_t lds = (size_t)kWtChs * (2 * 4 * 16);      // 128 KB
@@ -527,11 +650,34 @@ int launch_wt(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream) {
     }();
     (void)once;
     if (getenv("V2CE_WT_VERBOSE"))
-        fprintf(stderr, "[wt<%d,%d,%d> %dx%dx%dx%d C %d -> %d] box %d pairs x %d x %d (%d halo elements), %lld tiles\n", CO_FR, PO_FR, RES, d.B, d.T,
-                d.Hout, d.Wout, P.Cin, P.Cout, bx.pp, bx.th, bx.tw, P.plane, blocks);
+        fprintf(stderr, "[wt<%d,%d,%d> %dx%dx%dx%d C %d -> %d] box %d pairs x %d x %d%s (%d of %d positions, %d halo elements), %lld tiles\n", CO_FR, PO_FR, RES, d.B, d.T,
+                d.Hout, d.Wout, P.Cin, P.Cout, bx.pp, bx.th, bx.tw, bx.flat ? " rows: flat ranges" : "", P.n_pos, POS_TILE, P.plane, blocks);
     const unsigned grid = (unsigned)(blocks > n_cu ? n_cu : blocks);
+#ifdef V2CE_STAMP
+    V2CE_HIP_CHECK(hipMalloc(&P.stamps, (size_t)grid * 16 * sizeof(unsigned long long)));
+    V2CE_HIP_CHECK(hipMemset(P.stamps, 0, (size_t)grid * 16 * sizeof(unsigned long long)));
+#endif
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, P);
     V2CE_HIP_CHECK(hipGetLastError());
+#ifdef V2CE_STAMP
+    {
+        std::vector<unsigned long long> h((size_t)grid * 16);
+        V2CE_HIP_CHECK(hipDeviceSynchronize());
+        V2CE_HIP_CHECK(hipMemcpy(h.data(), P.stamps, h.size() * 8, hipMemcpyDeviceToHost));
+        V2CE_HIP_CHECK(hipFree(P.stamps));
+        auto mean = [&](int role, int a) {
+            double sm = 0;
+            for (unsigned k = 0; k < grid; ++k) sm += (double)h[((size_t)k * 2 + role) * 8 + a];
+            return sm / grid;
+        };
+        const double tot = mean(0, 0), chunks = mean(0, 4), tiles = chunks / (P.Cin / 16);
+        fprintf(stderr, "[stamp wt<%d,%d,%d> C %d -> %d %dx%d box %dx%dx%d] per workgroup: %.1f tiles, %.0f chunks, %.0f cycles (s_memtime, 100 MHz) | consumer: chunk barriers %.1f %%, "
+                "epilogue %.1f %% (its barriers %.1f %%), main loop %.1f %% = %.1f ticks per chunk | producer: chunk barriers %.1f %%, rendezvous %.1f %%, convert %.1f %%\n",
+                CO_FR, PO_FR, RES, P.Cin, P.Cout, d.Hout, d.Wout, bx.pp, bx.th, bx.tw, tiles, chunks, tot, 100 * mean(0, 1) / tot, 100 * mean(0, 3) / tot,
+                100 * mean(0, 2) / tot, 100 * (tot - mean(0, 1) - mean(0, 3)) / tot, (tot - mean(0, 1) - mean(0, 3)) / chunks, 100 * mean(1, 1) / mean(1, 0),
+                100 * mean(1, 2) / mean(1, 0), 100 * mean(1, 3) / mean(1, 0));
+    }
+#endif
     return V2CE_OK;
 }
 

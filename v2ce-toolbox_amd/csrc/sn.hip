@@ -113,6 +113,7 @@ struct SnLayer {
     float *t, *s, *rowmax, *sigma;
     int rows, cols, k3, cin;
     int up_c0;                  // > 0: `packed` is a v2ce_pack_weights_f16x2_up buffer whose first up_c0 input channels are also folded
+    int wt;                     // 1: `packed` is a v2ce_pack_weights_f16x2_wt buffer (36 tap slots; written by conv3d_wt.hip's pack passes)
 };
 struct SnBatch {
     SnLayer L[kMaxBatch];
@@ -223,6 +224,11 @@ __global__ __launch_bounds__(1024) void sn_batch_finalize_kernel(SnBatch B) {
         for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = fmaxf(m, mxs[i]);
         const float sg = (float)dot;
         P.sigma[0] = sg;
+        if (P.wt) {                                            // Winograd-T planes: max |G| comes from the pack's first pass
+            float *tail = reinterpret_cast<float *>(P.packed + 2ll * P.rows * P.cin * 36);
+            tail[0] = 0.0f; tail[1] = 0.0f; tail[2] = 0.0f; tail[3] = 0.0f;
+            return;
+        }
         float *tail = reinterpret_cast<float *>(P.packed + 2ll * P.rows * P.cols);
         const float am = fabsf(m / sg);                        // = max |w / sigma| of weights_absmax_kernel
         tail[0] = am;
@@ -347,6 +353,9 @@ extern "C" int v2ce_sn_update_batch(const v2ce_sn_layer *layers, int n, void *wo
         o.w = in.w_bar; o.u = in.u; o.v = in.v; o.packed = static_cast<_Float16 *>(in.packed);
         o.rows = in.rows; o.cols = in.cols; o.k3 = in.k3; o.cin = in.cols / in.k3;
         o.up_c0 = in.up_c0;
+        o.wt = in.wt;
+        V2CE_REQUIRE(in.wt == 0 || (in.wt == 1 && in.k3 == 27 && in.up_c0 == 0), V2CE_ERR_BAD_ARG,
+                     "v2ce_sn_update_batch: layer %d: wt must be 0 or 1, on a 3x3x3 layer without up_c0", l);
         V2CE_REQUIRE(in.up_c0 == 0 || (in.k3 == 27 && in.up_c0 > 0 && in.up_c0 % 16 == 0 && in.up_c0 < o.cin), V2CE_ERR_BAD_ARG,
                      "v2ce_sn_update_batch: layer %d: up_c0 must be a multiple of 16 below Cin of a 3x3x3 layer", l);
         o.part = reinterpret_cast<double *>(ws);
@@ -359,7 +368,8 @@ extern "C" int v2ce_sn_update_batch(const v2ce_sn_layer *layers, int n, void *wo
         B.row_blk[l + 1] = B.row_blk[l] + in.rows;
         V2CE_REQUIRE(in.rows % 32 == 0 && in.k3 * 2056 <= 64 * 1024, V2CE_ERR_UNSUPPORTED,
                      "v2ce_sn_update_batch: layer %d: rows %% 32 != 0 or k3 too large", l);
-        B.el_blk[l + 1] = B.el_blk[l] + (in.rows / 32) * (in.cols / in.k3 / 16);        // pack: (32 output channels, 16-channel group)
+        // pack: (32 output channels, 16-channel group); the Winograd-T layers are packed by conv3d_wt.hip
+        B.el_blk[l + 1] = B.el_blk[l] + (in.wt ? 0 : (in.rows / 32) * (in.cols / in.k3 / 16));
     }
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(sn_batch_wt_u_kernel, dim3(B.col_blk[n], kRowChunks), dim3(256), 0, st, B);
@@ -370,13 +380,28 @@ extern "C" int v2ce_sn_update_batch(const v2ce_sn_layer *layers, int n, void *wo
     // decoder conv1 layers (v2ce_conv3d_fwd_up2): the folded sums of W / sigma join the maximum the common pre-scale is derived from
     for (int l = 0; l < n; ++l)
         if (B.L[l].up_c0) v2ce_up_fold_absmax(B.L[l].w, B.L[l].rows, B.L[l].cin, B.L[l].up_c0, B.L[l].sigma, B.L[l].packed, st);
+    // Winograd-T layers (v2ce_conv3d_fwd_wt): max |G| of W / sigma, then the planes -- two launches for all of them
+    const float *wt_w[kMaxBatch], *wt_sigma[kMaxBatch];
+    void *wt_packed[kMaxBatch];
+    int wt_rows[kMaxBatch], wt_cin[kMaxBatch], n_wt = 0;
+    for (int l = 0; l < n; ++l)
+        if (B.L[l].wt) {
+            wt_w[n_wt] = B.L[l].w; wt_sigma[n_wt] = B.L[l].sigma; wt_packed[n_wt] = B.L[l].packed;
+            wt_rows[n_wt] = B.L[l].rows; wt_cin[n_wt] = B.L[l].cin;
+            ++n_wt;
+        }
+    for (int pass = 0; pass < 2 && n_wt; ++pass) {
+        const int rc = v2ce_wt_pack_batch(wt_w, wt_sigma, wt_packed, wt_rows, wt_cin, n_wt, pass, st);
+        if (rc != V2CE_OK) return rc;
+    }
     int k3max = 1;
     bool all27 = true;
     for (int l = 0; l < n; ++l) {
         k3max = layers[l].k3 > k3max ? layers[l].k3 : k3max;
         all27 = all27 && layers[l].k3 == 27;
     }
-    if (all27) hipLaunchKernelGGL(sn_batch_pack_kernel<27>, dim3(B.el_blk[n]), dim3(256), (size_t)27 * 2056, st, B);
+    if (B.el_blk[n] == 0) {}                               // (every layer is a Winograd-T layer)
+    else if (all27) hipLaunchKernelGGL(sn_batch_pack_kernel<27>, dim3(B.el_blk[n]), dim3(256), (size_t)27 * 2056, st, B);
     else hipLaunchKernelGGL(sn_batch_pack_kernel<0>, dim3(B.el_blk[n]), dim3(256), (size_t)k3max * 2056, st, B);
     for (int l = 0; l < n; ++l)
         if (B.L[l].up_c0) v2ce_up_fold_pack(B.L[l].w, B.L[l].rows, B.L[l].cin, B.L[l].up_c0, B.L[l].sigma, B.L[l].packed, st);

@@ -51,7 +51,8 @@ class ConvDesc(ctypes.Structure):
 class SnLayer(ctypes.Structure):
     """``v2ce_sn_layer`` (include/v2ce_hip.h): one spectral-norm layer of v2ce_sn_update_batch."""
     _fields_ = [("w_bar", ctypes.c_void_p), ("u", ctypes.c_void_p), ("v", ctypes.c_void_p), ("packed", ctypes.c_void_p),
-                ("rows", ctypes.c_int32), ("cols", ctypes.c_int32), ("k3", ctypes.c_int32), ("up_c0", ctypes.c_int32)]
+                ("rows", ctypes.c_int32), ("cols", ctypes.c_int32), ("k3", ctypes.c_int32), ("up_c0", ctypes.c_int32),
+                ("wt", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class LdatiOptions(ctypes.Structure):

@@ -276,21 +276,31 @@ class V2ce3d(nn.Module):
                     # contribution); a BatchNorm scale of (almost) zero in bn2 cannot be divided out: that block keeps its own launch
                     s2, sh2 = d["bn2"]
                     sd, shd = d["down_bn"]
-                    if float(s2.abs().min()) > 1e-20 and bool(torch.isfinite(sd / s2).all()):
+                    # (V2CE_WT_UNFOLD=1: keep the shortcut's own launch so that conv2 can run on the Winograd-T kernel)
+                    unfold = self._winograd() and blk.cout % 64 == 0 and os.environ.get("V2CE_WT_UNFOLD", "0") == "1"
+                    if not unfold and float(s2.abs().min()) > 1e-20 and bool(torch.isfinite(sd / s2).all()):
                         wf = (blk.downsample[0].weight * (sd / s2).view(-1, 1, 1, 1, 1)).contiguous()
                         d["fold"] = (self._pack(wf, split=True), s2, (sh2 + shd).contiguous())
+                # Winograd F(2,3) along T (v2ce_conv3d_fwd_wt) where a conv is a plain one-source stride-1 3x3x3 launch with
+                # >= 64 output channels: conv2 of a block whose shortcut does not ride in its K loop, conv1 of the middle blocks
+                wt = {"conv1": self._winograd() and splits["conv1"] and name == "res" and blk.stride_hw == 1 and blk.cout % 64 == 0
+                      and not self._fuse_shortcut(blk),
+                      "conv2": self._winograd() and splits["conv2"] and blk.cout % 64 == 0 and d["fold"] is None}
+                d["wt"] = wt
                 if blk.sn:
                     for cn in ("conv1", "conv2"):
                         m = getattr(blk, cn).module
                         rows, cols = m.weight_bar.shape[0], m.weight_bar[0].numel()
                         # a decoder's conv1 reads upsample(x) ++ skip: its first 2/3 input channels are packed phase-folded too
                         up_c0 = blk.cin * 2 // 3 if (name == "dec" and cn == "conv1" and self._upfold()) else 0
-                        d[cn + "_w"] = (self._split_buffer(rows, m.weight_bar.shape[1], 27, dev, up_c0=up_c0)
+                        d[cn + "_w"] = (self._split_buffer(rows, m.weight_bar.shape[1], 27, dev, up_c0=up_c0, wt=wt[cn])
                                         if splits[cn] else torch.empty(rows * cols, dtype=torch.float32, device=dev))
                         sn_ws = max(sn_ws, hip.lib().v2ce_sn_workspace_bytes(rows, cols))
                 else:
-                    d["conv1_w"] = self._pack(blk.conv1.weight.contiguous(), split=splits["conv1"])
-                    d["conv2_w"] = self._pack(blk.conv2.weight.contiguous(), split=splits["conv2"])
+                    for cn in ("conv1", "conv2"):
+                        w = getattr(blk, cn).weight.contiguous()
+                        out = self._split_buffer(w.shape[0], w.shape[1], 27, dev, wt=True) if wt[cn] else None
+                        d[cn + "_w"] = self._pack(w, out=out, split=splits[cn])
                 P[f"{name}{i}"] = d
         P["sn_ws"] = torch.empty(max(sn_ws, 16), dtype=torch.uint8, device=dev)
         P["sigma"] = torch.empty(1, dtype=torch.float32, device=dev)
@@ -305,6 +315,7 @@ class V2ce3d(nn.Module):
                 e.w_bar, e.u, e.v, e.packed = m.weight_bar.data_ptr(), m.weight_u.data_ptr(), m.weight_v.data_ptr(), out.data_ptr()
                 e.rows, e.cols, e.k3 = m.weight_bar.shape[0], m.weight_bar[0].numel(), 27
                 e.up_c0 = getattr(out, "up_c0", 0)
+                e.wt = 1 if getattr(out, "wt", False) else 0
             nb = hip.lib().v2ce_sn_batch_workspace_bytes(arr, len(inners))
             if nb:
                 P["sn_batch"] = (arr, len(inners), torch.empty(nb, dtype=torch.uint8, device=dev))
@@ -326,6 +337,11 @@ class V2ce3d(nn.Module):
         if self.precision != "f16x2":
             return False
         return ksize == 3 or stride == 2 or cout >= 64
+
+    def _winograd(self) -> bool:
+        """Winograd F(2,3) along T for the plain stride-1 3x3x3 convs (v2ce_conv3d_fwd_wt: 2/3 of the multiplies;
+        V2CE_WINOGRAD=0: the direct kernel, for A/B runs)."""
+        return self.precision == "f16x2" and os.environ.get("V2CE_WINOGRAD", "1") != "0"
 
     def _upfold(self) -> bool:
         """Phase-folded upsampled channels in the decoders' conv1 (v2ce_conv3d_fwd_up2; V2CE_UPFOLD=0: the mapped gather
