@@ -379,7 +379,16 @@ size_t v2ce_pack_weights_f16x2_wt_bytes(int Cout, int Cin);
 int v2ce_pack_weights_f16x2_wt(const float *w, int Cout, int Cin, const float *sigma, void *w_wt, v2ce_stream_t stream);
 int v2ce_conv3d_fwd_wt(const v2ce_conv3d_desc *desc, const float *x, const void *w_wt, const float *scale, const float *shift,
                        const float *residual, float *y, const float *x_absmax, float *y_absmax, v2ce_stream_t stream);
-/* Name of the kernel instantiation v2ce_conv3d_fwd_wt would launch ("conv3d_wt_kernel<CO_FR,PO_FR,RES>"). */
+/* The same with the block's folded 1x1x1 shortcut in the launch's K loop -- the contract of v2ce_conv3d_fwd_tail (tail_desc,
+ * tx0 / tx1 / maps, tail_w = v2ce_pack_weights_f16x2 of the [Cout][tC0 + tC1][1] weights, range slots of the tail inputs), on the
+ * Winograd-T kernel: the tail's terms enter the transform domain split over the four slots (csrc/conv3d_wt.hip).  The tail's
+ * channel count must be a multiple of 64. */
+int v2ce_conv3d_fwd_wt_tail(const v2ce_conv3d_desc *desc, const float *x, const void *w_wt, const float *scale, const float *shift,
+                            float *y, const float *x_absmax, float *y_absmax, const v2ce_conv3d_desc *tail_desc, const float *tx0,
+                            const float *tx1, const int32_t *thmap, const int32_t *twmap, const void *tail_w,
+                            const float *tx0_absmax, const float *tx1_absmax, v2ce_stream_t stream);
+/* Name of the kernel instantiation v2ce_conv3d_fwd_wt[_tail] would launch ("conv3d_wt_kernel<CO_FR,PO_FR,RES,TAIL>");
+ * with_residual: 0 | 1 | 2 = the tail form. */
 int v2ce_conv3d_wt_variant(const v2ce_conv3d_desc *desc, int with_residual, char *name, size_t cap);
 
 /* Name of the kernel instantiation v2ce_conv3d_fwd would launch for desc ("conv3d_kernel<KS,S,

@@ -123,3 +123,57 @@ def test_wt_rejects_what_it_cannot_do():
     rc = hip.lib().v2ce_conv3d_fwd_wt(ctypes.byref(d), t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), None, t.data_ptr(),
                                       None, None, None)
     assert rc != 0 and b"Cout" in hip.lib().v2ce_last_error()
+
+
+@pytest.mark.parametrize("case", [
+    # Cmid (= Cout), tail C0, tail C1, tail stride, H, W, mapped low-res source, per-element slots, T
+    (64, 64, 0, 2, 19, 23, False, False, 3),      # strided shortcut from the block input
+    (64, 128, 64, 1, 20, 26, True, True, 3),      # decoder-like: shortcut reads upsample(x0) ++ skip (dec2's shape family), odd T
+    (128, 256, 128, 1, 9, 13, True, True, 4),     # dec1's family
+    (256, 512, 256, 1, 8, 11, True, False, 2),    # dec0's family: 768 tail channels over two sources
+    (256, 256, 0, 1, 17, 22, False, True, 16),    # res-block-like on the 17x22 planes (flat range tiles)
+])
+def test_conv3d_wt_folded_tail_vs_f64(case):
+    """v2ce_conv3d_fwd_wt_tail: relu(s2 (W2 * t + Wd' * x) + shift) from ONE accumulator set in the transform domain -- a residual
+    block's conv2 on the Winograd-T kernel with the 1x1x1 shortcut folded into its K loop -- against the two convolutions in f64
+    (same cases and bar as tests/test_gpu_unet.py::test_conv3d_folded_tail_vs_f64, incl. the 1000x magnitude gap both ways)."""
+    from oracle import unet as U
+    from v2ce_toolbox_amd import hip
+    from v2ce_toolbox_amd.v2ce_3d import V2ce3d
+    cm, c0, c1, ts, H, W, mapped, per_elem, T = case
+    B = 2
+    g = torch.Generator().manual_seed(cm + c0 + c1)
+    t_in = torch.randn(B, cm, T, H, W, generator=g)
+    Hx, Wx = (H * ts - (ts - 1), W * ts - (ts - 1)) if ts == 2 else (H, W)
+    lo = ((Hx + 1) // 2, (Wx + 1) // 2) if mapped else (Hx, Wx)
+    x0 = torch.randn(B, c0, T, *lo, generator=g) * (1000.0 if cm == 64 and ts == 1 else 1.0)
+    x1 = torch.randn(B, c1, T, Hx, Wx, generator=g) * 1000.0 if c1 and cm == 64 else (torch.randn(B, c1, T, Hx, Wx, generator=g) if c1 else None)
+    if cm == 256 and c1 == 0:
+        t_in = t_in * 300.0
+    w2 = torch.randn(cm, cm, 3, 3, 3, generator=g) * (2.0 / (cm * 27)) ** 0.5
+    wd = torch.randn(cm, c0 + c1, 1, 1, 1, generator=g) * (1.0 / (c0 + c1)) ** 0.5
+    s2, sh = torch.rand(cm, generator=g) + 0.5, torch.randn(cm, generator=g)
+    m = _model()
+    m._prep = {"absmax": torch.zeros((4, B, 2) if per_elem else (4, 2), device="cuda")}
+
+    def dev(x):
+        d = V2ce3d.to_c16(to_btchw(x).cuda())
+        d.absmax = (to_btchw(x).abs().amax(dim=(1, 2, 3, 4)).reshape(B, 1).repeat(1, 2).contiguous() if per_elem
+                    else x.abs().max().reshape(1)).cuda()
+        return d
+    m.profile = []
+    y = V2ce3d._conv(m, dev(t_in), None, _weights(m, w2, True), s2.cuda(), sh.cuda(), cm, 3, 1, hip.ACT_RELU, split=True, dense_out=True,
+                     tail=(dev(x0), None if x1 is None else dev(x1), (Hx, Wx) if mapped else None, ts,
+                           V2ce3d._pack(m, wd.cuda().contiguous(), split=True)))
+    torch.cuda.synchronize()
+    assert m.profile[0][0] == "conv3d_wt_kernel<2,4,0,1>", m.profile[0][0]
+    xs = U.upsample_nearest_hw(x0, (Hx, Wx)).double() if mapped else x0.double()
+    if x1 is not None:
+        xs = torch.cat([xs, x1.double()], dim=1)
+    acc = F.conv3d(t_in.double(), w2.double(), None, 1, 1) + F.conv3d(xs, wd.double(), None, (1, ts, ts), 0)
+    want = torch.relu(acc * s2.double().view(1, -1, 1, 1, 1) + sh.double().view(1, -1, 1, 1, 1)).numpy()
+    got = V2ce3d.to_planar(y).permute(0, 2, 1, 3, 4).cpu().numpy()
+    scale = max(1.0, float(np.abs(want).max()) / 4.0)
+    assert got.shape == want.shape
+    assert np.all(np.abs(got - want) <= TOL * scale + TOL * np.abs(want)), float(np.abs(got - want).max())
+    assert 0 < float(y.absmax.reshape(-1, 2)[:, 1].max()) < 1.0        # a finite range-guard bound was reported

@@ -1,10 +1,9 @@
 #!/bin/bash
-# the network with and without the Winograd-T convolutions, same box, interleaved; run on the GPU box
+# the network with and without the Winograd-T convolutions (and their folded tails), same box, interleaved; run on the GPU box
 for rep in ${REPS:-1 2}; do
-for cfg in ${CFGS:-"0 0" "1 0" "1 1"}; do
-  set -- $cfg
-  echo "== V2CE_WINOGRAD=$1 V2CE_WT_UNFOLD=$2 (rep $rep)"
-  V2CE_WINOGRAD=$1 V2CE_WT_UNFOLD=$2 python3 bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-exact-f32 --no-host-to-host 2>/dev/null | python3 -c "
+for cfg in ${CFGS:-0:1 1:0 1:1}; do
+  echo "== V2CE_WINOGRAD=${cfg%:*} V2CE_WT_TAIL=${cfg#*:} (rep $rep)"
+  V2CE_WINOGRAD=${cfg%:*} V2CE_WT_TAIL=${cfg#*:} python3 bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-exact-f32 --no-host-to-host 2>/dev/null | python3 -c "
 import json,sys
 d=[json.loads(l) for l in sys.stdin if l.startswith('{\"metric\"')][0]
 print(round(d['value']), round(d['ms_per_step'],3), 'executed GF/pair', round(d.get('executed_flop_per_pair',0)/1e9,1))

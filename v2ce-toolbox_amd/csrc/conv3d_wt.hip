@@ -52,11 +52,19 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 #define ACC_T(var_, t0_) do {} while (0)
 #endif
 
-template <int CO_FR, int PO_FR, int RES>
+// TAIL: the block's folded 1x1x1 shortcut rides behind the 3x3x3 conv's chunks (v2ce_conv3d_fwd_tail's contract: P.tx0 (++ tx1) read at
+// the output positions, P.sc_w = the [Cout][tC0 + tC1][1] weights, P.tCG channel groups).  In the transform domain a term z(t) = Wd x(t)
+// of the OUTPUT splits over the slots as  m0 += WdA x(2p),  m3 -= WdA x(2p+1),  m1 += WdB (x(2p) + x(2p+1)) / 2,
+// m2 += WdB (x(2p) - x(2p+1)) / 2  (A / B = first / second half of the tail's channel groups): y(2p) = m0 + m1 + m2 and
+// y(2p+1) = m1 - m2 - m3 then gain Wd x(2p) and Wd x(2p+1), and every wave does a quarter of the tail's MFMAs.  A producer lane owns an
+// output pair-position and one of the two k-steps of a barrier: four 64-byte loads (two time steps x group of half A, group of half B),
+// the same register shape as a chunk of the main loop.
+template <int CO_FR, int PO_FR, int RES, bool TAIL = false>
 __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
 #if defined(__HIP_DEVICE_COMPILE__)
     [[maybe_unused]] unsigned long long t_all = TICK(), t_bar = 0, t_epi = 0, t_xbar = 0, t_cvt = 0;
     static_assert(PO_FR == 4, "the output transform hands position fragment f to consumer wave f");
+    static_assert(!TAIL || RES == 0, "a folded tail replaces the residual");
     constexpr int CK = 16, NA = 3, CO_TILE = CO_FR * 32, chs = kWtChs;
     constexpr int NX = 2 * CO_FR;                                    // extra barriers per tile (output transform)
     f16x8 *pieces = reinterpret_cast<f16x8 *>(conv_smem);            // [2][4][chs] x 16 B
@@ -110,6 +118,15 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
     auto amax_of = [&](int b) -> float { return P.x0_absmax ? P.x0_absmax[b * P.amax_bs] : 4094.0f; };
     // the transformed inputs reach 2 max |x|: one binade less than the direct kernel's pre-scale
     auto scale_of = [&](int b) -> float { return P.x0_absmax ? pow2_prescale(2.0f * amax_of(b)) : 0.5f * kActScale; };
+    const int NTB = TAIL ? P.tCG / 4 : 0;                             // tail barriers per tile: two k-steps per wave each
+    const int CGT = CG + NTB;
+    auto tamax_of = [&](int b) -> float {
+        if (!P.tx0_absmax) return 4094.0f;
+        float am = P.tx0_absmax[b * P.amax_bs];
+        if (P.tx1_absmax) am = fmaxf(am, P.tx1_absmax[b * P.amax_bs]);
+        return am;
+    };
+    auto tscale_of = [&](int b) -> float { return P.tx0_absmax ? pow2_prescale(tamax_of(b)) : kActScale; };
     // range guard (conv3d_f16x2_ws_kernel): K = 9 Cin terms per slot, three slots per output, operands 2 max |x| and max |G|
     if (P.guard && blockIdx.x == 0 && wave == 0) {
         float sm = 0.0f;
@@ -119,7 +136,15 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
         const int nb = P.amax_bs ? P.B : 1;
         for (int b = lane; b < nb; b += 64) {
             const float am = 2.0f * amax_of(b), xs = scale_of(b);
-            P.guard[b * P.amax_bs] = sm * (float)(P.Cin * 27) * 0x1p-25f * (tail[0] / xs + am / tail[1]);
+            float E = sm * (float)(P.Cin * 27) * 0x1p-25f * (tail[0] / xs + am / tail[1]);
+            if (TAIL) {                                               // (conv3d_f16x2_ws_kernel, FUSE 3: the bounds add)
+                const float *tl = reinterpret_cast<const float *>(P.sc_w + 2 * (long long)P.tCG * P.Cout * 16);
+                const float tam = tamax_of(b), txs = tscale_of(b);
+                E += sm * (float)(P.tCG * 16) * 0x1p-25f * (tl[0] / txs + tam / tl[1]);
+                const float rho = (txs * tl[1]) / (xs * tail[1]);
+                if (!(rho > 0x1p-40f && rho < 0x1p40f)) E = __builtin_inff();
+            }
+            P.guard[b * P.amax_bs] = E;
         }
     }
 
@@ -133,12 +158,58 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
         const int ptid = tid - 256;                                   // = the element (p, hh, hw) of the halo box this lane owns
         const bool wave_on = (wave - 4) * 64 < P.plane;               // wave-uniform
         float x_scale = scale_of(T.b);
+        float t_scale = TAIL ? tscale_of(T.b) : 1.0f;
+        unsigned toff[2][2];                                          // tail: [source][time step 2p, 2p+1] of this lane's output position
+        __amdgpu_buffer_rsrc_t rs_t0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x0), 0, 0, 0x00020000), rs_t1 = rs_t0;
         unsigned goff[4];                                             // the element's four time steps 2p-1 .. 2p+2 (kOOB: zero padding)
         float R0[4][CK], R1[4][CK];
         __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x0), 0, 0, 0x00020000);
         const long long seq = (long long)P.T * P.Cin * (P.Hin * P.Winp);
         const int cg_bytes = P.Hin * P.Winp * 64;                     // bytes between 16-channel groups of a time step
         auto load_chunk = [&](const TileId &L, int cidx, float (&R)[4][CK]) {
+            if (TAIL && cidx >= CG) {                                 // uniform: a tail barrier's two k-steps
+                typedef float f32x4g __attribute__((ext_vector_type(4)));
+                if (cidx == CG) {
+#pragma unroll
+                    for (int sidx = 0; sidx < 2; ++sidx) toff[sidx][0] = toff[sidx][1] = kOOB;
+                    int pp, th, tw;
+                    if (pos_of(ptid & 127, L, pp, th, tw)) {
+                        const int h = L.h0 + th, w = L.w0 + tw;
+                        if (h < P.Hout && w < P.Wout) {
+                            const int hi = h * P.tS, wi = w * P.tS;
+                            const int hs = P.thmap ? P.thmap[hi] : hi, ws = P.twmap ? P.twmap[wi] : wi;
+#pragma unroll
+                            for (int i = 0; i < 2; ++i) {
+                                const int t = L.t0 + 2 * pp + i;
+                                if (t < P.T) {
+                                    toff[0][i] = 4u * (unsigned)((t * P.tC0) * (P.tH0 * P.tW0p)) + 64u * (unsigned)(hs * P.tW0p + ws);
+                                    toff[1][i] = 4u * (unsigned)((t * P.tC1) * (P.tHin * P.tWinp)) + 64u * (unsigned)(hi * P.tWinp + wi);
+                                }
+                            }
+                        }
+                    }
+                    const long long seq0 = (long long)P.T * P.tC0 * (P.tH0 * P.tW0p), seq1 = (long long)P.T * P.tC1 * (P.tHin * P.tWinp);
+                    rs_t0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.tx0 + L.b * seq0), 0, (int)(seq0 * 4), 0x00020000);
+                    rs_t1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.tx1 ? P.tx1 + L.b * seq1 : P.tx0), 0, P.tx1 ? (int)(seq1 * 4) : 0, 0x00020000);
+                }
+                const int gs = (wave - 4) >> 1;                       // lanes 0-127: the barrier's first k-step, 128-255: its second
+                const int CG0 = P.tC0 / 16;
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) {                      // half A's group, half B's group
+                    const int g = hb * (P.tCG / 2) + 2 * (cidx - CG) + gs;
+                    const bool s1 = g >= CG0;                         // uniform: which source holds group g
+                    const int gbytes = s1 ? (g - CG0) * (P.tHin * P.tWinp * 64) : g * (P.tH0 * P.tW0p * 64);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int k4 = 0; k4 < CK / 4; ++k4) {
+                            const f32x4g v = s1 ? __builtin_bit_cast(f32x4g, __builtin_amdgcn_raw_buffer_load_b128(rs_t1, toff[1][i], gbytes + 16 * k4, 0))
+                                                : __builtin_bit_cast(f32x4g, __builtin_amdgcn_raw_buffer_load_b128(rs_t0, toff[0][i], gbytes + 16 * k4, 0));
+                            R[2 * hb + i][4 * k4] = v[0]; R[2 * hb + i][4 * k4 + 1] = v[1]; R[2 * hb + i][4 * k4 + 2] = v[2]; R[2 * hb + i][4 * k4 + 3] = v[3];
+                        }
+                }
+                return;
+            }
             if (cidx == 0) {                                          // uniform: a new tile
 #pragma unroll
                 for (int i = 0; i < 4; ++i) goff[i] = kOOB;
@@ -175,7 +246,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
         auto load_next = [&](float (&R)[4][CK]) {
             if (!moreL) return;
             load_chunk(TL, cgL, R);
-            if (++cgL == CG) {
+            if (++cgL == CGT) {
                 cgL = 0;
                 vbL += (int)gridDim.x;
                 moreL = next_tile(vbL, TL);
@@ -184,8 +255,10 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
         int cgC = 0;                                                  // conversion cursor: chunk inside the tile
         auto convert = [&](const float (&R)[4][CK]) {
             f16x8 *qb = pieces + (gc & 1) * 4 * chs;
-            if (!wave_on) return;
+            const bool tail = TAIL && cgC >= CG;                      // uniform
+            if (!wave_on && !tail) return;
             [[maybe_unused]] const unsigned long long tcv = TICK();
+            const float c_scale = tail ? t_scale : x_scale;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -196,14 +269,18 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
                     for (int c2 = 0; c2 < 4; ++c2) {
                         const int ca = 8 * hg + 2 * c2, cb = ca + 1;
                         // input transform B^T d (f32): d0 - d2 | d1 + d2 | d2 - d1 | d1 - d3
-                        const float xa = j == 0 ? R[0][ca] - R[2][ca] : j == 1 ? R[1][ca] + R[2][ca] : j == 2 ? R[2][ca] - R[1][ca] : R[1][ca] - R[3][ca];
-                        const float xb = j == 0 ? R[0][cb] - R[2][cb] : j == 1 ? R[1][cb] + R[2][cb] : j == 2 ? R[2][cb] - R[1][cb] : R[1][cb] - R[3][cb];
+                        float xa = j == 0 ? R[0][ca] - R[2][ca] : j == 1 ? R[1][ca] + R[2][ca] : j == 2 ? R[2][ca] - R[1][ca] : R[1][ca] - R[3][ca];
+                        float xb = j == 0 ? R[0][cb] - R[2][cb] : j == 1 ? R[1][cb] + R[2][cb] : j == 2 ? R[2][cb] - R[1][cb] : R[1][cb] - R[3][cb];
+                        if (tail) {     // R = { xA(2p), xA(2p+1), xB(2p), xB(2p+1) }:  xA(2p) | (xB(2p) + xB(2p+1)) / 2 | (xB(2p) - xB(2p+1)) / 2 | -xA(2p+1)
+                            xa = j == 0 ? R[0][ca] : j == 1 ? (R[2][ca] + R[3][ca]) * 0.5f : j == 2 ? (R[2][ca] - R[3][ca]) * 0.5f : -R[1][ca];
+                            xb = j == 0 ? R[0][cb] : j == 1 ? (R[2][cb] + R[3][cb]) * 0.5f : j == 2 ? (R[2][cb] - R[3][cb]) * 0.5f : -R[1][cb];
+                        }
                         unsigned h, l;                                // hi = f16(x s), lo = f16(x s - hi)  (conv3d.hip, producers)
                         asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
                             "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
                             "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
                             "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-                            : "=&v"(h), "=&v"(l) : "v"(xa), "v"(xb), "v"(x_scale));
+                            : "=&v"(h), "=&v"(l) : "v"(xa), "v"(xb), "v"(c_scale));
                         ph[c2] = h;
                         pl[c2] = l;
                     }
@@ -216,11 +293,14 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
         bool moreC = true;
         auto advance = [&]() {
             ++gc;
-            if (++cgC == CG) {
+            if (++cgC == CGT) {
                 cgC = 0;
                 vb += (int)gridDim.x;
                 moreC = next_tile(vb, T);
-                if (moreC) x_scale = scale_of(T.b);
+                if (moreC) {
+                    x_scale = scale_of(T.b);
+                    if (TAIL) t_scale = tscale_of(T.b);
+                }
             }
         };
         auto tile_rendezvous = [&]() {                                // the consumers' output transform of the tile before this one
@@ -350,6 +430,66 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
             });
         }
 
+        float out_inv_scale = inv_scale;
+        if constexpr (TAIL) {
+            const long long tplane = (long long)P.tCG * P.Cout * 16;              // halves per plane of the tail weights
+            const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(P.sc_w), 0, (int)(4 * tplane), 0x00020000);
+            const float t_scale = tscale_of(T.b);
+            const float wt_scale = reinterpret_cast<const float *>(P.sc_w + 2 * tplane)[1];
+            const float rho = (t_scale * wt_scale) / (x_scale * w_scale);         // a power of two: the rescale is exact
+#pragma unroll
+            for (int q = 0; q < CO_FR; ++q)
+#pragma unroll
+                for (int f = 0; f < PO_FR; ++f)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[q][f][r] *= rho;
+            out_inv_scale = 1.0f / (t_scale * wt_scale);
+            const int gbase = (wave == 0 || wave == 3) ? 0 : P.tCG / 2;           // this slot's half of the channel groups
+            const int nstep = P.tCG / 2;
+            int bpt[PO_FR];
+#pragma unroll
+            for (int f = 0; f < PO_FR; ++f) bpt[f] = half * chs + wave * kWtSlot + f * 32 + l32;
+            f16x8 ath[2][CO_FR], atl[2][CO_FR];                                   // A fragments, double-buffered over the k-steps
+#pragma unroll
+            for (int q = 0; q < CO_FR; ++q) {
+                ath[0][q] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_t, wlane[q], gbase * cg_stride, 0));
+                atl[0][q] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_t, wlane[q], gbase * cg_stride + (int)(2 * tplane), 0));
+            }
+            for (int kb = 0; kb < NTB; ++kb, ++gc) {
+                const f16x8 *qb = pieces + (gc & 1) * 4 * chs;
+                { [[maybe_unused]] const unsigned long long tb = TICK();
+                __syncthreads();                                                  // barrier gc: two k-steps of the tail ready
+                ACC_T(t_bar, tb); }
+#pragma unroll
+                for (int gs = 0; gs < 2; ++gs) {
+                    const int step = 2 * kb + gs;
+                    if (step) {
+#pragma unroll
+                        for (int q = 0; q < CO_FR; ++q) { ath[0][q] = ath[1][q]; atl[0][q] = atl[1][q]; }
+                    }
+                    const int wn = (gbase + (step + 1 < nstep ? step + 1 : step)) * cg_stride;
+#pragma unroll
+                    for (int q = 0; q < CO_FR; ++q) {
+                        ath[1][q] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_t, wlane[q], wn, 0));
+                        atl[1][q] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_t, wlane[q], wn + (int)(2 * tplane), 0));
+                    }
+#pragma unroll
+                    for (int f = 0; f < PO_FR; ++f) {
+                        bh[f] = qb[bpt[f] + gs * 128];
+                        bl[f] = qb[bpt[f] + gs * 128 + 2 * chs];
+                    }
+#pragma unroll
+                    for (int f = 0; f < PO_FR; ++f)
+#pragma unroll
+                        for (int q = 0; q < CO_FR; ++q) {
+                            acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ath[0][q], bh[f], acc[q][f], 0, 0, 0);
+                            acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ath[0][q], bl[f], acc[q][f], 0, 0, 0);
+                            acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(atl[0][q], bh[f], acc[q][f], 0, 0, 0);
+                        }
+                }
+            }
+        }
+
         // ---- output transform + epilogue.  This wave stores position fragment f = wave: outputs t = 2p, 2p + 1.
         [[maybe_unused]] const unsigned long long te = TICK();
         int poff[2];
@@ -435,7 +575,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const float y = o == 0 ? (mm[rr][0][k] + mm[rr][1][k]) + mm[rr][2][k] : (mm[rr][1][k] - mm[rr][2][k]) - mm[rr][3][k];
-                            float v = y * (scq[r4][k] * inv_scale) + shq[r4][k];
+                            float v = y * (scq[r4][k] * out_inv_scale) + shq[r4][k];
                             v += rv[o][r4][k];
                             v = apply_act(v, slope);
                             out[k] = v;
@@ -608,11 +748,11 @@ WtBox choose_wt_box(int B, int T, int H, int W, int n_co, int n_cu, int pos_tile
     return best;
 }
 
-template <int CO_FR, int PO_FR, int RES>
+template <int CO_FR, int PO_FR, int RES, bool TAIL = false>
 int launch_wt(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream) {
     constexpr int CO_TILE = CO_FR * 32, POS_TILE = PO_FR * 32;
     if (g_wt_name_out) {
-        snprintf(g_wt_name_out, g_wt_name_cap, "conv3d_wt_kernel<%d,%d,%d>", CO_FR, PO_FR, RES);
+        snprintf(g_wt_name_out, g_wt_name_cap, "conv3d_wt_kernel<%d,%d,%d,%d>", CO_FR, PO_FR, RES, (int)TAIL);
         return V2CE_OK;
     }
     static const int n_cu = [] {
@@ -643,14 +783,14 @@ int launch_wt(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream) {
     const long long blocks = (long long)8 * P.per_xcd * P.n_co_tiles;
     P.total_blocks = (int)blocks;
     const size_t lds = (size_t)kWtChs * (2 * 4 * 16);      // 128 KB
-    auto kern = conv3d_wt_kernel<CO_FR, PO_FR, RES>;
+    auto kern = conv3d_wt_kernel<CO_FR, PO_FR, RES, TAIL>;
     static const int once = [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         return 0;
     }();
     (void)once;
     if (getenv("V2CE_WT_VERBOSE"))
-        fprintf(stderr, "[wt<%d,%d,%d> %dx%dx%dx%d C %d -> %d] box %d pairs x %d x %d%s (%d of %d positions, %d halo elements), %lld tiles\n", CO_FR, PO_FR, RES, d.B, d.T,
+        fprintf(stderr, "[wt<%d,%d,%d%s> %dx%dx%dx%d C %d -> %d] box %d pairs x %d x %d%s (%d of %d positions, %d halo elements), %lld tiles\n", CO_FR, PO_FR, RES, TAIL ? ",tail" : "", d.B, d.T,
                 d.Hout, d.Wout, P.Cin, P.Cout, bx.pp, bx.th, bx.tw, bx.flat ? " rows: flat ranges" : "", P.n_pos, POS_TILE, P.plane, blocks);
     const unsigned grid = (unsigned)(blocks > n_cu ? n_cu : blocks);
 #ifdef V2CE_STAMP
@@ -681,8 +821,16 @@ int launch_wt(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream) {
     return V2CE_OK;
 }
 
+struct WtTail {
+    const v2ce_conv3d_desc *desc;
+    const float *tx0, *tx1;
+    const int *thmap, *twmap;
+    const void *w;
+    const float *tx0_absmax, *tx1_absmax;
+};
+
 int wt_dispatch(const v2ce_conv3d_desc *desc, const float *x, const void *w_wt, const float *scale, const float *shift,
-                const float *residual, float *y, const float *x_absmax, float *y_absmax, v2ce_stream_t stream) {
+                const float *residual, float *y, const float *x_absmax, float *y_absmax, v2ce_stream_t stream, const WtTail *tl = nullptr) {
     clear_error();
     V2CE_REQUIRE(desc && (g_wt_name_out || (x && w_wt && scale && shift && y)), V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd_wt: null pointer");
     const v2ce_conv3d_desc &d = *desc;
@@ -712,6 +860,29 @@ int wt_dispatch(const v2ce_conv3d_desc *desc, const float *x, const void *w_wt, 
     P.amax_bs = d.absmax_batch_stride;
     V2CE_REQUIRE(P.amax_bs == 0 || P.amax_bs >= 2, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd_wt: absmax_batch_stride must be 0 or >= 2");
     hipStream_t st = as_stream(stream);
+    if (tl) {
+        // (the contract of v2ce_conv3d_fwd_tail, conv3d.hip)
+        V2CE_REQUIRE(tl->desc && tl->w && !residual, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd_wt_tail: null tail description / weights, or a residual");
+        const v2ce_conv3d_desc &t = *tl->desc;
+        V2CE_REQUIRE(t.ksize == 1 && (t.stride_hw == 1 || t.stride_hw == 2) && t.layout == V2CE_LAYOUT_C16 && t.B == d.B && t.T == d.T &&
+                     t.Cout == d.Cout && t.Hout == d.Hout && t.Wout == d.Wout && t.C0 > 0 && t.C0 % 16 == 0 && t.C1 >= 0 &&
+                     t.C1 % 16 == 0 && t.Hout == (t.Hin - 1) / t.stride_hw + 1 && t.Wout == (t.Win - 1) / t.stride_hw + 1,
+                     V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd_wt_tail: the tail must be a 1x1x1 conv (channels-last-16, channel counts multiples "
+                     "of 16) producing exactly the main conv's output shape");
+        V2CE_REQUIRE(((t.C0 + t.C1) / 16) % 4 == 0, V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd_wt_tail: the tail's channel count must be a multiple of 64");
+        V2CE_REQUIRE((g_wt_name_out || tl->tx0) && (t.C1 == 0 || tl->tx1 || g_wt_name_out) && (tl->thmap == nullptr) == (tl->twmap == nullptr) &&
+                     (tl->thmap || (t.H0 == t.Hin && t.W0 == t.Win)), V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd_wt_tail: tail inputs / index maps");
+        V2CE_REQUIRE((tl->tx0_absmax != nullptr) == (x_absmax != nullptr) && (t.C1 == 0 || !tl->tx0_absmax || tl->tx1_absmax), V2CE_ERR_BAD_ARG,
+                     "v2ce_conv3d_fwd_wt_tail: range slots of the tail inputs");
+        P.tx0 = tl->tx0; P.tx1 = t.C1 > 0 ? tl->tx1 : nullptr; P.thmap = tl->thmap; P.twmap = tl->twmap;
+        P.tC0 = t.C0; P.tH0 = t.H0; P.tW0p = t.W0_pitch > 0 ? t.W0_pitch : t.W0; P.tC1 = t.C1; P.tHin = t.Hin; P.tWin = t.Win;
+        P.tWinp = t.Win_pitch > 0 ? t.Win_pitch : t.Win; P.tS = t.stride_hw; P.tCG = (t.C0 + t.C1) / 16;
+        P.tx0_absmax = tl->tx0_absmax; P.tx1_absmax = t.C1 > 0 ? tl->tx1_absmax : nullptr;
+        P.sc_w = static_cast<const _Float16 *>(tl->w);
+        V2CE_REQUIRE((long long)t.T * t.C0 * t.H0 * P.tW0p < (1ll << 29) && (long long)t.T * t.C1 * t.Hin * P.tWinp < (1ll << 29),
+                     V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd_wt_tail: a single sequence exceeds the 2 GiB buffer-descriptor range");
+        return launch_wt<2, 4, 0, true>(P, d, st);
+    }
     if (residual || (g_wt_name_out && scale)) return launch_wt<2, 4, 1>(P, d, st);
     return launch_wt<2, 4, 0>(P, d, st);
 }
@@ -761,13 +932,30 @@ extern "C" int v2ce_conv3d_fwd_wt(const v2ce_conv3d_desc *desc, const float *x, 
     return wt_dispatch(desc, x, w_wt, scale, shift, residual, y, x_absmax, y_absmax, stream);
 }
 
+extern "C" int v2ce_conv3d_fwd_wt_tail(const v2ce_conv3d_desc *desc, const float *x, const void *w_wt, const float *scale, const float *shift,
+                                       float *y, const float *x_absmax, float *y_absmax, const v2ce_conv3d_desc *tail_desc, const float *tx0,
+                                       const float *tx1, const int32_t *thmap, const int32_t *twmap, const void *tail_w,
+                                       const float *tx0_absmax, const float *tx1_absmax, v2ce_stream_t stream) {
+    g_wt_name_out = nullptr;
+    const WtTail tl{tail_desc, tx0, tx1, thmap, twmap, tail_w, tx0_absmax, tx1_absmax};
+    return wt_dispatch(desc, x, w_wt, scale, shift, nullptr, y, x_absmax, y_absmax, stream, &tl);
+}
+
 extern "C" int v2ce_conv3d_wt_variant(const v2ce_conv3d_desc *desc, int with_residual, char *name, size_t cap) {
     V2CE_REQUIRE(name && cap > 0, V2CE_ERR_BAD_ARG, "v2ce_conv3d_wt_variant: no buffer");
     name[0] = '\0';
     g_wt_name_out = name;
     g_wt_name_cap = cap;
     static const float dummy = 0.0f;
-    const int rc = wt_dispatch(desc, nullptr, nullptr, with_residual ? &dummy : nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    int rc;
+    if (with_residual == 2) {                              // the tail variant (any valid tail description names the same kernel)
+        v2ce_conv3d_desc t = *desc;
+        t.ksize = 1; t.stride_hw = 1; t.C0 = 64; t.C1 = 0; t.H0 = t.Hin = desc->Hout; t.W0 = t.Win = desc->Wout; t.layout = V2CE_LAYOUT_C16;
+        const WtTail tl{&t, nullptr, nullptr, nullptr, nullptr, &dummy, nullptr, nullptr};
+        rc = wt_dispatch(desc, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &tl);
+    } else {
+        rc = wt_dispatch(desc, nullptr, nullptr, with_residual ? &dummy : nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    }
     g_wt_name_out = nullptr;
     return rc;
 }

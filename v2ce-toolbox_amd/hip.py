@@ -32,7 +32,7 @@ EXPORTS = [
     "v2ce_voxelize_events", "v2ce_conv3d_fwd_pred", "v2ce_conv3d_fwd_sc", "v2ce_conv3d_fwd_tail", "v2ce_pack_pred_weights_f16x2", "v2ce_pack_pred_weights_f16x2_bytes",
     "v2ce_sampler_count", "v2ce_sampler_workspace_bytes", "v2ce_sampler_emit", "v2ce_sampler_pool",
     "v2ce_conv3d_fwd_up2", "v2ce_pack_weights_f16x2_up", "v2ce_pack_weights_f16x2_up_bytes", "v2ce_conv3d_up2_variant",
-    "v2ce_conv3d_fwd_wt", "v2ce_pack_weights_f16x2_wt", "v2ce_pack_weights_f16x2_wt_bytes", "v2ce_conv3d_wt_variant",
+    "v2ce_conv3d_fwd_wt", "v2ce_conv3d_fwd_wt_tail", "v2ce_pack_weights_f16x2_wt", "v2ce_pack_weights_f16x2_wt_bytes", "v2ce_conv3d_wt_variant",
     "v2ce_conv3d_head_f16x2", "v2ce_pack_head_weights_f16x2", "v2ce_pack_head_weights_f16x2_bytes", "v2ce_absmax_batch",
 ]
 
@@ -157,6 +157,8 @@ def lib() -> ctypes.CDLL:
     L.v2ce_conv3d_up2_variant.restype = ctypes.c_int
     L.v2ce_conv3d_fwd_wt.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 9
     L.v2ce_conv3d_fwd_wt.restype = ctypes.c_int
+    L.v2ce_conv3d_fwd_wt_tail.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 7 + [ctypes.POINTER(ConvDesc)] + [vp] * 8
+    L.v2ce_conv3d_fwd_wt_tail.restype = ctypes.c_int
     L.v2ce_pack_weights_f16x2_wt.argtypes = [vp, i32, i32, vp, vp, vp]
     L.v2ce_pack_weights_f16x2_wt.restype = ctypes.c_int
     L.v2ce_pack_weights_f16x2_wt_bytes.argtypes = [i32, i32]
@@ -240,7 +242,8 @@ def require_device_f32(t: torch.Tensor, name: str) -> torch.Tensor:
     return t.contiguous()
 
 
-def conv_wt_variant(desc: ConvDesc, with_residual: bool) -> str:
+def conv_wt_variant(desc: ConvDesc, with_residual) -> str:
+    """with_residual: False / True, or 2 for the folded-tail form."""
     buf = ctypes.create_string_buffer(96)
     check(lib().v2ce_conv3d_wt_variant(ctypes.byref(desc), int(with_residual), buf, 96), "v2ce_conv3d_wt_variant")
     return buf.value.decode()

@@ -285,7 +285,8 @@ class V2ce3d(nn.Module):
                 # >= 64 output channels: conv2 of a block whose shortcut does not ride in its K loop, conv1 of the middle blocks
                 wt = {"conv1": self._winograd() and splits["conv1"] and name == "res" and blk.stride_hw == 1 and blk.cout % 64 == 0
                       and not self._fuse_shortcut(blk),
-                      "conv2": self._winograd() and splits["conv2"] and blk.cout % 64 == 0 and d["fold"] is None}
+                      "conv2": self._winograd() and splits["conv2"] and blk.cout % 64 == 0 and
+                      (d["fold"] is None or (blk.cin % 64 == 0 and os.environ.get("V2CE_WT_TAIL", "1") != "0"))}
                 d["wt"] = wt
                 if blk.sn:
                     for cn in ("conv1", "conv2"):
@@ -430,8 +431,8 @@ class V2ce3d(nn.Module):
         # Winograd F(2,3) along T (v2ce_conv3d_fwd_wt): a one-source stride-1 3x3x3 conv whose weights were packed transformed
         wt = split and getattr(w_packed, "wt", False)
         if wt:
-            assert ksize == 3 and stride == 1 and x1 is None and hmap is None and pred is None and tail is None and sc is None, \
-                "Winograd-T weights drive only the plain one-source 3x3x3 stride-1 launch"
+            assert ksize == 3 and stride == 1 and x1 is None and hmap is None and pred is None and sc is None, \
+                "Winograd-T weights drive only the one-source 3x3x3 stride-1 launch (plain, with a residual, or with a folded tail)"
         C1 = 0 if x1 is None else x1.shape[2] * (16 if getattr(x1, "c16", False) else 1)
         Winp = Win if x1 is None else x1.shape[4]
         assert x1 is None or getattr(x1, "lw", Winp) == Win
@@ -463,7 +464,7 @@ class V2ce3d(nn.Module):
         if prof is not None:       # HIP events on the launch stream (torch's current stream)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        if wt:
+        if wt and tail is None:
             hip.check(hip.lib().v2ce_conv3d_fwd_wt(ctypes.byref(d), x0.data_ptr(), w_packed.data_ptr(), scale.data_ptr(),
                                                    shift.data_ptr(), hip.ptr(residual), y.data_ptr(), hip.ptr(a0), hip.ptr(ay),
                                                    hip.stream_ptr(x0.device)),
@@ -505,12 +506,19 @@ class V2ce3d(nn.Module):
                               absmax_batch_stride=d.absmax_batch_stride)
             ta0 = getattr(tx0, "absmax", None) if a0 is not None else None
             ta1 = None if tx1 is None or ta0 is None else tx1.absmax
-            hip.check(hip.lib().v2ce_conv3d_fwd_tail(ctypes.byref(d), x0.data_ptr(), hip.ptr(x1), hip.ptr(hmap), hip.ptr(wmap),
-                                                     w_packed.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(),
-                                                     hip.ptr(a0), hip.ptr(a1), hip.ptr(ay), ctypes.byref(td), tx0.data_ptr(),
-                                                     hip.ptr(tx1), hip.ptr(thmap), hip.ptr(twmap), tw.data_ptr(),
-                                                     hip.ptr(ta0), hip.ptr(ta1), hip.stream_ptr(x0.device)),
-                      "v2ce_conv3d_fwd_tail")
+            if wt:
+                hip.check(hip.lib().v2ce_conv3d_fwd_wt_tail(ctypes.byref(d), x0.data_ptr(), w_packed.data_ptr(), scale.data_ptr(),
+                                                            shift.data_ptr(), y.data_ptr(), hip.ptr(a0), hip.ptr(ay), ctypes.byref(td),
+                                                            tx0.data_ptr(), hip.ptr(tx1), hip.ptr(thmap), hip.ptr(twmap), tw.data_ptr(),
+                                                            hip.ptr(ta0), hip.ptr(ta1), hip.stream_ptr(x0.device)),
+                          "v2ce_conv3d_fwd_wt_tail")
+            else:
+                hip.check(hip.lib().v2ce_conv3d_fwd_tail(ctypes.byref(d), x0.data_ptr(), hip.ptr(x1), hip.ptr(hmap), hip.ptr(wmap),
+                                                         w_packed.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(),
+                                                         hip.ptr(a0), hip.ptr(a1), hip.ptr(ay), ctypes.byref(td), tx0.data_ptr(),
+                                                         hip.ptr(tx1), hip.ptr(thmap), hip.ptr(twmap), tw.data_ptr(),
+                                                         hip.ptr(ta0), hip.ptr(ta1), hip.stream_ptr(x0.device)),
+                          "v2ce_conv3d_fwd_tail")
         elif sc is not None:           # fused 1x1x1 shortcut: second output tensor
             sc_w, sc_scale, sc_shift = sc
             y_sc = torch.empty_like(y)
@@ -538,7 +546,7 @@ class V2ce3d(nn.Module):
                 flops += 2.0 * B * T * Hout * Wout * cout * (C0 + C1)
             if tail is not None:
                 flops += 2.0 * B * T * Hout * Wout * cout * 16 * (tail[0].shape[2] + (0 if tail[1] is None else tail[1].shape[2]))
-            name = hip.conv_wt_variant(d, residual is not None) if wt else hip.conv_up2_variant(d, sc is not None) if up2 else \
+            name = hip.conv_wt_variant(d, 2 if tail is not None else residual is not None) if wt else hip.conv_up2_variant(d, sc is not None) if up2 else \
                 hip.conv_variant(d, hmap is not None, (1 if pred is not None else (2 if sc is not None else (3 if tail is not None else 0))) +
                                  (4 if residual is not None else 0))
             # (flops = the ALGORITHMIC count of the reference's convolution; a phase-folded launch executes fewer: `executed`)
