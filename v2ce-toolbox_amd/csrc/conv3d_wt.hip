@@ -59,6 +59,12 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // y(2p+1) = m1 - m2 - m3 then gain Wd x(2p) and Wd x(2p+1), and every wave does a quarter of the tail's MFMAs.  A producer lane owns an
 // output pair-position and one of the two k-steps of a barrier: four 64-byte loads (two time steps x group of half A, group of half B),
 // the same register shape as a chunk of the main loop.
+// A tail barrier carries only 48 MFMAs per wave (a chunk of the main loop: 216), less than the latency of the gathers behind it, so the
+// tail barriers are INTERLEAVED with the main chunks (M0 T0 M1 T1 ...: a tail barrier's loads are issued two barriers = more than one
+// main chunk ahead; all tail barriers behind the main loop measured 3x their MFMA time, the producers waiting for loads).  The two parts
+// therefore accumulate at ONE power-of-two scale S = min(x_scale w_scale, t_scale wt_scale): the part with the larger natural scale
+// gives up log2 of the ratio in headroom (0-3 bits on this network), which the range-guard bound -- computed from the scales really
+// used -- accounts for.
 template <int CO_FR, int PO_FR, int RES, bool TAIL = false>
 __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -127,6 +133,15 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
         return am;
     };
     auto tscale_of = [&](int b) -> float { return P.tx0_absmax ? pow2_prescale(tamax_of(b)) : kActScale; };
+    const float wt_scale = TAIL ? reinterpret_cast<const float *>(P.sc_w + 2 * (long long)P.tCG * P.Cout * 16)[1] : 1.0f;
+    // TAIL: the common accumulator scale of batch element b, and the input pre-scales that produce it (all powers of two)
+    auto acc_scale_of = [&](int b) -> float { return TAIL ? fminf(scale_of(b) * w_scale, tscale_of(b) * wt_scale) : scale_of(b) * w_scale; };
+    auto xs_of = [&](int b) -> float { return TAIL ? acc_scale_of(b) / w_scale : scale_of(b); };
+    auto ts_of = [&](int b) -> float { return acc_scale_of(b) / wt_scale; };
+    // the order of a tile's CGT barriers: main chunk and tail barrier alternate while both remain
+    const int nI = CG < NTB ? CG : NTB;
+    auto is_tail = [&](int k) -> bool { return TAIL && (k < 2 * nI ? (k & 1) != 0 : NTB > CG); };
+    auto idx_of = [&](int k) -> int { return !TAIL ? k : (k < 2 * nI ? k >> 1 : k - nI); };
     // range guard (conv3d_f16x2_ws_kernel): K = 9 Cin terms per slot, three slots per output, operands 2 max |x| and max |G|
     if (P.guard && blockIdx.x == 0 && wave == 0) {
         float sm = 0.0f;
@@ -135,14 +150,13 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
         for (int o = 32; o; o >>= 1) sm = fmaxf(sm, __shfl_xor(sm, o));
         const int nb = P.amax_bs ? P.B : 1;
         for (int b = lane; b < nb; b += 64) {
-            const float am = 2.0f * amax_of(b), xs = scale_of(b);
+            const float am = 2.0f * amax_of(b), xs = xs_of(b);
             float E = sm * (float)(P.Cin * 27) * 0x1p-25f * (tail[0] / xs + am / tail[1]);
             if (TAIL) {                                               // (conv3d_f16x2_ws_kernel, FUSE 3: the bounds add)
                 const float *tl = reinterpret_cast<const float *>(P.sc_w + 2 * (long long)P.tCG * P.Cout * 16);
-                const float tam = tamax_of(b), txs = tscale_of(b);
+                const float tam = tamax_of(b), txs = ts_of(b);
                 E += sm * (float)(P.tCG * 16) * 0x1p-25f * (tl[0] / txs + tam / tl[1]);
-                const float rho = (txs * tl[1]) / (xs * tail[1]);
-                if (!(rho > 0x1p-40f && rho < 0x1p40f)) E = __builtin_inff();
+                if (!(xs > 0x1p-100f && txs > 0x1p-100f)) E = __builtin_inff();     // (a scale gap beyond the f32 range)
             }
             P.guard[b * P.amax_bs] = E;
         }
@@ -157,27 +171,27 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
         // ------------------------------------------------------------------ producers
         const int ptid = tid - 256;                                   // = the element (p, hh, hw) of the halo box this lane owns
         const bool wave_on = (wave - 4) * 64 < P.plane;               // wave-uniform
-        float x_scale = scale_of(T.b);
-        float t_scale = TAIL ? tscale_of(T.b) : 1.0f;
+        float x_scale = xs_of(T.b);
+        float t_scale = TAIL ? ts_of(T.b) : 1.0f;
         unsigned toff[2][2];                                          // tail: [source][time step 2p, 2p+1] of this lane's output position
+        [[maybe_unused]] int tm_pp = 0, tm_hi = 0, tm_wi = 0, tm_hs = 0, tm_ws = 0;
+        [[maybe_unused]] bool tm_ok = false;
         __amdgpu_buffer_rsrc_t rs_t0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x0), 0, 0, 0x00020000), rs_t1 = rs_t0;
         unsigned goff[4];                                             // the element's four time steps 2p-1 .. 2p+2 (kOOB: zero padding)
         float R0[4][CK], R1[4][CK];
         __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x0), 0, 0, 0x00020000);
         const long long seq = (long long)P.T * P.Cin * (P.Hin * P.Winp);
         const int cg_bytes = P.Hin * P.Winp * 64;                     // bytes between 16-channel groups of a time step
-        auto load_chunk = [&](const TileId &L, int cidx, float (&R)[4][CK]) {
-            if (TAIL && cidx >= CG) {                                 // uniform: a tail barrier's two k-steps
+        auto load_chunk = [&](const TileId &L, int kseq, float (&R)[4][CK]) {
+            const int cidx = idx_of(kseq);                            // main chunk / tail barrier number
+            if (is_tail(kseq)) {                                      // uniform: a tail barrier's two k-steps
                 typedef float f32x4g __attribute__((ext_vector_type(4)));
-                if (cidx == CG) {
+                if (cidx == 0) {
 #pragma unroll
                     for (int sidx = 0; sidx < 2; ++sidx) toff[sidx][0] = toff[sidx][1] = kOOB;
-                    int pp, th, tw;
-                    if (pos_of(ptid & 127, L, pp, th, tw)) {
-                        const int h = L.h0 + th, w = L.w0 + tw;
-                        if (h < P.Hout && w < P.Wout) {
-                            const int hi = h * P.tS, wi = w * P.tS;
-                            const int hs = P.thmap ? P.thmap[hi] : hi, ws = P.twmap ? P.twmap[wi] : wi;
+                    if (tm_ok) {                                      // (position and map entries: fetched with the tile's first chunk)
+                        {
+                            const int hi = tm_hi, wi = tm_wi, hs = tm_hs, ws = tm_ws, pp = tm_pp;
 #pragma unroll
                             for (int i = 0; i < 2; ++i) {
                                 const int t = L.t0 + 2 * pp + i;
@@ -196,7 +210,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
                 const int CG0 = P.tC0 / 16;
 #pragma unroll
                 for (int hb = 0; hb < 2; ++hb) {                      // half A's group, half B's group
-                    const int g = hb * (P.tCG / 2) + 2 * (cidx - CG) + gs;
+                    const int g = hb * (P.tCG / 2) + 2 * cidx + gs;
                     const bool s1 = g >= CG0;                         // uniform: which source holds group g
                     const int gbytes = s1 ? (g - CG0) * (P.tHin * P.tWinp * 64) : g * (P.tH0 * P.tW0p * 64);
 #pragma unroll
@@ -211,6 +225,16 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
                 return;
             }
             if (cidx == 0) {                                          // uniform: a new tile
+                if constexpr (TAIL) {
+                    // the tail's gather position of this lane, its index-map entries requested now and used one barrier later
+                    int pp, th, tw;
+                    tm_ok = pos_of(ptid & 127, L, pp, th, tw) && L.h0 + th < P.Hout && L.w0 + tw < P.Wout;
+                    tm_pp = pp;
+                    tm_hi = tm_ok ? (L.h0 + th) * P.tS : 0;
+                    tm_wi = tm_ok ? (L.w0 + tw) * P.tS : 0;
+                    tm_hs = P.thmap ? P.thmap[tm_hi] : tm_hi;
+                    tm_ws = P.twmap ? P.twmap[tm_wi] : tm_wi;
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) goff[i] = kOOB;
                 if (ptid < P.plane) {
@@ -253,28 +277,19 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
             }
         };
         int cgC = 0;                                                  // conversion cursor: chunk inside the tile
-        auto convert = [&](const float (&R)[4][CK]) {
+        // one transformed, split element (slot j, channels 8 hg .. 8 hg + 7) into LDS; `tf(j, c)`: the transformed value of channel c
+        auto convert_with = [&](float c_scale0, float c_scale12, auto tf) __attribute__((always_inline)) {
             f16x8 *qb = pieces + (gc & 1) * 4 * chs;
-            const bool tail = TAIL && cgC >= CG;                      // uniform
-            if (!wave_on && !tail) return;
-            [[maybe_unused]] const unsigned long long tcv = TICK();
-            const float c_scale = tail ? t_scale : x_scale;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+                const float c_scale = (j == 1 || j == 2) ? c_scale12 : c_scale0;
 #pragma unroll
                 for (int hg = 0; hg < 2; ++hg) {
                     typedef unsigned u32x4c __attribute__((ext_vector_type(4)));
                     u32x4c ph, pl;
 #pragma unroll
                     for (int c2 = 0; c2 < 4; ++c2) {
-                        const int ca = 8 * hg + 2 * c2, cb = ca + 1;
-                        // input transform B^T d (f32): d0 - d2 | d1 + d2 | d2 - d1 | d1 - d3
-                        float xa = j == 0 ? R[0][ca] - R[2][ca] : j == 1 ? R[1][ca] + R[2][ca] : j == 2 ? R[2][ca] - R[1][ca] : R[1][ca] - R[3][ca];
-                        float xb = j == 0 ? R[0][cb] - R[2][cb] : j == 1 ? R[1][cb] + R[2][cb] : j == 2 ? R[2][cb] - R[1][cb] : R[1][cb] - R[3][cb];
-                        if (tail) {     // R = { xA(2p), xA(2p+1), xB(2p), xB(2p+1) }:  xA(2p) | (xB(2p) + xB(2p+1)) / 2 | (xB(2p) - xB(2p+1)) / 2 | -xA(2p+1)
-                            xa = j == 0 ? R[0][ca] : j == 1 ? (R[2][ca] + R[3][ca]) * 0.5f : j == 2 ? (R[2][ca] - R[3][ca]) * 0.5f : -R[1][ca];
-                            xb = j == 0 ? R[0][cb] : j == 1 ? (R[2][cb] + R[3][cb]) * 0.5f : j == 2 ? (R[2][cb] - R[3][cb]) * 0.5f : -R[1][cb];
-                        }
+                        const float xa = tf(j, 8 * hg + 2 * c2), xb = tf(j, 8 * hg + 2 * c2 + 1);
                         unsigned h, l;                                // hi = f16(x s), lo = f16(x s - hi)  (conv3d.hip, producers)
                         asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
                             "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
@@ -288,6 +303,23 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
                     qb[(2 + hg) * chs + j * kWtSlot + ptid] = __builtin_bit_cast(f16x8, pl);
                 }
             }
+        };
+        auto convert = [&](const float (&R)[4][CK]) {
+            const bool tail = is_tail(cgC);                           // uniform
+            if (!wave_on && !tail) return;
+            [[maybe_unused]] const unsigned long long tcv = TICK();
+            if (tail) {
+                // R = { xA(2p), xA(2p+1), xB(2p), xB(2p+1) }:  xA(2p) | (xB(2p) + xB(2p+1)) / 2 | (xB(2p) - xB(2p+1)) / 2 | -xA(2p+1)
+                // (the halving rides in the pre-scale of slots 1 and 2: exact)
+                convert_with(t_scale, 0.5f * t_scale, [&](int j, int c) -> float {
+                    return j == 0 ? R[0][c] : j == 1 ? R[2][c] + R[3][c] : j == 2 ? R[2][c] - R[3][c] : -R[1][c];
+                });
+            } else {
+                // input transform B^T d (f32): d0 - d2 | d1 + d2 | d2 - d1 | d1 - d3
+                convert_with(x_scale, x_scale, [&](int j, int c) -> float {
+                    return j == 0 ? R[0][c] - R[2][c] : j == 1 ? R[1][c] + R[2][c] : j == 2 ? R[2][c] - R[1][c] : R[1][c] - R[3][c];
+                });
+            }
             ACC_T(t_cvt, tcv);
         };
         bool moreC = true;
@@ -298,8 +330,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
                 vb += (int)gridDim.x;
                 moreC = next_tile(vb, T);
                 if (moreC) {
-                    x_scale = scale_of(T.b);
-                    if (TAIL) t_scale = tscale_of(T.b);
+                    x_scale = xs_of(T.b);
+                    if (TAIL) t_scale = ts_of(T.b);
                 }
             }
         };
@@ -359,8 +391,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
     bool more = true;
     while (more) {
         const int co0 = T.co_t * CO_TILE;
-        const float x_scale = scale_of(T.b);
-        const float inv_scale = 1.0f / (x_scale * w_scale);           // a power of two: exact
+        const float inv_scale = 1.0f / acc_scale_of(T.b);             // a power of two: exact
         int bhb[PO_FR];
 #pragma unroll
         for (int f = 0; f < PO_FR; ++f) {
@@ -390,89 +421,79 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[q][f][r] = 0.0f;
 
-        for (int cg = 0; cg < CG; ++cg, ++gc) {
-            const f16x8 *qb = pieces + (gc & 1) * 4 * chs;
-            const int wc = slot_off + cg * cg_stride;
-            const int wn = cg + 1 < CG ? wc + cg_stride : slot_off;   // last chunk: chunk 0 again (the next tile's start)
-            { [[maybe_unused]] const unsigned long long tb = TICK();
-            __syncthreads();                                          // barrier gc: pieces[gc & 1] ready
-            ACC_T(t_bar, tb); }
-#pragma unroll
-            for (int f = 0; f < PO_FR; ++f) {
-                bh[f] = qb[bhb[f]];
-                bl[f] = qb[bhb[f] + 2 * chs];
-            }
-            step_loop<0, 9>([&](auto tc) {
-                constexpr int tap = decltype(tc)::value;
-                constexpr int nt = tap + 1;
-                constexpr int dh = nt / 3, dw = nt % 3;
-                constexpr int pt = tap + NA - 1;                      // the tap whose A fragments are fetched now
-                if constexpr (pt < 9) {
-                    V2CE_LOAD_A(pt % NA, wc + pt * tap_stride)
-                } else {
-                    V2CE_LOAD_A(pt % NA, wn + (pt - 9) * tap_stride)
-                }
-                const int toff = dh * P.HWd + dw;                     // next tap's offset in the slot's plane
-#pragma unroll
-                for (int f = 0; f < PO_FR; ++f) {
-#pragma unroll
-                    for (int q = 0; q < CO_FR; ++q) {
-                        acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tap % NA][q], bh[f], acc[q][f], 0, 0, 0);
-                        acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tap % NA][q], bl[f], acc[q][f], 0, 0, 0);
-                        acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tap % NA][q], bh[f], acc[q][f], 0, 0, 0);
-                    }
-                    if constexpr (nt < 9) {                           // refill in place for the next tap
-                        bh[f] = qb[bhb[f] + toff];
-                        bl[f] = qb[bhb[f] + toff + 2 * chs];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            });
-        }
-
-        float out_inv_scale = inv_scale;
+        // tail state (TAIL): this slot's half of the channel groups, A fragments double-buffered over the k-steps
+        const long long tplane = TAIL ? (long long)P.tCG * P.Cout * 16 : 0;      // halves per plane of the tail weights
+        const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(TAIL ? P.sc_w : P.wq), 0, (int)(4 * tplane), 0x00020000);
+        const int gbase = (wave == 0 || wave == 3) ? 0 : P.tCG / 2;
+        int bpt[TAIL ? PO_FR : 1];
+        f16x8 ath[2][TAIL ? CO_FR : 1], atl[2][TAIL ? CO_FR : 1];
         if constexpr (TAIL) {
-            const long long tplane = (long long)P.tCG * P.Cout * 16;              // halves per plane of the tail weights
-            const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(P.sc_w), 0, (int)(4 * tplane), 0x00020000);
-            const float t_scale = tscale_of(T.b);
-            const float wt_scale = reinterpret_cast<const float *>(P.sc_w + 2 * tplane)[1];
-            const float rho = (t_scale * wt_scale) / (x_scale * w_scale);         // a power of two: the rescale is exact
-#pragma unroll
-            for (int q = 0; q < CO_FR; ++q)
-#pragma unroll
-                for (int f = 0; f < PO_FR; ++f)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[q][f][r] *= rho;
-            out_inv_scale = 1.0f / (t_scale * wt_scale);
-            const int gbase = (wave == 0 || wave == 3) ? 0 : P.tCG / 2;           // this slot's half of the channel groups
-            const int nstep = P.tCG / 2;
-            int bpt[PO_FR];
 #pragma unroll
             for (int f = 0; f < PO_FR; ++f) bpt[f] = half * chs + wave * kWtSlot + f * 32 + l32;
-            f16x8 ath[2][CO_FR], atl[2][CO_FR];                                   // A fragments, double-buffered over the k-steps
+        }
+        auto chunk_barrier = [&]() -> const f16x8 * {
+            const f16x8 *qb = pieces + (gc & 1) * 4 * chs;
+            [[maybe_unused]] const unsigned long long tb = TICK();
+            __syncthreads();                                          // barrier gc: pieces[gc & 1] ready
+            ACC_T(t_bar, tb);
+            ++gc;
+            return qb;
+        };
+        auto main_chunk = [&](int cg) __attribute__((always_inline)) {          // a 16-channel chunk of the 3x3x3 conv
+            const f16x8 *qb = chunk_barrier();
+                const int wc = slot_off + cg * cg_stride;
+                const int wn = cg + 1 < CG ? wc + cg_stride : slot_off;   // last chunk: chunk 0 again (the next tile's start)
 #pragma unroll
-            for (int q = 0; q < CO_FR; ++q) {
-                ath[0][q] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_t, wlane[q], gbase * cg_stride, 0));
-                atl[0][q] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_t, wlane[q], gbase * cg_stride + (int)(2 * tplane), 0));
+                for (int f = 0; f < PO_FR; ++f) {
+                    bh[f] = qb[bhb[f]];
+                    bl[f] = qb[bhb[f] + 2 * chs];
+                }
+                step_loop<0, 9>([&](auto tc) {
+                    constexpr int tap = decltype(tc)::value;
+                    constexpr int nt = tap + 1;
+                    constexpr int dh = nt / 3, dw = nt % 3;
+                    constexpr int pt = tap + NA - 1;                      // the tap whose A fragments are fetched now
+                    if constexpr (pt < 9) {
+                        V2CE_LOAD_A(pt % NA, wc + pt * tap_stride)
+                    } else {
+                        V2CE_LOAD_A(pt % NA, wn + (pt - 9) * tap_stride)
+                    }
+                    const int toff = dh * P.HWd + dw;                     // next tap's offset in the slot's plane
+#pragma unroll
+                    for (int f = 0; f < PO_FR; ++f) {
+#pragma unroll
+                        for (int q = 0; q < CO_FR; ++q) {
+                            acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tap % NA][q], bh[f], acc[q][f], 0, 0, 0);
+                            acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tap % NA][q], bl[f], acc[q][f], 0, 0, 0);
+                            acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tap % NA][q], bh[f], acc[q][f], 0, 0, 0);
+                        }
+                        if constexpr (nt < 9) {                           // refill in place for the next tap
+                            bh[f] = qb[bhb[f] + toff];
+                            bl[f] = qb[bhb[f] + toff + 2 * chs];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                });
+        };
+        auto tail_prefetch = [&](int kb) __attribute__((always_inline)) {       // the first step's A fragments of tail barrier kb
+            const int w0 = (gbase + 2 * kb) * cg_stride;
+#pragma unroll
+            for (int q = 0; q < (TAIL ? CO_FR : 0); ++q) {
+                ath[0][q] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_t, wlane[q], w0, 0));
+                atl[0][q] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_t, wlane[q], w0 + (int)(2 * tplane), 0));
             }
-            for (int kb = 0; kb < NTB; ++kb, ++gc) {
-                const f16x8 *qb = pieces + (gc & 1) * 4 * chs;
-                { [[maybe_unused]] const unsigned long long tb = TICK();
-                __syncthreads();                                                  // barrier gc: two k-steps of the tail ready
-                ACC_T(t_bar, tb); }
+        };
+        auto tail_barrier = [&](int kb) __attribute__((always_inline)) {        // two k-steps of the folded 1x1x1 tail
+            if constexpr (TAIL) {
+                const f16x8 *qb = chunk_barrier();
+                const int w1 = (gbase + 2 * kb + 1) * cg_stride;      // the second step's A fragments (the first step's are in flight since
+#pragma unroll                                                        // the end of the previous barrier's work)
+                for (int q = 0; q < CO_FR; ++q) {
+                    ath[1][q] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_t, wlane[q], w1, 0));
+                    atl[1][q] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_t, wlane[q], w1 + (int)(2 * tplane), 0));
+                }
 #pragma unroll
                 for (int gs = 0; gs < 2; ++gs) {
-                    const int step = 2 * kb + gs;
-                    if (step) {
-#pragma unroll
-                        for (int q = 0; q < CO_FR; ++q) { ath[0][q] = ath[1][q]; atl[0][q] = atl[1][q]; }
-                    }
-                    const int wn = (gbase + (step + 1 < nstep ? step + 1 : step)) * cg_stride;
-#pragma unroll
-                    for (int q = 0; q < CO_FR; ++q) {
-                        ath[1][q] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_t, wlane[q], wn, 0));
-                        atl[1][q] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_t, wlane[q], wn + (int)(2 * tplane), 0));
-                    }
 #pragma unroll
                     for (int f = 0; f < PO_FR; ++f) {
                         bh[f] = qb[bpt[f] + gs * 128];
@@ -482,13 +503,29 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
                     for (int f = 0; f < PO_FR; ++f)
 #pragma unroll
                         for (int q = 0; q < CO_FR; ++q) {
-                            acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ath[0][q], bh[f], acc[q][f], 0, 0, 0);
-                            acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ath[0][q], bl[f], acc[q][f], 0, 0, 0);
-                            acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(atl[0][q], bh[f], acc[q][f], 0, 0, 0);
+                            acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ath[gs][q], bh[f], acc[q][f], 0, 0, 0);
+                            acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ath[gs][q], bl[f], acc[q][f], 0, 0, 0);
+                            acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(atl[gs][q], bh[f], acc[q][f], 0, 0, 0);
                         }
                 }
             }
+        };
+        if constexpr (!TAIL) {
+            for (int cg = 0; cg < CG; ++cg) main_chunk(cg);
+        } else {
+            // M0 T0 M1 T1 ... while both remain (is_tail / idx_of: the producers walk the same order), then the rest of the longer part
+            for (int i = 0; i < nI; ++i) {
+                main_chunk(i);
+                tail_prefetch(i);
+                tail_barrier(i);
+            }
+            for (int i = nI; i < CG; ++i) main_chunk(i);
+            for (int i = nI; i < NTB; ++i) {
+                tail_prefetch(i);
+                tail_barrier(i);
+            }
         }
+        const float out_inv_scale = inv_scale;
 
         // ---- output transform + epilogue.  This wave stores position fragment f = wave: outputs t = 2p, 2p + 1.
         [[maybe_unused]] const unsigned long long te = TICK();
