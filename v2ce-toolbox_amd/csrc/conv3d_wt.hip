@@ -68,12 +68,15 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 template <int CO_FR, int PO_FR, int RES, bool TAIL = false>
 __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    [[maybe_unused]] unsigned long long t_all = TICK(), t_bar = 0, t_epi = 0, t_xbar = 0, t_cvt = 0;
+    [[maybe_unused]] unsigned long long t_all = TICK(), t_bar = 0, t_epi = 0, t_xbar = 0, t_cvt = 0, t_e0 = 0, t_e1 = 0, t_e2 = 0;
     static_assert(PO_FR == 4, "the output transform hands position fragment f to consumer wave f");
     static_assert(!TAIL || RES == 0, "a folded tail replaces the residual");
     constexpr int CK = 16, NA = 3, CO_TILE = CO_FR * 32, chs = kWtChs;
     constexpr int NX = 2 * CO_FR;                                    // extra barriers per tile (output transform)
     f16x8 *pieces = reinterpret_cast<f16x8 *>(conv_smem);            // [2][4][chs] x 16 B
+    // scale | shift of the tile's CO_TILE channels, read by the epilogue with LDS loads: a global load there would sit behind the
+    // previous round's stores in the in-order vector-memory counter (stamps: 2 k cycles per round waiting for write acknowledges)
+    float *aff = reinterpret_cast<float *>(conv_smem + (size_t)2 * 4 * chs * 16);     // [2][CO_TILE]
 
     const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -388,6 +391,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
         }                                                                                      \
     }
     int ring_co_t = -1;
+    int seen_b = -1;                                                  // range tracking: the batch element and the maximum already committed
+    unsigned seen_max = 0u;
     bool more = true;
     while (more) {
         const int co0 = T.co_t * CO_TILE;
@@ -402,6 +407,12 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
         }
         if (T.co_t != ring_co_t) {                                    // uniform: (re)load the ring for this channel tile
             ring_co_t = T.co_t;
+            // (every consumer wave writes the same values; the tile's chunk barriers separate them from the epilogue's reads,
+            // and the previous tile's reads from these writes: its last rendezvous barrier)
+            if (lane < CO_TILE) {
+                aff[lane] = P.scale[co0 + lane];
+                aff[CO_TILE + lane] = P.shift[co0 + lane];
+            }
 #pragma unroll
             for (int q = 0; q < CO_FR; ++q) {
                 int co = co0 + q * 32 + l32;
@@ -561,19 +572,25 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
         }
         const float slope = act_slope(P.act);
         unsigned ymax = 0u;
+        [[maybe_unused]] unsigned long long te2 = 0;
+        f32x4t rvq[2][2][4];                                          // residual of a round: [buffer][output 2p | 2p+1][r4]
+        // channels co0 + 32 q + 8 r4 + 4 half + {0..3}: group (co0 / 16 + 2 q + (r4 >> 1)), bytes 32 (r4 & 1) + 16 half inside it
+        auto soff_of = [&](int q, int r4) -> int { return (co0 / 16 + 2 * q + (r4 >> 1)) * gstride + 32 * (r4 & 1); };
+        auto load_res = [&](int q, f32x4t (&rv)[2][4]) {
 #pragma unroll
-        for (int q = 0; q < CO_FR; ++q) {
-            // channels co0 + 32 q + 8 r4 + 4 half + {0..3}: group (co0 / 16 + 2 q + (r4 >> 1)), bytes 32 (r4 & 1) + 16 half inside it
-            auto soff = [&](int r4) -> int { return (co0 / 16 + 2 * q + (r4 >> 1)) * gstride + 32 * (r4 & 1); };
-            f32x4t rv[2][4], scq[4], shq[4];
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
+            for (int r4 = 0; r4 < 4; ++r4)
 #pragma unroll
                 for (int o = 0; o < 2; ++o) {
-                    if constexpr (RES) rv[o][r4] = __builtin_bit_cast(f32x4t, __builtin_amdgcn_raw_buffer_load_b128(rs_r, vo[o], soff(r4), 0));
+                    if constexpr (RES) rv[o][r4] = __builtin_bit_cast(f32x4t, __builtin_amdgcn_raw_buffer_load_b128(rs_r, vo[o], soff_of(q, r4), 0));
                     else rv[o][r4] = f32x4t{0.0f, 0.0f, 0.0f, 0.0f};
                 }
-            }
+        };
+#pragma unroll
+        for (int q = 0; q < CO_FR; ++q) {
+            auto soff = [&](int r4) -> int { return soff_of(q, r4); };
+            f32x4t scq[4], shq[4];
+            f32x4t (&rv)[2][4] = rvq[q & 1];
+            if (q == 0) load_res(0, rvq[0]);
             // (round q > 0: the previous round's reads are behind its second barrier)
 #pragma unroll
             for (int f = 0; f < PO_FR; ++f)
@@ -583,13 +600,17 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
                     v[0] = acc[q][f][4 * r4]; v[1] = acc[q][f][4 * r4 + 1]; v[2] = acc[q][f][4 * r4 + 2]; v[3] = acc[q][f][4 * r4 + 3];
                     xch[f * chs + wave * kWtSlot + r4 * 64 + lane] = v;
                 }
+            // the next round's residual: issued now (its accumulators' registers are free) and IN FRONT of this round's stores
+            if (q + 1 < CO_FR) load_res(q + 1, rvq[(q + 1) & 1]);
+            ACC_T(t_e0, q == 0 ? te : te2);
             { [[maybe_unused]] const unsigned long long tb = TICK();
             lds_barrier();
             ACC_T(t_xbar, tb); }
+            [[maybe_unused]] const unsigned long long te1 = TICK();
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {                          // (cache hits after the first tiles; behind the barrier for the registers' sake)
-                scq[r4] = *reinterpret_cast<const f32x4t *>(P.scale + co0 + 32 * q + 8 * r4 + 4 * half);
-                shq[r4] = *reinterpret_cast<const f32x4t *>(P.shift + co0 + 32 * q + 8 * r4 + 4 * half);
+            for (int r4 = 0; r4 < 4; ++r4) {
+                scq[r4] = *reinterpret_cast<const f32x4t *>(aff + 32 * q + 8 * r4 + 4 * half);
+                shq[r4] = *reinterpret_cast<const f32x4t *>(aff + CO_TILE + 32 * q + 8 * r4 + 4 * half);
             }
 #pragma unroll
             for (int hp = 0; hp < 2; ++hp) {                          // two r4 per pass: 32 registers of transformed sums at a time
@@ -599,9 +620,11 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) mm[rr][jj] = xch[wave * chs + jj * kWtSlot + (2 * hp + rr) * 64 + lane];
                 if (hp == 1) {
+                    ACC_T(t_e1, te1);
                     [[maybe_unused]] const unsigned long long tb = TICK();
                     lds_barrier();                                    // reads done: the next round / the producers may write
                     ACC_T(t_xbar, tb);
+                    te2 = TICK();
                 }
 #pragma unroll
                 for (int rr = 0; rr < 2; ++rr) {
@@ -625,15 +648,30 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
                 }
             }
         }
-        if (P.y_absmax) absmax_commit(__builtin_bit_cast(float, ymax), P.y_absmax + T.b * P.amax_bs);
+        if (P.y_absmax) {
+            // max |y| of the tile -> the launch's range slot.  absmax_commit reads the slot first (a global load the wave then waits
+            // for: ~1.5 k cycles per tile); here the wave remembers the largest value it has already committed for this batch element
+            // and sends an atomic (no return value, nothing to wait for) only beyond that
+#pragma unroll
+            for (int o = 32; o; o >>= 1) {
+                const unsigned other = (unsigned)__shfl_xor((int)ymax, o);
+                ymax = other > ymax ? other : ymax;
+            }
+            if (T.b != seen_b) { seen_b = T.b; seen_max = 0u; }
+            if (ymax > seen_max) {                                    // uniform
+                seen_max = ymax;
+                if (lane == 0) atomicMax(reinterpret_cast<unsigned *>(P.y_absmax + T.b * P.amax_bs), ymax);
+            }
+        }
         ACC_T(t_epi, te);
+        ACC_T(t_e2, te2);
         vb += (int)gridDim.x;
         more = next_tile(vb, T);
     }
 #ifdef V2CE_STAMP
     if (lane == 0 && wave == 0) {
         unsigned long long *o = P.stamps + ((long long)blockIdx.x * 2 + 0) * 8;
-        o[0] = TICK() - t_all; o[1] = t_bar; o[2] = t_xbar; o[3] = t_epi; o[4] = (unsigned long long)gc;
+        o[0] = TICK() - t_all; o[1] = t_bar; o[2] = t_xbar; o[3] = t_epi; o[4] = (unsigned long long)gc; o[5] = t_e0; o[6] = t_e1; o[7] = t_e2;
     }
 #endif
 #undef V2CE_LOAD_A
@@ -819,7 +857,7 @@ int launch_wt(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream) {
     }
     const long long blocks = (long long)8 * P.per_xcd * P.n_co_tiles;
     P.total_blocks = (int)blocks;
-    const size_t lds = (size_t)kWtChs * (2 * 4 * 16);      // 128 KB
+    const size_t lds = (size_t)kWtChs * (2 * 4 * 16) + 2 * CO_TILE * sizeof(float);      // 128 KB of pieces + scale | shift of the tile's channels
     auto kern = conv3d_wt_kernel<CO_FR, PO_FR, RES, TAIL>;
     static const int once = [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -853,6 +891,8 @@ int launch_wt(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream) {
                 CO_FR, PO_FR, RES, P.Cin, P.Cout, d.Hout, d.Wout, bx.pp, bx.th, bx.tw, tiles, chunks, tot, 100 * mean(0, 1) / tot, 100 * mean(0, 3) / tot,
                 100 * mean(0, 2) / tot, 100 * (tot - mean(0, 1) - mean(0, 3)) / tot, (tot - mean(0, 1) - mean(0, 3)) / chunks, 100 * mean(1, 1) / mean(1, 0),
                 100 * mean(1, 2) / mean(1, 0), 100 * mean(1, 3) / mean(1, 0));
+        fprintf(stderr, "    epilogue per tile (cycles): loads + dump (incl. the previous round's compute and stores) %.0f, first barrier .. reads %.0f, last compute + stores + range %.0f, barriers %.0f\n",
+                mean(0, 5) / tiles, mean(0, 6) / tiles, mean(0, 7) / tiles, mean(0, 2) / tiles);
     }
 #endif
     return V2CE_OK;
