@@ -373,7 +373,8 @@ int v2ce_conv3d_up2_variant(const v2ce_conv3d_desc *desc, int with_shortcut, cha
  * in f32: the result differs from v2ce_conv3d_fwd's by rounding (1e-6 relative), inside the 1e-5 parity bar of the network
  * (csrc/conv3d_wt.hip; tools/winograd_t_sim.py).  desc: ksize 3, stride 1, precision F16X2, layout C16, C1 = 0 (x = x0 of C0
  * channels, H0 = Hin = Hout, W0 = Win = Wout), C0 % 16 == 0, Cout % 64 == 0.  w_wt = buffer of v2ce_pack_weights_f16x2_wt
- * (the transformed weights of W / sigma: 36 tap slots of [C0 / 16][Cout][16] per fp16 plane, then { max |G|, pre-scale, 0, 0 }).
+ * (the transformed weights of W / sigma: 36 tap slots of [C0 / 16][Cout][16] per fp16 plane, then { 1.5 max |W / sigma| >= max |G|,
+ * pre-scale, 0, 0 }).
  * residual (may be NULL): added before the activation, layout of y.  x_absmax / y_absmax as for v2ce_conv3d_fwd. */
 size_t v2ce_pack_weights_f16x2_wt_bytes(int Cout, int Cin);
 int v2ce_pack_weights_f16x2_wt(const float *w, int Cout, int Cin, const float *sigma, void *w_wt, v2ce_stream_t stream);

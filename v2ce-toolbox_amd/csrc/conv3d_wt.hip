@@ -679,9 +679,11 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// weights: G_j of W / sigma as fp16 hi / lo planes [2][slot * 9 + dh * 3 + dw][Cin / 16][Cout][16], tail { max |G|, pre-scale, 0, 0 }.
+// weights: G_j of W / sigma as fp16 hi / lo planes [2][slot * 9 + dh * 3 + dw][Cin / 16][Cout][16], tail { bound on |G|, pre-scale, 0, 0 }.
 // A workgroup takes 32 output channels x one 16-channel group (32 runs of 432 contiguous floats of W), like sn_batch_pack_kernel.
-// PASS 0: max |G| into tail[0] (atomic max on the bit pattern; the caller zeroes it); PASS 1: the planes.
+// PASS 0: the bound 1.5 max |W / sigma| >= max |G| (|(g0 +- g1 + g2) / 2| <= 1.5 max |g|) into tail[0] (atomic max on the bit pattern;
+// the caller zeroes it) -- the spectral-norm batch knows max |W| from its own passes and writes the same value without this pass
+// (sn.hip, 0.1 ms per call for the ten layers); PASS 1: the planes, pre-scaled by the power of two derived from tail[0].
 // ---------------------------------------------------------------------------------------------
 constexpr int kWtMaxBatch = 16;
 struct WtLayer {
@@ -735,13 +737,14 @@ __global__ __launch_bounds__(256) void wt_pack_kernel(WtBatch B) {
                 hi[(s * 9 + t9) * 514 + col * 16 + j] = h;
                 lo[(s * 9 + t9) * 514 + col * 16 + j] = (_Float16)(v - (float)h);
             } else {
-                m = fmaxf(m, fabsf(G[s]));
+                m = fmaxf(m, fabsf(s == 1 ? g1 : G[s]));              // max |g| over the three time taps (G[0] = g0, G[3] = g2)
             }
         }
     }
     if (!PASS) {
 #pragma unroll
         for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        m *= 1.5f;
         if ((threadIdx.x & 63) == 0 && __float_as_uint(m) > __atomic_load_n(reinterpret_cast<unsigned *>(tail), __ATOMIC_RELAXED))
             atomicMax(reinterpret_cast<unsigned *>(tail), __float_as_uint(m));
         return;

@@ -224,9 +224,10 @@ __global__ __launch_bounds__(1024) void sn_batch_finalize_kernel(SnBatch B) {
         for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = fmaxf(m, mxs[i]);
         const float sg = (float)dot;
         P.sigma[0] = sg;
-        if (P.wt) {                                            // Winograd-T planes: max |G| comes from the pack's first pass
+        if (P.wt) {                                            // Winograd-T planes: the bound 1.5 max |w / sigma| of conv3d_wt.hip's pack, pass 0
             float *tail = reinterpret_cast<float *>(P.packed + 2ll * P.rows * P.cin * 36);
-            tail[0] = 0.0f; tail[1] = 0.0f; tail[2] = 0.0f; tail[3] = 0.0f;
+            const float bound = 1.5f * fabsf(m / sg);
+            tail[0] = bound; tail[1] = pow2_prescale(bound); tail[2] = 0.0f; tail[3] = 0.0f;
             return;
         }
         float *tail = reinterpret_cast<float *>(P.packed + 2ll * P.rows * P.cols);
@@ -390,8 +391,8 @@ extern "C" int v2ce_sn_update_batch(const v2ce_sn_layer *layers, int n, void *wo
             wt_rows[n_wt] = B.L[l].rows; wt_cin[n_wt] = B.L[l].cin;
             ++n_wt;
         }
-    for (int pass = 0; pass < 2 && n_wt; ++pass) {
-        const int rc = v2ce_wt_pack_batch(wt_w, wt_sigma, wt_packed, wt_rows, wt_cin, n_wt, pass, st);
+    if (n_wt) {                                            // (pass 0 -- the bound on |G| -- is what the finalize kernel has just written)
+        const int rc = v2ce_wt_pack_batch(wt_w, wt_sigma, wt_packed, wt_rows, wt_cin, n_wt, 1, st);
         if (rc != V2CE_OK) return rc;
     }
     int k3max = 1;
