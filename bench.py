@@ -465,9 +465,9 @@ def main():
     if model is not None:
         name = max(per, key=lambda k: per[k][0])
         v = per[name]
-        split = "f16x2" in name or "up_kernel" in name
+        split = "f16x2" in name or "up_kernel" in name or "wt_kernel" in name
         peak = PEAK_SPLIT_TFLOPS if split else PEAK_F32_MATRIX_TFLOPS
-        ws3 = [q[3] / q[0] / 1e12 / PEAK_SPLIT_TFLOPS for k, q in per.items() if "ws_kernel<3," in k or "up_kernel<" in k]
+        ws3 = [q[3] / q[0] / 1e12 / PEAK_SPLIT_TFLOPS for k, q in per.items() if "ws_kernel<3," in k or "up_kernel<" in k or "wt_kernel<" in k]
         roofline = {"bound": "mfma", "kernel": name, "achieved": v[1] / v[0] / 1e12,
                     "peak": peak, "unit": "TFLOP/s",
                     "frac": v[1] / v[0] / 1e12 / peak, "traffic": None,
@@ -480,7 +480,8 @@ def main():
                     "min_3x3x3_split_variant_frac": min(ws3) if ws3 else None,
                     "frac_note": "achieved / frac count the ALGORITHMIC flop of the reference's convolution (SURVEY 8d: 135.58 GFLOP per "
                                  "frame-pair); executed_* count what the launch really multiplies (the decoder conv1 kernels fold the "
-                                 "2x-upsampled channels' 27 taps into 12: DESIGN 4.1e); min_3x3x3_split_variant_frac is on executed flop"}
+                                 "2x-upsampled channels' 27 taps into 12: DESIGN 4.1e; the Winograd-T kernels multiply 36 instead of 54 "
+                                 "times per pair of time steps: DESIGN 4.1g); min_3x3x3_split_variant_frac is on executed flop"}
     else:
         roofline = {"bound": "hbm", "kernel": "v2ce_ldati_count + v2ce_ldati_emit (count_tiles, tile_scan, tile_pass, bucket_scan, bucket_sort)",
                     "achieved": ldati["achieved_GBps"],
