@@ -501,14 +501,23 @@ def main():
         if prov.get("source_hash") != my_hash:
             raise LookupError(f"{os.path.basename(path)} was collected from other kernel sources ({prov.get('source_hash')} != {my_hash})")
         return data, prov
+    def counter_key(table):
+        """The counter tables carry rocprofv3's demangled names (a bool template argument prints as true / false)."""
+        k = roofline["kernel"].replace(" ", "")
+        if k in table:
+            return k
+        for a, b in ((",1>", ",true>"), (",0>", ",false>")):
+            if k.endswith(a) and k[:-len(a)] + b in table:
+                return k[:-len(a)] + b
+        return k
+
     stale = []
     try:
         import glob
         files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{args.workload}_pmc_traffic.json")))
         pmc, prov = fresh(files[-1])
         if model is not None:
-            key = roofline["kernel"].replace(" ", "")
-            roofline["traffic"] = pmc[key]["traffic_bytes"]
+            roofline["traffic"] = pmc[counter_key(pmc)]["traffic_bytes"]
         else:   # all ldati_* kernels of one steady-state call: one-time device checks and the kernels of the first call only
             # (a fused pass whose expectation missed, its two-pass repeat: at most half the launches of the others) left out
             ld = {k: v for k, v in pmc.items() if k.startswith("ldati_") and not any(x in k for x in ("check", "probe", "slope_tab", "commit"))}
@@ -526,7 +535,7 @@ def main():
         if model is not None:
             files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_e2e_mfma_busy.json")))
             data, prov = fresh(files[-1])
-            mb = data[roofline["kernel"].replace(" ", "")]
+            mb = data[counter_key(data)]
             roofline["mfma_busy"] = mb["mfma_busy"]
             roofline["mfma_busy_source"] = os.path.basename(files[-1]) + f" (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8), avg per launch; {prov['lib_version']}, sources {prov['source_hash']})"
         else:
