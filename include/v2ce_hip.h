@@ -364,6 +364,12 @@ int v2ce_conv3d_fwd_up2(const v2ce_conv3d_desc *desc, const float *x0, const flo
                         const float *scale, const float *shift, float *y, const float *x0_absmax,
                         const float *x1_absmax, float *y_absmax, const void *sc_w, const float *sc_scale,
                         const float *sc_shift, float *sc_y, v2ce_stream_t stream);
+/* The upsampled channels' share of the same convolution alone: y = scale * conv(upsample(x0); W[:, :C0]) + shift, no activation (desc.act
+ * is ignored), for a caller that computes the skip channels' share with another launch and adds this output as that launch's residual
+ * (conv1 of the wide decoder blocks: the skip channels on the Winograd-T kernel, v2ce_conv3d_fwd_wt with a v2ce_pack_weights_f16x2_wt_slice
+ * buffer of channels [C0, C0 + C1)).  desc and w_up exactly as for v2ce_conv3d_fwd_up2 (the buffer of the whole layer). */
+int v2ce_conv3d_fwd_up2_part(const v2ce_conv3d_desc *desc, const float *x0, const void *w_up, const float *scale, const float *shift,
+                             float *y, const float *x0_absmax, const float *x1_absmax, float *y_absmax, v2ce_stream_t stream);
 /* Name of the kernel instantiation v2ce_conv3d_fwd_up2 would launch ("conv3d_up_kernel<WCO,CO_FR,PO_FR,FUSE>"). */
 int v2ce_conv3d_up2_variant(const v2ce_conv3d_desc *desc, int with_shortcut, char *name, size_t cap);
 
@@ -378,6 +384,10 @@ int v2ce_conv3d_up2_variant(const v2ce_conv3d_desc *desc, int with_shortcut, cha
  * residual (may be NULL): added before the activation, layout of y.  x_absmax / y_absmax as for v2ce_conv3d_fwd. */
 size_t v2ce_pack_weights_f16x2_wt_bytes(int Cout, int Cin);
 int v2ce_pack_weights_f16x2_wt(const float *w, int Cout, int Cin, const float *sigma, void *w_wt, v2ce_stream_t stream);
+/* the same for input channels [ci0, ci0 + Cin) of a [Cout][Cin_total][27] tensor (ci0 % 16 == 0); the pre-scale bound is taken over the
+ * whole tensor (what v2ce_sn_update_batch writes for v2ce_sn_layer.packed_skip) */
+int v2ce_pack_weights_f16x2_wt_slice(const float *w, int Cout, int Cin_total, int ci0, int Cin, const float *sigma, void *w_wt,
+                                     v2ce_stream_t stream);
 int v2ce_conv3d_fwd_wt(const v2ce_conv3d_desc *desc, const float *x, const void *w_wt, const float *scale, const float *shift,
                        const float *residual, float *y, const float *x_absmax, float *y_absmax, v2ce_stream_t stream);
 /* The same with the block's folded 1x1x1 shortcut in the launch's K loop -- the contract of v2ce_conv3d_fwd_tail (tail_desc,
@@ -478,6 +488,9 @@ typedef struct {
     int32_t wt;           /* 1: `packed` is a v2ce_pack_weights_f16x2_wt buffer instead (Winograd-T planes of w_bar / sigma, k3 = 27,
                            * up_c0 = 0); 0: the plain planes */
     int32_t reserved;     /* 0 */
+    void *packed_skip;    /* NULL, or (up_c0 > 0): also write the Winograd-T planes of input channels [up_c0, Cin) of w_bar / sigma --
+                           * a v2ce_pack_weights_f16x2_wt_bytes(rows, Cin - up_c0) buffer, as v2ce_pack_weights_f16x2_wt_slice does --
+                           * for the split launch of a decoder conv1 (v2ce_conv3d_fwd_up2_part + v2ce_conv3d_fwd_wt) */
 } v2ce_sn_layer;
 size_t v2ce_sn_batch_workspace_bytes(const v2ce_sn_layer *layers, int n);
 int v2ce_sn_update_batch(const v2ce_sn_layer *layers, int n, void *workspace, size_t workspace_bytes,

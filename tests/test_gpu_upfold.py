@@ -210,3 +210,42 @@ def test_head_split_half_vs_f64(case):
         assert abs(slots[0, b, 0] - float(x[b].abs().max())) <= 1e-6 * float(x[b].abs().max())       # max |x| of the sequence
         assert abs(slots[1, b, 0] - np.abs(want[b]).max()) <= 2e-5 * max(1.0, np.abs(want[b]).max())  # max |y|
         assert 0 < slots[1, b, 1] < 2.5e-6                                                           # its guard value
+
+
+@pytest.mark.parametrize("case", [(1, 4, 128, 64, 64, 26, 35), (2, 16, 256, 128, 128, 17, 23), (1, 5, 64, 32, 64, 21, 27)])
+def test_conv3d_up2_split_launch_vs_f64(case):
+    """conv1 of a wide decoder block as two launches (v2ce_conv3d_fwd_up2_part: the upsampled channels, phase-folded, no activation;
+    v2ce_conv3d_fwd_wt: the skip channels on the Winograd-T kernel with the first launch's output as its residual): the f64
+    convolution of upsample(x0) ++ x1, and the partial sum alone."""
+    from v2ce_toolbox_amd import hip
+    from v2ce_toolbox_amd.v2ce_3d import V2ce3d
+    B, T, C0, C1, Cout, H, W = case
+    H0, W0 = (H + 1) // 2, (W + 1) // 2
+    g = torch.Generator().manual_seed(C0 + 5 * H + W)
+    amp = 0.25 if (C0 + C1) * 27 > 8000 else 1.0
+    x0 = amp * torch.randn(B, C0, T, H0, W0, generator=g)
+    x1 = amp * torch.randn(B, C1, T, H, W, generator=g)
+    w = torch.randn(Cout, C0 + C1, 3, 3, 3, generator=g) * (2.0 / ((C0 + C1) * 27)) ** 0.5
+    sc1, sh1 = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    sigma = torch.tensor([1.3], device="cuda")
+    m = _model()
+    xd0, xd1 = to_btchw(x0).cuda(), to_btchw(x1).cuda()
+    xd0.absmax, xd1.absmax = xd0.abs().max().reshape(1), xd1.abs().max().reshape(1)
+    c0, c1 = V2ce3d.to_c16(xd0), V2ce3d.to_c16(xd1)
+    wq = _up_weights(m, w, C0, sigma)
+    sk = V2ce3d._split_buffer(Cout, C1, 27, "cuda", wt=True)
+    sk.ci0 = C0
+    V2ce3d._pack(m, w.cuda().contiguous(), sigma, sk, split=True)
+    assert V2ce3d._up2_ok(m, c0, c1, wq, (H, W))
+    m.profile = []
+    part = V2ce3d._conv_up_part(m, c0, c1, wq, sc1.cuda(), sh1.cuda(), Cout, (H, W))
+    y = V2ce3d._conv(m, c1, None, sk, sc1.cuda(), torch.zeros(Cout, device="cuda"), Cout, 3, 1, hip.ACT_RELU, residual=part, split=True)
+    torch.cuda.synchronize()
+    assert "conv3d_up_kernel" in m.profile[0][0] and "conv3d_wt_kernel" in m.profile[1][0], [p[0] for p in m.profile]
+    ws = w / 1.3
+    w_up_only = ws.clone()
+    w_up_only[:, C0:] = 0
+    assert_close(V2ce3d.to_planar(part).permute(0, 2, 1, 3, 4).cpu().numpy(),
+                 ref_conv(x0, w_up_only, sc1, sh1, 3, 1, 0, x1=x1, up_to=(H, W)), f"partial sum {case}")
+    assert_close(V2ce3d.to_planar(y).permute(0, 2, 1, 3, 4).cpu().numpy(),
+                 ref_conv(x0, ws, sc1, sh1, 3, 1, 1, x1=x1, up_to=(H, W)), f"split conv1 {case}")

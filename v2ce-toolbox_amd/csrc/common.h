@@ -57,7 +57,8 @@ int v2ce_up_fold_pack(const float *w, int Cout, int Cin, int C0, const float *si
 
 // the Winograd planes (conv3d_wt.hip) of up to 16 layers in one launch per pass: pass 0 raises tail[0] (zeroed by the caller) to
 // max |G|, pass 1 derives the pre-scale from it and writes the planes; sigma[l]: device scalar or null
+// cin_total / ci0 (may be null: the whole tensor): layer l packs input channels [ci0[l], ci0[l] + cin[l]) of a [rows][cin_total[l]][27] tensor
 int v2ce_wt_pack_batch(const float *const *w, const float *const *sigma, void *const *packed, const int *rows, const int *cin, int n, int pass,
-                       hipStream_t st);
+                       hipStream_t st, const int *cin_total = nullptr, const int *ci0 = nullptr);
 
 }  // namespace v2ce

@@ -76,6 +76,8 @@ struct UpParams {
     int dbg;                      // timing experiments (V2CE_UP_DBG; WRONG results): 1 = stores dropped by the range check, 2 = no epilogue
     int HWh;                      // HWd / 2: first odd column of the de-interleaved skip halo
     int CG0;                      // C0 / 16
+    int part;                     // 1: only the upsampled channels' chunks run (v2ce_conv3d_fwd_up2_part): the skip channels' share of the
+                                  // convolution comes from another launch that adds this one's output as its residual
     int odd_h, odd_w;
     int fold_off;                 // bytes from wq to the folded region's hi plane
     int fold_plane;               // bytes between its hi and lo planes
@@ -238,6 +240,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_up_kernel(UpParams U) {
     const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int CG = P.Cin / CK, CG0 = U.CG0;
+    const int CGE = U.part ? CG0 : CG;                                       // chunks a tile runs (the weight buffer's strides keep CG)
     const long long wplane = (long long)K3 * CG * P.Cout * 16;               // halves per plane of the plain region
     const int tap_stride = CG * P.Cout * 32, tap_stride0 = CG0 * P.Cout * 32, cg_stride = P.Cout * 32;
 
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_up_kernel(UpParams U) {
         auto load_next = [&](float (&R)[CK][EPT]) {
             if (!moreL) return;
             load_chunk(TL, cgL, R);
-            if (++cgL == CG) {
+            if (++cgL == CGE) {
                 cgL = 0;
                 vbL += (int)gridDim.x;
                 moreL = next_tile(vbL, TL);
@@ -388,7 +391,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_up_kernel(UpParams U) {
         bool moreC = true;
         auto advance = [&]() {
             ++gc;
-            if (++cgC == CG) {
+            if (++cgC == CGE) {
                 cgC = 0;
                 vb += (int)gridDim.x;
                 moreC = next_tile(vb, T);
@@ -638,7 +641,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_up_kernel(UpParams U) {
         for (int cg = 0; cg < CG0; ++cg, ++gc) {
             const f16x8 *qb = chunk_head(cg);
             // after this chunk's last list: the next upsampled chunk's first list, or the first skip chunk's
-            const ListRef after = cg + 1 < CG0 ? list0(phase_of(0), cg + 1) : list1(CG0);
+            const ListRef after = cg + 1 < CG0 ? list0(phase_of(0), cg + 1) : (CGE > CG0 ? list1(CG0) : list0(phase_of(0), 0));
             step_loop<0, NG>([&](auto gcst) {
                 constexpr int g = decltype(gcst)::value;
                 const int p = phase_of(g), ph = p >> 1, pw = p & 1;
@@ -669,7 +672,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_up_kernel(UpParams U) {
         }
         // ---- skip chunks
         set_bases(true, 0);
-        for (int cg = CG0; cg < CG; ++cg, ++gc) {
+        for (int cg = CG0; cg < CGE; ++cg, ++gc) {
             const f16x8 *qb = chunk_head(cg);
             // the last chunk prefetches the first list of the next tile with the same channel tile
             const ListRef nxt = cg + 1 < CG ? list1(cg + 1) : list0(phase_of(0), 0);
@@ -1099,9 +1102,10 @@ extern "C" int v2ce_pack_weights_f16x2_up(const float *w, int Cout, int C0, int 
 static int up_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const float *x1, const void *w_up,
                        const float *scale, const float *shift, float *y, const float *x0_absmax,
                        const float *x1_absmax, float *y_absmax, const void *sc_w, const float *sc_scale,
-                       const float *sc_shift, float *sc_y, v2ce_stream_t stream) {
+                       const float *sc_shift, float *sc_y, v2ce_stream_t stream, bool part = false) {
     clear_error();
-    V2CE_REQUIRE(desc && (g_up_name_out || (x0 && x1 && w_up && scale && shift && y)), V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd_up2: null pointer");
+    V2CE_REQUIRE(desc && (g_up_name_out || (x0 && (x1 || part) && w_up && scale && shift && y)), V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd_up2: null pointer");
+    V2CE_REQUIRE(!part || !sc_w, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd_up2_part: no fused shortcut on a partial launch");
     const v2ce_conv3d_desc &d = *desc;
     V2CE_REQUIRE(d.B > 0 && d.T > 0 && d.C0 > 0 && d.C1 > 0 && d.Hin > 0 && d.Win > 0 && d.Cout > 0, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd_up2: bad shape");
     V2CE_REQUIRE(d.ksize == 3 && d.stride_hw == 1 && d.precision == V2CE_PRECISION_F16X2 && d.layout == V2CE_LAYOUT_C16, V2CE_ERR_UNSUPPORTED,
@@ -1140,6 +1144,7 @@ static int up_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const floa
     V2CE_REQUIRE(P.amax_bs == 0 || P.amax_bs >= 2, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd_up2: absmax_batch_stride must be 0 or >= 2");
     P.sc_w = static_cast<const _Float16 *>(sc_w); P.sc_scale = sc_scale; P.sc_shift = sc_shift; P.sc_y = sc_y;
     U.CG0 = d.C0 / 16;
+    U.part = part ? 1 : 0;
     U.odd_h = d.Hout & 1; U.odd_w = d.Wout & 1;
     U.fold_off = (int)up_fold_off(d.Cout, P.Cin);
     U.fold_plane = (int)((size_t)kUpSlots * d.C0 * d.Cout * 2);
@@ -1197,6 +1202,12 @@ extern "C" int v2ce_conv3d_fwd_up2(const v2ce_conv3d_desc *desc, const float *x0
                                    const float *sc_shift, float *sc_y, v2ce_stream_t stream) {
     g_up_name_out = nullptr;
     return up_dispatch(desc, x0, x1, w_up, scale, shift, y, x0_absmax, x1_absmax, y_absmax, sc_w, sc_scale, sc_shift, sc_y, stream);
+}
+
+extern "C" int v2ce_conv3d_fwd_up2_part(const v2ce_conv3d_desc *desc, const float *x0, const void *w_up, const float *scale, const float *shift,
+                                        float *y, const float *x0_absmax, const float *x1_absmax, float *y_absmax, v2ce_stream_t stream) {
+    g_up_name_out = nullptr;
+    return up_dispatch(desc, x0, nullptr, w_up, scale, shift, y, x0_absmax, x1_absmax, y_absmax, nullptr, nullptr, nullptr, nullptr, stream, true);
 }
 
 extern "C" int v2ce_conv3d_up2_variant(const v2ce_conv3d_desc *desc, int with_shortcut, char *name, size_t cap) {

@@ -169,11 +169,28 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
     TileId T;
     if (!next_tile(vb, T)) return;
     int gc = 0;                                                       // chunks handled so far: pieces buffer gc & 1
+    // In rectangle mode a lane's (pair, row, column) inside the box does not depend on the tile: decoded once (two integer divisions
+    // by run-time values per position -- ~100 VALU instructions; per tile they were 2 k cycles of a 64-channel layer's 47 k).
+    // Range tiles (P.flat) decode per tile: their rows depend on where the range starts.
+    struct Pos { int pp, th, tw; bool ok; };
+    auto pos_cached = [&](int m) -> Pos {
+        Pos q{0, 0, 0, false};
+        if (!P.flat) q.ok = pos_of(m, T, q.pp, q.th, q.tw);
+        return q;
+    };
+    auto pos_get = [&](const Pos &c, int m, const TileId &L) -> Pos {
+        if (!P.flat) return c;
+        Pos q;
+        q.ok = pos_of(m, L, q.pp, q.th, q.tw);
+        return q;
+    };
 
     if (wave >= 4) {
         // ------------------------------------------------------------------ producers
         const int ptid = tid - 256;                                   // = the element (p, hh, hw) of the halo box this lane owns
         const bool wave_on = (wave - 4) * 64 < P.plane;               // wave-uniform
+        const int e_pp = ptid / (P.HH * P.HWd), e_hh = (ptid - e_pp * (P.HH * P.HWd)) / P.HWd, e_hw = ptid - e_pp * (P.HH * P.HWd) - e_hh * P.HWd;
+        const Pos tpos = pos_cached(ptid & 127);                      // (tail: the output pair-position this lane gathers for)
         float x_scale = xs_of(T.b);
         float t_scale = TAIL ? ts_of(T.b) : 1.0f;
         unsigned toff[2][2];                                          // tail: [source][time step 2p, 2p+1] of this lane's output position
@@ -230,21 +247,18 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
             if (cidx == 0) {                                          // uniform: a new tile
                 if constexpr (TAIL) {
                     // the tail's gather position of this lane, its index-map entries requested now and used one barrier later
-                    int pp, th, tw;
-                    tm_ok = pos_of(ptid & 127, L, pp, th, tw) && L.h0 + th < P.Hout && L.w0 + tw < P.Wout;
-                    tm_pp = pp;
-                    tm_hi = tm_ok ? (L.h0 + th) * P.tS : 0;
-                    tm_wi = tm_ok ? (L.w0 + tw) * P.tS : 0;
+                    const Pos q = pos_get(tpos, ptid & 127, L);
+                    tm_ok = q.ok && L.h0 + q.th < P.Hout && L.w0 + q.tw < P.Wout;
+                    tm_pp = q.pp;
+                    tm_hi = tm_ok ? (L.h0 + q.th) * P.tS : 0;
+                    tm_wi = tm_ok ? (L.w0 + q.tw) * P.tS : 0;
                     tm_hs = P.thmap ? P.thmap[tm_hi] : tm_hi;
                     tm_ws = P.twmap ? P.twmap[tm_wi] : tm_wi;
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) goff[i] = kOOB;
                 if (ptid < P.plane) {
-                    const int pp = ptid / (P.HH * P.HWd);
-                    const int rem = ptid - pp * (P.HH * P.HWd);
-                    const int hh = rem / P.HWd;
-                    const int hw = rem - hh * P.HWd;
+                    const int pp = e_pp, hh = e_hh, hw = e_hw;
                     const int h = L.h0 - 1 + hh, w = L.w0 - 1 + hw;
                     if (h >= 0 && h < P.Hin && w >= 0 && w < P.Win) {
 #pragma unroll
@@ -390,6 +404,19 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
             al[slot_][q] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_a, wlane[q], so_ + lo_off, 0)); \
         }                                                                                      \
     }
+    // this lane's offset in the slot's plane for each of its fragments (-1: no position), and (pair << 20 | row << 10 | column) of the
+    // position it stores (-1: none) -- one register each across the main loop
+    int crel[PO_FR];
+#pragma unroll
+    for (int f = 0; f < PO_FR; ++f) {
+        const Pos q = pos_cached(f * 32 + l32);
+        crel[f] = q.ok ? (q.pp * P.HH + q.th) * P.HWd + q.tw : -1;
+    }
+    int spk;
+    {
+        const Pos q = pos_cached(wave * 32 + l32);
+        spk = q.ok ? (q.pp << 20) | (q.th << 10) | q.tw : -1;
+    }
     int ring_co_t = -1;
     int seen_b = -1;                                                  // range tracking: the batch element and the maximum already committed
     unsigned seen_max = 0u;
@@ -402,8 +429,13 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
         for (int f = 0; f < PO_FR; ++f) {
             const int m = f * 32 + l32;                               // pair-position (p, h, w) of the box
             bhb[f] = half * chs + wave * kWtSlot;
-            int pp, th, tw;
-            if (pos_of(m, T, pp, th, tw)) bhb[f] += (pp * P.HH + th) * P.HWd + tw;
+            if (!P.flat) {
+                bhb[f] += crel[f] >= 0 ? crel[f] : 0;
+            } else {
+                Pos q;
+                q.ok = pos_of(m, T, q.pp, q.th, q.tw);
+                if (q.ok) bhb[f] += (q.pp * P.HH + q.th) * P.HWd + q.tw;
+            }
         }
         if (T.co_t != ring_co_t) {                                    // uniform: (re)load the ring for this channel tile
             ring_co_t = T.co_t;
@@ -544,9 +576,11 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
         {
             const int m = wave * 32 + l32;
             poff[0] = poff[1] = -1;
-            int pp, th, tw;
-            if (pos_of(m, T, pp, th, tw)) {
-                const int t = T.t0 + 2 * pp, h = T.h0 + th, w = T.w0 + tw;
+            Pos q;
+            if (!P.flat) { q.ok = spk >= 0; q.pp = spk >> 20; q.th = (spk >> 10) & 1023; q.tw = spk & 1023; }
+            else q.ok = pos_of(m, T, q.pp, q.th, q.tw);
+            if (q.ok) {
+                const int t = T.t0 + 2 * q.pp, h = T.h0 + q.th, w = T.w0 + q.tw;
                 if (h < P.Hout && w < P.Wout) {
                     if (t < P.T) poff[0] = 4 * ((t * P.Cout) * (P.Hout * P.Woutp)) + 64 * (h * P.Woutp + w);
                     if (t + 1 < P.T) poff[1] = 4 * (((t + 1) * P.Cout) * (P.Hout * P.Woutp)) + 64 * (h * P.Woutp + w);
@@ -687,9 +721,11 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
 // ---------------------------------------------------------------------------------------------
 constexpr int kWtMaxBatch = 16;
 struct WtLayer {
-    const float *w, *sigma;       // [Cout][Cin][27]; sigma: device scalar or null (1)
+    const float *w, *sigma;       // [Cout][cin_total][27]; sigma: device scalar or null (1)
     _Float16 *packed;
-    int rows, cin;
+    int rows, cin;                // output channels; input channels PACKED: [ci0, ci0 + cin) of the tensor's cin_total
+    int cin_total, ci0;
+    long long tail_halves;        // where the tail { bound, pre-scale, 0, 0 } sits: 2 * rows * (channels of the buffer) * 36 halves into `packed`
 };
 struct WtBatch {
     WtLayer L[kWtMaxBatch];
@@ -710,11 +746,11 @@ __global__ __launch_bounds__(256) void wt_pack_kernel(WtBatch B) {
     const int blk = blockIdx.x - B.blk[l];
     const int cg = blk % CG, co0 = (blk / CG) * 32;
     const long long n = (long long)P.rows * P.cin * kWtTaps;
-    float *tail = reinterpret_cast<float *>(P.packed + 2 * n);
+    float *tail = reinterpret_cast<float *>(P.packed + P.tail_halves);
     const float sigma = P.sigma ? P.sigma[0] : 1.0f;
     for (int e = threadIdx.x; e < 32 * 432; e += 256) {
         const int col = e / 432, rem = e - col * 432;
-        wf[e] = P.w[((long long)(co0 + col) * P.cin + cg * 16) * 27 + rem] / sigma;
+        wf[e] = P.w[((long long)(co0 + col) * P.cin_total + P.ci0 + cg * 16) * 27 + rem] / sigma;
     }
     __syncthreads();
     const float w_scale = PASS ? pow2_prescale(tail[0]) : 1.0f;
@@ -971,14 +1007,20 @@ int wt_dispatch(const v2ce_conv3d_desc *desc, const float *x, const void *w_wt, 
 
 // internals for sn.hip: the Winograd planes of spectral-norm layers, all layers of a batch in one launch per pass
 int v2ce_wt_pack_batch(const float *const *w, const float *const *sigma, void *const *packed, const int *rows, const int *cin, int n, int pass,
-                       hipStream_t st) {
+                       hipStream_t st, const int *cin_total, const int *ci0) {
     V2CE_REQUIRE(n >= 0 && n <= kWtMaxBatch, V2CE_ERR_BAD_ARG, "v2ce_wt_pack_batch: 0..%d layers", kWtMaxBatch);
     WtBatch B{};
     B.n = n;
     for (int l = 0; l < n; ++l) {
         V2CE_REQUIRE(rows[l] % 32 == 0 && cin[l] % 16 == 0, V2CE_ERR_UNSUPPORTED, "v2ce_wt_pack_batch: Cout %% 32, Cin %% 16");
-        B.L[l] = WtLayer{w[l], sigma[l], static_cast<_Float16 *>(packed[l]), rows[l], cin[l]};
-        B.blk[l + 1] = B.blk[l] + (rows[l] / 32) * (cin[l] / 16);
+        B.L[l] = WtLayer{w[l], sigma[l], static_cast<_Float16 *>(packed[l]), rows[l], cin[l], cin_total ? cin_total[l] : cin[l], ci0 ? ci0[l] : 0,
+                         2ll * rows[l] * cin[l] * kWtTaps};
+        if (pass == 0) {        // the bound is taken over the WHOLE tensor (what the spectral-norm batch knows): walk all channels, same tail
+            B.L[l].cin = B.L[l].cin_total;
+            B.L[l].ci0 = 0;
+        }
+        V2CE_REQUIRE(B.L[l].ci0 >= 0 && B.L[l].ci0 + cin[l] <= B.L[l].cin_total, V2CE_ERR_BAD_ARG, "v2ce_wt_pack_batch: channel slice out of range");
+        B.blk[l + 1] = B.blk[l] + (rows[l] / 32) * (B.L[l].cin / 16);
     }
     if (n == 0) return V2CE_OK;
     return wt_pack_launch(B, pass, st);
@@ -993,17 +1035,23 @@ extern "C" size_t v2ce_pack_weights_f16x2_wt_bytes(int Cout, int Cin) {
     return (size_t)2 * kWtTaps * Cout * Cin * sizeof(_Float16) + 16;
 }
 
-extern "C" int v2ce_pack_weights_f16x2_wt(const float *w, int Cout, int Cin, const float *sigma, void *w_wt, v2ce_stream_t stream) {
+extern "C" int v2ce_pack_weights_f16x2_wt_slice(const float *w, int Cout, int Cin_total, int ci0, int Cin, const float *sigma, void *w_wt,
+                                                v2ce_stream_t stream) {
     clear_error();
-    V2CE_REQUIRE(w && w_wt && Cout > 0 && Cin > 0, V2CE_ERR_BAD_ARG, "v2ce_pack_weights_f16x2_wt: bad argument");
-    V2CE_REQUIRE(Cout % 32 == 0 && Cin % 16 == 0, V2CE_ERR_UNSUPPORTED, "v2ce_pack_weights_f16x2_wt: Cout must be a multiple of 32, Cin of 16");
+    V2CE_REQUIRE(w && w_wt && Cout > 0 && Cin > 0 && ci0 >= 0 && ci0 + Cin <= Cin_total, V2CE_ERR_BAD_ARG, "v2ce_pack_weights_f16x2_wt: bad argument");
+    V2CE_REQUIRE(Cout % 32 == 0 && Cin % 16 == 0 && ci0 % 16 == 0, V2CE_ERR_UNSUPPORTED,
+                 "v2ce_pack_weights_f16x2_wt: Cout must be a multiple of 32, the channel slice of 16");
     hipStream_t st = as_stream(stream);
     unsigned char *tail = static_cast<unsigned char *>(w_wt) + (size_t)2 * kWtTaps * Cout * Cin * sizeof(_Float16);
     V2CE_HIP_CHECK(hipMemsetAsync(tail, 0, 16, st));
     void *pk = w_wt;
-    int rc = v2ce_wt_pack_batch(&w, &sigma, &pk, &Cout, &Cin, 1, 0, st);
+    int rc = v2ce_wt_pack_batch(&w, &sigma, &pk, &Cout, &Cin, 1, 0, st, &Cin_total, &ci0);
     if (rc != V2CE_OK) return rc;
-    return v2ce_wt_pack_batch(&w, &sigma, &pk, &Cout, &Cin, 1, 1, st);
+    return v2ce_wt_pack_batch(&w, &sigma, &pk, &Cout, &Cin, 1, 1, st, &Cin_total, &ci0);
+}
+
+extern "C" int v2ce_pack_weights_f16x2_wt(const float *w, int Cout, int Cin, const float *sigma, void *w_wt, v2ce_stream_t stream) {
+    return v2ce_pack_weights_f16x2_wt_slice(w, Cout, Cin, 0, Cin, sigma, w_wt, stream);
 }
 
 extern "C" int v2ce_conv3d_fwd_wt(const v2ce_conv3d_desc *desc, const float *x, const void *w_wt, const float *scale, const float *shift,

@@ -114,6 +114,7 @@ struct SnLayer {
     int rows, cols, k3, cin;
     int up_c0;                  // > 0: `packed` is a v2ce_pack_weights_f16x2_up buffer whose first up_c0 input channels are also folded
     int wt;                     // 1: `packed` is a v2ce_pack_weights_f16x2_wt buffer (36 tap slots; written by conv3d_wt.hip's pack passes)
+    _Float16 *packed_skip;      // up_c0 > 0 and non-null: ALSO the Winograd-T planes of input channels [up_c0, cin) (v2ce_pack_weights_f16x2_wt_slice)
 };
 struct SnBatch {
     SnLayer L[kMaxBatch];
@@ -229,6 +230,11 @@ __global__ __launch_bounds__(1024) void sn_batch_finalize_kernel(SnBatch B) {
             const float bound = 1.5f * fabsf(m / sg);
             tail[0] = bound; tail[1] = pow2_prescale(bound); tail[2] = 0.0f; tail[3] = 0.0f;
             return;
+        }
+        if (P.packed_skip) {                                   // the skip channels' Winograd-T planes: the same bound on |G|
+            float *tail = reinterpret_cast<float *>(P.packed_skip + 2ll * P.rows * (P.cin - P.up_c0) * 36);
+            const float bound = 1.5f * fabsf(m / sg);
+            tail[0] = bound; tail[1] = pow2_prescale(bound); tail[2] = 0.0f; tail[3] = 0.0f;
         }
         float *tail = reinterpret_cast<float *>(P.packed + 2ll * P.rows * P.cols);
         const float am = fabsf(m / sg);                        // = max |w / sigma| of weights_absmax_kernel
@@ -355,6 +361,8 @@ extern "C" int v2ce_sn_update_batch(const v2ce_sn_layer *layers, int n, void *wo
         o.rows = in.rows; o.cols = in.cols; o.k3 = in.k3; o.cin = in.cols / in.k3;
         o.up_c0 = in.up_c0;
         o.wt = in.wt;
+        o.packed_skip = static_cast<_Float16 *>(in.packed_skip);
+        V2CE_REQUIRE(!in.packed_skip || in.up_c0 > 0, V2CE_ERR_BAD_ARG, "v2ce_sn_update_batch: layer %d: packed_skip needs up_c0", l);
         V2CE_REQUIRE(in.wt == 0 || (in.wt == 1 && in.k3 == 27 && in.up_c0 == 0), V2CE_ERR_BAD_ARG,
                      "v2ce_sn_update_batch: layer %d: wt must be 0 or 1, on a 3x3x3 layer without up_c0", l);
         V2CE_REQUIRE(in.up_c0 == 0 || (in.k3 == 27 && in.up_c0 > 0 && in.up_c0 % 16 == 0 && in.up_c0 < o.cin), V2CE_ERR_BAD_ARG,
@@ -384,15 +392,20 @@ extern "C" int v2ce_sn_update_batch(const v2ce_sn_layer *layers, int n, void *wo
     // Winograd-T layers (v2ce_conv3d_fwd_wt): max |G| of W / sigma, then the planes -- two launches for all of them
     const float *wt_w[kMaxBatch], *wt_sigma[kMaxBatch];
     void *wt_packed[kMaxBatch];
-    int wt_rows[kMaxBatch], wt_cin[kMaxBatch], n_wt = 0;
-    for (int l = 0; l < n; ++l)
+    int wt_rows[kMaxBatch], wt_cin[kMaxBatch], wt_tot[kMaxBatch], wt_ci0[kMaxBatch], n_wt = 0;
+    for (int l = 0; l < n; ++l) {
         if (B.L[l].wt) {
             wt_w[n_wt] = B.L[l].w; wt_sigma[n_wt] = B.L[l].sigma; wt_packed[n_wt] = B.L[l].packed;
-            wt_rows[n_wt] = B.L[l].rows; wt_cin[n_wt] = B.L[l].cin;
+            wt_rows[n_wt] = B.L[l].rows; wt_cin[n_wt] = B.L[l].cin; wt_tot[n_wt] = B.L[l].cin; wt_ci0[n_wt] = 0;
+            ++n_wt;
+        } else if (B.L[l].packed_skip) {                   // decoder conv1: its skip channels for the Winograd-T launch
+            wt_w[n_wt] = B.L[l].w; wt_sigma[n_wt] = B.L[l].sigma; wt_packed[n_wt] = B.L[l].packed_skip;
+            wt_rows[n_wt] = B.L[l].rows; wt_cin[n_wt] = B.L[l].cin - B.L[l].up_c0; wt_tot[n_wt] = B.L[l].cin; wt_ci0[n_wt] = B.L[l].up_c0;
             ++n_wt;
         }
+    }
     if (n_wt) {                                            // (pass 0 -- the bound on |G| -- is what the finalize kernel has just written)
-        const int rc = v2ce_wt_pack_batch(wt_w, wt_sigma, wt_packed, wt_rows, wt_cin, n_wt, 1, st);
+        const int rc = v2ce_wt_pack_batch(wt_w, wt_sigma, wt_packed, wt_rows, wt_cin, n_wt, 1, st, wt_tot, wt_ci0);
         if (rc != V2CE_OK) return rc;
     }
     int k3max = 1;

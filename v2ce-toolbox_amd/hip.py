@@ -32,7 +32,7 @@ EXPORTS = [
     "v2ce_voxelize_events", "v2ce_conv3d_fwd_pred", "v2ce_conv3d_fwd_sc", "v2ce_conv3d_fwd_tail", "v2ce_pack_pred_weights_f16x2", "v2ce_pack_pred_weights_f16x2_bytes",
     "v2ce_sampler_count", "v2ce_sampler_workspace_bytes", "v2ce_sampler_emit", "v2ce_sampler_pool",
     "v2ce_conv3d_fwd_up2", "v2ce_pack_weights_f16x2_up", "v2ce_pack_weights_f16x2_up_bytes", "v2ce_conv3d_up2_variant",
-    "v2ce_conv3d_fwd_wt", "v2ce_conv3d_fwd_wt_tail", "v2ce_pack_weights_f16x2_wt", "v2ce_pack_weights_f16x2_wt_bytes", "v2ce_conv3d_wt_variant",
+    "v2ce_conv3d_fwd_wt", "v2ce_conv3d_fwd_wt_tail", "v2ce_pack_weights_f16x2_wt", "v2ce_pack_weights_f16x2_wt_slice", "v2ce_conv3d_fwd_up2_part", "v2ce_pack_weights_f16x2_wt_bytes", "v2ce_conv3d_wt_variant",
     "v2ce_conv3d_head_f16x2", "v2ce_pack_head_weights_f16x2", "v2ce_pack_head_weights_f16x2_bytes", "v2ce_absmax_batch",
 ]
 
@@ -52,7 +52,7 @@ class SnLayer(ctypes.Structure):
     """``v2ce_sn_layer`` (include/v2ce_hip.h): one spectral-norm layer of v2ce_sn_update_batch."""
     _fields_ = [("w_bar", ctypes.c_void_p), ("u", ctypes.c_void_p), ("v", ctypes.c_void_p), ("packed", ctypes.c_void_p),
                 ("rows", ctypes.c_int32), ("cols", ctypes.c_int32), ("k3", ctypes.c_int32), ("up_c0", ctypes.c_int32),
-                ("wt", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("wt", ctypes.c_int32), ("reserved", ctypes.c_int32), ("packed_skip", ctypes.c_void_p)]
 
 
 class LdatiOptions(ctypes.Structure):
@@ -159,6 +159,10 @@ def lib() -> ctypes.CDLL:
     L.v2ce_conv3d_fwd_wt.restype = ctypes.c_int
     L.v2ce_conv3d_fwd_wt_tail.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 7 + [ctypes.POINTER(ConvDesc)] + [vp] * 8
     L.v2ce_conv3d_fwd_wt_tail.restype = ctypes.c_int
+    L.v2ce_pack_weights_f16x2_wt_slice.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp]
+    L.v2ce_pack_weights_f16x2_wt_slice.restype = ctypes.c_int
+    L.v2ce_conv3d_fwd_up2_part.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 9
+    L.v2ce_conv3d_fwd_up2_part.restype = ctypes.c_int
     L.v2ce_pack_weights_f16x2_wt.argtypes = [vp, i32, i32, vp, vp, vp]
     L.v2ce_pack_weights_f16x2_wt.restype = ctypes.c_int
     L.v2ce_pack_weights_f16x2_wt_bytes.argtypes = [i32, i32]

@@ -192,10 +192,11 @@ class V2ce3d(nn.Module):
                       "v2ce_pack_weights_f16x2_up")
             return out
         if split and out is not None and getattr(out, "wt", False):
-            # Winograd F(2,3) along T: the transformed weights of W / sigma (v2ce_conv3d_fwd_wt)
-            hip.check(hip.lib().v2ce_pack_weights_f16x2_wt(w.data_ptr(), cout, cin, hip.ptr(sigma), out.data_ptr(),
-                                                           hip.stream_ptr(w.device)),
-                      "v2ce_pack_weights_f16x2_wt")
+            # Winograd F(2,3) along T: the transformed weights of W / sigma (v2ce_conv3d_fwd_wt); `ci0`: of input channels ci0.. only
+            ci0 = getattr(out, "ci0", 0)
+            hip.check(hip.lib().v2ce_pack_weights_f16x2_wt_slice(w.data_ptr(), cout, cin, ci0, cin - ci0, hip.ptr(sigma), out.data_ptr(),
+                                                                 hip.stream_ptr(w.device)),
+                      "v2ce_pack_weights_f16x2_wt_slice")
             return out
         if split:      # fp16 hi/lo planes for the split-half conv path
             if out is None:
@@ -296,6 +297,12 @@ class V2ce3d(nn.Module):
                         up_c0 = blk.cin * 2 // 3 if (name == "dec" and cn == "conv1" and self._upfold()) else 0
                         d[cn + "_w"] = (self._split_buffer(rows, m.weight_bar.shape[1], 27, dev, up_c0=up_c0, wt=wt[cn])
                                         if splits[cn] else torch.empty(rows * cols, dtype=torch.float32, device=dev))
+                        if up_c0 and self._up_split(blk):
+                            # the skip channels of a wide decoder's conv1 on the Winograd-T kernel (v2ce_conv3d_fwd_up2_part + v2ce_conv3d_fwd_wt)
+                            sk = self._split_buffer(rows, m.weight_bar.shape[1] - up_c0, 27, dev, wt=True)
+                            sk.ci0 = up_c0
+                            d["conv1_skip_w"] = sk
+                            d["zero_shift"] = torch.zeros(rows, dtype=torch.float32, device=dev)
                         sn_ws = max(sn_ws, hip.lib().v2ce_sn_workspace_bytes(rows, cols))
                 else:
                     for cn in ("conv1", "conv2"):
@@ -308,15 +315,16 @@ class V2ce3d(nn.Module):
         P["sn_batch"] = None
         if self.precision == "f16x2":
             # all 12 spectral-norm layers in one v2ce_sn_update_batch call (six launches instead of 84)
-            inners = [(getattr(blk, cn).module, P[f"{name}{i}"][cn + "_w"])
+            inners = [(getattr(blk, cn).module, P[f"{name}{i}"][cn + "_w"], P[f"{name}{i}"].get("conv1_skip_w") if cn == "conv1" else None)
                       for name, blocks in (("res", self.UNet.resblocks), ("dec", self.UNet.decoders))
                       for i, blk in enumerate(blocks) if blk.sn for cn in ("conv1", "conv2")]
             arr = (hip.SnLayer * len(inners))()
-            for e, (m, out) in zip(arr, inners):
+            for e, (m, out, skip) in zip(arr, inners):
                 e.w_bar, e.u, e.v, e.packed = m.weight_bar.data_ptr(), m.weight_u.data_ptr(), m.weight_v.data_ptr(), out.data_ptr()
                 e.rows, e.cols, e.k3 = m.weight_bar.shape[0], m.weight_bar[0].numel(), 27
                 e.up_c0 = getattr(out, "up_c0", 0)
                 e.wt = 1 if getattr(out, "wt", False) else 0
+                e.packed_skip = None if skip is None else skip.data_ptr()
             nb = hip.lib().v2ce_sn_batch_workspace_bytes(arr, len(inners))
             if nb:
                 P["sn_batch"] = (arr, len(inners), torch.empty(nb, dtype=torch.uint8, device=dev))
@@ -343,6 +351,15 @@ class V2ce3d(nn.Module):
         """Winograd F(2,3) along T for the plain stride-1 3x3x3 convs (v2ce_conv3d_fwd_wt: 2/3 of the multiplies;
         V2CE_WINOGRAD=0: the direct kernel, for A/B runs)."""
         return self.precision == "f16x2" and os.environ.get("V2CE_WINOGRAD", "1") != "0"
+
+    def _up_split(self, blk) -> bool:
+        """conv1 of a decoder with >= 64 output channels as TWO launches: the upsampled channels phase-folded
+        (v2ce_conv3d_fwd_up2_part, no activation) and the skip channels on the Winograd-T kernel with the first launch's output as
+        its residual -- the skip channels are 53 % of the layer's multiplies, two thirds of them remain.  V2CE_UP_SPLIT=0: one launch."""
+        # (the shallower the block the larger the second launch's epilogue and the partial sum's round trip against the multiplies
+        # saved: measured per block in tools/upsplit_ab.sh -- dec0 1.74 -> 1.52 ms, dec1 1.51 -> 1.49, dec2 1.47 -> 1.50)
+        return self._upfold() and self._winograd() and blk.cout % 64 == 0 and os.environ.get("V2CE_UP_SPLIT", "1") != "0" and \
+            blk.cout >= int(os.environ.get("V2CE_UP_SPLIT_MIN_COUT", "128"))
 
     def _upfold(self) -> bool:
         """Phase-folded upsampled channels in the decoders' conv1 (v2ce_conv3d_fwd_up2; V2CE_UPFOLD=0: the mapped gather
@@ -558,6 +575,43 @@ class V2ce3d(nn.Module):
             return y, y_sc
         return y
 
+    def _up2_ok(self, x0, x1, w_packed, up_to) -> bool:
+        """The phase-folded decoder launch applies: exact 2x nearest upsample (ATen's map is then dst >> 1) into folded weights."""
+        H0, W0 = x0.shape[3], getattr(x0, "lw", x0.shape[4])
+        Hin, Win = up_to
+        return (getattr(x0, "c16", False) and getattr(x1, "c16", False) and getattr(w_packed, "up_c0", 0) == x0.shape[2] * 16
+                and H0 == (Hin + 1) // 2 and W0 == (Win + 1) // 2 and _nearest_is_half(H0, Hin) and _nearest_is_half(W0, Win))
+
+    def _conv_up_part(self, x0, x1, w_up, scale, shift, cout, up_to):
+        """scale * conv(upsample(x0); W[:, :C0]) + shift on the phase-folded kernel, no activation (v2ce_conv3d_fwd_up2_part): the
+        residual of the Winograd-T launch that adds the skip channels' share and the activation."""
+        B, T, G0, H0, W0p = x0.shape[:5]
+        C0, C1 = G0 * 16, x1.shape[2] * 16
+        W0 = getattr(x0, "lw", W0p)
+        Hin, Win = up_to
+        Woutp = self._pitch(Win)
+        y = torch.empty((B, T, cout // 16, Hin, Woutp, 16), dtype=torch.float32, device=x0.device)
+        y.lw, y.c16 = Win, True
+        d = hip.ConvDesc(B=B, T=T, C0=C0, H0=H0, W0=W0, C1=C1, Hin=Hin, Win=Win, Cout=cout, Hout=Hin, Wout=Win, ksize=3, stride_hw=1,
+                         act=hip.ACT_NONE, tile_t=0, tile_h=0, tile_w=0, precision=hip.PRECISION_F16X2, W0_pitch=W0p,
+                         Win_pitch=x1.shape[4], Wout_pitch=Woutp, layout=hip.LAYOUT_C16,
+                         absmax_batch_stride=2 if self._prep["absmax"].dim() == 3 else 0)
+        ay = self._prep["absmax"][self._slot]          # (only its range-guard value matters: the partial sum feeds no split-half launch)
+        self._slot += 1
+        a0 = getattr(x0, "absmax", None)
+        prof = getattr(self, "profile", None)
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        hip.check(hip.lib().v2ce_conv3d_fwd_up2_part(ctypes.byref(d), x0.data_ptr(), w_up.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                                     y.data_ptr(), hip.ptr(a0), hip.ptr(a0), hip.ptr(ay), hip.stream_ptr(x0.device)),
+                  "v2ce_conv3d_fwd_up2_part")
+        if prof is not None:
+            e1.record()
+            per_tap = 2.0 * B * T * Hin * Win * cout * C0
+            prof.append((hip.conv_up2_variant(d, False), 27 * per_tap, e0, e1, 12 * per_tap))
+        return y
+
     def _head_split(self, x, table, bias):
         """The head convolution on the split-half kernel: max |x| per sequence into a range slot (v2ce_absmax_batch), then
         v2ce_conv3d_head_f16x2 -- planar network input in, channels-last-16 activations out."""
@@ -614,7 +668,12 @@ class V2ce3d(nn.Module):
                                 sc=(d["down_w"], *d["down_bn"]))
         elif d.get("fold") is not None and pred is None:
             # the shortcut rides in conv2's K loop (v2ce_conv3d_fwd_tail): relu(s2 (W2 * t + Wd' * x) + shift2 + shift_d)
-            t = self._conv(x0, x1, w1, *d["bn1"], blk.cout, 3, s, hip.ACT_RELU, up_to=up_to, split=True)
+            if d.get("conv1_skip_w") is not None and x1 is not None and self._up2_ok(x0, x1, w1, up_to):
+                part = self._conv_up_part(x0, x1, w1, *d["bn1"], blk.cout, up_to)
+                t = self._conv(x1, None, d["conv1_skip_w"], d["bn1"][0], d["zero_shift"], blk.cout, 3, 1, hip.ACT_RELU, residual=part,
+                               split=True)
+            else:
+                t = self._conv(x0, x1, w1, *d["bn1"], blk.cout, 3, s, hip.ACT_RELU, up_to=up_to, split=True)
             fw, fscale, fshift = d["fold"]
             return self._conv(t, None, d["conv2_w"], fscale, fshift, blk.cout, 3, 1, hip.ACT_RELU, split=True, track=track,
                               tail=(x0, x1, up_to, s, fw))
@@ -677,6 +736,8 @@ class V2ce3d(nn.Module):
             for i, blk in enumerate(blocks):
                 d = self._prep[f"{name}{i}"]
                 self._sn_weight(blk.conv1.module, d["conv1_w"])
+                if d.get("conv1_skip_w") is not None:          # (P["sigma"] still holds conv1's)
+                    self._pack(blk.conv1.module.weight_bar, self._prep["sigma"], d["conv1_skip_w"], split=True)
                 self._sn_weight(blk.conv2.module, d["conv2_w"])
 
     def _advance_spectral_norm(self):
