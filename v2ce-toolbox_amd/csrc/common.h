@@ -54,6 +54,9 @@ int v2ce_pack_weights_f16x2_pack_only(const float *w, int Cout, int Cin, int k3,
 // the folded region of a v2ce_pack_weights_f16x2_up buffer (conv3d_up.hip): max |folded sums| into tail[0]; the pack itself
 int v2ce_up_fold_absmax(const float *w, int Cout, int Cin, int C0, const float *sigma, void *w_up, hipStream_t st);
 int v2ce_up_fold_pack(const float *w, int Cout, int Cin, int C0, const float *sigma, void *w_up, hipStream_t st);
+// the same for up to eight layers in one launch; pass 0 = the maxima, pass 1 = the packs
+int v2ce_up_fold_batch(const float *const *w, const int *Cout, const int *Cin, const int *C0, const float *const *sigma, void *const *w_up,
+                       int n, int pass, hipStream_t st);
 
 // the Winograd planes (conv3d_wt.hip) of up to 16 layers in one launch per pass: pass 0 raises tail[0] (zeroed by the caller) to
 // max |G|, pass 1 derives the pre-scale from it and writes the planes; sigma[l]: device scalar or null

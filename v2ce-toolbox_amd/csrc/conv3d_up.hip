@@ -739,14 +739,34 @@ __global__ __launch_bounds__(512, 1) void conv3d_up_kernel(UpParams U) {
 // ---------------------------------------------------------------------------------------------
 // weights: the folded region behind a v2ce_pack_weights_f16x2 buffer
 // ---------------------------------------------------------------------------------------------
+// up to eight layers per launch (the four decoder conv1 weights of a forward pass: one launch per pass instead of four)
+constexpr int kUpFoldBatch = 8;
+struct UpFoldLayer {
+    const float *w, *sigma;
+    float *tail;
+    _Float16 *fold;
+    int Cout, Cin, C0;
+};
+struct UpFoldBatch {
+    UpFoldLayer L[kUpFoldBatch];
+    int n;
+    int blk[kUpFoldBatch + 1];    // prefix of the layers' workgroups
+};
+
 // max over every tap of every list of the folded region of |sum of (w / sigma)| for the C0 channels -> atomic max into tail[0]
 // (the correction lists hold single weights or two-term sums: covered by the plain maximum and the folded lists')
-__global__ __launch_bounds__(256) void up_fold_absmax_kernel(const float *__restrict__ w, int Cout, int Cin, int C0,
-                                                             const float *sigma, float *tail) {
+__global__ __launch_bounds__(256) void up_fold_absmax_kernel(UpFoldBatch B) {
+    int l = 0;
+    while (l + 1 < B.n && (int)blockIdx.x >= B.blk[l + 1]) ++l;
+    const float *__restrict__ w = B.L[l].w;
+    const float *sigma = B.L[l].sigma;
+    float *tail = B.L[l].tail;
+    const int Cout = B.L[l].Cout, Cin = B.L[l].Cin, C0 = B.L[l].C0;
+    const int bid = blockIdx.x - B.blk[l], nblk = B.blk[l + 1] - B.blk[l];
     // one thread per (co, ci < C0, dt): its nine (dh, dw) weights
     const long long n = (long long)Cout * C0 * 3;
     float m = 0.0f;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+    for (long long e = (long long)bid * 256 + threadIdx.x; e < n; e += (long long)nblk * 256) {
         const int dt = (int)(e % 3);
         const long long r = e / 3;
         const int ci = (int)(r % C0), co = (int)(r / C0);
@@ -782,11 +802,18 @@ __global__ __launch_bounds__(256) void up_fold_absmax_kernel(const float *__rest
 // fold[plane][slot][cg][co][16] (108 slots) = fp16 hi / lo of  +-s * sum over the slot's source taps of w[co][cg*16+j][.] / sigma,
 // s = pow2_prescale(tail[0]).  A workgroup takes 32 output channels x one 16-channel group: stages their 27 taps (scaled
 // quotients, f32) in LDS -- 32 contiguous runs of W in -- and writes, per slot and plane, 1 KiB contiguous.
-__global__ __launch_bounds__(256) void up_fold_pack_kernel(const float *__restrict__ w, int Cout, int Cin, int C0,
-                                                           const float *sigma, const float *tail, _Float16 *__restrict__ fold) {
+__global__ __launch_bounds__(256) void up_fold_pack_kernel(UpFoldBatch B) {
     __shared__ float st[32 * 16 * 27];
+    int l = 0;
+    while (l + 1 < B.n && (int)blockIdx.x >= B.blk[l + 1]) ++l;
+    const float *__restrict__ w = B.L[l].w;
+    const float *sigma = B.L[l].sigma;
+    const float *tail = B.L[l].tail;
+    _Float16 *__restrict__ fold = B.L[l].fold;
+    const int Cout = B.L[l].Cout, Cin = B.L[l].Cin, C0 = B.L[l].C0;
+    const int bid = blockIdx.x - B.blk[l];
     const int CG0 = C0 / 16, run = 16 * 27;
-    const int cg = blockIdx.x % CG0, co0 = (blockIdx.x / CG0) * 32;
+    const int cg = bid % CG0, co0 = (bid / CG0) * 32;
     const float w_scale = pow2_prescale(tail[0]);
     const float sg = sigma ? sigma[0] : 1.0f;
     for (int e = threadIdx.x; e < 32 * run; e += 256) {
@@ -1064,18 +1091,30 @@ extern "C" size_t v2ce_pack_weights_f16x2_up_bytes(int Cout, int C0, int C1) {
 
 // enqueue the two fold passes behind a tail[0] that already holds max |w / sigma| (see v2ce_pack_weights_f16x2_up and
 // v2ce_sn_update_batch, which call them around their own plain packs)
-int v2ce::v2ce_up_fold_absmax(const float *w, int Cout, int Cin, int C0, const float *sigma, void *w_up, hipStream_t st) {
-    float *tail = reinterpret_cast<float *>(static_cast<char *>(w_up) + (size_t)Cout * Cin * 27 * 4);
-    const long long n = (long long)Cout * C0 * 3;
-    const unsigned nb = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(up_fold_absmax_kernel, dim3(nb < 2048 ? nb : 2048), dim3(256), 0, st, w, Cout, Cin, C0, sigma, tail);
+int v2ce::v2ce_up_fold_batch(const float *const *w, const int *Cout, const int *Cin, const int *C0, const float *const *sigma, void *const *w_up,
+                             int n, int pass, hipStream_t st) {
+    V2CE_REQUIRE(n >= 0 && n <= kUpFoldBatch, V2CE_ERR_BAD_ARG, "v2ce_up_fold_batch: 0..%d layers", kUpFoldBatch);
+    if (n == 0) return V2CE_OK;
+    UpFoldBatch B{};
+    B.n = n;
+    for (int l = 0; l < n; ++l) {
+        char *base = static_cast<char *>(w_up[l]);
+        B.L[l] = UpFoldLayer{w[l], sigma[l], reinterpret_cast<float *>(base + (size_t)Cout[l] * Cin[l] * 27 * 4),
+                             reinterpret_cast<_Float16 *>(base + up_fold_off(Cout[l], Cin[l])), Cout[l], Cin[l], C0[l]};
+        const long long items = (long long)Cout[l] * C0[l] * 3;
+        const long long nb = (items + 255) / 256;
+        B.blk[l + 1] = B.blk[l] + (pass == 0 ? (int)(nb < 2048 ? nb : 2048) : (Cout[l] / 32) * (C0[l] / 16));
+    }
+    if (pass == 0) hipLaunchKernelGGL(up_fold_absmax_kernel, dim3((unsigned)B.blk[n]), dim3(256), 0, st, B);
+    else hipLaunchKernelGGL(up_fold_pack_kernel, dim3((unsigned)B.blk[n]), dim3(256), 0, st, B);
+    V2CE_HIP_CHECK(hipGetLastError());
     return V2CE_OK;
 }
+int v2ce::v2ce_up_fold_absmax(const float *w, int Cout, int Cin, int C0, const float *sigma, void *w_up, hipStream_t st) {
+    return v2ce_up_fold_batch(&w, &Cout, &Cin, &C0, &sigma, &w_up, 1, 0, st);
+}
 int v2ce::v2ce_up_fold_pack(const float *w, int Cout, int Cin, int C0, const float *sigma, void *w_up, hipStream_t st) {
-    const float *tail = reinterpret_cast<const float *>(static_cast<char *>(w_up) + (size_t)Cout * Cin * 27 * 4);
-    _Float16 *fold = reinterpret_cast<_Float16 *>(static_cast<char *>(w_up) + up_fold_off(Cout, Cin));
-    hipLaunchKernelGGL(up_fold_pack_kernel, dim3((unsigned)((Cout / 32) * (C0 / 16))), dim3(256), 0, st, w, Cout, Cin, C0, sigma, tail, fold);
-    return V2CE_OK;
+    return v2ce_up_fold_batch(&w, &Cout, &Cin, &C0, &sigma, &w_up, 1, 1, st);
 }
 
 extern "C" int v2ce_pack_weights_f16x2_up(const float *w, int Cout, int C0, int C1, const float *sigma, void *w_up,

@@ -387,8 +387,24 @@ extern "C" int v2ce_sn_update_batch(const v2ce_sn_layer *layers, int n, void *wo
     hipLaunchKernelGGL(sn_batch_w_v_kernel, dim3(B.row_blk[n]), dim3(256), 0, st, B);
     hipLaunchKernelGGL(sn_batch_finalize_kernel, dim3(n), dim3(1024), 0, st, B);
     // decoder conv1 layers (v2ce_conv3d_fwd_up2): the folded sums of W / sigma join the maximum the common pre-scale is derived from
+    const float *uf_w[kMaxBatch], *uf_sigma[kMaxBatch];
+    void *uf_packed[kMaxBatch];
+    int uf_rows[kMaxBatch], uf_cin[kMaxBatch], uf_c0[kMaxBatch], n_uf = 0;
     for (int l = 0; l < n; ++l)
-        if (B.L[l].up_c0) v2ce_up_fold_absmax(B.L[l].w, B.L[l].rows, B.L[l].cin, B.L[l].up_c0, B.L[l].sigma, B.L[l].packed, st);
+        if (B.L[l].up_c0 && n_uf < 8) {
+            uf_w[n_uf] = B.L[l].w; uf_sigma[n_uf] = B.L[l].sigma; uf_packed[n_uf] = B.L[l].packed;
+            uf_rows[n_uf] = B.L[l].rows; uf_cin[n_uf] = B.L[l].cin; uf_c0[n_uf] = B.L[l].up_c0;
+            ++n_uf;
+        }
+    {
+        int n_up = 0;
+        for (int l = 0; l < n; ++l) n_up += B.L[l].up_c0 ? 1 : 0;
+        V2CE_REQUIRE(n_up <= 8, V2CE_ERR_UNSUPPORTED, "v2ce_sn_update_batch: at most eight layers with up_c0");
+    }
+    if (n_uf) {
+        const int rc = v2ce_up_fold_batch(uf_w, uf_rows, uf_cin, uf_c0, uf_sigma, uf_packed, n_uf, 0, st);
+        if (rc != V2CE_OK) return rc;
+    }
     // Winograd-T layers (v2ce_conv3d_fwd_wt): max |G| of W / sigma, then the planes -- two launches for all of them
     const float *wt_w[kMaxBatch], *wt_sigma[kMaxBatch];
     void *wt_packed[kMaxBatch];
@@ -417,8 +433,10 @@ extern "C" int v2ce_sn_update_batch(const v2ce_sn_layer *layers, int n, void *wo
     if (B.el_blk[n] == 0) {}                               // (every layer is a Winograd-T layer)
     else if (all27) hipLaunchKernelGGL(sn_batch_pack_kernel<27>, dim3(B.el_blk[n]), dim3(256), (size_t)27 * 2056, st, B);
     else hipLaunchKernelGGL(sn_batch_pack_kernel<0>, dim3(B.el_blk[n]), dim3(256), (size_t)k3max * 2056, st, B);
-    for (int l = 0; l < n; ++l)
-        if (B.L[l].up_c0) v2ce_up_fold_pack(B.L[l].w, B.L[l].rows, B.L[l].cin, B.L[l].up_c0, B.L[l].sigma, B.L[l].packed, st);
+    if (n_uf) {
+        const int rc = v2ce_up_fold_batch(uf_w, uf_rows, uf_cin, uf_c0, uf_sigma, uf_packed, n_uf, 1, st);
+        if (rc != V2CE_OK) return rc;
+    }
     V2CE_HIP_CHECK(hipGetLastError());
     return V2CE_OK;
 }
