@@ -735,7 +735,7 @@ struct WtBatch {
 constexpr size_t kWtPackLds = (size_t)32 * 432 * 4 + (size_t)2 * kWtTaps * 514 * 2;
 
 template <int PASS>
-__global__ __launch_bounds__(256) void wt_pack_kernel(WtBatch B) {
+__global__ __launch_bounds__(512) void wt_pack_kernel(WtBatch B) {   // (129 KB of LDS: one workgroup per CU -- eight waves of it)
     extern __shared__ __attribute__((aligned(16))) unsigned char wt_smem[];
     float *wf = reinterpret_cast<float *>(wt_smem);                   // [32][16][27] = W / sigma
     _Float16 *hi = reinterpret_cast<_Float16 *>(wt_smem + 32 * 432 * 4), *lo = hi + kWtTaps * 514;
@@ -748,7 +748,7 @@ __global__ __launch_bounds__(256) void wt_pack_kernel(WtBatch B) {
     const long long n = (long long)P.rows * P.cin * kWtTaps;
     float *tail = reinterpret_cast<float *>(P.packed + P.tail_halves);
     const float sigma = P.sigma ? P.sigma[0] : 1.0f;
-    for (int e = threadIdx.x; e < 32 * 432; e += 256) {
+    for (int e = threadIdx.x; e < 32 * 432; e += 512) {
         const int col = e / 432, rem = e - col * 432;
         wf[e] = P.w[((long long)(co0 + col) * P.cin_total + P.ci0 + cg * 16) * 27 + rem] / sigma;
     }
@@ -756,7 +756,7 @@ __global__ __launch_bounds__(256) void wt_pack_kernel(WtBatch B) {
     const float w_scale = PASS ? pow2_prescale(tail[0]) : 1.0f;
     if (PASS && blk == 0 && threadIdx.x == 0) tail[1] = w_scale;
     float m = 0.0f;
-    for (int it = threadIdx.x; it < 32 * 16 * 9; it += 256) {
+    for (int it = threadIdx.x; it < 32 * 16 * 9; it += 512) {
         const int col = it / 144, rem = it - col * 144, j = rem / 9, t9 = rem - j * 9;
         const float *g = wf + col * 432 + j * 27 + t9;
         const float g0 = g[0], g1 = g[9], g2 = g[18];
@@ -789,8 +789,9 @@ __global__ __launch_bounds__(256) void wt_pack_kernel(WtBatch B) {
     const unsigned *hi32 = reinterpret_cast<const unsigned *>(hi), *lo32 = reinterpret_cast<const unsigned *>(lo);
     for (int tap = 0; tap < kWtTaps; ++tap) {
         const long long o = (((long long)tap * CG + cg) * P.rows + co0) * 16;       // halves
-        reinterpret_cast<unsigned *>(P.packed + o)[threadIdx.x] = hi32[tap * 257 + threadIdx.x];
-        reinterpret_cast<unsigned *>(P.packed + n + o)[threadIdx.x] = lo32[tap * 257 + threadIdx.x];
+        const int t = threadIdx.x & 255;                              // threads 0-255: the hi plane's 256 dwords of this tap, 256-511: the lo plane's
+        if (threadIdx.x < 256) reinterpret_cast<unsigned *>(P.packed + o)[t] = hi32[tap * 257 + t];
+        else reinterpret_cast<unsigned *>(P.packed + n + o)[t] = lo32[tap * 257 + t];
     }
 }
 
@@ -802,8 +803,8 @@ int wt_pack_launch(const WtBatch &B, int pass, hipStream_t st) {
     }();
     (void)once;
     if (B.blk[B.n] == 0) return V2CE_OK;
-    if (pass == 0) hipLaunchKernelGGL(wt_pack_kernel<0>, dim3(B.blk[B.n]), dim3(256), kWtPackLds, st, B);
-    else hipLaunchKernelGGL(wt_pack_kernel<1>, dim3(B.blk[B.n]), dim3(256), kWtPackLds, st, B);
+    if (pass == 0) hipLaunchKernelGGL(wt_pack_kernel<0>, dim3(B.blk[B.n]), dim3(512), kWtPackLds, st, B);
+    else hipLaunchKernelGGL(wt_pack_kernel<1>, dim3(B.blk[B.n]), dim3(512), kWtPackLds, st, B);
     V2CE_HIP_CHECK(hipGetLastError());
     return V2CE_OK;
 }
