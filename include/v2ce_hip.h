@@ -397,9 +397,14 @@ int v2ce_conv3d_fwd_wt(const v2ce_conv3d_desc *desc, const float *x, const void 
 int v2ce_conv3d_fwd_wt_tail(const v2ce_conv3d_desc *desc, const float *x, const void *w_wt, const float *scale, const float *shift,
                             float *y, const float *x_absmax, float *y_absmax, const v2ce_conv3d_desc *tail_desc, const float *tx0,
                             const float *tx1, const int32_t *thmap, const int32_t *twmap, const void *tail_w,
-                            const float *tx0_absmax, const float *tx1_absmax, v2ce_stream_t stream);
+                            const float *tx0_absmax, const float *tx1_absmax, const float *residual, int res_h, int res_w_pitch,
+                            v2ce_stream_t stream);
+/* residual (may be NULL): added before the activation like v2ce_conv3d_fwd_wt's.  res_h > 0: it is a LOW-resolution tensor
+ * [B][T][Cout/16][res_h = ceil(Hout / 2)][res_w_pitch][16] read at (h >> 1, w >> 1) -- the 2x nearest upsample of a decoder block:
+ * the upsampled source's share of the folded shortcut, bn_d-scale * Wd[:, :C0] * x0, is computed at the source's resolution (a quarter
+ * of the positions) and only the skip channels ride as the tail. */
 /* Name of the kernel instantiation v2ce_conv3d_fwd_wt[_tail] would launch ("conv3d_wt_kernel<CO_FR,PO_FR,RES,TAIL>");
- * with_residual: 0 | 1 | 2 = the tail form. */
+ * with_residual: 0 | 1 | 2 = the tail form | 3 = the tail form with a residual. */
 int v2ce_conv3d_wt_variant(const v2ce_conv3d_desc *desc, int with_residual, char *name, size_t cap);
 
 /* Name of the kernel instantiation v2ce_conv3d_fwd would launch for desc ("conv3d_kernel<KS,S,

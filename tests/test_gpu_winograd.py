@@ -177,3 +177,38 @@ def test_conv3d_wt_folded_tail_vs_f64(case):
     assert got.shape == want.shape
     assert np.all(np.abs(got - want) <= TOL * scale + TOL * np.abs(want)), float(np.abs(got - want).max())
     assert 0 < float(y.absmax.reshape(-1, 2)[:, 1].max()) < 1.0        # a finite range-guard bound was reported
+
+
+def test_conv3d_wt_tail_with_upsampled_residual_vs_f64():
+    """A decoder block's conv2 with the folded shortcut split by source: the skip channels ride as the tail of the Winograd-T launch,
+    the upsampled channels' share arrives as a LOW-resolution residual read at (h >> 1, w >> 1) (v2ce_conv3d_fwd_wt_tail, res_h) --
+    against conv2 + the whole 1x1x1 shortcut in f64.  Odd output size: the last source row / column feeds one output row / column."""
+    from oracle import unet as U
+    from v2ce_toolbox_amd import hip
+    from v2ce_toolbox_amd.v2ce_3d import V2ce3d
+    B, T, cm, c0, c1, H, W = 2, 5, 128, 256, 128, 13, 19
+    g = torch.Generator().manual_seed(17)
+    t_in = torch.randn(B, cm, T, H, W, generator=g)
+    x0 = torch.randn(B, c0, T, (H + 1) // 2, (W + 1) // 2, generator=g)
+    x1 = torch.randn(B, c1, T, H, W, generator=g)
+    w2 = torch.randn(cm, cm, 3, 3, 3, generator=g) * (2.0 / (cm * 27)) ** 0.5
+    wd = torch.randn(cm, c0 + c1, 1, 1, 1, generator=g) * (1.0 / (c0 + c1)) ** 0.5
+    s2, sh = torch.rand(cm, generator=g) + 0.5, torch.randn(cm, generator=g)
+    m = _model()
+
+    def dev(x):
+        d = V2ce3d.to_c16(to_btchw(x).cuda())
+        d.absmax = x.abs().max().reshape(1).cuda()
+        return d
+    lo = V2ce3d._pack(m, wd[:, :c0].contiguous().cuda(), split=True)
+    sk = V2ce3d._pack(m, wd[:, c0:].contiguous().cuda(), split=True)
+    r0 = V2ce3d._conv(m, dev(x0), None, lo, s2.cuda(), torch.zeros(cm, device="cuda"), cm, 1, 1, hip.ACT_NONE, split=True)
+    m.profile = []
+    y = V2ce3d._conv(m, dev(t_in), None, _weights(m, w2, True), s2.cuda(), sh.cuda(), cm, 3, 1, hip.ACT_RELU, split=True, dense_out=True,
+                     tail=(dev(x1), None, None, 1, sk), residual=r0, residual_up=True)
+    torch.cuda.synchronize()
+    assert m.profile[0][0] == "conv3d_wt_kernel<2,4,1,1>", m.profile[0][0]
+    xs = torch.cat([U.upsample_nearest_hw(x0, (H, W)).double(), x1.double()], dim=1)
+    acc = F.conv3d(t_in.double(), w2.double(), None, 1, 1) + F.conv3d(xs, wd.double(), None, 1, 0)
+    want = torch.relu(acc * s2.double().view(1, -1, 1, 1, 1) + sh.double().view(1, -1, 1, 1, 1)).numpy()
+    assert_close(V2ce3d.to_planar(y).permute(0, 2, 1, 3, 4).cpu().numpy(), want, "conv2 + split shortcut")

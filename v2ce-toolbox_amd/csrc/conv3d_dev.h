@@ -27,6 +27,8 @@ struct ConvParams {
     int nT, nH, nW;       // boxes per dimension
     int HT, HH, HWd;      // halo box
     int plane;            // HT*HH*HWd  (LDS stride between channels)
+    int res_up, rH, rWp;  // conv3d_wt.hip: the residual is a 2x nearest-upsampled LOW-resolution tensor [B][T][Cout/16][rH][rWp][16], read at
+                          // (h >> 1, w >> 1) (the upsampled source's share of a decoder's folded shortcut, computed where it is small)
     int flat;             // > 0 (conv3d_wt.hip): a tile's positions are a RANGE of `flat` consecutive positions of the row-major
                           // Hout x Wout plane (per time block) instead of a TH x TW rectangle -- planes like 17 x 22 split into three
                           // ranges of 125 where rectangles of <= 128 positions need four; nH = 1, nW = ranges per plane, TW = Wout,

@@ -70,7 +70,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
 #if defined(__HIP_DEVICE_COMPILE__)
     [[maybe_unused]] unsigned long long t_all = TICK(), t_bar = 0, t_epi = 0, t_xbar = 0, t_cvt = 0, t_e0 = 0, t_e1 = 0, t_e2 = 0;
     static_assert(PO_FR == 4, "the output transform hands position fragment f to consumer wave f");
-    static_assert(!TAIL || RES == 0, "a folded tail replaces the residual");
+    // (TAIL with RES: a decoder's folded shortcut split by source -- the skip channels ride as the tail, the upsampled channels'
+    // share arrives as a low-resolution residual, ConvParams::res_up)
     constexpr int CK = 16, NA = 3, CO_TILE = CO_FR * 32, chs = kWtChs;
     constexpr int NX = 2 * CO_FR;                                    // extra barriers per tile (output transform)
     f16x8 *pieces = reinterpret_cast<f16x8 *>(conv_smem);            // [2][4][chs] x 16 B
@@ -572,10 +573,11 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
 
         // ---- output transform + epilogue.  This wave stores position fragment f = wave: outputs t = 2p, 2p + 1.
         [[maybe_unused]] const unsigned long long te = TICK();
-        int poff[2];
+        int poff[2], roff[2];                                         // byte offsets of the two outputs, and of their residuals
         {
             const int m = wave * 32 + l32;
             poff[0] = poff[1] = -1;
+            roff[0] = roff[1] = -1;
             Pos q;
             if (!P.flat) { q.ok = spk >= 0; q.pp = spk >> 20; q.th = (spk >> 10) & 1023; q.tw = spk & 1023; }
             else q.ok = pos_of(m, T, q.pp, q.th, q.tw);
@@ -584,6 +586,12 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
                 if (h < P.Hout && w < P.Wout) {
                     if (t < P.T) poff[0] = 4 * ((t * P.Cout) * (P.Hout * P.Woutp)) + 64 * (h * P.Woutp + w);
                     if (t + 1 < P.T) poff[1] = 4 * (((t + 1) * P.Cout) * (P.Hout * P.Woutp)) + 64 * (h * P.Woutp + w);
+                    if (RES && P.res_up) {
+                        if (t < P.T) roff[0] = 4 * ((t * P.Cout) * (P.rH * P.rWp)) + 64 * ((h >> 1) * P.rWp + (w >> 1));
+                        if (t + 1 < P.T) roff[1] = 4 * (((t + 1) * P.Cout) * (P.rH * P.rWp)) + 64 * ((h >> 1) * P.rWp + (w >> 1));
+                    } else {
+                        roff[0] = poff[0]; roff[1] = poff[1];
+                    }
                 }
             }
         }
@@ -596,8 +604,14 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
         const long long yseq = (long long)P.T * P.Cout * (P.Hout * P.Woutp);
         const int gstride = P.Hout * P.Woutp * 64;                    // bytes between 16-channel groups of a time step
         const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(P.y + T.b * yseq, 0, (int)(yseq * 4), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(RES ? P.res + T.b * yseq : P.scale), 0,
-                                                                              RES ? (int)(yseq * 4) : 0, 0x00020000);
+        const bool r_up = RES && P.res_up;                            // uniform
+        const long long rseq = r_up ? (long long)P.T * P.Cout * (P.rH * P.rWp) : yseq;
+        const int gstride_r = r_up ? P.rH * P.rWp * 64 : gstride;
+        const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(RES ? P.res + T.b * rseq : P.scale), 0,
+                                                                              RES ? (int)(rseq * 4) : 0, 0x00020000);
+        unsigned vr[2];
+#pragma unroll
+        for (int o = 0; o < 2; ++o) vr[o] = roff[o] >= 0 ? (unsigned)(roff[o] + 16 * half) : kOOB;
         unsigned vo[2], vmask[2];
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
@@ -615,7 +629,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
             for (int r4 = 0; r4 < 4; ++r4)
 #pragma unroll
                 for (int o = 0; o < 2; ++o) {
-                    if constexpr (RES) rv[o][r4] = __builtin_bit_cast(f32x4t, __builtin_amdgcn_raw_buffer_load_b128(rs_r, vo[o], soff_of(q, r4), 0));
+                    if constexpr (RES) rv[o][r4] = __builtin_bit_cast(f32x4t, __builtin_amdgcn_raw_buffer_load_b128(
+                                                       rs_r, vr[o], (co0 / 16 + 2 * q + (r4 >> 1)) * gstride_r + 32 * (r4 & 1), 0));
                     else rv[o][r4] = f32x4t{0.0f, 0.0f, 0.0f, 0.0f};
                 }
         };
@@ -944,6 +959,7 @@ struct WtTail {
     const int *thmap, *twmap;
     const void *w;
     const float *tx0_absmax, *tx1_absmax;
+    int res_h, res_wp;            // > 0 with a residual: it is a 2x-upsampled low-resolution tensor of res_h rows at a row pitch of res_wp
 };
 
 int wt_dispatch(const v2ce_conv3d_desc *desc, const float *x, const void *w_wt, const float *scale, const float *shift,
@@ -979,7 +995,13 @@ int wt_dispatch(const v2ce_conv3d_desc *desc, const float *x, const void *w_wt, 
     hipStream_t st = as_stream(stream);
     if (tl) {
         // (the contract of v2ce_conv3d_fwd_tail, conv3d.hip)
-        V2CE_REQUIRE(tl->desc && tl->w && !residual, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd_wt_tail: null tail description / weights, or a residual");
+        V2CE_REQUIRE(tl->desc && tl->w, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd_wt_tail: null tail description / weights");
+        if (residual && tl->res_h > 0) {
+            V2CE_REQUIRE(tl->res_h == (d.Hout + 1) / 2 && tl->res_wp >= (d.Wout + 1) / 2, V2CE_ERR_BAD_ARG,
+                         "v2ce_conv3d_fwd_wt_tail: an upsampled residual has ceil(Hout / 2) rows of at least ceil(Wout / 2) columns");
+            V2CE_REQUIRE((long long)d.T * d.Cout * tl->res_h * tl->res_wp < (1ll << 29), V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd_wt_tail: residual too large");
+            P.res_up = 1; P.rH = tl->res_h; P.rWp = tl->res_wp;
+        }
         const v2ce_conv3d_desc &t = *tl->desc;
         V2CE_REQUIRE(t.ksize == 1 && (t.stride_hw == 1 || t.stride_hw == 2) && t.layout == V2CE_LAYOUT_C16 && t.B == d.B && t.T == d.T &&
                      t.Cout == d.Cout && t.Hout == d.Hout && t.Wout == d.Wout && t.C0 > 0 && t.C0 % 16 == 0 && t.C1 >= 0 &&
@@ -998,6 +1020,7 @@ int wt_dispatch(const v2ce_conv3d_desc *desc, const float *x, const void *w_wt, 
         P.sc_w = static_cast<const _Float16 *>(tl->w);
         V2CE_REQUIRE((long long)t.T * t.C0 * t.H0 * P.tW0p < (1ll << 29) && (long long)t.T * t.C1 * t.Hin * P.tWinp < (1ll << 29),
                      V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd_wt_tail: a single sequence exceeds the 2 GiB buffer-descriptor range");
+        if (residual) return launch_wt<2, 4, 1, true>(P, d, st);
         return launch_wt<2, 4, 0, true>(P, d, st);
     }
     if (residual || (g_wt_name_out && scale)) return launch_wt<2, 4, 1>(P, d, st);
@@ -1064,10 +1087,11 @@ extern "C" int v2ce_conv3d_fwd_wt(const v2ce_conv3d_desc *desc, const float *x, 
 extern "C" int v2ce_conv3d_fwd_wt_tail(const v2ce_conv3d_desc *desc, const float *x, const void *w_wt, const float *scale, const float *shift,
                                        float *y, const float *x_absmax, float *y_absmax, const v2ce_conv3d_desc *tail_desc, const float *tx0,
                                        const float *tx1, const int32_t *thmap, const int32_t *twmap, const void *tail_w,
-                                       const float *tx0_absmax, const float *tx1_absmax, v2ce_stream_t stream) {
+                                       const float *tx0_absmax, const float *tx1_absmax, const float *residual, int res_h, int res_w_pitch,
+                                       v2ce_stream_t stream) {
     g_wt_name_out = nullptr;
-    const WtTail tl{tail_desc, tx0, tx1, thmap, twmap, tail_w, tx0_absmax, tx1_absmax};
-    return wt_dispatch(desc, x, w_wt, scale, shift, nullptr, y, x_absmax, y_absmax, stream, &tl);
+    const WtTail tl{tail_desc, tx0, tx1, thmap, twmap, tail_w, tx0_absmax, tx1_absmax, res_h, res_w_pitch};
+    return wt_dispatch(desc, x, w_wt, scale, shift, residual, y, x_absmax, y_absmax, stream, &tl);
 }
 
 extern "C" int v2ce_conv3d_wt_variant(const v2ce_conv3d_desc *desc, int with_residual, char *name, size_t cap) {
@@ -1080,8 +1104,13 @@ extern "C" int v2ce_conv3d_wt_variant(const v2ce_conv3d_desc *desc, int with_res
     if (with_residual == 2) {                              // the tail variant (any valid tail description names the same kernel)
         v2ce_conv3d_desc t = *desc;
         t.ksize = 1; t.stride_hw = 1; t.C0 = 64; t.C1 = 0; t.H0 = t.Hin = desc->Hout; t.W0 = t.Win = desc->Wout; t.layout = V2CE_LAYOUT_C16;
-        const WtTail tl{&t, nullptr, nullptr, nullptr, nullptr, &dummy, nullptr, nullptr};
+        const WtTail tl{&t, nullptr, nullptr, nullptr, nullptr, &dummy, nullptr, nullptr, 0, 0};
         rc = wt_dispatch(desc, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &tl);
+    } else if (with_residual == 3) {                       // the tail variant with a residual
+        v2ce_conv3d_desc t = *desc;
+        t.ksize = 1; t.stride_hw = 1; t.C0 = 64; t.C1 = 0; t.H0 = t.Hin = desc->Hout; t.W0 = t.Win = desc->Wout; t.layout = V2CE_LAYOUT_C16;
+        const WtTail tl{&t, nullptr, nullptr, nullptr, nullptr, &dummy, nullptr, nullptr, 0, 0};
+        rc = wt_dispatch(desc, nullptr, nullptr, nullptr, nullptr, &dummy, nullptr, nullptr, nullptr, nullptr, &tl);
     } else {
         rc = wt_dispatch(desc, nullptr, nullptr, with_residual ? &dummy : nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     }

@@ -157,7 +157,7 @@ def lib() -> ctypes.CDLL:
     L.v2ce_conv3d_up2_variant.restype = ctypes.c_int
     L.v2ce_conv3d_fwd_wt.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 9
     L.v2ce_conv3d_fwd_wt.restype = ctypes.c_int
-    L.v2ce_conv3d_fwd_wt_tail.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 7 + [ctypes.POINTER(ConvDesc)] + [vp] * 8
+    L.v2ce_conv3d_fwd_wt_tail.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 7 + [ctypes.POINTER(ConvDesc)] + [vp] * 8 + [i32, i32, vp]
     L.v2ce_conv3d_fwd_wt_tail.restype = ctypes.c_int
     L.v2ce_pack_weights_f16x2_wt_slice.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp]
     L.v2ce_pack_weights_f16x2_wt_slice.restype = ctypes.c_int

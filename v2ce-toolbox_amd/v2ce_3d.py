@@ -289,6 +289,17 @@ class V2ce3d(nn.Module):
                       "conv2": self._winograd() and splits["conv2"] and blk.cout % 64 == 0 and
                       (d["fold"] is None or (blk.cin % 64 == 0 and os.environ.get("V2CE_WT_TAIL", "1") != "0"))}
                 d["wt"] = wt
+                d["fold_lo"] = d["fold_skip"] = None
+                if name == "dec" and d["fold"] is not None and wt["conv2"] and self._upfold() and (blk.cin // 3) % 64 == 0 and \
+                        os.environ.get("V2CE_TAIL_LOWRES", "1") != "0":
+                    # the folded shortcut split by source: the upsampled channels' share s2 Wd'[:, :C0] x0 is computed at the SOURCE's
+                    # resolution (a 1x1x1 launch on a quarter of the positions) and added as an upsampled residual
+                    # (v2ce_conv3d_fwd_wt_tail, res_h); only the skip channels ride as the tail -- a third of its gathers and MFMAs
+                    c0 = blk.cin * 2 // 3
+                    wf = (blk.downsample[0].weight * (d["down_bn"][0] / d["bn2"][0]).view(-1, 1, 1, 1, 1))
+                    d["fold_lo"] = self._pack(wf[:, :c0].contiguous(), split=True)
+                    d["fold_skip"] = self._pack(wf[:, c0:].contiguous(), split=True)
+                d["zero_shift"] = torch.zeros(blk.cout, dtype=torch.float32, device=dev)
                 if blk.sn:
                     for cn in ("conv1", "conv2"):
                         m = getattr(blk, cn).module
@@ -421,7 +432,7 @@ class V2ce3d(nn.Module):
         return (w + 31) // 32 * 32
 
     def _conv(self, x0, x1, w_packed, scale, shift, cout, ksize, stride, act, residual=None,
-              up_to=None, split=False, track=False, pred=None, sc=None, dense_out=False, tail=None):
+              up_to=None, split=False, track=False, pred=None, sc=None, dense_out=False, tail=None, residual_up=False):
         """x0 [B,T,C0,H0,W0] (optionally nearest-upsampled to ``up_to``), x1 [B,T,C1,Hin,Win]."""
         # activations between the layers are [B,T,C,H,pitch] (planar) or [B,T,C/16,H,pitch,16] (`.c16`: what the
         # split-half kernels take and produce, include/v2ce_hip.h V2CE_LAYOUT_C16), logical width in `.lw` (see _pitch)
@@ -457,7 +468,9 @@ class V2ce3d(nn.Module):
         Hout = (Hin + 2 * pad - ksize) // stride + 1
         Wout = (Win + 2 * pad - ksize) // stride + 1
         Woutp = self._pitch(Wout) if dense_out is False else Wout
-        assert residual is None or residual.shape[4] == Woutp
+        assert residual is None or residual_up or residual.shape[4] == Woutp
+        if residual_up:         # a low-resolution residual read at (h >> 1, w >> 1): only the Winograd-T tail launch takes it
+            assert wt and tail is not None and residual.shape[3] == (Hout + 1) // 2 and getattr(residual, "c16", False)
         y = torch.empty((B, T, cout // 16, Hout, Woutp, 16) if c16 else (B, T, cout, Hout, Woutp),
                         dtype=torch.float32, device=x0.device)
         y.lw, y.c16 = Wout, c16
@@ -509,7 +522,7 @@ class V2ce3d(nn.Module):
                       "v2ce_conv3d_fwd_pred")
         elif tail is not None:         # folded 1x1x1 tail: the block's shortcut inside this launch's K loop
             tx0, tx1, t_up_to, t_stride, tw = tail
-            assert getattr(tx0, "c16", False) and (tx1 is None or getattr(tx1, "c16", False)) and residual is None
+            assert getattr(tx0, "c16", False) and (tx1 is None or getattr(tx1, "c16", False)) and (residual is None or wt)
             tC0, tH0, tW0p = tx0.shape[2] * 16, tx0.shape[3], tx0.shape[4]
             tW0 = getattr(tx0, "lw", tW0p)
             tHin, tWin = t_up_to if t_up_to is not None else (tH0, tW0)
@@ -527,7 +540,9 @@ class V2ce3d(nn.Module):
                 hip.check(hip.lib().v2ce_conv3d_fwd_wt_tail(ctypes.byref(d), x0.data_ptr(), w_packed.data_ptr(), scale.data_ptr(),
                                                             shift.data_ptr(), y.data_ptr(), hip.ptr(a0), hip.ptr(ay), ctypes.byref(td),
                                                             tx0.data_ptr(), hip.ptr(tx1), hip.ptr(thmap), hip.ptr(twmap), tw.data_ptr(),
-                                                            hip.ptr(ta0), hip.ptr(ta1), hip.stream_ptr(x0.device)),
+                                                            hip.ptr(ta0), hip.ptr(ta1), hip.ptr(residual),
+                                                            residual.shape[3] if residual_up else 0, residual.shape[4] if residual_up else 0,
+                                                            hip.stream_ptr(x0.device)),
                           "v2ce_conv3d_fwd_wt_tail")
             else:
                 hip.check(hip.lib().v2ce_conv3d_fwd_tail(ctypes.byref(d), x0.data_ptr(), hip.ptr(x1), hip.ptr(hmap), hip.ptr(wmap),
@@ -563,7 +578,7 @@ class V2ce3d(nn.Module):
                 flops += 2.0 * B * T * Hout * Wout * cout * (C0 + C1)
             if tail is not None:
                 flops += 2.0 * B * T * Hout * Wout * cout * 16 * (tail[0].shape[2] + (0 if tail[1] is None else tail[1].shape[2]))
-            name = hip.conv_wt_variant(d, 2 if tail is not None else residual is not None) if wt else hip.conv_up2_variant(d, sc is not None) if up2 else \
+            name = hip.conv_wt_variant(d, (3 if residual is not None else 2) if tail is not None else residual is not None) if wt else hip.conv_up2_variant(d, sc is not None) if up2 else \
                 hip.conv_variant(d, hmap is not None, (1 if pred is not None else (2 if sc is not None else (3 if tail is not None else 0))) +
                                  (4 if residual is not None else 0))
             # (flops = the ALGORITHMIC count of the reference's convolution; a phase-folded launch executes fewer: `executed`)
@@ -574,6 +589,13 @@ class V2ce3d(nn.Module):
         if sc is not None:
             return y, y_sc
         return y
+
+    @staticmethod
+    def _half_up(x0, up_to) -> bool:
+        """x0 is the source of an exact 2x nearest upsample to `up_to` (ATen's map is then dst >> 1)."""
+        H0, W0 = x0.shape[3], getattr(x0, "lw", x0.shape[4])
+        Hin, Win = up_to
+        return H0 == (Hin + 1) // 2 and W0 == (Win + 1) // 2 and _nearest_is_half(H0, Hin) and _nearest_is_half(W0, Win)
 
     def _up2_ok(self, x0, x1, w_packed, up_to) -> bool:
         """The phase-folded decoder launch applies: exact 2x nearest upsample (ATen's map is then dst >> 1) into folded weights."""
@@ -675,6 +697,10 @@ class V2ce3d(nn.Module):
             else:
                 t = self._conv(x0, x1, w1, *d["bn1"], blk.cout, 3, s, hip.ACT_RELU, up_to=up_to, split=True)
             fw, fscale, fshift = d["fold"]
+            if d.get("fold_lo") is not None and x1 is not None and up_to is not None and self._half_up(x0, up_to):
+                r0 = self._conv(x0, None, d["fold_lo"], fscale, d["zero_shift"], blk.cout, 1, 1, hip.ACT_NONE, split=True)
+                return self._conv(t, None, d["conv2_w"], fscale, fshift, blk.cout, 3, 1, hip.ACT_RELU, split=True, track=track,
+                                  tail=(x1, None, None, 1, d["fold_skip"]), residual=r0, residual_up=True)
             return self._conv(t, None, d["conv2_w"], fscale, fshift, blk.cout, 3, 1, hip.ACT_RELU, split=True, track=track,
                               tail=(x0, x1, up_to, s, fw))
         else:
