@@ -1491,6 +1491,10 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
             // form (RES 1) pays on the 32-channel tiles only (+3 %; the two-fragment-row tiles lose 6-12 % to its
             // registers), the others keep the run-time form
 #define V2CE_WS_RES(R_, ...) (P.res ? launch_f16x2_ws<__VA_ARGS__, R_>(P, d, st) : launch_f16x2_ws<__VA_ARGS__, 0>(P, d, st))
+            // (one 32-channel fragment row per wave: 12 MFMAs per tap -- a ring of nine taps covers the weight loads' L2 latency
+            // where three do not; V2CE_NA9=0: the three-slot ring)
+            static const bool na9 = [] { const char *e = getenv("V2CE_NA9"); return !(e && e[0] == '0'); }();
+            if (small_co && P.pred_w && na9) return V2CE_WS_RES(1, 3, 1, 1, 1, 4, 9, 1);
             if (small_co && P.pred_w) return V2CE_WS_RES(1, 3, 1, 1, 1, 4, 3, 1);
             if (small_co && P.sc_w) return launch_f16x2_ws<3, 1, 1, 1, 4, 3, 2, 0>(P, d, st);
             if (small_co) return V2CE_WS_RES(1, 3, 1, 1, 1, 4, 3, 0);
@@ -1531,7 +1535,10 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
         // stride 2: the halo box is ~4x the output box, so 128-position boxes; one 32-channel fragment
         // row per wave measured best (Cout >= 128: 300-320; Cout = 64: 245)
         if (P.sc_w) {
+            static const bool na9 = [] { const char *e = getenv("V2CE_NA9"); return !(e && e[0] == '0'); }();
+            // (128-channel tiles: both accumulator sets of four fragments and a nine-slot ring do not fit -- 173 spilled registers)
             if (d.Cout >= 128) return launch_f16x2_ws<3, 2, 4, 1, 4, 3, 2, 0>(P, d, st);
+            if (!small_co && na9) return launch_f16x2_ws<3, 2, 2, 1, 2, 9, 2, 0>(P, d, st);
             if (!small_co) return launch_f16x2_ws<3, 2, 2, 1, 2, 3, 2, 0>(P, d, st);
             return launch_f16x2_ws<3, 2, 1, 1, 1, 3, 2, 0>(P, d, st);
         }
