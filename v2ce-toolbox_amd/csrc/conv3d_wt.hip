@@ -70,14 +70,17 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
 #if defined(__HIP_DEVICE_COMPILE__)
     [[maybe_unused]] unsigned long long t_all = TICK(), t_bar = 0, t_epi = 0, t_xbar = 0, t_cvt = 0, t_e0 = 0, t_e1 = 0, t_e2 = 0;
     static_assert(PO_FR == 4, "the output transform hands position fragment f to consumer wave f");
+    // who runs the epilogue behind the output transform: the producers (their vector-memory counter takes the tile's 64 KB of stores, the
+    // consumers go on with the next tile), or -- the tail variants, whose producers have no registers left for it (63-186 spilled
+    // registers, dec2's launch 0.83 -> 0.88 ms) -- the consumers themselves
+    constexpr bool PEPI = !TAIL;
     // (TAIL with RES: a decoder's folded shortcut split by source -- the skip channels ride as the tail, the upsampled channels'
     // share arrives as a low-resolution residual, ConvParams::res_up)
     constexpr int CK = 16, NA = 3, CO_TILE = CO_FR * 32, chs = kWtChs;
-    constexpr int NX = 2 * CO_FR;                                    // extra barriers per tile (output transform)
     f16x8 *pieces = reinterpret_cast<f16x8 *>(conv_smem);            // [2][4][chs] x 16 B
     // scale | shift of the tile's CO_TILE channels, read by the epilogue with LDS loads: a global load there would sit behind the
     // previous round's stores in the in-order vector-memory counter (stamps: 2 k cycles per round waiting for write acknowledges)
-    float *aff = reinterpret_cast<float *>(conv_smem + (size_t)2 * 4 * chs * 16);     // [2][CO_TILE]
+    float *aff = reinterpret_cast<float *>(conv_smem + (size_t)2 * 4 * chs * 16);     // [tile parity][scale | shift][CO_TILE]
 
     const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -194,6 +197,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
         const Pos tpos = pos_cached(ptid & 127);                      // (tail: the output pair-position this lane gathers for)
         float x_scale = xs_of(T.b);
         float t_scale = TAIL ? ts_of(T.b) : 1.0f;
+        TileId Tprev = T;                                             // the tile whose chunks are all staged: its epilogue is the producers' (tile_rendezvous)
         unsigned toff[2][2];                                          // tail: [source][time step 2p, 2p+1] of this lane's output position
         [[maybe_unused]] int tm_pp = 0, tm_hi = 0, tm_wi = 0, tm_hs = 0, tm_ws = 0;
         [[maybe_unused]] bool tm_ok = false;
@@ -345,6 +349,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
             ++gc;
             if (++cgC == CGT) {
                 cgC = 0;
+                Tprev = T;
                 vb += (int)gridDim.x;
                 moreC = next_tile(vb, T);
                 if (moreC) {
@@ -353,10 +358,131 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
                 }
             }
         };
-        auto tile_rendezvous = [&]() {                                // the consumers' output transform of the tile before this one
+        // The epilogue of the tile BEFORE the one being staged (Tprev), by the producers: consumer wave j has left the accumulators of
+        // slot j in LDS; producer wave f sums the four slots of position fragment f into y(2p), y(2p+1), applies scale, shift, residual
+        // and activation (conv_epilogue's arithmetic, conv3d_dev.h) and stores.  The stores -- 64 KB per tile through a path that takes
+        // ~8 k cycles for them, in a vector-memory counter that is in order with the loads behind them -- drain in the producers'
+        // time: the consumers go on with the next tile's MFMAs after the two barriers of the last round.
+        const int fr = wave - 4;                                      // the position fragment this wave stores
+        int spk;                                                      // (pair << 20 | row << 10 | column) of this lane's position in it, -1: none
+        {
+            const Pos q = pos_cached(fr * 32 + l32);
+            spk = q.ok ? (q.pp << 20) | (q.th << 10) | q.tw : -1;
+        }
+        int seen_b = -1;                                              // range tracking: the batch element and the maximum already committed
+        unsigned seen_max = 0u;
+        int ntile_p = 0;
+        auto tile_rendezvous = [&]() {
             [[maybe_unused]] const unsigned long long tb = TICK();
+            if constexpr (!PEPI) {                                    // the consumers' own epilogue: only its barriers
 #pragma unroll
-            for (int k = 0; k < NX; ++k) lds_barrier();
+                for (int k = 0; k < 2 * CO_FR; ++k) lds_barrier();
+                ACC_T(t_xbar, tb);
+                return;
+            }
+            typedef float f32x4t __attribute__((ext_vector_type(4)));
+            typedef unsigned u32x4t __attribute__((ext_vector_type(4)));
+            const TileId &E = Tprev;
+            const int co0 = E.co_t * CO_TILE;
+            const float out_inv_scale = 1.0f / acc_scale_of(E.b);
+            const float *a2 = aff + (ntile_p & 1) * 2 * CO_TILE;
+            ++ntile_p;
+            int poff[2], roff[2];                                     // byte offsets of the two outputs, and of their residuals
+            {
+                const int m = fr * 32 + l32;
+                poff[0] = poff[1] = -1;
+                roff[0] = roff[1] = -1;
+                Pos q;
+                if (!P.flat) { q.ok = spk >= 0; q.pp = spk >> 20; q.th = (spk >> 10) & 1023; q.tw = spk & 1023; }
+                else q.ok = pos_of(m, E, q.pp, q.th, q.tw);
+                if (q.ok) {
+                    const int t = E.t0 + 2 * q.pp, h = E.h0 + q.th, w = E.w0 + q.tw;
+                    if (h < P.Hout && w < P.Wout) {
+                        if (t < P.T) poff[0] = 4 * ((t * P.Cout) * (P.Hout * P.Woutp)) + 64 * (h * P.Woutp + w);
+                        if (t + 1 < P.T) poff[1] = 4 * (((t + 1) * P.Cout) * (P.Hout * P.Woutp)) + 64 * (h * P.Woutp + w);
+                        if (RES && P.res_up) {
+                            if (t < P.T) roff[0] = 4 * ((t * P.Cout) * (P.rH * P.rWp)) + 64 * ((h >> 1) * P.rWp + (w >> 1));
+                            if (t + 1 < P.T) roff[1] = 4 * (((t + 1) * P.Cout) * (P.rH * P.rWp)) + 64 * ((h >> 1) * P.rWp + (w >> 1));
+                        } else {
+                            roff[0] = poff[0]; roff[1] = poff[1];
+                        }
+                    }
+                }
+            }
+            const f32x4t *xch = reinterpret_cast<const f32x4t *>(pieces + ((gc - 1) & 1) * 4 * chs);   // the buffer of that tile's last chunk
+            const long long yseq = (long long)P.T * P.Cout * (P.Hout * P.Woutp);
+            const int gstride = P.Hout * P.Woutp * 64;                // bytes between 16-channel groups of a time step
+            const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(P.y + E.b * yseq, 0, (int)(yseq * 4), 0x00020000);
+            const bool r_up = RES && P.res_up;                        // uniform
+            const long long rseq = r_up ? (long long)P.T * P.Cout * (P.rH * P.rWp) : yseq;
+            const int gstride_r = r_up ? P.rH * P.rWp * 64 : gstride;
+            const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(RES ? P.res + E.b * rseq : P.scale), 0,
+                                                                                  RES ? (int)(rseq * 4) : 0, 0x00020000);
+            unsigned vr[2], vo[2], vmask[2];
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                vr[o] = roff[o] >= 0 ? (unsigned)(roff[o] + 16 * half) : kOOB;
+                vo[o] = poff[o] >= 0 ? (unsigned)(poff[o] + 16 * half) : kOOB;
+                vmask[o] = poff[o] >= 0 ? 0x7fffffffu : 0u;
+            }
+            const float slope = act_slope(P.act);
+            unsigned ymax = 0u;
+            // channels co0 + 32 q + 8 r4 + 4 half + {0..3}: group (co0 / 16 + 2 q + (r4 >> 1)), bytes 32 (r4 & 1) + 16 half inside it
+#pragma unroll
+            for (int q = 0; q < CO_FR; ++q) {
+                f32x4t rv[2][4];                                      // the round's residual, requested before the round is waited for
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+                    for (int o = 0; o < 2; ++o) {
+                        if constexpr (RES) rv[o][r4] = __builtin_bit_cast(f32x4t, __builtin_amdgcn_raw_buffer_load_b128(
+                                                           rs_r, vr[o], (co0 / 16 + 2 * q + (r4 >> 1)) * gstride_r + 32 * (r4 & 1), 0));
+                        else rv[o][r4] = f32x4t{0.0f, 0.0f, 0.0f, 0.0f};
+                    }
+                lds_barrier();                                        // the consumers' round q is in LDS
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    // (one r4 at a time: sixteen registers of transformed sums next to the two chunks in flight -- reading the whole round
+                    // first, or half of it, spills 50-500 registers and costs more than the consumers' shorter wait gains)
+                    f32x4t mm[4];
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) mm[jj] = xch[fr * chs + jj * kWtSlot + r4 * 64 + lane];
+                    if (r4 == 3) lds_barrier();                       // every read of the round is done: the consumers may overwrite it
+                    const f32x4t scq = *reinterpret_cast<const f32x4t *>(a2 + 32 * q + 8 * r4 + 4 * half);
+                    const f32x4t shq = *reinterpret_cast<const f32x4t *>(a2 + CO_TILE + 32 * q + 8 * r4 + 4 * half);
+#pragma unroll
+                    for (int o = 0; o < 2; ++o) {
+                        f32x4t out;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float y = o == 0 ? (mm[0][k] + mm[1][k]) + mm[2][k] : (mm[1][k] - mm[2][k]) - mm[3][k];
+                            float v = y * (scq[k] * out_inv_scale) + shq[k];
+                            v += rv[o][r4][k];
+                            v = apply_act(v, slope);
+                            out[k] = v;
+                            const unsigned av = __builtin_bit_cast(unsigned, v) & vmask[o];
+                            ymax = av > ymax ? av : ymax;
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4t, out), rs_y, vo[o],
+                                                               (co0 / 16 + 2 * q + (r4 >> 1)) * gstride + 32 * (r4 & 1), 0);
+                        asm volatile("s_nop 1" : "+v"(out));          // (16-byte store data hazard: conv_epilogue)
+                    }
+                }
+            }
+            if (P.y_absmax) {
+                // max |y| of the tile -> the launch's range slot; the wave remembers the largest value it has already committed for this
+                // batch element and sends an atomic (no return value, nothing to wait for) only beyond that
+#pragma unroll
+                for (int o = 32; o; o >>= 1) {
+                    const unsigned other = (unsigned)__shfl_xor((int)ymax, o);
+                    ymax = other > ymax ? other : ymax;
+                }
+                if (E.b != seen_b) { seen_b = E.b; seen_max = 0u; }
+                if (ymax > seen_max) {                                // uniform
+                    seen_max = ymax;
+                    if (lane == 0) atomicMax(reinterpret_cast<unsigned *>(P.y_absmax + E.b * P.amax_bs), ymax);
+                }
+            }
             ACC_T(t_xbar, tb);
         };
         load_next(R0);
@@ -405,22 +531,23 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
             al[slot_][q] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_a, wlane[q], so_ + lo_off, 0)); \
         }                                                                                      \
     }
-    // this lane's offset in the slot's plane for each of its fragments (-1: no position), and (pair << 20 | row << 10 | column) of the
-    // position it stores (-1: none) -- one register each across the main loop
+    // this lane's offset in the slot's plane for each of its fragments (-1: no position) -- one register each across the main loop
     int crel[PO_FR];
 #pragma unroll
     for (int f = 0; f < PO_FR; ++f) {
         const Pos q = pos_cached(f * 32 + l32);
         crel[f] = q.ok ? (q.pp * P.HH + q.th) * P.HWd + q.tw : -1;
     }
-    int spk;
-    {
+
+    int ring_co_t = -1;
+    int ntile = 0;                                                    // tiles of this workgroup so far: parity of the scale / shift table
+    [[maybe_unused]] int spk = -1;                                    // (!PEPI: the position this lane stores, packed; range tracking state)
+    if constexpr (!PEPI) {
         const Pos q = pos_cached(wave * 32 + l32);
         spk = q.ok ? (q.pp << 20) | (q.th << 10) | q.tw : -1;
     }
-    int ring_co_t = -1;
-    int seen_b = -1;                                                  // range tracking: the batch element and the maximum already committed
-    unsigned seen_max = 0u;
+    [[maybe_unused]] int seen_b = -1;
+    [[maybe_unused]] unsigned seen_max = 0u;
     bool more = true;
     while (more) {
         const int co0 = T.co_t * CO_TILE;
@@ -440,12 +567,16 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
         }
         if (T.co_t != ring_co_t) {                                    // uniform: (re)load the ring for this channel tile
             ring_co_t = T.co_t;
-            // (every consumer wave writes the same values; the tile's chunk barriers separate them from the epilogue's reads,
-            // and the previous tile's reads from these writes: its last rendezvous barrier)
+        }
+        {
+            // scale | shift of this tile's channels for the producers' epilogue, in the table of the tile's parity (they read it while
+            // the consumers are already in the next tile, which writes the other one); every consumer wave writes the same values
+            float *a2 = aff + (ntile & 1) * 2 * CO_TILE;
             if (lane < CO_TILE) {
-                aff[lane] = P.scale[co0 + lane];
-                aff[CO_TILE + lane] = P.shift[co0 + lane];
+                a2[lane] = P.scale[co0 + lane];
+                a2[CO_TILE + lane] = P.shift[co0 + lane];
             }
+            ++ntile;
 #pragma unroll
             for (int q = 0; q < CO_FR; ++q) {
                 int co = co0 + q * 32 + l32;
@@ -569,8 +700,31 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
                 tail_barrier(i);
             }
         }
-        const float out_inv_scale = inv_scale;
 
+        if constexpr (PEPI) {
+        // ---- output transform: the accumulators go to the producers through LDS, one channel fragment row per round
+        [[maybe_unused]] const unsigned long long te = TICK();
+        typedef float f32x4t __attribute__((ext_vector_type(4)));
+        f32x4t *xch = reinterpret_cast<f32x4t *>(pieces + ((gc - 1) & 1) * 4 * chs);   // the buffer of the tile's last chunk
+#pragma unroll
+        for (int q = 0; q < CO_FR; ++q) {
+            // (round q > 0: the producers' reads of the previous round are behind its second barrier)
+#pragma unroll
+            for (int f = 0; f < PO_FR; ++f)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    f32x4t v;
+                    v[0] = acc[q][f][4 * r4]; v[1] = acc[q][f][4 * r4 + 1]; v[2] = acc[q][f][4 * r4 + 2]; v[3] = acc[q][f][4 * r4 + 3];
+                    xch[f * chs + wave * kWtSlot + r4 * 64 + lane] = v;
+                }
+            [[maybe_unused]] const unsigned long long tb = TICK();
+            lds_barrier();                                            // the round is in LDS
+            lds_barrier();                                            // the producers have read it
+            ACC_T(t_xbar, tb);
+        }
+        ACC_T(t_epi, te);
+        } else {
+        const float *aff_c = aff + ((ntile - 1) & 1) * 2 * CO_TILE;   // (this tile's table)
         // ---- output transform + epilogue.  This wave stores position fragment f = wave: outputs t = 2p, 2p + 1.
         [[maybe_unused]] const unsigned long long te = TICK();
         int poff[2], roff[2];                                         // byte offsets of the two outputs, and of their residuals
@@ -658,8 +812,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
             [[maybe_unused]] const unsigned long long te1 = TICK();
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
-                scq[r4] = *reinterpret_cast<const f32x4t *>(aff + 32 * q + 8 * r4 + 4 * half);
-                shq[r4] = *reinterpret_cast<const f32x4t *>(aff + CO_TILE + 32 * q + 8 * r4 + 4 * half);
+                scq[r4] = *reinterpret_cast<const f32x4t *>(aff_c + 32 * q + 8 * r4 + 4 * half);
+                shq[r4] = *reinterpret_cast<const f32x4t *>(aff_c + CO_TILE + 32 * q + 8 * r4 + 4 * half);
             }
 #pragma unroll
             for (int hp = 0; hp < 2; ++hp) {                          // two r4 per pass: 32 registers of transformed sums at a time
@@ -684,7 +838,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const float y = o == 0 ? (mm[rr][0][k] + mm[rr][1][k]) + mm[rr][2][k] : (mm[rr][1][k] - mm[rr][2][k]) - mm[rr][3][k];
-                            float v = y * (scq[r4][k] * out_inv_scale) + shq[r4][k];
+                            float v = y * (scq[r4][k] * inv_scale) + shq[r4][k];
                             v += rv[o][r4][k];
                             v = apply_act(v, slope);
                             out[k] = v;
@@ -714,6 +868,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
         }
         ACC_T(t_epi, te);
         ACC_T(t_e2, te2);
+        }
         vb += (int)gridDim.x;
         more = next_tile(vb, T);
     }
@@ -912,7 +1067,7 @@ int launch_wt(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream) {
     }
     const long long blocks = (long long)8 * P.per_xcd * P.n_co_tiles;
     P.total_blocks = (int)blocks;
-    const size_t lds = (size_t)kWtChs * (2 * 4 * 16) + 2 * CO_TILE * sizeof(float);      // 128 KB of pieces + scale | shift of the tile's channels
+    const size_t lds = (size_t)kWtChs * (2 * 4 * 16) + 2 * 2 * CO_TILE * sizeof(float);  // 128 KB of pieces + two scale | shift tables
     auto kern = conv3d_wt_kernel<CO_FR, PO_FR, RES, TAIL>;
     static const int once = [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
