@@ -443,7 +443,15 @@ __global__ __launch_bounds__(512, 1) void conv3d_up_kernel(UpParams U) {
 #define V2CE_UP_NB_SC 1
 #endif
     constexpr int NB = CO_FR == 1 ? (FUSE == 2 ? V2CE_UP_NB_SC : 2) : 1;
-    f16x8 ah[3][CO_FR], al[3][CO_FR], bh[NB][PO_FR], bl[NB][PO_FR];
+    // two-fragment lists (CO_FR = 2: the folded lists of a wave with two phases of two fragments, or with one phase of two): a fragment's
+    // in-place refill has only the other fragment's six MFMAs (192 cycles) to land -- the B sets alternate by tap there too.  Only
+    // the list's own fragments are live, so two sets of two cost what one set of four does (the skip chunks' lists keep one set).
+#ifndef V2CE_UP_NB2F
+#define V2CE_UP_NB2F 2
+#endif
+    constexpr int NB0 = (NB == 1 && NFG == 2) ? V2CE_UP_NB2F : NB;            // B sets of the folded lists
+    constexpr int NBA = NB0 > NB ? NB0 : NB;
+    f16x8 ah[3][CO_FR], al[3][CO_FR], bh[NBA][PO_FR], bl[NBA][PO_FR];
     int wlane[CO_FR];
 #define V2CE_LOAD_A(slot_, soff_, lod_)                                                        \
     {                                                                                          \
@@ -571,13 +579,14 @@ __global__ __launch_bounds__(512, 1) void conv3d_up_kernel(UpParams U) {
             step_loop<0, NT>([&](auto tc) {
                 constexpr int tap = decltype(tc)::value;
                 constexpr int pt = tap + 2;                   // the tap whose A fragments are fetched now
-                constexpr int cs = NB == 2 ? tap % 2 : 0, ns = NB == 2 ? (tap + 1) % 2 : 0;      // B sets of this / the next tap
+                constexpr int NBL = SKIP ? NB : NB0;                                             // B sets of this list
+                constexpr int cs = NBL == 2 ? tap % 2 : 0, ns = NBL == 2 ? (tap + 1) % 2 : 0;    // B sets of this / the next tap
                 if constexpr (pt < NT) {
                     V2CE_LOAD_A(pt % 3, cur.abase + pt * cur.tstride, cur.lod)
                 } else {
                     V2CE_LOAD_A(pt % 3, nxt.abase + (pt - NT) * nxt.tstride, nxt.lod)
                 }
-                if constexpr (NB == 2 && tap + 1 < NT) {       // the next tap's B fragments, a whole tap ahead
+                if constexpr (NBL == 2 && tap + 1 < NT) {      // the next tap's B fragments, a whole tap ahead
 #pragma unroll
                     for (int f = F0; f < F0 + NF; ++f) {
                         const int a = addr(f, tap + 1);
@@ -606,7 +615,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_up_kernel(UpParams U) {
                             }
                         }
                     }
-                    if constexpr (NB == 1 && tap + 1 < NT) {   // refill in place for the next tap
+                    if constexpr (NBL == 1 && tap + 1 < NT) {  // refill in place for the next tap
                         const int a = addr(f, tap + 1);
                         bh[0][f] = qb[a];
                         bl[0][f] = qb[a + 2 * chs];
