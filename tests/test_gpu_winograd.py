@@ -212,3 +212,24 @@ def test_conv3d_wt_tail_with_upsampled_residual_vs_f64():
     acc = F.conv3d(t_in.double(), w2.double(), None, 1, 1) + F.conv3d(xs, wd.double(), None, 1, 0)
     want = torch.relu(acc * s2.double().view(1, -1, 1, 1, 1) + sh.double().view(1, -1, 1, 1, 1)).numpy()
     assert_close(V2ce3d.to_planar(y).permute(0, 2, 1, 3, 4).cpu().numpy(), want, "conv2 + split shortcut")
+
+
+@pytest.mark.parametrize("case", [(6, 64, 96), (2, 40, 56), (4, 33, 47)])
+def test_network_with_odd_sequence_lengths_vs_oracle(case):
+    """The whole UNet on sequences of 5 / 1 / 3 frame-pairs (the Winograd-T kernels pair time steps: the last pair's second step does
+    not exist; ragged planes) against the oracle at 1e-5 -- reference forward /root/reference/scripts/unet_2layer.py:335-379."""
+    from oracle import glue as OG
+    from oracle import unet as U
+    from v2ce_toolbox_amd import synth
+    from v2ce_toolbox_amd.v2ce_3d import V2ce3d
+    nfr, H, W = case
+    sd = synth.make_state_dict(0)
+    x = OG.preprocess(synth.synthetic_frames(nfr, H, W, seed=5))[None]
+    want = U.forward({k: v.clone() for k, v in sd.items()}, torch.from_numpy(x)).contiguous().numpy()
+    m = V2ce3d()
+    m.load_state_dict(sd)
+    m = m.eval().to("cuda")
+    m.profile = []
+    got = m(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert any("conv3d_wt_kernel" in p[0] for p in m.profile), "the Winograd-T launches ran"
+    assert_close(got, want, f"network {case}")
