@@ -490,7 +490,7 @@ class V2ce3d(nn.Module):
             if split:          # untracked inputs (None) select the kernel's fixed pre-scale
                 a0 = getattr(x0, "absmax", None)
                 a1 = None if x1 is None or a0 is None else x1.absmax
-        prof = getattr(self, "profile", None)
+        prof = self._prof_list()
         if prof is not None:       # HIP events on the launch stream (torch's current stream)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -621,7 +621,7 @@ class V2ce3d(nn.Module):
         ay = self._prep["absmax"][self._slot]          # (only its range-guard value matters: the partial sum feeds no split-half launch)
         self._slot += 1
         a0 = getattr(x0, "absmax", None)
-        prof = getattr(self, "profile", None)
+        prof = self._prof_list()
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -633,6 +633,18 @@ class V2ce3d(nn.Module):
             per_tap = 2.0 * B * T * Hin * Win * cout * C0
             prof.append((hip.conv_up2_variant(d, False), 27 * per_tap, e0, e1, 12 * per_tap))
         return y
+
+    def _prof_list(self):
+        """The list this launch's HIP events go to, or None.  ``profile_filter`` (a set of launch indices of a forward call, or None):
+        events only around those launches -- ~90 event records per forward cost 0.13-0.24 ms of a 16 ms step (bench.py profiles
+        every launch in its warm-up steps and only the dominant kernel family in the timed ones)."""
+        prof = getattr(self, "profile", None)
+        idx = getattr(self, "_launch_idx", 0)
+        self._launch_idx = idx + 1
+        flt = getattr(self, "profile_filter", None)
+        if prof is None or (flt is not None and idx not in flt):
+            return None
+        return prof
 
     def _head_split(self, x, table, bias):
         """The head convolution on the split-half kernel: max |x| per sequence into a range slot (v2ce_absmax_batch), then
@@ -654,7 +666,7 @@ class V2ce3d(nn.Module):
         d = hip.ConvDesc(B=B, T=T, C0=2, H0=H, W0=W, C1=0, Hin=H, Win=W, Cout=32, Hout=H, Wout=W, ksize=3, stride_hw=1,
                          act=hip.ACT_LEAKY, tile_t=0, tile_h=0, tile_w=0, precision=hip.PRECISION_F16X2, W0_pitch=W, Win_pitch=W,
                          Wout_pitch=Wp, layout=hip.LAYOUT_C16, absmax_batch_stride=2 if per_b else 0)
-        prof = getattr(self, "profile", None)
+        prof = self._prof_list()
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -808,6 +820,7 @@ class V2ce3d(nn.Module):
             self._prepare()
         P, U = self._prep, self.UNet
         self._slot = 0
+        self._launch_idx = 0
         if self.precision == "f16x2":
             if P["absmax"].shape[1] != x.shape[0]:
                 P["absmax"] = torch.zeros((64, x.shape[0], 2), dtype=torch.float32, device=x.device)
