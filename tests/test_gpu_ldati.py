@@ -435,6 +435,52 @@ def test_dense_tile_kernel_equals_per_bin_kernel(gold_dir, monkeypatch):
     assert hashlib.sha256(ev.to_recarrays()[0].tobytes()).hexdigest() == meta["sha256_packed_events"]
 
 
+def test_pair_pass_kernel_equals_per_bin_kernel(monkeypatch):
+    """ldati_tile_pair_kernel (round 6: two bins of a dense tile per pass where their records share the LDS) against the
+    per-bin dense kernel (V2CE_LDATI_NO_PAIR=1): same bytes and the oracle's events -- on Philox stress frames (pairs 0-1 .. 6-7
+    and bin 8 alone in the 16-wave form), at half and quarter that density (the 8-wave form, two workgroups per CU; at the
+    lower density every pass is a pair), on a tile mix where pairs and single-bin passes alternate (a bin that fits with
+    neither neighbour), with a voxel outside the slope table in either bin of a pair, at 60 fps with a start time, through the
+    two-pass path (fused count off) and the dense slot mode (second call of a stream) alike."""
+    from v2ce_toolbox_amd import LDATI
+
+    def both(run):
+        monkeypatch.delenv("V2CE_LDATI_NO_PAIR", raising=False)
+        a = run()
+        monkeypatch.setenv("V2CE_LDATI_NO_PAIR", "1")
+        b = run()
+        monkeypatch.delenv("V2CE_LDATI_NO_PAIR")
+        assert np.array_equal(a.seg_counts, b.seg_counts)
+        assert a.packed().cpu().numpy().tobytes() == b.packed().cpu().numpy().tobytes()
+        return a
+
+    for scale, seed in ((6.0, 5), (3.0, 6), (1.5, 7)):
+        vox = (scale * np.random.default_rng(seed).random((2, 2, 10, 260, 346))).astype(np.float32)
+        LDATI._SEG_HINT.clear()
+        ev = both(lambda: hip_events(vox, seed=31 + seed, frame_base=3))           # first call of a stream: the two-pass path
+        ev2 = both(lambda: hip_events(vox, seed=31 + seed, frame_base=3))          # second call: the dense kernel is the count pass
+        assert ev.packed().cpu().numpy().tobytes() == ev2.packed().cpu().numpy().tobytes()
+        seg, ts, x, y, p = O.emit_soa(vox[:1], fps=30, seed=31 + seed, frame_base=3)
+        n0 = int(seg.sum())
+        assert np.array_equal(ev.seg_counts[:1], seg) and np.array_equal(ev.ts.cpu().numpy()[:n0], ts)
+        assert np.array_equal(ev.x.cpu().numpy()[:n0], x) and np.array_equal(ev.y.cpu().numpy()[:n0], y)
+        assert np.array_equal(ev.p.cpu().numpy()[:n0], p)
+    # bins of very different weight: pairs where two light bins meet, single passes around the heavy ones
+    rng = np.random.default_rng(11)
+    mix = (rng.random((2, 2, 10, 128, 160)) * np.array([1, 9, 1, 1, 12, 12, 1, 0.2, 5, 3], np.float32)[None, None, :, None, None]).astype(np.float32)
+    mix[0, 0, 4, 50, 7] = 45.0                                    # count 45 > 31: outside the slope table, second bin of a pair
+    mix[1, 1, 2, 70, 9] = 60.0                                    # ... and the first bin of one
+    mix[1, 0, :, :40] = 0.0                                       # an empty stretch: bins without a record inside a pass
+    for fps, t0 in ((30, 0), (60, 0.5)):
+        LDATI._SEG_HINT.clear()
+        for _ in range(2):
+            soa_equal(both(lambda: hip_events(mix, fps, t0, seed=77, frame_base=1)), *O.emit_soa(mix, fps=fps, t0=t0, seed=77, frame_base=1))
+    # the fused count switched off: tile offsets from the count pass instead of slots
+    monkeypatch.setenv("V2CE_LDATI_NO_FUSED", "1")
+    soa_equal(both(lambda: hip_events(mix, seed=78)), *O.emit_soa(mix, fps=30, seed=78))
+    monkeypatch.delenv("V2CE_LDATI_NO_FUSED")
+
+
 def test_c5_stress_chunk_full_size(monkeypatch):
     """BASELINE config 5 at the size bench.py times: 24 frame-pairs of 346x260 `6 U[0,1)` voxels, Philox (127.7 M events:
     the fullest chunk histograms, 32-bit record offsets).  Counts of the first and the last frame vs the oracle, sortedness

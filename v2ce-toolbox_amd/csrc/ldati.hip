@@ -94,6 +94,7 @@ struct LdatiParams {
     int T, tpp;                   // tiles per frame (2*tpp), tiles per polarity plane
     int PB;                       // bits of a pixel index
     int capA, cap2;               // LDS capacities (records) of the tile pass / the bucket sort
+    int capP;                     // > 0: ldati_tile_pair_kernel -- records of one PASS (one or two bins of a tile) its LDS holds (>= capA)
     int tbits;                    // binary-search steps over the tiles of a frame
     const unsigned *tile_off;     // [B][T][9] exclusive prefix of the tile counts inside the segment
     const unsigned *tc;           // [B][T][9] the tile counts themselves
@@ -1828,6 +1829,471 @@ __device__ __forceinline__ void dense_tile_body(const LdatiParams &P) {
     STAMP_FLUSH(0, 10);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 6: TWO bins of a dense tile per pass (`dense_pair_body`, the common call only: dense_tile_body<NW, true>'s switches).
+// What the per-bin kernel pays per (tile, BIN) whatever the bin holds -- the classification scans, six workgroup barriers, the
+// scan of the (row, bucket) histogram, the list and batch hand-out, the copy-out prologue: 4.9 us of a workgroup's life per
+// bin (the round-5 density sweep, tools/ldati_density_probe.py: the tile pass of 24 frame-pairs takes 363 us + 2.25 us per million
+// events, i.e. more than half of the stress chunk's 650 us does not depend on the events) -- is paid once per PASS; a pass holds bins c and c + 1 when their records fit the LDS together (capP), else bin c alone.  The two
+// bins' records share S (bin c's positions first), the work lists (an entry carries its bin), the batches of the timestamp
+// phase, one histogram whose cell index is (bin in pass, bucket), one scan, one rank phase and one copy-out loop per run.
+// To make room for two bins' cells the histogram counts in 16 bits, two cells per word: a cell never exceeds the pass's record
+// count (<= capP < 2^16), offsets included, so a half never carries into its neighbour, and the LDS atomic still returns the
+// stable rank (lanes of one wave-instruction that hit the same WORD are served in lane order whichever half they add to).
+// LDS map (dynamic): S [capP] | O [capP + 16] (lists alias it) | hist [NW][2^(12 - shift)] words | wave totals, partials, ...
+// Requires 12-bit keys (NK <= 4096: the bin of a record rides in bit 24 of its S word) and 2^(12 - shift) <= threads.
+// ---------------------------------------------------------------------------------------------
+template <int NW>
+__device__ __forceinline__ void dense_pair_body(const LdatiParams &P) {
+    constexpr int NT = 64 * NW, PPT = kTilePix / NT, WPX = 64 * PPT;
+    static_assert(PPT == 4 || PPT == 2, "a lane owns 2 or 4 consecutive pixels");
+    const int t = blockIdx.x, b = blockIdx.y;
+    if (P.sparse_cap) {                                 // the sparse tile kernel owns the lightly populated tiles
+        const unsigned *tcr = P.tc + ((long long)b * P.T + t) * 9;
+        unsigned ntot = 0;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) ntot += tcr[c];
+        if (ntot <= (unsigned)P.sparse_cap) return;
+    }
+    const int pidx = t < P.tpp ? 1 : 0;
+    const int x0 = (t < P.tpp ? t : t - P.tpp) * kTilePix;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float2 *stab = g_slope_tab[P.fast_slot];
+    const unsigned hsl = 12u - (unsigned)P.shift;       // log2 of a bin's cell stride = log2 of the words of a histogram row
+    const unsigned HS = 1u << hsl;
+
+    unsigned *S = reinterpret_cast<unsigned *>(tile_smem);
+    unsigned *O = S + P.capP;
+    unsigned *hist = O + P.capP + 16;                   // [NW][HS] words, two 16-bit cells each: cell g = bin in pass << hsl | bucket
+    unsigned *part = hist + NW * HS;                    // [6][NW] wave totals (see D1)
+    unsigned *spart = part + 6 * NW;                    // [NW + 1] scan partials
+    unsigned *bctr = spart + NW + 1;                    // the next batch of the timestamp phase
+    unsigned *dsto = bctr + 2;                          // [9][2] where the tile's run of bin c starts in records[]
+    unsigned *nbin = dsto + 18;                         // [9] slot mode: the bins' record counts
+    unsigned *myhist = hist + wid * HS;
+
+    const float *plane0 = P.vox + (long long)(b * 2 + pidx) * 10 * P.HW;
+    const unsigned frame = (unsigned)(P.frame_base + b);
+    const int lpx0 = wid * WPX + lane * PPT;
+    const int gpx0 = x0 + lpx0;
+    const float eps = 1e-6f;
+
+    auto load_plane = [&](int plane, float (&y)[PPT]) {          // (16-byte aligned planes: the common call)
+        const float *src = plane0 + (long long)plane * P.HW + gpx0;
+        if (PPT == 4) {
+            const float4 v = gpx0 < P.HW ? *reinterpret_cast<const float4 *>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+            y[0] = v.x; y[1] = v.y; y[PPT - 2] = v.z; y[PPT - 1] = v.w;
+        } else {
+            const float2 v = gpx0 < P.HW ? *reinterpret_cast<const float2 *>(src) : make_float2(0.f, 0.f);
+            y[0] = v.x; y[1] = v.y;
+        }
+    };
+
+    // the relocation recurrence as a window over the bins: counts of bins c - 1 .. c + 2, tendencies of c .. c + 2; the planes of
+    // bins c + 3 and c + 4 (and voxel 9 beside plane 8) are in flight
+    int nm1[PPT], n0[PPT], n1[PPT], n2[PPT];
+    float d0[PPT], d1[PPT], d2[PPT], ya[PPT], yb[PPT], y9[PPT];
+    {
+        float p0[PPT], p1[PPT], p2[PPT];
+        load_plane(0, p0);
+        load_plane(1, p1);
+        load_plane(2, p2);
+        load_plane(3, ya);
+        load_plane(4, yb);
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            float r = p0[q] - 0.0f;
+            float cc = ceilf(r - eps);
+            d0[q] = cc - r;
+            n0[q] = (int)cc;
+            r = p1[q] - d0[q];
+            cc = ceilf(r - eps);
+            d1[q] = cc - r;
+            n1[q] = (int)cc;
+            r = p2[q] - d1[q];
+            cc = ceilf(r - eps);
+            d2[q] = cc - r;
+            n2[q] = (int)cc;
+            nm1[q] = 0;
+            y9[q] = 0.0f;
+        }
+    }
+    auto advance = [&](int c) {                          // the window's first bin moves from c to c + 1
+        const int pn = c + 3;                            // ya holds plane pn
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            nm1[q] = n0[q]; n0[q] = n1[q]; n1[q] = n2[q];
+            d0[q] = d1[q]; d1[q] = d2[q];
+            int ni = 0;
+            if (pn <= 8) {
+                const float r = ya[q] - d2[q];
+                const float cc = ceilf(r - eps);
+                d2[q] = cc - r;
+                ni = (int)cc;
+                if (pn == 8) ni += (int)(y9[q] - d2[q]);         // LDATI.py:106
+            }
+            n2[q] = ni;
+            ya[q] = yb[q];
+        }
+        if (pn + 2 <= 8) load_plane(pn + 2, yb);
+        if (pn + 2 == 8) load_plane(9, y9);
+    };
+
+    for (unsigned i = tid; i < NW * HS; i += NT) hist[i] = 0;
+    if (tid == 0) *bctr = 0;
+    if (tid < 9) {
+        const long long d = P.slot_cap ? (((long long)b * P.T + t) * 9 + tid) * (long long)P.slot_cap
+                                       : P.seg_offsets[b * 9 + tid] + (long long)P.tile_off[((long long)b * P.T + t) * 9 + tid];
+        dsto[2 * tid] = (unsigned)d;
+        dsto[2 * tid + 1] = (unsigned)((unsigned long long)d >> 32);
+        if (P.slot_cap) P.tile_abs_w[(long long)(b * 9 + tid) * P.Tp + t] = (unsigned)d;
+    }
+    int vmax_l = 0;
+    __syncthreads();
+
+    // one bin's classes and positions (dense_tile_body's D1): cls 0 nothing, 1 single, 2 / 3 multi from the table with k == 0 /
+    // k != 0, 4 multi outside the table; running sums per lane: At = events | singles << 16, Ut = k == 0 units | k != 0 units << 16
+    auto classify = [&](const int (&np)[PPT], const int (&nc)[PPT], const int (&nn)[PPT], bool edge, unsigned (&cls)[PPT],
+                        unsigned (&aex)[PPT], unsigned (&uex)[PPT], unsigned &At, unsigned &Ut, unsigned &Ae) {
+        At = Ut = Ae = 0;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const int n = nc[q];
+            const bool multi = n >= 2;
+            const int dd = edge ? 0 : nn[q] - np[q];
+            const bool intab = (unsigned)(dd + kSlopeM) <= 2u * kSlopeM && (unsigned)n <= (unsigned)kSlopeM &&
+                               (unsigned)(np[q] | nn[q]) < (1u << 23);
+            const unsigned si = (unsigned)((dd + kSlopeM) * (kSlopeM + 1) + n);
+            const unsigned cl = n == 1 ? 1u : !multi ? 0u : !intab ? 4u : dd == 0 ? 2u : 3u;
+            cls[q] = cl | ((si & 0x7FFu) << 3);
+            const unsigned units = (unsigned)(n + 3) >> 2;
+            aex[q] = At;
+            uex[q] = Ut;
+            At += (cl ? (unsigned)n : 0u) + (cl == 1u ? 0x10000u : 0u);
+            Ut += cl == 2u ? units : cl == 3u ? units << 16 : 0u;
+            Ae += cl ? ((unsigned)n < (1u << 20) ? (unsigned)n : 1u << 20) : 0u;
+        }
+    };
+    // totals and this wave's exclusive prefix of NW per-wave values written to LDS in front of a barrier
+    auto wave_totals = [&](const unsigned *src, unsigned &total, unsigned &base) {
+        const unsigned p = wave_incl_scan(lane < NW ? src[lane] : 0u, lane);
+        total = (unsigned)__builtin_amdgcn_readlane((int)p, NW - 1);
+        base = wid ? (unsigned)__builtin_amdgcn_readlane((int)p, wid - 1) : 0u;
+    };
+
+    STAMP_DECL;
+    for (int c = 0; c < 9;) {
+        STAMP(0);
+        const bool hasB = c + 1 < 9;
+        // ---- D1: classes and positions of bins c (A) and c + 1 (B) -------------------------------------------------
+        unsigned clsA[PPT], aexA[PPT], uexA[PPT], clsB[PPT], aexB[PPT], uexB[PPT];
+        unsigned AtA, UtA, AeA, AtB, UtB, AeB;
+        classify(nm1, n0, n1, c == 0 || c == 8, clsA, aexA, uexA, AtA, UtA, AeA);
+        classify(n0, n1, n2, c + 1 == 8, clsB, aexB, uexB, AtB, UtB, AeB);
+        if (!hasB) { AtB = UtB = AeB = 0; }
+        const unsigned iA = wave_incl_scan(AtA, lane), iUA = wave_incl_scan(UtA, lane);
+        const unsigned iB = wave_incl_scan(AtB, lane), iUB = wave_incl_scan(UtB, lane);
+        const unsigned rA = (unsigned)__builtin_amdgcn_readlane((int)iA, 63), rUA = (unsigned)__builtin_amdgcn_readlane((int)iUA, 63);
+        const unsigned rB = (unsigned)__builtin_amdgcn_readlane((int)iB, 63), rUB = (unsigned)__builtin_amdgcn_readlane((int)iUB, 63);
+        if (lane == 0) { part[wid] = rA; part[NW + wid] = rUA; part[2 * NW + wid] = rB; part[3 * NW + wid] = rUB; }
+        if (P.slot_cap) {                                // (uniform) the unpacked event sums: see dense_tile_body
+            const unsigned eA = (unsigned)__builtin_amdgcn_readlane((int)wave_incl_scan(AeA, lane), 63);
+            const unsigned eB = (unsigned)__builtin_amdgcn_readlane((int)wave_incl_scan(AeB, lane), 63);
+            if (lane == 0) { part[4 * NW + wid] = eA; part[5 * NW + wid] = eB; }
+        }
+        __syncthreads();                                 // A: wave totals; O (the previous pass's runs) is free again
+        STAMP(1);
+        unsigned tA, tUA, tB, tUB, bsA, bsUA, bsB, bsUB;
+        wave_totals(part, tA, bsA);
+        wave_totals(part + NW, tUA, bsUA);
+        wave_totals(part + 2 * NW, tB, bsB);
+        wave_totals(part + 3 * NW, tUB, bsUB);
+        bool doB = hasB;
+        if (P.slot_cap) {
+            unsigned N32A, N32B, dummy;
+            wave_totals(part + 4 * NW, N32A, dummy);
+            wave_totals(part + 5 * NW, N32B, dummy);
+            if (tid == 0) {
+                nbin[c] = N32A;
+                if (hasB) nbin[c + 1] = N32B;
+            }
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) {
+                vmax_l = n0[q] > vmax_l ? n0[q] : vmax_l;
+                if (hasB) vmax_l = n1[q] > vmax_l ? n1[q] : vmax_l;
+            }
+            if (N32A > (unsigned)P.capA) {               // uniform: a run beyond its slot is only counted
+                advance(c);
+                ++c;
+                continue;
+            }
+            if (N32B > (unsigned)P.capA) doB = false;
+        }
+        const unsigned NA = tA & 0xFFFFu;
+        if (doB && NA + (tB & 0xFFFFu) > (unsigned)P.capP) doB = false;
+        if (!doB) { tB = tUB = 0; }
+        const unsigned NB_ = tB & 0xFFFFu, Ntot = NA + NB_;
+        const unsigned NsA = tA >> 16, NsB = tB >> 16, Ns = NsA + NsB;
+        const unsigned U0 = (tUA & 0xFFFFu) + (tUB & 0xFFFFu), U1 = (tUA >> 16) + (tUB >> 16);
+        // the two runs in O: A at its destination's phase modulo four records, B behind it at its own
+        const unsigned dshA = dsto[2 * c] & 3u, dshB = doB ? dsto[2 * (c + 1)] & 3u : 0u;
+        const unsigned obB = ((dshA + NA + 3u) & ~3u) + dshB;
+        uint2 *UL1 = reinterpret_cast<uint2 *>(O), *UL0 = UL1 + U1;
+        unsigned *SLs = O + 2u * (U1 + U0);
+        int lgL = 6;
+        while (((unsigned)NW << lgL) < Ntot) ++lgL;
+        const float offtA = P.offt[c], offtB = P.offt[hasB ? c + 1 : c];
+        const int kbA = (int)P.kbase[c], kbB = (int)P.kbase[hasB ? c + 1 : c];
+        const unsigned pcA = (unsigned)(pidx * 9 + c);
+        auto put = [&](unsigned sp, unsigned rec, unsigned g) {
+            S[sp] = rec;
+            atomicAdd(&hist[((sp >> lgL) << hsl) + (g >> 1)], 1u << ((g & 1u) << 4));
+        };
+        // ---- D2: work lists of the pass: k != 0 units | k == 0 units | singles, each wave's entries of A in front of its entries of B
+        {
+            // this wave's first entries: the waves in front (both bins), then for B this wave's entries of A
+            const unsigned wU = (bsUA & 0xFFFFu) + (doB ? bsUB & 0xFFFFu : 0u), wK = (bsUA >> 16) + (doB ? bsUB >> 16 : 0u);
+            const unsigned wS = (bsA >> 16) + (doB ? bsB >> 16 : 0u);
+            auto lists = [&](unsigned bsel, const unsigned (&cls)[PPT], const unsigned (&aex)[PPT], const unsigned (&uex)[PPT],
+                             const int (&np)[PPT], const int (&nc)[PPT], const int (&nn)[PPT], const float (&dc)[PPT],
+                             unsigned lanA, unsigned lanU, unsigned pos0, unsigned u0at, unsigned u1at, unsigned sat, int cb) {
+#pragma unroll
+                for (int q = 0; q < PPT; ++q) {
+                    const unsigned local = (unsigned)(lpx0 + q), pos = pos0 + ((lanA + aex[q]) & 0xFFFFu);
+                    const int n = nc[q];
+                    const unsigned cl = cls[q] & 7u;
+                    if (cl == 1u) {
+                        SLs[sat + ((lanA + aex[q]) >> 16)] = pos | (local << 14) | (bsel << 25);
+                        S[pos] = __float_as_uint(dc[q]);                 // the single's tendency waits in its record slot
+                    } else if (cl == 2u || cl == 3u) {
+                        const unsigned ue = lanU + uex[q];
+                        uint2 *dstu = cl == 2u ? UL0 + u0at + (ue & 0xFFFFu) : UL1 + u1at + (ue >> 16);
+                        const unsigned units = (unsigned)(n + 3) >> 2, hi = (cls[q] >> 3) << 14, lb = local | (bsel << 28);
+                        dstu[0] = make_uint2(lb | (((unsigned)n < 4u ? (unsigned)n : 4u) << 29), pos | hi);
+                        for (unsigned jb = 1; jb < units; ++jb) {
+                            const unsigned left = (unsigned)n - 4u * jb;
+                            dstu[jb] = make_uint2(lb | (jb << 11) | ((left < 4u ? left : 4u) << 29), (pos + 4u * jb) | hi);
+                        }
+                    } else if (cl == 4u) {               // outside the slope table: generated in place by its owner
+                        float k, bb;
+                        slope_params(np[q], n, nn[q], cb, P, k, bb);
+                        const unsigned px = (unsigned)x0 + local;
+                        for (int j = 0; j < n; ++j) {
+                            const float u = philox_uniform(P.seed, px, (unsigned)j, (unsigned)(pidx * 9 + cb), frame);
+                            const unsigned key = multi_key(k, bb, u, P.offt[cb], (int)P.kbase[cb], P, true);
+                            put(pos + (unsigned)j, (bsel << 24) | (key << 12) | (1u << kLocalBits) | local, (bsel << hsl) | (key >> P.shift));
+                        }
+                    }
+                }
+            };
+            lists(0u, clsA, aexA, uexA, nm1, n0, n1, d0, iA - AtA, iUA - UtA, bsA & 0xFFFFu, wU, wK, wS, c);
+            if (doB)
+                lists(1u, clsB, aexB, uexB, n0, n1, n2, d1, iB - AtB, iUB - UtB, NA + (bsB & 0xFFFFu), wU + (rUA & 0xFFFFu), wK + (rUA >> 16),
+                      wS + (rA >> 16), c + 1);
+        }
+        __syncthreads();                                 // A2: the work lists are complete
+        STAMP(2);
+        // ---- D3: timestamps, once; batches of 64 list entries handed out through an LDS counter ----------------------
+        auto single_batch = [&](unsigned i) {            // (called by whole waves: single_key votes)
+            const bool has = i < Ns;
+            const unsigned e = has ? SLs[i] : 0u, sp = e & 0x3FFFu, bsel = e >> 25;
+            const unsigned key = single_key(has, has ? __uint_as_float(S[sp]) : 0.0f, bsel ? offtB : offtA, (long long)(bsel ? kbB : kbA), true, P);
+            if (has) put(sp, (bsel << 24) | (key << 12) | ((e >> 14) & (kTilePix - 1)), (bsel << hsl) | (key >> P.shift));
+        };
+        auto unit_batch = [&](auto mode_c, const uint2 *list, unsigned i, unsigned count) {
+            constexpr int MODE = decltype(mode_c)::value;        // 1: k == 0 units (checked fast constant divisions), 3: k != 0 units
+            if (i < count) {
+                const uint2 e = list[i];
+                const unsigned local = e.x & (kTilePix - 1), jb = (e.x >> kLocalBits) & 0x1FFFFu, bsel = (e.x >> 28) & 1u, cnt = e.x >> 29;
+                const unsigned sp = e.y & 0x3FFFu;
+                float2 kb = make_float2(0.0f, 0.0f);
+                if (MODE == 3) kb = stab[e.y >> 14];
+                const unsigned px = (unsigned)x0 + local;
+                const float offt_c = bsel ? offtB : offtA;
+                const int kbase_c = bsel ? kbB : kbA;
+                unsigned o[4];
+                philox4_b3(P.seed, px, jb, pcA + bsel, frame, o);
+                float tq[4];
+                if (MODE == 3) {
+                    const float r1 = rcp_refined(kb.x), bb2 = kb.y * kb.y, k2 = 2.0f * kb.x;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) tq[s] = div_rn_nr(-kb.y + sqrt_rn_nr(bb2 + k2 * u24(o[s])), kb.x, r1);
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) tq[s] = k0_time_fast(u24(o[s]), P.FPS, P.RFPS, P.R9);
+                }
+                const unsigned tag = (bsel << 24) | (1u << kLocalBits) | local, gsel = bsel << hsl;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    float tt = tq[s] + offt_c;
+                    tt = tt * 1e6f;
+                    int kk = (int)tt - kbase_c;
+                    kk = kk < 0 ? 0 : kk;
+                    const unsigned key = (unsigned)(kk >= P.NK ? P.NK - 1 : kk);
+                    if ((unsigned)s < cnt) put(sp + s, (key << 12) | tag, gsel | (key >> P.shift));
+                }
+            }
+        };
+        {
+            const unsigned nK = (U1 + 63u) >> 6, nZ = (U0 + 63u) >> 6, nS = (Ns + 63u) >> 6, nb = nK + nZ + nS;
+            unsigned nxt = 0;
+            if (lane == 0) nxt = atomicAdd(bctr, 1u);
+            for (;;) {
+                const unsigned bid = (unsigned)__builtin_amdgcn_readfirstlane((int)nxt);
+                if (bid >= nb) break;
+                const bool early = bid + 2u * NW < nb;
+                if (early && lane == 0) nxt = atomicAdd(bctr, 1u);
+                if (bid < nK) unit_batch(std::integral_constant<int, 3>{}, UL1, bid * 64u + lane, U1);
+                else if (bid < nK + nZ) unit_batch(std::integral_constant<int, 1>{}, UL0, (bid - nK) * 64u + lane, U0);
+                else single_batch((bid - nK - nZ) * 64u + lane);
+                if (!early && lane == 0) nxt = atomicAdd(bctr, 1u);
+            }
+        }
+        STAMP(4);
+        __syncthreads();                                 // B: every row of the histogram is complete
+        STAMP(5);
+        // ---- D4: cell-major, row-minor exclusive scan; the tile's rows of the run table -----------------------------
+        {
+            // thread = one word of the rows = two neighbouring cells of one bin, all NW rows (HS <= NT: the host's condition)
+            unsigned v[NW];
+            unsigned run0 = 0, run1 = 0;
+            const bool mine = (unsigned)tid < HS;
+            if (mine) {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) v[w] = hist[(unsigned)w * HS + tid];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    const unsigned c0 = v[w] & 0xFFFFu, c1 = v[w] >> 16;
+                    v[w] = run0 | (run1 << 16);
+                    run0 += c0;
+                    run1 += c1;
+                }
+            }
+            unsigned tot;
+            const unsigned boff = block_excl_scan<NW>(run0 + run1, spart, &tot);
+            if (mine) {
+                const unsigned bsel = (unsigned)tid >> (hsl - 1u);           // cells [0, HS) are bin A's, [HS, 2 HS) bin B's
+                const unsigned adj = bsel ? obB - NA : dshA;                  // prefix inside the pass -> index in O
+                const unsigned packed = (boff + adj) | ((boff + run0 + adj) << 16);
+#pragma unroll
+                for (int w = 0; w < NW; ++w) hist[(unsigned)w * HS + tid] = v[w] + packed;
+                const unsigned bkt = (2u * (unsigned)tid) & (HS - 1u);
+                const int cb = c + (int)bsel;
+                if (bsel == 0u || doB) {
+                    unsigned short *row = P.roff + ((long long)(b * 9 + cb) * P.T + t) * (P.NB + 1);
+                    const unsigned rb = boff - (bsel ? NA : 0u);
+                    if (bkt < (unsigned)P.NB) row[bkt] = (unsigned short)rb;
+                    if (bkt + 1u < (unsigned)P.NB) row[bkt + 1u] = (unsigned short)(rb + run0);
+                }
+            }
+            if (tid == 0) {
+                P.roff[((long long)(b * 9 + c) * P.T + t) * (P.NB + 1) + P.NB] = (unsigned short)NA;
+                if (doB) P.roff[((long long)(b * 9 + c + 1) * P.T + t) * (P.NB + 1) + P.NB] = (unsigned short)NB_;
+            }
+        }
+        __syncthreads();                                 // C: cell offsets per row
+        STAMP(6);
+        // ---- D5: stable ranks: the wave walks its records in position order; the rank is what the LDS atomic returns ------
+        {
+            const unsigned sh = 12u + (unsigned)P.shift;
+            const unsigned lo = (unsigned)wid << lgL, hi = min(Ntot, lo + (1u << lgL));
+            unsigned i = lo + lane, i0 = lo;
+            for (; i0 + 256u <= hi; i0 += 256u, i += 256u) {
+                unsigned rec[4], at[4], hs[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rec[j] = S[i + 64u * j];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned g = rec[j] >> sh;
+                    hs[j] = (g & 1u) << 4;
+                    at[j] = atomicAdd(&myhist[g >> 1], 1u << hs[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) O[(at[j] >> hs[j]) & 0xFFFFu] = rec[j] & 0xFFFFFFu;
+            }
+            for (; i < hi; i += 64u) {
+                const unsigned rec = S[i], g = rec >> sh, hs = (g & 1u) << 4;
+                O[(atomicAdd(&myhist[g >> 1], 1u << hs) >> hs) & 0xFFFFu] = rec & 0xFFFFFFu;
+            }
+        }
+        STAMP(7);
+        __syncthreads();                                 // D: the runs are complete in O
+        STAMP(8);
+        for (unsigned i = tid; i < NW * HS; i += NT) hist[i] = 0;      // for the next pass (first touched behind its barrier A)
+        if (tid == 0) *bctr = 0;
+        {
+            // O[ob + i] -> dst[i]: 16-byte pieces where the piece lies inside the run, single records at its two ends
+            auto copy_run = [&](int cb, unsigned ob, unsigned dsh, unsigned N) {
+                const long long dst0 = (long long)(((unsigned long long)dsto[2 * cb + 1] << 32) | dsto[2 * cb]);
+                unsigned *dstq = P.temp + (dst0 - (long long)dsh);            // 16-byte aligned
+                const uint4 *src = reinterpret_cast<const uint4 *>(O + (ob - dsh));
+                const unsigned nq = (dsh + N + 3u) >> 2;
+                for (unsigned q = tid; q < nq; q += NT) {
+                    const uint4 v = src[q];
+                    if (4u * q >= dsh && 4u * q + 4u <= dsh + N) {
+                        reinterpret_cast<uint4 *>(dstq)[q] = v;
+                    } else {
+                        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (4u * q + j >= dsh && 4u * q + j < dsh + N) dstq[4u * q + j] = w[j];
+                    }
+                }
+            };
+            copy_run(c, dshA, dshA, NA);
+            if (doB) copy_run(c + 1, obB, dshB, NB_);
+        }
+        STAMP(9);
+        advance(c);
+        ++c;
+        if (doB) {
+            advance(c);
+            ++c;
+        }
+    }
+    if (P.slot_cap) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int m = __shfl_xor(vmax_l, o);
+            vmax_l = m > vmax_l ? m : vmax_l;
+        }
+        if (lane == 0 && vmax_l > 0 && (unsigned long long)vmax_l > *reinterpret_cast<volatile unsigned long long *>(&P.stats_w[0]))
+            atomicMax(&P.stats_w[0], (unsigned long long)vmax_l);
+        __syncthreads();
+        if (tid < 9) P.tc_w[((long long)b * P.T + t) * 9 + tid] = nbin[tid];
+        if (tid == 0) {
+            unsigned tile_total = 0;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) tile_total += nbin[c];
+            if (tile_total > 0 && (unsigned long long)tile_total > *reinterpret_cast<volatile unsigned long long *>(&P.stats_w[4]))
+                atomicMax(&P.stats_w[4], (unsigned long long)tile_total);
+        }
+    }
+    STAMP(0);
+    STAMP_FLUSH(0, 10);
+}
+
+// true when every run-time switch of the common call is on (dense_tile_body<NW, true>'s condition)
+__device__ __forceinline__ bool dense_fast_call(const LdatiParams &P) {
+    bool fast = P.fast_slot >= 0 && P.rng_mode == V2CE_RNG_PHILOX && !P.ballot_ranks && P.ts32 && (P.HW & 3) == 0 &&
+                P.strategy != V2CE_STRATEGY_NONE;
+    if (fast) {
+        const FastDiv &f = g_fastdiv[P.fast_slot];
+        fast = __builtin_amdgcn_readfirstlane((int)f.fps_bits) == (int)__float_as_uint(P.FPS) && __builtin_amdgcn_readfirstlane(f.ok) != 0 &&
+               __builtin_amdgcn_readfirstlane(f.tab_ready) != 0 && __builtin_amdgcn_readfirstlane(f.ok64) != 0 &&
+               __builtin_amdgcn_readfirstlane(g_lds_order_ok) != 0;
+    }
+    return fast;
+}
+
+// the pair-pass form for the common call; any other call (replayed uniforms, 'none', ballot ranks, a device table not ready)
+// runs the per-bin body in the same launch (the LDS of the launch covers both maps)
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 4) void ldati_tile_pair_kernel(LdatiParams P) {
+    if (dense_fast_call(P)) dense_pair_body<NW>(P);
+    else dense_tile_body<NW, false>(P);
+}
+
 template <int NW>
 __global__ __launch_bounds__(64 * NW, 4) void ldati_tile_dense_kernel(LdatiParams P) {   // 4 waves per SIMD: two 512-thread workgroups per CU
     bool fast = P.fast_slot >= 0 && P.rng_mode == V2CE_RNG_PHILOX && !P.ballot_ranks && P.ts32 && (P.HW & 3) == 0 &&
@@ -3233,9 +3699,50 @@ bool dense_kernel_serves(const LdatiParams &P, const Opts &o) {
     return !o.bidir && !P.kbb && P.ts32 && !getenv("V2CE_LDATI_OLD_TILE") &&
            (o.strategy == V2CE_STRATEGY_NONE || (o.strategy == V2CE_STRATEGY_SLOPE && P.fast_slot >= 0));
 }
+// the pair-pass kernel's host-side conditions (its device-side ones -- the tables of this fps, the LDS order probe -- are read
+// in the kernel, which runs the per-bin body when one fails)
+bool dense_kernel_serves_pair(const LdatiParams &P) {
+    return P.rng_mode == V2CE_RNG_PHILOX && P.strategy == V2CE_STRATEGY_SLOPE && !P.ballot_ranks && P.ts32 && (P.HW & 3) == 0 &&
+           P.fast_slot >= 0;
+}
+// dynamic LDS of ldati_tile_pair_kernel<NW>'s pair body: S [capP] | O [capP + 16] | hist [NW][2^(12 - shift)] | wave totals, partials, ...
+size_t dense_pair_lds(int capP, int shift, int NW) {
+    return ((size_t)2 * capP + 16 + ((size_t)NW << (12 - shift)) + 6 * NW + NW + 1 + 2 + 18 + 10 + 3) * 4;
+}
+// records of one pass the pair body can hold in `budget` bytes of LDS (a multiple of 256), 0 when the call has no pair form:
+// 12-bit keys (the bin of a record rides above them), one histogram word per thread in the scan, 14-bit positions
+int pair_capacity(const LdatiParams &P, const Plan &pl, int NW, size_t budget) {
+    if (P.NK > 4096 || pl.shift > 8 || (1 << (12 - pl.shift)) > 64 * NW || getenv("V2CE_LDATI_NO_PAIR")) return 0;
+    const size_t fixed = dense_pair_lds(0, pl.shift, NW);
+    if (fixed + 2048 > budget) return 0;
+    long long cap = (long long)((budget - fixed) / 8) & ~255ll;
+    if (cap > kCapTile) cap = kCapTile;
+    return cap >= pl.capA ? (int)cap : 0;
+}
 int launch_dense_kernel(const LdatiParams &P, const Plan &pl, int B, hipStream_t st) {
     const size_t lds8 = dense_tile_lds(pl.capA, pl.NB, 8), lds16 = dense_tile_lds(pl.capA, pl.NB, 16);
     static const int force_nw = [] { const char *e = getenv("V2CE_LDATI_DENSE_NW"); return e ? atoi(e) : 0; }();   // kernel A/B runs
+    // round 6: two bins per pass where their records fit the LDS together (dense_pair_body); 512 threads when the largest single
+    // (tile, bin) fits two workgroups per CU in that form too
+    if (dense_kernel_serves_pair(P)) {
+        const int cap8 = pair_capacity(P, pl, 8, 80 * 1024), cap16 = pair_capacity(P, pl, 16, 160 * 1024);
+        const bool p8 = force_nw == 16 ? false : cap8 > 0;
+        const int capP = p8 ? cap8 : cap16;
+        if (capP > 0) {
+            LdatiParams Q = P;
+            Q.capP = capP;
+            const int nw = p8 ? 8 : 16;
+            size_t lds = dense_pair_lds(capP, pl.shift, nw);
+            const size_t single = dense_tile_lds(pl.capA, pl.NB, nw);          // (a call that is not the common one runs the per-bin body)
+            if (single > lds) lds = single;
+            if (lds <= 160 * 1024) {
+                auto pk = p8 ? ldati_tile_pair_kernel<8> : ldati_tile_pair_kernel<16>;
+                V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(pk, dim3(pl.T, B), dim3(64 * nw), lds, st, Q);
+                return V2CE_OK;
+            }
+        }
+    }
     const bool w8 = force_nw == 16 ? false : (force_nw == 8 && lds8 <= 160 * 1024) ? true : lds8 <= 80 * 1024;       // two workgroups per CU
     auto dk = w8 ? ldati_tile_dense_kernel<8> : ldati_tile_dense_kernel<16>;
     const size_t lds = w8 ? lds8 : lds16;
