@@ -549,6 +549,8 @@ def main():
     try:
         import glob
         files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{args.workload}_pmc_traffic.json")))
+        if not files:
+            raise LookupError(f"no counter summary committed for this workload (profiles/r*_{args.workload}_pmc_traffic.json)")
         pmc, prov = fresh(files[-1])
         if model is not None:
             roofline["traffic"] = pmc[counter_key(pmc)]["traffic_bytes"]
@@ -568,12 +570,16 @@ def main():
         import glob
         if model is not None:
             files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_e2e_mfma_busy.json")))
+            if not files:
+                raise LookupError("no counter summary committed for this workload (profiles/r*_e2e_mfma_busy.json)")
             data, prov = fresh(files[-1])
             mb = data[counter_key(data)]
             roofline["mfma_busy"] = mb["mfma_busy"]
             roofline["mfma_busy_source"] = os.path.basename(files[-1]) + f" (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8), avg per launch; {prov['lib_version']}, sources {prov['source_hash']})"
         else:
             files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{args.workload}_sq_counters.json")))
+            if not files:
+                raise LookupError(f"no counter summary committed for this workload (profiles/r*_{args.workload}_sq_counters.json)")
             sq, prov = fresh(files[-1])
             roofline["valu_frac"] = sq["valu_frac"]
             roofline["valu_lane_slots_per_event"] = sq["valu_lane_slots_per_event"]

@@ -49,4 +49,4 @@ for title, base, names in (("tile pass (wave 0 of every workgroup)", 0, names_t)
     tot = v[base:base + len(names)].sum()
     print(title)
     for i, n in enumerate(names):
-        print(f"   {n:32s} {100 * v[base + i] / tot:6.1f} %")
+        print(f"   {n:32s} {100 * v[base + i] / tot:6.1f} %   {v[base + i] / 3e6:9.2f} Mcycles per call (wave 0 of every workgroup)")

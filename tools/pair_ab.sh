@@ -36,3 +36,9 @@ for r in csv.DictReader(open(sys.argv[1])):
 PY
   done
 done
+# phase stamps of the tile pass, both kernels (diagnostic library)
+for mode in pair nopair; do
+  if [ $mode = nopair ]; then export V2CE_LDATI_NO_PAIR=1; else unset V2CE_LDATI_NO_PAIR; fi
+  echo "stamps $mode"
+  V2CE_HIP_LIB=v2ce-toolbox_amd/csrc/libv2ce_hip_stamp.so timeout 300 python3 tools/ldati_stamps.py stress 2>&1 | head -12
+done

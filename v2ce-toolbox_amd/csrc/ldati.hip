@@ -1840,7 +1840,7 @@ __device__ __forceinline__ void dense_tile_body(const LdatiParams &P) {
 // To make room for two bins' cells the histogram counts in 16 bits, two cells per word: a cell never exceeds the pass's record
 // count (<= capP < 2^16), offsets included, so a half never carries into its neighbour, and the LDS atomic still returns the
 // stable rank (lanes of one wave-instruction that hit the same WORD are served in lane order whichever half they add to).
-// LDS map (dynamic): S [capP] | O [capP + 16] (lists alias it) | hist [NW][2^(12 - shift)] words | wave totals, partials, ...
+// LDS map (dynamic): S [capP] | O [capP + 16] (lists alias it) | hist [NW][2^(12 - shift)] words | wave totals, partials, ... | voxel 9 [2048]
 // Requires 12-bit keys (NK <= 4096: the bin of a record rides in bit 24 of its S word) and 2^(12 - shift) <= threads.
 // ---------------------------------------------------------------------------------------------
 template <int NW>
@@ -1870,6 +1870,7 @@ __device__ __forceinline__ void dense_pair_body(const LdatiParams &P) {
     unsigned *bctr = spart + NW + 1;                    // the next batch of the timestamp phase
     unsigned *dsto = bctr + 2;                          // [9][2] where the tile's run of bin c starts in records[]
     unsigned *nbin = dsto + 18;                         // [9] slot mode: the bins' record counts
+    float *y9s = reinterpret_cast<float *>(nbin + 10);  // [PPT][NT] voxel 9 of the tile's pixels
     unsigned *myhist = hist + wid * HS;
 
     const float *plane0 = P.vox + (long long)(b * 2 + pidx) * 10 * P.HW;
@@ -1889,17 +1890,17 @@ __device__ __forceinline__ void dense_pair_body(const LdatiParams &P) {
         }
     };
 
-    // the relocation recurrence as a window over the bins: counts of bins c - 1 .. c + 2, tendencies of c .. c + 2; the planes of
-    // bins c + 3 and c + 4 (and voxel 9 beside plane 8) are in flight
+    // the relocation recurrence as a window over the bins: counts of bins c - 1 .. c + 2, tendencies of c .. c + 2.  The planes the
+    // window needs to move on (c + 3, c + 4) are loaded at the head of every pass and consumed at its end -- each into its own
+    // registers (a register move of a load in flight would wait for it); voxel 9, needed once beside plane 8, waits in LDS
     int nm1[PPT], n0[PPT], n1[PPT], n2[PPT];
-    float d0[PPT], d1[PPT], d2[PPT], ya[PPT], yb[PPT], y9[PPT];
+    float d0[PPT], d1[PPT], d2[PPT], ya[PPT], yb[PPT];
     {
-        float p0[PPT], p1[PPT], p2[PPT];
+        float p0[PPT], p1[PPT], p2[PPT], p9[PPT];
         load_plane(0, p0);
         load_plane(1, p1);
         load_plane(2, p2);
-        load_plane(3, ya);
-        load_plane(4, yb);
+        load_plane(9, p9);
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
             float r = p0[q] - 0.0f;
@@ -1915,28 +1916,25 @@ __device__ __forceinline__ void dense_pair_body(const LdatiParams &P) {
             d2[q] = cc - r;
             n2[q] = (int)cc;
             nm1[q] = 0;
-            y9[q] = 0.0f;
+            ya[q] = yb[q] = 0.0f;
+            y9s[q * NT + tid] = p9[q];                  // (read back by the same thread: no barrier)
         }
     }
-    auto advance = [&](int c) {                          // the window's first bin moves from c to c + 1
-        const int pn = c + 3;                            // ya holds plane pn
+    auto advance = [&](int pn, const float (&yp)[PPT]) {  // the window's first bin moves on by one; yp = plane pn = its first bin + 3
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
             nm1[q] = n0[q]; n0[q] = n1[q]; n1[q] = n2[q];
             d0[q] = d1[q]; d1[q] = d2[q];
             int ni = 0;
             if (pn <= 8) {
-                const float r = ya[q] - d2[q];
+                const float r = yp[q] - d2[q];
                 const float cc = ceilf(r - eps);
                 d2[q] = cc - r;
                 ni = (int)cc;
-                if (pn == 8) ni += (int)(y9[q] - d2[q]);         // LDATI.py:106
+                if (pn == 8) ni += (int)(y9s[q * NT + tid] - d2[q]);        // LDATI.py:106
             }
             n2[q] = ni;
-            ya[q] = yb[q];
         }
-        if (pn + 2 <= 8) load_plane(pn + 2, yb);
-        if (pn + 2 == 8) load_plane(9, y9);
     };
 
     for (unsigned i = tid; i < NW * HS; i += NT) hist[i] = 0;
@@ -1951,27 +1949,29 @@ __device__ __forceinline__ void dense_pair_body(const LdatiParams &P) {
     int vmax_l = 0;
     __syncthreads();
 
-    // one bin's classes and positions (dense_tile_body's D1): cls 0 nothing, 1 single, 2 / 3 multi from the table with k == 0 /
-    // k != 0, 4 multi outside the table; running sums per lane: At = events | singles << 16, Ut = k == 0 units | k != 0 units << 16
-    auto classify = [&](const int (&np)[PPT], const int (&nc)[PPT], const int (&nn)[PPT], bool edge, unsigned (&cls)[PPT],
-                        unsigned (&aex)[PPT], unsigned (&uex)[PPT], unsigned &At, unsigned &Ut, unsigned &Ae) {
+    // one voxel's class (dense_tile_body's D1): 0 nothing, 1 single, 2 / 3 multi from the slope table with k == 0 / k != 0, 4 multi
+    // outside the table; the table index in bits 3..13.  The pass computes it twice -- for the sums in front of barrier A and again
+    // behind it for the lists -- instead of keeping six values per pixel alive across the barrier (the kernel has no registers left)
+    auto voxel_class = [&](int np, int n, int nn, bool edge) -> unsigned {
+        const int dd = edge ? 0 : nn - np;
+        const bool intab = (unsigned)(dd + kSlopeM) <= 2u * kSlopeM && (unsigned)n <= (unsigned)kSlopeM && (unsigned)(np | nn) < (1u << 23);
+        const unsigned si = (unsigned)((dd + kSlopeM) * (kSlopeM + 1) + n);
+        const unsigned cl = n == 1 ? 1u : n < 2 ? 0u : !intab ? 4u : dd == 0 ? 2u : 3u;
+        return cl | ((si & 0x7FFu) << 3);
+    };
+    // a voxel's contribution to the lane's running sums: At = events | singles << 16, Ut = k == 0 units | k != 0 units << 16
+    auto voxel_sums = [&](unsigned cls, int n, unsigned &At, unsigned &Ut) {
+        const unsigned cl = cls & 7u, units = (unsigned)(n + 3) >> 2;
+        At += (cl ? (unsigned)n : 0u) + (cl == 1u ? 0x10000u : 0u);
+        Ut += cl == 2u ? units : cl == 3u ? units << 16 : 0u;
+    };
+    auto classify = [&](const int (&np)[PPT], const int (&nc)[PPT], const int (&nn)[PPT], bool edge, unsigned &At, unsigned &Ut, unsigned &Ae) {
         At = Ut = Ae = 0;
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
-            const int n = nc[q];
-            const bool multi = n >= 2;
-            const int dd = edge ? 0 : nn[q] - np[q];
-            const bool intab = (unsigned)(dd + kSlopeM) <= 2u * kSlopeM && (unsigned)n <= (unsigned)kSlopeM &&
-                               (unsigned)(np[q] | nn[q]) < (1u << 23);
-            const unsigned si = (unsigned)((dd + kSlopeM) * (kSlopeM + 1) + n);
-            const unsigned cl = n == 1 ? 1u : !multi ? 0u : !intab ? 4u : dd == 0 ? 2u : 3u;
-            cls[q] = cl | ((si & 0x7FFu) << 3);
-            const unsigned units = (unsigned)(n + 3) >> 2;
-            aex[q] = At;
-            uex[q] = Ut;
-            At += (cl ? (unsigned)n : 0u) + (cl == 1u ? 0x10000u : 0u);
-            Ut += cl == 2u ? units : cl == 3u ? units << 16 : 0u;
-            Ae += cl ? ((unsigned)n < (1u << 20) ? (unsigned)n : 1u << 20) : 0u;
+            const unsigned cls = voxel_class(np[q], nc[q], nn[q], edge);
+            voxel_sums(cls, nc[q], At, Ut);
+            Ae += (cls & 7u) ? ((unsigned)nc[q] < (1u << 20) ? (unsigned)nc[q] : 1u << 20) : 0u;
         }
     };
     // totals and this wave's exclusive prefix of NW per-wave values written to LDS in front of a barrier
@@ -1985,11 +1985,12 @@ __device__ __forceinline__ void dense_pair_body(const LdatiParams &P) {
     for (int c = 0; c < 9;) {
         STAMP(0);
         const bool hasB = c + 1 < 9;
+        if (c + 3 <= 8) load_plane(c + 3, ya);           // consumed when the window moves on, behind the pass
+        if (c + 4 <= 8) load_plane(c + 4, yb);
         // ---- D1: classes and positions of bins c (A) and c + 1 (B) -------------------------------------------------
-        unsigned clsA[PPT], aexA[PPT], uexA[PPT], clsB[PPT], aexB[PPT], uexB[PPT];
         unsigned AtA, UtA, AeA, AtB, UtB, AeB;
-        classify(nm1, n0, n1, c == 0 || c == 8, clsA, aexA, uexA, AtA, UtA, AeA);
-        classify(n0, n1, n2, c + 1 == 8, clsB, aexB, uexB, AtB, UtB, AeB);
+        classify(nm1, n0, n1, c == 0 || c == 8, AtA, UtA, AeA);
+        classify(n0, n1, n2, c + 1 == 8, AtB, UtB, AeB);
         if (!hasB) { AtB = UtB = AeB = 0; }
         const unsigned iA = wave_incl_scan(AtA, lane), iUA = wave_incl_scan(UtA, lane);
         const unsigned iB = wave_incl_scan(AtB, lane), iUB = wave_incl_scan(UtB, lane);
@@ -2023,7 +2024,7 @@ __device__ __forceinline__ void dense_pair_body(const LdatiParams &P) {
                 if (hasB) vmax_l = n1[q] > vmax_l ? n1[q] : vmax_l;
             }
             if (N32A > (unsigned)P.capA) {               // uniform: a run beyond its slot is only counted
-                advance(c);
+                advance(c + 3, ya);
                 ++c;
                 continue;
             }
@@ -2054,21 +2055,22 @@ __device__ __forceinline__ void dense_pair_body(const LdatiParams &P) {
             // this wave's first entries: the waves in front (both bins), then for B this wave's entries of A
             const unsigned wU = (bsUA & 0xFFFFu) + (doB ? bsUB & 0xFFFFu : 0u), wK = (bsUA >> 16) + (doB ? bsUB >> 16 : 0u);
             const unsigned wS = (bsA >> 16) + (doB ? bsB >> 16 : 0u);
-            auto lists = [&](unsigned bsel, const unsigned (&cls)[PPT], const unsigned (&aex)[PPT], const unsigned (&uex)[PPT],
-                             const int (&np)[PPT], const int (&nc)[PPT], const int (&nn)[PPT], const float (&dc)[PPT],
+            auto lists = [&](unsigned bsel, const int (&np)[PPT], const int (&nc)[PPT], const int (&nn)[PPT], const float (&dc)[PPT], bool edge,
                              unsigned lanA, unsigned lanU, unsigned pos0, unsigned u0at, unsigned u1at, unsigned sat, int cb) {
 #pragma unroll
                 for (int q = 0; q < PPT; ++q) {
-                    const unsigned local = (unsigned)(lpx0 + q), pos = pos0 + ((lanA + aex[q]) & 0xFFFFu);
-                    const int n = nc[q];
-                    const unsigned cl = cls[q] & 7u;
+                    int n = nc[q];
+                    asm volatile("" : "+v"(n));           // (opaque: the class is recomputed here, not carried across the barrier)
+                    const unsigned cls = voxel_class(np[q], n, nn[q], edge);
+                    const unsigned local = (unsigned)(lpx0 + q), pos = pos0 + (lanA & 0xFFFFu);
+                    const unsigned cl = cls & 7u;
                     if (cl == 1u) {
-                        SLs[sat + ((lanA + aex[q]) >> 16)] = pos | (local << 14) | (bsel << 25);
+                        SLs[sat + (lanA >> 16)] = pos | (local << 14) | (bsel << 25);
                         S[pos] = __float_as_uint(dc[q]);                 // the single's tendency waits in its record slot
                     } else if (cl == 2u || cl == 3u) {
-                        const unsigned ue = lanU + uex[q];
+                        const unsigned ue = lanU;
                         uint2 *dstu = cl == 2u ? UL0 + u0at + (ue & 0xFFFFu) : UL1 + u1at + (ue >> 16);
-                        const unsigned units = (unsigned)(n + 3) >> 2, hi = (cls[q] >> 3) << 14, lb = local | (bsel << 28);
+                        const unsigned units = (unsigned)(n + 3) >> 2, hi = (cls >> 3) << 14, lb = local | (bsel << 28);
                         dstu[0] = make_uint2(lb | (((unsigned)n < 4u ? (unsigned)n : 4u) << 29), pos | hi);
                         for (unsigned jb = 1; jb < units; ++jb) {
                             const unsigned left = (unsigned)n - 4u * jb;
@@ -2084,11 +2086,12 @@ __device__ __forceinline__ void dense_pair_body(const LdatiParams &P) {
                             put(pos + (unsigned)j, (bsel << 24) | (key << 12) | (1u << kLocalBits) | local, (bsel << hsl) | (key >> P.shift));
                         }
                     }
+                    voxel_sums(cls, n, lanA, lanU);      // the lane's running sums: the next pixel's positions
                 }
             };
-            lists(0u, clsA, aexA, uexA, nm1, n0, n1, d0, iA - AtA, iUA - UtA, bsA & 0xFFFFu, wU, wK, wS, c);
+            lists(0u, nm1, n0, n1, d0, c == 0 || c == 8, iA - AtA, iUA - UtA, bsA & 0xFFFFu, wU, wK, wS, c);
             if (doB)
-                lists(1u, clsB, aexB, uexB, n0, n1, n2, d1, iB - AtB, iUB - UtB, NA + (bsB & 0xFFFFu), wU + (rUA & 0xFFFFu), wK + (rUA >> 16),
+                lists(1u, n0, n1, n2, d1, c + 1 == 8, iB - AtB, iUB - UtB, NA + (bsB & 0xFFFFu), wU + (rUA & 0xFFFFu), wK + (rUA >> 16),
                       wS + (rA >> 16), c + 1);
         }
         __syncthreads();                                 // A2: the work lists are complete
@@ -2244,12 +2247,9 @@ __device__ __forceinline__ void dense_pair_body(const LdatiParams &P) {
             if (doB) copy_run(c + 1, obB, dshB, NB_);
         }
         STAMP(9);
-        advance(c);
-        ++c;
-        if (doB) {
-            advance(c);
-            ++c;
-        }
+        advance(c + 3, ya);
+        if (doB) advance(c + 4, yb);
+        c += doB ? 2 : 1;
     }
     if (P.slot_cap) {
 #pragma unroll
@@ -3707,7 +3707,7 @@ bool dense_kernel_serves_pair(const LdatiParams &P) {
 }
 // dynamic LDS of ldati_tile_pair_kernel<NW>'s pair body: S [capP] | O [capP + 16] | hist [NW][2^(12 - shift)] | wave totals, partials, ...
 size_t dense_pair_lds(int capP, int shift, int NW) {
-    return ((size_t)2 * capP + 16 + ((size_t)NW << (12 - shift)) + 6 * NW + NW + 1 + 2 + 18 + 10 + 3) * 4;
+    return ((size_t)2 * capP + 16 + ((size_t)NW << (12 - shift)) + 6 * NW + NW + 1 + 2 + 18 + 10 + kTilePix + 3) * 4;
 }
 // records of one pass the pair body can hold in `budget` bytes of LDS (a multiple of 256), 0 when the call has no pair form:
 // 12-bit keys (the bin of a record rides above them), one histogram word per thread in the scan, 14-bit positions

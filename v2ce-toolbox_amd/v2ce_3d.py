@@ -432,8 +432,12 @@ class V2ce3d(nn.Module):
         return (w + 31) // 32 * 32
 
     def _conv(self, x0, x1, w_packed, scale, shift, cout, ksize, stride, act, residual=None,
-              up_to=None, split=False, track=False, pred=None, sc=None, dense_out=False, tail=None, residual_up=False):
-        """x0 [B,T,C0,H0,W0] (optionally nearest-upsampled to ``up_to``), x1 [B,T,C1,Hin,Win]."""
+              up_to=None, split=False, track=False, pred=None, sc=None, dense_out=False, tail=None, residual_up=False,
+              algo_hw=None):
+        """x0 [B,T,C0,H0,W0] (optionally nearest-upsampled to ``up_to``), x1 [B,T,C1,Hin,Win].
+        ``algo_hw``: the output resolution at which the REFERENCE computes this launch's operator when the launch itself runs at the
+        source's (the upsampled channels' share of a decoder shortcut, submodules.py:262 on unet_2layer.py:360's upsampled tensor):
+        only the profile's algorithmic flop column uses it."""
         # activations between the layers are [B,T,C,H,pitch] (planar) or [B,T,C/16,H,pitch,16] (`.c16`: what the
         # split-half kernels take and produce, include/v2ce_hip.h V2CE_LAYOUT_C16), logical width in `.lw` (see _pitch)
         head_bridge = (not split and self.precision == "f16x2" and ksize == 3 and stride == 1 and x1 is None
@@ -572,6 +576,9 @@ class V2ce3d(nn.Module):
         if prof is not None:
             e1.record()
             flops = 2.0 * B * T * Hout * Wout * cout * (C0 + C1) * ksize ** 3
+            launch_flops = flops
+            if algo_hw is not None:        # a 1x1x1 launch at the source's resolution standing for the reference's at the upsampled one
+                flops = 2.0 * B * T * algo_hw[0] * algo_hw[1] * cout * (C0 + C1) * ksize ** 3
             if pred is not None:
                 flops += 2.0 * B * T * Hout * Wout * pred[2] * cout
             if sc is not None:
@@ -583,6 +590,8 @@ class V2ce3d(nn.Module):
                                  (4 if residual is not None else 0))
             # (flops = the ALGORITHMIC count of the reference's convolution; a phase-folded launch executes fewer: `executed`)
             executed = flops - (2.0 * B * T * Hout * Wout * cout * C0 * 15 if up2 else 0.0)
+            if algo_hw is not None:
+                executed = launch_flops
             if wt:          # four transformed 3x3 convolutions per pair of time steps instead of six tap rows
                 executed = 2.0 * B * ((T + 1) // 2) * Hout * Wout * cout * C0 * 36
             prof.append((name, flops, e0, e1, executed))
@@ -710,7 +719,7 @@ class V2ce3d(nn.Module):
                 t = self._conv(x0, x1, w1, *d["bn1"], blk.cout, 3, s, hip.ACT_RELU, up_to=up_to, split=True)
             fw, fscale, fshift = d["fold"]
             if d.get("fold_lo") is not None and x1 is not None and up_to is not None and self._half_up(x0, up_to):
-                r0 = self._conv(x0, None, d["fold_lo"], fscale, d["zero_shift"], blk.cout, 1, 1, hip.ACT_NONE, split=True)
+                r0 = self._conv(x0, None, d["fold_lo"], fscale, d["zero_shift"], blk.cout, 1, 1, hip.ACT_NONE, split=True, algo_hw=up_to)
                 return self._conv(t, None, d["conv2_w"], fscale, fshift, blk.cout, 3, 1, hip.ACT_RELU, split=True, track=track,
                                   tail=(x1, None, None, 1, d["fold_skip"]), residual=r0, residual_up=True)
             return self._conv(t, None, d["conv2_w"], fscale, fshift, blk.cout, 3, 1, hip.ACT_RELU, split=True, track=track,
