@@ -307,7 +307,7 @@ def main():
     # rank 0 receives every rank's records of a step over RCCL on a communication stream (dist.StreamedGather, the
     # product driver's: pipeline.run_clip); the byte counts are read one step later, so no rank waits on its compute stream
     comm = vdist.default_comm(force=dist_on)
-    gather_mode = vdist.default_gather_mode(world)        # the product's default: 'device' below eight ranks, 'host' from eight on
+    gather_mode = vdist.default_gather_mode(world)        # the product's default: 'device' (V2CE_GATHER=host opts in)
     d2h = {"bytes": 0, "s": 0.0}
 
     def new_exchange():
@@ -441,6 +441,34 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # First-hardware-curve readiness: from eight ranks on the same steps are timed once more with the OTHER exchange,
+    # so that the first run on an 8-GPU node shows north_star's RCCL gather ('device', the default and `value`) and the per-rank
+    # PCIe download ('host') side by side.  V2CE_BENCH_BOTH_GATHERS=1 forces it at any world > 1, =0 switches it off.
+    main_gather, main_mode, other_gather, main_events = gather, gather_mode, None, n_events[0]
+    both = os.environ.get("V2CE_BENCH_BOTH_GATHERS")
+    if dist_on and args.workload == "e2e" and both != "0" and (world >= 8 or both == "1"):
+        gather_mode = "host" if main_mode == "device" else "device"
+        try:
+            model.profile_filter = set()                      # no per-launch events in this run
+            run_steps(1, False)
+            torch.cuda.synchronize()
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run_steps(args.steps, False)
+            torch.cuda.synchronize()
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+            tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            other_gather = {"mode": gather_mode, "ms_per_step": 1e3 * float(tt[0]) / args.steps,
+                            "value": world * pairs_per_rank * args.steps / float(tt[0]), "unit": "frame-pairs/s",
+                            "gathered_bytes_per_step": gather.bytes_last}
+            if gather_mode == "host":
+                other_gather["registered_segment"] = bool(host_segments and host_segments[0][1] is not None)
+        except Exception as e:                                # noqa: BLE001 -- the main line must still be printed
+            other_gather = {"mode": gather_mode, "error": f"{type(e).__name__}: {e}"}
+        gather, gather_mode, n_events[0] = main_gather, main_mode, main_events
     for _, rseg in host_segments:
         if rseg is not None:
             rseg.close()
@@ -644,6 +672,8 @@ def main():
             if gather_mode == "host":
                 line["gather"]["registered_segment"] = bool(host_segments and host_segments[0][1] is not None)
                 line["gather"]["dma_bytes_last_run"] = int(getattr(gather, "dma_bytes", 0))
+            if other_gather is not None:
+                line["gather"]["other_mode"] = other_gather       # the same steps timed with the other exchange (not `value`)
         if world == 1 and args.workload == "e2e":
             if not args.no_host_to_host:
                 line["host_to_host"] = host_to_host(args, device, max(args.steps, 16))   # >= 16 batches (1025 frames): the drain of the last batch (0.5 ms LDATI + 152 MB D2H) is a fixed ~7 ms

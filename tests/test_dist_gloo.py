@@ -302,6 +302,57 @@ def test_gather_modes_equal_single_process(mode, tmp_path):
     assert z.tobytes() == single.tobytes() and not os.path.exists(tmp_path / f"{mode}.npz.part")
 
 
+def _window_worker(rank, world, port, q, window):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), V2CE_GATHER="host")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from test_product_glue import FakeModel
+        from v2ce_toolbox_amd import pipeline, synth
+        from v2ce_toolbox_amd import v2ce as cli
+        seen = []
+        orig = pipeline.vdist.HostDirectGather
+
+        class Spy(orig):                                         # (how many bytes went through the window on this rank)
+            def finalize(self):
+                seen.append((self.reg_bytes, self.dma_bytes))
+                return super().finalize()
+        pipeline.vdist.HostDirectGather = Spy
+        pipeline._registered_window_bytes = lambda n_pairs, device: window
+        frames = synth.synthetic_frames(85, 8, 20, seed=3)
+        out = cli.run(frames, FakeModel(), infer_type="center", width=12, height=8, batch_size=2, device="cpu", stage2=fake_stage2(30))
+        q.put((rank, None if out is None else bytes(out.tobytes()), seen[0]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("window", ["none", "part", "straddle", "all"])
+def test_host_gather_window_covers_part_of_the_clip(window):
+    """gather='host' with the shared window (the mapping every rank fills directly: page-locked and written by DMA on GPU ranks,
+    a plain mapping here) covering nothing, the first part, a size that cuts a rank's piece, or all of the clip: the pieces that
+    end inside the window go there, the rest takes the pwrite path behind it, and rank 0's array is the single-process bytes in
+    every case (VERDICT r5 #7: the three window cases had run on one GPU only)."""
+    from v2ce_toolbox_amd import synth
+    from v2ce_toolbox_amd import v2ce as cli
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_product_glue import FakeModel
+    frames = synth.synthetic_frames(85, 8, 20, seed=3)
+    single = cli.run(frames, FakeModel(), infer_type="center", width=12, height=8, batch_size=2, device="cpu", stage2=fake_stage2(30))
+    total = len(single.tobytes())
+    size = {"none": 0, "part": (total // 3) & ~63, "straddle": total // 2 + 7, "all": total + 4096}[window]
+    got = _spawn(_window_worker, 2, (size,))
+    assert got[0][1] == single.tobytes() and got[1][1] is None
+    through = sum(g[2][1] for g in got)
+    assert all(g[2][0] == size for g in got)
+    if window == "none":
+        assert through == 0
+    elif window == "all":
+        assert through == total
+    else:
+        assert 0 < through < total and through <= size
+
+
 def failing_stage2(fps, bad_rank, bad_pair):
     begin, finish = fake_stage2(fps)
 

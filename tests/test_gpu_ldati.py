@@ -436,8 +436,8 @@ def test_dense_tile_kernel_equals_per_bin_kernel(gold_dir, monkeypatch):
 
 
 def test_pair_pass_kernel_equals_per_bin_kernel(monkeypatch):
-    """ldati_tile_pair_kernel (round 6: two bins of a dense tile per pass where their records share the LDS) against the
-    per-bin dense kernel (V2CE_LDATI_NO_PAIR=1): same bytes and the oracle's events -- on Philox stress frames (pairs 0-1 .. 6-7
+    """ldati_tile_pair_kernel (round 6: two bins of a dense tile per pass where their records share the LDS; V2CE_LDATI_PAIR=1)
+    against the per-bin dense kernel (the default): same bytes and the oracle's events -- on Philox stress frames (pairs 0-1 .. 6-7
     and bin 8 alone in the 16-wave form), at half and quarter that density (the 8-wave form, two workgroups per CU; at the
     lower density every pass is a pair), on a tile mix where pairs and single-bin passes alternate (a bin that fits with
     neither neighbour), with a voxel outside the slope table in either bin of a pair, at 60 fps with a start time, through the
@@ -445,11 +445,10 @@ def test_pair_pass_kernel_equals_per_bin_kernel(monkeypatch):
     from v2ce_toolbox_amd import LDATI
 
     def both(run):
-        monkeypatch.delenv("V2CE_LDATI_NO_PAIR", raising=False)
+        monkeypatch.setenv("V2CE_LDATI_PAIR", "1")             # (opt-in: measured slower on the stress chunk)
         a = run()
-        monkeypatch.setenv("V2CE_LDATI_NO_PAIR", "1")
+        monkeypatch.delenv("V2CE_LDATI_PAIR")
         b = run()
-        monkeypatch.delenv("V2CE_LDATI_NO_PAIR")
         assert np.array_equal(a.seg_counts, b.seg_counts)
         assert a.packed().cpu().numpy().tobytes() == b.packed().cpu().numpy().tobytes()
         return a

@@ -7,7 +7,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_gpu_ldati.py -x -q -k "pair_pass or dense_tile_kernel_equals or fused_dense or c5_stress or dense_slot" 2>&1 | tail -5
 for mode in pair nopair; do
-  if [ $mode = nopair ]; then export V2CE_LDATI_NO_PAIR=1; else unset V2CE_LDATI_NO_PAIR; fi
+  if [ $mode = nopair ]; then unset V2CE_LDATI_PAIR; else export V2CE_LDATI_PAIR=1; fi
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/dens_$mode -- python3 tools/ldati_density_probe.py > $OUT/dens_$mode.log 2>&1
   grep "^scale" $OUT/dens_$mode.log
   python3 - $OUT/dens_$mode <<'PY'
@@ -38,7 +38,7 @@ PY
 done
 # phase stamps of the tile pass, both kernels (diagnostic library)
 for mode in pair nopair; do
-  if [ $mode = nopair ]; then export V2CE_LDATI_NO_PAIR=1; else unset V2CE_LDATI_NO_PAIR; fi
+  if [ $mode = nopair ]; then unset V2CE_LDATI_PAIR; else export V2CE_LDATI_PAIR=1; fi
   echo "stamps $mode"
   V2CE_HIP_LIB=v2ce-toolbox_amd/csrc/libv2ce_hip_stamp.so timeout 300 python3 tools/ldati_stamps.py stress 2>&1 | head -12
 done

@@ -3712,7 +3712,15 @@ size_t dense_pair_lds(int capP, int shift, int NW) {
 // records of one pass the pair body can hold in `budget` bytes of LDS (a multiple of 256), 0 when the call has no pair form:
 // 12-bit keys (the bin of a record rides above them), one histogram word per thread in the scan, 14-bit positions
 int pair_capacity(const LdatiParams &P, const Plan &pl, int NW, size_t budget) {
-    if (P.NK > 4096 || pl.shift > 8 || (1 << (12 - pl.shift)) > 64 * NW || getenv("V2CE_LDATI_NO_PAIR")) return 0;
+    // Opt-in (V2CE_LDATI_PAIR=1; V2CE_LDATI_NO_PAIR=1 wins): measured in round 6 (profiles/r06_a_ldati_pair_*), the pair passes
+    // save what they were built to save -- the scan of the histogram, the barriers, the copy-out prologue: 49 -> 30, 36 -> 49 (!),
+    // 26 -> 19 Mcycles per stress call -- and lose more than that in the two phases that turned out NOT to be latency: the
+    // classification and the work lists are bound by VALU issue (all sixteen waves run the same ~100 + ~100 instructions at
+    // once, four per SIMD), their work doubles with the second bin and what is shared -- one barrier -- is small against it
+    // (D1 45 -> 90, D2 58 -> 126 Mcycles).  Stress chunk 691 -> 731 us; half density 481 -> 480; quarter density 402 -> 374.
+    const char *on = getenv("V2CE_LDATI_PAIR");
+    if (!(on && on[0] == '1') || getenv("V2CE_LDATI_NO_PAIR")) return 0;
+    if (P.NK > 4096 || pl.shift > 8 || (1 << (12 - pl.shift)) > 64 * NW) return 0;
     const size_t fixed = dense_pair_lds(0, pl.shift, NW);
     if (fixed + 2048 > budget) return 0;
     long long cap = (long long)((budget - fixed) / 8) & ~255ll;

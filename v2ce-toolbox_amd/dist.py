@@ -275,14 +275,17 @@ _SLOT_CACHE, _SLOT_LOCK = [], threading.Lock()
 
 
 def default_gather_mode(world: int) -> str:
-    """How the ranks' records reach host memory unless the caller says otherwise (V2CE_GATHER overrides): 'device' -- RCCL
-    gather to rank 0's HBM, rank 0 downloads everything over its one PCIe link (~57 GB/s measured) -- up to seven ranks;
-    'host' -- every rank writes its own records into the registered shared segment over its own link -- from eight ranks on,
-    where the e2e regime's 8 x 7.3 GB/s of records no longer fit rank 0's link."""
+    """How the ranks' records reach host memory unless the caller says otherwise: 'device' -- RCCL gather of the final event
+    list to rank 0's HBM (north_star's exchange), rank 0 downloads everything over its one PCIe link (~57 GB/s measured) -- at
+    every world size.  'host' (V2CE_GATHER=host, or gather='host') -- every rank writes its own records into the registered
+    shared segment over its own link -- is the remedy reasoned for eight ranks, where the e2e regime's 8 x 7.3 GB/s of records
+    no longer fit rank 0's link; it has run at world 1 (RCCL) and on gloo only, never with eight processes
+    page-locking one tmpfs segment, so it stays opt-in until a run on an 8-GPU node has shown both modes (ADVICE r5;
+    bench.py --gpus 8 prints both)."""
     env = os.environ.get("V2CE_GATHER")
     if env:
         return env
-    return "host" if world >= 8 else "device"
+    return "device"
 
 
 class RegisteredSegment:
@@ -290,27 +293,31 @@ class RegisteredSegment:
     a copy-out stream can write with ``copy_(..., non_blocking=True)``.  Page-locking costs ~70 us per MB: a process that runs
     several clips into one segment (bench.py) keeps the object and hands it to every HostDirectGather."""
 
-    def __init__(self, path: str, nbytes: int):
+    def __init__(self, path: str, nbytes: int, page_lock: bool = True):
+        """page_lock=False (CPU ranks): the plain shared mapping -- the same window arithmetic, a memcpy instead of a DMA."""
         import mmap
-        self.path, self.nbytes = path, int(nbytes)
+        self.path, self.nbytes, self.locked = path, int(nbytes), False
         fd = os.open(path, os.O_RDWR)
         try:
             self.map = mmap.mmap(fd, self.nbytes)
         finally:
             os.close(fd)
         self.tensor = torch.frombuffer(self.map, dtype=torch.uint8)
-        rc = torch.cuda.cudart().cudaHostRegister(self.tensor.data_ptr(), self.nbytes, 0)
-        if int(rc) != 0:
-            self.tensor = None
-            self.map.close()
-            raise RuntimeError(f"hipHostRegister failed with code {int(rc)}")
+        if page_lock:
+            rc = torch.cuda.cudart().cudaHostRegister(self.tensor.data_ptr(), self.nbytes, 0)
+            if int(rc) != 0:
+                self.tensor = None
+                self.map.close()
+                raise RuntimeError(f"hipHostRegister failed with code {int(rc)}")
+            self.locked = True
 
     def close(self) -> None:
         if self.tensor is not None:
-            try:
-                torch.cuda.cudart().cudaHostUnregister(self.tensor.data_ptr())
-            except Exception:                                   # noqa: BLE001
-                pass
+            if self.locked:
+                try:
+                    torch.cuda.cudart().cudaHostUnregister(self.tensor.data_ptr())
+                except Exception:                               # noqa: BLE001
+                    pass
             self.tensor = None
             try:
                 self.map.close()
@@ -362,9 +369,9 @@ class HostDirectGather:
         self.reg_bytes, self.reg_seg, self.reg_own, self.reg_tensor = 0, None, False, None
         if segment is not None and self.cuda and not need_crc and data_start == 0:
             self.reg_seg, self.reg_tensor, self.reg_bytes = segment, segment.tensor, segment.nbytes
-        elif registered_bytes > 0 and self.cuda and not need_crc and data_start == 0:
-            try:
-                self.reg_seg = RegisteredSegment(path, int(registered_bytes))
+        elif registered_bytes > 0 and not need_crc and data_start == 0:
+            try:                                               # (CPU ranks: the shared mapping without the page lock)
+                self.reg_seg = RegisteredSegment(path, int(registered_bytes), page_lock=self.cuda)
                 self.reg_own, self.reg_tensor, self.reg_bytes = True, self.reg_seg.tensor, int(registered_bytes)
             except Exception as e:                              # noqa: BLE001 -- the staging path serves everything
                 import logging
@@ -401,7 +408,8 @@ class HostDirectGather:
             slot, n, done, off, _keep, host = item
             try:
                 if self.error is None and n < 0:
-                    done.synchronize()                         # a piece that went by DMA: its bytes are in the segment now
+                    if done is not None:
+                        done.synchronize()                     # a piece that went by DMA: its bytes are in the segment now
                     self.pieces.append((0, -n))
                 elif self.error is None and n:
                     if done is not None:
@@ -424,7 +432,9 @@ class HostDirectGather:
         # stage-2 failure: -1 with the next byte count, every rank stops at that step (raising it here, on this
         # rank alone, left the peers in the next collective until the watchdog fired)
         n = int(packed.numel())
-        ex = self.comm.all_gather_int(-1 if (failed or self.error is not None) else n, packed.device)
+        # (wait=False: the count is host-known and the copies are ordered by their own `done` / `ready` events, so a failure flag
+        # still travels when the compute stream is stuck -- like StreamedGather and EventGather)
+        ex = self.comm.all_gather_int(-1 if (failed or self.error is not None) else n, packed.device, wait=False)
         slot, done, host = None, None, None
         if n and packed.is_cuda and self.reg_bytes:
             # registered window: the copy itself waits for the byte counts (the piece's offset) in _finish_one; only the event
@@ -443,6 +453,8 @@ class HostDirectGather:
                 slot[0][:n].copy_(packed, non_blocking=True)
                 done = torch.cuda.Event()
                 done.record(self.copy_stream)
+        elif n and self.reg_bytes:
+            host = "dma"                                       # CPU rank with a window: placed (or written) once the offset is known
         elif n:
             host = packed.numpy()
         self.inflight.append((ex, slot, n, done, (packed, keep), host))
@@ -466,6 +478,15 @@ class HostDirectGather:
         off = off % self.ring_bytes if self.ring_bytes else off
         if isinstance(host, str):                              # "dma": straight into the registered window, or staged after all
             packed = keep[0]
+            if not packed.is_cuda:                             # CPU rank: a copy into the shared mapping, or the pwrite path beyond it
+                if off + n <= self.reg_bytes:
+                    a = self.data_start + off
+                    self.reg_tensor[a:a + n].copy_(packed)
+                    self.dma_bytes += n
+                    self.work.put((None, -n, None, off, keep, None))
+                else:
+                    self.work.put((None, n, None, off, keep, packed.numpy()))
+                return
             if off + n <= self.reg_bytes:
                 with torch.cuda.stream(self.copy_stream):
                     self.copy_stream.wait_event(done)
@@ -635,8 +656,8 @@ class TorchComm:
     def streamed_gather(self, on_pieces, dst: int = 0) -> StreamedGather:
         return StreamedGather(dst, self.group, on_pieces)
 
-    def all_gather_int(self, value: int, device) -> SizeExchange:
-        return SizeExchange(value, device, self.group)
+    def all_gather_int(self, value: int, device, wait: bool = True) -> SizeExchange:
+        return SizeExchange(value, device, self.group, wait=wait)
 
     def all_gather_object(self, obj) -> list:
         out = [None] * self.world
@@ -781,7 +802,7 @@ class ThreadComm:
                 return None
         return _G()
 
-    def all_gather_int(self, value: int, device):
+    def all_gather_int(self, value: int, device, wait: bool = True):
         got = self._exchange(int(value), range(self.world))
 
         class _R:

@@ -372,12 +372,13 @@ def _shared_segment_path() -> str:
 def _registered_window_bytes(n_pairs: int, device) -> int:
     """Bytes of the shared host segment that every rank page-locks and fills by DMA (dist.HostDirectGather): V2CE_HOST_SEGMENT_MB,
     default min(2 MiB per frame-pair -- 4.7 Mevents: twice what UNet output at 346x260 yields --, half of what /dev/shm has free);
-    0 on CPU runs.  A clip that outgrows the window keeps working: the rest takes the staging + pwrite path."""
-    if torch.device(device).type != "cuda":
-        return 0
+    0 on CPU runs unless the variable asks for one (the same window as a plain shared mapping).  A clip that outgrows the window keeps
+    working: the rest takes the staging + pwrite path."""
     env = os.environ.get("V2CE_HOST_SEGMENT_MB")
     if env is not None:
         return max(0, int(env)) << 20
+    if torch.device(device).type != "cuda":
+        return 0
     want = int(n_pairs) * (2 << 20)
     try:
         st = os.statvfs("/dev/shm" if os.path.isdir("/dev/shm") else (os.environ.get("TMPDIR") or "/tmp"))
@@ -409,8 +410,8 @@ def run_clip(frames: np.ndarray, model, *, infer_type="center", seq_len=16, widt
     host array (``StreamingEventSink``); the function then returns None on every rank and closes the writer.
 
     comm: ``dist.TorchComm`` / ``dist.ThreadComm`` / ``dist.LocalComm`` (default: from torch.distributed).
-    gather (more than one rank; V2CE_GATHER overrides; default ``dist.default_gather_mode``: 'device' below eight ranks, 'host'
-    from eight on): 'device' -- the records are gathered on rank 0's GPU over RCCL / xGMI (``dist.StreamedGather``) and rank 0
+    gather (more than one rank; V2CE_GATHER overrides; default ``dist.default_gather_mode``: 'device' at every world size -- 'host'
+    is opt-in until a run on an 8-GPU node has shown both): 'device' -- the records are gathered on rank 0's GPU over RCCL / xGMI (``dist.StreamedGather``) and rank 0
     downloads them into its pinned sink (one PCIe link: ~57 GB/s measured, against 8 x 7.3 GB/s of records at N = 8 in the e2e
     regime: the link is the budget there); 'host' -- every rank brings its own records to host memory over its own
     PCIe link, into its slice of the output (``dist.HostDirectGather``; only byte counts cross RCCL): a shared tmpfs segment
@@ -481,7 +482,17 @@ def run_clip(frames: np.ndarray, model, *, infer_type="center", seq_len=16, widt
             info = None
         info = comm.broadcast_object(info, src=0)
         path, data_start, need_crc = info[:3]
-        exchange = vdist.HostDirectGather(comm, device, path, data_start, need_crc, registered_bytes=info[3] if len(info) > 3 else 0)
+        try:
+            exchange = vdist.HostDirectGather(comm, device, path, data_start, need_crc, registered_bytes=info[3] if len(info) > 3 else 0)
+        except BaseException:
+            # the constructor is collective and raises on every rank when one of them cannot open or page-lock the file: rank 0
+            # takes the segment (and a half-written .npz) with it
+            if rank == 0:
+                if seg_path is not None and os.path.exists(seg_path):
+                    os.unlink(seg_path)
+                if writer is not None:
+                    writer.abort()
+            raise
     elif multi:
         step_pairs = collections.deque(bp.n_pairs for bp in plans)
 
@@ -641,6 +652,10 @@ def run_clip(frames: np.ndarray, model, *, infer_type="center", seq_len=16, widt
             if nbytes == 0:
                 os.unlink(seg_path)
                 return np.empty(0, dtype)
+            if os.path.getsize(seg_path) > nbytes:
+                # the registered window was sized ahead of the clip (~2x the real volume): every rank has unregistered and closed it by
+                # now, so the tail goes back to /dev/shm before the array pins the file's pages for its lifetime
+                os.truncate(seg_path, nbytes)
             mm = np.memmap(seg_path, dtype=np.uint8, mode="r+", shape=(nbytes,))
             os.unlink(seg_path)                             # the mapping keeps the pages; the name goes now
             return mm.view(dtype)
