@@ -492,11 +492,26 @@ typedef struct {
                            * up_c0 input channels -- the nearest-upsampled source -- are also packed phase-folded */
     int32_t wt;           /* 1: `packed` is a v2ce_pack_weights_f16x2_wt buffer instead (Winograd-T planes of w_bar / sigma, k3 = 27,
                            * up_c0 = 0); 0: the plain planes */
-    int32_t reserved;     /* 0 */
+    int32_t flags;        /* 0, or a sum of V2CE_SN_NO_PACK / V2CE_SN_NO_ITERATE (round 6, below) */
     void *packed_skip;    /* NULL, or (up_c0 > 0): also write the Winograd-T planes of input channels [up_c0, Cin) of w_bar / sigma --
                            * a v2ce_pack_weights_f16x2_wt_bytes(rows, Cin - up_c0) buffer, as v2ce_pack_weights_f16x2_wt_slice does --
                            * for the split launch of a decoder conv1 (v2ce_conv3d_fwd_up2_part + v2ce_conv3d_fwd_wt) */
+    /* Round 6: the weights w_bar are constant, only the scalar sigma changes from call to call (spectral_norm.py:31 divides every
+     * weight by it).  A caller may pack w_bar ONCE (sigma = 1) and carry 1 / sigma in the convolution's epilogue scale instead:
+     *   V2CE_SN_NO_PACK     iterate only: u, v, sigma are updated, `packed` (may be NULL) is left alone;
+     *                       scale_out [rows] (may be NULL) = bn_scale [rows] / sigma, inv_sigma_out [1] (may be NULL) = 1 / sigma
+     *   V2CE_SN_NO_ITERATE  pack only: u, v (may be NULL) are left alone and `packed` = the plain planes (k3 = 1 or 27, up_c0 = wt = 0)
+     *                       of w_bar / *sigma_src, its {max |w / sigma|, pre-scale} tail from wmax = max |w_bar| -- what a block's
+     *                       folded 1x1x1 shortcut needs once its convolution carries 1 / sigma in the scale: Wd' * sigma, i.e.
+     *                       sigma_src = that layer's inv_sigma_out of a PREVIOUS v2ce_sn_update_batch call on the stream. */
+    const float *bn_scale;
+    float *scale_out, *inv_sigma_out;
+    const float *sigma_src;
+    float wmax;
+    int32_t reserved;     /* 0 */
 } v2ce_sn_layer;
+#define V2CE_SN_NO_PACK 1
+#define V2CE_SN_NO_ITERATE 2
 size_t v2ce_sn_batch_workspace_bytes(const v2ce_sn_layer *layers, int n);
 int v2ce_sn_update_batch(const v2ce_sn_layer *layers, int n, void *workspace, size_t workspace_bytes,
                          v2ce_stream_t stream);

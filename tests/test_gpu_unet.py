@@ -618,6 +618,50 @@ def test_batched_spectral_norm_equals_per_layer_calls():
             assert torch.equal(ms[0]._prep[k][cn], ms[1]._prep[k][cn]), (k, cn)
 
 
+def test_spectral_norm_packed_once_equals_repack(monkeypatch):
+    """Round 6: the planes of W_bar packed once, 1 / sigma in the epilogue scale and the folded shortcuts re-packed as Wd' sigma
+    (the default) against the re-pack of all twelve layers in every forward (V2CE_SN_REPACK=1, rounds 1-5): the same u / v bit
+    for bit, outputs within 2e-6 of each other over three calls (one f32 rounding moves from every weight to every output) and
+    both inside the 1e-5 bar against the oracle at every call; the epilogue scales are bn's over the layer's sigma; a
+    fast-forwarded replica (advance_spectral_norm) lands on the same state."""
+    from v2ce_toolbox_amd.v2ce_3d import V2ce3d
+    xn = OG.preprocess(synth.synthetic_frames(17, 32, 48, seed=6))[None]
+    x = torch.from_numpy(xn).cuda()
+    ms = []
+    for repack in ("0", "1"):
+        monkeypatch.setenv("V2CE_SN_REPACK", repack)
+        m = V2ce3d(precision="f16x2")
+        m.load_state_dict(synth.make_state_dict(0), strict=True)
+        m = m.eval().to("cuda")
+        m._prepare()
+        ms.append(m)
+    monkeypatch.delenv("V2CE_SN_REPACK")
+    assert ms[0]._prep["sn_once"] is not None and ms[1]._prep["sn_once"] is None
+    assert len(ms[0]._prep["sn_once"]["tails"]) >= 5
+    sd = U.clone_state(synth.make_state_dict(0))
+    for call in range(3):
+        ya, yb = ms[0](x).cpu().numpy(), ms[1](x).cpu().numpy()
+        want = U.forward(sd, torch.from_numpy(xn)).numpy()
+        assert np.abs(ya - yb).max() <= 2e-6 * max(1.0, np.abs(yb).max()), (call, np.abs(ya - yb).max())
+        for y in (ya, yb):
+            assert np.all(np.abs(y - want) <= TOL + TOL * np.abs(want)), (call, np.abs(y - want).max())
+    for (n, p), (_, q) in zip(ms[0].named_parameters(), ms[1].named_parameters()):
+        if n.endswith(("weight_u", "weight_v")):
+            assert torch.equal(p, q), n
+    d = ms[0]._prep["dec0"]
+    sig = 1.0 / ms[0]._prep["sn_once"]["inv_sigma"].cpu().numpy()
+    assert np.all(sig > 0) and np.allclose(d["bn2_eff"][0].cpu().numpy() * sig[5], d["bn2"][0].cpu().numpy(), rtol=3e-7)
+    # a replica that skips two calls and catches up
+    monkeypatch.delenv("V2CE_SN_REPACK", raising=False)
+    r = V2ce3d(precision="f16x2")
+    r.load_state_dict(synth.make_state_dict(0), strict=True)
+    r = r.eval().to("cuda")
+    for _ in range(2):
+        r.advance_spectral_norm()
+    y3 = r(x)
+    assert torch.equal(y3, torch.from_numpy(ya).cuda())
+
+
 def _padded(x_ncdhw, pitch):
     """[N,C,D,H,W] CPU tensor -> device [B,T,C,H,pitch] with NaN in the padding columns and .lw = W."""
     x = to_btchw(x_ncdhw)

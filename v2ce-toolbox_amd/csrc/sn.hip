@@ -104,7 +104,7 @@ __global__ __launch_bounds__(1024) void sn_finalize_kernel(const float *__restri
 // summation orders as the kernels above; max |W| rides on the W v pass (max |W / sigma| = max |W| / |sigma|:
 // correctly rounded division is monotone), so the weights are read three times, not four.
 // ---------------------------------------------------------------------------------------------
-constexpr int kMaxBatch = 16;
+constexpr int kMaxBatch = 16;   // (the batch travels to the kernels by value: 16 x 152 bytes + the prefixes stay below the 4 KB of kernel arguments)
 struct SnLayer {
     const float *w;
     float *u, *v;
@@ -115,6 +115,10 @@ struct SnLayer {
     int up_c0;                  // > 0: `packed` is a v2ce_pack_weights_f16x2_up buffer whose first up_c0 input channels are also folded
     int wt;                     // 1: `packed` is a v2ce_pack_weights_f16x2_wt buffer (36 tap slots; written by conv3d_wt.hip's pack passes)
     _Float16 *packed_skip;      // up_c0 > 0 and non-null: ALSO the Winograd-T planes of input channels [up_c0, cin) (v2ce_pack_weights_f16x2_wt_slice)
+    int no_pack, no_iterate;    // v2ce_sn_layer.flags (round 6: w_bar packed once, 1 / sigma carried in the epilogue scale)
+    const float *bn_scale, *sigma_src;
+    float *scale_out, *inv_sigma_out;
+    float wmax;
 };
 struct SnBatch {
     SnLayer L[kMaxBatch];
@@ -123,6 +127,8 @@ struct SnBatch {
     int row_blk[kMaxBatch + 1];   // prefix of rows
     int el_blk[kMaxBatch + 1];    // prefix of (rows / 32) * (Cin / 16): pack workgroups
 };
+
+static_assert(sizeof(SnBatch) <= 3584, "SnBatch travels by value in the kernel arguments");
 
 __device__ __forceinline__ int find_layer(const int *prefix, int n, int b) {
     int l = 0;
@@ -216,6 +222,10 @@ __global__ __launch_bounds__(1024) void sn_batch_finalize_kernel(SnBatch B) {
         d += (double)ui * (double)P.s[i];
     }
     const double dot = block_sum(d, sh);
+    if (P.scale_out) {                                         // the convolution's epilogue scale with 1 / sigma in it (round 6)
+        const float sgf = (float)dot;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) P.scale_out[i] = P.bn_scale[i] / sgf;
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     __syncthreads();
@@ -225,6 +235,8 @@ __global__ __launch_bounds__(1024) void sn_batch_finalize_kernel(SnBatch B) {
         for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = fmaxf(m, mxs[i]);
         const float sg = (float)dot;
         P.sigma[0] = sg;
+        if (P.inv_sigma_out) P.inv_sigma_out[0] = 1.0f / sg;
+        if (P.no_pack) return;                                 // (the packed planes and their tail are the caller's: packed once)
         if (P.wt) {                                            // Winograd-T planes: the bound 1.5 max |w / sigma| of conv3d_wt.hip's pack, pass 0
             float *tail = reinterpret_cast<float *>(P.packed + 2ll * P.rows * P.cin * 36);
             const float bound = 1.5f * fabsf(m / sg);
@@ -261,8 +273,15 @@ __global__ __launch_bounds__(256) void sn_batch_pack_kernel(SnBatch B) {
     const long long n = (long long)P.rows * P.cols;
     float *tail = reinterpret_cast<float *>(P.packed + 2 * n);
     // (tail[0] may have been raised behind the finalize kernel by the folded sums of an up layer: the scale is derived here)
-    const float w_scale = pow2_prescale(tail[0]), sigma = P.sigma[0];
-    if (blk == 0 && threadIdx.x == 0) tail[1] = w_scale;
+    // a pack-only layer (V2CE_SN_NO_ITERATE) brings its sigma and max |w|: max |w / sigma| = max |w| / |sigma| (the correctly
+    // rounded division is monotone), the value weights_absmax_kernel finds
+    const float sigma = P.no_iterate ? P.sigma_src[0] : P.sigma[0];
+    const float amax = P.no_iterate ? fabsf(P.wmax / sigma) : tail[0];
+    const float w_scale = pow2_prescale(amax);
+    if (blk == 0 && threadIdx.x == 0) {
+        tail[1] = w_scale;
+        if (P.no_iterate) tail[0] = amax;
+    }
     // (a tap's 512 halves are padded by one dword: consecutive lanes hold consecutive taps, 1 KiB apart = one LDS bank)
     _Float16 *hi = pk_smem, *lo = pk_smem + k3 * 514;
     constexpr int U = 6;                                 // loads in flight per thread (two workgroups per CU: latency-bound otherwise)
@@ -350,14 +369,23 @@ extern "C" int v2ce_sn_update_batch(const v2ce_sn_layer *layers, int n, void *wo
                  "v2ce_sn_update_batch: workspace %zu < %zu", workspace_bytes, v2ce_sn_batch_workspace_bytes(layers, n));
     SnBatch B{};
     B.n = n;
+    int n_iter = 0;
     unsigned char *ws = static_cast<unsigned char *>(workspace);
     for (int l = 0; l < n; ++l) {
         const v2ce_sn_layer &in = layers[l];
-        V2CE_REQUIRE(in.w_bar && in.u && in.v && in.packed && in.rows > 0 && in.cols > 0 && (in.k3 == 27 || in.k3 == 1) &&
+        const bool no_pack = (in.flags & V2CE_SN_NO_PACK) != 0, no_it = (in.flags & V2CE_SN_NO_ITERATE) != 0;
+        V2CE_REQUIRE((in.flags & ~3) == 0 && !(no_pack && no_it), V2CE_ERR_BAD_ARG, "v2ce_sn_update_batch: layer %d: bad flags %d", l, in.flags);
+        V2CE_REQUIRE(in.w_bar && (no_it || (in.u && in.v)) && (no_pack || in.packed) && in.rows > 0 && in.cols > 0 && (in.k3 == 27 || in.k3 == 1) &&
                      in.cols % in.k3 == 0 && (in.cols / in.k3) % 16 == 0, V2CE_ERR_BAD_ARG,
                      "v2ce_sn_update_batch: layer %d: bad argument", l);
+        V2CE_REQUIRE(!no_it || (in.sigma_src && in.wmax >= 0.0f && in.up_c0 == 0 && in.wt == 0 && !in.packed_skip), V2CE_ERR_BAD_ARG,
+                     "v2ce_sn_update_batch: layer %d: a pack-only layer brings sigma_src and wmax and has plain planes", l);
+        V2CE_REQUIRE(!in.scale_out || (in.bn_scale && !no_it), V2CE_ERR_BAD_ARG, "v2ce_sn_update_batch: layer %d: scale_out needs bn_scale and an iterated layer", l);
+        n_iter += no_it ? 0 : 1;
         SnLayer &o = B.L[l];
         o.w = in.w_bar; o.u = in.u; o.v = in.v; o.packed = static_cast<_Float16 *>(in.packed);
+        o.no_pack = no_pack; o.no_iterate = no_it;
+        o.bn_scale = in.bn_scale; o.scale_out = in.scale_out; o.inv_sigma_out = in.inv_sigma_out; o.sigma_src = in.sigma_src; o.wmax = in.wmax;
         o.rows = in.rows; o.cols = in.cols; o.k3 = in.k3; o.cin = in.cols / in.k3;
         o.up_c0 = in.up_c0;
         o.wt = in.wt;
@@ -378,27 +406,31 @@ extern "C" int v2ce_sn_update_batch(const v2ce_sn_layer *layers, int n, void *wo
         V2CE_REQUIRE(in.rows % 32 == 0 && in.k3 * 2056 <= 64 * 1024, V2CE_ERR_UNSUPPORTED,
                      "v2ce_sn_update_batch: layer %d: rows %% 32 != 0 or k3 too large", l);
         // pack: (32 output channels, 16-channel group); the Winograd-T layers are packed by conv3d_wt.hip
-        B.el_blk[l + 1] = B.el_blk[l] + (in.wt ? 0 : (in.rows / 32) * (in.cols / in.k3 / 16));
+        B.el_blk[l + 1] = B.el_blk[l] + ((in.wt || no_pack) ? 0 : (in.rows / 32) * (in.cols / in.k3 / 16));
     }
+    V2CE_REQUIRE(n_iter == 0 || n_iter == n, V2CE_ERR_UNSUPPORTED,
+                 "v2ce_sn_update_batch: pack-only layers (V2CE_SN_NO_ITERATE) go into a call of their own");
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(sn_batch_wt_u_kernel, dim3(B.col_blk[n], kRowChunks), dim3(256), 0, st, B);
-    hipLaunchKernelGGL(sn_batch_colsum_kernel, dim3(B.col_blk[n]), dim3(256), 0, st, B);
-    hipLaunchKernelGGL(sn_batch_normalize_kernel, dim3(n), dim3(1024), 0, st, B);
-    hipLaunchKernelGGL(sn_batch_w_v_kernel, dim3(B.row_blk[n]), dim3(256), 0, st, B);
-    hipLaunchKernelGGL(sn_batch_finalize_kernel, dim3(n), dim3(1024), 0, st, B);
+    if (n_iter) {
+        hipLaunchKernelGGL(sn_batch_wt_u_kernel, dim3(B.col_blk[n], kRowChunks), dim3(256), 0, st, B);
+        hipLaunchKernelGGL(sn_batch_colsum_kernel, dim3(B.col_blk[n]), dim3(256), 0, st, B);
+        hipLaunchKernelGGL(sn_batch_normalize_kernel, dim3(n), dim3(1024), 0, st, B);
+        hipLaunchKernelGGL(sn_batch_w_v_kernel, dim3(B.row_blk[n]), dim3(256), 0, st, B);
+        hipLaunchKernelGGL(sn_batch_finalize_kernel, dim3(n), dim3(1024), 0, st, B);
+    }
     // decoder conv1 layers (v2ce_conv3d_fwd_up2): the folded sums of W / sigma join the maximum the common pre-scale is derived from
     const float *uf_w[kMaxBatch], *uf_sigma[kMaxBatch];
     void *uf_packed[kMaxBatch];
     int uf_rows[kMaxBatch], uf_cin[kMaxBatch], uf_c0[kMaxBatch], n_uf = 0;
     for (int l = 0; l < n; ++l)
-        if (B.L[l].up_c0 && n_uf < 8) {
+        if (B.L[l].up_c0 && !B.L[l].no_pack && n_uf < 8) {
             uf_w[n_uf] = B.L[l].w; uf_sigma[n_uf] = B.L[l].sigma; uf_packed[n_uf] = B.L[l].packed;
             uf_rows[n_uf] = B.L[l].rows; uf_cin[n_uf] = B.L[l].cin; uf_c0[n_uf] = B.L[l].up_c0;
             ++n_uf;
         }
     {
         int n_up = 0;
-        for (int l = 0; l < n; ++l) n_up += B.L[l].up_c0 ? 1 : 0;
+        for (int l = 0; l < n; ++l) n_up += (B.L[l].up_c0 && !B.L[l].no_pack) ? 1 : 0;
         V2CE_REQUIRE(n_up <= 8, V2CE_ERR_UNSUPPORTED, "v2ce_sn_update_batch: at most eight layers with up_c0");
     }
     if (n_uf) {
@@ -410,6 +442,7 @@ extern "C" int v2ce_sn_update_batch(const v2ce_sn_layer *layers, int n, void *wo
     void *wt_packed[kMaxBatch];
     int wt_rows[kMaxBatch], wt_cin[kMaxBatch], wt_tot[kMaxBatch], wt_ci0[kMaxBatch], n_wt = 0;
     for (int l = 0; l < n; ++l) {
+        if (B.L[l].no_pack) continue;
         if (B.L[l].wt) {
             wt_w[n_wt] = B.L[l].w; wt_sigma[n_wt] = B.L[l].sigma; wt_packed[n_wt] = B.L[l].packed;
             wt_rows[n_wt] = B.L[l].rows; wt_cin[n_wt] = B.L[l].cin; wt_tot[n_wt] = B.L[l].cin; wt_ci0[n_wt] = 0;

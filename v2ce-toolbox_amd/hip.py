@@ -52,7 +52,12 @@ class SnLayer(ctypes.Structure):
     """``v2ce_sn_layer`` (include/v2ce_hip.h): one spectral-norm layer of v2ce_sn_update_batch."""
     _fields_ = [("w_bar", ctypes.c_void_p), ("u", ctypes.c_void_p), ("v", ctypes.c_void_p), ("packed", ctypes.c_void_p),
                 ("rows", ctypes.c_int32), ("cols", ctypes.c_int32), ("k3", ctypes.c_int32), ("up_c0", ctypes.c_int32),
-                ("wt", ctypes.c_int32), ("reserved", ctypes.c_int32), ("packed_skip", ctypes.c_void_p)]
+                ("wt", ctypes.c_int32), ("flags", ctypes.c_int32), ("packed_skip", ctypes.c_void_p),
+                ("bn_scale", ctypes.c_void_p), ("scale_out", ctypes.c_void_p), ("inv_sigma_out", ctypes.c_void_p),
+                ("sigma_src", ctypes.c_void_p), ("wmax", ctypes.c_float), ("reserved", ctypes.c_int32)]
+
+
+SN_NO_PACK, SN_NO_ITERATE = 1, 2
 
 
 class LdatiOptions(ctypes.Structure):

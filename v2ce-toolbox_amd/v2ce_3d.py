@@ -282,6 +282,7 @@ class V2ce3d(nn.Module):
                     if not unfold and float(s2.abs().min()) > 1e-20 and bool(torch.isfinite(sd / s2).all()):
                         wf = (blk.downsample[0].weight * (sd / s2).view(-1, 1, 1, 1, 1)).contiguous()
                         d["fold"] = (self._pack(wf, split=True), s2, (sh2 + shd).contiguous())
+                        d["fold_w32"] = wf
                 # Winograd F(2,3) along T (v2ce_conv3d_fwd_wt) where a conv is a plain one-source stride-1 3x3x3 launch with
                 # >= 64 output channels: conv2 of a block whose shortcut does not ride in its K loop, conv1 of the middle blocks
                 wt = {"conv1": self._winograd() and splits["conv1"] and name == "res" and blk.stride_hw == 1 and blk.cout % 64 == 0
@@ -298,7 +299,8 @@ class V2ce3d(nn.Module):
                     c0 = blk.cin * 2 // 3
                     wf = (blk.downsample[0].weight * (d["down_bn"][0] / d["bn2"][0]).view(-1, 1, 1, 1, 1))
                     d["fold_lo"] = self._pack(wf[:, :c0].contiguous(), split=True)
-                    d["fold_skip"] = self._pack(wf[:, c0:].contiguous(), split=True)
+                    d["fold_skip_w32"] = wf[:, c0:].contiguous()
+                    d["fold_skip"] = self._pack(d["fold_skip_w32"], split=True)
                 d["zero_shift"] = torch.zeros(blk.cout, dtype=torch.float32, device=dev)
                 if blk.sn:
                     for cn in ("conv1", "conv2"):
@@ -339,6 +341,47 @@ class V2ce3d(nn.Module):
             nb = hip.lib().v2ce_sn_batch_workspace_bytes(arr, len(inners))
             if nb:
                 P["sn_batch"] = (arr, len(inners), torch.empty(nb, dtype=torch.uint8, device=dev))
+            P["sn_once"] = None
+            if nb and os.environ.get("V2CE_SN_REPACK", "0") != "1":
+                # Round 6: W_bar is constant, only the scalar sigma changes from call to call (spectral_norm.py:31: w = W_bar / sigma).
+                # The planes of W_bar -- plain, phase-folded, Winograd-T: all linear in W_bar -- are packed ONCE, here, and 1 / sigma
+                # rides in the launch's epilogue scale (bn scale / sigma, written by the batched power iteration); a block's folded
+                # shortcut Wd' sits in the same accumulators and is therefore re-packed as Wd' sigma (five 1x1x1 tensors, 0.8 M
+                # weights instead of 38 M).  One f32 rounding moves from every weight to every output: ~1e-7 relative.
+                # V2CE_SN_REPACK=1: the re-pack of every forward (rounds 1-5).
+                one = torch.ones(1, dtype=torch.float32, device=dev)
+                inv_sigma = torch.ones(len(inners), dtype=torch.float32, device=dev)
+                keep, tails, k = [one, inv_sigma], [], 0
+                for name, blocks in (("res", self.UNet.resblocks), ("dec", self.UNet.decoders)):
+                    for i, blk in enumerate(blocks):
+                        if not blk.sn:
+                            continue
+                        d = P[f"{name}{i}"]
+                        for cn, bn in (("conv1", "bn1"), ("conv2", "bn2")):
+                            m, out, skip = inners[k]
+                            self._pack(m.weight_bar, one, out, split=True)
+                            if skip is not None:
+                                self._pack(m.weight_bar, one, skip, split=True)
+                            eff = torch.empty_like(d[bn][0])
+                            d[bn + "_eff"] = (eff, d[bn][1])
+                            e = arr[k]
+                            e.flags = hip.SN_NO_PACK
+                            e.bn_scale, e.scale_out = d[bn][0].data_ptr(), eff.data_ptr()
+                            e.inv_sigma_out = inv_sigma[k:].data_ptr()
+                            if cn == "conv2" and d.get("fold") is not None:
+                                for w32, buf in ((d["fold_w32"], d["fold"][0]), (d.get("fold_skip_w32"), d.get("fold_skip"))):
+                                    if w32 is not None:
+                                        tails.append((w32, buf, k, float(w32.abs().max())))
+                            k += 1
+                tarr = (hip.SnLayer * max(len(tails), 1))()
+                for e, (w32, buf, kk, wmax) in zip(tarr, tails):
+                    e.w_bar, e.packed = w32.data_ptr(), buf.data_ptr()
+                    e.rows, e.cols, e.k3 = w32.shape[0], w32.shape[1], 1
+                    e.flags, e.sigma_src, e.wmax = hip.SN_NO_ITERATE, inv_sigma[kk:].data_ptr(), wmax
+                tws = None
+                if tails:
+                    tws = torch.empty(max(hip.lib().v2ce_sn_batch_workspace_bytes(tarr, len(tails)), 16), dtype=torch.uint8, device=dev)
+                P["sn_once"] = {"one": one, "inv_sigma": inv_sigma, "tails": tails, "tail_batch": (tarr, len(tails), tws), "keep": keep}
         # one max-|y| slot per conv launch of a forward pass (split-half path: the consumer derives its
         # power-of-two activation pre-scale from the producer's slot, all on the device)
         # (+ the launch's range-guard value in the second float, include/v2ce_hip.h)
@@ -706,31 +749,36 @@ class V2ce3d(nn.Module):
             self._await_sn()
         w1 = d["conv1_w"]
         track = self.precision == "f16x2"      # the block output may feed a split-half conv
+        # (a spectral-norm layer whose planes were packed once carries 1 / sigma in its epilogue scale: _prepare, "sn_once")
+        bn1, bn2 = d.get("bn1_eff", d["bn1"]), d.get("bn2_eff", d["bn2"])
         if self._fuse_shortcut(blk):
-            t, res = self._conv(x0, x1, w1, *d["bn1"], blk.cout, 3, s, hip.ACT_RELU, up_to=up_to, split=True,
+            t, res = self._conv(x0, x1, w1, *bn1, blk.cout, 3, s, hip.ACT_RELU, up_to=up_to, split=True,
                                 sc=(d["down_w"], *d["down_bn"]))
         elif d.get("fold") is not None and pred is None:
             # the shortcut rides in conv2's K loop (v2ce_conv3d_fwd_tail): relu(s2 (W2 * t + Wd' * x) + shift2 + shift_d)
             if d.get("conv1_skip_w") is not None and x1 is not None and self._up2_ok(x0, x1, w1, up_to):
-                part = self._conv_up_part(x0, x1, w1, *d["bn1"], blk.cout, up_to)
-                t = self._conv(x1, None, d["conv1_skip_w"], d["bn1"][0], d["zero_shift"], blk.cout, 3, 1, hip.ACT_RELU, residual=part,
+                part = self._conv_up_part(x0, x1, w1, *bn1, blk.cout, up_to)
+                t = self._conv(x1, None, d["conv1_skip_w"], bn1[0], d["zero_shift"], blk.cout, 3, 1, hip.ACT_RELU, residual=part,
                                split=True)
             else:
-                t = self._conv(x0, x1, w1, *d["bn1"], blk.cout, 3, s, hip.ACT_RELU, up_to=up_to, split=True)
+                t = self._conv(x0, x1, w1, *bn1, blk.cout, 3, s, hip.ACT_RELU, up_to=up_to, split=True)
             fw, fscale, fshift = d["fold"]
+            # conv2's scale: bn2's, over sigma when the planes are W_bar's (the folded shortcut then arrives as Wd' sigma: _sn_all);
+            # the low-resolution share below is added BEHIND the scale and keeps bn2's own
+            cscale = bn2[0]
             if d.get("fold_lo") is not None and x1 is not None and up_to is not None and self._half_up(x0, up_to):
                 r0 = self._conv(x0, None, d["fold_lo"], fscale, d["zero_shift"], blk.cout, 1, 1, hip.ACT_NONE, split=True, algo_hw=up_to)
-                return self._conv(t, None, d["conv2_w"], fscale, fshift, blk.cout, 3, 1, hip.ACT_RELU, split=True, track=track,
+                return self._conv(t, None, d["conv2_w"], cscale, fshift, blk.cout, 3, 1, hip.ACT_RELU, split=True, track=track,
                                   tail=(x1, None, None, 1, d["fold_skip"]), residual=r0, residual_up=True)
-            return self._conv(t, None, d["conv2_w"], fscale, fshift, blk.cout, 3, 1, hip.ACT_RELU, split=True, track=track,
+            return self._conv(t, None, d["conv2_w"], cscale, fshift, blk.cout, 3, 1, hip.ACT_RELU, split=True, track=track,
                               tail=(x0, x1, up_to, s, fw))
         else:
-            t = self._conv(x0, x1, w1, *d["bn1"], blk.cout, 3, s, hip.ACT_RELU, up_to=up_to,
+            t = self._conv(x0, x1, w1, *bn1, blk.cout, 3, s, hip.ACT_RELU, up_to=up_to,
                            split=self._split(blk.cin, blk.cout))
             res = self._conv(x0, x1, d["down_w"], *d["down_bn"], blk.cout, 1, s, hip.ACT_NONE, up_to=up_to,
                              split=self._split(blk.cin, blk.cout, 1, s))
         w2 = d["conv2_w"]
-        return self._conv(t, None, w2, *d["bn2"], blk.cout, 3, 1, hip.ACT_RELU, residual=res,
+        return self._conv(t, None, w2, *bn2, blk.cout, 3, 1, hip.ACT_RELU, residual=res,
                           split=self._split(blk.cout, blk.cout), track=track and pred is None, pred=pred)
 
     def _launch_sn(self):
@@ -778,14 +826,38 @@ class V2ce3d(nn.Module):
             dev = ws.device
             hip.check(hip.lib().v2ce_sn_update_batch(arr, n, ws.data_ptr(), ws.numel(), hip.stream_ptr(dev)),
                       "v2ce_sn_update_batch")
+            once = self._prep.get("sn_once")
+            if once is not None and once["tails"]:            # the folded shortcuts Wd' sigma (pack-only layers: one launch)
+                tarr, tn, tws = once["tail_batch"]
+                hip.check(hip.lib().v2ce_sn_update_batch(tarr, tn, tws.data_ptr(), tws.numel(), hip.stream_ptr(dev)),
+                          "v2ce_sn_update_batch")
             return
+        once = self._prep.get("sn_once")
+        k = 0
         for name, blocks in (("res", self.UNet.resblocks), ("dec", self.UNet.decoders)):
             for i, blk in enumerate(blocks):
                 d = self._prep[f"{name}{i}"]
+                if once is not None:
+                    # the per-layer form of the pack-once scheme (tests): power iteration, then scale / sigma and 1 / sigma by
+                    # the same IEEE divisions the batched kernels make
+                    for cn, bn in (("conv1", "bn1"), ("conv2", "bn2")):
+                        inner = getattr(blk, cn).module
+                        rows, cols = inner.weight_bar.shape[0], inner.weight_bar[0].numel()
+                        P = self._prep
+                        hip.check(hip.lib().v2ce_sn_power_iter(inner.weight_u.data_ptr(), inner.weight_v.data_ptr(), inner.weight_bar.data_ptr(),
+                                                               rows, cols, P["sigma"].data_ptr(), P["sn_ws"].data_ptr(), P["sn_ws"].numel(),
+                                                               hip.stream_ptr(inner.weight_bar.device)), "v2ce_sn_power_iter")
+                        torch.div(d[bn][0], P["sigma"], out=d[bn + "_eff"][0])
+                        torch.div(once["one"], P["sigma"], out=once["inv_sigma"][k:k + 1])
+                        k += 1
+                    continue
                 self._sn_weight(blk.conv1.module, d["conv1_w"])
                 if d.get("conv1_skip_w") is not None:          # (P["sigma"] still holds conv1's)
                     self._pack(blk.conv1.module.weight_bar, self._prep["sigma"], d["conv1_skip_w"], split=True)
                 self._sn_weight(blk.conv2.module, d["conv2_w"])
+        if once is not None:
+            for w32, buf, kk, _ in once["tails"]:
+                self._pack(w32.view(*w32.shape[:2], 1, 1, 1), once["inv_sigma"][kk:kk + 1], buf, split=True)
 
     def _advance_spectral_norm(self):
         if self._prep is None:
