@@ -331,6 +331,18 @@ int v2ce_conv3d_fwd_tail(const v2ce_conv3d_desc *desc, const float *x0, const fl
                          const v2ce_conv3d_desc *tail_desc, const float *tx0, const float *tx1,
                          const int32_t *thmap, const int32_t *twmap, const void *tail_w,
                          const float *tx0_absmax, const float *tx1_absmax, v2ce_stream_t stream);
+/* Round 6: the same tail behind the 32-channel convolution that carries the fused 1x1x1 head (v2ce_conv3d_fwd_pred: Cout = 32, ReLU,
+ * pred_* as there; y may be NULL) -- conv2 + pred of the last decoder block (submodules.py:249-264 on unet_2layer.py:358-365,374) with
+ * the block's shortcut split by source: the skip channels ride as the tail, the upsampled source's share bn_d-scale * Wd[:, :C0] * x0 is
+ * computed at the source's resolution and arrives as `residual`, a LOW-resolution tensor [B][T][Cout/16][res_h = ceil(Hout / 2)]
+ * [res_w_pitch][16] read at (h >> 1, w >> 1) and added before the activation (residual may be NULL; a full-resolution residual is not
+ * taken).  One source x0 (channels-last-16), no index maps on the main conv. */
+int v2ce_conv3d_fwd_tail_pred(const v2ce_conv3d_desc *desc, const float *x0, const float *w_packed, const float *scale,
+                              const float *shift, float *y, const float *x0_absmax, float *y_absmax, const void *pred_w,
+                              const float *pred_b, int pred_cout, float *pred_y, const v2ce_conv3d_desc *tail_desc,
+                              const float *tx0, const float *tx1, const int32_t *thmap, const int32_t *twmap,
+                              const void *tail_w, const float *tx0_absmax, const float *tx1_absmax, const float *residual,
+                              int res_h, int res_w_pitch, v2ce_stream_t stream);
 
 /* The UNet's first layer (scripts/unet_2layer.py:341: ConvLayer3D(2, 32, 3, padding 1) + LeakyReLU; scripts/submodules.py:96,
  * 115-124) in split-half arithmetic: K = 54 as four 16-wide k-steps of three fp16 MFMAs, the output -- 16x the input -- as

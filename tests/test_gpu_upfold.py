@@ -249,3 +249,40 @@ def test_conv3d_up2_split_launch_vs_f64(case):
                  ref_conv(x0, w_up_only, sc1, sh1, 3, 1, 0, x1=x1, up_to=(H, W)), f"partial sum {case}")
     assert_close(V2ce3d.to_planar(y).permute(0, 2, 1, 3, 4).cpu().numpy(),
                  ref_conv(x0, ws, sc1, sh1, 3, 1, 1, x1=x1, up_to=(H, W)), f"split conv1 {case}")
+
+
+@pytest.mark.parametrize("hw", [(32, 48), (33, 47), (65, 90)])
+def test_last_decoder_shortcut_split_by_source(hw, monkeypatch):
+    """Round 6: dec3 with its 1x1x1 shortcut split by source (plain phase-folded conv1; the upsampled channels' share at the source's
+    resolution as conv2's low-resolution residual; the skip channels as conv2's folded tail; pred fused: v2ce_conv3d_fwd_tail_pred)
+    against the fused-shortcut form of rounds 2-5 (V2CE_DEC3_SPLIT=0) and against the oracle -- even and odd planes (the residual
+    is read at (h >> 1, w >> 1) with ceil(H / 2) rows), three calls (the tail is re-packed as Wd' sigma in every forward)."""
+    from oracle import glue as OG
+    from oracle import unet as U
+    from v2ce_toolbox_amd import synth
+    from v2ce_toolbox_amd.v2ce_3d import V2ce3d
+    H, W = hw
+    xn = OG.preprocess(synth.synthetic_frames(9, H, W, seed=11))[None]
+    x = torch.from_numpy(xn).cuda()
+    ms = []
+    for split in ("1", "0"):
+        monkeypatch.setenv("V2CE_DEC3_SPLIT", split)
+        m = V2ce3d(precision="f16x2")
+        m.load_state_dict(synth.make_state_dict(0), strict=True)
+        m = m.eval().to("cuda")
+        m._prepare()
+        ms.append(m)
+    monkeypatch.delenv("V2CE_DEC3_SPLIT")
+    assert ms[0]._prep["dec3"].get("fold_lo") is not None and ms[1]._prep["dec3"].get("fold_lo") is None
+    sd = U.clone_state(synth.make_state_dict(0))
+    for call in range(3):
+        ya, yb = ms[0](x).cpu().numpy(), ms[1](x).cpu().numpy()
+        want = U.forward(sd, torch.from_numpy(xn)).numpy()
+        assert np.abs(ya - yb).max() <= 3e-6 * max(1.0, np.abs(yb).max()), (call, np.abs(ya - yb).max())
+        for y in (ya, yb):
+            assert np.all(np.abs(y - want) <= 1e-5 + 1e-5 * np.abs(want)), (call, np.abs(y - want).max())
+    ms[0].profile = []
+    ms[0](x)
+    names = [p[0] for p in ms[0].profile]
+    assert any(n.startswith("conv3d_f16x2_ws_kernel<3,1,1,1,4,9,4,1>") for n in names), names
+    assert any(n.startswith("conv3d_up_kernel<1,1,4,0>") for n in names), names

@@ -348,6 +348,8 @@ __global__ __launch_bounds__(256, MW) void conv3d_kernel(ConvParams P) {
 // FUSE: 0 = plain, 1 = fused 1x1x1 head (pred_epilogue), 2 = fused 1x1x1 shortcut (second accumulator set),
 //       3 = folded 1x1x1 tail: a residual block's shortcut as P.tCG more K chunks of the SAME accumulators (conv2 of the
 //           block: relu(s2 (W2 * t + Wd' * x) + shift), Wd' = Wd sd / s2 folded on the host; no shortcut tensor at all)
+//       4 = 3 + 1 (round 6): the folded tail AND the fused head -- conv2 of the last decoder block with its shortcut split by source:
+//           the skip channels ride as the tail, the upsampled channels' share arrives as a low-resolution residual (P.res_up)
 // RES: residual known at compile time (0 = none, 1 = present) or checked at run time (2), see conv_epilogue
 template <int KS, int S, int WCO, int CO_FR, int PO_FR, int NA, int FUSE = 0, int RES = 2>
 __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
@@ -355,7 +357,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
     // KS = 1: the "halo box" is the output box itself (positions gathered with stride S), one tap
     constexpr int K3 = KS * KS * KS, CK = 16, EPT = 5, PAD = KS / 2, GS = KS == 1 ? S : 1;
     constexpr int CO_TILE = WCO * CO_FR * 32;
-    const int chs = FUSE == 3 ? P.tCHS : (P.plane + 63) & ~63;
+    const int chs = (FUSE == 3 || FUSE == 4) ? P.tCHS : (P.plane + 63) & ~63;
     f16x8 *pieces = reinterpret_cast<f16x8 *>(conv_smem);                      // [2][4][chs] x 16 B
 
     const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
         return am;
     };
     auto scale_of = [&](int b) -> float { return P.x0_absmax ? pow2_prescale(amax_of(b)) : kActScale; };
-    constexpr bool TAIL = FUSE == 3;
+    constexpr bool TAIL = FUSE == 3 || FUSE == 4;
     static_assert(!TAIL || KS == 3, "the folded tail rides behind a 3x3x3 conv");
     const int CGT = TAIL ? CG + P.tSC : CG;                  // barriers (chunks / tail super-chunks) per tile
     auto tamax_of = [&](int b) -> float {                    // the same for the tail's input
@@ -868,9 +870,28 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
             if (sink == 12345.678f && poff[0] >= 0) P.y[0] = sink;
         } else
 #endif
-        if constexpr (FUSE == 1) {                              // 32-channel conv with the fused 1x1x1 head
+        if constexpr (FUSE == 1 || FUSE == 4) {                 // 32-channel conv with the fused 1x1x1 head
             static_assert(KS == 3 && S == 1 && WCO == 1 && CO_FR == 1, "the fused head rides on a 32-channel tile");
-            conv_epilogue<CO_FR, PO_FR, true, true, RES, true>(P, acc, poff, co0, half, T.b, inv_scale);
+            if constexpr (FUSE == 4 && RES == 1) {
+                int rp[PO_FR];                                  // the low-resolution residual's offsets (conv_epilogue, rpoff)
+#pragma unroll
+                for (int f = 0; f < PO_FR; ++f) {
+                    const int m = (wpo * PO_FR + f) * 32 + l32;
+                    rp[f] = -1;
+                    if (m < P.n_pos) {
+                        const int tt = m / (P.TH * P.TW);
+                        const int rem = m - tt * (P.TH * P.TW);
+                        const int th = rem / P.TW;
+                        const int tw = rem - th * P.TW;
+                        const int t = T.t0 + tt, h = T.h0 + th, w = T.w0 + tw;
+                        if (t < P.T && h < P.Hout && w < P.Wout)
+                            rp[f] = 4 * ((t * P.Cout) * (P.rH * P.rWp)) + 64 * ((h >> 1) * P.rWp + (w >> 1));
+                    }
+                }
+                conv_epilogue<CO_FR, PO_FR, true, true, RES, true>(P, acc, poff, co0, half, T.b, out_inv_scale, &rp);
+            } else {
+                conv_epilogue<CO_FR, PO_FR, true, true, RES, true>(P, acc, poff, co0, half, T.b, out_inv_scale);
+            }
             pred_epilogue<PO_FR>(P, acc, wpo * PO_FR * 32, lane, T.b, T.t0, T.h0, T.w0);
         } else {
             conv_epilogue<CO_FR, PO_FR, true, false, RES, true>(P, acc, poff, co0, half, T.b, out_inv_scale);   // Cout need not fill the last channel tile
@@ -1241,7 +1262,7 @@ int launch_f16x2_ws(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream)
     P.per_xcd = (P.n_spatial + 7) / 8;
     const long long blocks = (long long)8 * P.per_xcd * P.n_co_tiles;
     int chs = (P.plane + 63) & ~63;
-    if (FUSE == 3) {
+    if (FUSE == 3 || FUSE == 4) {
         // tail super-chunks: as many channel groups per barrier as the producers' 5 x 256 element slots (= 160 KB of pieces) hold
         P.tNPP = (P.n_pos + 63) & ~63;
         const int tch = 1280 / P.tNPP;
@@ -1378,7 +1399,7 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
                            const float *sc_scale = nullptr, const float *sc_shift = nullptr, float *sc_y = nullptr,
                            const v2ce_conv3d_desc *tail = nullptr, const float *tx0 = nullptr, const float *tx1 = nullptr,
                            const int32_t *thmap = nullptr, const int32_t *twmap = nullptr,
-                           const float *tx0_absmax = nullptr, const float *tx1_absmax = nullptr) {
+                           const float *tx0_absmax = nullptr, const float *tx1_absmax = nullptr, int res_h = 0, int res_wp = 0) {
     clear_error();
     V2CE_REQUIRE(desc && (g_name_out || (x0 && w_packed && scale && shift && (y || pred_w))), V2CE_ERR_BAD_ARG,
                  "v2ce_conv3d_fwd: null pointer");
@@ -1426,10 +1447,19 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
     P.sc_w = static_cast<const _Float16 *>(sc_w); P.sc_scale = sc_scale; P.sc_shift = sc_shift; P.sc_y = sc_y;
     if (tail) {
         const v2ce_conv3d_desc &t = *tail;
-        V2CE_REQUIRE(d.precision == V2CE_PRECISION_F16X2 && d.ksize == 3 && d.stride_hw == 1 && d.Cout >= 64 && !pred_w && !residual &&
-                     sc_w && !sc_y, V2CE_ERR_UNSUPPORTED,
+        // (round 6, v2ce_conv3d_fwd_tail_pred: the 32-channel conv with the fused head takes a tail too, and with it a low-resolution
+        // residual -- the last decoder block's shortcut split by source)
+        const bool tail_pred = pred_w && d.Cout == 32 && (!residual || res_h > 0);
+        V2CE_REQUIRE(d.precision == V2CE_PRECISION_F16X2 && d.ksize == 3 && d.stride_hw == 1 && sc_w && !sc_y &&
+                     (tail_pred || (d.Cout >= 64 && !pred_w && !residual)), V2CE_ERR_UNSUPPORTED,
                      "v2ce_conv3d_fwd_tail: the folded tail rides behind a split-half 3x3x3 stride-1 conv with >= 64 output channels, "
-                     "no residual and no fused head");
+                     "no residual and no fused head -- or behind the 32-channel conv with the fused head (v2ce_conv3d_fwd_tail_pred)");
+        if (residual && res_h > 0) {
+            V2CE_REQUIRE(res_h == (d.Hout + 1) / 2 && res_wp >= (d.Wout + 1) / 2, V2CE_ERR_BAD_ARG,
+                         "v2ce_conv3d_fwd_tail_pred: an upsampled residual has ceil(Hout / 2) rows of at least ceil(Wout / 2) columns");
+            V2CE_REQUIRE((long long)d.T * d.Cout * res_h * res_wp < (1ll << 29), V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd_tail_pred: residual too large");
+            P.res_up = 1; P.rH = res_h; P.rWp = res_wp;
+        }
         V2CE_REQUIRE(t.ksize == 1 && (t.stride_hw == 1 || t.stride_hw == 2) && t.layout == V2CE_LAYOUT_C16 && t.B == d.B && t.T == d.T &&
                      t.Cout == d.Cout && t.Hout == d.Hout && t.Wout == d.Wout && t.C0 > 0 && t.C0 % 16 == 0 && t.C1 >= 0 &&
                      t.C1 % 16 == 0 && t.Hout == (t.Hin - 1) / t.stride_hw + 1 && t.Wout == (t.Win - 1) / t.stride_hw + 1,
@@ -1494,6 +1524,8 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
             // (one 32-channel fragment row per wave: 12 MFMAs per tap -- a ring of nine taps covers the weight loads' L2 latency
             // where three do not; V2CE_NA9=0: the three-slot ring)
             static const bool na9 = [] { const char *e = getenv("V2CE_NA9"); return !(e && e[0] == '0'); }();
+            if (small_co && P.pred_w && tail)              // the fused head behind a conv with a folded tail (round 6)
+                return P.res ? launch_f16x2_ws<3, 1, 1, 1, 4, 9, 4, 1>(P, d, st) : launch_f16x2_ws<3, 1, 1, 1, 4, 9, 4, 0>(P, d, st);
             if (small_co && P.pred_w && na9) return V2CE_WS_RES(1, 3, 1, 1, 1, 4, 9, 1);
             if (small_co && P.pred_w) return V2CE_WS_RES(1, 3, 1, 1, 1, 4, 3, 1);
             if (small_co && P.sc_w) return launch_f16x2_ws<3, 1, 1, 1, 4, 3, 2, 0>(P, d, st);
@@ -1686,6 +1718,21 @@ extern "C" int v2ce_conv3d_fwd_tail(const v2ce_conv3d_desc *desc, const float *x
                            tail_desc, tx0, tx1, thmap, twmap, tx0_absmax, tx1_absmax);
 }
 
+extern "C" int v2ce_conv3d_fwd_tail_pred(const v2ce_conv3d_desc *desc, const float *x0, const float *w_packed, const float *scale,
+                                         const float *shift, float *y, const float *x0_absmax, float *y_absmax, const void *pred_w,
+                                         const float *pred_b, int pred_cout, float *pred_y, const v2ce_conv3d_desc *tail_desc,
+                                         const float *tx0, const float *tx1, const int32_t *thmap, const int32_t *twmap,
+                                         const void *tail_w, const float *tx0_absmax, const float *tx1_absmax, const float *residual,
+                                         int res_h, int res_w_pitch, v2ce_stream_t stream) {
+    g_name_out = nullptr;
+    clear_error();
+    V2CE_REQUIRE(pred_w && tail_desc && tail_w, V2CE_ERR_BAD_ARG, "v2ce_conv3d_fwd_tail_pred: null head weights / tail description / tail weights");
+    V2CE_REQUIRE(!residual || res_h > 0, V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd_tail_pred: the residual is the low-resolution one (res_h > 0)");
+    return conv3d_dispatch(desc, x0, nullptr, nullptr, nullptr, w_packed, scale, shift, residual, y, x0_absmax, nullptr, y_absmax, stream,
+                           pred_w, pred_b, pred_cout, pred_y, tail_w, nullptr, nullptr, nullptr, tail_desc, tx0, tx1, thmap, twmap,
+                           tx0_absmax, tx1_absmax, res_h, res_w_pitch);
+}
+
 extern "C" size_t v2ce_pack_pred_weights_f16x2_bytes(void) { return 2048 * 2 + 16; }
 
 extern "C" int v2ce_pack_pred_weights_f16x2(const float *w, int cout, int cin, void *table, v2ce_stream_t stream) {
@@ -1699,7 +1746,8 @@ extern "C" int v2ce_pack_pred_weights_f16x2(const float *w, int cout, int cin, v
 }
 
 extern "C" int v2ce_conv3d_variant_fused(const v2ce_conv3d_desc *desc, int mapped, int fuse_in, char *name, size_t cap) {
-    const int fuse = fuse_in & 3;
+    const bool tail_pred = (fuse_in & 8) != 0;              // the tail behind the conv with the fused head (v2ce_conv3d_fwd_tail_pred)
+    const int fuse = tail_pred ? 3 : fuse_in & 3;
     const bool with_res = (fuse_in & 4) != 0;
     V2CE_REQUIRE(name && cap > 0, V2CE_ERR_BAD_ARG, "v2ce_conv3d_variant: no buffer");
     name[0] = '\0';
@@ -1716,11 +1764,12 @@ extern "C" int v2ce_conv3d_variant_fused(const v2ce_conv3d_desc *desc, int mappe
     }
     const int rc = conv3d_dispatch(desc, nullptr, nullptr, m, m, nullptr, nullptr, nullptr, with_res ? &dummy : nullptr,
                                    nullptr, nullptr, nullptr, nullptr, nullptr,
-                                   fuse == 1 ? &dummy : nullptr, fuse == 1 ? &dummy : nullptr, fuse == 1 ? 1 : 0,
-                                   fuse == 1 ? const_cast<float *>(&dummy) : nullptr,
+                                   (fuse == 1 || tail_pred) ? &dummy : nullptr, (fuse == 1 || tail_pred) ? &dummy : nullptr,
+                                   (fuse == 1 || tail_pred) ? 1 : 0, (fuse == 1 || tail_pred) ? const_cast<float *>(&dummy) : nullptr,
                                    fuse >= 2 ? &dummy : nullptr, fuse == 2 ? &dummy : nullptr,
                                    fuse == 2 ? &dummy : nullptr, fuse == 2 ? const_cast<float *>(&dummy) : nullptr,
-                                   fuse == 3 ? &td : nullptr);
+                                   fuse == 3 ? &td : nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                   (tail_pred && with_res && desc) ? (desc->Hout + 1) / 2 : 0, (tail_pred && with_res && desc) ? (desc->Wout + 1) / 2 : 0);
     g_name_out = nullptr;
     return rc;
 }

@@ -138,7 +138,10 @@ __device__ __forceinline__ float apply_act(float t, float slope) { return fmaxf(
 template <int CO_FR, int PO_FR, bool CHECK_CO = false, bool KEEP = false, int RES = 2, bool C16 = false>
 __device__ __forceinline__ void conv_epilogue(const ConvParams &P, f32x16 (&acc)[CO_FR][PO_FR],
                                               const int (&poff)[PO_FR], int co0, int half, int b,
-                                              float inv_scale) {
+                                              float inv_scale, const int (*rpoff)[PO_FR] = nullptr) {
+    // rpoff (C16, a residual): the residual is a 2x nearest-upsampled LOW-resolution tensor [B][T][Cout/16][rH][rWp][16]
+    // (ConvParams::res_up): (*rpoff)[f] = byte offset of the position's group at (h >> 1, w >> 1) inside channel group 0 of its time
+    // step there, or < 0
     typedef float f32x4q __attribute__((ext_vector_type(4)));
     typedef unsigned u32x4q __attribute__((ext_vector_type(4)));
     const float *__restrict__ scale = P.scale;
@@ -148,8 +151,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &P, f32x16 (&acc)
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(P.y ? P.y + b * seq : const_cast<float *>(P.scale), 0,
                                                                           P.y ? (int)(seq * 4) : 0, 0x00020000);
     const bool has_res = RES == 1 || (RES == 2 && P.res != nullptr);
+    const bool rup = C16 && rpoff != nullptr;
+    const long long seq_r = rup ? (long long)P.T * P.Cout * (P.rH * P.rWp) : seq;
+    const int rstride4 = rup ? P.rH * P.rWp * 4 : cstride4;
     const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(has_res ? P.res + b * seq : P.scale), 0, has_res ? (int)(seq * 4) : 0, 0x00020000);
+        const_cast<float *>(has_res ? P.res + b * seq_r : P.scale), 0, has_res ? (int)(seq_r * 4) : 0, 0x00020000);
     const int cbase = co0 + 4 * half;                      // this lane's channel for (q, r) = (0, 0)
     const float slope = act_slope(P.act);
     unsigned vo[PO_FR], vmask[PO_FR];
@@ -159,18 +165,21 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &P, f32x16 (&acc)
         else vo[f] = poff[f] >= 0 ? (unsigned)(poff[f] * 4 + cbase * cstride4) : kOOB;
         vmask[f] = poff[f] >= 0 ? 0x7fffffffu : 0u;        // |v| of a masked lane counts as 0
     }
+    unsigned vor[PO_FR];                                   // the residual's offsets: the output's, or the low-resolution tensor's
+#pragma unroll
+    for (int f = 0; f < PO_FR; ++f) vor[f] = rup ? ((*rpoff)[f] >= 0 ? (unsigned)((*rpoff)[f] + 16 * half) : kOOB) : vo[f];
 #ifdef V2CE_ABLATE_EPI   // diagnostic build: 2 = every store is issued but dropped by the range check, 3 = every residual load
     unsigned vo_st[PO_FR], vo_ld[PO_FR];
 #pragma unroll
     for (int f = 0; f < PO_FR; ++f) {
         vo_st[f] = P.ablate == 2 ? kOOB : vo[f];
-        vo_ld[f] = P.ablate == 3 ? kOOB : vo[f];
+        vo_ld[f] = P.ablate == 3 ? kOOB : vor[f];
     }
 #define V2CE_VO_ST vo_st
 #define V2CE_VO_LD vo_ld
 #else
 #define V2CE_VO_ST vo
-#define V2CE_VO_LD vo
+#define V2CE_VO_LD vor
 #endif
     // scalar (wave-uniform) byte offset of batch (q, r4) = channels cbase + 32 q + 8 r4 + {0..3}
     auto soff = [&](int q, int r4, int k) -> int {
@@ -183,7 +192,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &P, f32x16 (&acc)
             const bool cok = !CHECK_CO || co0 + q * 32 + 8 * r4 < P.Cout;
 #pragma unroll
             for (int f = 0; f < PO_FR; ++f) {
-                const f32x4q v = __builtin_bit_cast(f32x4q, __builtin_amdgcn_raw_buffer_load_b128(rs_r, cok ? V2CE_VO_LD[f] : kOOB, soff(q, r4, 0), 0));
+                const int so = rup ? (co0 / 16 + 2 * q + (r4 >> 1)) * (rstride4 * 16) + 32 * (r4 & 1) : soff(q, r4, 0);
+                const f32x4q v = __builtin_bit_cast(f32x4q, __builtin_amdgcn_raw_buffer_load_b128(rs_r, cok ? V2CE_VO_LD[f] : kOOB, so, 0));
                 rv[0][f] = v[0]; rv[1][f] = v[1]; rv[2][f] = v[2]; rv[3][f] = v[3];
             }
         } else {

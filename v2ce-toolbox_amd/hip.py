@@ -29,7 +29,7 @@ EXPORTS = [
     "v2ce_conv3d_variant", "v2ce_conv3d_variant_fused", "v2ce_pack_weights_f16x2", "v2ce_pack_weights_f16x2_bytes",
     "v2ce_pack_weights", "v2ce_sn_workspace_bytes", "v2ce_sn_power_iter", "v2ce_sn_batch_workspace_bytes", "v2ce_sn_update_batch",
     "v2ce_preprocess_pairs", "v2ce_preprocess_pairs_resize",
-    "v2ce_voxelize_events", "v2ce_conv3d_fwd_pred", "v2ce_conv3d_fwd_sc", "v2ce_conv3d_fwd_tail", "v2ce_pack_pred_weights_f16x2", "v2ce_pack_pred_weights_f16x2_bytes",
+    "v2ce_voxelize_events", "v2ce_conv3d_fwd_pred", "v2ce_conv3d_fwd_sc", "v2ce_conv3d_fwd_tail", "v2ce_conv3d_fwd_tail_pred", "v2ce_pack_pred_weights_f16x2", "v2ce_pack_pred_weights_f16x2_bytes",
     "v2ce_sampler_count", "v2ce_sampler_workspace_bytes", "v2ce_sampler_emit", "v2ce_sampler_pool",
     "v2ce_conv3d_fwd_up2", "v2ce_pack_weights_f16x2_up", "v2ce_pack_weights_f16x2_up_bytes", "v2ce_conv3d_up2_variant",
     "v2ce_conv3d_fwd_wt", "v2ce_conv3d_fwd_wt_tail", "v2ce_pack_weights_f16x2_wt", "v2ce_pack_weights_f16x2_wt_slice", "v2ce_conv3d_fwd_up2_part", "v2ce_pack_weights_f16x2_wt_bytes", "v2ce_conv3d_wt_variant",
@@ -152,6 +152,8 @@ def lib() -> ctypes.CDLL:
     L.v2ce_conv3d_fwd_sc.restype = ctypes.c_int
     L.v2ce_conv3d_fwd_tail.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 11 + [ctypes.POINTER(ConvDesc)] + [vp] * 8
     L.v2ce_conv3d_fwd_tail.restype = ctypes.c_int
+    L.v2ce_conv3d_fwd_tail_pred.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 9 + [i32, vp, ctypes.POINTER(ConvDesc)] + [vp] * 8 + [i32, i32, vp]
+    L.v2ce_conv3d_fwd_tail_pred.restype = ctypes.c_int
     L.v2ce_conv3d_fwd_up2.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 14
     L.v2ce_conv3d_fwd_up2.restype = ctypes.c_int
     L.v2ce_pack_weights_f16x2_up.argtypes = [vp, i32, i32, i32, vp, vp, vp]

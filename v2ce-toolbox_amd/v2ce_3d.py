@@ -272,7 +272,7 @@ class V2ce3d(nn.Module):
                                          split=self._fuse_shortcut(blk) or self._split(blk.cin, blk.cout, 1, blk.stride_hw))
                 d["down_bn"] = self._fold_bn(blk.downsample[1], blk.downsample[0].bias)
                 d["fold"] = None
-                if self._fold_shortcut(blk):
+                if self._fold_shortcut(blk) or self._dec_last_split(name, i, blk):
                     # Wd' = Wd sd / s2 (one f32 rounding per weight on top of the 22-bit split: ~2^-22 relative on the shortcut's
                     # contribution); a BatchNorm scale of (almost) zero in bn2 cannot be divided out: that block keeps its own launch
                     s2, sh2 = d["bn2"]
@@ -291,8 +291,8 @@ class V2ce3d(nn.Module):
                       (d["fold"] is None or (blk.cin % 64 == 0 and os.environ.get("V2CE_WT_TAIL", "1") != "0"))}
                 d["wt"] = wt
                 d["fold_lo"] = d["fold_skip"] = None
-                if name == "dec" and d["fold"] is not None and wt["conv2"] and self._upfold() and (blk.cin // 3) % 64 == 0 and \
-                        os.environ.get("V2CE_TAIL_LOWRES", "1") != "0":
+                if name == "dec" and d["fold"] is not None and self._upfold() and os.environ.get("V2CE_TAIL_LOWRES", "1") != "0" and \
+                        ((wt["conv2"] and (blk.cin // 3) % 64 == 0) or self._dec_last_split(name, i, blk)):
                     # the folded shortcut split by source: the upsampled channels' share s2 Wd'[:, :C0] x0 is computed at the SOURCE's
                     # resolution (a 1x1x1 launch on a quarter of the positions) and added as an upsampled residual
                     # (v2ce_conv3d_fwd_wt_tail, res_h); only the skip channels ride as the tail -- a third of its gathers and MFMAs
@@ -431,6 +431,14 @@ class V2ce3d(nn.Module):
             return False                                   # A/B: the strided blocks' shortcuts as conv2 tails (stride-2 gather)
         return blk.stride_hw == 2 or blk.cout <= 32
 
+    def _dec_last_split(self, name, i, blk) -> bool:
+        """Round 6: the LAST decoder block (32 channels; the `pred` head rides on its conv2) with its 1x1x1 shortcut split by source
+        like dec0-2's -- the upsampled channels' share at the source's resolution as conv2's low-resolution residual, the skip channels as
+        conv2's folded tail (v2ce_conv3d_fwd_tail_pred) -- instead of riding on conv1 as a second accumulator set that writes a second
+        full-resolution tensor and leaves conv1 no registers to double-buffer its B fragments.  V2CE_DEC3_SPLIT=0: the fused form."""
+        return (self.precision == "f16x2" and name == "dec" and i == len(self.UNet.decoders) - 1 and blk.cout == 32 and blk.stride_hw == 1
+                and blk.cin == 96 and self._upfold() and os.environ.get("V2CE_DEC3_SPLIT", "1") != "0")
+
     def _fold_shortcut(self, blk) -> bool:
         """Fold the block's 1x1x1 shortcut into conv2's K loop (v2ce_conv3d_fwd_tail)?  Where it does not already ride on
         conv1 (``_fuse_shortcut``) and conv2 has >= 64 output channels: res0-1, dec0-2.  V2CE_FOLD_SHORTCUT=0 disables."""
@@ -516,8 +524,8 @@ class V2ce3d(nn.Module):
         Wout = (Win + 2 * pad - ksize) // stride + 1
         Woutp = self._pitch(Wout) if dense_out is False else Wout
         assert residual is None or residual_up or residual.shape[4] == Woutp
-        if residual_up:         # a low-resolution residual read at (h >> 1, w >> 1): only the Winograd-T tail launch takes it
-            assert wt and tail is not None and residual.shape[3] == (Hout + 1) // 2 and getattr(residual, "c16", False)
+        if residual_up:         # a low-resolution residual read at (h >> 1, w >> 1): the Winograd-T tail launch and the tail + head launch
+            assert (wt or pred is not None) and tail is not None and residual.shape[3] == (Hout + 1) // 2 and getattr(residual, "c16", False)
         y = torch.empty((B, T, cout // 16, Hout, Woutp, 16) if c16 else (B, T, cout, Hout, Woutp),
                         dtype=torch.float32, device=x0.device)
         y.lw, y.c16 = Wout, c16
@@ -557,6 +565,24 @@ class V2ce3d(nn.Module):
                                                     hip.ptr(a0), hip.ptr(a1), hip.ptr(ay), hip.ptr(sc_w), hip.ptr(sc_scale),
                                                     hip.ptr(sc_shift), hip.ptr(y_sc), hip.stream_ptr(x0.device)),
                       "v2ce_conv3d_fwd_up2")
+        elif pred is not None and tail is not None:      # the fused head behind a conv with a folded tail and a low-resolution residual
+            tab, pbias, pcout = pred
+            tx0, tx1, t_up_to, t_stride, tw = tail
+            assert tx1 is None and t_up_to is None and t_stride == 1 and getattr(tx0, "c16", False) and x1 is None and hmap is None
+            assert residual is None or (residual_up and residual.shape[3] == (Hout + 1) // 2 and getattr(residual, "c16", False))
+            tC0, tH0, tW0p = tx0.shape[2] * 16, tx0.shape[3], tx0.shape[4]
+            tW0 = getattr(tx0, "lw", tW0p)
+            td = hip.ConvDesc(B=B, T=T, C0=tC0, H0=tH0, W0=tW0, C1=0, Hin=tH0, Win=tW0, Cout=cout, Hout=Hout, Wout=Wout, ksize=1,
+                              stride_hw=1, act=hip.ACT_NONE, tile_t=0, tile_h=0, tile_w=0, precision=hip.PRECISION_F16X2,
+                              W0_pitch=tW0p, Win_pitch=tW0p, Wout_pitch=Woutp, layout=hip.LAYOUT_C16, absmax_batch_stride=d.absmax_batch_stride)
+            y = torch.empty((B, T, pcout, Hout, Wout), dtype=torch.float32, device=x0.device)
+            hip.check(hip.lib().v2ce_conv3d_fwd_tail_pred(ctypes.byref(d), x0.data_ptr(), w_packed.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                                          None, hip.ptr(a0), hip.ptr(ay), tab.data_ptr(), pbias.data_ptr(), pcout, y.data_ptr(),
+                                                          ctypes.byref(td), tx0.data_ptr(), None, None, None, tw.data_ptr(),
+                                                          hip.ptr(getattr(tx0, "absmax", None) if a0 is not None else None), None,
+                                                          hip.ptr(residual), residual.shape[3] if residual is not None else 0,
+                                                          residual.shape[4] if residual is not None else 0, hip.stream_ptr(x0.device)),
+                      "v2ce_conv3d_fwd_tail_pred")
         elif pred is not None:           # fused 1x1x1 head: only its output is materialised
             tab, pbias, pcout = pred
             y = torch.empty((B, T, pcout, Hout, Wout), dtype=torch.float32, device=x0.device)
@@ -629,7 +655,7 @@ class V2ce3d(nn.Module):
             if tail is not None:
                 flops += 2.0 * B * T * Hout * Wout * cout * 16 * (tail[0].shape[2] + (0 if tail[1] is None else tail[1].shape[2]))
             name = hip.conv_wt_variant(d, (3 if residual is not None else 2) if tail is not None else residual is not None) if wt else hip.conv_up2_variant(d, sc is not None) if up2 else \
-                hip.conv_variant(d, hmap is not None, (1 if pred is not None else (2 if sc is not None else (3 if tail is not None else 0))) +
+                hip.conv_variant(d, hmap is not None, ((8 if tail is not None else 1) if pred is not None else (2 if sc is not None else (3 if tail is not None else 0))) +
                                  (4 if residual is not None else 0))
             # (flops = the ALGORITHMIC count of the reference's convolution; a phase-folded launch executes fewer: `executed`)
             executed = flops - (2.0 * B * T * Hout * Wout * cout * C0 * 15 if up2 else 0.0)
@@ -751,6 +777,15 @@ class V2ce3d(nn.Module):
         track = self.precision == "f16x2"      # the block output may feed a split-half conv
         # (a spectral-norm layer whose planes were packed once carries 1 / sigma in its epilogue scale: _prepare, "sn_once")
         bn1, bn2 = d.get("bn1_eff", d["bn1"]), d.get("bn2_eff", d["bn2"])
+        if (pred is not None and d.get("fold_lo") is not None and d.get("fold") is not None and blk.cout == 32 and x1 is not None
+                and up_to is not None and self._half_up(x0, up_to) and self._up2_ok(x0, x1, w1, up_to)):
+            # the last decoder block, its shortcut split by source (_dec_last_split): plain phase-folded conv1, the upsampled channels'
+            # share of the shortcut at the source's resolution, conv2 + the skip channels' tail + pred in one launch
+            t = self._conv(x0, x1, w1, *bn1, blk.cout, 3, s, hip.ACT_RELU, up_to=up_to, split=True)
+            fw, fscale, fshift = d["fold"]
+            r0 = self._conv(x0, None, d["fold_lo"], fscale, d["zero_shift"], blk.cout, 1, 1, hip.ACT_NONE, split=True, algo_hw=up_to)
+            return self._conv(t, None, d["conv2_w"], bn2[0], fshift, blk.cout, 3, 1, hip.ACT_RELU, split=True, pred=pred,
+                              tail=(x1, None, None, 1, d["fold_skip"]), residual=r0, residual_up=True)
         if self._fuse_shortcut(blk):
             t, res = self._conv(x0, x1, w1, *bn1, blk.cout, 3, s, hip.ACT_RELU, up_to=up_to, split=True,
                                 sc=(d["down_w"], *d["down_bn"]))
