@@ -255,7 +255,8 @@ def test_conv3d_up2_split_launch_vs_f64(case):
 def test_last_decoder_shortcut_split_by_source(hw, monkeypatch):
     """Round 6: dec3 with its 1x1x1 shortcut split by source (plain phase-folded conv1; the upsampled channels' share at the source's
     resolution as conv2's low-resolution residual; the skip channels as conv2's folded tail; pred fused: v2ce_conv3d_fwd_tail_pred)
-    against the fused-shortcut form of rounds 2-5 (V2CE_DEC3_SPLIT=0) and against the oracle -- even and odd planes (the residual
+    -- opt-in, V2CE_DEC3_SPLIT=1: measured slower than the fused form, DESIGN 4.1h -- against the fused-shortcut form of rounds 2-5
+    (the default) and against the oracle -- even and odd planes (the residual
     is read at (h >> 1, w >> 1) with ceil(H / 2) rows), three calls (the tail is re-packed as Wd' sigma in every forward)."""
     from oracle import glue as OG
     from oracle import unet as U

@@ -435,9 +435,14 @@ class V2ce3d(nn.Module):
         """Round 6: the LAST decoder block (32 channels; the `pred` head rides on its conv2) with its 1x1x1 shortcut split by source
         like dec0-2's -- the upsampled channels' share at the source's resolution as conv2's low-resolution residual, the skip channels as
         conv2's folded tail (v2ce_conv3d_fwd_tail_pred) -- instead of riding on conv1 as a second accumulator set that writes a second
-        full-resolution tensor and leaves conv1 no registers to double-buffer its B fragments.  V2CE_DEC3_SPLIT=0: the fused form."""
+        full-resolution tensor and leaves conv1 no registers to double-buffer its B fragments.
+        OPT-IN (V2CE_DEC3_SPLIT=1): measured on 64 frame-pairs (profiles/r06_c_dec3_split_ab.txt) conv1 1.96 -> 1.66 ms as predicted, but
+        conv2 + pred 1.02 -> 1.24 ms -- its tail reads the 737 MB skip tensor that conv1 had read anyway, so the launch moves as many bytes
+        as with the full-resolution shortcut tensor it no longer reads -- and the low-resolution 1x1x1 launch adds 0.15 ms (409 MB in,
+        205 MB out): 16.32 -> 16.38 ms per step.  What paid for dec0-2 (whose shortcut was a launch of its own) does not pay where the
+        shortcut rode on a launch that had both sources in its LDS already."""
         return (self.precision == "f16x2" and name == "dec" and i == len(self.UNet.decoders) - 1 and blk.cout == 32 and blk.stride_hw == 1
-                and blk.cin == 96 and self._upfold() and os.environ.get("V2CE_DEC3_SPLIT", "1") != "0")
+                and blk.cin == 96 and self._upfold() and os.environ.get("V2CE_DEC3_SPLIT", "0") == "1")
 
     def _fold_shortcut(self, blk) -> bool:
         """Fold the block's 1x1x1 shortcut into conv2's K loop (v2ce_conv3d_fwd_tail)?  Where it does not already ride on
