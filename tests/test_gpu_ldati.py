@@ -435,9 +435,11 @@ def test_dense_tile_kernel_equals_per_bin_kernel(gold_dir, monkeypatch):
     assert hashlib.sha256(ev.to_recarrays()[0].tobytes()).hexdigest() == meta["sha256_packed_events"]
 
 
-def test_pair_pass_kernel_equals_per_bin_kernel(monkeypatch):
-    """ldati_tile_pair_kernel (round 6: two bins of a dense tile per pass where their records share the LDS; V2CE_LDATI_PAIR=1)
-    against the per-bin dense kernel (the default): same bytes and the oracle's events -- on Philox stress frames (pairs 0-1 .. 6-7
+@pytest.mark.parametrize("form", ["V2CE_LDATI_PAIR", "V2CE_LDATI_ONEPASS"])
+def test_pair_pass_kernel_equals_per_bin_kernel(form, monkeypatch):
+    """ldati_tile_pair_kernel (round 6: two bins of a dense tile per pass where their records share the LDS; V2CE_LDATI_PAIR=1) and
+    ldati_tile_onepass_kernel (the classification of all nine bins in one sweep, the work lists in global scratch, pair passes
+    behind it; V2CE_LDATI_ONEPASS=1) against the per-bin dense kernel (the default): same bytes and the oracle's events -- on Philox stress frames (pairs 0-1 .. 6-7
     and bin 8 alone in the 16-wave form), at half and quarter that density (the 8-wave form, two workgroups per CU; at the
     lower density every pass is a pair), on a tile mix where pairs and single-bin passes alternate (a bin that fits with
     neither neighbour), with a voxel outside the slope table in either bin of a pair, at 60 fps with a start time, through the
@@ -445,9 +447,9 @@ def test_pair_pass_kernel_equals_per_bin_kernel(monkeypatch):
     from v2ce_toolbox_amd import LDATI
 
     def both(run):
-        monkeypatch.setenv("V2CE_LDATI_PAIR", "1")             # (opt-in: measured slower on the stress chunk)
+        monkeypatch.setenv(form, "1")                          # (both forms are opt-in: DESIGN 4.2 round 6)
         a = run()
-        monkeypatch.delenv("V2CE_LDATI_PAIR")
+        monkeypatch.delenv(form)
         b = run()
         assert np.array_equal(a.seg_counts, b.seg_counts)
         assert a.packed().cpu().numpy().tobytes() == b.packed().cpu().numpy().tobytes()

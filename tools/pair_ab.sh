@@ -6,8 +6,10 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_gpu_ldati.py -x -q -k "pair_pass or dense_tile_kernel_equals or fused_dense or c5_stress or dense_slot" 2>&1 | tail -5
-for mode in pair nopair; do
-  if [ $mode = nopair ]; then unset V2CE_LDATI_PAIR; else export V2CE_LDATI_PAIR=1; fi
+for mode in ${MODES:-onepass pair nopair}; do
+  unset V2CE_LDATI_PAIR V2CE_LDATI_ONEPASS
+  if [ $mode = pair ]; then export V2CE_LDATI_PAIR=1; fi
+  if [ $mode = onepass ]; then export V2CE_LDATI_ONEPASS=1; fi
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/dens_$mode -- python3 tools/ldati_density_probe.py > $OUT/dens_$mode.log 2>&1
   grep "^scale" $OUT/dens_$mode.log
   python3 - $OUT/dens_$mode <<'PY'
@@ -37,8 +39,10 @@ PY
   done
 done
 # phase stamps of the tile pass, both kernels (diagnostic library)
-for mode in pair nopair; do
-  if [ $mode = nopair ]; then unset V2CE_LDATI_PAIR; else export V2CE_LDATI_PAIR=1; fi
+for mode in ${MODES:-onepass pair nopair}; do
+  unset V2CE_LDATI_PAIR V2CE_LDATI_ONEPASS
+  if [ $mode = pair ]; then export V2CE_LDATI_PAIR=1; fi
+  if [ $mode = onepass ]; then export V2CE_LDATI_ONEPASS=1; fi
   echo "stamps $mode"
   V2CE_HIP_LIB=v2ce-toolbox_amd/csrc/libv2ce_hip_stamp.so timeout 300 python3 tools/ldati_stamps.py stress 2>&1 | head -12
 done

@@ -95,6 +95,8 @@ struct LdatiParams {
     int PB;                       // bits of a pixel index
     int capA, cap2;               // LDS capacities (records) of the tile pass / the bucket sort
     int capP;                     // > 0: ldati_tile_pair_kernel -- records of one PASS (one or two bins of a tile) its LDS holds (>= capA)
+    unsigned *lists;              // ldati_tile_onepass_kernel: the tiles' work lists [B][T][list_stride] words, or null
+    int list_stride;
     int tbits;                    // binary-search steps over the tiles of a frame
     const unsigned *tile_off;     // [B][T][9] exclusive prefix of the tile counts inside the segment
     const unsigned *tc;           // [B][T][9] the tile counts themselves
@@ -2273,6 +2275,461 @@ __device__ __forceinline__ void dense_pair_body(const LdatiParams &P) {
     STAMP_FLUSH(0, 10);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 6, second form: ONE pass over the tile for the classification of all nine bins (`dense_onepass_body`).
+// The pair passes above showed where the per-bin kernel's fixed cost sits: not in latency that a second bin could share, but in
+// the classification (D1) and the work lists (D2) themselves -- every bin re-runs ~200 wave-instructions on all sixteen waves
+// for two voxels per lane, 27 % of the kernel (profiles/r06_a_ldati_pair_stamps_stress.txt).  The sparse kernel does the same
+// work for all nine bins of four pixels in one sweep at an eighth of that per voxel.  So:
+//   pre-phase (once per tile): ten plane loads, the relocation recurrence, the classes of all nine bins in registers; per bin three
+//       packed wave scans (events | singles, k == 0 units | k != 0 units, events unpacked | voxels outside the slope table); ONE
+//       exchange of the wave totals; wave 0 turns them into every wave's bases and the PASS PLAN (bins paired where their records
+//       fit the LDS together, as in dense_pair_body); then every lane writes its voxels' list entries -- 8 bytes per unit of four
+//       draws or single event, 16 per voxel outside the table -- to the tile's scratch in GLOBAL memory (the lists of nine bins
+//       are 200 KB on the stress chunk: they do not fit beside the records), grouped by (pass, class), positions already final;
+//   per pass: timestamps straight from the lists (a batch's 512 bytes are requested one batch ahead), then the pair body's
+//       histogram scan, ranks and copy-out.  No classification, no list building, no window over the planes inside the loop, and
+//       four workgroup barriers per pass instead of six per bin: a wave clears its own histogram row behind its rank loop and the
+//       batch counter alternates between two words, so nothing separates a pass's copy-out from the next pass's timestamps.
+// Requirements as dense_pair_body's (12-bit keys, the common call); scratch: P.lists, P.list_stride words per tile.
+// ---------------------------------------------------------------------------------------------
+template <int NW>
+__device__ __forceinline__ void dense_onepass_body(const LdatiParams &P) {
+    constexpr int NT = 64 * NW, PPT = kTilePix / NT, WPX = 64 * PPT;
+    static_assert(PPT == 4 || PPT == 2, "a lane owns 2 or 4 consecutive pixels");
+    const int t = blockIdx.x, b = blockIdx.y;
+    if (P.sparse_cap) {                                 // the sparse tile kernel owns the lightly populated tiles
+        const unsigned *tcr = P.tc + ((long long)b * P.T + t) * 9;
+        unsigned ntot = 0;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) ntot += tcr[c];
+        if (ntot <= (unsigned)P.sparse_cap) return;
+    }
+    const int pidx = t < P.tpp ? 1 : 0;
+    const int x0 = (t < P.tpp ? t : t - P.tpp) * kTilePix;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float2 *stab = g_slope_tab[P.fast_slot];
+    const unsigned hsl = 12u - (unsigned)P.shift;
+    const unsigned HS = 1u << hsl;
+
+    unsigned *S = reinterpret_cast<unsigned *>(tile_smem);
+    unsigned *O = S + P.capP;
+    unsigned *hist = O + P.capP + 16;                   // [NW][HS] words, two 16-bit cells each
+    unsigned *part = hist + NW * HS;                    // [9][3][NW]: wave totals, then (wave 0) every wave's exclusive prefix
+    unsigned *btot = part + 27 * NW;                    // [9][3] the bins' totals
+    unsigned *bplan = btot + 27;                        // [9] pass | half << 4 | skipped << 5 of every bin
+    unsigned *pinfo = bplan + 9;                        // [9][12] per pass: see the plan below
+    unsigned *spart = pinfo + 9 * 12;                   // [NW + 1] scan partials
+    unsigned *bctr = spart + NW + 1;                    // [2] the next batch of the timestamp phase (alternating by pass)
+    unsigned *dsto = bctr + 2;                          // [9][2] where the tile's run of bin c starts in records[]
+    unsigned *misc = dsto + 18;                         // [0] passes
+    unsigned *myhist = hist + wid * HS;
+
+    const float *plane0 = P.vox + (long long)(b * 2 + pidx) * 10 * P.HW;
+    const unsigned frame = (unsigned)(P.frame_base + b);
+    const int lpx0 = wid * WPX + lane * PPT;
+    const int gpx0 = x0 + lpx0;
+    unsigned *lists = P.lists + ((long long)b * P.T + t) * (long long)P.list_stride;
+
+    // ---- pre-phase 1: the ten planes, the recurrence, per-lane sums of every bin ------------------------------------------
+    int nn[PPT][9];
+    float td[PPT][9];
+    {
+        float yv[PPT][10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            const float *src = plane0 + (long long)i * P.HW + gpx0;
+            if (PPT == 4) {
+                const float4 v = gpx0 < P.HW ? *reinterpret_cast<const float4 *>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+                yv[0][i] = v.x; yv[1][i] = v.y; yv[PPT - 2][i] = v.z; yv[PPT - 1][i] = v.w;
+            } else {
+                const float2 v = gpx0 < P.HW ? *reinterpret_cast<const float2 *>(src) : make_float2(0.f, 0.f);
+                yv[0][i] = v.x; yv[1][i] = v.y;
+            }
+        }
+        for (unsigned i = tid; i < NW * HS; i += NT) hist[i] = 0;
+        if (tid < 2) bctr[tid] = 0;
+        if (tid < 9) {
+            const long long d = P.slot_cap ? (((long long)b * P.T + t) * 9 + tid) * (long long)P.slot_cap
+                                           : P.seg_offsets[b * 9 + tid] + (long long)P.tile_off[((long long)b * P.T + t) * 9 + tid];
+            dsto[2 * tid] = (unsigned)d;
+            dsto[2 * tid + 1] = (unsigned)((unsigned long long)d >> 32);
+            if (P.slot_cap) P.tile_abs_w[(long long)(b * 9 + tid) * P.Tp + t] = (unsigned)d;
+        }
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) relocate_all(yv[q], false, nn[q], td[q]);
+    }
+    // a voxel's class: 0 nothing, 1 single, 2 / 3 multi from the slope table with k == 0 / k != 0, 4 multi outside the table; the
+    // table index in bits 3..13
+    auto voxel_class = [&](int np, int n, int nx, bool edge) -> unsigned {
+        const int dd = edge ? 0 : nx - np;
+        const bool intab = (unsigned)(dd + kSlopeM) <= 2u * kSlopeM && (unsigned)n <= (unsigned)kSlopeM && (unsigned)(np | nx) < (1u << 23);
+        const unsigned si = (unsigned)((dd + kSlopeM) * (kSlopeM + 1) + n);
+        const unsigned cl = n == 1 ? 1u : n < 2 ? 0u : !intab ? 4u : dd == 0 ? 2u : 3u;
+        return cl | ((si & 0x7FFu) << 3);
+    };
+    // its contribution to the lane's running sums: A = events (32 bits, saturating per voxel: a tile's sum cannot wrap, so the
+    // count is right for ANY grid), U = k == 0 units | k != 0 units << 16, R = singles | voxels outside the table << 16 (the packed
+    // fields are meaningful for the bins that fit: at most capA < 2^16 events)
+    auto voxel_sums = [&](unsigned cls, int n, unsigned &A, unsigned &U, unsigned &R) {
+        const unsigned cl = cls & 7u, units = (unsigned)(n + 3) >> 2;
+        A += cl ? ((unsigned)n < (1u << 20) ? (unsigned)n : 1u << 20) : 0u;
+        U += cl == 2u ? units : cl == 3u ? units << 16 : 0u;
+        R += (cl == 1u ? 1u : 0u) + (cl == 4u ? 0x10000u : 0u);
+    };
+    int vmax_l = 0;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+        unsigned A = 0, U = 0, R = 0;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const unsigned cls = voxel_class(c > 0 ? nn[q][c - 1] : 0, nn[q][c], c < 8 ? nn[q][c + 1] : 0, c == 0 || c == 8);
+            voxel_sums(cls, nn[q][c], A, U, R);
+            vmax_l = nn[q][c] > vmax_l ? nn[q][c] : vmax_l;
+        }
+        const unsigned iA = wave_incl_scan(A, lane), iU = wave_incl_scan(U, lane), iR = wave_incl_scan(R, lane);
+        if (lane == 63) { part[(c * 3 + 0) * NW + wid] = iA; part[(c * 3 + 1) * NW + wid] = iU; part[(c * 3 + 2) * NW + wid] = iR; }
+    }
+    // (the lane's own prefixes are formed again in phase 3 -- 27 scans once per tile -- instead of living in 27 registers across
+    // the two barriers; the counts are made opaque so that the compiler does not carry the first results over)
+#pragma unroll
+    for (int q = 0; q < PPT; ++q)
+#pragma unroll
+        for (int c = 0; c < 9; ++c) asm volatile("" : "+v"(nn[q][c]));
+    __syncthreads();                                    // 1: wave totals of all nine bins
+    // ---- pre-phase 2 (wave 0): every wave's exclusive prefix, the bins' totals, the pass plan ------------------------------
+    if (wid == 0) {
+        if (lane < 27) {
+            unsigned v[NW], run = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v[w] = part[lane * NW + w];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                part[lane * NW + w] = run;
+                run += v[w];
+            }
+            btot[lane] = run;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            // bins are walked in order; bin c opens a pass and takes c + 1 along when both fit the LDS; a bin beyond its slot (slot
+            // mode) is only counted.  pinfo[p]: 0 first bin | bins << 8, 1 N_A, 2 N_B, 3 k != 0 units, 4 k == 0 units, 5 singles,
+            // 6 voxels outside the table, 7 first word of the pass's lists
+            unsigned np = 0, off = 0;
+            int c = 0;
+            while (c < 9) {
+                const unsigned NA32 = btot[c * 3];
+                if (P.slot_cap && NA32 > (unsigned)P.capA) { bplan[c] = 1u << 5; ++c; continue; }
+                unsigned nbins = 1, NB32 = 0;
+                if (c + 1 < 9) {
+                    NB32 = btot[(c + 1) * 3];
+                    if (!(P.slot_cap && NB32 > (unsigned)P.capA) && NA32 + NB32 <= (unsigned)P.capP) nbins = 2;
+                }
+                unsigned u1 = btot[c * 3 + 1] >> 16, u0 = btot[c * 3 + 1] & 0xFFFFu, ns = btot[c * 3 + 2] & 0xFFFFu, nr = btot[c * 3 + 2] >> 16;
+                bplan[c] = np;
+                if (nbins == 2) {
+                    u1 += btot[(c + 1) * 3 + 1] >> 16; u0 += btot[(c + 1) * 3 + 1] & 0xFFFFu;
+                    ns += btot[(c + 1) * 3 + 2] & 0xFFFFu; nr += btot[(c + 1) * 3 + 2] >> 16;
+                    bplan[c + 1] = np | (1u << 4);
+                }
+                unsigned *pi = pinfo + np * 12;
+                pi[0] = (unsigned)c | (nbins << 8);
+                pi[1] = NA32; pi[2] = nbins == 2 ? NB32 : 0u;
+                pi[3] = u1; pi[4] = u0; pi[5] = ns; pi[6] = nr; pi[7] = off;
+                pi[8] = off + ((2u * (u1 + u0 + ns) + 3u) & ~3u);          // the 16-byte entries of the voxels outside the table
+                off = pi[8] + 4u * nr;
+                ++np;
+                c += (int)nbins;
+            }
+            misc[0] = np;
+            if (off > (unsigned)P.list_stride) misc[0] = 0xFFFFFFFFu;      // cannot happen (the host sizes the scratch from the slot capacity): checked below
+        }
+    }
+    __syncthreads();                                    // 2: prefixes, totals, plan
+    const unsigned npass = misc[0];
+    if (npass == 0xFFFFFFFFu) {                          // uniform
+        if (tid == 0) atomicExch(reinterpret_cast<unsigned *>(P.status), 4u);
+        return;
+    }
+    // ---- pre-phase 3: the list entries of every voxel, straight to their final places in the tile's scratch ------------------
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+        const unsigned bp = bplan[c];
+        if (bp & (1u << 5)) continue;                    // uniform: only counted
+        const unsigned *pi = pinfo + (bp & 15u) * 12;
+        const unsigned bsel = (bp >> 4) & 1u;
+        const unsigned cA = pi[0] & 0xFFu, twoBins = (pi[0] >> 8) == 2u;
+        const unsigned U1 = pi[3], U0 = pi[4], Ns = pi[5];
+        uint2 *UL1 = reinterpret_cast<uint2 *>(lists + pi[7]), *UL0 = UL1 + U1, *SL = UL0 + U0;
+        uint4 *RL = reinterpret_cast<uint4 *>(lists + pi[8]);
+        (void)Ns;
+        // entries of the pass's first bin precede the second bin's, wave by wave inside each
+        const unsigned pA = part[(c * 3 + 0) * NW + wid], pU = part[(c * 3 + 1) * NW + wid], pR = part[(c * 3 + 2) * NW + wid];
+        unsigned lanA, lanU, lanR;                       // the lane's exclusive prefixes inside its wave
+        {
+            unsigned A = 0, U = 0, R = 0;
+#pragma unroll
+            for (int q = 0; q < PPT; ++q)
+                voxel_sums(voxel_class(c > 0 ? nn[q][c - 1] : 0, nn[q][c], c < 8 ? nn[q][c + 1] : 0, c == 0 || c == 8), nn[q][c], A, U, R);
+            lanA = wave_incl_scan(A, lane) - A; lanU = wave_incl_scan(U, lane) - U; lanR = wave_incl_scan(R, lane) - R;
+        }
+        unsigned a = pA + lanA + (bsel ? pi[1] : 0u);                                              // position in the pass's S
+        unsigned s = (pR & 0xFFFFu) + (lanR & 0xFFFFu) + (bsel ? btot[cA * 3 + 2] & 0xFFFFu : 0u);
+        unsigned u0 = (pU & 0xFFFFu) + (lanU & 0xFFFFu) + (bsel ? btot[cA * 3 + 1] & 0xFFFFu : 0u);
+        unsigned u1 = (pU >> 16) + (lanU >> 16) + (bsel ? btot[cA * 3 + 1] >> 16 : 0u);
+        unsigned r = (pR >> 16) + (lanR >> 16) + (bsel ? btot[cA * 3 + 2] >> 16 : 0u);
+        (void)twoBins;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const int n = nn[q][c];
+            const unsigned cls = voxel_class(c > 0 ? nn[q][c - 1] : 0, n, c < 8 ? nn[q][c + 1] : 0, c == 0 || c == 8);
+            const unsigned cl = cls & 7u, local = (unsigned)(lpx0 + q);
+            if (cl == 1u) {
+                SL[s] = make_uint2(a | (local << 14) | (bsel << 25), __float_as_uint(td[q][c]));
+                ++s;
+            } else if (cl == 2u || cl == 3u) {
+                uint2 *dstu = cl == 2u ? UL0 + u0 : UL1 + u1;
+                const unsigned units = (unsigned)(n + 3) >> 2, hi = (cls >> 3) << 14, lb = local | (bsel << 28);
+                dstu[0] = make_uint2(lb | (((unsigned)n < 4u ? (unsigned)n : 4u) << 29), a | hi);
+                for (unsigned jb = 1; jb < units; ++jb) {
+                    const unsigned left = (unsigned)n - 4u * jb;
+                    dstu[jb] = make_uint2(lb | (jb << 11) | ((left < 4u ? left : 4u) << 29), (a + 4u * jb) | hi);
+                }
+                if (cl == 2u) u0 += units; else u1 += units;
+            } else if (cl == 4u) {
+                float k, bb;
+                slope_params(c > 0 ? nn[q][c - 1] : 0, n, c < 8 ? nn[q][c + 1] : 0, c, P, k, bb);
+                RL[r] = make_uint4(local | (bsel << 11) | ((unsigned)n << 12), a, __float_as_uint(k), __float_as_uint(bb));
+                ++r;
+            }
+            a += cl ? (unsigned)n : 0u;
+        }
+    }
+    if (P.slot_cap) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int m = __shfl_xor(vmax_l, o);
+            vmax_l = m > vmax_l ? m : vmax_l;
+        }
+        if (lane == 0 && vmax_l > 0 && (unsigned long long)vmax_l > *reinterpret_cast<volatile unsigned long long *>(&P.stats_w[0]))
+            atomicMax(&P.stats_w[0], (unsigned long long)vmax_l);
+        if (tid < 9) P.tc_w[((long long)b * P.T + t) * 9 + tid] = btot[tid * 3];
+        if (tid == 0) {
+            unsigned tile_total = 0;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) tile_total += btot[c * 3];
+            if (tile_total > 0 && (unsigned long long)tile_total > *reinterpret_cast<volatile unsigned long long *>(&P.stats_w[4]))
+                atomicMax(&P.stats_w[4], (unsigned long long)tile_total);
+        }
+    }
+    __syncthreads();                                    // 3: the lists are complete (and visible: one CU, one vector cache)
+
+    STAMP_DECL;
+    for (unsigned p = 0; p < npass; ++p) {
+        STAMP(0);
+        const unsigned *pi = pinfo + p * 12;
+        const int c = (int)(pi[0] & 0xFFu);
+        const bool doB = (pi[0] >> 8) == 2u;
+        const unsigned NA = pi[1], NB_ = pi[2], Ntot = NA + NB_, U1 = pi[3], U0 = pi[4], Ns = pi[5], Nr = pi[6];
+        const uint2 *UL1 = reinterpret_cast<const uint2 *>(lists + pi[7]), *UL0 = UL1 + U1, *SL = UL0 + U0;
+        const uint4 *RL = reinterpret_cast<const uint4 *>(lists + pi[8]);
+        const unsigned dshA = dsto[2 * c] & 3u, dshB = doB ? dsto[2 * (c + 1)] & 3u : 0u;
+        const unsigned obB = ((dshA + NA + 3u) & ~3u) + dshB;
+        int lgL = 6;
+        while (((unsigned)NW << lgL) < Ntot) ++lgL;
+        const float offtA = P.offt[c], offtB = P.offt[doB ? c + 1 : c];
+        const int kbA = (int)P.kbase[c], kbB = (int)P.kbase[doB ? c + 1 : c];
+        const unsigned pcA = (unsigned)(pidx * 9 + c);
+        unsigned *bc = bctr + (p & 1u);
+        auto put = [&](unsigned sp, unsigned rec, unsigned g) {
+            S[sp] = rec;
+            atomicAdd(&hist[((sp >> lgL) << hsl) + (g >> 1)], 1u << ((g & 1u) << 4));
+        };
+        // ---- D3: timestamps, once, from the lists; batches of 64 entries handed out through an LDS counter ------------------
+        auto single_batch = [&](uint2 e, bool has) {     // (called by whole waves: single_key votes)
+            const unsigned sp = e.x & 0x3FFFu, bsel = (e.x >> 25) & 1u;
+            const unsigned key = single_key(has, has ? __uint_as_float(e.y) : 0.0f, bsel ? offtB : offtA, (long long)(bsel ? kbB : kbA), true, P);
+            if (has) put(sp, (bsel << 24) | (key << 12) | ((e.x >> 14) & (kTilePix - 1)), (bsel << hsl) | (key >> P.shift));
+        };
+        auto unit_batch = [&](auto mode_c, uint2 e, bool has) {
+            constexpr int MODE = decltype(mode_c)::value;        // 1: k == 0 units (checked fast constant divisions), 3: k != 0 units
+            if (has) {
+                const unsigned local = e.x & (kTilePix - 1), jb = (e.x >> kLocalBits) & 0x1FFFFu, bsel = (e.x >> 28) & 1u, cnt = e.x >> 29;
+                const unsigned sp = e.y & 0x3FFFu;
+                float2 kb = make_float2(0.0f, 0.0f);
+                if (MODE == 3) kb = stab[e.y >> 14];
+                const unsigned px = (unsigned)x0 + local;
+                const float offt_c = bsel ? offtB : offtA;
+                const int kbase_c = bsel ? kbB : kbA;
+                unsigned o[4];
+                philox4_b3(P.seed, px, jb, pcA + bsel, frame, o);
+                float tq[4];
+                if (MODE == 3) {
+                    const float r1 = rcp_refined(kb.x), bb2 = kb.y * kb.y, k2 = 2.0f * kb.x;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) tq[s] = div_rn_nr(-kb.y + sqrt_rn_nr(bb2 + k2 * u24(o[s])), kb.x, r1);
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) tq[s] = k0_time_fast(u24(o[s]), P.FPS, P.RFPS, P.R9);
+                }
+                const unsigned tag = (bsel << 24) | (1u << kLocalBits) | local, gsel = bsel << hsl;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    float tt = tq[s] + offt_c;
+                    tt = tt * 1e6f;
+                    int kk = (int)tt - kbase_c;
+                    kk = kk < 0 ? 0 : kk;
+                    const unsigned key = (unsigned)(kk >= P.NK ? P.NK - 1 : kk);
+                    if ((unsigned)s < cnt) put(sp + s, (key << 12) | tag, gsel | (key >> P.shift));
+                }
+            }
+        };
+        auto rare_batch = [&](unsigned i) {              // voxels outside the slope table: the lane walks its voxel's draws
+            if (i < Nr) {
+                const uint4 e = RL[i];
+                const unsigned local = e.x & (kTilePix - 1), bsel = (e.x >> 11) & 1u, n = e.x >> 12;
+                const float k = __uint_as_float(e.z), bb = __uint_as_float(e.w);
+                const unsigned px = (unsigned)x0 + local;
+                for (unsigned j = 0; j < n; ++j) {
+                    const float u = philox_uniform(P.seed, px, j, pcA + bsel, frame);
+                    const unsigned key = multi_key(k, bb, u, bsel ? offtB : offtA, bsel ? kbB : kbA, P, true);
+                    put(e.y + j, (bsel << 24) | (key << 12) | (1u << kLocalBits) | local, (bsel << hsl) | (key >> P.shift));
+                }
+            }
+        };
+        {
+            const unsigned nK = (U1 + 63u) >> 6, nZ = (U0 + 63u) >> 6, nS = (Ns + 63u) >> 6, nR = (Nr + 63u) >> 6, nb = nK + nZ + nS + nR;
+            // the list entry of batch `bid` for this lane (k != 0 units | k == 0 units | singles are all 8-byte entries of one array)
+            auto entry_of = [&](unsigned bid, bool &has) -> uint2 {
+                unsigned i, cnt;
+                const uint2 *lst;
+                if (bid < nK) { i = bid * 64u + lane; cnt = U1; lst = UL1; }
+                else if (bid < nK + nZ) { i = (bid - nK) * 64u + lane; cnt = U0; lst = UL0; }
+                else { i = (bid - nK - nZ) * 64u + lane; cnt = bid < nK + nZ + nS ? Ns : 0u; lst = SL; }
+                has = i < cnt;
+                return has ? lst[i] : make_uint2(0u, 0u);
+            };
+            unsigned nxt = 0;
+            if (lane == 0) nxt = atomicAdd(bc, 1u);
+            unsigned bid = (unsigned)__builtin_amdgcn_readfirstlane((int)nxt);
+            bool has = false;
+            uint2 e = bid < nb ? entry_of(bid, has) : make_uint2(0u, 0u);
+            while (bid < nb) {
+                // the next batch is reserved now and its entries requested: both round trips run under this batch
+                if (lane == 0) nxt = atomicAdd(bc, 1u);
+                const unsigned nbid = (unsigned)__builtin_amdgcn_readfirstlane((int)nxt);
+                bool nhas = false;
+                const uint2 ne = nbid < nb ? entry_of(nbid, nhas) : make_uint2(0u, 0u);
+                if (bid < nK) unit_batch(std::integral_constant<int, 3>{}, e, has);
+                else if (bid < nK + nZ) unit_batch(std::integral_constant<int, 1>{}, e, has);
+                else if (bid < nK + nZ + nS) single_batch(e, has);
+                else rare_batch((bid - nK - nZ - nS) * 64u + lane);
+                bid = nbid; e = ne; has = nhas;
+            }
+        }
+        STAMP(4);
+        __syncthreads();                                 // B: every row of the histogram is complete
+        STAMP(5);
+        if (tid == 0) bctr[(p + 1u) & 1u] = 0;          // the next pass's counter (this pass's is not read again)
+        // ---- D4: cell-major, row-minor exclusive scan; the tile's rows of the run table (dense_pair_body's) ----------------
+        {
+            unsigned v[NW];
+            unsigned run0 = 0, run1 = 0;
+            const bool mine = (unsigned)tid < HS;
+            if (mine) {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) v[w] = hist[(unsigned)w * HS + tid];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    const unsigned c0 = v[w] & 0xFFFFu, c1 = v[w] >> 16;
+                    v[w] = run0 | (run1 << 16);
+                    run0 += c0;
+                    run1 += c1;
+                }
+            }
+            unsigned tot;
+            const unsigned boff = block_excl_scan<NW>(run0 + run1, spart, &tot);
+            if (mine) {
+                const unsigned bsel = (unsigned)tid >> (hsl - 1u);
+                const unsigned adj = bsel ? obB - NA : dshA;
+                const unsigned packed = (boff + adj) | ((boff + run0 + adj) << 16);
+#pragma unroll
+                for (int w = 0; w < NW; ++w) hist[(unsigned)w * HS + tid] = v[w] + packed;
+                const unsigned bkt = (2u * (unsigned)tid) & (HS - 1u);
+                const int cb = c + (int)bsel;
+                if (bsel == 0u || doB) {
+                    unsigned short *row = P.roff + ((long long)(b * 9 + cb) * P.T + t) * (P.NB + 1);
+                    const unsigned rb = boff - (bsel ? NA : 0u);
+                    if (bkt < (unsigned)P.NB) row[bkt] = (unsigned short)rb;
+                    if (bkt + 1u < (unsigned)P.NB) row[bkt + 1u] = (unsigned short)(rb + run0);
+                }
+            }
+            if (tid == 0) {
+                P.roff[((long long)(b * 9 + c) * P.T + t) * (P.NB + 1) + P.NB] = (unsigned short)NA;
+                if (doB) P.roff[((long long)(b * 9 + c + 1) * P.T + t) * (P.NB + 1) + P.NB] = (unsigned short)NB_;
+            }
+        }
+        __syncthreads();                                 // C: cell offsets per row
+        STAMP(6);
+        // ---- D5: stable ranks; the wave then clears its own row for the next pass (nobody else touches it before barrier D) ----
+        {
+            const unsigned sh = 12u + (unsigned)P.shift;
+            const unsigned lo = (unsigned)wid << lgL, hi = min(Ntot, lo + (1u << lgL));
+            unsigned i = lo + lane, i0 = lo;
+            for (; i0 + 256u <= hi; i0 += 256u, i += 256u) {
+                unsigned rec[4], at[4], hs[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rec[j] = S[i + 64u * j];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned g = rec[j] >> sh;
+                    hs[j] = (g & 1u) << 4;
+                    at[j] = atomicAdd(&myhist[g >> 1], 1u << hs[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) O[(at[j] >> hs[j]) & 0xFFFFu] = rec[j] & 0xFFFFFFu;
+            }
+            for (; i < hi; i += 64u) {
+                const unsigned rec = S[i], g = rec >> sh, hs = (g & 1u) << 4;
+                O[(atomicAdd(&myhist[g >> 1], 1u << hs) >> hs) & 0xFFFFu] = rec & 0xFFFFFFu;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();             // (one wave's LDS operations complete in order)
+            for (unsigned j = lane; j < HS; j += 64u) myhist[j] = 0;
+        }
+        STAMP(7);
+        __syncthreads();                                 // D: the runs are complete in O, the histogram is clean
+        STAMP(8);
+        {
+            auto copy_run = [&](int cb, unsigned ob, unsigned dsh, unsigned N) {
+                const long long dst0 = (long long)(((unsigned long long)dsto[2 * cb + 1] << 32) | dsto[2 * cb]);
+                unsigned *dstq = P.temp + (dst0 - (long long)dsh);            // 16-byte aligned
+                const uint4 *src = reinterpret_cast<const uint4 *>(O + (ob - dsh));
+                const unsigned nq = (dsh + N + 3u) >> 2;
+                for (unsigned q = tid; q < nq; q += NT) {
+                    const uint4 v = src[q];
+                    if (4u * q >= dsh && 4u * q + 4u <= dsh + N) {
+                        reinterpret_cast<uint4 *>(dstq)[q] = v;
+                    } else {
+                        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (4u * q + j >= dsh && 4u * q + j < dsh + N) dstq[4u * q + j] = w[j];
+                    }
+                }
+            };
+            copy_run(c, dshA, dshA, NA);
+            if (doB) copy_run(c + 1, obB, dshB, NB_);
+        }
+        STAMP(9);
+        // (the next pass's timestamps write S and the histogram, the copy-out above reads O: no barrier between them; O is
+        // written again only behind the next pass's barrier C, which every thread reaches after its copy-out)
+    }
+    STAMP(0);
+    STAMP_FLUSH(0, 10);
+}
+
 // true when every run-time switch of the common call is on (dense_tile_body<NW, true>'s condition)
 __device__ __forceinline__ bool dense_fast_call(const LdatiParams &P) {
     bool fast = P.fast_slot >= 0 && P.rng_mode == V2CE_RNG_PHILOX && !P.ballot_ranks && P.ts32 && (P.HW & 3) == 0 &&
@@ -2291,6 +2748,13 @@ __device__ __forceinline__ bool dense_fast_call(const LdatiParams &P) {
 template <int NW>
 __global__ __launch_bounds__(64 * NW, 4) void ldati_tile_pair_kernel(LdatiParams P) {
     if (dense_fast_call(P)) dense_pair_body<NW>(P);
+    else dense_tile_body<NW, false>(P);
+}
+
+// the one-pass form for the common call (P.lists != NULL); any other call runs the per-bin body in the same launch
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 4) void ldati_tile_onepass_kernel(LdatiParams P) {
+    if (dense_fast_call(P)) dense_onepass_body<NW>(P);
     else dense_tile_body<NW, false>(P);
 }
 
@@ -3401,12 +3865,18 @@ size_t dense_tile_lds(int capA, int NB, int NW) {
     return ((size_t)2 * capA + 8 + (size_t)NW * NB + 3 * NW + NW + 1 + 2 + 18 + 10 + 2) * 4;
 }
 
+// words of one tile's work lists (ldati_tile_onepass_kernel): two per unit of four draws or single event -- at most one per event
+// of a multi-event voxel, two per single, i.e. N + 2048 per bin --, four per voxel outside the slope table (>= 32 events each), and
+// the passes' alignment; capA = the most events a (tile, bin) that is not merely counted can hold
+size_t onepass_list_words(int capA) { return ((size_t)9 * ((size_t)capA + capA / 8 + kTilePix) + 64 + 3) & ~(size_t)3; }
+bool onepass_enabled() { const char *e = getenv("V2CE_LDATI_ONEPASS"); return e && e[0] == '1'; }
 // geometry and capacities of the two-level path
 struct Plan {
     int tpp, T, Tp, shift, NB, nb1, PB, capA, cap2, tbits, tile_threads, span, sort_threads;
     size_t n_tab, n_bkt;                 // entries of roff; of bofs
     size_t lds_tile, lds_sort;
     size_t bytes;                        // workspace
+    size_t list_words, off_lists;        // ldati_tile_onepass_kernel's work lists: words per tile, byte offset inside the workspace (0 words: off)
     bool ok;
 };
 
@@ -3483,6 +3953,12 @@ Plan make_plan(const HostScalars &h, int B, int H, int W, int64_t total_events,
     p.bytes = (p.n_bkt + 2 * (size_t)B * 9 * p.NB + 2 * (size_t)B * 9 + 4 +
                (size_t)(total_events > 0 ? total_events : 0)) * 4 + ((p.n_tab * 2 + 3) / 4) * 4 + (size_t)B * 9 * p.NB * p.Tp * 4;
     if (p.lds_tile > 160 * 1024 || p.lds_sort > 160 * 1024) p.ok = false;
+    p.list_words = 0;
+    p.off_lists = (p.bytes + 15) / 16 * 16;
+    if (onepass_enabled() && p.capA <= kCapTile) {
+        p.list_words = onepass_list_words(p.capA);
+        p.bytes = p.off_lists + (size_t)B * p.T * p.list_words * 4;
+    }
     return p;
 }
 
@@ -3620,7 +4096,7 @@ namespace {
 // tile exceeded its slot.
 struct FusedLayout {
     Plan p0;
-    size_t off_abs, off_rec, off_roff, bytes;
+    size_t off_abs, off_rec, off_roff, off_lists, bytes;
     int slot_cap;                        // dense mode: records per (tile, bin) slot (= the tile pass's LDS capacity); 0 = sparse mode
     bool ok;
 };
@@ -3641,7 +4117,8 @@ FusedLayout make_fused_layout(const HostScalars &h, const Opts &o, int B, int H,
     F.off_abs = 16;
     F.off_rec = (F.off_abs + n_abs * 4 + 15) / 16 * 16;
     F.off_roff = (F.off_rec + n_rec * 4 + 15) / 16 * 16;
-    F.bytes = (F.off_roff + p.n_tab * 2 + 15) / 16 * 16;
+    F.off_lists = (F.off_roff + p.n_tab * 2 + 15) / 16 * 16;
+    F.bytes = F.off_lists + (F.slot_cap && p.list_words ? (size_t)B * p.T * p.list_words * 4 : 0);
     return F;
 }
 
@@ -3727,8 +4204,41 @@ int pair_capacity(const LdatiParams &P, const Plan &pl, int NW, size_t budget) {
     if (cap > kCapTile) cap = kCapTile;
     return cap >= pl.capA ? (int)cap : 0;
 }
+// dynamic LDS of ldati_tile_onepass_kernel<NW>'s body: S [capP] | O [capP + 16] | hist [NW][2^(12 - shift)] | wave prefixes [27][NW] | totals,
+// plan, pass table, partials, ...
+size_t dense_onepass_lds(int capP, int shift, int NW) {
+    return ((size_t)2 * capP + 16 + ((size_t)NW << (12 - shift)) + 27 * NW + 27 + 9 + 108 + NW + 1 + 2 + 18 + 4 + 3) * 4;
+}
+int onepass_capacity(const LdatiParams &P, const Plan &pl, int NW, size_t budget) {
+    if (P.NK > 4096 || pl.shift > 8 || (1 << (12 - pl.shift)) > 64 * NW) return 0;
+    const size_t fixed = dense_onepass_lds(0, pl.shift, NW);
+    if (fixed + 2048 > budget) return 0;
+    long long cap = (long long)((budget - fixed) / 8) & ~255ll;
+    if (cap > kCapTile) cap = kCapTile;
+    return cap >= pl.capA ? (int)cap : 0;
+}
 int launch_dense_kernel(const LdatiParams &P, const Plan &pl, int B, hipStream_t st) {
     const size_t lds8 = dense_tile_lds(pl.capA, pl.NB, 8), lds16 = dense_tile_lds(pl.capA, pl.NB, 16);
+    if (P.lists && dense_kernel_serves_pair(P)) {           // the one-pass classification (round 6, second form)
+        static const int force = [] { const char *e = getenv("V2CE_LDATI_DENSE_NW"); return e ? atoi(e) : 0; }();
+        const int cap8 = onepass_capacity(P, pl, 8, 80 * 1024), cap16 = onepass_capacity(P, pl, 16, 160 * 1024);
+        const bool p8 = force == 16 ? false : cap8 > 0;
+        const int capP = p8 ? cap8 : cap16;
+        if (capP > 0) {
+            LdatiParams Q = P;
+            Q.capP = capP;
+            const int nw = p8 ? 8 : 16;
+            size_t lds = dense_onepass_lds(capP, pl.shift, nw);
+            const size_t single = dense_tile_lds(pl.capA, pl.NB, nw);
+            if (single > lds) lds = single;
+            if (lds <= 160 * 1024) {
+                auto ok = p8 ? ldati_tile_onepass_kernel<8> : ldati_tile_onepass_kernel<16>;
+                V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ok), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(ok, dim3(pl.T, B), dim3(64 * nw), lds, st, Q);
+                return V2CE_OK;
+            }
+        }
+    }
     static const int force_nw = [] { const char *e = getenv("V2CE_LDATI_DENSE_NW"); return e ? atoi(e) : 0; }();   // kernel A/B runs
     // round 6: two bins per pass where their records fit the LDS together (dense_pair_body); 512 threads when the largest single
     // (tile, bin) fits two workgroups per CU in that form too
@@ -3814,6 +4324,10 @@ extern "C" int v2ce_ldati_count_fused(const float *vox, int B, int H, int W, dou
     P.tile_abs_w = reinterpret_cast<unsigned *>(fb + F.off_abs);
     P.temp = reinterpret_cast<unsigned *>(fb + F.off_rec);
     P.roff = reinterpret_cast<unsigned short *>(fb + F.off_roff);
+    if (F.slot_cap && pl.list_words) {
+        P.lists = reinterpret_cast<unsigned *>(fb + F.off_lists);
+        P.list_stride = (int)pl.list_words;
+    }
     if (F.slot_cap && dense_kernel_serves(P, o)) {
         // dense regime: ldati_tile_dense_kernel is the count pass and the tile pass at once (slot mode)
         P.sparse_cap = 0;
@@ -3963,6 +4477,10 @@ int emit_impl(const float *vox, int B, int H, int W, double fps, double t0,
         P.temp = reinterpret_cast<unsigned *>(P.status + 4);
         P.roff = reinterpret_cast<unsigned short *>(P.temp + (size_t)total_events);
         P.gruns = reinterpret_cast<unsigned *>(P.roff + ((pl.n_tab + 1) & ~(size_t)1));
+        if (pl.list_words) {
+            P.lists = reinterpret_cast<unsigned *>(wb + pl.off_lists);
+            P.list_stride = (int)pl.list_words;
+        }
         V2CE_HIP_CHECK(hipMemsetAsync(P.status, 0, 4 * sizeof(int), st));
         // the fused count already ran the sparse tile pass: usable when its assumed geometry is the plan's and every tile fitted
         bool fused = false;
