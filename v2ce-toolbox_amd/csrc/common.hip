@@ -16,5 +16,5 @@ void set_error(const char *fmt, ...) {
 void clear_error() { g_err[0] = '\0'; }
 }  // namespace v2ce
 
-extern "C" const char *v2ce_version(void) { return "v2ce-toolbox_amd 0.5 (gfx950)"; }
+extern "C" const char *v2ce_version(void) { return "v2ce-toolbox_amd 0.6 (gfx950)"; }
 extern "C" const char *v2ce_last_error(void) { return v2ce::g_err; }

@@ -3869,6 +3869,12 @@ size_t dense_tile_lds(int capA, int NB, int NW) {
 // of a multi-event voxel, two per single, i.e. N + 2048 per bin --, four per voxel outside the slope table (>= 32 events each), and
 // the passes' alignment; capA = the most events a (tile, bin) that is not merely counted can hold
 size_t onepass_list_words(int capA) { return ((size_t)9 * ((size_t)capA + capA / 8 + kTilePix) + 64 + 3) & ~(size_t)3; }
+// Opt-in (V2CE_LDATI_ONEPASS=1).  Measured in round 6 (profiles/r06_d_ldati_onepass_*): inside the pass loop the form does what it
+// was built for -- classification and list building are gone (103 Mcycles per stress call), the histogram scan, copy-out and loop
+// head shrink with the pair passes (94 -> 46) -- but the sweep in front of the loop costs ~150 Mcycles (54 wave scans, 36
+// classifications and ~22 000 scattered 8-byte stores per tile, on a workgroup that is alone on its CU) and the timestamp phase
+// 127 -> 210: a batch's list entries now come from L2 / the memory-side cache, one batch of prefetch does not cover that.  Stress
+// chunk 698 -> 880 us, half density 480 -> 640, quarter density 400 -> 530.  The lists have to stay in LDS; there they only fit per bin.
 bool onepass_enabled() { const char *e = getenv("V2CE_LDATI_ONEPASS"); return e && e[0] == '1'; }
 // geometry and capacities of the two-level path
 struct Plan {
