@@ -139,7 +139,7 @@ def mfma_table(out):
 def main():
     out = sys.argv[1]
     ev = {}
-    for wl in ("ldati_stress", "e2e"):
+    for wl in ("ldati_stress", "e2e", "ldati_sparse"):
         # events per call from the bench line of the same run when present
         for f in glob.glob(os.path.join(out, f"sq_{wl}_s1.log")):
             for line in open(f):
@@ -150,7 +150,7 @@ def main():
                     except Exception:
                         pass
     text = []
-    for wl in ("ldati_stress", "e2e"):
+    for wl in ("ldati_stress", "e2e", "ldati_sparse"):
         text += ldati_table(out, wl, ev.get(wl, 0))
     if text:
         open(os.path.join(out, "ldati_sq_counters.txt"), "w").write("\n".join(text) + "\n")

@@ -17,7 +17,7 @@ dst = os.path.join(ROOT, "profiles")
 for f in glob.glob(os.path.join(src, "bench_*.json")):
     if os.path.getsize(f):
         shutil.copy(f, os.path.join(dst, f"{tag}_{os.path.basename(f)}"))
-for wl in ("e2e", "ldati_stress"):
+for wl in ("e2e", "ldati_stress", "ldati_sparse"):
     st = glob.glob(os.path.join(src, f"kt_{wl}", "*", "*kernel_stats.csv"))
     if st:
         shutil.copy(st[0], os.path.join(dst, f"{tag}_{wl}_kernel_stats.csv"))
