@@ -170,6 +170,20 @@ def test_rccl_collectives_world_of_one():
 
 
 
+def test_bench_times_both_exchanges_under_torchrun():
+    """bench.py's multi-rank path on nccl at a world of one (V2CE_BENCH_FORCE_DIST=1) with V2CE_BENCH_BOTH_GATHERS=1 -- what
+    the driver's first 8-GPU run takes by itself (round 6): the JSON line carries `value` for the default exchange ('device':
+    the RCCL gather north_star names) and, under gather.other_mode, the same steps timed with 'host'."""
+    import json
+    r = torchrun([os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-exact-f32",
+                  "--no-host-to-host"], {"V2CE_BENCH_FORCE_DIST": "1", "V2CE_BENCH_BOTH_GATHERS": "1"})
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    g = line["gather"]
+    assert g["mode"] == "device" and g["inside_timed_region"] and line["value"] > 0 and line["rccl_world"] == 1
+    other = g["other_mode"]
+    assert other["mode"] == "host" and "error" not in other and other["value"] > 0 and other["gathered_bytes_per_step"] > 0
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: the real multi-process RCCL path (ADVICE r3)")
 @pytest.mark.parametrize("mode", ["host", "device"])
 def test_two_ranks_nccl_equal_single_process(tmp_path, mode):
