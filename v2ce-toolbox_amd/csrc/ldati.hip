@@ -3303,9 +3303,12 @@ template <bool PACKED, int K, int kSortThreads>
 __global__ __launch_bounds__(kSortThreads, 4) void ldati_bucket_sort_kernel(LdatiParams P) {
     constexpr int kSortWaves = kSortThreads / 64;
     const int seg = blockIdx.y;
-    if (blockIdx.x >= P.ngroups[seg]) return;            // uniform per workgroup (flagged segments have no groups; empty
-                                                         // workgroups cost nothing measurable: a compact group list changed nothing)
+    // (the group word is requested together with the group count -- an entry beyond the count holds whatever the workspace held and
+    // is not used --: one dependent global-load latency less in front of every working workgroup's setup)
+    const unsigned ngr = P.ngroups[seg];
     const unsigned grp = P.groups[(long long)seg * P.NB + blockIdx.x];
+    if (blockIdx.x >= ngr) return;                       // uniform per workgroup (flagged segments have no groups; empty
+                                                         // workgroups cost nothing measurable: a compact group list changed nothing)
     const int bk0 = (int)(grp & 0xFFFFu), bk1 = (int)(grp >> 16);           // coarse buckets [bk0, bk1)
     const unsigned *bofs = P.bofs + (long long)seg * (P.NB + 1);
     const unsigned N = bofs[bk1] - bofs[bk0];
@@ -3803,6 +3806,14 @@ __global__ __launch_bounds__(256) void events_unpack_kernel(const unsigned char 
     }
 }
 
+// the few words a call needs zeroed before its first kernel (statistics, status words): one launch instead of the two to four
+// fill kernels that hipMemsetAsync makes of two small, 8-byte-aligned ranges (~5 us each plus their gaps: 4 % of an e2e call)
+__global__ void ldati_zero_words_kernel(unsigned *a, int na, unsigned *b, int nb) {
+    const int i = threadIdx.x;
+    if (i < na) a[i] = 0u;
+    if (b && i < nb) b[i] = 0u;
+}
+
 // host-side scalars, computed exactly like CPU torch does
 struct HostScalars {
     float VS, VS2, INV, FPS;
@@ -4064,7 +4075,7 @@ extern "C" int v2ce_ldati_count(const float *vox, int B, int H, int W, const v2c
     unsigned *tc = static_cast<unsigned *>(tile_ws);
     unsigned *tile_off = tc + (size_t)B * T * 9;
     if (int rc = probe_lds_order(s)) return rc;
-    V2CE_HIP_CHECK(hipMemsetAsync(stats, 0, 4 * sizeof(int64_t), s));
+    hipLaunchKernelGGL(ldati_zero_words_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<unsigned *>(stats), 8, static_cast<unsigned *>(nullptr), 0);
     // 'random' emits like 'slope' (every draw of a multi-event voxel); 'none' only the singles
     const int count_strategy = o.strategy == V2CE_STRATEGY_NONE ? V2CE_STRATEGY_NONE : V2CE_STRATEGY_SLOPE;
     hipLaunchKernelGGL(ldati_count_tiles_kernel, dim3(T, B), dim3(kCountThreads), 0, s, vox, HW, tpp, count_strategy, o.bidir, tc,
@@ -4317,9 +4328,8 @@ extern "C" int v2ce_ldati_count_fused(const float *vox, int B, int H, int W, dou
     unsigned *tc = static_cast<unsigned *>(tile_ws);
     unsigned *tile_off = tc + (size_t)B * pl.T * 9;
     if (int rc = probe_lds_order(s)) return rc;
-    V2CE_HIP_CHECK(hipMemsetAsync(stats, 0, 8 * sizeof(int64_t), s));
     unsigned char *fb = static_cast<unsigned char *>(fused_ws);
-    V2CE_HIP_CHECK(hipMemsetAsync(fb, 0, 16, s));
+    hipLaunchKernelGGL(ldati_zero_words_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<unsigned *>(stats), 16, reinterpret_cast<unsigned *>(fb), 4);
     LdatiParams P{};
     if (int rc = fill_params(P, h, o, vox, B, H, W, fps, rng_mode, uniforms, replay_max_n, seed, frame_base, s)) return rc;
     P.shift = pl.shift; P.NB = pl.NB; P.nb1 = pl.nb1; P.T = pl.T; P.Tp = pl.Tp; P.tpp = pl.tpp; P.PB = pl.PB;
@@ -4443,7 +4453,7 @@ int emit_impl(const float *vox, int B, int H, int W, double fps, double t0,
             // ---- generic path ('random': timestamps spread over a second): tile pass in key mode, one
             // library radix sort of the 60-bit keys, decode (+ pack)
             P.status = reinterpret_cast<int *>(wb);
-            V2CE_HIP_CHECK(hipMemsetAsync(P.status, 0, 4 * sizeof(int), st));
+            hipLaunchKernelGGL(ldati_zero_words_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned *>(P.status), 4, static_cast<unsigned *>(nullptr), 0);
             unsigned long long *kA = reinterpret_cast<unsigned long long *>(wb + L.main_bytes);
             unsigned long long *kB = reinterpret_cast<unsigned long long *>(wb + L.main_bytes + L.keys_bytes / 2);
             void *tmp = wb + L.main_bytes + L.keys_bytes;
@@ -4487,7 +4497,7 @@ int emit_impl(const float *vox, int B, int H, int W, double fps, double t0,
             P.lists = reinterpret_cast<unsigned *>(wb + pl.off_lists);
             P.list_stride = (int)pl.list_words;
         }
-        V2CE_HIP_CHECK(hipMemsetAsync(P.status, 0, 4 * sizeof(int), st));
+        hipLaunchKernelGGL(ldati_zero_words_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned *>(P.status), 4, static_cast<unsigned *>(nullptr), 0);
         // the fused count already ran the sparse tile pass: usable when its assumed geometry is the plan's and every tile fitted
         bool fused = false;
         if (fused_ws && !P.kbb && (fused_tile_bin_hint > 0 || P.sparse_cap)) {
