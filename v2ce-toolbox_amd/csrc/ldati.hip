@@ -53,7 +53,13 @@ constexpr int kMaxShift = 8;          // log2 of the widest coarse bucket
 constexpr int kMaxSpanKeys = 128;     // timestamps a sort group spans at most (its histogram has 4x as many bins)
 constexpr int kSmallGroupSpanKeys = 256;   // ... in the small-group regime (make_plan; measured 128 / 256 / 512: e2e sort 94 / 89 / 116 us)
 constexpr int kCapTile = 15360;       // events of one (tile, bin) the tile pass can hold in LDS
-constexpr int kSparseCap = 8192;      // events of one tile over all nine bins the sparse tile kernel holds
+#ifndef V2CE_SPARSE_CAP               // (diagnostic builds: tools/sparse_cap_ab.sh)
+#define V2CE_SPARSE_CAP 8192
+#endif
+#ifndef V2CE_SPARSE_WAVES
+#define V2CE_SPARSE_WAVES 1
+#endif
+constexpr int kSparseCap = V2CE_SPARSE_CAP;      // events of one tile over all nine bins the sparse tile kernel holds
 constexpr int kSparseThreads = 512;
 constexpr size_t kSparseLds = (size_t)(2 * kSparseCap + kSparseThreads * 5 + 34) * 4 + 9 * 8 + (kSparseThreads / 64) * 10 * 4;
 constexpr int kSlopeM = 31;            // slope table (g_slope_tab): |count difference| <= kSlopeM, count <= kSlopeM; else computed
@@ -2824,7 +2830,7 @@ __global__ __launch_bounds__(256) void ldati_selfcheck_kernel(float VS, float VS
 // records (`temp` + slot; the (tile, bin) starts go to tile_abs for the bucket sort).  A tile beyond kSparseCap only reports
 // its counts; the host then takes the two-pass path for the call (v2ce_ldati_emit_fused).
 template <bool FUSED>
-__global__ __launch_bounds__(kSparseThreads) void ldati_tile_sparse_kernel(LdatiParams P) {
+__global__ __launch_bounds__(kSparseThreads, V2CE_SPARSE_WAVES) void ldati_tile_sparse_kernel(LdatiParams P) {
     constexpr int NT = kSparseThreads, NW = NT / 64, PPT = kTilePix / NT;
     constexpr int HWORDS = NT * 5;                       // 10 cells per thread >= 9 * kMaxNB + 1
     const int t = blockIdx.x, b = blockIdx.y;
