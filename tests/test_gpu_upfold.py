@@ -285,5 +285,5 @@ def test_last_decoder_shortcut_split_by_source(hw, monkeypatch):
     ms[0].profile = []
     ms[0](x)
     names = [p[0] for p in ms[0].profile]
-    assert any(n.startswith("conv3d_f16x2_ws_kernel<3,1,1,1,4,9,4,1>") for n in names), names
+    assert any(n.startswith("conv3d_f16x2_ws_kernel<3,1,1,1,4,9,4,1,") for n in names), names
     assert any(n.startswith("conv3d_up_kernel<1,1,4,0>") for n in names), names

@@ -36,6 +36,12 @@
 #endif
 #include <type_traits>
 
+// producer-side epilogue (conv3d_f16x2_ws_kernel, OPT bit 0): position fragments per wave whose epilogue stays with the consumers
+// (measured on dec3.conv2 + head: 2 of 4 -> 0.94 ms, 1 of 4 -> 0.98, 0 of 4 -> 0.99, all four = no hand-over -> 1.01)
+#ifndef V2CE_PEPI_KEEP
+#define V2CE_PEPI_KEEP 2
+#endif
+
 namespace v2ce {
 namespace {
 
@@ -351,14 +357,43 @@ __global__ __launch_bounds__(256, MW) void conv3d_kernel(ConvParams P) {
 //       4 = 3 + 1 (round 6): the folded tail AND the fused head -- conv2 of the last decoder block with its shortcut split by source:
 //           the skip channels ride as the tail, the upsampled channels' share arrives as a low-resolution residual (P.res_up)
 // RES: residual known at compile time (0 = none, 1 = present) or checked at run time (2), see conv_epilogue
-template <int KS, int S, int WCO, int CO_FR, int PO_FR, int NA, int FUSE = 0, int RES = 2>
+// OPT bit 0, "PEPI" (round 6): the tile's epilogue is SHARED between the roles.  The 32-channel tile with the fused head has two chunks
+//       of 324 MFMAs per wave and an epilogue (residual, scale / shift, ReLU, the head's MFMAs, 20 planar channels of stores) that
+//       took 17-19 k of its 46 k cycles with the producers idle at barriers for half of the launch.  Now the consumers leave the
+//       accumulators of V2CE_PEPI_KEEP .. PO_FR - 1 of a wave's position fragments in the pieces buffer the tile's last chunk has just
+//       freed (a barrier in front of the dump: every consumer wave must be done with those pieces; one behind it: the producers may
+//       start) and run the epilogue of the others themselves, while producer wave w + 4 -- the lane layout of consumer wave w --
+//       takes the dumped ones.  Both use ONE lean form (epi_fragment): tables in LDS instead of global loads, one LDS round trip
+//       per fragment, a power-of-two pre-scale per position instead of a wave maximum, the residual requested ahead of the
+//       hand-over; nothing in it waits for a store.  dec3.conv2 + head: 1.00-1.04 -> 0.93-0.97 ms (with what did not
+//       work: all four fragments on the producers, B fragments reused across the time taps).
+template <int KS, int S, int WCO, int CO_FR, int PO_FR, int NA, int FUSE = 0, int RES = 2, int OPT = 0>
 __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int PEPI = OPT & 1;                              // (OPT: a bit set; bit 0 = the producer-side epilogue)
     // KS = 1: the "halo box" is the output box itself (positions gathered with stride S), one tap
     constexpr int K3 = KS * KS * KS, CK = 16, EPT = 5, PAD = KS / 2, GS = KS == 1 ? S : 1;
     constexpr int CO_TILE = WCO * CO_FR * 32;
-    const int chs = (FUSE == 3 || FUSE == 4) ? P.tCHS : (P.plane + 63) & ~63;
+    static_assert(!PEPI || (FUSE == 1 && CO_FR == 1), "producer-side epilogue: the 32-channel tile with the fused head");
+    // PEPI: the consumers keep the first kKeepFr position fragments of a wave for their own epilogue and hand the others over -- the
+    // two epilogues run side by side between the tile's last chunk and the next tile's first
+    constexpr int kKeepFr = PEPI ? V2CE_PEPI_KEEP : PO_FR, kDumpFr = PO_FR - kKeepFr;
+    constexpr int kDumpWave = CO_FR * kDumpFr * 4 * 64;      // f32x4 per consumer wave in the accumulator dump (PEPI)
+    int chs_ = (FUSE == 3 || FUSE == 4) ? P.tCHS : (P.plane + 63) & ~63;
+    if (PEPI && chs_ < kDumpWave) chs_ = kDumpWave;          // a pieces buffer (4 chs x 16 B) holds the four waves' dumps
+    const int chs = chs_;
     f16x8 *pieces = reinterpret_cast<f16x8 *>(conv_smem);                      // [2][4][chs] x 16 B
+    [[maybe_unused]] unsigned *pepi_flag = reinterpret_cast<unsigned *>(conv_smem + (size_t)chs * 128);   // PEPI: producer waves done reading a dump
+    if constexpr (PEPI != 0) {                               // (all of it visible behind the first chunk barrier, long before its first use)
+        // LDS behind the pieces: counter (16 B) | scale[32] shift[32] of the conv, bias[32] of the head | the head's A fragments (4 KB)
+        if (threadIdx.x < 32) {
+            float *tab = reinterpret_cast<float *>(pepi_flag + 4);
+            tab[threadIdx.x] = P.scale[threadIdx.x];
+            tab[32 + threadIdx.x] = P.shift[threadIdx.x];
+            tab[64 + threadIdx.x] = P.pred_b[threadIdx.x];
+        }
+        if (threadIdx.x < 256) reinterpret_cast<f16x8 *>(pepi_flag + 100)[threadIdx.x] = reinterpret_cast<const f16x8 *>(P.pred_w)[threadIdx.x];
+    }
 
     const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -456,6 +491,163 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
     if (!next_tile(vb, T)) return;
     int gc = 0;                                             // chunks handled so far: pieces buffer gc & 1
 
+    // ---- PEPI: the lean epilogue of ONE position fragment, used by both roles (consumer wave w and producer wave w + 4 share the
+    // lane layout of wave w's accumulator tiles).  conv_epilogue's arithmetic (scale, shift, residual, activation, range tracking;
+    // conv3d_dev.h) on the sixteen registers of the fragment, then pred_epilogue's: split into fp16 halves at a power of two per
+    // POSITION, six MFMAs, bias, ReLU, planar stores.  Scale / shift / bias and the head's A fragments come from LDS -- a global load
+    // here would sit behind earlier stores in the in-order vector-memory counter -- in one round trip; nothing in it waits for a store.
+    typedef float f32x4d __attribute__((ext_vector_type(4)));
+    [[maybe_unused]] int epk[PO_FR];                        // this lane's position in each fragment, packed tt << 20 | th << 10 | tw (-1: none)
+    if constexpr (PEPI != 0) {
+#pragma unroll
+        for (int f = 0; f < PO_FR; ++f) {
+            const int m = ((wave & 3) * PO_FR + f) * 32 + l32;
+            epk[f] = -1;
+            if (m < P.n_pos) {
+                const int tt = m / (P.TH * P.TW);
+                const int rem = m - tt * (P.TH * P.TW);
+                const int th = rem / P.TW;
+                epk[f] = (tt << 20) | (th << 10) | (rem - th * P.TW);
+            }
+        }
+    }
+    // this lane's offsets in fragment f of tile E: vo = bytes of its 16-byte channel quad inside channel group 0 of the conv's output /
+    // residual, vp = bytes of its head output in channel 4 half (kOOB: outside the tensor)
+    [[maybe_unused]] auto epi_offsets = [&](const TileId &E, int f, unsigned &vo, unsigned &vp) __attribute__((always_inline)) {
+        int pk = epk[f];
+        asm volatile("" : "+v"(pk));                        // (unpacked at the use, not kept unpacked for the life of the kernel)
+        vo = vp = kOOB;
+        if (pk >= 0) {
+            const int tt = pk >> 20, th = (pk >> 10) & 1023, tw = pk & 1023;
+            const int t = E.t0 + tt, h = E.h0 + th, w = E.w0 + tw;
+            if (t < P.T && h < P.Hout && w < P.Wout) {
+                vo = (unsigned)(4 * ((t * P.Cout) * (P.Hout * P.Woutp)) + 64 * (h * P.Woutp + w) + 16 * half);
+                vp = (unsigned)((((t * P.pred_cout) * (P.Hout * P.Wout)) + h * P.Wout + w) * 4 + 4 * half * (P.Hout * P.Wout * 4));
+            }
+        }
+    };
+    // the residual of fragment f of tile E: channels 8 r4 + 4 half + {0..3} of register quad r4 = group r4 >> 1, bytes 32 (r4 & 1) + 16 half
+    [[maybe_unused]] auto epi_load_res = [&](const TileId &E, int f, f32x4d (&rv)[4]) __attribute__((always_inline)) {
+        if constexpr (PEPI != 0 && RES == 1) {
+            const long long seq = (long long)P.T * P.Cout * (P.Hout * P.Woutp);
+            const int gstride = P.Hout * P.Woutp * 64;
+            const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.res + E.b * seq), 0, (int)(seq * 4), 0x00020000);
+            unsigned vo, vp;
+            epi_offsets(E, f, vo, vp);
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+                rv[r4] = __builtin_bit_cast(f32x4d, __builtin_amdgcn_raw_buffer_load_b128(rs_r, vo, (r4 >> 1) * gstride + 32 * (r4 & 1), 0));
+        }
+    };
+    // a = the fragment's sixteen accumulators as four register quads, rv = its residual; `between` runs after the last use of rv and
+    // before the fragment's stores (the place to request the next residual)
+    [[maybe_unused]] auto epi_fragment = [&](const TileId &E, int f, const f32x4d (&a)[4], const f32x4d (&rv)[4], unsigned &ymax,
+                                             auto &&between) __attribute__((always_inline)) {
+        if constexpr (PEPI != 0) {
+            typedef unsigned u32x4d __attribute__((ext_vector_type(4)));
+            const float inv = 1.0f / (scale_of(E.b) * w_scale);
+            const float *tab = reinterpret_cast<const float *>(pepi_flag + 4);                      // scale[32] | shift[32] | bias[32]
+            const f16x8 *atab = reinterpret_cast<const f16x8 *>(pepi_flag + 100);                   // the head's A fragments (4 KB)
+            const long long seq = (long long)P.T * P.Cout * (P.Hout * P.Woutp);
+            const int gstride = P.Hout * P.Woutp * 64;            // bytes between 16-channel groups of a time step
+            const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(P.y ? P.y + E.b * seq : const_cast<float *>(P.scale), 0,
+                                                                                  P.y ? (int)(seq * 4) : 0, 0x00020000);
+            const long long pseq = (long long)P.T * P.pred_cout * (P.Hout * P.Wout);
+            const int pstride4 = P.Hout * P.Wout * 4;
+            const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(P.pred_y + E.b * pseq, 0, (int)(pseq * 4), 0x00020000);
+            const float pw_scale = reinterpret_cast<const float *>(P.pred_w + 2048)[0];
+            const float slope = act_slope(P.act);
+            unsigned vo, vp;
+            epi_offsets(E, f, vo, vp);
+            const unsigned vmask = vo != kOOB ? 0x7fffffffu : 0u;
+            // every LDS read of the fragment in front of ONE wait (with a wait per register quad the epilogue was 100 LDS round trips
+            // in a row behind the consumers' B-fragment reads: ~1 k cycles each)
+            f32x4d scq[4], shq[4], bq[4];
+            f16x8 ahp[2], alp[2];
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                scq[r4] = *reinterpret_cast<const f32x4d *>(tab + 8 * r4 + 4 * half);
+                shq[r4] = *reinterpret_cast<const f32x4d *>(tab + 32 + 8 * r4 + 4 * half);
+                bq[r4] = *reinterpret_cast<const f32x4d *>(tab + 64 + 8 * r4 + 4 * half);
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                ahp[k] = atab[((k * 2 + 0) * 32 + l32) * 2 + half];
+                alp[k] = atab[((k * 2 + 1) * 32 + l32) * 2 + half];
+            }
+            float v[16];
+            float mx = 0.0f;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                f32x4d y4;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float t = a[r4][k] * (scq[r4][k] * inv) + shq[r4][k];
+                    if constexpr (RES == 1) t += rv[r4][k];
+                    t = apply_act(t, slope);
+                    y4[k] = t;
+                    const unsigned av = __builtin_bit_cast(unsigned, t) & vmask;
+                    ymax = av > ymax ? av : ymax;
+                    const float kept = __builtin_bit_cast(float, av == 0u ? 0u : __builtin_bit_cast(unsigned, t));
+                    v[4 * r4 + k] = kept;
+                    mx = fmaxf(mx, fabsf(kept));
+                }
+                if (P.y) {                                      // uniform: the decoder output itself is rarely wanted
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4d, y4), rs_y, vo, (r4 >> 1) * gstride + 32 * (r4 & 1), 0);
+                    asm volatile("s_nop 1" : "+v"(y4));        // (16-byte store data hazard: conv_epilogue)
+                }
+            }
+            between();
+            // pre-scale of the split: a power of two per POSITION (a column of the B fragment, whose sixteen channels of a k-step sit in
+            // this lane and in lane ^ 32; the same column of the output lands in this lane), so one exchange between the wave's halves
+            // replaces the six-step wave maximum of pred_epilogue
+            {
+                // (inline asm: through __builtin_amdgcn_permlane32_swap this build's compiler takes BOTH results from the first register
+                // and the lower half of the wave never sees the upper half's maximum -- found by the golden test)
+                float ma = mx, mb = mx;
+                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(ma), "+v"(mb));
+                mx = fmaxf(mx, fmaxf(ma, mb));
+            }
+            const float v_scale = pow2_prescale(mx);
+            f32x16 out;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[r] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                typedef unsigned u32x4c __attribute__((ext_vector_type(4)));
+                u32x4c ph, pl;                                  // hi = f16(x s), lo = f16(x s - hi): the producers' four mixed-precision FMAs per pair
+#pragma unroll
+                for (int c2 = 0; c2 < 4; ++c2) {
+                    unsigned h, l;
+                    asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
+                        "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
+                        "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
+                        "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                        : "=&v"(h), "=&v"(l) : "v"(v[8 * k + 2 * c2]), "v"(v[8 * k + 2 * c2 + 1]), "v"(v_scale));
+                    ph[c2] = h;
+                    pl[c2] = l;
+                }
+                const f16x8 bhp = __builtin_bit_cast(f16x8, ph), blp = __builtin_bit_cast(f16x8, pl);
+                out = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahp[k], bhp, out, 0, 0, 0);
+                out = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahp[k], blp, out, 0, 0, 0);
+                out = __builtin_amdgcn_mfma_f32_32x32x16_f16(alp[k], bhp, out, 0, 0, 0);
+            }
+            const float invp = 1.0f / (v_scale * pw_scale);
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                if (8 * r4 >= P.pred_cout) continue;            // uniform: rows of the 32 that the head does not have (20 channels: a quarter of the stores)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int oq = k + 8 * r4;                  // output channel minus 4 * half
+                    const bool ook = oq + 4 * half < P.pred_cout;
+                    float y = out[4 * r4 + k] * invp + bq[r4][k];
+                    y = fmaxf(y, 0.0f) + 0.0f;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), rs_p, ook ? vp : kOOB, oq * pstride4, 0);
+                }
+            }
+        }
+    };
+
     if (wave >= 4) {
         // ------------------------------------------------------------------ producers
         // a chunk travels global -> registers (gather with the halo offsets; out-of-range offsets
@@ -496,7 +688,11 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
                         src_cbase = P.tC0;
                     }
                 } else {
-                halo_offsets<EPT, true>(P, L.t0 - PAD, L.h0 * S - PAD, L.w0 * S - PAD, want_src == 1, ptid, goff, GS);
+                // (PEPI: the decomposition of the element index -- the same for every tile -- is NOT to be hoisted out of the tile loop:
+                // fifteen registers for the life of the kernel that the producer-side epilogue cannot afford; ~400 VALU per tile instead)
+                int ptid_l = ptid;
+                if constexpr (PEPI != 0) asm volatile("" : "+v"(ptid_l));
+                halo_offsets<EPT, true>(P, L.t0 - PAD, L.h0 * S - PAD, L.w0 * S - PAD, want_src == 1, ptid_l, goff, GS);
                 if (want_src == 0) {
                     const long long seq = (long long)P.T * P.C0 * (P.H0 * P.W0p);
                     rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.x0 + L.b * seq), 0, (int)(seq * 4), 0x00020000);
@@ -557,12 +753,14 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
 #ifdef V2CE_ABLATE_UP
             const int ne_abl = (!tail && cgC * CK < P.C0 && P.hmap) ? V2CE_ABLATE_UP : EPT;
 #endif
+            int rb = ptid;
+            if constexpr (PEPI != 0) asm volatile("" : "+v"(rb));   // (the piece addresses are formed here, not kept for the life of the kernel)
 #pragma unroll
             for (int i = 0; i < EPT; ++i) {
 #ifdef V2CE_ABLATE_UP
                 if (i >= ne_abl) continue;
 #endif
-                const int r = ptid + 256 * i;
+                const int r = rb + 256 * i;
                 if ((wave - 4) * 64 + 256 * i < lim) {                // wave-uniform (lanes past the box write padding)
 #pragma unroll
                     for (int hg = 0; hg < 2; ++hg) {
@@ -591,10 +789,12 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
         };
         // the conversion cursor counts the chunks of this workgroup's tiles
         bool moreC = true;
+        [[maybe_unused]] TileId Tprev = T;                  // PEPI: the tile whose chunks have all been staged
         auto advance = [&]() {
             ++gc;
             if (++cgC == CGT) {
                 cgC = 0;
+                if constexpr (PEPI != 0) Tprev = T;
                 vb += (int)gridDim.x;
                 moreC = next_tile(vb, T);
                 if (moreC) {
@@ -603,24 +803,92 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
                 }
             }
         };
+        [[maybe_unused]] unsigned long long t_all = TICK(), t_bar = 0, t_epi = 0, t_cvt = 0, t_ld = 0;   // (-DV2CE_STAMP: where the producers' time goes)
+        [[maybe_unused]] f32x4d epi_rv[4];                             // residual of ONE fragment, rolling (epi_load_res)
+        [[maybe_unused]] auto epi_prefetch = [&](const TileId &E) __attribute__((always_inline)) { epi_load_res(E, kKeepFr, epi_rv); };
+        // PEPI: the epilogue of the fragments kKeepFr .. PO_FR - 1 of tile E, whose consumers left those accumulators in the pieces buffer
+        // of its last chunk (g_last): this wave takes the dump of consumer wave (wave - 4) -- the same lane layout.  The residual of
+        // fragment f + 1 is requested as soon as fragment f's values have been consumed and BEFORE fragment f's stores.
+        [[maybe_unused]] auto tile_epilogue = [&](const TileId &E, int g_last) __attribute__((always_inline)) {
+            if constexpr (PEPI != 0) {
+                const f32x4d *dump = reinterpret_cast<const f32x4d *>(pieces + (g_last & 1) * 4 * chs) + (wave - 4) * kDumpWave;
+                unsigned ymax = 0u;
+                step_loop<kKeepFr, PO_FR>([&](auto fc) {
+                    constexpr int f = decltype(fc)::value;   // the wave's fragment; its accumulators are fragment f - kKeepFr of the dump
+                    f32x4d a[4];
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) a[r4] = dump[((f - kKeepFr) * 4 + r4) * 64 + lane];
+                    epi_fragment(E, f, a, epi_rv, ymax, [&]() __attribute__((always_inline)) {
+                        if constexpr (f + 1 < PO_FR) epi_load_res(E, f + 1, epi_rv);
+                    });
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                if (P.y_absmax) absmax_commit(__builtin_bit_cast(float, ymax), P.y_absmax + E.b * P.amax_bs);
+            }
+        };
+        // one chunk: convert it, issue the loads of the chunk two ahead, meet the consumers.  PEPI: a chunk that opens a tile (not the
+        // first) is preceded by the barrier behind which the consumers dump the previous tile's accumulators, and followed by that
+        // tile's epilogue.
+        auto chunk_step = [&](float (&R)[CK][EPT], int stamp_a, int stamp_b) __attribute__((always_inline)) {
+            { [[maybe_unused]] const unsigned long long tc = TICK();
+            convert(R);
+            ACC_T(t_cvt, tc); }
+            if (gc == 0 && stamp_a >= 0) STAMP(1, 2);
+            if constexpr (PEPI != 0) {
+                // R is reloaded BEHIND the rendezvous (its loads still have a whole consumer chunk to land in) and declared dead in
+                // front of it: the epilogue has its eighty registers.  (With both chunks in flight next to the epilogue 236 registers
+                // went to scratch and the launch took 3.7 ms instead of 1.0; with the reload on two paths the register allocator
+                // spilled the chunks themselves.)
+                const bool opens = cgC == 0 && gc != 0;               // uniform
+                if (opens) {
+                    epi_prefetch(Tprev);
+                    { [[maybe_unused]] const unsigned long long tb = TICK();
+                    lds_barrier();                                    // (the consumers' pieces of the previous tile are dead)
+                    lds_barrier();                                    // their accumulators are in that buffer
+                    ACC_T(t_bar, tb); }
+                    { [[maybe_unused]] const unsigned long long te = TICK();
+                    tile_epilogue(Tprev, gc - 1);                      // (beside the consumers' own half of it)
+                    ACC_T(t_epi, te); }
+                }
+                { [[maybe_unused]] const unsigned long long tb = TICK();
+                __syncthreads();                                      // barrier gc: pieces[gc & 1] ready; every producer wave is done with the dump
+                ACC_T(t_bar, tb); }
+#pragma unroll
+                for (int c = 0; c < CK; ++c)
+#pragma unroll
+                    for (int i = 0; i < EPT; ++i) R[c][i] = 0.0f;
+                { [[maybe_unused]] const unsigned long long tl = TICK();
+                load_next(R);
+                ACC_T(t_ld, tl); }
+            } else {
+                load_next(R);
+                if (gc == 0 && stamp_a >= 0) STAMP(1, 3);
+                __syncthreads();                                      // barrier gc: pieces[gc & 1] ready
+            }
+            if (gc == 0 && stamp_a >= 0) STAMP(1, 4);
+            if (gc == 1 && stamp_b >= 0) STAMP(1, 5);
+            advance();
+        };
         STAMP(1, 0);
         load_next(R0);
         load_next(R1);
         STAMP(1, 1);
         while (moreC) {
-            convert(R0);
-            if (gc == 0) STAMP(1, 2);
-            load_next(R0);
-            if (gc == 0) STAMP(1, 3);
-            __syncthreads();                                          // barrier gc: pieces[gc & 1] ready
-            if (gc == 0) STAMP(1, 4);
-            advance();
+            chunk_step(R0, 0, -1);
             if (!moreC) break;
-            convert(R1);
-            load_next(R1);
-            __syncthreads();
-            if (gc == 1) STAMP(1, 5);
-            advance();
+            chunk_step(R1, -1, 0);
+        }
+        if constexpr (PEPI != 0) {                                    // the last tile's accumulators
+            epi_prefetch(Tprev);
+            lds_barrier();
+            lds_barrier();
+            tile_epilogue(Tprev, gc - 1);
+#ifdef V2CE_STAMP
+            if (lane == 0 && wave == 4) {
+                unsigned long long *o = P.stamps + (long long)gridDim.x * 16 + ((long long)blockIdx.x * 2 + 1) * 8;
+                o[0] = TICK() - t_all; o[1] = t_bar; o[2] = t_epi; o[3] = t_cvt; o[4] = t_ld;
+            }
+#endif
         }
         STAMP(1, 6);
         return;
@@ -657,6 +925,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
     }
     int ring_co_t = -1;
     bool more = true;
+    [[maybe_unused]] unsigned long long tc_all = TICK(), tc_bar = 0, tc_dump = 0, tc_own = 0, tc_mma = 0;
     while (more) {
         const int co0 = T.co_t * CO_TILE + wco * CO_FR * 32;     // this wave's first channel
         const float x_scale = scale_of(T.b);
@@ -726,7 +995,10 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
                 for (int q = 0; q < CO_FR; ++q) { ah[0][q] = ah[1][q]; al[0][q] = al[1][q]; }
                 V2CE_LOAD_A(1, wn)
             }
+            { [[maybe_unused]] const unsigned long long tb = TICK();
             __syncthreads();                                   // barrier gc: pieces[gc & 1] ready
+            ACC_T(tc_bar, tb); }
+            [[maybe_unused]] const unsigned long long tm = TICK();
             if (gc == 0) STAMP(0, 1);
             if (gc == 1) STAMP(0, 2);
 #pragma unroll
@@ -778,6 +1050,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             });
+            ACC_T(tc_mma, tm);
         }
         float out_inv_scale = inv_scale;
         if constexpr (TAIL) {
@@ -870,6 +1143,37 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
             if (sink == 12345.678f && poff[0] >= 0) P.y[0] = sink;
         } else
 #endif
+        if constexpr (PEPI != 0) {
+            // the producers run the epilogue of this wave's fragments kKeepFr .. PO_FR - 1 (tile_epilogue) out of the buffer of the tile's
+            // last chunk, this wave the others', side by side
+            [[maybe_unused]] const unsigned long long td = TICK();
+            f32x4d rvK[kKeepFr][4];                             // the residual of this wave's own fragments, requested in front of the hand-over
+#pragma unroll
+            for (int f = 0; f < kKeepFr; ++f) epi_load_res(T, f, rvK[f]);
+            lds_barrier();                                      // every consumer wave is done with those pieces
+            f32x4d *dump = reinterpret_cast<f32x4d *>(pieces + ((gc - 1) & 1) * 4 * chs) + wave * kDumpWave;
+#pragma unroll
+            for (int f = kKeepFr; f < PO_FR; ++f)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4)
+                    dump[((f - kKeepFr) * 4 + r4) * 64 + lane] = f32x4d{acc[0][f][4 * r4], acc[0][f][4 * r4 + 1], acc[0][f][4 * r4 + 2], acc[0][f][4 * r4 + 3]};
+            lds_barrier();                                      // the producers may start
+            ACC_T(tc_dump, td);
+            {
+                [[maybe_unused]] const unsigned long long to = TICK();
+                unsigned ymax = 0u;
+                step_loop<0, kKeepFr>([&](auto fc) {
+                    constexpr int f = decltype(fc)::value;
+                    f32x4d a[4];
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) a[r4] = f32x4d{acc[0][f][4 * r4], acc[0][f][4 * r4 + 1], acc[0][f][4 * r4 + 2], acc[0][f][4 * r4 + 3]};
+                    epi_fragment(T, f, a, rvK[f], ymax, []() {});
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                if (P.y_absmax) absmax_commit(__builtin_bit_cast(float, ymax), P.y_absmax + T.b * P.amax_bs);
+                ACC_T(tc_own, to);
+            }
+        } else
         if constexpr (FUSE == 1 || FUSE == 4) {                 // 32-channel conv with the fused 1x1x1 head
             static_assert(KS == 3 && S == 1 && WCO == 1 && CO_FR == 1, "the fused head rides on a 32-channel tile");
             if constexpr (FUSE == 4 && RES == 1) {
@@ -909,6 +1213,14 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
         if (gc == CG) STAMP(0, 4);
         vb += (int)gridDim.x;
         more = next_tile(vb, T);
+    }
+    if constexpr (PEPI != 0) {
+#ifdef V2CE_STAMP
+        if (lane == 0 && wave == 0) {
+            unsigned long long *o = P.stamps + (long long)gridDim.x * 16 + (long long)blockIdx.x * 2 * 8;
+            o[0] = TICK() - tc_all; o[1] = tc_bar; o[2] = tc_dump; o[3] = tc_own; o[4] = tc_mma;
+        }
+#endif
     }
 #undef V2CE_LOAD_A
 #endif  // __HIP_DEVICE_COMPILE__
@@ -1229,13 +1541,14 @@ __global__ __launch_bounds__(256) void weights_absmax_kernel(const float *__rest
     if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned *>(tail), __float_as_uint(m));
 }
 
-template <int KS, int S, int WCO, int CO_FR, int PO_FR, int NA, int FUSE = 0, int RES = 2>
+template <int KS, int S, int WCO, int CO_FR, int PO_FR, int NA, int FUSE = 0, int RES = 2, int OPT = 0>
 int launch_f16x2_ws(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream) {
+    constexpr int PEPI = OPT & 1;
     static_assert(27 % NA == 0 && NA >= 2, "the A-fragment ring must divide the 27 taps");
     constexpr int CO_TILE = WCO * CO_FR * 32, POS_TILE = (4 / WCO) * PO_FR * 32;
-    constexpr int MAX_PLANE = 1280;         // 128 B of LDS per halo element; 5 elements per producer lane
+    constexpr int MAX_PLANE = PEPI ? 1216 : 1280;      // 128 B of LDS per halo element; 5 elements per producer lane (PEPI: + 4.4 KB of tables)
     if (g_name_out) {
-        snprintf(g_name_out, g_name_cap, "conv3d_f16x2_ws_kernel<%d,%d,%d,%d,%d,%d,%d,%d>", KS, S, WCO, CO_FR, PO_FR, NA, FUSE, RES);
+        snprintf(g_name_out, g_name_cap, "conv3d_f16x2_ws_kernel<%d,%d,%d,%d,%d,%d,%d,%d,%d>", KS, S, WCO, CO_FR, PO_FR, NA, FUSE, RES, OPT);
         return V2CE_OK;
     }
     Tile t{d.tile_t, d.tile_h, d.tile_w};
@@ -1272,14 +1585,18 @@ int launch_f16x2_ws(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream)
         chs = chs > P.tTCH * P.tNPP ? chs : P.tTCH * P.tNPP;
         P.tCHS = chs;
     }
-    const size_t lds = (size_t)chs * (2 * 4 * 16);
+    if (PEPI) {                             // a pieces buffer doubles as the accumulator dump of the four consumer waves (16 B x 64 lanes per register quad)
+        constexpr int dump = CO_FR * (PO_FR - V2CE_PEPI_KEEP) * 4 * 64;     // (kDumpWave of the kernel)
+        chs = chs > dump ? chs : dump;
+    }
+    const size_t lds = (size_t)chs * (2 * 4 * 16) + (PEPI ? 400 + 4096 : 0);       // (PEPI: + the producers' read counter and epilogue tables)
     V2CE_REQUIRE(lds <= 160 * 1024, V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd(f16x2 ws): %zu B of LDS", lds);
-    auto kern = conv3d_f16x2_ws_kernel<KS, S, WCO, CO_FR, PO_FR, NA, FUSE, RES>;
+    auto kern = conv3d_f16x2_ws_kernel<KS, S, WCO, CO_FR, PO_FR, NA, FUSE, RES, OPT>;
     V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 #ifdef V2CE_STAMP
-    V2CE_HIP_CHECK(hipMalloc(&P.stamps, (size_t)blocks * 16 * sizeof(unsigned long long)));
-    V2CE_HIP_CHECK(hipMemset(P.stamps, 0, (size_t)blocks * 16 * sizeof(unsigned long long)));
+    V2CE_HIP_CHECK(hipMalloc(&P.stamps, (size_t)blocks * 32 * sizeof(unsigned long long)));    // (PEPI: accumulators behind the first grid * 16)
+    V2CE_HIP_CHECK(hipMemset(P.stamps, 0, (size_t)blocks * 32 * sizeof(unsigned long long)));
 #endif
     // persistent: one workgroup per CU walks the virtual blocks (a multiple of 8 keeps tiles on their XCD)
     static const int n_cu = [] {
@@ -1296,7 +1613,7 @@ int launch_f16x2_ws(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream)
     V2CE_HIP_CHECK(hipGetLastError());
 #ifdef V2CE_STAMP
     {
-        std::vector<unsigned long long> h((size_t)blocks * 16);
+        std::vector<unsigned long long> h((size_t)blocks * 32);
         V2CE_HIP_CHECK(hipDeviceSynchronize());
         V2CE_HIP_CHECK(hipMemcpy(h.data(), P.stamps, h.size() * 8, hipMemcpyDeviceToHost));
         V2CE_HIP_CHECK(hipFree(P.stamps));
@@ -1314,6 +1631,25 @@ int launch_f16x2_ws(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream)
                 "producer: issue0 %lld, wait+convert0 %lld, issue1 %lld, bar0 wait %lld, chunk1 iter %lld, total %lld\n",
                 KS, S, WCO, CO_FR, PO_FR, NA, P.Cin / 16, P.plane, blocks, med(0, 0, 1), med(0, 1, 2), med(0, 2, 3), med(0, 3, 4), med(0, 0, 4),
                 med(1, 0, 1), med(1, 1, 2), med(1, 2, 3), med(1, 3, 4), med(1, 4, 5), med(1, 0, 6));
+        if (PEPI) {
+            const unsigned grid_ = (unsigned)(blocks > n_cu ? n_cu : blocks);
+            auto acc = [&](int role, int k) {
+                std::vector<long long> v;
+                for (unsigned b = 0; b < grid_; ++b) {
+                    const unsigned long long x = h[(size_t)grid_ * 16 + ((size_t)b * 2 + role) * 8 + k];
+                    if (h[(size_t)grid_ * 16 + ((size_t)b * 2 + role) * 8]) v.push_back((long long)x);
+                }
+                if (v.empty()) return -1ll;
+                std::sort(v.begin(), v.end());
+                return v[v.size() / 2];
+            };
+            const double tiles = (double)blocks / grid_;
+            fprintf(stderr, "    [pepi, s_memtime ticks per workgroup, %.1f tiles each] consumer: total %lld, chunk barriers %lld, hand-over barriers + dump %lld | "
+                    "producer: total %lld, barriers %lld, epilogues %lld, convert %lld, load issue %lld\n", tiles,
+                    acc(0, 0), acc(0, 1), acc(0, 2), acc(1, 0), acc(1, 1), acc(1, 2), acc(1, 3), acc(1, 4));
+            fprintf(stderr, "    [pepi] consumer: tap loops %lld, own half of the epilogues %lld\n", acc(0, 4), acc(0, 3));
+
+        }
     }
 #endif
     return V2CE_OK;
@@ -1526,6 +1862,10 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
             static const bool na9 = [] { const char *e = getenv("V2CE_NA9"); return !(e && e[0] == '0'); }();
             if (small_co && P.pred_w && tail)              // the fused head behind a conv with a folded tail (round 6)
                 return P.res ? launch_f16x2_ws<3, 1, 1, 1, 4, 9, 4, 1>(P, d, st) : launch_f16x2_ws<3, 1, 1, 1, 4, 9, 4, 0>(P, d, st);
+            // (round 6: its epilogue on the producer waves; V2CE_PEPI=0: the consumers' own)
+            static const bool pepi = [] { const char *e = getenv("V2CE_PEPI"); return !(e && e[0] == '0'); }();
+            if (small_co && P.pred_w && pepi)
+                return P.res ? launch_f16x2_ws<3, 1, 1, 1, 4, 3, 1, 1, 1>(P, d, st) : launch_f16x2_ws<3, 1, 1, 1, 4, 3, 1, 0, 1>(P, d, st);
             if (small_co && P.pred_w && na9) return V2CE_WS_RES(1, 3, 1, 1, 1, 4, 9, 1);
             if (small_co && P.pred_w) return V2CE_WS_RES(1, 3, 1, 1, 1, 4, 3, 1);
             if (small_co && P.sc_w) return launch_f16x2_ws<3, 1, 1, 1, 4, 3, 2, 0>(P, d, st);

@@ -95,10 +95,21 @@ constexpr unsigned kOOB = 0x80000000u;   // buffer voffset that is always out of
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 #ifdef V2CE_STAMP
+#define TICK() __builtin_amdgcn_s_memtime()
+#define ACC_T(var_, t0_) var_ += TICK() - (t0_)
+#else
+#define TICK() 0ull
+#define ACC_T(var_, t0_) do {} while (0)
+#endif
+#ifdef V2CE_STAMP
 #define STAMP(role_, k_) do { if (lane == 0 && (wave == 0 || wave == 4)) P.stamps[((long long)blockIdx.x * 2 + (role_)) * 8 + (k_)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STAMP(role_, k_) do {} while (0)
 #endif
+
+// workgroup barrier that waits only for this wave's LDS traffic (__syncthreads also drains the vector-memory counter: an
+// epilogue's stores would be waited for at every rendezvous)
+[[maybe_unused]] __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // wave-level max of m (>= 0), then one atomic max per wave on the float's bit pattern
 __device__ __forceinline__ void absmax_commit(float m, float *slot) {

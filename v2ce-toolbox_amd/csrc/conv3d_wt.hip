@@ -38,20 +38,6 @@ constexpr int kWtSlot = 256;             // element slots per transform slot in 
 constexpr int kWtChs = 4 * kWtSlot;      // pieces per quarter plane (hi ch 0-7 | hi ch 8-15 | lo 0-7 | lo 8-15)
 constexpr int kWtTaps = 36;              // 4 transform slots x 9 (dh, dw) taps
 
-#if defined(__HIP_DEVICE_COMPILE__)
-// workgroup barrier that waits only for this wave's LDS traffic (__syncthreads also drains the vector-memory counter: the
-// epilogue's stores of the previous round would be waited for at every rendezvous)
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-#endif
-
-#ifdef V2CE_STAMP
-#define TICK() __builtin_amdgcn_s_memtime()
-#define ACC_T(var_, t0_) var_ += TICK() - (t0_)
-#else
-#define TICK() 0ull
-#define ACC_T(var_, t0_) do {} while (0)
-#endif
-
 // TAIL: the block's folded 1x1x1 shortcut rides behind the 3x3x3 conv's chunks (v2ce_conv3d_fwd_tail's contract: P.tx0 (++ tx1) read at
 // the output positions, P.sc_w = the [Cout][tC0 + tC1][1] weights, P.tCG channel groups).  In the transform domain a term z(t) = Wd x(t)
 // of the OUTPUT splits over the slots as  m0 += WdA x(2p),  m3 -= WdA x(2p+1),  m1 += WdB (x(2p) + x(2p+1)) / 2,
