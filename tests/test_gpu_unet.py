@@ -525,6 +525,41 @@ def test_v2ce3d_split_half_matches_reference_three_calls(gold_dir):
         assert_close(got, want, "split-half golden")
 
 
+_SWITCH_SCRIPT = """
+import sys, numpy as np, torch
+sys.path.insert(0, '.')
+from v2ce_toolbox_amd import synth
+from v2ce_toolbox_amd.v2ce_3d import V2ce3d
+m = V2ce3d(); m.load_state_dict(synth.make_state_dict(0), strict=True); m = m.eval().to('cuda')
+x = torch.randn(1, 16, 2, 70, 90, generator=torch.Generator().manual_seed(5)).cuda()
+np.save(sys.argv[1], m(x).cpu().numpy())
+"""
+
+
+@pytest.mark.parametrize("switch", ["V2CE_PEPI=0", "V2CE_PEPI_SC=1"])
+def test_shared_epilogue_switches_agree(switch, tmp_path):
+    """Round 6: the conv with the fused head shares its epilogue between consumer and producer waves (default; V2CE_PEPI=0 = the
+    consumers' own), the strided convs with the fused shortcut can (V2CE_PEPI_SC=1, measured slower).  The switches are read
+    once per process, so each side runs in its own interpreter; the lean epilogue rounds differently (a pre-scale per position
+    instead of per wave, contracted multiply-adds): equal to f32 rounding."""
+    import subprocess
+    import sys
+    outs = []
+    for env_kv in (None, switch):
+        env = dict(os.environ)
+        env.pop("V2CE_PEPI", None)
+        env.pop("V2CE_PEPI_SC", None)
+        if env_kv:
+            k, v = env_kv.split("=")
+            env[k] = v
+        f = str(tmp_path / f"out_{len(outs)}.npy")
+        subprocess.run([sys.executable, "-c", _SWITCH_SCRIPT, f], check=True, env=env, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        outs.append(np.load(f))
+    assert outs[0].shape == (1, 16, 20, 70, 90)
+    assert_close(outs[0], outs[1], switch, 2e-6)
+
+
 def test_fused_head_matches_unfused():
     """Default path: `pred` fused into the last decoder conv (v2ce_conv3d_fwd_pred).  Asking for the
     intermediates runs the layers separately; both must agree to f32 rounding."""

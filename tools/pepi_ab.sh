@@ -13,5 +13,5 @@ for mode in ${MODES:-1 0 1 0}; do
   grep "^{" $OUT/e2e_$mode.log | python3 -c "
 import sys,json; j=json.loads(sys.stdin.readline()); print('$VAR=$mode', 'ms/step', round(j['ms_per_step'],4), 'value', round(j['value'],1))
 for k,v in j['kernels'].items():
-    if ',9,1,' in k or ',3,1,' in k or ',9,2,' in k or 'up_kernel<1,1,4' in k: print('    %.3f ms x%d  %s' % (v['avg_ms'], v['launches'], k))"
+    if ',9,1,' in k or ',3,1,' in k or 'ws_kernel<3,2,' in k or 'up_kernel<1,1,4' in k: print('    %.3f ms x%d  %s' % (v['avg_ms'], v['launches'], k))"
 done

@@ -374,18 +374,30 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
     // KS = 1: the "halo box" is the output box itself (positions gathered with stride S), one tap
     constexpr int K3 = KS * KS * KS, CK = 16, EPT = 5, PAD = KS / 2, GS = KS == 1 ? S : 1;
     constexpr int CO_TILE = WCO * CO_FR * 32;
-    static_assert(!PEPI || (FUSE == 1 && CO_FR == 1), "producer-side epilogue: the 32-channel tile with the fused head");
+    static_assert(!PEPI || ((FUSE == 1 || FUSE == 2) && CO_FR == 1),
+                  "shared epilogue: one 32-channel fragment row per wave, with the fused head or the fused shortcut");
     // PEPI: the consumers keep the first kKeepFr position fragments of a wave for their own epilogue and hand the others over -- the
     // two epilogues run side by side between the tile's last chunk and the next tile's first
-    constexpr int kKeepFr = PEPI ? V2CE_PEPI_KEEP : PO_FR, kDumpFr = PO_FR - kKeepFr;
-    constexpr int kDumpWave = CO_FR * kDumpFr * 4 * 64;      // f32x4 per consumer wave in the accumulator dump (PEPI)
+    constexpr int kKeepFr = PEPI ? (FUSE == 1 ? V2CE_PEPI_KEEP : PO_FR / 2) : PO_FR, kDumpFr = PO_FR - kKeepFr;
+    constexpr int kDumpSets = FUSE == 2 ? 2 : 1;             // (the fused shortcut's second accumulator set travels too)
+    constexpr int kDumpWave = kDumpFr * kDumpSets * 4 * 64;  // f32x4 per consumer wave in the accumulator dump (PEPI)
     int chs_ = (FUSE == 3 || FUSE == 4) ? P.tCHS : (P.plane + 63) & ~63;
     if (PEPI && chs_ < kDumpWave) chs_ = kDumpWave;          // a pieces buffer (4 chs x 16 B) holds the four waves' dumps
     const int chs = chs_;
     f16x8 *pieces = reinterpret_cast<f16x8 *>(conv_smem);                      // [2][4][chs] x 16 B
     [[maybe_unused]] unsigned *pepi_flag = reinterpret_cast<unsigned *>(conv_smem + (size_t)chs * 128);   // PEPI: producer waves done reading a dump
     if constexpr (PEPI != 0) {                               // (all of it visible behind the first chunk barrier, long before its first use)
-        // LDS behind the pieces: counter (16 B) | scale[32] shift[32] of the conv, bias[32] of the head | the head's A fragments (4 KB)
+        // LDS behind the pieces, 16 B in: scale[32] shift[32] of the conv, bias[32] of the head | the head's A fragments (4 KB)
+        // -- or (fused shortcut) scale[Cout] | shift[Cout] | sc_scale[Cout] | sc_shift[Cout]
+        if constexpr (FUSE == 2) {
+            float *tab = reinterpret_cast<float *>(pepi_flag + 4);
+            for (int i = threadIdx.x; i < P.Cout; i += 512) {
+                tab[i] = P.scale[i];
+                tab[P.Cout + i] = P.shift[i];
+                tab[2 * P.Cout + i] = P.sc_scale[i];
+                tab[3 * P.Cout + i] = P.sc_shift[i];
+            }
+        } else {
         if (threadIdx.x < 32) {
             float *tab = reinterpret_cast<float *>(pepi_flag + 4);
             tab[threadIdx.x] = P.scale[threadIdx.x];
@@ -393,6 +405,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
             tab[64 + threadIdx.x] = P.pred_b[threadIdx.x];
         }
         if (threadIdx.x < 256) reinterpret_cast<f16x8 *>(pepi_flag + 100)[threadIdx.x] = reinterpret_cast<const f16x8 *>(P.pred_w)[threadIdx.x];
+        }
     }
 
     const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
@@ -501,7 +514,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
     if constexpr (PEPI != 0) {
 #pragma unroll
         for (int f = 0; f < PO_FR; ++f) {
-            const int m = ((wave & 3) * PO_FR + f) * 32 + l32;
+            const int m = (((wave & 3) / WCO) * PO_FR + f) * 32 + l32;
             epk[f] = -1;
             if (m < P.n_pos) {
                 const int tt = m / (P.TH * P.TW);
@@ -543,7 +556,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
     // before the fragment's stores (the place to request the next residual)
     [[maybe_unused]] auto epi_fragment = [&](const TileId &E, int f, const f32x4d (&a)[4], const f32x4d (&rv)[4], unsigned &ymax,
                                              auto &&between) __attribute__((always_inline)) {
-        if constexpr (PEPI != 0) {
+        if constexpr (PEPI != 0 && FUSE == 1) {
             typedef unsigned u32x4d __attribute__((ext_vector_type(4)));
             const float inv = 1.0f / (scale_of(E.b) * w_scale);
             const float *tab = reinterpret_cast<const float *>(pepi_flag + 4);                      // scale[32] | shift[32] | bias[32]
@@ -644,6 +657,55 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
                     y = fmaxf(y, 0.0f) + 0.0f;
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), rs_p, ook ? vp : kOOB, oq * pstride4, 0);
                 }
+            }
+        }
+    };
+
+    // the same for the conv with the fused shortcut (FUSE 2): y = act(scale a + shift), sc_y = sc_scale ad + sc_shift, both in the
+    // channels-last-16 layout (one 16-byte store per register quad and output)
+    [[maybe_unused]] auto epi_fragment_sc = [&](const TileId &E, int f, const f32x4d (&a)[4], const f32x4d (&ad)[4], unsigned &ymax) __attribute__((always_inline)) {
+        if constexpr (PEPI != 0 && FUSE == 2) {
+            typedef unsigned u32x4d __attribute__((ext_vector_type(4)));
+            const int co0 = E.co_t * CO_TILE + ((wave & 3) % WCO) * 32;
+            const long long wpl_d = (long long)CG * P.Cout * 16;
+            const float xs = scale_of(E.b);
+            const float inv = 1.0f / (xs * w_scale), invd = 1.0f / (xs * reinterpret_cast<const float *>(P.sc_w + 2 * wpl_d)[1]);
+            const float *tab = reinterpret_cast<const float *>(pepi_flag + 4);
+            const long long seq = (long long)P.T * P.Cout * (P.Hout * P.Woutp);
+            const int gstride = P.Hout * P.Woutp * 64;            // bytes between 16-channel groups of a time step
+            const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(P.y + E.b * seq, 0, (int)(seq * 4), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(P.sc_y + E.b * seq, 0, (int)(seq * 4), 0x00020000);
+            const float slope = act_slope(P.act);
+            unsigned vo, vp;
+            epi_offsets(E, f, vo, vp);
+            const unsigned vmask = vo != kOOB ? 0x7fffffffu : 0u;
+            f32x4d scq[4], shq[4], dq[4], dsh[4];                 // one LDS round trip
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int cb = co0 + 8 * r4 + 4 * half;
+                scq[r4] = *reinterpret_cast<const f32x4d *>(tab + cb);
+                shq[r4] = *reinterpret_cast<const f32x4d *>(tab + P.Cout + cb);
+                dq[r4] = *reinterpret_cast<const f32x4d *>(tab + 2 * P.Cout + cb);
+                dsh[r4] = *reinterpret_cast<const f32x4d *>(tab + 3 * P.Cout + cb);
+            }
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const bool cok = co0 + 8 * r4 < P.Cout;            // uniform (Cout need not fill the last channel tile)
+                const int so = (co0 / 16 + (r4 >> 1)) * gstride + 32 * (r4 & 1);
+                f32x4d y4, d4;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float t = a[r4][k] * (scq[r4][k] * inv) + shq[r4][k];
+                    t = apply_act(t, slope);
+                    y4[k] = t;
+                    const unsigned av = __builtin_bit_cast(unsigned, t) & (cok ? vmask : 0u);
+                    ymax = av > ymax ? av : ymax;
+                    d4[k] = ad[r4][k] * (dq[r4][k] * invd) + dsh[r4][k];
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4d, y4), rs_y, cok ? vo : kOOB, so, 0);
+                asm volatile("s_nop 1" : "+v"(y4));            // (16-byte store data hazard: conv_epilogue)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4d, d4), rs_s, cok ? vo : kOOB, so, 0);
+                asm volatile("s_nop 1" : "+v"(d4));
             }
         }
     };
@@ -817,10 +879,17 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
                     constexpr int f = decltype(fc)::value;   // the wave's fragment; its accumulators are fragment f - kKeepFr of the dump
                     f32x4d a[4];
 #pragma unroll
-                    for (int r4 = 0; r4 < 4; ++r4) a[r4] = dump[((f - kKeepFr) * 4 + r4) * 64 + lane];
-                    epi_fragment(E, f, a, epi_rv, ymax, [&]() __attribute__((always_inline)) {
-                        if constexpr (f + 1 < PO_FR) epi_load_res(E, f + 1, epi_rv);
-                    });
+                    for (int r4 = 0; r4 < 4; ++r4) a[r4] = dump[(((f - kKeepFr) * kDumpSets) * 4 + r4) * 64 + lane];
+                    if constexpr (FUSE == 2) {
+                        f32x4d ad[4];
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4) ad[r4] = dump[(((f - kKeepFr) * kDumpSets + 1) * 4 + r4) * 64 + lane];
+                        epi_fragment_sc(E, f, a, ad, ymax);
+                    } else {
+                        epi_fragment(E, f, a, epi_rv, ymax, [&]() __attribute__((always_inline)) {
+                            if constexpr (f + 1 < PO_FR) epi_load_res(E, f + 1, epi_rv);
+                        });
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 });
                 if (P.y_absmax) absmax_commit(__builtin_bit_cast(float, ymax), P.y_absmax + E.b * P.amax_bs);
@@ -1155,8 +1224,11 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
 #pragma unroll
             for (int f = kKeepFr; f < PO_FR; ++f)
 #pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4)
-                    dump[((f - kKeepFr) * 4 + r4) * 64 + lane] = f32x4d{acc[0][f][4 * r4], acc[0][f][4 * r4 + 1], acc[0][f][4 * r4 + 2], acc[0][f][4 * r4 + 3]};
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    dump[(((f - kKeepFr) * kDumpSets) * 4 + r4) * 64 + lane] = f32x4d{acc[0][f][4 * r4], acc[0][f][4 * r4 + 1], acc[0][f][4 * r4 + 2], acc[0][f][4 * r4 + 3]};
+                    if constexpr (SC)
+                        dump[(((f - kKeepFr) * kDumpSets + 1) * 4 + r4) * 64 + lane] = f32x4d{accd[0][f][4 * r4], accd[0][f][4 * r4 + 1], accd[0][f][4 * r4 + 2], accd[0][f][4 * r4 + 3]};
+                }
             lds_barrier();                                      // the producers may start
             ACC_T(tc_dump, td);
             {
@@ -1167,6 +1239,12 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
                     f32x4d a[4];
 #pragma unroll
                     for (int r4 = 0; r4 < 4; ++r4) a[r4] = f32x4d{acc[0][f][4 * r4], acc[0][f][4 * r4 + 1], acc[0][f][4 * r4 + 2], acc[0][f][4 * r4 + 3]};
+                    if constexpr (SC) {
+                        f32x4d ad[4];
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4) ad[r4] = f32x4d{accd[0][f][4 * r4], accd[0][f][4 * r4 + 1], accd[0][f][4 * r4 + 2], accd[0][f][4 * r4 + 3]};
+                        epi_fragment_sc(T, f, a, ad, ymax);
+                    } else
                     epi_fragment(T, f, a, rvK[f], ymax, []() {});
                     __builtin_amdgcn_sched_barrier(0);
                 });
@@ -1203,7 +1281,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
 #ifdef V2CE_ABLATE_EPI
         if (P.ablate != 1)
 #endif
-        if constexpr (SC) {                                     // shortcut: bn_d(conv_d x), no activation, no residual
+        if constexpr (SC && PEPI == 0) {                        // shortcut: bn_d(conv_d x), no activation, no residual
             ConvParams Q = P;
             Q.scale = P.sc_scale; Q.shift = P.sc_shift; Q.res = nullptr; Q.y = P.sc_y; Q.act = V2CE_ACT_NONE;
             Q.y_absmax = nullptr;
@@ -1546,7 +1624,7 @@ int launch_f16x2_ws(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream)
     constexpr int PEPI = OPT & 1;
     static_assert(27 % NA == 0 && NA >= 2, "the A-fragment ring must divide the 27 taps");
     constexpr int CO_TILE = WCO * CO_FR * 32, POS_TILE = (4 / WCO) * PO_FR * 32;
-    constexpr int MAX_PLANE = PEPI ? 1216 : 1280;      // 128 B of LDS per halo element; 5 elements per producer lane (PEPI: + 4.4 KB of tables)
+    constexpr int MAX_PLANE = PEPI ? 1152 : 1280;      // 128 B of LDS per halo element; 5 elements per producer lane (PEPI: + up to 8.2 KB of tables)
     if (g_name_out) {
         snprintf(g_name_out, g_name_cap, "conv3d_f16x2_ws_kernel<%d,%d,%d,%d,%d,%d,%d,%d,%d>", KS, S, WCO, CO_FR, PO_FR, NA, FUSE, RES, OPT);
         return V2CE_OK;
@@ -1586,10 +1664,12 @@ int launch_f16x2_ws(ConvParams P, const v2ce_conv3d_desc &d, hipStream_t stream)
         P.tCHS = chs;
     }
     if (PEPI) {                             // a pieces buffer doubles as the accumulator dump of the four consumer waves (16 B x 64 lanes per register quad)
-        constexpr int dump = CO_FR * (PO_FR - V2CE_PEPI_KEEP) * 4 * 64;     // (kDumpWave of the kernel)
+        constexpr int keep = FUSE == 1 ? V2CE_PEPI_KEEP : PO_FR / 2;
+        constexpr int dump = (PO_FR - keep) * (FUSE == 2 ? 2 : 1) * 4 * 64;     // (kDumpWave of the kernel)
         chs = chs > dump ? chs : dump;
+        V2CE_REQUIRE(FUSE == 1 || d.Cout <= 512, V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd(f16x2 ws, shared epilogue): more than 512 output channels");
     }
-    const size_t lds = (size_t)chs * (2 * 4 * 16) + (PEPI ? 400 + 4096 : 0);       // (PEPI: + the producers' read counter and epilogue tables)
+    const size_t lds = (size_t)chs * (2 * 4 * 16) + (PEPI ? (FUSE == 1 ? 400 + 4096 : 16 + 16 * (size_t)d.Cout) : 0);   // (PEPI: + the epilogue's tables)
     V2CE_REQUIRE(lds <= 160 * 1024, V2CE_ERR_UNSUPPORTED, "v2ce_conv3d_fwd(f16x2 ws): %zu B of LDS", lds);
     auto kern = conv3d_f16x2_ws_kernel<KS, S, WCO, CO_FR, PO_FR, NA, FUSE, RES, OPT>;
     V2CE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -1909,6 +1989,11 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
         if (P.sc_w) {
             static const bool na9 = [] { const char *e = getenv("V2CE_NA9"); return !(e && e[0] == '0'); }();
             // (128-channel tiles: both accumulator sets of four fragments and a nine-slot ring do not fit -- 173 spilled registers)
+            // (round 6: the epilogue shared with the producer waves as on the conv with the fused head -- measured SLOWER here, opt-in
+            // with V2CE_PEPI_SC=1: the three 128-channel launches 0.495 -> 0.503 ms, enc0.conv1 0.670 -> 0.713)
+            static const bool pepi_sc = [] { const char *e = getenv("V2CE_PEPI_SC"); return e && e[0] == '1'; }();
+            if (pepi_sc && d.Cout >= 128 && d.Cout <= 512 && !P.res) return launch_f16x2_ws<3, 2, 4, 1, 4, 3, 2, 0, 1>(P, d, st);
+            if (pepi_sc && !small_co && d.Cout < 128 && na9 && !P.res) return launch_f16x2_ws<3, 2, 2, 1, 2, 9, 2, 0, 1>(P, d, st);
             if (d.Cout >= 128) return launch_f16x2_ws<3, 2, 4, 1, 4, 3, 2, 0>(P, d, st);
             if (!small_co && na9) return launch_f16x2_ws<3, 2, 2, 1, 2, 9, 2, 0>(P, d, st);
             if (!small_co) return launch_f16x2_ws<3, 2, 2, 1, 2, 3, 2, 0>(P, d, st);
