@@ -104,6 +104,19 @@ def test_pipelined_run_equals_serial_composition(infer_type, wf):
     assert got.tobytes() == want.tobytes()
 
 
+def test_ldati_stream_equals_main_stream(monkeypatch):
+    """Round 6: stage 2 runs on its own stream beside the next batch's convolutions (pipeline.run_clip; V2CE_LDATI_STREAM=0 puts
+    it back behind the model on the main stream).  Same bytes either way, over enough batches for the streams to overlap."""
+    from v2ce_toolbox_amd import v2ce as cli
+    frames = synth.synthetic_frames(200, 64, 96, seed=4)
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("V2CE_LDATI_STREAM", flag)
+        outs.append(cli.run(frames, load_model(), infer_type="center", width=96, height=64, batch_size=2, fps=30, seed=3))
+    assert len(outs[0]) == len(outs[1]) > 10000
+    assert outs[0].tobytes() == outs[1].tobytes()
+
+
 def test_explicit_device_index(tmp_path):
     """--device cuda:0 spelled out (the C ABI launches on the current device's streams)."""
     out = tmp_path / "o"

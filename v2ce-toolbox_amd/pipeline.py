@@ -32,6 +32,7 @@ Multi-GPU (one process per GPU, ``torch.distributed``; ``dist.py``):
 from __future__ import annotations
 
 import collections
+import contextlib
 import os
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Sequence
@@ -435,7 +436,31 @@ def run_clip(frames: np.ndarray, model, *, infer_type="center", seq_len=16, widt
     if gather not in ("host", "device"):
         raise ValueError(f"gather must be 'host' or 'device', got {gather!r}")
     plans = plan_batches(len(frames), seq_len, batch_size)
-    begin, finish = stage2 or default_stage2(fps, seed, len(frames) - 1, device)
+    begin0, finish0 = stage2 or default_stage2(fps, seed, len(frames) - 1, device)
+    # Stage 2 runs on its OWN stream beside the next batch's convolutions (round 6).  The conv kernels are persistent -- one workgroup per
+    # CU, which its LDS and registers fill -- so LDATI's short workgroups run where a conv launch has no tile left for a CU: its
+    # 0.4 ms per batch disappear in the tails of the thirty launches of a forward call (16.38 -> 16.03 ms per 64 frame-pairs).
+    # V2CE_LDATI_STREAM=0: behind the model on the main stream, as before.
+    ldati_stream = None
+    if torch.device(device).type == "cuda" and os.environ.get("V2CE_LDATI_STREAM", "1") != "0":
+        ldati_stream = torch.cuda.Stream(device=device, priority=int(os.environ.get("V2CE_LDATI_STREAM_PRIORITY", "-1")))
+
+    def begin(vox, first_pair):
+        if ldati_stream is None:
+            return begin0(vox, first_pair)
+        ready = torch.cuda.Event()
+        ready.record()                                       # the model's output (and anything else the main stream did to vox)
+        with torch.cuda.stream(ldati_stream):
+            ldati_stream.wait_event(ready)
+            handle = begin0(vox, first_pair)
+        vox.record_stream(ldati_stream)                     # (the caching allocator must not hand vox out again before stage 2 is done)
+        return handle
+
+    def finish(handle):
+        if ldati_stream is None:
+            return finish0(handle)
+        with torch.cuda.stream(ldati_stream):
+            return finish0(handle)
     fw = resized_width(frames, height)
     tiles = pano_tiles(fw, width) if infer_type == "pano" else None
     calls_per_batch = len(tiles) if tiles else 1
@@ -542,16 +567,23 @@ def run_clip(frames: np.ndarray, model, *, infer_type="center", seq_len=16, widt
         t_f = tick("flush.finish", t_f)
         st = getattr(keep, "_status", None)
         if st is not None:                                  # 4 bytes folded on the stream; the event object is not retained
-            if status["acc"] is None:
-                status["acc"] = torch.zeros_like(st)
-            torch.maximum(status["acc"], st, out=status["acc"])
+            with torch.cuda.stream(ldati_stream) if ldati_stream is not None else contextlib.nullcontext():
+                if status["acc"] is None:
+                    status["acc"] = torch.zeros_like(st)
+                torch.maximum(status["acc"], st, out=status["acc"])
             status["msg"] = getattr(keep, "_status_message", None) or status["msg"]
+        if ldati_stream is not None and multi and handle is not None:
+            # the exchanges read the records on the main stream: behind stage 2 (which ran beside the model call enqueued since)
+            emitted = torch.cuda.Event()
+            emitted.record(ldati_stream)
+            torch.cuda.current_stream(device).wait_event(emitted)
+            packed.record_stream(torch.cuda.current_stream(device))
         if host_direct:
             exchange.submit(packed, failed=failure["exc"] is not None, keep=keep)
         elif multi:
             exchange.submit(packed, failed=failure["exc"] is not None)
         else:
-            sink.push(packed, n_pairs, keep)
+            sink.push(packed, n_pairs, keep, src_stream=ldati_stream if handle is not None else None)
         tick("flush.push", t_f)
 
     def next_nonempty(i):
@@ -633,6 +665,8 @@ def run_clip(frames: np.ndarray, model, *, infer_type="center", seq_len=16, widt
             exchange.drain()
         # the LDATI status words of all ranks, before anything is finalised (a rank with a bad segment must not leave rank 0
         # closing a valid-looking file)
+        if ldati_stream is not None:
+            ldati_stream.synchronize()
         st_local = float(int(status["acc"].item())) if status["acc"] is not None else 0.0
         st_all = comm.max_float(st_local, device=device) if multi else st_local
         if st_all != 0.0:
