@@ -554,11 +554,12 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
     };
     // a = the fragment's sixteen accumulators as four register quads, rv = its residual; `between` runs after the last use of rv and
     // before the fragment's stores (the place to request the next residual)
+    // inv = 1 / (the tile's activation pre-scale x the weights' pre-scale), pw_scale = the head weights' pre-scale: fetched once per
+    // tile by the caller (scalar loads whose round trip would otherwise open every fragment)
     [[maybe_unused]] auto epi_fragment = [&](const TileId &E, int f, const f32x4d (&a)[4], const f32x4d (&rv)[4], unsigned &ymax,
-                                             auto &&between) __attribute__((always_inline)) {
+                                             float inv, float pw_scale, auto &&between) __attribute__((always_inline)) {
         if constexpr (PEPI != 0 && FUSE == 1) {
             typedef unsigned u32x4d __attribute__((ext_vector_type(4)));
-            const float inv = 1.0f / (scale_of(E.b) * w_scale);
             const float *tab = reinterpret_cast<const float *>(pepi_flag + 4);                      // scale[32] | shift[32] | bias[32]
             const f16x8 *atab = reinterpret_cast<const f16x8 *>(pepi_flag + 100);                   // the head's A fragments (4 KB)
             const long long seq = (long long)P.T * P.Cout * (P.Hout * P.Woutp);
@@ -568,7 +569,6 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
             const long long pseq = (long long)P.T * P.pred_cout * (P.Hout * P.Wout);
             const int pstride4 = P.Hout * P.Wout * 4;
             const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(P.pred_y + E.b * pseq, 0, (int)(pseq * 4), 0x00020000);
-            const float pw_scale = reinterpret_cast<const float *>(P.pred_w + 2048)[0];
             const float slope = act_slope(P.act);
             unsigned vo, vp;
             epi_offsets(E, f, vo, vp);
@@ -875,6 +875,11 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
             if constexpr (PEPI != 0) {
                 const f32x4d *dump = reinterpret_cast<const f32x4d *>(pieces + (g_last & 1) * 4 * chs) + (wave - 4) * kDumpWave;
                 unsigned ymax = 0u;
+                [[maybe_unused]] float inv = 1.0f, pw_scale = 1.0f;
+                if constexpr (FUSE == 1) {
+                    inv = 1.0f / (scale_of(E.b) * w_scale);
+                    pw_scale = reinterpret_cast<const float *>(P.pred_w + 2048)[0];
+                }
                 step_loop<kKeepFr, PO_FR>([&](auto fc) {
                     constexpr int f = decltype(fc)::value;   // the wave's fragment; its accumulators are fragment f - kKeepFr of the dump
                     f32x4d a[4];
@@ -886,7 +891,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
                         for (int r4 = 0; r4 < 4; ++r4) ad[r4] = dump[(((f - kKeepFr) * kDumpSets + 1) * 4 + r4) * 64 + lane];
                         epi_fragment_sc(E, f, a, ad, ymax);
                     } else {
-                        epi_fragment(E, f, a, epi_rv, ymax, [&]() __attribute__((always_inline)) {
+                        epi_fragment(E, f, a, epi_rv, ymax, inv, pw_scale, [&]() __attribute__((always_inline)) {
                             if constexpr (f + 1 < PO_FR) epi_load_res(E, f + 1, epi_rv);
                         });
                     }
@@ -1216,6 +1221,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
             // the producers run the epilogue of this wave's fragments kKeepFr .. PO_FR - 1 (tile_epilogue) out of the buffer of the tile's
             // last chunk, this wave the others', side by side
             [[maybe_unused]] const unsigned long long td = TICK();
+            [[maybe_unused]] float pw_scale_c = 1.0f;
+            if constexpr (FUSE == 1) pw_scale_c = reinterpret_cast<const float *>(P.pred_w + 2048)[0];
             f32x4d rvK[kKeepFr][4];                             // the residual of this wave's own fragments, requested in front of the hand-over
 #pragma unroll
             for (int f = 0; f < kKeepFr; ++f) epi_load_res(T, f, rvK[f]);
@@ -1245,7 +1252,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
                         for (int r4 = 0; r4 < 4; ++r4) ad[r4] = f32x4d{accd[0][f][4 * r4], accd[0][f][4 * r4 + 1], accd[0][f][4 * r4 + 2], accd[0][f][4 * r4 + 3]};
                         epi_fragment_sc(T, f, a, ad, ymax);
                     } else
-                    epi_fragment(T, f, a, rvK[f], ymax, []() {});
+                    epi_fragment(T, f, a, rvK[f], ymax, out_inv_scale, pw_scale_c, []() {});
                     __builtin_amdgcn_sched_barrier(0);
                 });
                 if (P.y_absmax) absmax_commit(__builtin_bit_cast(float, ymax), P.y_absmax + T.b * P.amax_bs);
