@@ -536,10 +536,11 @@ np.save(sys.argv[1], m(x).cpu().numpy())
 """
 
 
-@pytest.mark.parametrize("switch", ["V2CE_PEPI=0", "V2CE_PEPI_SC=1"])
+@pytest.mark.parametrize("switch", ["V2CE_PEPI=0", "V2CE_PEPI_SC=1", "V2CE_G4=1"])
 def test_shared_epilogue_switches_agree(switch, tmp_path):
     """Round 6: the conv with the fused head shares its epilogue between consumer and producer waves (default; V2CE_PEPI=0 = the
-    consumers' own), the strided convs with the fused shortcut can (V2CE_PEPI_SC=1, measured slower).  The switches are read
+    consumers' own), the strided convs with the fused shortcut can (V2CE_PEPI_SC=1, measured slower); V2CE_G4=1 = four lanes per
+    element in the producers' gather (measured no faster).  The switches are read
     once per process, so each side runs in its own interpreter; the lean epilogue rounds differently (a pre-scale per position
     instead of per wave, contracted multiply-adds): equal to f32 rounding."""
     import subprocess
@@ -549,6 +550,7 @@ def test_shared_epilogue_switches_agree(switch, tmp_path):
         env = dict(os.environ)
         env.pop("V2CE_PEPI", None)
         env.pop("V2CE_PEPI_SC", None)
+        env.pop("V2CE_G4", None)
         if env_kv:
             k, v = env_kv.split("=")
             env[k] = v

@@ -371,6 +371,12 @@ template <int KS, int S, int WCO, int CO_FR, int PO_FR, int NA, int FUSE = 0, in
 __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int PEPI = OPT & 1;                              // (OPT: a bit set; bit 0 = the producer-side epilogue)
+    // bit 1, "G4": the producers gather with FOUR LANES PER ELEMENT -- load instruction k of a quad of lanes fetches the four 16-byte
+    // quarters of the element lane k of the quad owns (its offset arrives by a quad broadcast), so an instruction touches 16 whole
+    // 64-byte lines instead of a quarter of each of 64: the texture path the consumers' weight loads share is what the gather
+    // occupies.  A lane then holds four channels of four elements instead of sixteen of one: 8-byte pieces.
+    constexpr bool G4 = (OPT & 2) != 0;
+    static_assert(!G4 || (KS == 3 && FUSE != 3 && FUSE != 4), "four-lane gather: plain 3x3x3 chunks (no folded tail)");
     // KS = 1: the "halo box" is the output box itself (positions gathered with stride S), one tap
     constexpr int K3 = KS * KS * KS, CK = 16, EPT = 5, PAD = KS / 2, GS = KS == 1 ? S : 1;
     constexpr int CO_TILE = WCO * CO_FR * 32;
@@ -783,6 +789,16 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
                     // the chunk is one 16-channel group: the element's 64 bytes in four 16-byte loads (one cache
                     // line per element; the planar layout needs 16 loads from 16 lines)
                     typedef float f32x4g __attribute__((ext_vector_type(4)));
+                    if constexpr (G4) {
+                        // R[4 k + c][i] = channel 4 (lane & 3) + c of the element that lane k of this lane's quad owns
+                        const int so = ((ci0 - src_cbase) / 16) * (src_cstride4 * 16);
+                        step_loop<0, 4>([&](auto kc) {
+                            constexpr int k = decltype(kc)::value;
+                            const unsigned vk = (unsigned)__builtin_amdgcn_mov_dpp((int)vo, k | (k << 2) | (k << 4) | (k << 6), 0xf, 0xf, true);
+                            const f32x4g v = __builtin_bit_cast(f32x4g, __builtin_amdgcn_raw_buffer_load_b128(rs_in, vk + 16u * (unsigned)(ptid & 3), so, 0));
+                            R[4 * k][i] = v[0]; R[4 * k + 1][i] = v[1]; R[4 * k + 2][i] = v[2]; R[4 * k + 3][i] = v[3];
+                        });
+                    } else
 #pragma unroll
                     for (int k4 = 0; k4 < CK / 4; ++k4) {
                         const f32x4g v = __builtin_bit_cast(f32x4g, __builtin_amdgcn_raw_buffer_load_b128(
@@ -823,6 +839,33 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
                 if (i >= ne_abl) continue;
 #endif
                 const int r = rb + 256 * i;
+                if constexpr (G4) {
+                    if ((wave - 4) * 64 + 256 * i < lim) {            // wave-uniform
+                        // this lane's four channels 4 j .. 4 j + 3 (j = lane & 3) of the quad's four elements: 8 bytes of the hi piece and
+                        // 8 of the lo piece of 8-channel group j >> 1, second half of the piece for odd j
+                        typedef unsigned u32x2c __attribute__((ext_vector_type(2)));
+                        const int j = rb & 3;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            u32x2c ph, pl;
+#pragma unroll
+                            for (int c2 = 0; c2 < 2; ++c2) {
+                                const float xa = R[4 * k + 2 * c2][i], xb = R[4 * k + 2 * c2 + 1][i];
+                                unsigned h, l;
+                                asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
+                                    "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
+                                    "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
+                                    "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                                    : "=&v"(h), "=&v"(l) : "v"(xa), "v"(xb), "v"(c_scale));
+                                ph[c2] = h;
+                                pl[c2] = l;
+                            }
+                            const int rk = (r & ~3) + k;
+                            reinterpret_cast<u32x2c *>(qb + (j >> 1) * chs + rk)[j & 1] = ph;
+                            reinterpret_cast<u32x2c *>(qb + (2 + (j >> 1)) * chs + rk)[j & 1] = pl;
+                        }
+                    }
+                } else
                 if ((wave - 4) * 64 + 256 * i < lim) {                // wave-uniform (lanes past the box write padding)
 #pragma unroll
                     for (int hg = 0; hg < 2; ++hg) {
@@ -1952,6 +1995,9 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
             // (round 6: its epilogue on the producer waves; V2CE_PEPI=0: the consumers' own)
             static const bool pepi = [] { const char *e = getenv("V2CE_PEPI"); return !(e && e[0] == '0'); }();
             // (nine ring slots: the consumers' path has the registers -- the 229 of the kernel are the producers' -- 0.94 -> 0.91 ms)
+            static const bool g4s = [] { const char *e = getenv("V2CE_G4"); return e && e[0] == '1'; }();
+            if (small_co && P.pred_w && pepi && na9 && g4s)
+                return P.res ? launch_f16x2_ws<3, 1, 1, 1, 4, 9, 1, 1, 3>(P, d, st) : launch_f16x2_ws<3, 1, 1, 1, 4, 9, 1, 0, 3>(P, d, st);
             if (small_co && P.pred_w && pepi && na9)
                 return P.res ? launch_f16x2_ws<3, 1, 1, 1, 4, 9, 1, 1, 1>(P, d, st) : launch_f16x2_ws<3, 1, 1, 1, 4, 9, 1, 0, 1>(P, d, st);
             if (small_co && P.pred_w && pepi)
@@ -2002,6 +2048,11 @@ static int conv3d_dispatch(const v2ce_conv3d_desc *desc, const float *x0, const 
             // (round 6: the epilogue shared with the producer waves as on the conv with the fused head -- measured SLOWER here, opt-in
             // with V2CE_PEPI_SC=1: the three 128-channel launches 0.495 -> 0.503 ms, enc0.conv1 0.670 -> 0.713)
             static const bool pepi_sc = [] { const char *e = getenv("V2CE_PEPI_SC"); return e && e[0] == '1'; }();
+            // (round 6: four lanes per element in the producers' gather, VERDICT r5 #3 (a) -- measured no faster, opt-in with V2CE_G4=1:
+            // the three 128-channel launches 0.482 -> 0.481 ms, enc0.conv1 0.717 -> 0.745, dec3.conv2 + head 0.88 -> 0.89)
+            static const bool g4 = [] { const char *e = getenv("V2CE_G4"); return e && e[0] == '1'; }();
+            if (g4 && d.Cout >= 128) return launch_f16x2_ws<3, 2, 4, 1, 4, 3, 2, 0, 2>(P, d, st);
+            if (g4 && !small_co && na9) return launch_f16x2_ws<3, 2, 2, 1, 2, 9, 2, 0, 2>(P, d, st);
             if (pepi_sc && d.Cout >= 128 && d.Cout <= 512 && !P.res) return launch_f16x2_ws<3, 2, 4, 1, 4, 3, 2, 0, 1>(P, d, st);
             if (pepi_sc && !small_co && d.Cout < 128 && na9 && !P.res) return launch_f16x2_ws<3, 2, 2, 1, 2, 9, 2, 0, 1>(P, d, st);
             if (d.Cout >= 128) return launch_f16x2_ws<3, 2, 4, 1, 4, 3, 2, 0>(P, d, st);
