@@ -784,6 +784,58 @@ def test_conv3d_fused_shortcut_vs_f64(case):
 
 
 @pytest.mark.parametrize("case", [
+    # T, H, W, with a residual, head channels
+    (5, 37, 50, True, 20),        # ragged in T, H and W: partial tiles, masked lanes in both halves of the shared epilogue
+    (16, 20, 44, False, 20),      # no residual (the RES = 0 instantiation)
+    (3, 9, 70, True, 32),         # every head row present
+    (2, 260, 346, True, 20),      # the network's geometry: (8, 4, 16) boxes
+])
+def test_conv3d_fused_head_vs_f64(case):
+    """v2ce_conv3d_fwd_pred: a 32-channel 3x3x3 conv (BN, residual, ReLU) with the 1x1x1 head (bias, ReLU) on the same launch --
+    since round 6 with its epilogue shared between consumer and producer waves -- against both layers in f64."""
+    from v2ce_toolbox_amd import hip
+    from v2ce_toolbox_amd.v2ce_3d import V2ce3d
+    T, H, W, with_res, pc = case
+    B = 2
+    g = torch.Generator().manual_seed(T + H + W)
+    x = torch.randn(B, 32, T, H, W, generator=g)
+    w = torch.randn(32, 32, 3, 3, 3, generator=g) * (2.0 / (32 * 27)) ** 0.5
+    sc, sh = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.3
+    res = torch.randn(B, 32, T, H, W, generator=g) if with_res else None
+    wp = torch.randn(pc, 32, generator=g) * 0.2
+    bp = torch.randn(pc, generator=g) * 0.1
+    m = V2ce3d.__new__(V2ce3d)
+    torch.nn.Module.__init__(m)
+    m._maps, m.precision, m._slot = {}, "f16x2", 0
+    m._prep = {"absmax": torch.zeros((4, 2), device="cuda")}
+
+    def c16(t):                                   # channels-last-16 with the activations' row pitch (rows of >= 64 are padded to 32)
+        d = V2ce3d.to_c16(to_btchw(t).cuda())
+        Wp = V2ce3d._pitch(W)
+        if Wp != W:
+            p = torch.zeros((*d.shape[:4], Wp, 16), device="cuda")
+            p[:, :, :, :, :W] = d
+            p.lw, p.c16 = W, True
+            d = p
+        return d
+    xd = c16(x)
+    xd.absmax = x.abs().max().reshape(1).cuda()
+    rd = c16(res) if with_res else None
+    tab = torch.empty(hip.lib().v2ce_pack_pred_weights_f16x2_bytes() // 2, dtype=torch.float16, device="cuda")
+    wpd = wp.cuda().contiguous()
+    hip.check(hip.lib().v2ce_pack_pred_weights_f16x2(wpd.data_ptr(), pc, 32, tab.data_ptr(), hip.stream_ptr(wpd.device)), "pack")
+    bias = torch.zeros(32, device="cuda")
+    bias[:pc] = bp.cuda()
+    got = V2ce3d._conv(m, xd, None, V2ce3d._pack(m, w.cuda().contiguous(), split=True), sc.cuda(), sh.cuda(), 32, 3, 1, hip.ACT_RELU,
+                       residual=rd, split=True, pred=(tab, bias, pc))
+    torch.cuda.synchronize()
+    assert got.shape == (B, T, pc, H, W)
+    y = torch.from_numpy(ref_conv(x, w, sc, sh, 3, 1, 1, residual=res))                      # [B, 32, T, H, W] f64
+    want = torch.relu(torch.einsum("oc,bcthw->bothw", wp.double(), y) + bp.double().view(1, -1, 1, 1, 1))
+    assert_close(got.permute(0, 2, 1, 3, 4).cpu().numpy(), want.numpy(), "fused head")
+
+
+@pytest.mark.parametrize("case", [
     # Cmid (= Cout), tail C0, tail C1, tail stride, H, W, mapped low-res source, per-element slots
     (64, 32, 0, 2, 19, 23, False, False),       # encoder-like: strided shortcut from the block input
     (64, 128, 64, 1, 20, 26, True, True),       # decoder-like: shortcut reads upsample(x0) ++ skip (dec2's shape family)
