@@ -1138,11 +1138,13 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
                 constexpr int nt = tap + 1;
                 constexpr int dt = nt / 9, dh = (nt / 3) % 3, dw = nt % 3;
                 constexpr int pt = tap + NA - 1;              // the tap whose A fragments are fetched now
+#if !(defined(V2CE_ABLATE_TAPS) && (V2CE_ABLATE_TAPS & 1))   // diagnostic build (tools/tap_ablate.sh): the ring is never refilled -- WRONG results
                 if constexpr (pt < K3) {
                     V2CE_LOAD_A(pt % NA, wc + pt * tap_stride)
                 } else {
                     V2CE_LOAD_A(pt % NA, wn + (pt - K3) * tap_stride)
                 }
+#endif
                 const int toff = (dt * P.HH + dh) * P.HWd + dw;          // next tap's offset in the halo box
 #pragma unroll
                 for (int f = 0; f < PO_FR; ++f) {
@@ -1160,10 +1162,12 @@ __global__ __launch_bounds__(512, 1) void conv3d_f16x2_ws_kernel(ConvParams P) {
                             accd[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ald[q], bh[f], accd[q][f], 0, 0, 0);
                         }
                     }
+#if !(defined(V2CE_ABLATE_TAPS) && (V2CE_ABLATE_TAPS & 2))   // diagnostic build: tap 0's B fragments serve every tap -- WRONG results
                     if constexpr (nt < K3) {                 // refill in place for the next tap
                         bh[f] = qb[bhb[f] + toff];
                         bl[f] = qb[bhb[f] + toff + 2 * chs];
                     }
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
             });

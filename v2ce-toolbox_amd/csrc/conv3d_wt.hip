@@ -267,6 +267,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int k4 = 0; k4 < CK / 4; ++k4) {
+#if defined(V2CE_ABLATE_TAPS) && (V2CE_ABLATE_TAPS & 4)   // diagnostic build: a quarter of the gather's load instructions -- WRONG results
+                        if (k4) { R[i][4 * k4] = R[i][0]; R[i][4 * k4 + 1] = R[i][1]; R[i][4 * k4 + 2] = R[i][2]; R[i][4 * k4 + 3] = R[i][3]; continue; }
+#endif
                         const f32x4g v = __builtin_bit_cast(f32x4g, __builtin_amdgcn_raw_buffer_load_b128(rs_in, goff[i], cidx * cg_bytes + 16 * k4, 0));
                         R[i][4 * k4] = v[0]; R[i][4 * k4 + 1] = v[1]; R[i][4 * k4 + 2] = v[2]; R[i][4 * k4 + 3] = v[3];
                     }
@@ -614,11 +617,13 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
                     constexpr int nt = tap + 1;
                     constexpr int dh = nt / 3, dw = nt % 3;
                     constexpr int pt = tap + NA - 1;                      // the tap whose A fragments are fetched now
+#if !(defined(V2CE_ABLATE_TAPS) && (V2CE_ABLATE_TAPS & 1))   // diagnostic build (tools/tap_ablate.sh): the ring is never refilled -- WRONG results
                     if constexpr (pt < 9) {
                         V2CE_LOAD_A(pt % NA, wc + pt * tap_stride)
                     } else {
                         V2CE_LOAD_A(pt % NA, wn + (pt - 9) * tap_stride)
                     }
+#endif
                     const int toff = dh * P.HWd + dw;                     // next tap's offset in the slot's plane
 #pragma unroll
                     for (int f = 0; f < PO_FR; ++f) {
@@ -628,10 +633,12 @@ __global__ __launch_bounds__(512, 1) void conv3d_wt_kernel(ConvParams P) {
                             acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tap % NA][q], bl[f], acc[q][f], 0, 0, 0);
                             acc[q][f] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tap % NA][q], bh[f], acc[q][f], 0, 0, 0);
                         }
+#if !(defined(V2CE_ABLATE_TAPS) && (V2CE_ABLATE_TAPS & 2))   // diagnostic build: tap 0's B fragments serve every tap -- WRONG results
                         if constexpr (nt < 9) {                           // refill in place for the next tap
                             bh[f] = qb[bhb[f] + toff];
                             bl[f] = qb[bhb[f] + toff + 2 * chs];
                         }
+#endif
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 });
