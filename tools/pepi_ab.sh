@@ -1,8 +1,9 @@
 #!/bin/bash
-# A/B of a switch of the 32-channel conv + fused head (round 6): parity tests, then the e2e bench both ways on one box.
-#   VAR=V2CE_TRU (B fragments reused across the time taps) or V2CE_PEPI (epilogue on the producer waves); MODES="1 0 1 0"
+# A/B of a conv switch (round 6): parity tests, then the e2e bench both ways on one box.
+#   VAR=V2CE_PEPI (default: the last decoder conv's epilogue shared with the producer waves), V2CE_PEPI_SC, V2CE_G4, V2CE_NA9,
+#   V2CE_LDATI_STREAM ...; MODES="1 0 1 0"
 TAG=${1:-pepi}
-VAR=${VAR:-V2CE_TRU}
+VAR=${VAR:-V2CE_PEPI}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
