@@ -370,7 +370,7 @@ def main():
         add = offsets[fp:fp + vox.shape[0]] if model is not None else None
         if side_stream is not None:                             # LDATI beside the next step's convs, as pipeline.run_clip runs it
             ready = torch.cuda.Event()
-            ready.record()
+            ready.record(torch.cuda.current_stream(device))
             with torch.cuda.stream(side_stream):
                 side_stream.wait_event(ready)
                 h = ldati_begin(vox, fps=fps, seed=0x5EED, frame_base=fp, frame_ts_add=add, profile=ldati_prof if profile else None)

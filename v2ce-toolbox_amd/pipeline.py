@@ -449,7 +449,7 @@ def run_clip(frames: np.ndarray, model, *, infer_type="center", seq_len=16, widt
         if ldati_stream is None:
             return begin0(vox, first_pair)
         ready = torch.cuda.Event()
-        ready.record()                                       # the model's output (and anything else the main stream did to vox)
+        ready.record(torch.cuda.current_stream(device))     # the model's output (and anything else the main stream did to vox)
         with torch.cuda.stream(ldati_stream):
             ldati_stream.wait_event(ready)
             handle = begin0(vox, first_pair)
