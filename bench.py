@@ -10,7 +10,9 @@ BASELINE.json configs[1] "batch=4 sliding frame-pairs" case) 16-pair sequences o
 346x260 frames -> V2ce3d -> LDATI (count, emit with the per-frame offset fused, packed 13-byte
 records) on the device.  The loop is software-pipelined exactly like the product driver
 (pipeline.run_clip): LDATI's emit phase of step k-1 is enqueued behind the model of step k, so the
-host's read of the segment table never drains the GPU; all K steps complete inside the timed region.
+host's read of the segment table never drains the GPU -- and (round 6) LDATI has its own high-priority
+stream, so its workgroups run beside the next step's convolutions, on the CUs a persistent conv launch
+has no tile left for (V2CE_LDATI_STREAM=0: on the main stream); all K steps complete inside the timed region.
 With N > 1 every rank processes its own contiguous block of sequences (weak scaling, no data-path
 collective) and the packed events are gathered to rank 0 over RCCL inside the timed region.
 `--workload pano` is BASELINE config 4 (1384x260, batch 8): one 346-wide tile per GPU of a 4-rank
